@@ -1,0 +1,104 @@
+"""ctypes binding of libunetk.so (include/unetk.h).
+
+The C ABI takes raw device pointers + sizes + a hipStream_t; PyTorch is used only to own device
+memory and streams.  There is NO fallback: if the library is missing, loading raises, and every
+op in boxsegliver_amd.ops goes through this module.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t,
+                    c_void_p)
+
+_LIB = None
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libunetk.so")
+
+UNETK_MAX_CLASSES = 8
+W_NONE, W_NUMERICAL, W_PROPORTION, W_PIXELMAP = 0, 1, 2, 3
+
+
+class ConvDesc(Structure):
+    _fields_ = [("N", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
+                ("x_stride", c_int32), ("y_stride", c_int32)]
+
+
+class DeconvDesc(Structure):
+    _fields_ = [("N", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
+                ("out_stride", c_int32), ("out_coff", c_int32)]
+
+
+class HeadDesc(Structure):
+    _fields_ = [("N", c_int32), ("HW", c_int32), ("C", c_int32), ("ncls", c_int32),
+                ("weight_mode", c_int32), ("numeric_w", c_float * UNETK_MAX_CLASSES),
+                ("proportion_decay", c_float)]
+
+
+P = c_void_p
+_SIGNATURES = {
+    "unetk_abi_version": (c_int, []),
+    "unetk_error_string": (c_char_p, [c_int]),
+    "unetk_conv3x3_pack": (c_int, [P, c_int, c_int, P, P, P]),
+    "unetk_conv3x3_stat_rows": (c_int, [POINTER(ConvDesc)]),
+    "unetk_conv3x3_fwd": (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
+    "unetk_conv3x3_dgrad": (c_int, [POINTER(ConvDesc), P, P, P, P]),
+    "unetk_conv3x3_wgrad_ws_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "unetk_conv3x3_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, c_size_t, P]),
+    "unetk_bn_finalize_ws_bytes": (c_size_t, [c_int, c_int]),
+    "unetk_bn_finalize": (c_int, [P, c_int, c_int, c_int64, P, P, c_float, c_float, c_int, P, P, P, P, P, P,
+                                  P, c_size_t, P]),
+    "unetk_affine_relu": (c_int, [P, P, P, P, c_int64, c_int, c_int, P]),
+    "unetk_bn_bwd_ws_bytes": (c_size_t, [c_int64, c_int]),
+    "unetk_bn_relu_bwd": (c_int, [P, P, c_int, P, P, P, P, P, P, P, c_int64, c_int, P, c_size_t, P]),
+    "unetk_maxpool2_fwd": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, P]),
+    "unetk_maxpool2_bwd": (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "unetk_deconv2x2_pack": (c_int, [P, c_int, c_int, P, P, P]),
+    "unetk_deconv2x2_fwd": (c_int, [POINTER(DeconvDesc), P, P, P, P, P]),
+    "unetk_deconv2x2_bwd_ws_bytes": (c_size_t, [POINTER(DeconvDesc)]),
+    "unetk_deconv2x2_bwd": (c_int, [POINTER(DeconvDesc), P, P, P, P, P, P, P, P, c_size_t, P]),
+    "unetk_head_result_floats": (c_size_t, [POINTER(HeadDesc)]),
+    "unetk_head_ws_bytes": (c_size_t, [POINTER(HeadDesc)]),
+    "unetk_head_fwd": (c_int, [POINTER(HeadDesc), P, P, P, P, P, P, P, P, P, c_size_t, P]),
+    "unetk_head_bwd": (c_int, [POINTER(HeadDesc), P, P, P, P, P, P, c_float, c_float, P, P, P, P, P, c_size_t, P]),
+    "unetk_head_predict": (c_int, [P, c_int64, c_int, P, P, P]),
+    "unetk_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, P]),
+    "unetk_momentum_step": (c_int, [P, P, P, c_int64, c_float, c_float, c_int, c_float, c_float, P]),
+    "unetk_sumsq": (c_int, [P, c_int64, P, P, c_size_t, P]),
+}
+
+EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
+
+
+class UnetkError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if libunetk.so is absent."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise UnetkError(
+                "libunetk.so not found at {} -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU / PyTorch fallback for the hot path)".format(LIB_PATH))
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = handle
+    return _LIB
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().unetk_error_string(int(code))
+        raise UnetkError("{} failed: {} (code {})".format(what, msg.decode() if msg else "?", code))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,330 @@
+"""Train / eval entry points -- mirror of the reference's core/estimator.py `CustomEstimator`.
+
+Kept: constructor `(model_fn, model_dir, config, params, warm_start_from)` (:187), `train(input_fn,
+steps, hooks, max_steps, saving_listeners)` (:234-261), `evaluate_online(session, predict_keys, steps,
+yield_single_examples)` (:334-357), `predict(input_fn, predict_keys, hooks, checkpoint_path,
+latest_filename, yield_single_examples)` (:281-332), properties `model_dir / params / config`;
+resume from `model_dir` (:249-253), NaN-loss abort (:676), checkpoint status file `checkpoint`
+(:694-719), per-step log line `loss, lr, step, <Class>/<Metric> (x it/s)` (core/hooks.py:536-543).
+
+Replaced: the TF graph/session machinery.  The hot loop (`mon_sess.run([train_op, loss])`, :756-757)
+is an eager loop that enqueues HIP kernels on the current stream; data parallelism is one process
+per GPU (torch.distributed / RCCL) instead of in-graph MirroredStrategy (:528-619).
+"""
+import json
+import logging
+import math
+import os
+import time
+from pathlib import Path
+
+import torch
+
+from ..NetworksV2.base import ModeKeys
+
+log = logging.getLogger("boxsegliver_amd")
+
+
+class RunConfig(object):
+    """The subset of tf.estimator.RunConfig the reference sets (entry/main.py:139-147)."""
+
+    def __init__(self, model_dir=None, save_checkpoints_steps=5000, keep_checkpoint_max=1, log_step_count_steps=500,
+                 train_distribute=None, tf_random_seed=None):
+        self.model_dir = model_dir
+        self.save_checkpoints_steps = save_checkpoints_steps
+        self.keep_checkpoint_max = keep_checkpoint_max
+        self.log_step_count_steps = log_step_count_steps
+        self.train_distribute = train_distribute
+        self.tf_random_seed = tf_random_seed
+
+
+class SessionRunHook(object):
+    """Minimal tf.train.SessionRunHook protocol for the hooks of core/hooks.py."""
+
+    def begin(self):
+        pass
+
+    def after_create_session(self, session, coord=None):
+        pass
+
+    def before_run(self, run_context):
+        pass
+
+    def after_run(self, run_context, run_values):
+        pass
+
+    def end(self, session):
+        pass
+
+
+class _RunContext(object):
+    def __init__(self, session):
+        self.session = session
+        self.stop_requested = False
+
+    def request_stop(self):
+        self.stop_requested = True
+
+
+class _Session(object):
+    """What hooks / evaluate_online receive in place of a tf.Session."""
+
+    def __init__(self, estimator):
+        self.estimator = estimator
+
+
+class NanLossDuringTrainingError(RuntimeError):
+    def __str__(self):
+        return "NaN loss during training."
+
+
+def _load_global_step_from_checkpoint_dir(model_dir, status_file="checkpoint"):
+    """core/estimator.py:52-59"""
+    try:
+        with open(os.path.join(model_dir, status_file)) as f:
+            return int(json.load(f)["global_step"])
+    except (OSError, ValueError, KeyError):
+        return 0
+
+
+class CustomEstimator(object):
+    def __init__(self, model_fn, model_dir=None, config=None, params=None, warm_start_from=None):
+        if model_fn is None:
+            raise ValueError('model_fn must be provided to Estimator.')
+        self._config = config or RunConfig(model_dir=model_dir)
+        if model_dir:
+            self._config.model_dir = model_dir
+        self._model_dir = self._config.model_dir
+        self._train_distribution = self._config.train_distribute
+        self._model_fn = model_fn
+        self._params = params or {}
+        self._warm_start_from = warm_start_from
+        self.predictions = None
+        self._eval_iter_fn = None
+        self.double_dataloader_modes = self._params.get("double_dataloader_modes", None)
+        if self.double_dataloader_modes and len(self.double_dataloader_modes) != 2:
+            raise ValueError("double_dataloader_modes need a list of 2 elements for specifying input_fn modes")
+
+    @property
+    def model_dir(self):
+        return self._model_dir
+
+    @property
+    def config(self):
+        return self._config
+
+    @property
+    def params(self):
+        return self._params
+
+    # ------------------------------------------------------------------ checkpoints
+    def _model(self):
+        inst = self._params.get("model_instances")
+        return inst[0] if inst else None
+
+    def checkpoint_path(self, checkpoint_path=None, latest_filename=None):
+        if checkpoint_path:
+            return checkpoint_path
+        status = os.path.join(self._model_dir, latest_filename or "checkpoint")
+        if os.path.exists(status):
+            with open(status) as f:
+                return os.path.join(self._model_dir, json.load(f)["model_checkpoint_path"])
+        return None
+
+    def save_checkpoint(self, status_file="checkpoint", tag="model.ckpt"):
+        model, solver = self._model(), self._params.get("solver")
+        if model is None or model.params is None or not self._model_dir:
+            return None
+        rank = self._train_distribution.rank if self._train_distribution else 0
+        if rank != 0:
+            return None
+        os.makedirs(self._model_dir, exist_ok=True)
+        step = solver.global_step if solver else 0
+        fname = "{}-{}.pt".format(tag, step)
+        torch.save({"variables": model.params.state_dict(), "solver": solver.state_dict() if solver else None},
+                   os.path.join(self._model_dir, fname))
+        old = None
+        status = os.path.join(self._model_dir, status_file)
+        if os.path.exists(status):
+            with open(status) as f:
+                old = json.load(f).get("model_checkpoint_path")
+        with open(status, "w") as f:
+            json.dump({"model_checkpoint_path": fname, "global_step": step}, f)
+        if old and old != fname and self._config.keep_checkpoint_max == 1:
+            try:
+                os.remove(os.path.join(self._model_dir, old))
+            except OSError:
+                pass
+        return fname
+
+    def _restore(self, path, model, solver=None):
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        model.params.load_state(ckpt["variables"])
+        if solver is not None and ckpt.get("solver"):
+            solver.load_state_dict(ckpt["solver"], model.params)
+
+    # ------------------------------------------------------------------ model_fn plumbing
+    def _call_model_fn(self, features, labels, mode, config=None):
+        return self._model_fn(features, labels, mode, self._params, config or self._config)
+
+    def _maybe_restore(self, model, solver):
+        if getattr(self, "_restored", False) or model.params is None:
+            return
+        self._restored = True
+        path = self.checkpoint_path()
+        if path and os.path.exists(path):
+            self._restore(path, model, solver)                     # auto-resume (:738-741)
+        elif self._warm_start_from:
+            self._restore(self._warm_start_from, model, None)      # warm start (:649-652)
+        strategy = self._train_distribution
+        if strategy is not None and strategy.num_replicas_in_sync > 1:
+            strategy.broadcast_(list(model.params.flat.values()))  # identical replicas
+
+    # ------------------------------------------------------------------ train
+    def train(self, input_fn, steps=None, hooks=None, max_steps=None, saving_listeners=None):
+        if (steps is not None) and (max_steps is not None):
+            raise ValueError('Can not provide both steps and max_steps.')
+        if steps is not None and steps <= 0:
+            raise ValueError('Must specify steps > 0, given: {}'.format(steps))
+        if max_steps is not None and max_steps <= 0:
+            raise ValueError('Must specify max_steps > 0, given: {}'.format(max_steps))
+        if max_steps is not None:
+            start_step = _load_global_step_from_checkpoint_dir(self._model_dir) if self._model_dir else 0
+            if max_steps <= start_step:
+                log.info('Skipping training since max_steps has already saved.')
+                return self
+        loss = self._train_model(input_fn, list(hooks or []), steps, max_steps)
+        log.info('Loss for final step: %s.', loss)
+        return self
+
+    def _train_model(self, input_fn, hooks, steps, max_steps):
+        args = self._params["args"]
+        solver = self._params["solver"]
+        solver.strategy = self._train_distribution
+        train_iter = iter(input_fn(ModeKeys.TRAIN, self._params))
+        if getattr(args, "eval_per_epoch", False):
+            self._eval_iter_fn = lambda: iter(input_fn("eval_online", self._params))
+        session = _Session(self)
+        for h in hooks:
+            h.begin()
+        for h in hooks:
+            h.after_create_session(session)
+        ctx = _RunContext(session)
+        log_step = max(int(getattr(args, "log_step", 500) or 500), 1)
+        save_steps = self._config.save_checkpoints_steps
+        done, last_loss = 0, None
+        t_last, it_last = time.time(), 0
+        first = True
+        while not ctx.stop_requested:
+            try:
+                features, labels = next(train_iter)
+            except StopIteration:
+                break
+            if first:
+                # run one forward to create variables, then restore / broadcast before the first update
+                first = False
+                model_peek = self._params.get("model_instances")
+                if not model_peek:
+                    self._params["model_instances"] = [self._params["model"](args)]
+                model = self._params["model_instances"][0]
+                if model.params is None:
+                    model({"images": features["images"], "labels": labels}, ModeKeys.EVAL,
+                          **{k: v for k, v in self._params.get("model_kwargs", {}).items()
+                             if k not in ("build_metrics", "build_summaries")})
+                self._maybe_restore(model, solver)
+                if max_steps is not None and solver.global_step >= max_steps:
+                    break
+            for h in hooks:
+                h.before_run(ctx)
+            spec = self._call_model_fn(features, labels, ModeKeys.TRAIN)
+            self.predictions = spec.predictions
+            done += 1
+            step = solver.global_step
+            if step % log_step == 0 or done == 1:
+                loss_val = float(spec.loss)           # host sync only at log steps
+                if math.isnan(loss_val):
+                    raise NanLossDuringTrainingError()          # NanTensorHook, estimator.py:676
+                last_loss = loss_val
+                vals = {"loss": loss_val, "lr": spec.train_op, "step": step}
+                for k, v in spec.model.metrics_dict.items():
+                    vals[k] = float(v)
+                now = time.time()
+                msg = ", ".join(("%s = %.4g" if k == "step" else "%s = %.3g") % (k, vals[k]) for k in sorted(vals))
+                if done > 1:
+                    msg += " ({:.3g} it/s)".format((done - it_last) / max(now - t_last, 1e-9))
+                t_last, it_last = now, done
+                log.info(msg)
+            for h in hooks:
+                h.after_run(ctx, spec)
+            if save_steps and step % save_steps == 0:
+                self.save_checkpoint()
+            if steps is not None and done >= steps:
+                break
+            if max_steps is not None and step >= max_steps:
+                break
+        for h in hooks:
+            h.end(session)
+        if last_loss is None and done:
+            last_loss = float(spec.loss)
+        self.save_checkpoint()
+        return last_loss
+
+    # ------------------------------------------------------------------ eval
+    def evaluate_online(self, session=None, predict_keys=None, steps=None, yield_single_examples=False):
+        """Evaluate from inside training with the live variables and is_training=False (moving BN
+        statistics), as the reference does by re-running the train graph with the eval iterator handle."""
+        if self._eval_iter_fn is None:
+            raise ValueError("evaluate_online needs --eval_per_epoch (an `eval_online` input_fn mode)")
+        counter = 0
+        for features, labels in self._eval_iter_fn():
+            if steps is not None and counter >= steps:
+                break
+            spec = self._call_model_fn(features, labels, ModeKeys.EVAL)
+            preds = spec.predictions if predict_keys is None else {k: spec.predictions[k] for k in predict_keys}
+            counter += 1
+            if not yield_single_examples:
+                yield preds
+            else:
+                n = features["images"].shape[0]
+                for i in range(n):
+                    yield {k: (v[i] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == n else v)
+                           for k, v in preds.items()}
+
+    def predict(self, input_fn, predict_keys=None, hooks=None, checkpoint_path=None, latest_filename=None,
+                yield_single_examples=True):
+        path = self.checkpoint_path(checkpoint_path, latest_filename)
+        restored = False
+        for features, labels in input_fn(ModeKeys.EVAL, self._params):
+            if not restored:
+                restored = True
+                if not self._params.get("model_instances"):
+                    self._params["model_instances"] = [self._params["model"](self._params["args"])]
+                model = self._params["model_instances"][0]
+                if model.params is None:
+                    self._call_model_fn(features, labels, ModeKeys.EVAL)
+                if path and os.path.exists(path):
+                    self._restore(path, model, None)
+            spec = self._call_model_fn(features, labels, ModeKeys.EVAL)
+            preds = spec.predictions
+            if isinstance(predict_keys, list):
+                keys = predict_keys + list(spec.model.metrics_dict.keys())
+                preds = {k: preds[k] for k in keys if k in preds}
+            elif predict_keys is not None:
+                raise TypeError("predict_keys must be None(for 3d eval) or a list(for 2d eval, "
+                                "for example [\"Names\", \"Indices\"])")
+            if not yield_single_examples:
+                yield preds
+            else:
+                n = features["images"].shape[0]
+                for i in range(n):
+                    yield {k: (v[i] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == n else v)
+                           for k, v in preds.items()}
+
+    def evaluate(self, evaluator, input_fn, hooks=None, checkpoint_path=None, latest_filename=None, cases=None):
+        """core/estimator.py:263-279: delegate to the evaluator, dump eval_results_{2d,3d}.txt."""
+        checkpoint_path = self.checkpoint_path(checkpoint_path, latest_filename)
+        results = evaluator.run(input_fn, hooks=hooks, checkpoint_path=checkpoint_path, cases=cases)
+        suffix = "_3d" if getattr(self._params["args"], "eval_3d", False) else "_2d"
+        with (Path(self.model_dir) / "eval_results{}.txt".format(suffix)).open("w") as f:
+            json.dump(results, f)
+        return results

@@ -1,0 +1,20 @@
+#!/usr/bin/env bash
+# Build libunetk.so (HIP kernels + C ABI) for gfx950.  Cross-compiles without a GPU.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+ROOT="$(cd "$HERE/../.." && pwd)"
+OUT="$ROOT/boxsegliver_amd/lib"
+mkdir -p "$OUT" "$ROOT/build"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function"
+objs=()
+for src in conv_igemm conv_wgrad deconv norm head optim; do
+  o="$ROOT/build/$src.o"
+  if [[ ! -f "$o" || "$HERE/$src.hip" -nt "$o" || "$HERE/common.h" -nt "$o" || "$ROOT/include/unetk.h" -nt "$o" ]]; then
+    "$HIPCC" $FLAGS -c "$HERE/$src.hip" -o "$o" &
+  fi
+  objs+=("$o")
+done
+wait
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libunetk.so" "${objs[@]}"
+echo "built $OUT/libunetk.so"

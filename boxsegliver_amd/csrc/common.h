@@ -1,0 +1,67 @@
+// Shared device/host helpers for libunetk (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "unetk.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define UNETK_LAUNCH_CHECK()                      \
+  do {                                            \
+    hipError_t e_ = hipGetLastError();            \
+    if (e_ != hipSuccess) return (int)e_;         \
+  } while (0)
+
+#define UNETK_REQUIRE(cond) \
+  do {                      \
+    if (!(cond)) return UNETK_E_BADARG; \
+  } while (0)
+
+static inline bool unetk_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// Blocks are dealt round-robin over the 8 XCDs (each with a private L2): ids b and b+8 share
+// one.  Remap so that each XCD walks a CONTIGUOUS range of logical tiles (neighbouring tiles
+// share input halos / weight panels -> L2 hits).  Bijective for any grid size.  Speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+// C/D fragment row of v_mfma_f32_32x32x2_f32: reg r (0..15), lane half h -> row index.
+__device__ __forceinline__ int mfma32_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void stg4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---- internal cross-file helpers (not part of the C ABI)
+// dst[i] = sum_s slab[s*n + i] in fixed order (n % 4 == 0).
+int unetk_launch_slab_reduce(const float* slab, int S, int64_t n, float* dst, hipStream_t st);
+// dst[k][c] = sum_rows src[k][row][c] (fp64 accumulate).  tmp: K*64*C floats when rows > 256.
+int unetk_rows_reduce(const float* src, int K, int rows, int C, float* dst, float* tmp, hipStream_t st);
+size_t unetk_rows_reduce_tmp_floats(int K, int rows, int C);
+
+// Thread mapping for [npix, C] column-wise kernels: thread = (channel quad, row lane).
+struct ColMap {
+  int cq_n, rows_per_iter;
+};
+static inline ColMap unetk_colmap(int C) {
+  ColMap m;
+  m.cq_n = C / 4;
+  m.rows_per_iter = 256 / m.cq_n;
+  return m;
+}
+constexpr int UNETK_COL_BLOCKS = 1024;

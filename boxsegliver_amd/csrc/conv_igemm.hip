@@ -1,0 +1,408 @@
+// conv3x3 (stride 1, SAME) forward / input-gradient as an implicit GEMM on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32), NHWC, for gfx950.
+//
+// Replaces the TF op behind slim.conv2d(x, C, 3) at NetworksV2/UNet.py:79,85,94 (forward) and its
+// Conv2DBackpropInput (dgrad = the same kernel on flipped/transposed filters).
+//
+// GEMM view: M = output pixels (a TH x 16 spatial tile of one image per block), N = Cout,
+// K = 9 taps x Cin.  Per 16-channel chunk the (TH+2) x 18 input halo is staged ONCE in LDS and all
+// nine taps read their shifted A fragments from it (9x fewer global reads than im2col); the
+// per-(chunk, tap) [16 x BN] filter panel is staged K4-interleaved so both A and B fragments are
+// single ds_read_b128.  Global->LDS staging is register-prefetched one step ahead (issue before the
+// MFMA block, write after it), LDS double-buffered, one barrier per step.
+//
+// Algorithmic bytes per block-step are tiny next to the 64-cycle fp32 MFMA, so the kernel is
+// MFMA-issue bound by construction; the roofline that bounds it is the fp32 matrix peak.
+#include "common.h"
+
+namespace {
+
+constexpr int CK = 16;   // input channels per K-chunk
+constexpr int PS = 20;   // LDS pixel stride (floats): 16 + 4 pad -> conflict-free ds_read_b128
+constexpr int TW = 16;   // spatial tile width
+constexpr int HWD = TW + 2;
+
+struct ConvParams {
+  const float* x;
+  const float* wp;
+  float* y;
+  float* stat;
+  int N, H, W, Cin, Cout, xs, ys;
+  int tiles_h, tiles_w, n_ntiles, stat_rows;
+};
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int TH = BM / TW, HH = TH + 2;
+  constexpr int HALO_PIX = HH * HWD;
+  constexpr int HALO_F = HALO_PIX * PS;
+  constexpr int WB_F = CK * BN;
+  constexpr int HR = (HALO_PIX * 4 + NT - 1) / NT;   // float4 halo loads per thread
+  constexpr int WR = (CK / 4 * BN) / NT;             // float4 weight loads per thread
+  static_assert((CK / 4 * BN) % NT == 0, "weight panel must split evenly");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* halo = smem;               // [2][HALO_F]
+  float* wbuf = smem + 2 * HALO_F;  // [2][WB_F]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = bid % p.n_ntiles;
+  const int mtile = bid / p.n_ntiles;
+  const int tw_i = mtile % p.tiles_w;
+  const int th_i = (mtile / p.tiles_w) % p.tiles_h;
+  const int n_img = mtile / (p.tiles_w * p.tiles_h);
+  const int h0 = th_i * TH, w0 = tw_i * TW, n0 = ntile * BN;
+
+  // ---- per-thread staging geometry (fixed across the K loop)
+  int64_t hoff[HR];
+  bool hok[HR];
+  int hlds[HR];
+#pragma unroll
+  for (int r = 0; r < HR; ++r) {
+    const int idx = tid + r * NT;
+    const int pix = idx >> 2, q = idx & 3;
+    const int hh = pix / HWD, ww = pix - hh * HWD;
+    const int gh = h0 - 1 + hh, gw = w0 - 1 + ww;
+    hok[r] = (idx < HALO_PIX * 4) && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+    hoff[r] = (((int64_t)n_img * p.H + gh) * p.W + gw) * p.xs + q * 4;
+    hlds[r] = (idx < HALO_PIX * 4) ? pix * PS + q * 4 : -1;
+  }
+  const int cin4 = p.Cin >> 2;
+  int64_t woff[WR];
+#pragma unroll
+  for (int r = 0; r < WR; ++r) {
+    const int idx = tid + r * NT;
+    const int q = idx / BN, n = idx - q * BN;
+    woff[r] = ((int64_t)q * p.Cout + n0 + n) * 4;
+  }
+
+  float4 hreg[HR], wreg[WR];
+  auto load_halo = [&](int c) {
+#pragma unroll
+    for (int r = 0; r < HR; ++r)
+      hreg[r] = hok[r] ? ldg4(p.x + hoff[r] + c * CK) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto store_halo = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < HR; ++r)
+      if (hlds[r] >= 0) *reinterpret_cast<float4*>(&halo[buf * HALO_F + hlds[r]]) = hreg[r];
+  };
+  auto load_w = [&](int c, int t) {
+    const float* base = p.wp + ((int64_t)t * cin4 + c * (CK / 4)) * p.Cout * 4;
+#pragma unroll
+    for (int r = 0; r < WR; ++r) wreg[r] = ldg4(base + woff[r]);
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < WR; ++r)
+      *reinterpret_cast<float4*>(&wbuf[buf * WB_F + (tid + r * NT) * 4]) = wreg[r];
+  };
+
+  // ---- fragment addresses
+  int abase[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int sub = wm * TM + tm;
+    abase[tm] = ((2 * sub + (l31 >> 4)) * HWD + (l31 & 15)) * PS + 4 * h;
+  }
+  const int bbase = (h * BN + wn * TN * 32 + l31) * 4;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+  const int nchunks = p.Cin / CK;
+
+  load_halo(0);
+  load_w(0, 0);
+  store_halo(0);
+  store_w(0);
+  __syncthreads();
+
+  int step = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const float* hb = halo + (c & 1) * HALO_F;
+    const bool more_chunks = (c + 1 < nchunks);
+#pragma unroll
+    for (int t = 0; t < 9; ++t, ++step) {
+      const bool has_next = (t < 8) || more_chunks;
+      if (has_next) load_w(t < 8 ? c : c + 1, t < 8 ? t + 1 : 0);
+      if (t == 5 && more_chunks) load_halo(c + 1);
+
+      const float* wb = wbuf + (step & 1) * WB_F;
+      const int toff = ((t / 3) * HWD + (t % 3)) * PS;
+#pragma unroll
+      for (int g = 0; g < CK / 8; ++g) {
+        float4 a[TM], b[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          a[tm] = *reinterpret_cast<const float4*>(&hb[abase[tm] + toff + 8 * g]);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          b[tn] = *reinterpret_cast<const float4*>(&wb[bbase + (2 * g * BN + tn * 32) * 4]);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].z, b[tn].z, acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].w, b[tn].w, acc[tm][tn], 0, 0, 0);
+          }
+      }
+
+      if (has_next) store_w((step + 1) & 1);
+      if (t == 5 && more_chunks) store_halo((c + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: store raw conv output, accumulate per-channel statistics
+  float ssum[TN], ssq[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) ssum[tn] = ssq[tn] = 0.f;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int sub = wm * TM + tm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = mfma32_row(r, h);
+      const int gh = h0 + 2 * sub + (i >> 4), gw = w0 + (i & 15);
+      if (gh < p.H && gw < p.W) {
+        float* yp = p.y + (((int64_t)n_img * p.H + gh) * p.W + gw) * p.ys + n0 + wn * TN * 32 + l31;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const float v = acc[tm][tn][r];
+          yp[tn * 32] = v;
+          ssum[tn] += v;
+          ssq[tn] += v * v;
+        }
+      }
+    }
+  }
+  if (p.stat != nullptr) {
+    float* red = smem;  // [2][WM][BN]; all LDS reads of the main loop are behind its last barrier
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      ssum[tn] += __shfl_xor(ssum[tn], 32);
+      ssq[tn] += __shfl_xor(ssq[tn], 32);
+      if (h == 0) {
+        red[(0 * WM + wm) * BN + (wn * TN + tn) * 32 + l31] = ssum[tn];
+        red[(1 * WM + wm) * BN + (wn * TN + tn) * 32 + l31] = ssq[tn];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int k = tid / BN, n = tid - k * BN;
+      float s = 0.f;
+#pragma unroll
+      for (int m = 0; m < WM; ++m) s += red[(k * WM + m) * BN + n];
+      p.stat[((int64_t)k * p.stat_rows + mtile) * p.Cout + n0 + n] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Direct kernel for layers the MFMA path does not cover (Encode1/conv1: Cin = 3, K = 27, HBM-bound:
+// it writes 256 B per pixel against 12 B read).  One block per 8x16 pixel tile; thread = (pixel lane,
+// 4 output channels).  Raw HWIO filters through L1/L2.
+__global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvParams p) {
+  const int cq_n = p.Cout >> 2;
+  const int PL = 256 / cq_n;
+  const int tid = threadIdx.x;
+  const int cq = tid % cq_n, pl = tid / cq_n;
+  const int mtile = blockIdx.x;
+  const int tw_i = mtile % p.tiles_w;
+  const int th_i = (mtile / p.tiles_w) % p.tiles_h;
+  const int n_img = mtile / (p.tiles_w * p.tiles_h);
+  const int h0 = th_i * 8, w0 = tw_i * TW;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), sq = s;
+  if (pl < PL) {
+    for (int pix = pl; pix < 128; pix += PL) {
+      const int gh = h0 + (pix >> 4), gw = w0 + (pix & 15);
+      if (gh >= p.H || gw >= p.W) continue;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ih = gh + kh - 1;
+        if (ih < 0 || ih >= p.H) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+          const int iw = gw + kw - 1;
+          if (iw < 0 || iw >= p.W) continue;
+          const float* xp = p.x + (((int64_t)n_img * p.H + ih) * p.W + iw) * p.xs;
+          const float* wq = p.wp + ((int64_t)(kh * 3 + kw) * p.Cin) * p.Cout + cq * 4;
+          for (int ci = 0; ci < p.Cin; ++ci) {
+            const float xv = xp[ci];
+            const float4 wv = ldg4(wq + (int64_t)ci * p.Cout);
+            a.x = fmaf(xv, wv.x, a.x);
+            a.y = fmaf(xv, wv.y, a.y);
+            a.z = fmaf(xv, wv.z, a.z);
+            a.w = fmaf(xv, wv.w, a.w);
+          }
+        }
+      }
+      stg4(p.y + (((int64_t)n_img * p.H + gh) * p.W + gw) * p.ys + cq * 4, a);
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      sq.x += a.x * a.x; sq.y += a.y * a.y; sq.z += a.z * a.z; sq.w += a.w * a.w;
+    }
+  }
+  if (p.stat != nullptr) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][PL][Cout]
+    if (pl < PL) {
+      stg4(&smem[(0 * PL + pl) * p.Cout + cq * 4], s);
+      stg4(&smem[(1 * PL + pl) * p.Cout + cq * 4], sq);
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * p.Cout; i += 256) {
+      const int k = i / p.Cout, c = i - k * p.Cout;
+      float v = 0.f;
+      for (int j = 0; j < PL; ++j) v += smem[(k * PL + j) * p.Cout + c];
+      p.stat[((int64_t)k * p.stat_rows + mtile) * p.Cout + c] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Filter re-layout.  K4-interleaved panel: wp[t][q][n][j] = B_t[k = 4q + j][n].
+//   forward : B_t[k = ci][n = co] = w[t][ci][co]
+//   dgrad   : B_t[k = co][n = ci] = w[8 - t][ci][co]   (taps flipped, channels swapped)
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, int Cin, int Cout,
+                                    float* __restrict__ wp_fwd, float* __restrict__ wp_dgrad) {
+  const int64_t total = (int64_t)9 * Cin * Cout / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (wp_fwd != nullptr) {
+      // i -> (t, q, n): K = Cin, N = Cout
+      const int n = (int)(i % Cout);
+      const int64_t r = i / Cout;
+      const int q = (int)(r % (Cin / 4));
+      const int t = (int)(r / (Cin / 4));
+      const float* s = w + ((int64_t)t * Cin + 4 * q) * Cout + n;
+      stg4(wp_fwd + i * 4, make_float4(s[0], s[Cout], s[2 * (int64_t)Cout], s[3 * (int64_t)Cout]));
+    }
+    if (wp_dgrad != nullptr) {
+      // i -> (t, q, n): K = Cout, N = Cin
+      const int n = (int)(i % Cin);
+      const int64_t r = i / Cin;
+      const int q = (int)(r % (Cout / 4));
+      const int t = (int)(r / (Cout / 4));
+      const float* s = w + ((int64_t)(8 - t) * Cin + n) * Cout + 4 * q;
+      stg4(wp_dgrad + i * 4, make_float4(s[0], s[1], s[2], s[3]));
+    }
+  }
+}
+
+struct ConvCfg {
+  int id;  // 0: 128x128 tile, 1: 128x64 tile, -1: direct
+  int th;
+};
+
+inline ConvCfg pick_cfg(int Cin, int Cout) {
+  if (Cin % CK == 0 && Cout % 128 == 0) return {0, 8};
+  if (Cin % CK == 0 && Cout % 64 == 0) return {1, 8};
+  return {-1, 8};
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_igemm(const ConvParams& p, int n_mtiles, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int TH = BM / TW;
+  constexpr size_t lds = (2 * (TH + 2) * HWD * PS + 2 * CK * BN) * sizeof(float);
+  static_assert(lds >= 2 * WM * BN * sizeof(float), "stat scratch must fit");
+  auto kern = conv3x3_igemm_kernel<WM, WN, TM, TN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  const int grid = n_mtiles * p.n_ntiles;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, st, p);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+int conv_run(ConvParams p, hipStream_t st) {
+  const ConvCfg cfg = pick_cfg(p.Cin, p.Cout);
+  p.tiles_h = (p.H + cfg.th - 1) / cfg.th;
+  p.tiles_w = (p.W + TW - 1) / TW;
+  const int n_mtiles = p.N * p.tiles_h * p.tiles_w;
+  p.stat_rows = n_mtiles;
+  if (cfg.id == 0) {
+    p.n_ntiles = p.Cout / 128;
+    return launch_igemm<2, 2, 2, 2>(p, n_mtiles, st);
+  }
+  if (cfg.id == 1) {
+    p.n_ntiles = p.Cout / 64;
+    return launch_igemm<4, 1, 1, 2>(p, n_mtiles, st);
+  }
+  if (p.Cout % 4 != 0 || p.Cout > 1024) return UNETK_E_UNSUPPORTED;
+  const int PL = 256 / (p.Cout / 4);
+  const size_t lds = p.stat ? (size_t)2 * PL * p.Cout * sizeof(float) : 0;
+  if (lds > 64 * 1024) return UNETK_E_UNSUPPORTED;
+  hipLaunchKernelGGL(conv3x3_direct_kernel, dim3(n_mtiles), dim3(256), lds, st, p);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+bool conv_desc_ok(const unetk_conv_desc* d) {
+  return d && d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->x_stride >= d->Cin &&
+         d->y_stride >= d->Cout;
+}
+
+}  // namespace
+
+extern "C" int unetk_conv3x3_pack(const float* w, int Cin, int Cout, float* wp_fwd, float* wp_dgrad,
+                                  void* stream) {
+  UNETK_REQUIRE(w && Cin > 0 && Cout > 0);
+  if (Cin % 4 != 0 || Cout % 4 != 0) return UNETK_E_UNSUPPORTED;
+  UNETK_REQUIRE(unetk_aligned16(w) && unetk_aligned16(wp_fwd) && unetk_aligned16(wp_dgrad));
+  const int64_t total = (int64_t)9 * Cin * Cout / 4;
+  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, wp_fwd,
+                     wp_dgrad);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+extern "C" int unetk_conv3x3_stat_rows(const unetk_conv_desc* d) {
+  if (!conv_desc_ok(d)) return UNETK_E_BADARG;
+  const ConvCfg cfg = pick_cfg(d->Cin, d->Cout);
+  return d->N * ((d->H + cfg.th - 1) / cfg.th) * ((d->W + TW - 1) / TW);
+}
+
+extern "C" int unetk_conv3x3_fwd(const unetk_conv_desc* d, const float* x, const float* w, float* y,
+                                 float* stat_partials, void* stream) {
+  UNETK_REQUIRE(conv_desc_ok(d) && x && w && y);
+  UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(w) && unetk_aligned16(y));
+  UNETK_REQUIRE(d->y_stride % 4 == 0);
+  if (pick_cfg(d->Cin, d->Cout).id >= 0) UNETK_REQUIRE(d->x_stride % 4 == 0);
+  ConvParams p{};
+  p.x = x; p.wp = w; p.y = y; p.stat = stat_partials;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.xs = d->x_stride; p.ys = d->y_stride;
+  return conv_run(p, (hipStream_t)stream);
+}
+
+extern "C" int unetk_conv3x3_dgrad(const unetk_conv_desc* d, const float* dy, const float* w, float* dx,
+                                   void* stream) {
+  UNETK_REQUIRE(conv_desc_ok(d) && dy && w && dx);
+  UNETK_REQUIRE(unetk_aligned16(dy) && unetk_aligned16(w) && unetk_aligned16(dx));
+  // dgrad = conv3x3 with Cin <-> Cout on the packed, tap-flipped filters
+  if (pick_cfg(d->Cout, d->Cin).id < 0) return UNETK_E_UNSUPPORTED;
+  UNETK_REQUIRE(d->x_stride % 4 == 0 && d->y_stride % 4 == 0);
+  ConvParams p{};
+  p.x = dy; p.wp = w; p.y = dx; p.stat = nullptr;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cout; p.Cout = d->Cin; p.xs = d->y_stride; p.ys = d->x_stride;
+  return conv_run(p, (hipStream_t)stream);
+}

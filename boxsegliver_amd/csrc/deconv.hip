@@ -1,0 +1,432 @@
+// Transposed conv k=2 s=2 (+bias, ReLU) written straight into the skip-concat buffer, and its backward.
+//
+// Replaces slim.conv2d_transpose(x, C/2, 2, 2) + tf.concat((skip, up), -1) at NetworksV2/UNet.py:91-93.
+// With kernel == stride there is no overlap: out[n,2y+a,2x+b,co] = sum_ci x[n,y,x,ci] * w[a,b,co,ci], i.e.
+// ONE dense GEMM  [pixels x Cin] . [Cin x (4*Cout)]  whose epilogue scatters each (a,b) column group to
+// its output pixel -- genuinely dense, so it runs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//   forward : M = input pixels, N = (a,b,co), K = ci      epilogue: +bias, ReLU, scatter into concat buffer
+//   dgrad   : M = input pixels, N = ci,       K = (a,b,co) A rows gathered from the 4 output pixels
+//   wgrad   : per (a,b): [co x ci] = sum_pixels dpre[pix(a,b)][co] * x[pix][ci]   (split-K slabs, fixed order)
+#include "common.h"
+
+namespace {
+
+constexpr int CK = 16, PS = 20;
+
+struct PwParams {
+  const float* a;     // fwd: x [M][Cin]; dgrad: dpre [N,2H,2W,Cout]
+  const float* wp;    // K4-interleaved [K/4][Ncols][4]
+  const float* bias;  // fwd only
+  float* out;
+  int M, K, Ncols;
+  int H, W, Cout;     // input spatial dims, deconv output channels
+  int out_stride, out_coff;
+  int n_ntiles;
+};
+
+// MODE 0: forward (scatter epilogue), MODE 1: dgrad (gather prologue)
+template <int MODE, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM* WN * 64) void pw_gemm_kernel(PwParams p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int A_F = BM * PS, WB_F = CK * BN;
+  constexpr int AR = (BM * 4) / NT, WR = (CK / 4 * BN) / NT;
+  static_assert((BM * 4) % NT == 0 && (CK / 4 * BN) % NT == 0, "tile must split evenly");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* abuf = smem;              // [2][A_F]
+  float* wbuf = smem + 2 * A_F;    // [2][WB_F]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = bid % p.n_ntiles, mtile = bid / p.n_ntiles;
+  const int m0 = mtile * BM, n0 = ntile * BN;
+
+  int64_t aoff[AR];
+  bool aok[AR];
+#pragma unroll
+  for (int r = 0; r < AR; ++r) {
+    const int idx = tid + r * NT;
+    const int row = idx >> 2, q = idx & 3;
+    const int m = m0 + row;
+    aok[r] = m < p.M;
+    if (MODE == 0) {
+      aoff[r] = (int64_t)m * p.K + q * 4;
+    } else {
+      const int xx = m % p.W;
+      const int yy = (m / p.W) % p.H;
+      const int nn = m / (p.W * p.H);
+      aoff[r] = (((int64_t)nn * 2 * p.H + 2 * yy) * 2 * p.W + 2 * xx) * p.Cout + q * 4;
+    }
+  }
+  int64_t woff[WR];
+#pragma unroll
+  for (int r = 0; r < WR; ++r) {
+    const int idx = tid + r * NT;
+    const int q = idx / BN, n = idx - q * BN;
+    woff[r] = ((int64_t)q * p.Ncols + n0 + n) * 4;
+  }
+
+  float4 areg[AR], wreg[WR];
+  auto load_a = [&](int s) {
+    int64_t koff;
+    if (MODE == 0) {
+      koff = (int64_t)s * CK;
+    } else {
+      const int k0 = s * CK;
+      const int ab = k0 / p.Cout, co0 = k0 - ab * p.Cout;
+      koff = ((int64_t)(ab >> 1) * 2 * p.W + (ab & 1)) * p.Cout + co0;
+    }
+#pragma unroll
+    for (int r = 0; r < AR; ++r) areg[r] = aok[r] ? ldg4(p.a + aoff[r] + koff) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      const int idx = tid + r * NT;
+      *reinterpret_cast<float4*>(&abuf[buf * A_F + (idx >> 2) * PS + (idx & 3) * 4]) = areg[r];
+    }
+  };
+  auto load_w = [&](int s) {
+    const float* base = p.wp + (int64_t)s * (CK / 4) * p.Ncols * 4;
+#pragma unroll
+    for (int r = 0; r < WR; ++r) wreg[r] = ldg4(base + woff[r]);
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < WR; ++r) *reinterpret_cast<float4*>(&wbuf[buf * WB_F + (tid + r * NT) * 4]) = wreg[r];
+  };
+
+  int abase[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) abase[tm] = ((wm * TM + tm) * 32 + l31) * PS + 4 * h;
+  const int bbase = (h * BN + wn * TN * 32 + l31) * 4;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+  const int nsteps = p.K / CK;
+  load_a(0);
+  load_w(0);
+  store_a(0);
+  store_w(0);
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const bool has_next = s + 1 < nsteps;
+    if (has_next) {
+      load_a(s + 1);
+      load_w(s + 1);
+    }
+    const float* ab_ = abuf + (s & 1) * A_F;
+    const float* wb = wbuf + (s & 1) * WB_F;
+#pragma unroll
+    for (int g = 0; g < CK / 8; ++g) {
+      float4 a[TM], b[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const float4*>(&ab_[abase[tm] + 8 * g]);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const float4*>(&wb[bbase + (2 * g * BN + tn * 32) * 4]);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].z, b[tn].z, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].w, b[tn].w, acc[tm][tn], 0, 0, 0);
+        }
+    }
+    if (has_next) {
+      store_a((s + 1) & 1);
+      store_w((s + 1) & 1);
+    }
+    __syncthreads();
+  }
+
+  // epilogue
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + (wn * TN + tn) * 32 + l31;
+    int ab = 0, co = n;
+    float bv = 0.f;
+    if (MODE == 0) {
+      ab = n / p.Cout;
+      co = n - ab * p.Cout;
+      bv = p.bias ? p.bias[co] : 0.f;
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + tm) * 32 + mfma32_row(r, h);
+        if (m >= p.M) continue;
+        if (MODE == 0) {
+          const int xx = m % p.W;
+          const int yy = (m / p.W) % p.H;
+          const int nn = m / (p.W * p.H);
+          const int64_t opix = ((int64_t)nn * 2 * p.H + 2 * yy + (ab >> 1)) * 2 * p.W + 2 * xx + (ab & 1);
+          p.out[opix * p.out_stride + p.out_coff + co] = fmaxf(acc[tm][tn][r] + bv, 0.f);
+        } else {
+          p.out[(int64_t)m * p.Ncols + n] = acc[tm][tn][r];
+        }
+      }
+  }
+}
+
+// dpre[pix][co] = dcat[pix][coff+co] * (cat[pix][coff+co] > 0); partial[blk][co] = column sums (bias grad)
+__global__ __launch_bounds__(256) void relu_bwd_bias_kernel(const float* __restrict__ cat, const float* __restrict__ dcat,
+                                                            int stride, int coff, float* __restrict__ dpre,
+                                                            float* __restrict__ partial, int64_t npix, int C, int cq_n,
+                                                            int rpi) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [rpi][C]
+  const int cq = threadIdx.x % cq_n, rl = threadIdx.x / cq_n;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rl < rpi) {
+    for (int64_t pix = (int64_t)blockIdx.x * rpi + rl; pix < npix; pix += (int64_t)gridDim.x * rpi) {
+      const float4 v = ldg4(cat + pix * stride + coff + cq * 4);
+      const float4 d = ldg4(dcat + pix * stride + coff + cq * 4);
+      float4 o;
+      o.x = v.x > 0.f ? d.x : 0.f;
+      o.y = v.y > 0.f ? d.y : 0.f;
+      o.z = v.z > 0.f ? d.z : 0.f;
+      o.w = v.w > 0.f ? d.w : 0.f;
+      stg4(dpre + pix * C + cq * 4, o);
+      s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    stg4(&smem[rl * C + cq * 4], s);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t = 0.f;
+    for (int j = 0; j < rpi; ++j) t += smem[j * C + c];
+    partial[(int64_t)blockIdx.x * C + c] = t;
+  }
+}
+
+// wgrad: slab[split][ab][co][ci] = sum over the split's pixels of dpre[pix(m,ab)][co] * x[m][ci]
+struct DwParams {
+  const float* x;
+  const float* dpre;
+  float* slab;
+  int M, H, W, Cin, Cout;
+  int m_per_split, n_co_tiles, n_ci_tiles;
+};
+
+__global__ __launch_bounds__(256) void deconv_wgrad_kernel(DwParams p) {
+  constexpr int KT = 128, CT = 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* at = smem;             // [KT][CT]  dpre rows (co)
+  float* bt = smem + KT * CT;   // [KT][CT]  x rows (ci)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave >> 1, wci = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  int bid = blockIdx.x;
+  const int ci_t = bid % p.n_ci_tiles; bid /= p.n_ci_tiles;
+  const int co_t = bid % p.n_co_tiles; bid /= p.n_co_tiles;
+  const int ab = bid & 3;
+  const int split = bid >> 2;
+  const int co0 = co_t * CT, ci0 = ci_t * CT;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int mb = split * p.m_per_split, me = min(mb + p.m_per_split, p.M);
+  for (int mt = mb; mt < me; mt += KT) {
+    __syncthreads();
+    for (int idx = tid; idx < KT * (CT / 4); idx += 256) {
+      const int row = idx >> 4, q = idx & 15;
+      const int m = mt + row;
+      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+      if (m < me) {
+        const int xx = m % p.W;
+        const int yy = (m / p.W) % p.H;
+        const int nn = m / (p.W * p.H);
+        const int64_t opix = ((int64_t)nn * 2 * p.H + 2 * yy + (ab >> 1)) * 2 * p.W + 2 * xx + (ab & 1);
+        va = ldg4(p.dpre + opix * p.Cout + co0 + q * 4);
+        vb = ldg4(p.x + (int64_t)m * p.Cin + ci0 + q * 4);
+      }
+      *reinterpret_cast<float4*>(&at[row * CT + q * 4]) = va;
+      *reinterpret_cast<float4*>(&bt[row * CT + q * 4]) = vb;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int s = 0; s < KT / 2; ++s) {
+      const float a = at[(2 * s + h) * CT + wco * 32 + l31];
+      const float b = bt[(2 * s + h) * CT + wci * 32 + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+  float* out = p.slab + ((int64_t)split * 4 + ab) * p.Cout * p.Cin;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = co0 + wco * 32 + mfma32_row(r, h);
+    out[(int64_t)co * p.Cin + ci0 + wci * 32 + l31] = acc[r];
+  }
+}
+
+// wp_fwd[q][n=(ab,co)][j] = w[ab][co][4q+j]   (K = Cin)
+// wp_dgrad[q][n=ci][j]    = w_flat[(4q+j)][ci] with w_flat = [(ab,co)][ci]   (K = 4*Cout)
+__global__ void pack_deconv_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ wp_fwd,
+                                   float* __restrict__ wp_dgrad) {
+  const int64_t total = (int64_t)Cin * Cout;  // float4 count = 4*Cin*Cout/4
+  const int Nf = 4 * Cout;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    if (wp_fwd != nullptr) {
+      const int n = (int)(i % Nf);
+      const int q = (int)(i / Nf);
+      stg4(wp_fwd + i * 4, ldg4(w + (int64_t)n * Cin + 4 * q));
+    }
+    if (wp_dgrad != nullptr) {
+      const int n = (int)(i % Cin);
+      const int q = (int)(i / Cin);
+      const float* s = w + (int64_t)(4 * q) * Cin + n;
+      stg4(wp_dgrad + i * 4, make_float4(s[0], s[Cin], s[2 * (int64_t)Cin], s[3 * (int64_t)Cin]));
+    }
+  }
+}
+
+template <int MODE, int WM, int WN, int TM, int TN>
+int launch_pw(const PwParams& p, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr size_t lds = (size_t)(2 * BM * PS + 2 * CK * BN) * sizeof(float);
+  const int n_mtiles = (p.M + BM - 1) / BM;
+  hipLaunchKernelGGL((pw_gemm_kernel<MODE, WM, WN, TM, TN>), dim3(n_mtiles * p.n_ntiles), dim3(WM * WN * 64), lds, st, p);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+bool deconv_desc_ok(const unetk_deconv_desc* d) {
+  return d && d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->out_coff >= 0 &&
+         d->out_stride >= d->out_coff + d->Cout;
+}
+
+struct DwPlan {
+  int S, m_per_split, nblk_bias;
+};
+DwPlan dw_plan(const unetk_deconv_desc* d) {
+  DwPlan pl{};
+  const int M = d->N * d->H * d->W;
+  const int panels = 4 * (d->Cin / 64) * (d->Cout / 64);
+  int S = (1024 + panels - 1) / panels;
+  const int mtiles = (M + 127) / 128;
+  if (S > mtiles) S = mtiles;
+  if (S < 1) S = 1;
+  const int tiles_per = (mtiles + S - 1) / S;
+  pl.m_per_split = tiles_per * 128;
+  pl.S = (mtiles + tiles_per - 1) / tiles_per;
+  const ColMap m = unetk_colmap(d->Cout);
+  int64_t g = ((int64_t)4 * M + m.rows_per_iter - 1) / m.rows_per_iter;
+  if (g > UNETK_COL_BLOCKS) g = UNETK_COL_BLOCKS;
+  pl.nblk_bias = (int)g;
+  return pl;
+}
+
+}  // namespace
+
+extern "C" int unetk_deconv2x2_pack(const float* w, int Cin, int Cout, float* wp_fwd, float* wp_dgrad,
+                                    void* stream) {
+  UNETK_REQUIRE(w && Cin > 0 && Cout > 0);
+  if (Cin % 4 != 0 || Cout % 4 != 0) return UNETK_E_UNSUPPORTED;
+  UNETK_REQUIRE(unetk_aligned16(w) && unetk_aligned16(wp_fwd) && unetk_aligned16(wp_dgrad));
+  const int64_t total = (int64_t)Cin * Cout;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(pack_deconv_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, wp_fwd, wp_dgrad);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+extern "C" int unetk_deconv2x2_fwd(const unetk_deconv_desc* d, const float* x, const float* wp_fwd,
+                                   const float* bias, float* out, void* stream) {
+  UNETK_REQUIRE(deconv_desc_ok(d) && x && wp_fwd && out);
+  UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(wp_fwd));
+  if (d->Cin % CK != 0 || d->Cout % 16 != 0) return UNETK_E_UNSUPPORTED;
+  PwParams p{};
+  p.a = x; p.wp = wp_fwd; p.bias = bias; p.out = out;
+  p.M = d->N * d->H * d->W; p.K = d->Cin; p.Ncols = 4 * d->Cout;
+  p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.out_stride = d->out_stride; p.out_coff = d->out_coff;
+  if (p.Ncols % 128 == 0) {
+    p.n_ntiles = p.Ncols / 128;
+    return launch_pw<0, 2, 2, 2, 2>(p, (hipStream_t)stream);
+  }
+  p.n_ntiles = p.Ncols / 64;
+  return launch_pw<0, 4, 1, 1, 2>(p, (hipStream_t)stream);
+}
+
+extern "C" size_t unetk_deconv2x2_bwd_ws_bytes(const unetk_deconv_desc* d) {
+  if (!deconv_desc_ok(d) || d->Cin % 64 != 0 || d->Cout % 64 != 0) return 0;
+  const DwPlan pl = dw_plan(d);
+  const size_t M = (size_t)d->N * d->H * d->W;
+  size_t f = 4 * M * d->Cout;                               // dpre
+  f += (size_t)pl.nblk_bias * d->Cout;                      // bias partials
+  f += unetk_rows_reduce_tmp_floats(1, pl.nblk_bias, d->Cout);
+  f += (size_t)pl.S * 4 * d->Cin * d->Cout;                 // wgrad slabs
+  return f * sizeof(float);
+}
+
+extern "C" int unetk_deconv2x2_bwd(const unetk_deconv_desc* d, const float* x, const float* wp_dgrad,
+                                   const float* cat, const float* dcat, float* dx, float* dw, float* dbias,
+                                   void* ws, size_t ws_bytes, void* stream) {
+  UNETK_REQUIRE(deconv_desc_ok(d) && x && wp_dgrad && cat && dcat && dx && dw && dbias && ws);
+  if (d->Cin % 64 != 0 || d->Cout % 64 != 0 || d->out_stride % 4 != 0 || d->out_coff % 4 != 0)
+    return UNETK_E_UNSUPPORTED;
+  UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(wp_dgrad) && unetk_aligned16(cat) && unetk_aligned16(dcat) &&
+                unetk_aligned16(dx) && unetk_aligned16(dw) && unetk_aligned16(ws));
+  if (ws_bytes < unetk_deconv2x2_bwd_ws_bytes(d)) return UNETK_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const DwPlan pl = dw_plan(d);
+  const int M = d->N * d->H * d->W;
+  float* dpre = (float*)ws;
+  float* bpart = dpre + (size_t)4 * M * d->Cout;
+  float* btmp = bpart + (size_t)pl.nblk_bias * d->Cout;
+  float* slab = btmp + unetk_rows_reduce_tmp_floats(1, pl.nblk_bias, d->Cout);
+
+  // 1. ReLU backward + bias-grad partials
+  const ColMap cm = unetk_colmap(d->Cout);
+  hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3(pl.nblk_bias), dim3(256), (size_t)cm.rows_per_iter * d->Cout * sizeof(float),
+                     st, cat, dcat, d->out_stride, d->out_coff, dpre, bpart, (int64_t)4 * M, d->Cout, cm.cq_n,
+                     cm.rows_per_iter);
+  UNETK_LAUNCH_CHECK();
+  int rc = unetk_rows_reduce(bpart, 1, pl.nblk_bias, d->Cout, dbias, btmp, st);
+  if (rc != UNETK_OK) return rc;
+
+  // 2. input gradient: [M x 4Cout] . [4Cout x Cin]
+  PwParams p{};
+  p.a = dpre; p.wp = wp_dgrad; p.bias = nullptr; p.out = dx;
+  p.M = M; p.K = 4 * d->Cout; p.Ncols = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout;
+  if (p.Ncols % 128 == 0) {
+    p.n_ntiles = p.Ncols / 128;
+    rc = launch_pw<1, 2, 2, 2, 2>(p, st);
+  } else {
+    p.n_ntiles = p.Ncols / 64;
+    rc = launch_pw<1, 4, 1, 1, 2>(p, st);
+  }
+  if (rc != UNETK_OK) return rc;
+
+  // 3. filter gradient
+  DwParams q{};
+  q.x = x; q.dpre = dpre; q.slab = slab; q.M = M; q.H = d->H; q.W = d->W; q.Cin = d->Cin; q.Cout = d->Cout;
+  q.m_per_split = pl.m_per_split; q.n_co_tiles = d->Cout / 64; q.n_ci_tiles = d->Cin / 64;
+  const int grid = pl.S * 4 * q.n_co_tiles * q.n_ci_tiles;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)deconv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       2 * 128 * 64 * (int)sizeof(float));
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(deconv_wgrad_kernel, dim3(grid), dim3(256), (size_t)2 * 128 * 64 * sizeof(float), st, q);
+  UNETK_LAUNCH_CHECK();
+  return unetk_launch_slab_reduce(slab, pl.S, (int64_t)4 * d->Cin * d->Cout, dw, st);
+}

@@ -1,0 +1,123 @@
+// Optimiser step on a flat fp32 parameter buffer (HBM-bound: 4 reads + 3 writes per element).
+//
+// Replaces tf.train.AdamOptimizer / MomentumOptimizer built at core/solver.py:204-219 and applied by
+// optimizer.minimize at :236-241, plus the gradient of slim.l2_regularizer (NetworksV2/base.py:128-135),
+// with TF's formulas (epsilon OUTSIDE the bias correction -- differs from torch.optim.Adam).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float lr_t, float b1, float b2,
+                                                   float eps, float gscale, float l2) {
+  const int64_t n4 = n >> 2;
+  const float c1 = 1.f - b1, c2 = 1.f - b2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pv = ldg4(p + i * 4), mv = ldg4(m + i * 4), vv = ldg4(v + i * 4);
+    const float4 gv = ldg4(g + i * 4);
+#define ADAM1(f)                                  \
+  {                                               \
+    const float gg = fmaf(l2, pv.f, gv.f * gscale); \
+    mv.f += c1 * (gg - mv.f);                     \
+    vv.f += c2 * (gg * gg - vv.f);                \
+    pv.f -= lr_t * mv.f / (sqrtf(vv.f) + eps);    \
+  }
+    ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+#undef ADAM1
+    stg4(p + i * 4, pv);
+    stg4(m + i * 4, mv);
+    stg4(v + i * 4, vv);
+  }
+  // tail (n % 4)
+  const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) {
+    const float gg = fmaf(l2, p[t], g[t] * gscale);
+    m[t] += c1 * (gg - m[t]);
+    v[t] += c2 * (gg * gg - v[t]);
+    p[t] -= lr_t * m[t] / (sqrtf(v[t]) + eps);
+  }
+}
+
+__global__ __launch_bounds__(256) void momentum_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ acc, int64_t n, float lr, float mom,
+                                                       int nesterov, float gscale, float l2) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gg = fmaf(l2, p[i], g[i] * gscale);
+    const float a = mom * acc[i] + gg;
+    acc[i] = a;
+    p[i] -= nesterov ? lr * (gg + mom * a) : lr * a;
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ p, int64_t n, double* __restrict__ part) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = (double)p[i];
+    s += v * v;
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void sumsq_final_kernel(const double* __restrict__ part, int nb, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < nb; ++i) s += part[i];
+    out[0] = (float)s;
+  }
+}
+
+inline int flat_grid(int64_t n4) {
+  int64_t g = (n4 + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int unetk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,
+                               float beta2, float eps, float gscale, float l2, void* stream) {
+  UNETK_REQUIRE(p && g && m && v && n > 0);
+  UNETK_REQUIRE(unetk_aligned16(p) && unetk_aligned16(g) && unetk_aligned16(m) && unetk_aligned16(v));
+  hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(n >> 2)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, beta1,
+                     beta2, eps, gscale, l2);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+extern "C" int unetk_momentum_step(float* p, const float* g, float* acc, int64_t n, float lr, float mom, int nesterov,
+                                   float gscale, float l2, void* stream) {
+  UNETK_REQUIRE(p && g && acc && n > 0);
+  hipLaunchKernelGGL(momentum_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, acc, n, lr, mom,
+                     nesterov, gscale, l2);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+extern "C" int unetk_sumsq(const float* p, int64_t n, float* out, void* ws, size_t ws_bytes, void* stream) {
+  UNETK_REQUIRE(p && out && ws && n > 0);
+  if (ws_bytes < 1024 * sizeof(double)) return UNETK_E_WORKSPACE;
+  int nb = flat_grid(n);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, n, (double*)ws);
+  UNETK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)ws, nb, out);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+extern "C" int unetk_abi_version(void) { return 1; }
+
+extern "C" const char* unetk_error_string(int code) {
+  switch (code) {
+    case UNETK_OK: return "ok";
+    case UNETK_E_BADARG: return "bad argument (null pointer, non-positive size or misaligned buffer)";
+    case UNETK_E_UNSUPPORTED: return "shape not supported by this build of libunetk";
+    case UNETK_E_WORKSPACE: return "workspace too small";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+  }
+}

@@ -1,0 +1,78 @@
+"""Synthetic LiTS-shaped input_fn: same tensor contract as the reference's
+DataLoader/Liver/input_pipeline.py:243-284 -- features["images"] f32 [bs,H,W,C] (window-normalised CT in
+[0,1] plus U(-noise, noise)), features["names"] int PIDs, labels int32 [bs,H,W] in {0..ncls-1}.
+
+images ~ U[0,1) + U(-0.05, 0.05); labels: class 1 = filled ellipse centred (0.45H, 0.4W), radii
+(0.3H, 0.25W) (~24 % area, liver-like); class 2 = disk radius 0.05H inside it (~0.8 %, tumor-like);
+per-sample random shift of +-0.1H.  Generated once with numpy default_rng(seed) and kept resident on
+the device; no file I/O.
+"""
+import numpy as np
+import torch
+
+
+def add_arguments(parser):
+    """The liver pipeline flags the model reads (DataLoader/Liver/input_pipeline.py:54-70)."""
+    group = parser.add_argument_group(title="Input Pipeline Arguments")
+    group.add_argument("--test_fold", type=int, default=2)
+    group.add_argument("--im_height", type=int, default=256)
+    group.add_argument("--im_width", type=int, default=256)
+    group.add_argument("--im_channel", type=int, default=3)
+    group.add_argument("--noise_scale", type=float, default=0.1)
+    group.add_argument("--random_flip", type=int, default=1)
+    group.add_argument("--eval_num_batches_per_epoch", type=int, default=100)
+    group.add_argument("--synthetic_batches", type=int, default=2, help="distinct synthetic batches kept on device")
+    group.add_argument("--seed", type=int, default=1234)
+
+
+def make_batch(bs, height, width, channel, num_classes, seed=1234, noise_scale=0.05):
+    rng = np.random.default_rng(seed)
+    images = rng.random((bs, height, width, channel), dtype=np.float32)
+    images += rng.uniform(-noise_scale, noise_scale, size=images.shape).astype(np.float32)
+    yy, xx = np.meshgrid(np.arange(height, dtype=np.float32), np.arange(width, dtype=np.float32), indexing="ij")
+    labels = np.zeros((bs, height, width), dtype=np.int32)
+    for b in range(bs):
+        dy, dx = rng.uniform(-0.1, 0.1, size=2) * height
+        cy, cx = 0.45 * height + dy, 0.4 * width + dx
+        ell = ((yy - cy) / (0.3 * height)) ** 2 + ((xx - cx) / (0.25 * width)) ** 2 <= 1.0
+        labels[b][ell] = 1
+        if num_classes > 2:
+            ty, tx = cy + 0.1 * height, cx - 0.05 * width
+            disk = (yy - ty) ** 2 + (xx - tx) ** 2 <= (0.05 * height) ** 2
+            labels[b][disk & ell] = 2
+    names = np.arange(bs, dtype=np.int64) + seed
+    return images, labels, names
+
+
+def input_fn(mode, params):
+    """input_fn(mode, params) -> iterator of (features, labels), modes train / eval_online / eval
+    (reference contract: DataLoader/Liver/input_pipeline.py:199-203)."""
+    args = params["args"]
+    num_gpus = max(getattr(args, "num_gpus", 1), 1)
+    bs = args.batch_size // num_gpus if num_gpus > 1 else args.batch_size
+    ncls = len(args.classes) + 1
+    rank = int(params.get("rank", 0))
+    device = params.get("device", torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available()
+                        else torch.device("cpu"))
+    nb = max(int(getattr(args, "synthetic_batches", 2)), 1)
+    base_seed = int(getattr(args, "seed", 1234) or 1234)
+    pool = []
+    for i in range(nb):
+        seed = base_seed + 1000 * rank + i + (0 if mode == "train" else 500)
+        images, labels, names = make_batch(bs, args.im_height, args.im_width, args.im_channel, ncls, seed,
+                                           getattr(args, "noise_scale", 0.05))
+        pool.append(({"images": torch.from_numpy(images).to(device), "names": torch.from_numpy(names)},
+                     torch.from_numpy(labels).to(device)))
+
+    def gen():
+        if mode == "train":
+            i = 0
+            while True:
+                yield pool[i % nb]
+                i += 1
+        else:
+            n = int(getattr(args, "eval_num_batches_per_epoch", nb) or nb)
+            for i in range(min(n, nb) if mode == "eval" else n):
+                yield pool[i % nb]
+
+    return gen()

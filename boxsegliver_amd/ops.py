@@ -1,0 +1,386 @@
+"""Host-side operators of the U-Net hot path: thin wrappers over the libunetk C ABI plus the
+torch.autograd.Function nodes the networks are composed from.
+
+PyTorch is plumbing here (device memory, streams, autograd bookkeeping); every FLOP and every
+byte moved on the hot path happens inside a hand-written HIP kernel reached through
+boxsegliver_amd._abi.  Nothing in this module falls back to torch ops or to the CPU oracle.
+
+Reference call sites replaced (relative to the reference repo root):
+  Conv3x3BnRelu : slim.repeat(x, 2, slim.conv2d, C, 3) unit           NetworksV2/UNet.py:79,85,94
+  MaxPool2x2    : slim.max_pool2d(x, [2, 2])                           NetworksV2/UNet.py:81
+  DeconvConcat  : slim.conv2d_transpose(x, C/2, 2, 2) + tf.concat      NetworksV2/UNet.py:91-93
+  HeadLoss      : logits 1x1 conv + loss + metrics                     UNet.py:97-155, loss_metrics.py:115-339
+"""
+import ctypes
+
+import torch
+
+from . import _abi
+from ._abi import ConvDesc, DeconvDesc, HeadDesc, check, ptr, stream_ptr
+
+
+# ----------------------------------------------------------------------------- memory helpers
+class _Workspace(object):
+    """One growing scratch buffer per device; ops on one stream use it back to back."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, nbytes, device):
+        nbytes = max(int(nbytes), 16)
+        key = (device.type, device.index)
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+            self._bufs[key] = buf
+        return buf
+
+
+WORKSPACE = _Workspace()
+
+
+def alias(t, offset_elems=0, size=None, stride=None):
+    """A fresh tensor object over t's storage (own autograd version counter).  The kernels write
+    disjoint channel slices of shared concat buffers; autograd must not see those as in-place ops."""
+    size = tuple(t.shape) if size is None else tuple(size)
+    stride = tuple(t.stride()) if stride is None else tuple(stride)
+    out = torch.empty(0, dtype=t.dtype, device=t.device)
+    out.set_(t.untyped_storage(), t.storage_offset() + offset_elems, size, stride)
+    return out
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _abi.UnetkError("libunetk ops need device tensors (got a CPU tensor); "
+                                  "there is no CPU path in the product")
+
+
+def _pix_stride(t):
+    """Pixel stride (floats) of an NHWC tensor whose channel dim is contiguous."""
+    assert t.dim() == 4 and t.stride(3) == 1, "NHWC with contiguous channels expected"
+    s = t.stride(2)
+    assert t.stride(1) == t.shape[2] * s and t.stride(0) == t.shape[1] * t.shape[2] * s, \
+        "only a channel-slice view of a dense NHWC buffer is supported"
+    return s
+
+
+# ----------------------------------------------------------------------------- raw op wrappers
+def conv3x3_pack(w, want_dgrad=True):
+    _require_cuda(w)
+    kh, kw, cin, cout = w.shape
+    assert kh == 3 and kw == 3
+    wp_f = torch.empty(9 * cin * cout, dtype=torch.float32, device=w.device)
+    wp_d = torch.empty_like(wp_f) if want_dgrad else None
+    check(_abi.lib().unetk_conv3x3_pack(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()), "conv3x3_pack")
+    return wp_f, wp_d
+
+
+def conv_uses_mfma(cin, cout):
+    return cin % 16 == 0 and cout % 64 == 0
+
+
+def conv3x3_fwd(x, w, cout, want_stats=True, y=None):
+    """x NHWC (pixel-strided ok); w = packed filter if conv_uses_mfma(cin, cout) else raw HWIO."""
+    _require_cuda(x, w)
+    n, h, wd, cin = x.shape
+    if y is None:
+        y = torch.empty((n, h, wd, cout), dtype=torch.float32, device=x.device)
+    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(x), _pix_stride(y))
+    stats = None
+    rows = 0
+    if want_stats:
+        rows = _abi.lib().unetk_conv3x3_stat_rows(ctypes.byref(d))
+        if rows <= 0:
+            check(rows, "conv3x3_stat_rows")
+        stats = torch.empty((2, rows, cout), dtype=torch.float32, device=x.device)
+    check(_abi.lib().unetk_conv3x3_fwd(ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(stats), stream_ptr()),
+          "conv3x3_fwd")
+    return y, stats, rows
+
+
+def conv3x3_dgrad(dy, wp_dgrad, cin, x_stride=None, dx=None):
+    _require_cuda(dy, wp_dgrad)
+    n, h, wd, cout = dy.shape
+    if dx is None:
+        dx = torch.empty((n, h, wd, cin), dtype=torch.float32, device=dy.device)
+    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(dx), _pix_stride(dy))
+    check(_abi.lib().unetk_conv3x3_dgrad(ctypes.byref(d), ptr(dy), ptr(wp_dgrad), ptr(dx), stream_ptr()),
+          "conv3x3_dgrad")
+    return dx
+
+
+def conv3x3_wgrad(x, dy):
+    _require_cuda(x, dy)
+    n, h, wd, cin = x.shape
+    cout = dy.shape[3]
+    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(x), _pix_stride(dy))
+    nbytes = _abi.lib().unetk_conv3x3_wgrad_ws_bytes(ctypes.byref(d))
+    if nbytes == 0:
+        raise _abi.UnetkError("conv3x3_wgrad: unsupported shape Cin={} Cout={}".format(cin, cout))
+    ws = WORKSPACE.get(nbytes, x.device)
+    dw = torch.empty((3, 3, cin, cout), dtype=torch.float32, device=x.device)
+    check(_abi.lib().unetk_conv3x3_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes, stream_ptr()),
+          "conv3x3_wgrad")
+    return dw
+
+
+def bn_finalize(stats, rows, count, gamma, beta, eps, decay, training, moving_mean, moving_var):
+    c = gamma.numel()
+    dev = gamma.device
+    out = torch.empty((4, c), dtype=torch.float32, device=dev)   # mean, rstd, scale, shift
+    nbytes = _abi.lib().unetk_bn_finalize_ws_bytes(max(rows, 1), c)
+    ws = WORKSPACE.get(nbytes, dev)
+    check(_abi.lib().unetk_bn_finalize(ptr(stats), rows, c, count, ptr(gamma), ptr(beta), eps, decay,
+                                       1 if training else 0, ptr(moving_mean), ptr(moving_var),
+                                       ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(ws), nbytes,
+                                       stream_ptr()), "bn_finalize")
+    return out
+
+
+def affine_relu(y, scale, shift, z):
+    npix = y.shape[0] * y.shape[1] * y.shape[2]
+    c = y.shape[3]
+    assert y.is_contiguous()
+    check(_abi.lib().unetk_affine_relu(ptr(y), ptr(scale), ptr(shift), ptr(z), npix, c, _pix_stride(z),
+                                       stream_ptr()), "affine_relu")
+    return z
+
+
+def bn_relu_bwd(y, dz, gamma, beta, mean, rstd):
+    npix = y.shape[0] * y.shape[1] * y.shape[2]
+    c = y.shape[3]
+    dy = torch.empty_like(y)
+    dgb = torch.empty((2, c), dtype=torch.float32, device=y.device)
+    nbytes = _abi.lib().unetk_bn_bwd_ws_bytes(npix, c)
+    if nbytes == 0:
+        raise _abi.UnetkError("bn_relu_bwd: unsupported channel count {}".format(c))
+    ws = WORKSPACE.get(nbytes, y.device)
+    check(_abi.lib().unetk_bn_relu_bwd(ptr(y), ptr(dz), _pix_stride(dz), ptr(gamma), ptr(mean), ptr(rstd), ptr(beta),
+                                       ptr(dy), ptr(dgb[0]), ptr(dgb[1]), npix, c, ptr(ws), nbytes, stream_ptr()),
+          "bn_relu_bwd")
+    return dy, dgb[0], dgb[1]
+
+
+def maxpool2_fwd(x):
+    _require_cuda(x)
+    n, h, w, c = x.shape
+    p = torch.empty((n, h // 2, w // 2, c), dtype=torch.float32, device=x.device)
+    check(_abi.lib().unetk_maxpool2_fwd(ptr(x), _pix_stride(x), ptr(p), n, h, w, c, stream_ptr()), "maxpool2_fwd")
+    return p
+
+
+def maxpool2_bwd(x, p, dp):
+    n, h, w, c = x.shape
+    dx = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+    check(_abi.lib().unetk_maxpool2_bwd(ptr(x), _pix_stride(x), ptr(p), ptr(dp.contiguous()), ptr(dx), n, h, w, c,
+                                        stream_ptr()), "maxpool2_bwd")
+    return dx
+
+
+def deconv2x2_pack(w):
+    _require_cuda(w)
+    kh, kw, cout, cin = w.shape
+    assert kh == 2 and kw == 2
+    wp_f = torch.empty(4 * cin * cout, dtype=torch.float32, device=w.device)
+    wp_d = torch.empty_like(wp_f)
+    check(_abi.lib().unetk_deconv2x2_pack(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()), "deconv2x2_pack")
+    return wp_f, wp_d
+
+
+def deconv2x2_fwd(x, wp_fwd, bias, cat, coff, cout):
+    n, h, w, cin = x.shape
+    assert x.is_contiguous()
+    d = DeconvDesc(n, h, w, cin, cout, _pix_stride(cat), coff)
+    check(_abi.lib().unetk_deconv2x2_fwd(ctypes.byref(d), ptr(x), ptr(wp_fwd), ptr(bias), ptr(cat), stream_ptr()),
+          "deconv2x2_fwd")
+    return cat
+
+
+def deconv2x2_bwd(x, wp_dgrad, cat, dcat, coff, cout):
+    n, h, w, cin = x.shape
+    d = DeconvDesc(n, h, w, cin, cout, _pix_stride(cat), coff)
+    assert _pix_stride(dcat) == _pix_stride(cat)
+    nbytes = _abi.lib().unetk_deconv2x2_bwd_ws_bytes(ctypes.byref(d))
+    if nbytes == 0:
+        raise _abi.UnetkError("deconv2x2_bwd: unsupported shape Cin={} Cout={}".format(cin, cout))
+    ws = WORKSPACE.get(nbytes, x.device)
+    dx = torch.empty_like(x)
+    dw = torch.empty((2, 2, cout, cin), dtype=torch.float32, device=x.device)
+    db = torch.empty((cout,), dtype=torch.float32, device=x.device)
+    check(_abi.lib().unetk_deconv2x2_bwd(ctypes.byref(d), ptr(x), ptr(wp_dgrad), ptr(cat), ptr(dcat), ptr(dx), ptr(dw),
+                                         ptr(db), ptr(ws), nbytes, stream_ptr()), "deconv2x2_bwd")
+    return dx, dw, db
+
+
+def head_desc(n, hw, c, ncls, weight_mode="none", numeric_w=None, proportion_decay=0.0):
+    mode = {"none": _abi.W_NONE, "numerical": _abi.W_NUMERICAL, "proportion": _abi.W_PROPORTION,
+            "pixelmap": _abi.W_PIXELMAP}[weight_mode]
+    d = HeadDesc()
+    d.N, d.HW, d.C, d.ncls, d.weight_mode = n, hw, c, ncls, mode
+    if mode == _abi.W_NUMERICAL:
+        if numeric_w is None or len(numeric_w) != ncls:
+            raise KeyError("w_type `numerical` need keyword argument `numeric_w`")
+        for i, v in enumerate(numeric_w):
+            d.numeric_w[i] = float(v)
+    d.proportion_decay = float(proportion_decay or 0.0)
+    return d
+
+
+def head_fwd(d, z, w, b, labels, pixel_w=None, want_probs=False):
+    _require_cuda(z, w, b)
+    npix = d.N * d.HW
+    dev = z.device
+    assert z.is_contiguous()
+    logits = torch.empty((npix, d.ncls), dtype=torch.float32, device=dev)
+    probs = torch.empty_like(logits) if want_probs else None
+    nres = _abi.lib().unetk_head_result_floats(ctypes.byref(d))
+    nbytes = _abi.lib().unetk_head_ws_bytes(ctypes.byref(d))
+    if nres == 0 or nbytes == 0:
+        raise _abi.UnetkError("head: bad descriptor")
+    result = torch.zeros((nres,), dtype=torch.float32, device=dev)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)    # kept for backward (weight tables)
+    check(_abi.lib().unetk_head_fwd(ctypes.byref(d), ptr(z), ptr(w), ptr(b), ptr(labels), ptr(pixel_w), ptr(logits),
+                                    ptr(probs), ptr(result), ptr(ws), nbytes, stream_ptr()), "head_fwd")
+    return logits, probs, result, ws
+
+
+def head_bwd(d, z, w, labels, pixel_w, logits, result, ws, xent_scale, dice_scale, dev_scales=None):
+    dz = torch.empty_like(z)
+    dw = torch.empty((d.C, d.ncls), dtype=torch.float32, device=z.device)
+    db = torch.empty((d.ncls,), dtype=torch.float32, device=z.device)
+    check(_abi.lib().unetk_head_bwd(ctypes.byref(d), ptr(z), ptr(w), ptr(labels), ptr(pixel_w), ptr(logits), ptr(result),
+                                    float(xent_scale), float(dice_scale), ptr(dev_scales), ptr(dz), ptr(dw), ptr(db),
+                                    ptr(ws), ws.numel(), stream_ptr()), "head_bwd")
+    return dz, dw, db
+
+
+def head_predict(probs, ncls, want_preds=True):
+    npix = probs.numel() // ncls
+    amax = torch.empty((npix,), dtype=torch.uint8, device=probs.device)
+    preds = torch.empty((ncls - 1, npix), dtype=torch.uint8, device=probs.device) if want_preds else None
+    check(_abi.lib().unetk_head_predict(ptr(probs), npix, ncls, ptr(amax), ptr(preds), stream_ptr()), "head_predict")
+    return amax, preds
+
+
+def adam_step(p, g, m, v, lr_t, beta1, beta2, eps, gscale=1.0, l2=0.0):
+    check(_abi.lib().unetk_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr_t, beta1, beta2, eps, gscale, l2,
+                                     stream_ptr()), "adam_step")
+
+
+def momentum_step(p, g, acc, lr, mom, nesterov, gscale=1.0, l2=0.0):
+    check(_abi.lib().unetk_momentum_step(ptr(p), ptr(g), ptr(acc), p.numel(), lr, mom, 1 if nesterov else 0, gscale,
+                                         l2, stream_ptr()), "momentum_step")
+
+
+def sumsq(p):
+    out = torch.empty((1,), dtype=torch.float32, device=p.device)
+    ws = WORKSPACE.get(8192, p.device)
+    check(_abi.lib().unetk_sumsq(ptr(p), p.numel(), ptr(out), ptr(ws), 8192, stream_ptr()), "sumsq")
+    return out
+
+
+# ----------------------------------------------------------------------------- autograd nodes
+class Conv3x3BnRelu(torch.autograd.Function):
+    """z = relu(batch_norm(conv3x3(x, w))) -- one slim.conv2d(x, C, 3) unit under UNet._net_arg_scope
+    (NetworksV2/UNet.py:41-56,79): conv without bias, slim.batch_norm(scale=True), ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, moving_mean, moving_var, training, eps, decay, out):
+        _require_cuda(x, w, gamma, beta)
+        cin, cout = w.shape[2], w.shape[3]
+        mfma = conv_uses_mfma(cin, cout)
+        need_dx = ctx.needs_input_grad[0]
+        if mfma:
+            wp_f, wp_d = conv3x3_pack(w, want_dgrad=need_dx)
+        else:
+            wp_f, wp_d = w, None
+            if need_dx:
+                raise _abi.UnetkError("conv3x3 input gradient needs Cin%64==0 and Cout%16==0 "
+                                      "(got {}->{})".format(cin, cout))
+        y, stats, rows = conv3x3_fwd(x, wp_f, cout, want_stats=training)
+        count = y.shape[0] * y.shape[1] * y.shape[2]
+        aff = bn_finalize(stats, rows, count, gamma, beta, eps, decay, training, moving_mean, moving_var)
+        z = out if out is not None else torch.empty_like(y)
+        affine_relu(y, aff[2], aff[3], z)
+        if training:
+            ctx.save_for_backward(x, y, gamma, beta, aff)
+            ctx.wp_d = wp_d
+            ctx.need_dx = need_dx
+        return alias(z) if out is not None else z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, y, gamma, beta, aff = ctx.saved_tensors
+        if dz.stride(3) != 1:
+            dz = dz.contiguous()
+        dy, dgamma, dbeta = bn_relu_bwd(y, dz, gamma, beta, aff[0], aff[1])
+        dw = conv3x3_wgrad(x, dy)
+        dx = conv3x3_dgrad(dy, ctx.wp_d, x.shape[3]) if ctx.need_dx else None
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None
+
+
+class MaxPool2x2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        p = maxpool2_fwd(x)
+        ctx.save_for_backward(x, p)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        x, p = ctx.saved_tensors
+        return maxpool2_bwd(x, p, dp)
+
+
+class DeconvConcat(torch.autograd.Function):
+    """cat = concat(skip, relu(conv2d_transpose(x, w, k=2, s=2) + b)); `skip` already lives in
+    cat[..., :C] (the encoder wrote it there), the kernel fills cat[..., C:] -- zero-copy concat."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, skip, cat):
+        _require_cuda(x, w, b, cat)
+        cout = w.shape[2]
+        coff = cat.shape[3] - cout
+        assert skip.data_ptr() == cat.data_ptr() and skip.shape[3] == coff
+        wp_f, wp_d = deconv2x2_pack(w)
+        deconv2x2_fwd(x, wp_f, b, cat, coff, cout)
+        ctx.save_for_backward(x, cat)
+        ctx.wp_d = wp_d
+        ctx.cout, ctx.coff = cout, coff
+        return alias(cat)
+
+    @staticmethod
+    def backward(ctx, dcat):
+        x, cat = ctx.saved_tensors
+        dcat = dcat.contiguous()
+        dx, dw, db = deconv2x2_bwd(x, ctx.wp_d, cat, dcat, ctx.coff, ctx.cout)
+        dskip = dcat[..., :ctx.coff]
+        return dx, dw, db, dskip, None
+
+
+class HeadLoss(torch.autograd.Function):
+    """(xent, dice) = loss head over logits = z @ w + b; also returns logits / probs / metric sums
+    as non-differentiable outputs."""
+
+    @staticmethod
+    def forward(ctx, z, w, b, labels, pixel_w, desc, want_probs):
+        w2 = w.reshape(desc.C, desc.ncls)
+        logits, probs, result, ws = head_fwd(desc, z, w2, b, labels, pixel_w, want_probs)
+        ctx.save_for_backward(z, w2, labels, pixel_w, logits, result, ws)
+        ctx.desc = desc
+        ctx.w_shape = w.shape
+        xent = result[0:1].reshape(())
+        dice = result[1:2].reshape(())
+        outs = (xent.clone(), dice.clone(), logits, probs if probs is not None else logits.new_empty(0), result)
+        ctx.mark_non_differentiable(outs[2], outs[3], outs[4])
+        return outs
+
+    @staticmethod
+    def backward(ctx, gx, gd, _gl, _gp, _gr):
+        z, w2, labels, pixel_w, logits, result, ws = ctx.saved_tensors
+        zero = torch.zeros((), dtype=torch.float32, device=z.device)
+        scales = torch.stack([gx if gx is not None else zero, gd if gd is not None else zero]).to(torch.float32)
+        dz, dw, db = head_bwd(ctx.desc, z, w2, labels, pixel_w, logits, result, ws,
+                              1.0 if gx is not None else 0.0, 1.0 if gd is not None else 0.0, scales)
+        return dz, dw.reshape(ctx.w_shape), db, None, None, None, None

@@ -1,0 +1,98 @@
+"""Data-parallel helpers -- mirror of the reference's utils/distribution_utils.py.
+
+The reference replicates the model in ONE process with tf.contrib.distribute.MirroredStrategy and an
+NCCL all-reduce (distribution_utils.py:27-104).  The MI355X design is one process per GPU with
+torch.distributed (backend "nccl" == RCCL over xGMI); gradients of the two flat parameter buffers are
+summed with ONE all-reduce each and scaled by 1/world inside the optimiser kernel, which is exactly
+TF's "per-replica loss x 1/N, gradients summed" (core/estimator.py:570-578).
+Batch-norm statistics stay replica-local, as in the reference (no SyncBN).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def per_device_batch_size(batch_size, num_gpus):
+    """distribution_utils.py:107-134 (same error text)."""
+    if num_gpus <= 1:
+        return batch_size
+    remainder = batch_size % num_gpus
+    if remainder:
+        err = ('When running with multiple GPUs, batch size '
+               'must be a multiple of the number of available GPUs. Found {} '
+               'GPUs with a batch size of {}; try --batch_size={} instead.'
+               ).format(num_gpus, batch_size, batch_size - remainder)
+        raise ValueError(err)
+    return int(batch_size / num_gpus)
+
+
+class DistributionStrategy(object):
+    """What get_distribution_strategy returns: a handle on the process group."""
+
+    def __init__(self, name, world_size, rank):
+        self.name = name
+        self.num_replicas_in_sync = world_size
+        self.rank = rank
+
+    def all_reduce_sum_(self, tensors):
+        if self.num_replicas_in_sync > 1:
+            works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True) for t in tensors]
+            for w in works:
+                w.wait()
+        return tensors
+
+    def reduce_mean(self, value):
+        """strategy.reduce(MEAN, loss) -- core/estimator.py:576,585."""
+        if self.num_replicas_in_sync > 1:
+            v = value.detach().clone().reshape(1)
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            return (v / self.num_replicas_in_sync).reshape(())
+        return value
+
+    def broadcast_(self, tensors, src=0):
+        if self.num_replicas_in_sync > 1:
+            for t in tensors:
+                dist.broadcast(t, src=src)
+
+
+def init_process_group_from_env(backend=None):
+    """One process per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from torchrun."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend)
+    return world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def get_distribution_strategy(distribution_strategy="default", num_gpus=0, num_workers=1,
+                              all_reduce_alg=None, session_config=None):
+    """distribution_utils.py:27-104.  `off` / num_gpus < 2 -> None; `mirrored`/`default` -> data
+    parallel over the initialised process group; `parameter_server` is accepted by the reference
+    flag parser but unused by any script -> NotImplementedError; multi-worker -> NotImplementedError
+    (:68-69)."""
+    if num_gpus < 0:
+        raise ValueError("`num_gpus` can not be negative.")
+    distribution_strategy = distribution_strategy.lower()
+    if distribution_strategy == "off":
+        if num_gpus > 1 or num_workers > 1:
+            raise ValueError("When {} GPUs and  {} workers are specified, distribution_strategy flag "
+                             "cannot be set to 'off'.".format(num_gpus, num_workers))
+        return None
+    if num_workers > 1:
+        raise NotImplementedError("multi-worker training is not supported (reference: distribution_utils.py:68-69)")
+    if distribution_strategy == "one_device" or num_gpus < 2:
+        if num_gpus > 1:
+            raise ValueError("`OneDeviceStrategy` can not be used for more than one device.")
+        return DistributionStrategy("one_device", 1, 0)
+    if distribution_strategy in ("mirrored", "default"):
+        world, rank, _ = init_process_group_from_env()
+        if world != num_gpus:
+            raise ValueError("--num_gpus {} but WORLD_SIZE is {}: launch one process per GPU "
+                             "(python -m torch.distributed.run --nproc-per-node {})".format(num_gpus, world, num_gpus))
+        return DistributionStrategy("mirrored", world, rank)
+    if distribution_strategy == "parameter_server":
+        raise NotImplementedError("parameter_server strategy is not used by the reference's scripts")
+    raise ValueError("Unrecognized Distribution Strategy: %r" % distribution_strategy)

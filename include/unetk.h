@@ -1,0 +1,193 @@
+/*
+ * unetk.h -- C ABI of libunetk.so: hand-written HIP (gfx950 / MI355X) kernels for the
+ * U-Net conv encoder/decoder + loss-head hot path of Jarvis73/BoxSegLiver.
+ *
+ * The reference has NO native boundary for this path (it is pure Python on
+ * tensorflow-gpu 1.13).  Each entry point below therefore cites the
+ * reference *call site* whose TensorFlow op it replaces (paths relative to the
+ * reference repo root).
+ *
+ * Conventions
+ *   - all tensors are device pointers, fp32, NHWC, densely packed unless a
+ *     "*_stride" (pixel stride, in floats) argument says otherwise; labels int32
+ *   - conv filters are TF HWIO [kh,kw,Cin,Cout]; transposed-conv filters are TF
+ *     [kh,kw,Cout,Cin]  (slim.conv2d / slim.conv2d_transpose variable layouts)
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it
+ *   - no allocation, no host sync, no global mutable state: caller owns all buffers,
+ *     including workspaces sized by the *_ws_bytes() queries  (graph-capturable)
+ *   - return 0 on success, else a negative UNETK_E_* or a positive hipError_t
+ */
+#ifndef UNETK_H_
+#define UNETK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNETK_OK 0
+#define UNETK_E_BADARG (-1)       /* null pointer / non-positive size / misaligned */
+#define UNETK_E_UNSUPPORTED (-2)  /* valid request this build has no kernel for */
+#define UNETK_E_WORKSPACE (-3)    /* workspace too small */
+
+#define UNETK_MAX_CLASSES 8
+
+/* loss head weight modes: loss_metrics.py:115-165 `_compute_weights` w_type */
+#define UNETK_W_NONE 0
+#define UNETK_W_NUMERICAL 1
+#define UNETK_W_PROPORTION 2
+#define UNETK_W_PIXELMAP 3 /* caller-provided per-pixel map (covers `boundary`, which the
+                              reference computes on the host via py_func, :149-159) */
+
+/* loss types: loss_metrics.py:42-45 --loss_type */
+#define UNETK_LOSS_XENTROPY 1
+#define UNETK_LOSS_DICE 2
+
+int unetk_abi_version(void);
+const char* unetk_error_string(int code);
+
+/* ---------------------------------------------------------------- conv 3x3 (slim.conv2d(x, C, 3))
+ * NetworksV2/UNet.py:79,85,94 -- stride 1, SAME, no bias (a normaliser follows).
+ * Geometry: x [N,H,W,Cin] (pixel stride x_stride >= Cin), y [N,H,W,Cout] (pixel stride y_stride). */
+typedef struct unetk_conv_desc {
+  int32_t N, H, W, Cin, Cout;
+  int32_t x_stride, y_stride;
+} unetk_conv_desc;
+
+/* Re-layout HWIO filters for the MFMA kernels ("K4-interleaved": [tap][Cin/4][Cout][4]).
+ * wp_fwd feeds unetk_conv3x3_fwd; wp_dgrad (taps flipped, Cin<->Cout swapped) feeds
+ * unetk_conv3x3_dgrad.  Either output may be NULL.  Each holds 9*Cin*Cout floats. */
+int unetk_conv3x3_pack(const float* w_hwio, int Cin, int Cout, float* wp_fwd, float* wp_dgrad,
+                       void* stream);
+
+/* Number of per-channel statistic partial rows unetk_conv3x3_fwd writes (one per pixel tile). */
+int unetk_conv3x3_stat_rows(const unetk_conv_desc* d);
+
+/* y = conv3x3(x, w).  If stat_partials != NULL also writes per-pixel-tile partial sums for the
+ * following norm: stat_partials[0][row][c] = sum y, stat_partials[1][row][c] = sum y^2
+ * (2 * stat_rows * Cout floats; deterministic, no atomics).
+ * `w` is wp_fwd from unetk_conv3x3_pack when Cin % 16 == 0 && Cout % 64 == 0, else the raw
+ * HWIO filter (direct kernel; used by Encode1/conv1 where Cin = 3). */
+int unetk_conv3x3_fwd(const unetk_conv_desc* d, const float* x, const float* w, float* y,
+                      float* stat_partials, void* stream);
+
+/* dx = conv3x3_input_grad(dy, w): d describes the FORWARD conv (dx has Cin channels,
+ * pixel stride x_stride; dy has Cout channels, pixel stride y_stride).  `w` = wp_dgrad. */
+int unetk_conv3x3_dgrad(const unetk_conv_desc* d, const float* dy, const float* w, float* dx,
+                        void* stream);
+
+/* dw[HWIO] = conv3x3_filter_grad(x, dy).  Split-K over pixel tiles through a workspace of
+ * fixed-order partial slabs (bit-reproducible). */
+size_t unetk_conv3x3_wgrad_ws_bytes(const unetk_conv_desc* d);
+int unetk_conv3x3_wgrad(const unetk_conv_desc* d, const float* x, const float* dy, float* dw,
+                        void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- normalisation (slim.batch_norm)
+ * NetworksV2/base.py:153-169; TF defaults eps 1e-3, decay .999.
+ * Finalise the conv's statistic partials into mean/var and the fused affine
+ * scale = gamma*rsqrt(var+eps), shift = beta - mean*scale; when training also update the moving
+ * statistics (moving = moving*decay + batch*(1-decay), unbiased variance).
+ * When training == 0 the affine is built from the moving statistics and partials are ignored. */
+size_t unetk_bn_finalize_ws_bytes(int stat_rows, int C);
+int unetk_bn_finalize(const float* stat_partials, int stat_rows, int C, int64_t count,
+                      const float* gamma, const float* beta, float eps, float decay, int training,
+                      float* moving_mean, float* moving_var, float* mean_out, float* rstd_out,
+                      float* scale_out, float* shift_out, void* ws, size_t ws_bytes, void* stream);
+
+/* z = relu(y*scale[c] + shift[c]); y dense [npix,C]; z pixel stride z_stride (concat placement). */
+int unetk_affine_relu(const float* y, const float* scale, const float* shift, float* z,
+                      int64_t npix, int C, int z_stride, void* stream);
+
+/* Backward of z = relu(bn_train(y)).  Pass 1 writes partial column sums of du and du*xhat
+ * (du = dz * (z > 0)); pass 2 forms dy.  dz has pixel stride dz_stride.
+ * ws must hold unetk_bn_bwd_ws_bytes(npix, C). dgamma/dbeta receive the parameter grads. */
+size_t unetk_bn_bwd_ws_bytes(int64_t npix, int C);
+int unetk_bn_relu_bwd(const float* y, const float* dz, int dz_stride, const float* gamma,
+                      const float* mean, const float* rstd, const float* beta, float* dy,
+                      float* dgamma, float* dbeta, int64_t npix, int C, void* ws, size_t ws_bytes,
+                      void* stream);
+
+/* ---------------------------------------------------------------- slim.max_pool2d(x, [2,2])  UNet.py:81
+ * VALID, stride 2.  x [N,H,W,C] with pixel stride x_stride; p dense [N,H/2,W/2,C].
+ * Backward routes dp to the first maximum in window scan order (TF MaxPoolGrad). */
+int unetk_maxpool2_fwd(const float* x, int x_stride, float* p, int N, int H, int W, int C,
+                       void* stream);
+int unetk_maxpool2_bwd(const float* x, int x_stride, const float* p, const float* dp, float* dx,
+                       int N, int H, int W, int C, void* stream);
+
+/* ---------------------------------------------------------------- slim.conv2d_transpose(x, C, 2, 2)
+ * UNet.py:91-93: kernel 2 stride 2, bias, ReLU, then tf.concat((skip, up), -1).
+ * out[n,2y+a,2x+b, out_coff+co] = relu(sum_ci x[n,y,x,ci]*w[a,b,co,ci] + bias[co]),
+ * written straight into the concat buffer (pixel stride out_stride). */
+typedef struct unetk_deconv_desc {
+  int32_t N, H, W, Cin, Cout; /* input geometry; output is [N,2H,2W,Cout] */
+  int32_t out_stride, out_coff;
+} unetk_deconv_desc;
+
+/* wp_fwd: [Cin/4][4*Cout][4]; wp_dgrad: [4*Cout/4][Cin][4]; each 4*Cin*Cout floats. */
+int unetk_deconv2x2_pack(const float* w, int Cin, int Cout, float* wp_fwd, float* wp_dgrad,
+                         void* stream);
+int unetk_deconv2x2_fwd(const unetk_deconv_desc* d, const float* x, const float* wp_fwd,
+                        const float* bias, float* out, void* stream);
+/* Backward.  dcat/cat: gradient and forward value of the concat buffer (same strides/offset as
+ * `out`).  Produces dx [N,H,W,Cin], dw [2,2,Cout,Cin], dbias [Cout]. */
+size_t unetk_deconv2x2_bwd_ws_bytes(const unetk_deconv_desc* d);
+int unetk_deconv2x2_bwd(const unetk_deconv_desc* d, const float* x, const float* wp_dgrad,
+                        const float* cat, const float* dcat, float* dx, float* dw, float* dbias,
+                        void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- logits + loss head
+ * UNet.py:97-135 + loss_metrics.py:115-231,261-339.
+ * logits = z @ w[C,ncls] + b  (slim.conv2d(x, ncls, 1), linear);  softmax;  weighted sparse
+ * softmax cross-entropy with SUM_BY_NONZERO_WEIGHTS and/or soft Dice loss;  thresholded
+ * (prob > 0.5) per-class counts for metric_dice / metric_voe / metric_vd. */
+typedef struct unetk_head_desc {
+  int32_t N, HW, C, ncls;
+  int32_t weight_mode;                    /* UNETK_W_* */
+  float numeric_w[UNETK_MAX_CLASSES];     /* --loss_numeric_w */
+  float proportion_decay;                 /* --loss_proportion_decay (<=0: none) */
+} unetk_head_desc;
+
+/* Reduced outputs of the forward pass (device, floats), layout:
+ *   [0] xent loss  [1] dice loss  [2] num_present
+ *   then per sample b, per foreground class c=1..ncls-1 (index 3 + (b*(ncls-1)+(c-1))*4 + k):
+ *     k=0 sum(pred*lab) k=1 sum(pred) k=2 sum(lab) k=3 sum(clip(pred+lab,0,1))
+ *   then per sample b: I_b, U_b  (soft dice intersection / union, loss_metrics.py:217-218) */
+size_t unetk_head_result_floats(const unetk_head_desc* d);
+size_t unetk_head_ws_bytes(const unetk_head_desc* d);
+/* logits [N*HW, ncls] always written; probs (same shape) optional; pixel_w only for PIXELMAP. */
+int unetk_head_fwd(const unetk_head_desc* d, const float* z, const float* w, const float* b,
+                   const int32_t* labels, const float* pixel_w, float* logits, float* probs,
+                   float* result, void* ws, size_t ws_bytes, void* stream);
+/* Backward of (xent_scale * xent + dice_scale * dice) w.r.t. z, w, b.  `result` and `ws` are
+ * the buffers the forward filled (ws keeps the per-sample weight tables).  dev_scales (nullable)
+ * points at two device floats multiplied into xent_scale / dice_scale (upstream gradients that
+ * live on the device -- avoids a host sync). */
+int unetk_head_bwd(const unetk_head_desc* d, const float* z, const float* w,
+                   const int32_t* labels, const float* pixel_w, const float* logits,
+                   const float* result, float xent_scale, float dice_scale,
+                   const float* dev_scales, float* dz, float* dw, float* db, void* ws,
+                   size_t ws_bytes, void* stream);
+/* Inference helpers: evaluators/evaluator_liver.py:663 np.argmax(prob, -1) (lowest index on ties)
+ * and UNet.py:112-118 Pred_c = prob_c > 0.5 (uint8).  preds is [ncls-1][npix] or NULL. */
+int unetk_head_predict(const float* probs, int64_t npix, int ncls, uint8_t* argmax,
+                       uint8_t* preds, void* stream);
+
+/* ---------------------------------------------------------------- optimiser  core/solver.py:204-243
+ * tf.train.AdamOptimizer on a flat parameter buffer.  g' = g*gscale + l2*p  (slim.l2_regularizer
+ * gradient, base.py:128-135);  m += (1-b1)(g'-m);  v += (1-b2)(g'^2-v);
+ * p -= lr_t * m / (sqrt(v) + eps)  with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller. */
+int unetk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t,
+                    float beta1, float beta2, float eps, float gscale, float l2, void* stream);
+/* tf.train.MomentumOptimizer: acc = mom*acc + g'; p -= lr*acc (nesterov: lr*(g' + mom*acc)). */
+int unetk_momentum_step(float* p, const float* g, float* acc, int64_t n, float lr, float mom,
+                        int nesterov, float gscale, float l2, void* stream);
+/* out[0] = sum(p^2) (fp64 accumulate) -- for the reported regularisation loss. ws >= 8 KiB. */
+int unetk_sumsq(const float* p, int64_t n, float* out, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNETK_H_ */

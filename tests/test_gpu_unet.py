@@ -1,0 +1,197 @@
+"""End-to-end GPU parity: the UNet plugin (HIP kernels) vs the CPU oracle on the same seeded weights
+and inputs -- logits, loss, every gradient, BN moving statistics, a 3-step Adam trajectory, argmax
+masks -- plus size-independent properties at the BASELINE config size."""
+import argparse
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import solver as osolver
+from oracle import unet2d
+
+pytestmark = pytest.mark.gpu
+
+
+def make_args(**over):
+    a = argparse.Namespace(
+        classes=["Liver", "Tumor"], batch_size=2, num_gpus=1, im_height=32, im_width=32, im_channel=3,
+        normalizer="batch_norm", without_norm=False, weight_init="xavier", weight_decay_rate=1e-5, bias_decay=False,
+        loss_type="xentropy", loss_weight_type="numerical", loss_numeric_w=[0.2, 0.4, 4.4], loss_proportion_decay=1000,
+        metrics_train=["Dice", "VOE", "VD"], img_grad=False, tag="test", seed=1234,
+        learning_rate=1e-3, learning_policy="period_step", lr_decay_step=100000, lr_decay_rate=0.1,
+        num_of_total_steps=1000, lr_power=0.9, lr_end=1e-6, lr_decay_boundaries=None, lr_custom_values=None,
+        optimizer="Adam", eval_per_epoch=False)
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+YML = dict(init_channels=64, num_down_samples=4, ret_prob=False, ret_pred=True, build_metrics=True, build_summaries=False)
+
+
+def synth(bs, h, w, ncls, seed=1234):
+    from boxsegliver_amd.data.synthetic import make_batch
+    images, labels, _ = make_batch(bs, h, w, 3, ncls, seed)
+    return images, labels
+
+
+def build(args, images, labels, yml=YML):
+    from boxsegliver_amd.NetworksV2.UNet import UNet
+    model = UNet(args)
+    inputs = {"images": torch.from_numpy(images).cuda(), "labels": torch.from_numpy(labels).cuda()}
+    model(inputs, "eval", **yml)           # creates the variables
+    return model, inputs
+
+
+def oracle_for(args, yml=YML):
+    ncls = len(args.classes) + 1
+    net = unet2d.UNet2DOracle(3, ncls, init_channels=yml["init_channels"], num_down_samples=yml["num_down_samples"])
+    params = unet2d.init_params(net.specs, seed=77)
+    # make BN parameters non-trivial so gamma/beta paths are exercised
+    g = torch.Generator().manual_seed(5)
+    for name, _, kind in net.specs:
+        if kind == "gamma":
+            params[name] = 0.5 + torch.rand(params[name].shape, generator=g)
+        elif kind == "beta":
+            params[name] = 0.2 * torch.randn(params[name].shape, generator=g)
+        elif kind == "bias":
+            params[name] = 0.1 * torch.randn(params[name].shape, generator=g)
+    return net, params
+
+
+def loss_kwargs(args):
+    return dict(loss_type=args.loss_type, loss_weight_type=args.loss_weight_type, numeric_w=args.loss_numeric_w,
+                proportion_decay=args.loss_proportion_decay, weight_decay_rate=args.weight_decay_rate,
+                bias_decay=args.bias_decay)
+
+
+def rel(got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
+@pytest.mark.parametrize("loss_type,w_type", [("xentropy", "numerical"), ("dice", "none"), ("xentropy", "none")])
+def test_unet_loss_logits_grads_match_oracle(loss_type, w_type):
+    args = make_args(loss_type=loss_type, loss_weight_type=w_type)
+    images, labels = synth(2, 32, 32, 3)
+    model, inputs = build(args, images, labels)
+    net, params = oracle_for(args)
+    model.params.load_state(params)
+    total, data_loss, logits, grads, new_stats = net.loss_and_grads(
+        params, torch.from_numpy(images), torch.from_numpy(labels).long(), **loss_kwargs(args))
+
+    model.params.zero_grad()
+    loss = model(inputs, "train", **YML)
+    loss.backward()
+    torch.cuda.synchronize()
+
+    assert abs(loss.item() - total.item()) < 1e-4 * max(1.0, abs(total.item()))
+    got_logits = model.layers["logits"].cpu().numpy()
+    assert np.abs(got_logits - logits.numpy()).max() < 1e-3                   # north-star tolerance
+    assert rel(got_logits, logits.numpy()) < 2e-4
+    # argmax masks: bit-exact wherever the oracle's own top-2 margin is not at rounding level
+    ref_arg = logits.numpy().argmax(-1)
+    srt = np.sort(logits.numpy(), -1)
+    safe = (srt[..., -1] - srt[..., -2]) > 1e-3
+    assert (got_logits.argmax(-1) == ref_arg)[safe].all()
+    assert safe.mean() > 0.98
+    worst = 0.0
+    for name in model.params.trainable_names():
+        g = model.params[name].grad.cpu().numpy()
+        r = rel(g, grads[name].numpy())
+        worst = max(worst, r)
+        assert r < 2e-3, (name, r)
+    # BN moving statistics updated with decay .999 / unbiased variance
+    for name, ref in new_stats.items():
+        np.testing.assert_allclose(model.params[name].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-6)
+    # in-graph metrics on thresholded predictions
+    _, _, mets = net.predictions_and_metrics(logits, torch.from_numpy(labels).long(), model.classes, args.metrics_train)
+    for k, v in mets.items():
+        assert abs(model.metrics_dict[k].item() - v.item()) < 1e-3, k
+
+
+def test_unet_three_step_adam_trajectory_and_eval():
+    args = make_args()
+    images, labels = synth(2, 32, 32, 3)
+    model, inputs = build(args, images, labels)
+    net, params = oracle_for(args)
+    model.params.load_state(params)
+    from boxsegliver_amd.core.solver import Solver
+    solver = Solver(args)
+    # oracle loop: TF-Adam on (data + L2) gradients, BN moving stats carried along
+    p = {k: v.clone() for k, v in params.items()}
+    opt = osolver.TFAdam(0.9, 0.99, 1e-8)
+    ref_losses, got_losses = [], []
+    for step in range(3):
+        total, _, _, grads, new_stats = net.loss_and_grads(p, torch.from_numpy(images), torch.from_numpy(labels).long(),
+                                                           **loss_kwargs(args))
+        ref_losses.append(total.item())
+        pn = {k: p[k].numpy() for k in grads}
+        opt.step(pn, {k: g.numpy() for k, g in grads.items()}, 1e-3)
+        for k, v in new_stats.items():
+            p[k] = v
+        loss = model(inputs, "train", **YML)
+        got_losses.append(loss.item())
+        solver(loss, model)
+    np.testing.assert_allclose(got_losses, ref_losses, rtol=2e-3)
+    assert solver.global_step == 3
+    # eval mode uses the moving statistics and yields probabilities / Pred masks
+    model(inputs, "eval", **YML)
+    lg_eval, _ = net.forward(p, torch.from_numpy(images), False)
+    prob_ref = torch.softmax(lg_eval, -1).numpy()
+    prob = model.probability.cpu().numpy()
+    assert np.abs(prob - prob_ref).max() < 5e-3
+    pred = model.predictions["LiverPred"].cpu().numpy()
+    assert pred.dtype == np.uint8 and pred.shape == (2, 32, 32, 1)
+    np.testing.assert_array_equal(pred[..., 0], (prob[..., 1] > 0.5).astype(np.uint8))
+
+
+def test_unet_two_class_liver_only_config0_shape():
+    # BASELINE configs[0]: liver only (2 classes), bs 2 -- at reduced spatial size for the CPU oracle
+    args = make_args(classes=["Liver"], loss_weight_type="none", loss_numeric_w=None, metrics_train=["Dice"])
+    images, labels = synth(2, 32, 32, 2)
+    model, inputs = build(args, images, labels)
+    net, params = oracle_for(args)
+    model.params.load_state(params)
+    total, _, logits, _, _ = net.loss_and_grads(params, torch.from_numpy(images), torch.from_numpy(labels).long(),
+                                                **loss_kwargs(args))
+    loss = model(inputs, "train", **YML)
+    assert abs(loss.item() - total.item()) < 1e-4
+    assert np.abs(model.layers["logits"].cpu().numpy() - logits.numpy()).max() < 1e-3
+    assert model.params.num_trainable() == 31037698
+
+
+def test_full_size_properties_bs32_256():
+    """BASELINE configs[1] size (bs 32, 256x256x3, 3 classes): too big for the CPU oracle, so check
+    size-independent properties: finite loss near ln(3)-scale, softmax rows sum to 1, Pred == (prob > .5)
+    bit-exactly, run-to-run bit-reproducibility of loss and gradients, and that one Adam step moves
+    the loss."""
+    args = make_args(batch_size=32, im_height=256, im_width=256)
+    images, labels = synth(32, 256, 256, 3)
+    model, inputs = build(args, images, labels)
+    assert model.params.num_trainable() == 31037763
+    yml = dict(YML, ret_prob=True)
+    model.params.zero_grad()
+    loss1 = model(inputs, "train", **yml)
+    loss1.backward()
+    g1 = model.params.grad["reg"].clone()
+    prob = model.probability
+    assert torch.isfinite(loss1)
+    assert (prob.sum(-1) - 1).abs().max().item() < 1e-5
+    assert torch.equal(model.predictions["TumorPred"][..., 0], (prob[..., 2] > 0.5).to(torch.uint8))
+    mm_before = {k: v.clone() for k, v in model.params.tensors.items() if "moving" in k}
+    # undo the moving-stat update so the second run sees identical state
+    model.params.zero_grad()
+    loss2 = model(inputs, "train", **yml)
+    loss2.backward()
+    assert loss1.item() == loss2.item()                         # fixed-order reductions
+    assert torch.equal(g1, model.params.grad["reg"])
+    from boxsegliver_amd.core.solver import Solver
+    solver = Solver(args)
+    for _ in range(3):
+        loss = model(inputs, "train", **yml)
+        solver(loss, model)
+    assert model(inputs, "train", **yml).item() < loss1.item()
+    assert len(mm_before) == 36
