@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""Benchmark of the U-Net hot path on MI355X: CT slices/s for one full training step
+(forward + backward + TF-Adam update [+ RCCL gradient all-reduce when N > 1]) of the 2-D UNet,
+Liver+Tumor, 256x256x3, bs 32 per GPU, fp32 (BASELINE.json configs[1]) on synthetic LiTS-shaped data.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around every launch of
+the conv kernels during the timed region; `cpu_baseline` times the CPU oracle (a restatement, not
+the TensorFlow reference -- TF 1.13 cannot run here) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# SURVEY.md 8d / BASELINE.md 3: conv / deconv / 1x1 FLOPs only, 2 per MAC, bwd = dgrad + wgrad
+GFLOP_PER_SLICE_FWD_BWD = 288.828
+FP32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 matrix (= vector) peak
+METRIC = "CT slices/sec/node (fwd+bwd) UNet 256×256 bs=32; Dice vs ref"
+
+
+def make_args(bs, num_gpus, size):
+    return argparse.Namespace(
+        classes=["Liver", "Tumor"], batch_size=bs * num_gpus, num_gpus=num_gpus, im_height=size, im_width=size,
+        im_channel=3, normalizer="batch_norm", without_norm=False, weight_init="xavier", weight_decay_rate=1e-6,
+        bias_decay=False, loss_type="xentropy", loss_weight_type="numerical", loss_numeric_w=[0.2, 0.4, 4.4],
+        loss_proportion_decay=1000, metrics_train=["Dice"], img_grad=False, tag="bench", seed=1234,
+        learning_rate=1e-3, learning_policy="plateau", lr_decay_step=100000, lr_decay_rate=0.2,
+        num_of_total_steps=600000, lr_power=0.9, lr_end=0.0, lr_decay_boundaries=None, lr_custom_values=None,
+        optimizer="Adam", eval_per_epoch=False, noise_scale=0.05, synthetic_batches=2)
+
+
+YML = dict(init_channels=64, num_down_samples=4, ret_prob=False, ret_pred=True, build_metrics=True,
+           build_summaries=False)
+
+
+def cpu_baseline(size, target_seconds=20.0):
+    """The CPU oracle (PyTorch-CPU restatement of the reference's TF semantics) timed on this host:
+    fwd + bwd + TF-Adam at batch 2 of the same 256x256x3 / 3-class workload."""
+    import numpy as np
+    from boxsegliver_amd.data.synthetic import make_batch
+    from oracle import solver as osolver
+    from oracle import unet2d
+    bs = 2
+    threads = torch.get_num_threads()
+    net = unet2d.UNet2DOracle(3, 3)
+    params = unet2d.init_params(net.specs, seed=1234)
+    images, labels, _ = make_batch(bs, size, size, 3, 3, 1234)
+    images, labels = torch.from_numpy(images), torch.from_numpy(labels).long()
+    opt = osolver.TFAdam(0.9, 0.99, 1e-8)
+    kw = dict(loss_type="xentropy", loss_weight_type="numerical", numeric_w=[0.2, 0.4, 4.4], weight_decay_rate=1e-6)
+
+    def step():
+        _, _, _, grads, stats = net.loss_and_grads(params, images, labels, **kw)
+        opt.step({k: params[k].numpy() for k in grads}, {k: g.numpy() for k, g in grads.items()}, 1e-3)
+        for k, v in stats.items():
+            params[k] = v
+
+    t0 = time.time()
+    step()                                   # warm-up
+    first = time.time() - t0
+    n = max(1, min(5, int(target_seconds / max(first, 1e-3)) - 1))
+    t0 = time.time()
+    for _ in range(n):
+        step()
+    dt = (time.time() - t0) / n
+    return {"value": bs / dt, "unit": "slices/s", "cores": threads, "kind": "port",
+            "sample": "oracle (PyTorch-CPU restatement, not TF): UNet {0}x{0}x3 3-class bs {1}, fwd+bwd+Adam, "
+                      "{2} timed step(s) after 1 warm-up, {3:.2f} s/step, host os.cpu_count()={4}".format(
+                          size, bs, n, dt, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="slices per GPU per step")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP-event timing")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node {} bench.py --gpus {} ..."
+                             .format(a.gpus, a.gpus))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")            # RCCL over xGMI
+
+    from boxsegliver_amd import ops
+    from boxsegliver_amd.NetworksV2.UNet import UNet
+    from boxsegliver_amd.core.solver import Solver
+    from boxsegliver_amd.data.synthetic import input_fn
+    from boxsegliver_amd.utils.distribution_utils import DistributionStrategy
+
+    args = make_args(a.batch, world, a.size)
+    params = {"args": args, "rank": rank, "device": torch.device("cuda", local_rank)}
+    data = input_fn("train", params)
+    model = UNet(args)
+    solver = Solver(args)
+    strategy = DistributionStrategy("mirrored", world, rank) if world > 1 else None
+    solver.strategy = strategy
+    features, labels = next(data)
+    model({"images": features["images"], "labels": labels}, "eval", **YML)        # create variables
+    if strategy is not None:
+        strategy.broadcast_(list(model.params.flat.values()))                      # identical replicas
+
+    def one_step():
+        features, labels = next(data)
+        loss = model({"images": features["images"], "labels": labels}, "train", **YML)
+        solver(loss, model)
+        return loss
+
+    for _ in range(a.warmup):
+        one_step()
+
+    ops.PROFILE = [] if (rank == 0 and not a.no_kernel_events) else None
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ops.PROFILE
+    ops.PROFILE = None
+    loss_val = float(loss)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms = elapsed / a.steps * 1e3
+        slices = a.batch * world * a.steps / elapsed
+        out = {
+            "metric": METRIC, "value": round(slices, 2), "unit": "slices/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "UNet 2D Liver+Tumor {0}x{0}x3 bs={1}/GPU fp32, fwd+bwd+TF-Adam{2} "
+                                   "(BASELINE.json configs[1])".format(a.size, a.batch,
+                                                                       "+RCCL grad all-reduce" if world > 1 else ""),
+                       "global_batch": a.batch * world, "parallelism": "dp{}".format(world), "classes": 3,
+                       "final_loss": round(loss_val, 5)},
+            "whole_step_tflops": round(slices * GFLOP_PER_SLICE_FWD_BWD * (a.size / 256.0) ** 2 / 1e3, 2),
+            "whole_step_frac_of_fp32_peak": round(slices * GFLOP_PER_SLICE_FWD_BWD * (a.size / 256.0) ** 2 / 1e3
+                                                  / (FP32_PEAK_TFLOPS * world), 4),
+        }
+        if prof:
+            agg = {}
+            for tag, flops, e0, e1 in prof:
+                d = agg.setdefault(tag, [0, 0.0, 0.0])
+                d[0] += 1
+                d[1] += flops
+                d[2] += e0.elapsed_time(e1) * 1e-3
+            kern = []
+            for tag, (cnt, flops, secs) in agg.items():
+                kern.append({"kernel": tag, "launches": cnt, "avg_launch_ms": round(secs / cnt * 1e3, 4),
+                             "avg_launch_gflop": round(flops / cnt / 1e9, 3),
+                             "achieved_tflops": round(flops / secs / 1e12, 2), "total_ms_per_step": round(secs / a.steps * 1e3, 3)})
+            kern.sort(key=lambda k: -k["total_ms_per_step"])
+            top = kern[0]
+            out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved_tflops"],
+                               "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(top["achieved_tflops"] / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                               "avg_launch_ms": top["avg_launch_ms"], "avg_launch_gflop": top["avg_launch_gflop"]}
+            out["kernels"] = kern
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(a.size)
+        print(json.dumps(out, ensure_ascii=False), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -69,6 +69,7 @@ class UNet(base.BaseNet):
         self.width = args.im_width
         self.channel = args.im_channel
         self._norm = None
+        self._taps = None           # debug: set to a dict to collect named activations
 
     # ------------------------------------------------------------------ variables
     def _ensure_params(self, device, init_channels, num_down_samples):
@@ -93,9 +94,12 @@ class UNet(base.BaseNet):
         p = self.params
         bn = scope + "/BatchNorm"
         nparams = self._norm[1]
-        return ops.Conv3x3BnRelu.apply(x, p[scope + "/weights"], p[bn + "/gamma"], p[bn + "/beta"],
-                                       p[bn + "/moving_mean"], p[bn + "/moving_variance"],
-                                       bool(nparams["is_training"]), nparams["eps"], nparams["decay"], out)
+        z = ops.Conv3x3BnRelu.apply(x, p[scope + "/weights"], p[bn + "/gamma"], p[bn + "/beta"],
+                                    p[bn + "/moving_mean"], p[bn + "/moving_variance"],
+                                    bool(nparams["is_training"]), nparams["eps"], nparams["decay"], out)
+        if self._taps is not None:
+            self._taps[scope] = z
+        return z
 
     # ------------------------------------------------------------------ network
     def _build_network(self, *args, **kwargs):

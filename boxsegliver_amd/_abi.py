@@ -75,6 +75,10 @@ def lib():
     """Load (once) and return the ctypes handle.  Raises if libunetk.so is absent."""
     global _LIB
     if _LIB is None:
+        # torch must be imported first: it bundles its own libamdhip64.so.7, and libunetk.so has to bind
+        # to THAT runtime (same soname) -- loading /opt/rocm's copy first leaves two HIP runtimes in
+        # the process and the second one sees no device.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise UnetkError(
                 "libunetk.so not found at {} -- run `python -c 'import __graft_entry__ as g; g.build()'` "

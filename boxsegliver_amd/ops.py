@@ -37,6 +37,37 @@ class _Workspace(object):
 
 
 WORKSPACE = _Workspace()
+DEBUG_CAPTURE = None    # tools/: set to a list to record each conv unit's backward operands
+PROFILE = None          # bench.py: set to a list -> (kernel tag, algorithmic FLOPs, start event, end event)
+
+
+class _Timed(object):
+    """HIP events on the CURRENT stream (the one the kernel is launched on) around one C-ABI call."""
+
+    def __init__(self, tag, flops):
+        self.on = PROFILE is not None
+        self.tag, self.flops = tag, flops
+
+    def __enter__(self):
+        if self.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on and exc[0] is None:
+            self.e1.record()
+            PROFILE.append((self.tag, self.flops, self.e0, self.e1))
+        return False
+
+
+def _igemm_tag(cin, cout):
+    if cin % 16 == 0 and cout % 128 == 0:
+        return "conv3x3_igemm_kernel<2,2,2,2>"
+    if cin % 16 == 0 and cout % 64 == 0:
+        return "conv3x3_igemm_kernel<4,1,1,2>"
+    return "conv3x3_direct_kernel"
 
 
 def alias(t, offset_elems=0, size=None, stride=None):
@@ -94,8 +125,9 @@ def conv3x3_fwd(x, w, cout, want_stats=True, y=None):
         if rows <= 0:
             check(rows, "conv3x3_stat_rows")
         stats = torch.empty((2, rows, cout), dtype=torch.float32, device=x.device)
-    check(_abi.lib().unetk_conv3x3_fwd(ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(stats), stream_ptr()),
-          "conv3x3_fwd")
+    with _Timed(_igemm_tag(cin, cout), 18.0 * n * h * wd * cin * cout):
+        check(_abi.lib().unetk_conv3x3_fwd(ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(stats), stream_ptr()),
+              "conv3x3_fwd")
     return y, stats, rows
 
 
@@ -105,8 +137,9 @@ def conv3x3_dgrad(dy, wp_dgrad, cin, x_stride=None, dx=None):
     if dx is None:
         dx = torch.empty((n, h, wd, cin), dtype=torch.float32, device=dy.device)
     d = ConvDesc(n, h, wd, cin, cout, _pix_stride(dx), _pix_stride(dy))
-    check(_abi.lib().unetk_conv3x3_dgrad(ctypes.byref(d), ptr(dy), ptr(wp_dgrad), ptr(dx), stream_ptr()),
-          "conv3x3_dgrad")
+    with _Timed(_igemm_tag(cout, cin), 18.0 * n * h * wd * cin * cout):
+        check(_abi.lib().unetk_conv3x3_dgrad(ctypes.byref(d), ptr(dy), ptr(wp_dgrad), ptr(dx), stream_ptr()),
+              "conv3x3_dgrad")
     return dx
 
 
@@ -120,8 +153,10 @@ def conv3x3_wgrad(x, dy):
         raise _abi.UnetkError("conv3x3_wgrad: unsupported shape Cin={} Cout={}".format(cin, cout))
     ws = WORKSPACE.get(nbytes, x.device)
     dw = torch.empty((3, 3, cin, cout), dtype=torch.float32, device=x.device)
-    check(_abi.lib().unetk_conv3x3_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes, stream_ptr()),
-          "conv3x3_wgrad")
+    tag = "conv3x3_wgrad_kernel(+slab_reduce)" if cin % 64 == 0 else "conv3x3_wgrad_smallc_kernel(+slab_reduce)"
+    with _Timed(tag, 18.0 * n * h * wd * cin * cout):
+        check(_abi.lib().unetk_conv3x3_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes,
+                                             stream_ptr()), "conv3x3_wgrad")
     return dw
 
 
@@ -192,8 +227,9 @@ def deconv2x2_fwd(x, wp_fwd, bias, cat, coff, cout):
     n, h, w, cin = x.shape
     assert x.is_contiguous()
     d = DeconvDesc(n, h, w, cin, cout, _pix_stride(cat), coff)
-    check(_abi.lib().unetk_deconv2x2_fwd(ctypes.byref(d), ptr(x), ptr(wp_fwd), ptr(bias), ptr(cat), stream_ptr()),
-          "deconv2x2_fwd")
+    with _Timed("pw_gemm_kernel<fwd>", 8.0 * n * h * w * cin * cout):
+        check(_abi.lib().unetk_deconv2x2_fwd(ctypes.byref(d), ptr(x), ptr(wp_fwd), ptr(bias), ptr(cat), stream_ptr()),
+              "deconv2x2_fwd")
     return cat
 
 
@@ -208,8 +244,9 @@ def deconv2x2_bwd(x, wp_dgrad, cat, dcat, coff, cout):
     dx = torch.empty_like(x)
     dw = torch.empty((2, 2, cout, cin), dtype=torch.float32, device=x.device)
     db = torch.empty((cout,), dtype=torch.float32, device=x.device)
-    check(_abi.lib().unetk_deconv2x2_bwd(ctypes.byref(d), ptr(x), ptr(wp_dgrad), ptr(cat), ptr(dcat), ptr(dx), ptr(dw),
-                                         ptr(db), ptr(ws), nbytes, stream_ptr()), "deconv2x2_bwd")
+    with _Timed("deconv2x2_bwd(relu_bwd+pw_gemm<dgrad>+deconv_wgrad)", 16.0 * n * h * w * cin * cout):
+        check(_abi.lib().unetk_deconv2x2_bwd(ctypes.byref(d), ptr(x), ptr(wp_dgrad), ptr(cat), ptr(dcat), ptr(dx),
+                                             ptr(dw), ptr(db), ptr(ws), nbytes, stream_ptr()), "deconv2x2_bwd")
     return dx, dw, db
 
 
@@ -307,6 +344,7 @@ class Conv3x3BnRelu(torch.autograd.Function):
             ctx.save_for_backward(x, y, gamma, beta, aff)
             ctx.wp_d = wp_d
             ctx.need_dx = need_dx
+            ctx.w_dbg = w.detach() if DEBUG_CAPTURE is not None else None
         return alias(z) if out is not None else z
 
     @staticmethod
@@ -317,6 +355,9 @@ class Conv3x3BnRelu(torch.autograd.Function):
         dy, dgamma, dbeta = bn_relu_bwd(y, dz, gamma, beta, aff[0], aff[1])
         dw = conv3x3_wgrad(x, dy)
         dx = conv3x3_dgrad(dy, ctx.wp_d, x.shape[3]) if ctx.need_dx else None
+        if DEBUG_CAPTURE is not None:
+            DEBUG_CAPTURE.append(dict(x=x, y=y, gamma=gamma, beta=beta, aff=aff, dz=dz, dy=dy, dw=dw, dx=dx,
+                                      dgamma=dgamma, dbeta=dbeta, w=ctx.w_dbg))
         return dx, dw, dgamma, dbeta, None, None, None, None, None, None
 
 

@@ -67,8 +67,11 @@ def weighted_sparse_softmax_cross_entropy(logits, labels, w_type="none", **kw):
 def sparse_dice_loss(probs, labels, eps=1e-8):
     """loss_metrics.py:180-226 (with_bg=False): 1 - mean_b(2 I_b / (U_b + eps))."""
     ncls = probs.shape[-1]
-    one_hot = F.one_hot(labels, ncls).to(torch.float32)[..., 1:]
-    p = probs.to(torch.float32)[..., 1:]
+    # the reference casts to float32 (:208-209); float64 is kept when the oracle is run in fp64 as
+    # the high-precision yardstick of the parity tests
+    dt = torch.float64 if probs.dtype == torch.float64 else torch.float32
+    one_hot = F.one_hot(labels, ncls).to(dt)[..., 1:]
+    p = probs.to(dt)[..., 1:]
     axes = tuple(range(1, probs.dim()))
     inter = (one_hot * p).sum(dim=axes)
     union = (one_hot + p).sum(dim=axes)
