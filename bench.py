@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP-event timing")
+    ap.add_argument("--detail", action="store_true", help="break the kernel table down by layer shape")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,6 +134,7 @@ def main():
         one_step()
 
     ops.PROFILE = [] if (rank == 0 and not a.no_kernel_events) else None
+    ops.PROFILE_SHAPES = bool(a.detail)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -145,7 +147,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ops.PROFILE
     ops.PROFILE = None
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -38,15 +38,16 @@ class _Workspace(object):
 
 WORKSPACE = _Workspace()
 DEBUG_CAPTURE = None    # tools/: set to a list to record each conv unit's backward operands
+PROFILE_SHAPES = False  # bench.py --detail: one row per (kernel, layer shape)
 PROFILE = None          # bench.py: set to a list -> (kernel tag, algorithmic FLOPs, start event, end event)
 
 
 class _Timed(object):
     """HIP events on the CURRENT stream (the one the kernel is launched on) around one C-ABI call."""
 
-    def __init__(self, tag, flops):
+    def __init__(self, tag, flops, shape=None):
         self.on = PROFILE is not None
-        self.tag, self.flops = tag, flops
+        self.tag, self.flops = (tag if not (PROFILE_SHAPES and shape) else "{} [{}]".format(tag, shape)), flops
 
     def __enter__(self):
         if self.on:
@@ -125,7 +126,7 @@ def conv3x3_fwd(x, w, cout, want_stats=True, y=None):
         if rows <= 0:
             check(rows, "conv3x3_stat_rows")
         stats = torch.empty((2, rows, cout), dtype=torch.float32, device=x.device)
-    with _Timed(_igemm_tag(cin, cout), 18.0 * n * h * wd * cin * cout):
+    with _Timed(_igemm_tag(cin, cout), 18.0 * n * h * wd * cin * cout, "fwd {}x{}x{} {}->{}".format(n, h, wd, cin, cout)):
         check(_abi.lib().unetk_conv3x3_fwd(ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(stats), stream_ptr()),
               "conv3x3_fwd")
     return y, stats, rows
@@ -137,7 +138,7 @@ def conv3x3_dgrad(dy, wp_dgrad, cin, x_stride=None, dx=None):
     if dx is None:
         dx = torch.empty((n, h, wd, cin), dtype=torch.float32, device=dy.device)
     d = ConvDesc(n, h, wd, cin, cout, _pix_stride(dx), _pix_stride(dy))
-    with _Timed(_igemm_tag(cout, cin), 18.0 * n * h * wd * cin * cout):
+    with _Timed(_igemm_tag(cout, cin), 18.0 * n * h * wd * cin * cout, "dgrad {}x{}x{} {}->{}".format(n, h, wd, cout, cin)):
         check(_abi.lib().unetk_conv3x3_dgrad(ctypes.byref(d), ptr(dy), ptr(wp_dgrad), ptr(dx), stream_ptr()),
               "conv3x3_dgrad")
     return dx
@@ -154,7 +155,7 @@ def conv3x3_wgrad(x, dy):
     ws = WORKSPACE.get(nbytes, x.device)
     dw = torch.empty((3, 3, cin, cout), dtype=torch.float32, device=x.device)
     tag = "conv3x3_wgrad_kernel(+slab_reduce)" if cin % 64 == 0 else "conv3x3_wgrad_smallc_kernel(+slab_reduce)"
-    with _Timed(tag, 18.0 * n * h * wd * cin * cout):
+    with _Timed(tag, 18.0 * n * h * wd * cin * cout, "{}x{}x{} {}->{}".format(n, h, wd, cin, cout)):
         check(_abi.lib().unetk_conv3x3_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes,
                                              stream_ptr()), "conv3x3_wgrad")
     return dw
@@ -227,7 +228,7 @@ def deconv2x2_fwd(x, wp_fwd, bias, cat, coff, cout):
     n, h, w, cin = x.shape
     assert x.is_contiguous()
     d = DeconvDesc(n, h, w, cin, cout, _pix_stride(cat), coff)
-    with _Timed("pw_gemm_kernel<fwd>", 8.0 * n * h * w * cin * cout):
+    with _Timed("pw_gemm_kernel<fwd>", 8.0 * n * h * w * cin * cout, "{}x{}x{} {}->{}".format(n, h, w, cin, cout)):
         check(_abi.lib().unetk_deconv2x2_fwd(ctypes.byref(d), ptr(x), ptr(wp_fwd), ptr(bias), ptr(cat), stream_ptr()),
               "deconv2x2_fwd")
     return cat
@@ -244,7 +245,8 @@ def deconv2x2_bwd(x, wp_dgrad, cat, dcat, coff, cout):
     dx = torch.empty_like(x)
     dw = torch.empty((2, 2, cout, cin), dtype=torch.float32, device=x.device)
     db = torch.empty((cout,), dtype=torch.float32, device=x.device)
-    with _Timed("deconv2x2_bwd(relu_bwd+pw_gemm<dgrad>+deconv_wgrad)", 16.0 * n * h * w * cin * cout):
+    with _Timed("deconv2x2_bwd(relu_bwd+pw_gemm<dgrad>+deconv_wgrad)", 16.0 * n * h * w * cin * cout,
+                "{}x{}x{} {}->{}".format(n, h, w, cin, cout)):
         check(_abi.lib().unetk_deconv2x2_bwd(ctypes.byref(d), ptr(x), ptr(wp_dgrad), ptr(cat), ptr(dcat), ptr(dx),
                                              ptr(dw), ptr(db), ptr(ws), nbytes, stream_ptr()), "deconv2x2_bwd")
     return dx, dw, db
