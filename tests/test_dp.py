@@ -1,0 +1,187 @@
+"""Data-parallel path: one process per GPU, gradients of the two flat buffers summed
+with one all-reduce each, 1/N folded into the optimiser, replica-local BN statistics.
+
+* CPU (gloo, world_size 2): the host logic -- DistributionStrategy collectives and
+  Solver.apply_gradients' sum-then-1/N semantics (TF MirroredStrategy: loss x 1/N, gradients summed,
+  core/estimator.py:570-578) with a test double for the HIP Adam kernel.
+* GPU (-m gpu; 2 ranks sharing the one card, gloo over device tensors): a real 2-replica UNet run
+  equals the single-process emulation that applies BN per half-batch (the DP parity definition)."""
+import argparse
+import math
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _solver_args():
+    return argparse.Namespace(
+        learning_rate=1e-3, learning_policy="period_step", lr_decay_step=100000, lr_decay_rate=0.1,
+        num_of_total_steps=1000, lr_power=0.9, lr_end=1e-6, lr_decay_boundaries=None, lr_custom_values=None,
+        optimizer="Adam")
+
+
+class _FakeStore(object):
+    def __init__(self, n):
+        self.flat = {"reg": torch.linspace(-1, 1, n), "noreg": torch.ones(8)}
+        self.grad = {"reg": torch.zeros(n), "noreg": torch.zeros(8)}
+
+
+def _cpu_adam(p, g, m, v, lr_t, b1, b2, eps, gscale=1.0, l2=0.0):
+    gg = g * gscale + l2 * p
+    m += (1 - b1) * (gg - m)
+    v += (1 - b2) * (gg * gg - v)
+    p -= lr_t * m / (v.sqrt() + eps)
+
+
+def _cpu_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from boxsegliver_amd import ops
+    from boxsegliver_amd.core.solver import Solver
+    from boxsegliver_amd.utils.distribution_utils import DistributionStrategy
+    ops.adam_step = _cpu_adam                       # test double for the HIP kernel (no GPU here)
+    strategy = DistributionStrategy("mirrored", world, rank)
+    store = _FakeStore(37)
+    if rank != 0:
+        store.flat["reg"].add_(5.0)                 # replicas start different ...
+    strategy.broadcast_(list(store.flat.values()))  # ... and are made identical
+    solver = Solver(_solver_args())
+    solver.strategy = strategy
+    for step in range(3):
+        gen = torch.Generator().manual_seed(100 * step + rank)
+        store.grad["reg"].copy_(torch.randn(37, generator=gen))
+        store.grad["noreg"].copy_(torch.randn(8, generator=gen))
+        solver.apply_gradients(store, 1e-2, 1e-3)
+    mean_loss = strategy.reduce_mean(torch.tensor(float(rank + 1)))
+    torch.save({"reg": store.flat["reg"], "noreg": store.flat["noreg"], "mean": mean_loss},
+               os.path.join(out_dir, "r{}.pt".format(rank)))
+    dist.destroy_process_group()
+
+
+def test_dp_host_logic_gloo_world2():
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_cpu_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        r = [torch.load(os.path.join(d, "r{}.pt".format(i))) for i in range(world)]
+    assert torch.equal(r[0]["reg"], r[1]["reg"]) and torch.equal(r[0]["noreg"], r[1]["noreg"])
+    assert r[0]["mean"].item() == pytest.approx(1.5)
+    # single-process reference: Adam on the MEAN of the replica gradients
+    p = {"reg": torch.linspace(-1, 1, 37), "noreg": torch.ones(8)}
+    st = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in p.items()}
+    for step in range(3):
+        gs = []
+        for rank in range(world):
+            gen = torch.Generator().manual_seed(100 * step + rank)
+            gs.append((torch.randn(37, generator=gen), torch.randn(8, generator=gen)))
+        t = step + 1
+        lr_t = 1e-3 * math.sqrt(1 - 0.99 ** t) / (1 - 0.9 ** t)
+        _cpu_adam(p["reg"], (gs[0][0] + gs[1][0]) / 2, *st["reg"], lr_t, 0.9, 0.99, 1e-8, 1.0, 1e-2)
+        _cpu_adam(p["noreg"], (gs[0][1] + gs[1][1]) / 2, *st["noreg"], lr_t, 0.9, 0.99, 1e-8, 1.0, 0.0)
+    np.testing.assert_allclose(r[0]["reg"].numpy(), p["reg"].numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(r[0]["noreg"].numpy(), p["noreg"].numpy(), rtol=1e-6, atol=1e-7)
+
+
+# ----------------------------------------------------------------------------------------- GPU
+YML = dict(init_channels=64, num_down_samples=2, ret_prob=False, ret_pred=True, build_metrics=True)
+
+
+def _unet_args(bs, num_gpus):
+    return argparse.Namespace(
+        classes=["Liver", "Tumor"], batch_size=bs, num_gpus=num_gpus, im_height=32, im_width=32, im_channel=3,
+        normalizer="batch_norm", without_norm=False, weight_init="xavier", weight_decay_rate=1e-5, bias_decay=False,
+        loss_type="xentropy", loss_weight_type="numerical", loss_numeric_w=[0.2, 0.4, 4.4], loss_proportion_decay=1000,
+        metrics_train=["Dice"], img_grad=False, tag="dp", seed=4321, **vars(_solver_args()))
+
+
+def _shard(rank):
+    from boxsegliver_amd.data.synthetic import make_batch
+    images, labels, _ = make_batch(2, 32, 32, 3, 3, 900 + rank)
+    return {"images": torch.from_numpy(images).cuda(), "labels": torch.from_numpy(labels).cuda()}
+
+
+def _gpu_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from boxsegliver_amd.NetworksV2.UNet import UNet
+    from boxsegliver_amd.core.solver import Solver
+    from boxsegliver_amd.utils.distribution_utils import DistributionStrategy
+    args = _unet_args(4, world)                      # global batch 4 -> 2 per replica
+    model = UNet(args)
+    assert model.bs == 2
+    inputs = _shard(rank)
+    model(inputs, "eval", **YML)
+    strategy = DistributionStrategy("mirrored", world, rank)
+    if rank != 0:
+        model.params.flat["reg"].mul_(0.5)          # prove the broadcast makes replicas identical
+    strategy.broadcast_(list(model.params.flat.values()))
+    solver = Solver(args)
+    solver.strategy = strategy
+    losses = []
+    for _ in range(2):
+        loss = model(inputs, "train", **YML)
+        losses.append(strategy.reduce_mean(loss.detach()).item())
+        solver(loss, model)
+    torch.cuda.synchronize()
+    torch.save({"flat": {k: v.cpu() for k, v in model.params.flat.items()}, "losses": losses},
+               os.path.join(out_dir, "r{}.pt".format(rank)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_dp_two_replicas_equal_per_chunk_bn_emulation():
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_gpu_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        r = [torch.load(os.path.join(d, "r{}.pt".format(i))) for i in range(world)]
+    for g in ("reg", "noreg"):
+        assert torch.equal(r[0]["flat"][g], r[1]["flat"][g])            # replicas stay in lock-step
+    assert not torch.equal(r[0]["flat"]["stats"], r[1]["flat"]["stats"])  # BN moving stats are replica-local
+    assert r[0]["losses"] == r[1]["losses"]
+
+    # single-process emulation: same initial variables (seed), BN applied per half-batch, mean gradient
+    from boxsegliver_amd.NetworksV2.UNet import UNet
+    from boxsegliver_amd.core.solver import Solver
+    args = _unet_args(2, 1)
+    model = UNet(args)
+    shards = [_shard(0), _shard(1)]
+    model(shards[0], "eval", **YML)
+    solver = Solver(args)
+    emu_losses = []
+    for _ in range(2):
+        grads, losses = [], []
+        stats0 = None
+        for i, sh in enumerate(shards):
+            before = model.params.flat["stats"].clone()
+            model.params.zero_grad()
+            loss = model(sh, "train", **YML)
+            loss.backward()
+            grads.append({k: v.clone() for k, v in model.params.grad.items()})
+            losses.append(loss.item())
+            if i == 0:
+                stats0 = model.params.flat["stats"].clone()     # rank 0's replica-local moving stats
+            model.params.flat["stats"].copy_(before)
+        model.params.flat["stats"].copy_(stats0)
+        for k in model.params.grad:
+            model.params.grad[k].copy_((grads[0][k] + grads[1][k]) * 0.5)
+        lr = solver._get_model_learning_rate()
+        solver.apply_gradients(model.params, args.weight_decay_rate, lr)
+        emu_losses.append(sum(losses) / 2)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(r[0]["losses"], emu_losses, rtol=1e-6)
+    for g in ("reg", "noreg", "stats"):
+        np.testing.assert_allclose(r[0]["flat"][g].numpy(), model.params.flat[g].cpu().numpy(), rtol=2e-5, atol=2e-7)
