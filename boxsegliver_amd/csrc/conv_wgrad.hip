@@ -1,35 +1,44 @@
 // conv3x3 filter gradient (Conv2DBackpropFilter of slim.conv2d(x, C, 3), NetworksV2/UNet.py:79,85,94)
 // as a split-K GEMM on the fp32 matrix cores: dW[tap][ci][co] = sum_pixels x[pixel + tap][ci] * dy[pixel][co].
 //
-// GEMM view: M = ci, N = co, K = pixels.  A block owns a 64(ci) x 64(co) x 9(taps) output panel and
-// walks a contiguous range of 8x16 pixel tiles; per tile it stages the 10x18 x-halo and the 8x16 dy
-// tile in LDS once and ALL NINE taps accumulate from them (each wave: a 32x32 panel for each of the
-// 9 taps = 144 accumulator registers).  Partial panels go to a workspace slab per split; a fixed-order
-// reduction sums the slabs -> bit-reproducible, no atomics (SURVEY.md 7 "wgrad").
+// GEMM view: M = ci, N = co, K = pixels.  A 512-thread block owns a 64(ci) x 64(co) x 9(taps) output
+// panel and walks a contiguous range of 8x16 pixel tiles.  Per tile the 10x18 x-halo and the 8x16 dy tile
+// (77 KB) are brought in by ASYNC direct-to-LDS loads (global_load_lds_dwordx4: no VGPRs, 1 KiB per
+// wave-instruction) into the OTHER half of a 2-stage LDS ring while all eight waves run MFMAs on the
+// current half: one barrier per tile, global latency fully behind 576 MFMAs per wave-pair.  ALL NINE taps
+// accumulate from the one staged halo (9 x 16 accumulator registers per wave); waves 0-3 take pixel rows
+// 0-3 of the tile, waves 4-7 rows 4-7 (two waves per SIMD), and are summed through LDS once at the end.
+// Partial panels go to a workspace slab per split; a fixed-order reduction sums the slabs ->
+// bit-reproducible, no atomics (SURVEY.md 7 "wgrad").
 #include "common.h"
 
 namespace {
 
 constexpr int TW = 16, TH = 8, HWD = TW + 2, HH = TH + 2;
-constexpr int CT = 64;  // channel tile (both ci and co)
+constexpr int CT = 64;                                   // channel tile (both ci and co)
+constexpr int XH_F = HH * HWD * CT;                      // 11520 floats: x halo   [180 pixels][64]
+constexpr int STAGE_F = XH_F + TH * TW * CT;             // 19712 floats: + dy tile [128 pixels][64]
+constexpr int NI_X = HH * HWD / 4;                       // 45 wave-instructions (4 pixels x 256 B each)
+constexpr int NI = NI_X + TH * TW / 4;                   // 77 per tile
+constexpr int IPW = (NI + 7) / 8;                        // 10 per wave
+static_assert(HH * HWD % 4 == 0 && XH_F == NI_X * 256, "halo must be a whole number of 1 KiB pieces");
 
 struct WgParams {
   const float* x;
   const float* dy;
+  const float* zeros;  // >= 256 B of zeros in global memory: source of out-of-image halo pixels
   float* slab;
   int N, H, W, Cin, Cout, xs, ys;
   int tiles_h, tiles_w, total_tiles, tiles_per_split, n_ci_tiles, n_co_tiles;
 };
 
-__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgParams p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xh = smem;                    // [HH*HWD][CT]
-  float* dyt = smem + HH * HWD * CT;   // [TH*TW][CT]
+__global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][STAGE_F]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wci = wave >> 1, wco = wave & 1;
+  const int khalf = wave >> 2, wci = (wave >> 1) & 1, wco = wave & 1;
   const int l31 = lane & 31, h = lane >> 5;
 
   int bid = blockIdx.x;
@@ -37,6 +46,46 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgParams p) {
   const int ci_t = bid % p.n_ci_tiles; bid /= p.n_ci_tiles;
   const int split = bid;
   const int ci0 = ci_t * CT, co0 = co_t * CT;
+
+  // ---- staging geometry: wave w issues pieces j = w + 8 i; lane = (pixel lp of the piece, float4 q)
+  const int lp = lane >> 4, q = lane & 15;
+  int rel_h[IPW], rel_w[IPW];   // pixel position relative to the tile origin
+#pragma unroll
+  for (int i = 0; i < IPW; ++i) {
+    const int j = wave + 8 * i;
+    if (j < NI_X) {
+      const int pix = 4 * j + lp;
+      rel_h[i] = pix / HWD - 1;
+      rel_w[i] = pix % HWD - 1;
+    } else {
+      const int pix = 4 * (j - NI_X) + lp;
+      rel_h[i] = pix >> 4;
+      rel_w[i] = pix & 15;
+    }
+  }
+  const float* zsrc = p.zeros + q * 4;
+
+  auto issue_tile = [&](int tile, int stage) {
+    const int tw_i = tile % p.tiles_w;
+    const int th_i = (tile / p.tiles_w) % p.tiles_h;
+    const int n_img = tile / (p.tiles_w * p.tiles_h);
+    const int h0 = th_i * TH, w0 = tw_i * TW;
+    const int64_t img_base = (int64_t)n_img * p.H;
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+      const int j = wave + 8 * i;
+      if (j < NI) {   // wave-uniform
+        const int gh = h0 + rel_h[i], gw = w0 + rel_w[i];
+        const bool ok = gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+        const int64_t pixoff = (img_base + gh) * p.W + gw;
+        const float* src = (j < NI_X) ? p.x + pixoff * p.xs + ci0 + q * 4 : p.dy + pixoff * p.ys + co0 + q * 4;
+        if (!ok) src = zsrc;
+        float* dst = smem + stage * STAGE_F + j * 256;   // wave-uniform; lanes land at dst + lane*16 B
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    }
+  };
 
   f32x16 acc[9];
 #pragma unroll
@@ -48,37 +97,22 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgParams p) {
   const int t_end = min(t_begin + p.tiles_per_split, p.total_tiles);
   const int a_lane = wci * 32 + l31, b_lane = wco * 32 + l31;
 
-  for (int tile = t_begin; tile < t_end; ++tile) {
-    const int tw_i = tile % p.tiles_w;
-    const int th_i = (tile / p.tiles_w) % p.tiles_h;
-    const int n_img = tile / (p.tiles_w * p.tiles_h);
-    const int h0 = th_i * TH, w0 = tw_i * TW;
-
-    __syncthreads();  // previous tile's fragment reads are done
-    // stage x halo: HH*HWD pixels x 16 float4
-    for (int idx = tid; idx < HH * HWD * (CT / 4); idx += 256) {
-      const int pix = idx >> 4, q = idx & 15;
-      const int hh = pix / HWD, ww = pix - hh * HWD;
-      const int gh = h0 - 1 + hh, gw = w0 - 1 + ww;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gh >= 0 && gh < p.H && gw >= 0 && gw < p.W)
-        v = ldg4(p.x + (((int64_t)n_img * p.H + gh) * p.W + gw) * p.xs + ci0 + q * 4);
-      *reinterpret_cast<float4*>(&xh[pix * CT + q * 4]) = v;
-    }
-    // stage dy tile: TH*TW pixels x 16 float4
-    for (int idx = tid; idx < TH * TW * (CT / 4); idx += 256) {
-      const int pix = idx >> 4, q = idx & 15;
-      const int gh = h0 + (pix >> 4), gw = w0 + (pix & 15);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gh < p.H && gw < p.W)
-        v = ldg4(p.dy + (((int64_t)n_img * p.H + gh) * p.W + gw) * p.ys + co0 + q * 4);
-      *reinterpret_cast<float4*>(&dyt[pix * CT + q * 4]) = v;
-    }
+  if (t_begin < t_end) issue_tile(t_begin, 0);
+  int stage = 0;
+  for (int tile = t_begin; tile < t_end; ++tile, stage ^= 1) {
+    // every wave: its own pieces of this tile have landed; barrier: everybody's have, and all reads of the
+    // other stage (previous tile) are done, so it may be refilled
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (tile + 1 < t_end) issue_tile(tile + 1, stage ^ 1);
 
-    // 64 k-steps; lane half h takes the odd/even column of each pixel pair
-    for (int r = 0; r < TH; ++r) {
-#pragma unroll 4
+    const float* xh = smem + stage * STAGE_F;
+    const float* dyt = xh + XH_F;
+    // this wave's 32 k-steps (rows 4*khalf .. +3); lane half h takes the odd/even column of a pixel pair
+#pragma unroll 1
+    for (int rr = 0; rr < TH / 2; ++rr) {
+      const int r = khalf * (TH / 2) + rr;
+#pragma unroll
       for (int c2 = 0; c2 < TW / 2; ++c2) {
         const int col = 2 * c2 + h;
         const float b = dyt[(r * TW + col) * CT + b_lane];
@@ -94,19 +128,115 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgParams p) {
     }
   }
 
-  // partial panel -> slab[split][tap][ci][co]
-  float* out = p.slab + (int64_t)split * 9 * p.Cin * p.Cout;
+  // ---- sum the two pixel-row halves through LDS (fixed order), then write the slab
+  __syncthreads();
+  float* red = smem;  // [4 wave pairs][144][64 lanes] = 147456 B <= 2 * STAGE_F * 4
+  const int pair = wave & 3;
+  if (khalf == 1) {
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ci = ci0 + wci * 32 + mfma32_row(r, h);
-      out[((int64_t)t * p.Cin + ci) * p.Cout + co0 + b_lane] = acc[t][r];
-    }
+      for (int r = 0; r < 16; ++r) red[(pair * 144 + t * 16 + r) * 64 + lane] = acc[t][r];
+  }
+  __syncthreads();
+  if (khalf == 0) {
+    float* out = p.slab + (int64_t)split * 9 * p.Cin * p.Cout;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + wci * 32 + mfma32_row(r, h);
+        out[((int64_t)t * p.Cin + ci) * p.Cout + co0 + b_lane] = acc[t][r] + red[(pair * 144 + t * 16 + r) * 64 + lane];
+      }
+  }
 }
 
-// Small-Cin filter gradient (Encode1/conv1, Cin = 3): HBM-bound on reading dy once.
-// thread = (co, pixel lane); 9*Cin accumulators per thread; Cin <= 4.
+
+// Small-Cin filter gradient for Cout = 64 and 9*Cin <= 32 (Encode1/conv1: Cin = 3).  HBM-bound on
+// reading dy once (537 MB at cfg1); the 27 x 64 contraction over pixels still goes through the matrix
+// cores (M = (tap, ci) padded to 32, N = co, K = pixels) because the scalar version is VALU-issue bound
+// (27 FMAs + 27 loads per pixel per lane), ~15x off the HBM roofline.
+// 4 waves = (pixel-row half) x (co half); dy tile by direct-to-LDS loads, x halo (Cin floats / pixel).
+__global__ __launch_bounds__(256) void conv3x3_wgrad_c3_kernel(WgParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* dyt = smem;                       // [128 pixels][64]   (32 pieces of 1 KiB)
+  float* xh = smem + TH * TW * CT;         // [180 pixels][4]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int khalf = wave >> 1, wco = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int cin = p.Cin, m_rows = 9 * cin;
+  const int split = blockIdx.x;
+  // A-operand gather: lane row i = (tap, ci)
+  const bool a_on = l31 < m_rows;
+  const int a_tap = a_on ? l31 / cin : 0, a_ci = a_on ? l31 % cin : 0;
+  const int a_off = ((a_tap / 3) * HWD + (a_tap % 3)) * 4 + a_ci;
+  const int lp = lane >> 4, q = lane & 15;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  const int t_begin = split * p.tiles_per_split;
+  const int t_end = min(t_begin + p.tiles_per_split, p.total_tiles);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int tw_i = tile % p.tiles_w;
+    const int th_i = (tile / p.tiles_w) % p.tiles_h;
+    const int n_img = tile / (p.tiles_w * p.tiles_h);
+    const int h0 = th_i * TH, w0 = tw_i * TW;
+    const int64_t img_base = (int64_t)n_img * p.H;
+    __syncthreads();   // previous tile's fragment reads are done
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {          // dy: piece j = wave + 4 i covers pixels 4j .. 4j+3
+      const int j = wave + 4 * i;
+      const int pix = 4 * j + lp;
+      const int gh = h0 + (pix >> 4), gw = w0 + (pix & 15);
+      const float* src = (gh < p.H && gw < p.W) ? p.dy + ((img_base + gh) * p.W + gw) * p.ys + q * 4
+                                                : p.zeros + q * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dyt + j * 256), 16, 0, 0);
+    }
+    for (int idx = tid; idx < HH * HWD * 4; idx += 256) {
+      const int pix = idx >> 2, c = idx & 3;
+      const int gh = h0 - 1 + pix / HWD, gw = w0 - 1 + pix % HWD;
+      float v = 0.f;
+      if (c < cin && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W) v = p.x[((img_base + gh) * p.W + gw) * p.xs + c];
+      xh[idx] = v;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < TH / 2; ++rr) {
+      const int r = khalf * (TH / 2) + rr;
+#pragma unroll
+      for (int c2 = 0; c2 < TW / 2; ++c2) {
+        const int col = 2 * c2 + h;
+        const float b = dyt[(r * TW + col) * CT + wco * 32 + l31];
+        float a = xh[(r * HWD + col) * 4 + a_off];
+        a = a_on ? a : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();
+  float* red = smem;   // [2][16][64]
+  if (khalf == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wco * 16 + r) * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (khalf == 0) {
+    float* out = p.slab + (int64_t)split * m_rows * p.Cout;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = mfma32_row(r, h);
+      if (i < m_rows) out[(int64_t)i * p.Cout + wco * 32 + l31] = acc[r] + red[(wco * 16 + r) * 64 + lane];
+    }
+  }
+}
+
+// Generic small-Cin filter gradient (fallback for Cin = 4 or Cout != 64): thread = (co, pixel lane).
 template <int CIN>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(WgParams p) {
   const int tid = threadIdx.x;
@@ -160,25 +290,50 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(WgParams p) {
 
 }  // namespace
 
-// dst[i] = sum_s slab[s][i], fixed order.  n % 4 == 0.
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, int S, int64_t n, float* __restrict__ dst) {
+// dst[i] = sum_s slab[s * rs][i], fixed order.  n % 4 == 0.
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, int S, int rs, int64_t n, float* __restrict__ dst) {
   const int64_t n4 = n >> 2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = 0; s < S; ++s) {
-      const float4 v = ldg4(slab + (int64_t)s * n + i * 4);
+      const float4 v = ldg4(slab + (int64_t)s * rs * n + i * 4);
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
     stg4(dst + i * 4, a);
   }
 }
 
+// Level 1 for many slabs: row group g = blockIdx.y sums rows [g*chunk, (g+1)*chunk) IN PLACE into row
+// g*chunk (each element is read and then overwritten by the same thread only).
+__global__ void slab_reduce_l1_kernel(float* __restrict__ slab, int S, int chunk, int64_t n) {
+  const int64_t n4 = n >> 2;
+  const int s0 = blockIdx.y * chunk, s1 = min(s0 + chunk, S);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = s0; s < s1; ++s) {
+      const float4 v = ldg4(slab + (int64_t)s * n + i * 4);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    stg4(slab + (int64_t)s0 * n + i * 4, a);
+  }
+}
+
+// NOTE: reduces in place when S > 16 (the slabs are scratch).
 int unetk_launch_slab_reduce(const float* slab, int S, int64_t n, float* dst, hipStream_t st) {
   const int64_t n4 = n >> 2;
   int grid = (int)((n4 + 255) / 256);
   if (grid > 8192) grid = 8192;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, st, slab, S, n, dst);
+  int rs = 1;
+  if (S > 16) {
+    const int chunk = (S + 15) / 16;
+    const int groups = (S + chunk - 1) / chunk;
+    hipLaunchKernelGGL(slab_reduce_l1_kernel, dim3(grid, groups), dim3(256), 0, st, const_cast<float*>(slab), S, chunk, n);
+    UNETK_LAUNCH_CHECK();
+    S = groups;
+    rs = chunk;
+  }
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, st, slab, S, rs, n, dst);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
@@ -200,7 +355,7 @@ WgPlan wg_plan(const unetk_conv_desc* d) {
     pl.n_ci_tiles = d->Cin / CT;
     pl.n_co_tiles = d->Cout / CT;
     const int panels = pl.n_ci_tiles * pl.n_co_tiles;
-    int S = (1024 + panels - 1) / panels;  // ~2 blocks/CU x 256 CUs x 2 rounds
+    int S = (512 + panels - 1) / panels;  // one 512-thread block per CU (155 KB of LDS) x 256 CUs x 2 rounds
     if (S > pl.total_tiles) S = pl.total_tiles;
     if (S < 1) S = 1;
     pl.tiles_per_split = (pl.total_tiles + S - 1) / S;
@@ -223,7 +378,7 @@ extern "C" size_t unetk_conv3x3_wgrad_ws_bytes(const unetk_conv_desc* d) {
   if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return 0;
   const WgPlan pl = wg_plan(d);
   if (pl.mode < 0) return 0;
-  return (size_t)pl.S * 9 * d->Cin * d->Cout * sizeof(float);
+  return 256 + (size_t)pl.S * 9 * d->Cin * d->Cout * sizeof(float);  // 256 B zero page + slabs
 }
 
 extern "C" int unetk_conv3x3_wgrad(const unetk_conv_desc* d, const float* x, const float* dy, float* dw,
@@ -237,13 +392,15 @@ extern "C" int unetk_conv3x3_wgrad(const unetk_conv_desc* d, const float* x, con
   if (ws_bytes < unetk_conv3x3_wgrad_ws_bytes(d)) return UNETK_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   WgParams p{};
-  p.x = x; p.dy = dy; p.slab = (float*)ws;
+  p.x = x; p.dy = dy; p.zeros = (const float*)ws; p.slab = (float*)ws + 64;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.xs = d->x_stride; p.ys = d->y_stride;
   p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.total_tiles = pl.total_tiles;
   p.tiles_per_split = pl.tiles_per_split; p.n_ci_tiles = pl.n_ci_tiles; p.n_co_tiles = pl.n_co_tiles;
   if (pl.mode == 0) {
     UNETK_REQUIRE(d->x_stride % 4 == 0 && d->y_stride % 4 == 0);
-    constexpr size_t lds = (size_t)(HH * HWD + TH * TW) * CT * sizeof(float);  // 78848 B
+    constexpr size_t lds = (size_t)2 * STAGE_F * sizeof(float);  // 157696 B: one block per CU
+    hipError_t ez = hipMemsetAsync(ws, 0, 256, st);
+    if (ez != hipSuccess) return (int)ez;
     static bool attr_done = false;
     if (!attr_done) {
       hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel,
@@ -252,9 +409,17 @@ extern "C" int unetk_conv3x3_wgrad(const unetk_conv_desc* d, const float* x, con
       attr_done = true;
     }
     const int grid = pl.S * pl.n_ci_tiles * pl.n_co_tiles;
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(grid), dim3(512), lds, st, p);
     UNETK_LAUNCH_CHECK();
   } else {
+    hipError_t ez = hipMemsetAsync(ws, 0, 256, st);
+    if (ez != hipSuccess) return (int)ez;
+    if (9 * d->Cin <= 32 && d->Cout == CT && d->y_stride % 4 == 0) {
+      const size_t lds3 = (size_t)(TH * TW * CT + HH * HWD * 4) * sizeof(float);
+      hipLaunchKernelGGL(conv3x3_wgrad_c3_kernel, dim3(pl.S), dim3(256), lds3, st, p);
+      UNETK_LAUNCH_CHECK();
+      return unetk_launch_slab_reduce((const float*)ws + 64, pl.S, (int64_t)9 * d->Cin * d->Cout, dw, st);
+    }
     const int PL = 256 / d->Cout;
     const size_t lds = (size_t)PL * 9 * d->Cin * d->Cout * sizeof(float);
     if (lds > 64 * 1024) return UNETK_E_UNSUPPORTED;
@@ -266,5 +431,5 @@ extern "C" int unetk_conv3x3_wgrad(const unetk_conv_desc* d, const float* x, con
     }
     UNETK_LAUNCH_CHECK();
   }
-  return unetk_launch_slab_reduce((const float*)ws, pl.S, (int64_t)9 * d->Cin * d->Cout, dw, st);
+  return unetk_launch_slab_reduce((const float*)ws + 64, pl.S, (int64_t)9 * d->Cin * d->Cout, dw, st);
 }

@@ -154,7 +154,7 @@ def conv3x3_wgrad(x, dy):
         raise _abi.UnetkError("conv3x3_wgrad: unsupported shape Cin={} Cout={}".format(cin, cout))
     ws = WORKSPACE.get(nbytes, x.device)
     dw = torch.empty((3, 3, cin, cout), dtype=torch.float32, device=x.device)
-    tag = "conv3x3_wgrad_kernel(+slab_reduce)" if cin % 64 == 0 else "conv3x3_wgrad_smallc_kernel(+slab_reduce)"
+    tag = "conv3x3_wgrad_kernel(+slab_reduce)" if cin % 64 == 0 else "conv3x3_wgrad_c3_kernel(+slab_reduce)"
     with _Timed(tag, 18.0 * n * h * wd * cin * cout, "{}x{}x{} {}->{}".format(n, h, wd, cin, cout)):
         check(_abi.lib().unetk_conv3x3_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes,
                                              stream_ptr()), "conv3x3_wgrad")

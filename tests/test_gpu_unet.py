@@ -74,8 +74,8 @@ def rel(got, ref):
 
 @pytest.mark.parametrize("loss_type,w_type", [("xentropy", "numerical"), ("dice", "none"), ("xentropy", "none")])
 def test_unet_loss_logits_grads_match_oracle(loss_type, w_type):
-    args = make_args(loss_type=loss_type, loss_weight_type=w_type)
-    images, labels = synth(2, 32, 32, 3)
+    args = make_args(loss_type=loss_type, loss_weight_type=w_type, im_height=64, im_width=64)
+    images, labels = synth(2, 64, 64, 3)
     model, inputs = build(args, images, labels)
     net, params = oracle_for(args)
     model.params.load_state(params)
@@ -116,7 +116,7 @@ def test_unet_loss_logits_grads_match_oracle(loss_type, w_type):
         worst = max(worst, l2)
         # (the fp32 CPU oracle's own distance to fp64 is the scale: small tensors fed by few pixels,
         # e.g. the 512 deconv biases at 4x4, feel a single flip the most)
-        assert l2 < max(5e-3, 5 * l2_cpu32), (name, l2, l2_cpu32)
+        assert l2 < max(1e-2, 5 * l2_cpu32), (name, l2, l2_cpu32)
         assert l2 < 3e-2 and rel(g, ref) < 1e-1, (name, l2, rel(g, ref))
     # BN moving statistics updated with decay .999 / unbiased variance
     for name, ref in new_stats.items():
