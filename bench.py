@@ -188,6 +188,17 @@ def main():
                                "frac": round(top["achieved_tflops"] / FP32_PEAK_TFLOPS, 4), "traffic": None,
                                "avg_launch_ms": top["avg_launch_ms"], "avg_launch_gflop": top["avg_launch_gflop"]}
             out["kernels"] = kern
+            # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside the
+            # process, so it comes from the committed rocprofv3 --pmc summary of this same command
+            # (profiles/r01_pmc_traffic.json, produced by tools/pmc_summary.py), else null.
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+                key = {k.replace(" ", ""): v for k, v in pmc.items()}.get(top["kernel"].replace(" ", ""))
+                if key and a.size == 256 and a.batch == 32:
+                    out["roofline"]["traffic"] = round(key["hbm_bytes_per_launch_corrected"])
+                    out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE)"
+            except (OSError, KeyError, ValueError):
+                pass
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.size)
         print(json.dumps(out, ensure_ascii=False), flush=True)
