@@ -94,9 +94,9 @@ class UNet(base.BaseNet):
         p = self.params
         bn = scope + "/BatchNorm"
         nparams = self._norm[1]
-        z = ops.Conv3x3BnRelu.apply(x, p[scope + "/weights"], p[bn + "/gamma"], p[bn + "/beta"],
-                                    p[bn + "/moving_mean"], p[bn + "/moving_variance"],
-                                    bool(nparams["is_training"]), nparams["eps"], nparams["decay"], out)
+        spec = ops.NormSpec("batch_norm", nparams["eps"], nparams["decay"], bool(nparams["is_training"]))
+        z = ops.Conv3x3NormRelu.apply(x, p[scope + "/weights"], p[bn + "/gamma"], p[bn + "/beta"],
+                                      p[bn + "/moving_mean"], p[bn + "/moving_variance"], spec, out, None, None, None)
         if self._taps is not None:
             self._taps[scope] = z
         return z

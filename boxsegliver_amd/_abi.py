@@ -26,6 +26,11 @@ class DeconvDesc(Structure):
                 ("out_stride", c_int32), ("out_coff", c_int32)]
 
 
+class NormDesc(Structure):
+    _fields_ = [("N", c_int32), ("HW", c_int32), ("C", c_int32), ("per_sample", c_int32), ("z_stride", c_int32),
+                ("guide_ch", c_int32), ("gw_stride", c_int32), ("gw_coff", c_int32)]
+
+
 class HeadDesc(Structure):
     _fields_ = [("N", c_int32), ("HW", c_int32), ("C", c_int32), ("ncls", c_int32),
                 ("weight_mode", c_int32), ("numeric_w", c_float * UNETK_MAX_CLASSES),
@@ -42,14 +47,15 @@ _SIGNATURES = {
     "unetk_conv3x3_dgrad": (c_int, [POINTER(ConvDesc), P, P, P, P]),
     "unetk_conv3x3_wgrad_ws_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "unetk_conv3x3_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, c_size_t, P]),
-    "unetk_bn_finalize_ws_bytes": (c_size_t, [c_int, c_int]),
-    "unetk_bn_finalize": (c_int, [P, c_int, c_int, c_int64, P, P, c_float, c_float, c_int, P, P, P, P, P, P,
-                                  P, c_size_t, P]),
-    "unetk_affine_relu": (c_int, [P, P, P, P, c_int64, c_int, c_int, P]),
-    "unetk_bn_bwd_ws_bytes": (c_size_t, [c_int64, c_int]),
-    "unetk_bn_relu_bwd": (c_int, [P, P, c_int, P, P, P, P, P, P, P, c_int64, c_int, P, c_size_t, P]),
+    "unetk_norm_finalize_ws_bytes": (c_size_t, [POINTER(NormDesc), c_int]),
+    "unetk_norm_finalize": (c_int, [POINTER(NormDesc), P, c_int, P, P, c_float, c_float, c_int, P, P, P, P, P, P,
+                                    P, c_size_t, P]),
+    "unetk_norm_apply_relu": (c_int, [POINTER(NormDesc), P, P, P, P, P, P, P, P]),
+    "unetk_norm_bwd_ws_bytes": (c_size_t, [POINTER(NormDesc)]),
+    "unetk_norm_relu_bwd": (c_int, [POINTER(NormDesc), P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "unetk_maxpool2_fwd": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, P]),
     "unetk_maxpool2_bwd": (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "unetk_avgpool2_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "unetk_deconv2x2_pack": (c_int, [P, c_int, c_int, P, P, P]),
     "unetk_deconv2x2_fwd": (c_int, [POINTER(DeconvDesc), P, P, P, P, P]),
     "unetk_deconv2x2_bwd_ws_bytes": (c_size_t, [POINTER(DeconvDesc)]),

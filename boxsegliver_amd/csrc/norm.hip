@@ -1,94 +1,58 @@
-// Normalisation, activation and pooling passes around the conv kernels (HBM-bound, float4 NHWC).
+// Normalisation + activation passes around the conv kernels (HBM-bound, float4 NHWC).
 //
-// Replaces slim.batch_norm (NetworksV2/base.py:153-162: eps 1e-3, decay .999, fused) + ReLU that
-// slim.conv2d applies after every 3x3 conv (UNet.py:79,85,94), and slim.max_pool2d (UNet.py:81).
-// The conv epilogue already produced per-tile sum / sum-of-squares partials, so the forward here is
-// one tiny finalise + ONE read-modify-write pass; the backward is two passes over (y, dz).
+// Replaces, after every slim.conv2d(x, C, 3) (NetworksV2/UNet.py:79,85,94; GUNet.py:181-188; UNet3D.py:153,165):
+//   slim.batch_norm    (NetworksV2/base.py:153-162: eps 1e-3, decay .999 / .99 in GUNet's encoder, fused;
+//                       training: batch mean + biased variance, unbiased variance into the moving average)
+//   slim.instance_norm (base.py:163-165: eps 1e-6, moments over the spatial axes per (n, c))
+//   optional centre / scale (GUNet.yml: norm_with_center true, norm_with_scale false, GUNet.py:313-330)
+//   GUNet's spatial modulation  net + sp_params[..., slice]  (GUNet.py:207-212) where sp_params is the
+//     1x1 conv of the pooled guide (GUNet.py:154-156): computed on the fly, never materialised
+//   ReLU
+// The conv epilogue already produced per-tile sum / sum-of-squares partials, so the forward is one tiny
+// finalise + ONE read-modify-write pass; the backward is two passes over (y, dz).
+//
+// One descriptor drives all of them: statistics groups Ns = per_sample ? N : 1, each over P pixels.
 #include "common.h"
 
 namespace {
 
-// ---------------------------------------------------------------- fixed-order row reductions
-// level 1: src[k][rows][C] -> tmp[k][RB][C]; block = 64 channels x 4 row lanes
-__global__ __launch_bounds__(256) void rows_reduce_l1_kernel(const float* __restrict__ src, int rows, int C,
-                                                             int RB, float* __restrict__ tmp) {
-  __shared__ double red[4][64];
-  const int cblocks = (C + 63) / 64;
-  int bid = blockIdx.x;
-  const int cb = bid % cblocks; bid /= cblocks;
-  const int rb = bid % RB;
-  const int k = bid / RB;
-  const int c = cb * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-  const int chunk = (rows + RB - 1) / RB;
-  const int r0 = rb * chunk, r1 = min(r0 + chunk, rows);
-  double s = 0.0;
-  if (c < C)
-    for (int r = r0 + rl; r < r1; r += 4) s += (double)src[((int64_t)k * rows + r) * C + c];
-  red[rl][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (rl == 0 && c < C)
-    tmp[((int64_t)k * RB + rb) * C + c] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+constexpr int MAXG = 4;   // guide channels
+
+struct NormGeom {
+  int Ns;        // statistic groups (1 for batch norm, N for instance norm)
+  int64_t P;     // pixels per group
+  int C, cq_n, rpi;
+};
+
+NormGeom geom(const unetk_norm_desc* d) {
+  NormGeom g;
+  g.Ns = d->per_sample ? d->N : 1;
+  g.P = d->per_sample ? (int64_t)d->HW : (int64_t)d->N * d->HW;
+  g.C = d->C;
+  const ColMap m = unetk_colmap(d->C);
+  g.cq_n = m.cq_n;
+  g.rpi = m.rows_per_iter;
+  return g;
 }
 
-// final: src[k][rows][C] -> dst[k][C]; block = 16 channels x 16 row lanes
-__global__ __launch_bounds__(256) void rows_reduce_final_kernel(const float* __restrict__ src, int rows, int C,
-                                                                float* __restrict__ dst) {
-  __shared__ double red[16][17];
-  const int cblocks = (C + 15) / 16;
-  const int cb = blockIdx.x % cblocks, k = blockIdx.x / cblocks;
-  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int c = cb * 16 + cl;
-  double s = 0.0;
-  if (c < C)
-    for (int r = rl; r < rows; r += 16) s += (double)src[((int64_t)k * rows + r) * C + c];
-  red[rl][cl] = s;
-  __syncthreads();
-  if (rl == 0 && c < C) {
-    double t = 0.0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) t += red[j][cl];
-    dst[(int64_t)k * C + c] = (float)t;
-  }
-}
-
-}  // namespace
-
-size_t unetk_rows_reduce_tmp_floats(int K, int rows, int C) { return rows > 256 ? (size_t)K * 64 * C : 0; }
-
-int unetk_rows_reduce(const float* src, int K, int rows, int C, float* dst, float* tmp, hipStream_t st) {
-  if (rows > 256) {
-    const int RB = 64;
-    const int cblocks = (C + 63) / 64;
-    hipLaunchKernelGGL(rows_reduce_l1_kernel, dim3(cblocks * RB * K), dim3(256), 0, st, src, rows, C, RB, tmp);
-    UNETK_LAUNCH_CHECK();
-    src = tmp;
-    rows = RB;
-  }
-  const int cblocks = (C + 15) / 16;
-  hipLaunchKernelGGL(rows_reduce_final_kernel, dim3(cblocks * K), dim3(256), 0, st, src, rows, C, dst);
-  UNETK_LAUNCH_CHECK();
-  return UNETK_OK;
-}
-
-namespace {
-
-// ---------------------------------------------------------------- BN finalise
-// sums[0][c] = sum y, sums[1][c] = sum y^2 over `count` elements
-__global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, double count, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float eps, float decay, int training,
-                                   float* __restrict__ moving_mean, float* __restrict__ moving_var,
-                                   float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                   float* __restrict__ scale_out, float* __restrict__ shift_out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// sums[0][g][c] = sum y, sums[1][g][c] = sum y^2 over `count` elements of group g
+__global__ void norm_finalize_kernel(const float* __restrict__ sums, int Ns, int C, double count,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                     float decay, int use_moving, int update_moving, float* __restrict__ moving_mean,
+                                     float* __restrict__ moving_var, float* __restrict__ mean_out,
+                                     float* __restrict__ rstd_out, float* __restrict__ scale_out,
+                                     float* __restrict__ shift_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Ns * C) return;
+  const int c = i % C;
   float mean, var;
-  if (training) {
-    const double m = (double)sums[c] / count;
-    double v = (double)sums[C + c] / count - m * m;
+  if (!use_moving) {
+    const double m = (double)sums[i] / count;
+    double v = (double)sums[Ns * C + i] / count - m * m;
     if (v < 0.0) v = 0.0;
     mean = (float)m;
     var = (float)v;
-    if (moving_mean != nullptr) {
+    if (update_moving) {   // batch norm only (Ns == 1)
       const double unbiased = count > 1.0 ? v * (count / (count - 1.0)) : v;
       moving_mean[c] = moving_mean[c] * decay + mean * (1.f - decay);
       moving_var[c] = moving_var[c] * decay + (float)unbiased * (1.f - decay);
@@ -101,279 +65,309 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, double
   const float g = gamma ? gamma[c] : 1.f;
   const float b = beta ? beta[c] : 0.f;
   const float scale = g * rstd;
-  if (mean_out) mean_out[c] = mean;
-  if (rstd_out) rstd_out[c] = rstd;
-  scale_out[c] = scale;
-  shift_out[c] = b - mean * scale;
+  mean_out[i] = mean;
+  rstd_out[i] = rstd;
+  scale_out[i] = scale;
+  shift_out[i] = b - mean * scale;
 }
 
-// ---------------------------------------------------------------- z = relu(y*scale + shift)
-__global__ __launch_bounds__(256) void affine_relu_kernel(const float* __restrict__ y, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, float* __restrict__ z,
-                                                          int64_t npix, int C, int zs, int cq_n, int rpi) {
-  const int cq = threadIdx.x % cq_n, rl = threadIdx.x / cq_n;
-  if (rl >= rpi) return;
-  const float4 sc = ldg4(scale + cq * 4), sh = ldg4(shift + cq * 4);
-  for (int64_t pix = (int64_t)blockIdx.x * rpi + rl; pix < npix; pix += (int64_t)gridDim.x * rpi) {
-    const float4 v = ldg4(y + pix * C + cq * 4);
-    float4 o;
-    o.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
-    o.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-    o.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
-    o.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-    stg4(z + pix * zs + cq * 4, o);
-  }
-}
+struct ApplyArgs {
+  const float* y;
+  const float* scale;   // [Ns][C]
+  const float* shift;
+  const float* guide;   // [N*HW][G] or null
+  const float* gw;      // [G][gw_stride], columns gw_coff ..
+  const float* gb;      // [gw_stride]
+  float* z;
+  int64_t P;
+  int C, zs, cq_n, rpi, gw_stride, gw_coff;
+};
 
-// ---------------------------------------------------------------- BN+ReLU backward
-// pass 1: partial[0][blk][c] = sum du, partial[1][blk][c] = sum du * xhat
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* __restrict__ dz,
-                                                            int dzs, const float* __restrict__ gamma,
-                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            const float* __restrict__ beta, float* __restrict__ partial,
-                                                            int64_t npix, int C, int cq_n, int rpi) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][rpi][C]
-  const int cq = threadIdx.x % cq_n, rl = threadIdx.x / cq_n;
-  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-  if (rl < rpi) {
-    const float4 mu = ldg4(mean + cq * 4), rs = ldg4(rstd + cq * 4), g = ldg4(gamma + cq * 4), b = ldg4(beta + cq * 4);
-    const float4 sc = make_float4(g.x * rs.x, g.y * rs.y, g.z * rs.z, g.w * rs.w);
-    const float4 sh = make_float4(b.x - mu.x * sc.x, b.y - mu.y * sc.y, b.z - mu.z * sc.z, b.w - mu.w * sc.w);
-    for (int64_t pix = (int64_t)blockIdx.x * rpi + rl; pix < npix; pix += (int64_t)gridDim.x * rpi) {
-      const float4 v = ldg4(y + pix * C + cq * 4);
-      const float4 d = ldg4(dz + pix * dzs + cq * 4);
-#define BNR(f)                                                  \
-  {                                                             \
-    const float du = fmaf(v.f, sc.f, sh.f) > 0.f ? d.f : 0.f;   \
-    s1.f += du;                                                 \
-    s2.f += du * ((v.f - mu.f) * rs.f);                         \
+// z = relu(y*scale + shift [+ guide . gw + gb])
+template <int G>
+__global__ __launch_bounds__(256) void norm_apply_relu_kernel(ApplyArgs a) {
+  const int cq = threadIdx.x % a.cq_n, rl = threadIdx.x / a.cq_n;
+  if (rl >= a.rpi) return;
+  const int n = blockIdx.y;
+  const float4 sc = ldg4(a.scale + (int64_t)n * a.C + cq * 4);
+  float4 sh = ldg4(a.shift + (int64_t)n * a.C + cq * 4);
+  float4 gwv[G > 0 ? G : 1];
+  if (G > 0) {
+    const float4 gbv = ldg4(a.gb + a.gw_coff + cq * 4);
+    sh.x += gbv.x; sh.y += gbv.y; sh.z += gbv.z; sh.w += gbv.w;
+#pragma unroll
+    for (int g = 0; g < G; ++g) gwv[g] = ldg4(a.gw + (int64_t)g * a.gw_stride + a.gw_coff + cq * 4);
   }
-      BNR(x) BNR(y) BNR(z) BNR(w)
-#undef BNR
+  const int64_t base = (int64_t)n * a.P;
+  for (int64_t pix = (int64_t)blockIdx.x * a.rpi + rl; pix < a.P; pix += (int64_t)gridDim.x * a.rpi) {
+    const float4 v = ldg4(a.y + (base + pix) * a.C + cq * 4);
+    float4 u;
+    u.x = fmaf(v.x, sc.x, sh.x); u.y = fmaf(v.y, sc.y, sh.y); u.z = fmaf(v.z, sc.z, sh.z); u.w = fmaf(v.w, sc.w, sh.w);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float gg = a.guide[(base + pix) * G + g];
+      u.x = fmaf(gg, gwv[g].x, u.x); u.y = fmaf(gg, gwv[g].y, u.y); u.z = fmaf(gg, gwv[g].z, u.z); u.w = fmaf(gg, gwv[g].w, u.w);
     }
-    stg4(&smem[(0 * rpi + rl) * C + cq * 4], s1);
-    stg4(&smem[(1 * rpi + rl) * C + cq * 4], s2);
+    u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
+    stg4(a.z + (base + pix) * a.zs + cq * 4, u);
+  }
+}
+
+struct BwdArgs {
+  const float* y;
+  const float* dz;
+  const float* scale;   // [Ns][C]
+  const float* shift;
+  const float* mean;
+  const float* rstd;
+  const float* guide;
+  const float* gw;
+  const float* gb;
+  const float* sums;    // [K][Ns][C]   (apply pass)
+  float* partial;       // [K][Ns][nblk][C] (reduce pass)
+  float* dy;
+  int64_t P;
+  int C, dzs, cq_n, rpi, gw_stride, gw_coff, Ns;
+};
+
+// pass 1: partial[0] = sum du, partial[1] = sum du*xhat, partial[2+g] = sum du*guide_g   (du = dz * (u > 0))
+template <int G>
+__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
+  constexpr int K = 2 + G;
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [K][rpi][C]
+  const int cq = threadIdx.x % a.cq_n, rl = threadIdx.x / a.cq_n;
+  const int n = blockIdx.y;
+  float4 s[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) s[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rl < a.rpi) {
+    const int64_t so = (int64_t)n * a.C + cq * 4;
+    const float4 mu = ldg4(a.mean + so), rs = ldg4(a.rstd + so), sc = ldg4(a.scale + so);
+    float4 sh = ldg4(a.shift + so);
+    float4 gwv[G > 0 ? G : 1];
+    if (G > 0) {
+      const float4 gbv = ldg4(a.gb + a.gw_coff + cq * 4);
+      sh.x += gbv.x; sh.y += gbv.y; sh.z += gbv.z; sh.w += gbv.w;
+#pragma unroll
+      for (int g = 0; g < G; ++g) gwv[g] = ldg4(a.gw + (int64_t)g * a.gw_stride + a.gw_coff + cq * 4);
+    }
+    const int64_t base = (int64_t)n * a.P;
+    for (int64_t pix = (int64_t)blockIdx.x * a.rpi + rl; pix < a.P; pix += (int64_t)gridDim.x * a.rpi) {
+      const float4 v = ldg4(a.y + (base + pix) * a.C + cq * 4);
+      const float4 d = ldg4(a.dz + (base + pix) * a.dzs + cq * 4);
+      float4 u;
+      u.x = fmaf(v.x, sc.x, sh.x); u.y = fmaf(v.y, sc.y, sh.y); u.z = fmaf(v.z, sc.z, sh.z); u.w = fmaf(v.w, sc.w, sh.w);
+      float gg[G > 0 ? G : 1];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        gg[g] = a.guide[(base + pix) * G + g];
+        u.x = fmaf(gg[g], gwv[g].x, u.x); u.y = fmaf(gg[g], gwv[g].y, u.y); u.z = fmaf(gg[g], gwv[g].z, u.z); u.w = fmaf(gg[g], gwv[g].w, u.w);
+      }
+#define NBR(f)                                       \
+  {                                                  \
+    const float du = u.f > 0.f ? d.f : 0.f;          \
+    s[0].f += du;                                    \
+    s[1].f += du * ((v.f - mu.f) * rs.f);            \
+    _Pragma("unroll") for (int g = 0; g < G; ++g) s[2 + g].f += du * gg[g]; \
+  }
+      NBR(x) NBR(y) NBR(z) NBR(w)
+#undef NBR
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) stg4(&smem[(k * a.rpi + rl) * a.C + cq * 4], s[k]);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) {
-    const int k = i / C, c = i - k * C;
-    float s = 0.f;
-    for (int j = 0; j < rpi; ++j) s += smem[(k * rpi + j) * C + c];
-    partial[((int64_t)k * gridDim.x + blockIdx.x) * C + c] = s;
+  for (int i = threadIdx.x; i < K * a.C; i += 256) {
+    const int k = i / a.C, c = i - k * a.C;
+    float t = 0.f;
+    for (int j = 0; j < a.rpi; ++j) t += smem[(k * a.rpi + j) * a.C + c];
+    a.partial[(((int64_t)k * a.Ns + n) * gridDim.x + blockIdx.x) * a.C + c] = t;
   }
 }
 
-// pass 2: dy = gamma*rstd * (du - sum_du/M - xhat * sum_du_xhat/M); sums = [2][C]
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ dz,
-                                                           int dzs, const float* __restrict__ gamma,
-                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                           const float* __restrict__ beta, const float* __restrict__ sums,
-                                                           float* __restrict__ dy, int64_t npix, int C, int cq_n, int rpi) {
-  const int cq = threadIdx.x % cq_n, rl = threadIdx.x / cq_n;
-  if (rl >= rpi) return;
-  const float inv_m = 1.0f / (float)npix;
-  const float4 mu = ldg4(mean + cq * 4), rs = ldg4(rstd + cq * 4), g = ldg4(gamma + cq * 4), b = ldg4(beta + cq * 4);
-  const float4 sc = make_float4(g.x * rs.x, g.y * rs.y, g.z * rs.z, g.w * rs.w);
-  const float4 sh = make_float4(b.x - mu.x * sc.x, b.y - mu.y * sc.y, b.z - mu.z * sc.z, b.w - mu.w * sc.w);
-  float4 k1 = ldg4(sums + cq * 4), k2 = ldg4(sums + C + cq * 4);
-  k1.x *= inv_m; k1.y *= inv_m; k1.z *= inv_m; k1.w *= inv_m;
-  k2.x *= inv_m; k2.y *= inv_m; k2.z *= inv_m; k2.w *= inv_m;
-  for (int64_t pix = (int64_t)blockIdx.x * rpi + rl; pix < npix; pix += (int64_t)gridDim.x * rpi) {
-    const float4 v = ldg4(y + pix * C + cq * 4);
-    const float4 d = ldg4(dz + pix * dzs + cq * 4);
-    float4 o;
-#define BNA(f)                                                  \
-  {                                                             \
-    const float du = fmaf(v.f, sc.f, sh.f) > 0.f ? d.f : 0.f;   \
-    const float xh = (v.f - mu.f) * rs.f;                       \
-    o.f = sc.f * (du - k1.f - xh * k2.f);                       \
+// pass 2: dy = scale * (du - sum_du/P - xhat * sum_du_xhat/P)
+template <int G>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdArgs a) {
+  const int cq = threadIdx.x % a.cq_n, rl = threadIdx.x / a.cq_n;
+  if (rl >= a.rpi) return;
+  const int n = blockIdx.y;
+  const float inv_p = 1.0f / (float)a.P;
+  const int64_t so = (int64_t)n * a.C + cq * 4;
+  const float4 mu = ldg4(a.mean + so), rs = ldg4(a.rstd + so), sc = ldg4(a.scale + so);
+  float4 sh = ldg4(a.shift + so);
+  float4 gwv[G > 0 ? G : 1];
+  if (G > 0) {
+    const float4 gbv = ldg4(a.gb + a.gw_coff + cq * 4);
+    sh.x += gbv.x; sh.y += gbv.y; sh.z += gbv.z; sh.w += gbv.w;
+#pragma unroll
+    for (int g = 0; g < G; ++g) gwv[g] = ldg4(a.gw + (int64_t)g * a.gw_stride + a.gw_coff + cq * 4);
   }
-    BNA(x) BNA(y) BNA(z) BNA(w)
-#undef BNA
-    stg4(dy + pix * C + cq * 4, o);
+  float4 k1 = ldg4(a.sums + so), k2 = ldg4(a.sums + (int64_t)a.Ns * a.C + so);
+  k1.x *= inv_p; k1.y *= inv_p; k1.z *= inv_p; k1.w *= inv_p;
+  k2.x *= inv_p; k2.y *= inv_p; k2.z *= inv_p; k2.w *= inv_p;
+  const int64_t base = (int64_t)n * a.P;
+  for (int64_t pix = (int64_t)blockIdx.x * a.rpi + rl; pix < a.P; pix += (int64_t)gridDim.x * a.rpi) {
+    const float4 v = ldg4(a.y + (base + pix) * a.C + cq * 4);
+    const float4 d = ldg4(a.dz + (base + pix) * a.dzs + cq * 4);
+    float4 u, o;
+    u.x = fmaf(v.x, sc.x, sh.x); u.y = fmaf(v.y, sc.y, sh.y); u.z = fmaf(v.z, sc.z, sh.z); u.w = fmaf(v.w, sc.w, sh.w);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float gg = a.guide[(base + pix) * G + g];
+      u.x = fmaf(gg, gwv[g].x, u.x); u.y = fmaf(gg, gwv[g].y, u.y); u.z = fmaf(gg, gwv[g].z, u.z); u.w = fmaf(gg, gwv[g].w, u.w);
+    }
+#define NBA(f)                                          \
+  {                                                     \
+    const float du = u.f > 0.f ? d.f : 0.f;             \
+    const float xh = (v.f - mu.f) * rs.f;               \
+    o.f = sc.f * (du - k1.f - xh * k2.f);               \
+  }
+    NBA(x) NBA(y) NBA(z) NBA(w)
+#undef NBA
+    stg4(a.dy + (base + pix) * a.C + cq * 4, o);
   }
 }
 
-__global__ void bn_bwd_params_kernel(const float* __restrict__ sums, int C, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta) {
+// parameter gradients from psum[k][c] = sum over statistic groups of sums[k][g][c]
+__global__ void norm_bwd_params_kernel(const float* __restrict__ psum, int C, int G, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ dgw, float* __restrict__ dgb) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  dbeta[c] = sums[c];
-  dgamma[c] = sums[C + c];
+  if (dbeta) dbeta[c] = psum[c];
+  if (dgamma) dgamma[c] = psum[C + c];
+  if (dgb) dgb[c] = psum[c];
+  for (int g = 0; g < G; ++g) dgw[(int64_t)g * C + c] = psum[(int64_t)(2 + g) * C + c];
 }
 
-// ---------------------------------------------------------------- max pool 2x2 s2 VALID
-__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, int xs, float* __restrict__ p,
-                                                           int N, int H, int W, int C) {
-  const int Ho = H >> 1, Wo = W >> 1, cq_n = C >> 2;
-  const int64_t total = (int64_t)N * Ho * Wo * cq_n;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int cq = (int)(i % cq_n);
-    int64_t r = i / cq_n;
-    const int wo = (int)(r % Wo); r /= Wo;
-    const int ho = (int)(r % Ho);
-    const int n = (int)(r / Ho);
-    const float* b = x + (((int64_t)n * H + 2 * ho) * W + 2 * wo) * xs + cq * 4;
-    const float4 a0 = ldg4(b), a1 = ldg4(b + xs), a2 = ldg4(b + (int64_t)W * xs), a3 = ldg4(b + (int64_t)W * xs + xs);
-    float4 o;
-    o.x = fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x));
-    o.y = fmaxf(fmaxf(a0.y, a1.y), fmaxf(a2.y, a3.y));
-    o.z = fmaxf(fmaxf(a0.z, a1.z), fmaxf(a2.z, a3.z));
-    o.w = fmaxf(fmaxf(a0.w, a1.w), fmaxf(a2.w, a3.w));
-    stg4(p + i * 4, o);
-  }
+bool norm_desc_ok(const unetk_norm_desc* d) {
+  return d && d->N > 0 && d->HW > 0 && d->C > 0 && d->guide_ch >= 0 && d->guide_ch <= MAXG;
+}
+bool norm_supported(const unetk_norm_desc* d) { return d->C % 4 == 0 && d->C <= 1024; }
+
+int bwd_blocks(const NormGeom& g) {
+  int64_t b = (g.P + g.rpi - 1) / g.rpi;
+  const int64_t cap = g.Ns > 1 ? 64 : UNETK_COL_BLOCKS;
+  if (b > cap) b = cap;
+  return (int)b;
 }
 
-__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ x, int xs, const float* __restrict__ p,
-                                                           const float* __restrict__ dp, float* __restrict__ dx, int N,
-                                                           int H, int W, int C) {
-  const int Ho = H >> 1, Wo = W >> 1, cq_n = C >> 2;
-  const int64_t total = (int64_t)N * Ho * Wo * cq_n;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int cq = (int)(i % cq_n);
-    int64_t r = i / cq_n;
-    const int wo = (int)(r % Wo); r /= Wo;
-    const int ho = (int)(r % Ho);
-    const int n = (int)(r / Ho);
-    const int64_t pix = ((int64_t)n * H + 2 * ho) * W + 2 * wo;
-    const float* b = x + pix * xs + cq * 4;
-    const float4 a0 = ldg4(b), a1 = ldg4(b + xs), a2 = ldg4(b + (int64_t)W * xs);  // 4th is implied
-    const float4 m = ldg4(p + i * 4), g = ldg4(dp + i * 4);
-    float4 o0, o1, o2, o3;
-    // first maximum in window scan order gets the gradient (TF MaxPoolGrad)
-#define MPB(f)                                              \
-  {                                                         \
-    const bool e0 = a0.f == m.f;                            \
-    const bool e1 = !e0 && a1.f == m.f;                     \
-    const bool e2 = !e0 && !e1 && a2.f == m.f;              \
-    const bool e3 = !e0 && !e1 && !e2;                      \
-    o0.f = e0 ? g.f : 0.f;                                  \
-    o1.f = e1 ? g.f : 0.f;                                  \
-    o2.f = e2 ? g.f : 0.f;                                  \
-    o3.f = e3 ? g.f : 0.f;                                  \
+#define G_DISPATCH(G_, CALL) \
+  switch (G_) {              \
+    case 0: { constexpr int GG = 0; CALL; } break; \
+    case 1: { constexpr int GG = 1; CALL; } break; \
+    case 2: { constexpr int GG = 2; CALL; } break; \
+    case 3: { constexpr int GG = 3; CALL; } break; \
+    default: { constexpr int GG = 4; CALL; } break; \
   }
-    MPB(x) MPB(y) MPB(z) MPB(w)
-#undef MPB
-    float* d = dx + pix * C + cq * 4;
-    stg4(d, o0);
-    stg4(d + C, o1);
-    stg4(d + (int64_t)W * C, o2);
-    stg4(d + (int64_t)W * C + C, o3);
-  }
-}
-
-inline int ew_grid(int64_t total_threads) {
-  int64_t g = (total_threads + 255) / 256;
-  if (g > 8192) g = 8192;
-  if (g < 1) g = 1;
-  return (int)g;
-}
 
 }  // namespace
 
-extern "C" size_t unetk_bn_finalize_ws_bytes(int stat_rows, int C) {
-  return (2 * (size_t)C + unetk_rows_reduce_tmp_floats(2, stat_rows, C)) * sizeof(float);
+extern "C" size_t unetk_norm_finalize_ws_bytes(const unetk_norm_desc* d, int stat_rows) {
+  if (!norm_desc_ok(d) || stat_rows <= 0) return 0;
+  const NormGeom g = geom(d);
+  const int rows_per_group = stat_rows / g.Ns;
+  return (2 * (size_t)g.Ns * d->C + unetk_rows_reduce_tmp_floats(2 * g.Ns, rows_per_group, d->C)) * sizeof(float);
 }
 
-extern "C" int unetk_bn_finalize(const float* stat_partials, int stat_rows, int C, int64_t count,
-                                 const float* gamma, const float* beta, float eps, float decay, int training,
-                                 float* moving_mean, float* moving_var, float* mean_out, float* rstd_out,
-                                 float* scale_out, float* shift_out, void* ws, size_t ws_bytes, void* stream) {
-  UNETK_REQUIRE(C > 0 && scale_out && shift_out);
+extern "C" int unetk_norm_finalize(const unetk_norm_desc* d, const float* stat_partials, int stat_rows,
+                                   const float* gamma, const float* beta, float eps, float decay, int training,
+                                   float* moving_mean, float* moving_var, float* mean_out, float* rstd_out,
+                                   float* scale_out, float* shift_out, void* ws, size_t ws_bytes, void* stream) {
+  UNETK_REQUIRE(norm_desc_ok(d) && mean_out && rstd_out && scale_out && shift_out);
   hipStream_t st = (hipStream_t)stream;
+  const NormGeom g = geom(d);
+  const int use_moving = (!d->per_sample && !training) ? 1 : 0;
   float* sums = nullptr;
-  if (training) {
-    UNETK_REQUIRE(stat_partials && stat_rows > 0 && count > 0 && ws);
-    if (ws_bytes < unetk_bn_finalize_ws_bytes(stat_rows, C)) return UNETK_E_WORKSPACE;
+  if (!use_moving) {
+    UNETK_REQUIRE(stat_partials && stat_rows > 0 && ws && stat_rows % g.Ns == 0);
+    if (ws_bytes < unetk_norm_finalize_ws_bytes(d, stat_rows)) return UNETK_E_WORKSPACE;
     sums = (float*)ws;
-    int rc = unetk_rows_reduce(stat_partials, 2, stat_rows, C, sums, sums + 2 * C, st);
+    // partials are [2][stat_rows][C] with each image's tiles contiguous -> [2*Ns][rows_per_group][C]
+    int rc = unetk_rows_reduce(stat_partials, 2 * g.Ns, stat_rows / g.Ns, d->C, sums, sums + 2 * g.Ns * d->C, st);
     if (rc != UNETK_OK) return rc;
   } else {
     UNETK_REQUIRE(moving_mean && moving_var);
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, (double)count, gamma,
-                     beta, eps, decay, training, moving_mean, moving_var, mean_out, rstd_out, scale_out, shift_out);
+  const int update_moving = (!d->per_sample && training && moving_mean && moving_var) ? 1 : 0;
+  const int total = g.Ns * d->C;
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sums, g.Ns, d->C, (double)g.P,
+                     gamma, beta, eps, decay, use_moving, update_moving, moving_mean, moving_var, mean_out, rstd_out,
+                     scale_out, shift_out);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
 
-extern "C" int unetk_affine_relu(const float* y, const float* scale, const float* shift, float* z, int64_t npix,
-                                 int C, int z_stride, void* stream) {
-  UNETK_REQUIRE(y && scale && shift && z && npix > 0 && C > 0 && z_stride >= C);
-  if (C % 4 != 0 || C > 1024 || z_stride % 4 != 0) return UNETK_E_UNSUPPORTED;
+extern "C" int unetk_norm_apply_relu(const unetk_norm_desc* d, const float* y, const float* scale, const float* shift,
+                                     const float* guide, const float* gw, const float* gb, float* z, void* stream) {
+  UNETK_REQUIRE(norm_desc_ok(d) && y && scale && shift && z && d->z_stride >= d->C);
+  if (!norm_supported(d) || d->z_stride % 4 != 0) return UNETK_E_UNSUPPORTED;
   UNETK_REQUIRE(unetk_aligned16(y) && unetk_aligned16(z) && unetk_aligned16(scale) && unetk_aligned16(shift));
-  const ColMap m = unetk_colmap(C);
-  int64_t g = (npix + m.rows_per_iter - 1) / m.rows_per_iter;
-  if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(affine_relu_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, y, scale, shift, z, npix, C,
-                     z_stride, m.cq_n, m.rows_per_iter);
+  if (d->guide_ch > 0) {
+    UNETK_REQUIRE(guide && gw && gb && d->gw_stride >= d->gw_coff + d->C);
+    UNETK_REQUIRE(d->gw_stride % 4 == 0 && d->gw_coff % 4 == 0 && unetk_aligned16(gw) && unetk_aligned16(gb));
+  }
+  const NormGeom g = geom(d);
+  ApplyArgs a{y, scale, shift, guide, gw, gb, z, g.P, d->C, d->z_stride, g.cq_n, g.rpi, d->gw_stride, d->gw_coff};
+  int64_t gx = (g.P + g.rpi - 1) / g.rpi;
+  const int64_t cap = g.Ns > 1 ? (4096 + g.Ns - 1) / g.Ns : 4096;
+  if (gx > cap) gx = cap;
+  G_DISPATCH(d->guide_ch, hipLaunchKernelGGL(norm_apply_relu_kernel<GG>, dim3((int)gx, g.Ns), dim3(256), 0,
+                                             (hipStream_t)stream, a));
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
 
-static int bn_bwd_blocks(int64_t npix, int C) {
-  const ColMap m = unetk_colmap(C);
-  int64_t g = (npix + m.rows_per_iter - 1) / m.rows_per_iter;
-  if (g > UNETK_COL_BLOCKS) g = UNETK_COL_BLOCKS;
-  return (int)g;
+extern "C" size_t unetk_norm_bwd_ws_bytes(const unetk_norm_desc* d) {
+  if (!norm_desc_ok(d) || !norm_supported(d)) return 0;
+  const NormGeom g = geom(d);
+  const int K = 2 + d->guide_ch;
+  const int nblk = bwd_blocks(g);
+  size_t f = (size_t)K * g.Ns * nblk * d->C;                         // partials
+  f += (size_t)K * g.Ns * d->C;                                      // sums per group
+  f += (size_t)K * d->C;                                             // sums over groups
+  f += unetk_rows_reduce_tmp_floats(K * g.Ns, nblk, d->C);
+  f += unetk_rows_reduce_tmp_floats(K, g.Ns, d->C);
+  return f * sizeof(float);
 }
 
-extern "C" size_t unetk_bn_bwd_ws_bytes(int64_t npix, int C) {
-  if (npix <= 0 || C <= 0 || C % 4 != 0 || C > 1024) return 0;
-  const int nblk = bn_bwd_blocks(npix, C);
-  return ((size_t)2 * nblk * C + 2 * (size_t)C + unetk_rows_reduce_tmp_floats(2, nblk, C)) * sizeof(float);
-}
-
-extern "C" int unetk_bn_relu_bwd(const float* y, const float* dz, int dz_stride, const float* gamma,
-                                 const float* mean, const float* rstd, const float* beta, float* dy, float* dgamma,
-                                 float* dbeta, int64_t npix, int C, void* ws, size_t ws_bytes, void* stream) {
-  UNETK_REQUIRE(y && dz && gamma && mean && rstd && beta && dy && dgamma && dbeta && ws);
-  UNETK_REQUIRE(npix > 0 && C > 0 && dz_stride >= C);
-  if (C % 4 != 0 || C > 1024 || dz_stride % 4 != 0) return UNETK_E_UNSUPPORTED;
+extern "C" int unetk_norm_relu_bwd(const unetk_norm_desc* d, const float* y, const float* dz, int dz_stride,
+                                   const float* scale, const float* shift, const float* mean, const float* rstd,
+                                   const float* guide, const float* gw, const float* gb, float* dy, float* dgamma,
+                                   float* dbeta, float* dgw, float* dgb, void* ws, size_t ws_bytes, void* stream) {
+  UNETK_REQUIRE(norm_desc_ok(d) && y && dz && scale && shift && mean && rstd && dy && ws && dz_stride >= d->C);
+  if (!norm_supported(d) || dz_stride % 4 != 0) return UNETK_E_UNSUPPORTED;
   UNETK_REQUIRE(unetk_aligned16(y) && unetk_aligned16(dz) && unetk_aligned16(dy) && unetk_aligned16(ws));
-  if (ws_bytes < unetk_bn_bwd_ws_bytes(npix, C)) return UNETK_E_WORKSPACE;
+  const int G = d->guide_ch;
+  if (G > 0) {
+    UNETK_REQUIRE(guide && gw && gb && dgw && dgb && d->gw_stride >= d->gw_coff + d->C);
+    UNETK_REQUIRE(d->gw_stride % 4 == 0 && d->gw_coff % 4 == 0 && unetk_aligned16(gw) && unetk_aligned16(gb));
+  }
+  if (ws_bytes < unetk_norm_bwd_ws_bytes(d)) return UNETK_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  const ColMap m = unetk_colmap(C);
-  const int nblk = bn_bwd_blocks(npix, C);
+  const NormGeom g = geom(d);
+  const int K = 2 + G;
+  const int nblk = bwd_blocks(g);
   float* partial = (float*)ws;
-  float* sums = partial + (size_t)2 * nblk * C;
-  float* tmp = sums + 2 * C;
-  const size_t lds = (size_t)2 * m.rows_per_iter * C * sizeof(float);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), lds, st, y, dz, dz_stride, gamma, mean, rstd, beta,
-                     partial, npix, C, m.cq_n, m.rows_per_iter);
+  float* sums = partial + (size_t)K * g.Ns * nblk * d->C;
+  float* psum = sums + (size_t)K * g.Ns * d->C;
+  float* tmp1 = psum + (size_t)K * d->C;
+  float* tmp2 = tmp1 + unetk_rows_reduce_tmp_floats(K * g.Ns, nblk, d->C);
+  BwdArgs a{y, dz, scale, shift, mean, rstd, guide, gw, gb, sums, partial, dy, g.P, d->C, dz_stride, g.cq_n, g.rpi,
+            d->gw_stride, d->gw_coff, g.Ns};
+  const size_t lds = (size_t)K * g.rpi * d->C * sizeof(float);
+  G_DISPATCH(G, hipLaunchKernelGGL(norm_bwd_reduce_kernel<GG>, dim3(nblk, g.Ns), dim3(256), lds, st, a));
   UNETK_LAUNCH_CHECK();
-  int rc = unetk_rows_reduce(partial, 2, nblk, C, sums, tmp, st);
+  int rc = unetk_rows_reduce(partial, K * g.Ns, nblk, d->C, sums, tmp1, st);   // -> sums[K][Ns][C]
   if (rc != UNETK_OK) return rc;
-  hipLaunchKernelGGL(bn_bwd_params_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, dgamma, dbeta);
+  rc = unetk_rows_reduce(sums, K, g.Ns, d->C, psum, tmp2, st);                 // -> psum[K][C]
+  if (rc != UNETK_OK) return rc;
+  hipLaunchKernelGGL(norm_bwd_params_kernel, dim3((d->C + 255) / 256), dim3(256), 0, st, psum, d->C, G, dgamma, dbeta,
+                     dgw, dgb);
   UNETK_LAUNCH_CHECK();
-  int64_t g = (npix + m.rows_per_iter - 1) / m.rows_per_iter;
-  if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((int)g), dim3(256), 0, st, y, dz, dz_stride, gamma, mean, rstd, beta,
-                     sums, dy, npix, C, m.cq_n, m.rows_per_iter);
-  UNETK_LAUNCH_CHECK();
-  return UNETK_OK;
-}
-
-extern "C" int unetk_maxpool2_fwd(const float* x, int x_stride, float* p, int N, int H, int W, int C,
-                                  void* stream) {
-  UNETK_REQUIRE(x && p && N > 0 && H > 1 && W > 1 && C > 0 && x_stride >= C);
-  if (C % 4 != 0 || x_stride % 4 != 0) return UNETK_E_UNSUPPORTED;
-  UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(p));
-  const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_stride, p, N,
-                     H, W, C);
-  UNETK_LAUNCH_CHECK();
-  return UNETK_OK;
-}
-
-extern "C" int unetk_maxpool2_bwd(const float* x, int x_stride, const float* p, const float* dp, float* dx, int N,
-                                  int H, int W, int C, void* stream) {
-  UNETK_REQUIRE(x && p && dp && dx && N > 0 && H > 1 && W > 1 && C > 0 && x_stride >= C);
-  if (C % 4 != 0 || x_stride % 4 != 0 || (H & 1) || (W & 1)) return UNETK_E_UNSUPPORTED;
-  UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(p) && unetk_aligned16(dp) && unetk_aligned16(dx));
-  const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_stride, p, dp,
-                     dx, N, H, W, C);
+  int64_t gx = (g.P + g.rpi - 1) / g.rpi;
+  const int64_t cap = g.Ns > 1 ? (4096 + g.Ns - 1) / g.Ns : 4096;
+  if (gx > cap) gx = cap;
+  G_DISPATCH(G, hipLaunchKernelGGL(norm_bwd_apply_kernel<GG>, dim3((int)gx, g.Ns), dim3(256), 0, st, a));
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }

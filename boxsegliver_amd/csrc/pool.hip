@@ -1,0 +1,124 @@
+// 2x2 pooling (HBM-bound, float4 NHWC).  slim.max_pool2d(x, [2,2]) at NetworksV2/UNet.py:81 (VALID; GUNet
+// sets SAME, identical for even sizes, GUNet.py:249-250) and slim.avg_pool2d(gs, 2) of GUNet's spatial-guide
+// pyramid (GUNet.py:155-158).
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- max pool 2x2 s2 VALID
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, int xs, float* __restrict__ p,
+                                                           int N, int H, int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1, cq_n = C >> 2;
+  const int64_t total = (int64_t)N * Ho * Wo * cq_n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % cq_n);
+    int64_t r = i / cq_n;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const float* b = x + (((int64_t)n * H + 2 * ho) * W + 2 * wo) * xs + cq * 4;
+    const float4 a0 = ldg4(b), a1 = ldg4(b + xs), a2 = ldg4(b + (int64_t)W * xs), a3 = ldg4(b + (int64_t)W * xs + xs);
+    float4 o;
+    o.x = fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x));
+    o.y = fmaxf(fmaxf(a0.y, a1.y), fmaxf(a2.y, a3.y));
+    o.z = fmaxf(fmaxf(a0.z, a1.z), fmaxf(a2.z, a3.z));
+    o.w = fmaxf(fmaxf(a0.w, a1.w), fmaxf(a2.w, a3.w));
+    stg4(p + i * 4, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ x, int xs, const float* __restrict__ p,
+                                                           const float* __restrict__ dp, float* __restrict__ dx, int N,
+                                                           int H, int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1, cq_n = C >> 2;
+  const int64_t total = (int64_t)N * Ho * Wo * cq_n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % cq_n);
+    int64_t r = i / cq_n;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const int64_t pix = ((int64_t)n * H + 2 * ho) * W + 2 * wo;
+    const float* b = x + pix * xs + cq * 4;
+    const float4 a0 = ldg4(b), a1 = ldg4(b + xs), a2 = ldg4(b + (int64_t)W * xs);  // 4th is implied
+    const float4 m = ldg4(p + i * 4), g = ldg4(dp + i * 4);
+    float4 o0, o1, o2, o3;
+    // first maximum in window scan order gets the gradient (TF MaxPoolGrad)
+#define MPB(f)                                              \
+  {                                                         \
+    const bool e0 = a0.f == m.f;                            \
+    const bool e1 = !e0 && a1.f == m.f;                     \
+    const bool e2 = !e0 && !e1 && a2.f == m.f;              \
+    const bool e3 = !e0 && !e1 && !e2;                      \
+    o0.f = e0 ? g.f : 0.f;                                  \
+    o1.f = e1 ? g.f : 0.f;                                  \
+    o2.f = e2 ? g.f : 0.f;                                  \
+    o3.f = e3 ? g.f : 0.f;                                  \
+  }
+    MPB(x) MPB(y) MPB(z) MPB(w)
+#undef MPB
+    float* d = dx + pix * C + cq * 4;
+    stg4(d, o0);
+    stg4(d + C, o1);
+    stg4(d + (int64_t)W * C, o2);
+    stg4(d + (int64_t)W * C + C, o3);
+  }
+}
+
+inline int ew_grid(int64_t total_threads) {
+  int64_t g = (total_threads + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+
+// guide pyramid: few channels (g = 1..2), not float4-able -> scalar kernel; SAME == VALID for even sizes
+__global__ void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ p, int N, int H, int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const int64_t total = (int64_t)N * Ho * Wo * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const float* b = x + (((int64_t)n * H + 2 * ho) * W + 2 * wo) * C + c;
+    p[i] = 0.25f * (b[0] + b[C] + b[(int64_t)W * C] + b[(int64_t)W * C + C]);
+  }
+}
+
+}  // namespace
+
+extern "C" int unetk_maxpool2_fwd(const float* x, int x_stride, float* p, int N, int H, int W, int C,
+                                  void* stream) {
+  UNETK_REQUIRE(x && p && N > 0 && H > 1 && W > 1 && C > 0 && x_stride >= C);
+  if (C % 4 != 0 || x_stride % 4 != 0) return UNETK_E_UNSUPPORTED;
+  UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(p));
+  const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_stride, p, N,
+                     H, W, C);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+extern "C" int unetk_maxpool2_bwd(const float* x, int x_stride, const float* p, const float* dp, float* dx, int N,
+                                  int H, int W, int C, void* stream) {
+  UNETK_REQUIRE(x && p && dp && dx && N > 0 && H > 1 && W > 1 && C > 0 && x_stride >= C);
+  if (C % 4 != 0 || x_stride % 4 != 0 || (H & 1) || (W & 1)) return UNETK_E_UNSUPPORTED;
+  UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(p) && unetk_aligned16(dp) && unetk_aligned16(dx));
+  const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_stride, p, dp,
+                     dx, N, H, W, C);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+extern "C" int unetk_avgpool2_fwd(const float* x, float* p, int N, int H, int W, int C, void* stream) {
+  UNETK_REQUIRE(x && p && N > 0 && H > 1 && W > 1 && C > 0);
+  if ((H & 1) || (W & 1)) return UNETK_E_UNSUPPORTED;
+  const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
+  hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, p, N, H, W, C);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}

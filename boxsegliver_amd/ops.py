@@ -16,7 +16,7 @@ import ctypes
 import torch
 
 from . import _abi
-from ._abi import ConvDesc, DeconvDesc, HeadDesc, check, ptr, stream_ptr
+from ._abi import ConvDesc, DeconvDesc, HeadDesc, NormDesc, check, ptr, stream_ptr
 
 
 # ----------------------------------------------------------------------------- memory helpers
@@ -161,41 +161,58 @@ def conv3x3_wgrad(x, dy):
     return dw
 
 
-def bn_finalize(stats, rows, count, gamma, beta, eps, decay, training, moving_mean, moving_var):
-    c = gamma.numel()
-    dev = gamma.device
-    out = torch.empty((4, c), dtype=torch.float32, device=dev)   # mean, rstd, scale, shift
-    nbytes = _abi.lib().unetk_bn_finalize_ws_bytes(max(rows, 1), c)
-    ws = WORKSPACE.get(nbytes, dev)
-    check(_abi.lib().unetk_bn_finalize(ptr(stats), rows, c, count, ptr(gamma), ptr(beta), eps, decay,
-                                       1 if training else 0, ptr(moving_mean), ptr(moving_var),
-                                       ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(ws), nbytes,
-                                       stream_ptr()), "bn_finalize")
+def norm_desc(y_shape, per_sample, z_stride=None, guide_ch=0, gw_stride=0, gw_coff=0):
+    n, c = y_shape[0], y_shape[-1]
+    hw = 1
+    for s in y_shape[1:-1]:
+        hw *= s
+    return NormDesc(n, hw, c, 1 if per_sample else 0, z_stride if z_stride is not None else c, guide_ch,
+                    gw_stride, gw_coff)
+
+
+def norm_finalize(d, stats, rows, gamma, beta, eps, decay, training, moving_mean, moving_var, device):
+    groups = d.N if d.per_sample else 1
+    out = torch.empty((4, groups, d.C), dtype=torch.float32, device=device)   # mean, rstd, scale, shift
+    nbytes = _abi.lib().unetk_norm_finalize_ws_bytes(ctypes.byref(d), max(rows, groups))
+    ws = WORKSPACE.get(nbytes, device)
+    check(_abi.lib().unetk_norm_finalize(ctypes.byref(d), ptr(stats), rows, ptr(gamma), ptr(beta), eps, decay,
+                                         1 if training else 0, ptr(moving_mean), ptr(moving_var), ptr(out[0]),
+                                         ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(ws), nbytes, stream_ptr()),
+          "norm_finalize")
     return out
 
 
-def affine_relu(y, scale, shift, z):
-    npix = y.shape[0] * y.shape[1] * y.shape[2]
-    c = y.shape[3]
+def norm_apply_relu(d, y, aff, z, guide=None, gw=None, gb=None):
     assert y.is_contiguous()
-    check(_abi.lib().unetk_affine_relu(ptr(y), ptr(scale), ptr(shift), ptr(z), npix, c, _pix_stride(z),
-                                       stream_ptr()), "affine_relu")
+    check(_abi.lib().unetk_norm_apply_relu(ctypes.byref(d), ptr(y), ptr(aff[2]), ptr(aff[3]), ptr(guide), ptr(gw),
+                                           ptr(gb), ptr(z), stream_ptr()), "norm_apply_relu")
     return z
 
 
-def bn_relu_bwd(y, dz, gamma, beta, mean, rstd):
-    npix = y.shape[0] * y.shape[1] * y.shape[2]
-    c = y.shape[3]
+def norm_relu_bwd(d, y, dz, aff, has_gamma, has_beta, guide=None, gw=None, gb=None):
+    dev = y.device
     dy = torch.empty_like(y)
-    dgb = torch.empty((2, c), dtype=torch.float32, device=y.device)
-    nbytes = _abi.lib().unetk_bn_bwd_ws_bytes(npix, c)
+    dgamma = torch.empty((d.C,), dtype=torch.float32, device=dev) if has_gamma else None
+    dbeta = torch.empty((d.C,), dtype=torch.float32, device=dev) if has_beta else None
+    dgw = torch.empty((d.guide_ch, d.C), dtype=torch.float32, device=dev) if d.guide_ch else None
+    dgb = torch.empty((d.C,), dtype=torch.float32, device=dev) if d.guide_ch else None
+    nbytes = _abi.lib().unetk_norm_bwd_ws_bytes(ctypes.byref(d))
     if nbytes == 0:
-        raise _abi.UnetkError("bn_relu_bwd: unsupported channel count {}".format(c))
-    ws = WORKSPACE.get(nbytes, y.device)
-    check(_abi.lib().unetk_bn_relu_bwd(ptr(y), ptr(dz), _pix_stride(dz), ptr(gamma), ptr(mean), ptr(rstd), ptr(beta),
-                                       ptr(dy), ptr(dgb[0]), ptr(dgb[1]), npix, c, ptr(ws), nbytes, stream_ptr()),
-          "bn_relu_bwd")
-    return dy, dgb[0], dgb[1]
+        raise _abi.UnetkError("norm_relu_bwd: unsupported channel count {}".format(d.C))
+    ws = WORKSPACE.get(nbytes, dev)
+    check(_abi.lib().unetk_norm_relu_bwd(ctypes.byref(d), ptr(y), ptr(dz), _pix_stride(dz), ptr(aff[2]), ptr(aff[3]),
+                                         ptr(aff[0]), ptr(aff[1]), ptr(guide), ptr(gw), ptr(gb), ptr(dy), ptr(dgamma),
+                                         ptr(dbeta), ptr(dgw), ptr(dgb), ptr(ws), nbytes, stream_ptr()),
+          "norm_relu_bwd")
+    return dy, dgamma, dbeta, dgw, dgb
+
+
+def avgpool2_fwd(x):
+    _require_cuda(x)
+    n, h, w, c = x.shape
+    p = torch.empty((n, h // 2, w // 2, c), dtype=torch.float32, device=x.device)
+    check(_abi.lib().unetk_avgpool2_fwd(ptr(x.contiguous()), ptr(p), n, h, w, c, stream_ptr()), "avgpool2_fwd")
+    return p
 
 
 def maxpool2_fwd(x):
@@ -320,13 +337,26 @@ def sumsq(p):
 
 
 # ----------------------------------------------------------------------------- autograd nodes
-class Conv3x3BnRelu(torch.autograd.Function):
-    """z = relu(batch_norm(conv3x3(x, w))) -- one slim.conv2d(x, C, 3) unit under UNet._net_arg_scope
-    (NetworksV2/UNet.py:41-56,79): conv without bias, slim.batch_norm(scale=True), ReLU."""
+class NormSpec(object):
+    """How a conv unit is normalised (the slim arg_scope state around slim.conv2d)."""
+
+    def __init__(self, kind="batch_norm", eps=1e-3, decay=0.999, training=True):
+        assert kind in ("batch_norm", "instance_norm")
+        self.kind, self.eps, self.decay, self.training = kind, eps, decay, training
+
+    @property
+    def per_sample(self):
+        return self.kind == "instance_norm"
+
+
+class Conv3x3NormRelu(torch.autograd.Function):
+    """z = relu(norm(conv3x3(x, w)) [+ spatial guide modulation]) -- one slim.conv2d(x, C, 3) unit:
+    conv without bias, slim.batch_norm / slim.instance_norm with optional centre (beta) and scale (gamma),
+    ReLU (NetworksV2/UNet.py:41-56,79; GUNet.py:162-217 `modulated_conv_block`)."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, moving_mean, moving_var, training, eps, decay, out):
-        _require_cuda(x, w, gamma, beta)
+    def forward(ctx, x, w, gamma, beta, moving_mean, moving_var, spec, out, guide, gw, gb):
+        _require_cuda(x, w)
         cin, cout = w.shape[2], w.shape[3]
         mfma = conv_uses_mfma(cin, cout)
         need_dx = ctx.needs_input_grad[0]
@@ -337,30 +367,40 @@ class Conv3x3BnRelu(torch.autograd.Function):
             if need_dx:
                 raise _abi.UnetkError("conv3x3 input gradient needs Cin%64==0 and Cout%16==0 "
                                       "(got {}->{})".format(cin, cout))
-        y, stats, rows = conv3x3_fwd(x, wp_f, cout, want_stats=training)
-        count = y.shape[0] * y.shape[1] * y.shape[2]
-        aff = bn_finalize(stats, rows, count, gamma, beta, eps, decay, training, moving_mean, moving_var)
+        use_batch_stats = spec.training or spec.per_sample
+        y, stats, rows = conv3x3_fwd(x, wp_f, cout, want_stats=use_batch_stats)
         z = out if out is not None else torch.empty_like(y)
-        affine_relu(y, aff[2], aff[3], z)
-        if training:
-            ctx.save_for_backward(x, y, gamma, beta, aff)
+        g_ch = 0 if guide is None else guide.shape[-1]
+        if g_ch:
+            gw = gw.contiguous()
+            gb = gb.contiguous()
+        d = norm_desc(y.shape, spec.per_sample, _pix_stride(z), g_ch, cout if g_ch else 0, 0)
+        aff = norm_finalize(d, stats, rows, gamma, beta, spec.eps, spec.decay, spec.training, moving_mean, moving_var,
+                            y.device)
+        norm_apply_relu(d, y, aff, z, guide, gw, gb)
+        if spec.training:
+            ctx.save_for_backward(x, y, aff, guide, gw, gb)
             ctx.wp_d = wp_d
             ctx.need_dx = need_dx
+            ctx.desc = d
+            ctx.has = (gamma is not None, beta is not None)
             ctx.w_dbg = w.detach() if DEBUG_CAPTURE is not None else None
+            ctx.gb_dbg = (gamma, beta) if DEBUG_CAPTURE is not None else None
         return alias(z) if out is not None else z
 
     @staticmethod
     def backward(ctx, dz):
-        x, y, gamma, beta, aff = ctx.saved_tensors
+        x, y, aff, guide, gw, gb = ctx.saved_tensors
         if dz.stride(3) != 1:
             dz = dz.contiguous()
-        dy, dgamma, dbeta = bn_relu_bwd(y, dz, gamma, beta, aff[0], aff[1])
+        dy, dgamma, dbeta, dgw, dgb = norm_relu_bwd(ctx.desc, y, dz, aff, ctx.has[0], ctx.has[1], guide, gw, gb)
         dw = conv3x3_wgrad(x, dy)
         dx = conv3x3_dgrad(dy, ctx.wp_d, x.shape[3]) if ctx.need_dx else None
         if DEBUG_CAPTURE is not None:
-            DEBUG_CAPTURE.append(dict(x=x, y=y, gamma=gamma, beta=beta, aff=aff, dz=dz, dy=dy, dw=dw, dx=dx,
-                                      dgamma=dgamma, dbeta=dbeta, w=ctx.w_dbg))
-        return dx, dw, dgamma, dbeta, None, None, None, None, None, None
+            DEBUG_CAPTURE.append(dict(x=x, y=y, gamma=ctx.gb_dbg[0], beta=ctx.gb_dbg[1], aff=aff, dz=dz, dy=dy, dw=dw,
+                                      dx=dx, dgamma=dgamma, dbeta=dbeta, w=ctx.w_dbg, guide=guide, gw=gw, gb=gb,
+                                      dgw=dgw, dgb=dgb, per_sample=bool(ctx.desc.per_sample)))
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, dgw, dgb
 
 
 class MaxPool2x2(torch.autograd.Function):

@@ -84,30 +84,46 @@ size_t unetk_conv3x3_wgrad_ws_bytes(const unetk_conv_desc* d);
 int unetk_conv3x3_wgrad(const unetk_conv_desc* d, const float* x, const float* dy, float* dw,
                         void* ws, size_t ws_bytes, void* stream);
 
-/* ---------------------------------------------------------------- normalisation (slim.batch_norm)
- * NetworksV2/base.py:153-169; TF defaults eps 1e-3, decay .999.
- * Finalise the conv's statistic partials into mean/var and the fused affine
- * scale = gamma*rsqrt(var+eps), shift = beta - mean*scale; when training also update the moving
- * statistics (moving = moving*decay + batch*(1-decay), unbiased variance).
- * When training == 0 the affine is built from the moving statistics and partials are ignored. */
-size_t unetk_bn_finalize_ws_bytes(int stat_rows, int C);
-int unetk_bn_finalize(const float* stat_partials, int stat_rows, int C, int64_t count,
-                      const float* gamma, const float* beta, float eps, float decay, int training,
-                      float* moving_mean, float* moving_var, float* mean_out, float* rstd_out,
-                      float* scale_out, float* shift_out, void* ws, size_t ws_bytes, void* stream);
+/* ---------------------------------------------------------------- normalisation + ReLU after each 3x3 conv
+ * slim.batch_norm   NetworksV2/base.py:153-162 -- TF defaults eps 1e-3, decay .999 (GUNet encoder .99,
+ *                   GUNet.py:321-325); training: batch mean + biased variance, unbiased variance into
+ *                   the moving average; eval: moving statistics                        
+ * slim.instance_norm base.py:163-165 -- eps 1e-6, moments over the spatial axes per (n, c)   (B4)
+ * centre / scale are optional (gamma / beta may be NULL): GUNet.yml norm_with_center / norm_with_scale.
+ * guide_ch > 0 adds GUNet's spatial modulation before the ReLU (GUNet.py:154-156,207-212):
+ *   u += sum_g guide[n,pix,g] * gw[g][gw_coff + c] + gb[gw_coff + c]   (the 1x1 conv of the pooled guide,
+ *   computed on the fly; gw is [guide_ch][gw_stride], gb is [gw_stride]). */
+typedef struct unetk_norm_desc {
+  int32_t N, HW, C;            /* activations [N, HW, C], dense */
+  int32_t per_sample;          /* 0 = batch norm (one statistic group), 1 = instance norm (N groups) */
+  int32_t z_stride;            /* pixel stride of the activated output (concat placement) */
+  int32_t guide_ch, gw_stride, gw_coff;
+} unetk_norm_desc;
 
-/* z = relu(y*scale[c] + shift[c]); y dense [npix,C]; z pixel stride z_stride (concat placement). */
-int unetk_affine_relu(const float* y, const float* scale, const float* shift, float* z,
-                      int64_t npix, int C, int z_stride, void* stream);
+/* Finalise the conv's statistic partials ([2][stat_rows][C], each image's tiles contiguous) into
+ * mean / rstd and the fused affine scale = gamma*rstd, shift = beta - mean*scale, each [groups][C].
+ * Batch norm in training also updates the moving statistics; batch norm with training == 0 builds the
+ * affine from the moving statistics and ignores the partials. */
+size_t unetk_norm_finalize_ws_bytes(const unetk_norm_desc* d, int stat_rows);
+int unetk_norm_finalize(const unetk_norm_desc* d, const float* stat_partials, int stat_rows,
+                        const float* gamma, const float* beta, float eps, float decay, int training,
+                        float* moving_mean, float* moving_var, float* mean_out, float* rstd_out,
+                        float* scale_out, float* shift_out, void* ws, size_t ws_bytes, void* stream);
 
-/* Backward of z = relu(bn_train(y)).  Pass 1 writes partial column sums of du and du*xhat
- * (du = dz * (z > 0)); pass 2 forms dy.  dz has pixel stride dz_stride.
- * ws must hold unetk_bn_bwd_ws_bytes(npix, C). dgamma/dbeta receive the parameter grads. */
-size_t unetk_bn_bwd_ws_bytes(int64_t npix, int C);
-int unetk_bn_relu_bwd(const float* y, const float* dz, int dz_stride, const float* gamma,
-                      const float* mean, const float* rstd, const float* beta, float* dy,
-                      float* dgamma, float* dbeta, int64_t npix, int C, void* ws, size_t ws_bytes,
-                      void* stream);
+/* z = relu(y*scale + shift [+ guide modulation]); z has pixel stride d->z_stride. */
+int unetk_norm_apply_relu(const unetk_norm_desc* d, const float* y, const float* scale,
+                          const float* shift, const float* guide, const float* gw, const float* gb,
+                          float* z, void* stream);
+
+/* Backward of z = relu(norm(y) [+ modulation]).  Pass 1: per-group column sums of du and du*xhat
+ * (du = dz * (z > 0)) [and du*guide_g]; pass 2: dy.  dz has pixel stride dz_stride.  Outputs (nullable
+ * when the parameter does not exist): dgamma[C], dbeta[C], dgw[guide_ch][C], dgb[C]. */
+size_t unetk_norm_bwd_ws_bytes(const unetk_norm_desc* d);
+int unetk_norm_relu_bwd(const unetk_norm_desc* d, const float* y, const float* dz, int dz_stride,
+                        const float* scale, const float* shift, const float* mean, const float* rstd,
+                        const float* guide, const float* gw, const float* gb, float* dy,
+                        float* dgamma, float* dbeta, float* dgw, float* dgb, void* ws,
+                        size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------- slim.max_pool2d(x, [2,2])  UNet.py:81
  * VALID, stride 2.  x [N,H,W,C] with pixel stride x_stride; p dense [N,H/2,W/2,C].
@@ -116,6 +132,8 @@ int unetk_maxpool2_fwd(const float* x, int x_stride, float* p, int N, int H, int
                        void* stream);
 int unetk_maxpool2_bwd(const float* x, int x_stride, const float* p, const float* dp, float* dx,
                        int N, int H, int W, int C, void* stream);
+/* slim.avg_pool2d(gs, 2) of GUNet's spatial-guide pyramid (GUNet.py:157-158); x, p dense, any C. */
+int unetk_avgpool2_fwd(const float* x, float* p, int N, int H, int W, int C, void* stream);
 
 /* ---------------------------------------------------------------- slim.conv2d_transpose(x, C, 2, 2)
  * UNet.py:91-93: kernel 2 stride 2, bias, ReLU, then tf.concat((skip, up), -1).

@@ -116,60 +116,119 @@ def test_conv3x3_wgrad_first_layer(ops):
     assert rel_err(dw.cpu().numpy(), wt.grad.numpy()) < 3e-6
 
 
-@pytest.mark.parametrize("c,npix_shape", [(64, (2, 16, 16)), (128, (1, 8, 24)), (1024, (2, 2, 2)), (256, (3, 5, 7))])
-def test_bn_relu_forward_backward(ops, c, npix_shape):
-    rng = np.random.default_rng(c)
-    n, h, w = npix_shape
+def _stats_like_conv_epilogue(yd, per_image_rows=True):
+    """Statistic partials as the conv epilogue produces them: rows of 128 pixels, each image's rows contiguous."""
+    n, c = yd.shape[0], yd.shape[-1]
+    flat = yd.reshape(n, -1, c)
+    rpi = (flat.shape[1] + 127) // 128
+    pad = rpi * 128 - flat.shape[1]
+    fp = torch.cat([flat, torch.zeros(n, pad, c, device="cuda")], 1).reshape(n * rpi, 128, c)
+    return torch.stack([fp.sum(1), (fp * fp).sum(1)]).contiguous(), n * rpi
+
+
+NORM_CASES = [
+    # kind, C, (n,h,w), has_gamma, has_beta, guide channels
+    ("batch_norm", 64, (2, 16, 16), True, True, 0),
+    ("batch_norm", 128, (1, 8, 24), True, True, 0),
+    ("batch_norm", 1024, (2, 2, 2), True, True, 0),
+    ("batch_norm", 256, (3, 5, 7), True, True, 0),
+    ("instance_norm", 64, (3, 16, 16), True, True, 0),
+    ("instance_norm", 256, (2, 6, 10), True, True, 0),
+    ("instance_norm", 128, (2, 16, 8), False, True, 1),     # GUNet.yml: centre only + 1-channel spatial guide
+    ("batch_norm", 128, (2, 16, 8), False, True, 2),        # BN encoder with a 2-channel guide
+    ("instance_norm", 64, (2, 8, 8), False, False, 0),
+]
+
+
+@pytest.mark.parametrize("kind,c,shape,has_gamma,has_beta,g_ch", NORM_CASES)
+def test_norm_relu_forward_backward(ops, kind, c, shape, has_gamma, has_beta, g_ch):
+    rng = np.random.default_rng(c + g_ch)
+    n, h, w = shape
+    per_sample = kind == "instance_norm"
+    eps = 1e-6 if per_sample else 1e-3
     y_np = (rng.standard_normal((n, h, w, c)) * 2 + 0.5).astype(np.float32)
-    gamma = (rng.random(c) + 0.5).astype(np.float32)
-    beta = (rng.standard_normal(c) * 0.3).astype(np.float32)
+    gamma = (rng.random(c) + 0.5).astype(np.float32) if has_gamma else None
+    beta = (rng.standard_normal(c) * 0.3).astype(np.float32) if has_beta else None
     mm0 = rng.standard_normal(c).astype(np.float32)
     mv0 = (rng.random(c) + 0.5).astype(np.float32)
     dz_np = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    guide = rng.random((n, h, w, g_ch)).astype(np.float32) if g_ch else None
+    gw_full = (rng.standard_normal((g_ch, 2 * c)) * 0.5).astype(np.float32) if g_ch else None
+    gb_full = (rng.standard_normal(2 * c) * 0.2).astype(np.float32) if g_ch else None
     # oracle (float64)
-    y64 = torch.tensor(y_np, dtype=torch.float64, requires_grad=True)
-    g64 = torch.tensor(gamma, dtype=torch.float64, requires_grad=True)
-    b64 = torch.tensor(beta, dtype=torch.float64, requires_grad=True)
-    zn, nmm, nmv = tf_ops.batch_norm(y64, g64, b64, torch.tensor(mm0, dtype=torch.float64),
-                                     torch.tensor(mv0, dtype=torch.float64), True)
+    t64 = lambda a: None if a is None else torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    y64, g64, b64, gw64, gb64 = t64(y_np), t64(gamma), t64(beta), t64(gw_full), t64(gb_full)
+    if per_sample:
+        zn = tf_ops.instance_norm(y64, g64, b64, eps=eps)
+        nmm = nmv = None
+    else:
+        zn, nmm, nmv = tf_ops.batch_norm(y64, g64, b64, torch.tensor(mm0, dtype=torch.float64),
+                                         torch.tensor(mv0, dtype=torch.float64), True, eps=eps)
+    if g_ch:   # GUNet.py:154-156,207-212: sp = conv1x1(guide) (+bias); net + sp[..., C:2C] (second conv of the block)
+        sp = torch.tensor(guide, dtype=torch.float64) @ gw64 + gb64
+        zn = zn + sp[..., c:2 * c]
     z_ref = torch.relu(zn)
     z_ref.backward(torch.tensor(dz_np, dtype=torch.float64))
-    # HIP: statistics partials as the conv epilogue would produce them (one row per 128 pixels)
+    # HIP
     yd = dev(y_np)
-    flat = yd.reshape(-1, c)
-    rows = (flat.shape[0] + 127) // 128
-    pad = rows * 128 - flat.shape[0]
-    fp = torch.cat([flat, torch.zeros(pad, c, device="cuda")]).reshape(rows, 128, c)
-    stats = torch.stack([fp.sum(1), (fp * fp).sum(1)]).contiguous()
+    stats, rows = _stats_like_conv_epilogue(yd)
     mm, mv = dev(mm0), dev(mv0)
-    aff = ops.bn_finalize(stats, rows, flat.shape[0], dev(gamma), dev(beta), 1e-3, 0.999, True, mm, mv)
+    gd, bd = (dev(gamma) if has_gamma else None), (dev(beta) if has_beta else None)
+    guide_d = dev(guide) if g_ch else None
+    gw_d = dev(gw_full[:, c:]) if g_ch else None            # this conv's column slice, contiguous [g][C]
+    gb_d = dev(gb_full[c:]) if g_ch else None
+    d = ops.norm_desc(yd.shape, per_sample, c, g_ch, c if g_ch else 0, 0)
+    aff = ops.norm_finalize(d, stats, rows, gd, bd, eps, 0.999, True, mm, mv, yd.device)
     z = torch.empty_like(yd)
-    ops.affine_relu(yd, aff[2], aff[3], z)
+    ops.norm_apply_relu(d, yd, aff, z, guide_d, gw_d, gb_d)
     assert rel_err(z.cpu().numpy(), z_ref.detach().numpy()) < 1e-5
-    np.testing.assert_allclose(mm.cpu().numpy(), nmm.numpy(), rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(mv.cpu().numpy(), nmv.numpy(), rtol=1e-5, atol=1e-6)
-    dy, dgamma, dbeta = ops.bn_relu_bwd(yd, dev(dz_np), dev(gamma), dev(beta), aff[0], aff[1])
+    if not per_sample:
+        np.testing.assert_allclose(mm.cpu().numpy(), nmm.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(mv.cpu().numpy(), nmv.numpy(), rtol=1e-5, atol=1e-6)
+    else:
+        assert torch.equal(mm.cpu(), torch.tensor(mm0))          # instance norm keeps no moving statistics
+    dy, dgamma, dbeta, dgw, dgb = ops.norm_relu_bwd(d, yd, dev(dz_np), aff, has_gamma, has_beta, guide_d, gw_d, gb_d)
     assert rel_err(dy.cpu().numpy(), y64.grad.numpy()) < 2e-5
-    assert rel_err(dgamma.cpu().numpy(), g64.grad.numpy()) < 2e-5
-    assert rel_err(dbeta.cpu().numpy(), b64.grad.numpy()) < 2e-5
-    # eval mode: moving statistics
-    aff_e = ops.bn_finalize(None, 0, flat.shape[0], dev(gamma), dev(beta), 1e-3, 0.999, False, mm, mv)
-    ze = torch.empty_like(yd)
-    ops.affine_relu(yd, aff_e[2], aff_e[3], ze)
-    ref_e, _, _ = tf_ops.batch_norm(torch.tensor(y_np, dtype=torch.float64), g64.detach(), b64.detach(),
-                                    mm.cpu().double(), mv.cpu().double(), False)
-    assert rel_err(ze.cpu().numpy(), torch.relu(ref_e).numpy()) < 1e-5
+    if has_gamma:
+        assert rel_err(dgamma.cpu().numpy(), g64.grad.numpy()) < 2e-5
+    if has_beta:
+        assert rel_err(dbeta.cpu().numpy(), b64.grad.numpy()) < 2e-5
+    if g_ch:
+        assert rel_err(dgw.cpu().numpy(), gw64.grad.numpy()[:, c:]) < 2e-5
+        assert rel_err(dgb.cpu().numpy(), gb64.grad.numpy()[c:]) < 2e-5
+        assert np.abs(gw64.grad.numpy()[:, :c]).max() == 0.0
+    if not per_sample:
+        # eval mode: moving statistics
+        aff_e = ops.norm_finalize(d, None, 0, gd, bd, eps, 0.999, False, mm, mv, yd.device)
+        ze = torch.empty_like(yd)
+        ops.norm_apply_relu(d, yd, aff_e, ze, guide_d, gw_d, gb_d)
+        ref_e, _, _ = tf_ops.batch_norm(torch.tensor(y_np, dtype=torch.float64), None if g64 is None else g64.detach(),
+                                        None if b64 is None else b64.detach(), mm.cpu().double(), mv.cpu().double(),
+                                        False, eps=eps)
+        if g_ch:
+            ref_e = ref_e + (torch.tensor(guide, dtype=torch.float64) @ gw64.detach() + gb64.detach())[..., c:2 * c]
+        assert rel_err(ze.cpu().numpy(), torch.relu(ref_e).numpy()) < 1e-5
 
 
-def test_affine_relu_into_concat_slice(ops):
+def test_norm_apply_into_concat_slice(ops):
     rng = np.random.default_rng(3)
     y = dev(rng.standard_normal((2, 4, 6, 64)))
     cat = torch.full((2, 4, 6, 128), -7.0, device="cuda")
-    sc, sh = dev(rng.random(64) + 0.5), dev(rng.standard_normal(64))
-    ops.affine_relu(y, sc, sh, cat[..., :64])
-    ref = torch.relu(y * sc + sh)
+    aff = torch.stack([torch.zeros(1, 64, device="cuda"), torch.ones(1, 64, device="cuda"),
+                       dev(rng.random((1, 64)) + 0.5), dev(rng.standard_normal((1, 64)))]).contiguous()
+    d = ops.norm_desc(y.shape, False, 128)
+    ops.norm_apply_relu(d, y, aff, cat[..., :64])
+    ref = torch.relu(y * aff[2, 0] + aff[3, 0])
     assert torch.allclose(cat[..., :64], ref, atol=1e-6)
     assert torch.all(cat[..., 64:] == -7.0)
+
+
+def test_avgpool_guide_pyramid(ops):
+    rng = np.random.default_rng(8)
+    g = rng.random((2, 8, 12, 1)).astype(np.float32)
+    p = ops.avgpool2_fwd(dev(g))
+    ref = tf_ops.avg_pool2x2_same(torch.tensor(g))
+    assert torch.allclose(p.cpu(), ref, atol=1e-7)
 
 
 def test_maxpool_forward_backward_with_ties(ops):
