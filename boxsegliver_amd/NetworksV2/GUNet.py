@@ -1,0 +1,244 @@
+"""Guided U-Net plugin (spatial-guide path) -- host-side mirror of the reference's NetworksV2/GUNet.py:220-415
+executing on the libunetk HIP kernels.
+
+U-Net backbone whose ENCODER conv units are modulated: conv3x3 -> norm (centre/scale per GUNet.yml) ->
++ spatial params slice -> ReLU (`modulated_conv_block`, GUNet.py:162-217), where the spatial params of level
+i are a 1x1 conv of the avg-pooled guide with 2*C_i channels (`_spatial_subnets`, :136-159).  On MI355X the
+1x1 conv is never materialised: the norm-apply kernel adds guide[n,pix,:] . gw[:, c] + gb[c] on the fly and
+the norm-backward kernel reduces the gradients of gw / gb in the same pass.
+
+Not built yet (raise NotImplementedError): the context (density) branch --use_context, --use_se,
+`after_affine`, --fix, --dropout.
+"""
+import torch
+
+from .. import ops
+from ..loss_metrics import build_head_desc, metric_from_sums
+from ..utils import distribution_utils
+from . import base
+from .base import ModeKeys, ParamStore
+
+
+def param_specs(in_channels, num_classes, guide_channel, init_channels, num_down_samples, mod_layers, normalizer,
+                norm_with_center, norm_with_scale, use_spatial, name):
+    """Variables with the reference's TF names: <name>/spatial/conv{i}/{weights,biases},
+    <name>/Encode/down_conv{i}/mod_conv{j}/{weights,<Norm>/...}, <name>/Decode/up{i}/{weights,biases},
+    <name>/Decode/up_conv{i}/up_conv{i}_{j}/..., <name>/AdjustChannels/{weights,biases}."""
+    specs = []
+    bn = normalizer == "batch_norm"
+    ns = "BatchNorm" if bn else "InstanceNorm"
+
+    def norm_vars(scope, c, center, scale):
+        if center:
+            specs.append(("{}/{}/beta".format(scope, ns), (c,), "beta"))
+        if scale:
+            specs.append(("{}/{}/gamma".format(scope, ns), (c,), "gamma"))
+        if bn:
+            specs.append(("{}/{}/moving_mean".format(scope, ns), (c,), "moving_mean"))
+            specs.append(("{}/{}/moving_variance".format(scope, ns), (c,), "moving_var"))
+
+    if use_spatial:
+        for i in range(num_down_samples + 1):
+            if i in mod_layers:
+                c2 = 2 * init_channels * 2 ** i
+                specs.append(("{}/spatial/conv{}/weights".format(name, i + 1), (1, 1, guide_channel, c2), "conv_w"))
+                specs.append(("{}/spatial/conv{}/biases".format(name, i + 1), (c2,), "bias"))
+    cin = in_channels
+    for i in range(num_down_samples + 1):
+        c = init_channels * 2 ** i
+        mod = use_spatial and i in mod_layers
+        for j in (1, 2):
+            scope = "{}/Encode/down_conv{}/mod_conv{}".format(name, i + 1, j)
+            specs.append((scope + "/weights", (3, 3, cin, c), "conv_w"))
+            if mod:
+                norm_vars(scope, c, norm_with_center, norm_with_scale)
+            else:
+                norm_vars(scope, c, True, True)       # GUNet.py:183-188: scale=True (BN) / IN defaults
+            cin = c
+    c = init_channels * 2 ** num_down_samples
+    for i in reversed(range(num_down_samples)):
+        c //= 2
+        d = "{}/Decode/up{}".format(name, i + 1)
+        specs.append((d + "/weights", (2, 2, c, 2 * c), "deconv_w"))
+        specs.append((d + "/biases", (c,), "bias"))
+        for j in (1, 2):
+            scope = "{0}/Decode/up_conv{1}/up_conv{1}_{2}".format(name, i + 1, j)
+            specs.append((scope + "/weights", (3, 3, 2 * c if j == 1 else c, c), "conv_w"))
+            norm_vars(scope, c, True, True)
+    specs.append((name + "/AdjustChannels/weights", (1, 1, c, num_classes), "conv_w"))
+    specs.append((name + "/AdjustChannels/biases", (num_classes,), "bias"))
+    return specs
+
+
+class GUNet(base.BaseNet):
+    def __init__(self, args, name=None):
+        """Don't create tensors in __init__() (reference GUNet.py:221-238)."""
+        super(GUNet, self).__init__(args)
+        self.name = name or "GUNet"
+        self.classes.extend(self.args.classes)
+        self.bs = distribution_utils.per_device_batch_size(args.batch_size, args.num_gpus)
+        self.height = args.im_height
+        self.width = args.im_width
+        self.channel = args.im_channel
+        self.use_context_guide = getattr(args, "use_context", False)
+        self.use_spatial_guide = getattr(args, "use_spatial", False)
+        self.side_dropout = getattr(args, "side_dropout", 0.5)
+        self.dropout = getattr(args, "dropout", None)
+        self.use_se = getattr(args, "use_se", False)
+        self._taps = None
+
+    def _net_arg_scope(self, *args, **kwargs):
+        """GUNet.py:240-257: as UNet (decoder norm = _get_normalization defaults), pools with SAME."""
+        if getattr(self.args, "without_norm", False):
+            raise NotImplementedError("--without_norm has no HIP kernel yet")
+        if self.use_context_guide or self.use_se:
+            raise NotImplementedError("GUNet context branch (--use_context / --use_se) is not built yet")
+        if getattr(self.args, "fix", False) or self.dropout:
+            raise NotImplementedError("GUNet --fix / --dropout are not built yet")
+        self._norm = self._get_normalization()
+        return self._norm
+
+    def _spec(self, decay=None):
+        kind, np_ = self._norm
+        if kind == "batch_norm":
+            return ops.NormSpec("batch_norm", np_["eps"], decay if decay is not None else np_["decay"],
+                                bool(np_["is_training"]))
+        return ops.NormSpec("instance_norm", np_["eps"], 0.0, self.is_training)
+
+    def _unit(self, x, scope, spec, out=None, guide=None, gw=None, gb=None):
+        p = self.params
+        ns = scope + ("/BatchNorm" if spec.kind == "batch_norm" else "/InstanceNorm")
+        z = ops.Conv3x3NormRelu.apply(x, p[scope + "/weights"], p.get(ns + "/gamma"), p.get(ns + "/beta"),
+                                      p.get(ns + "/moving_mean"), p.get(ns + "/moving_variance"), spec, out, guide, gw,
+                                      gb)
+        if self._taps is not None:
+            self._taps[scope] = z
+        return z
+
+    def _build_network(self, *args, **kwargs):
+        base_channels = kwargs.get("init_channels", 64)
+        nds = kwargs.get("num_down_samples", 4)
+        mod_layers = list(kwargs.get("mod_layers", []))
+        norm_with_center = kwargs.get("norm_with_center", False)
+        norm_with_scale = kwargs.get("norm_with_scale", False)
+        if kwargs.get("after_affine", False):
+            raise NotImplementedError("GUNet after_affine is not built yet")
+        images = self._inputs["images"]
+        if not images.is_cuda:
+            raise ops._abi.UnetkError("GUNet runs on the GPU only: move `images` to cuda (no CPU path)")
+        n, h, w, _ = images.shape
+        if h % (1 << nds) or w % (1 << nds):
+            raise ValueError("H and W must be divisible by 2**num_down_samples")
+        dev = images.device
+        nm = self.name
+        g_ch = int(getattr(self.args, "guide_channel", 1)) if self.use_spatial_guide else 0
+        if self.params is None:
+            if getattr(self.args, "img_grad", False):
+                raise NotImplementedError("--img_grad has no HIP kernel yet")
+            specs = param_specs(self.channel, self.num_classes, g_ch, base_channels, nds, mod_layers,
+                                self.args.normalizer, norm_with_center, norm_with_scale, self.use_spatial_guide, nm)
+            self.params = ParamStore(specs, dev, bias_decay=getattr(self.args, "bias_decay", False))
+            self.params.initialize(self._get_initializer()[0], seed=getattr(self.args, "seed", None))
+        p = self.params
+
+        with torch.set_grad_enabled(self.mode == ModeKeys.TRAIN):
+            # spatial guide pyramid (GUNet.py:136-159): avg-pool between levels; the 1x1 conv is fused downstream
+            guides = {}
+            if self.use_spatial_guide:
+                gs = self._inputs["sp_guide"].to(torch.float32).contiguous()
+                if gs.shape != (n, h, w, g_ch):
+                    raise ValueError("sp_guide must be [bs, H, W, {}], got {}".format(g_ch, tuple(gs.shape)))
+                for i in range(nds + 1):
+                    if i in mod_layers:
+                        guides[i] = gs
+                    if i < nds:
+                        gs = ops.avgpool2_fwd(gs)
+
+            x = images.contiguous()
+            cats, skips = {}, {}
+            hh, ww = h, w
+            for i in range(nds + 1):
+                c = base_channels * 2 ** i
+                mod = i in guides
+                spec = self._spec(0.99) if mod else self._spec()           # GUNet.py:313-330 decay .99
+                for j in (1, 2):
+                    scope = "{}/Encode/down_conv{}/mod_conv{}".format(nm, i + 1, j)
+                    out = None
+                    if j == 2 and i < nds:
+                        cat = torch.empty((n, hh, ww, 2 * c), dtype=torch.float32, device=dev)
+                        out = ops.alias(cat, 0, (n, hh, ww, c), cat.stride())
+                        cats[i] = cat
+                    if mod:
+                        gw = p["{}/spatial/conv{}/weights".format(nm, i + 1)].view(g_ch, 2 * c)[:, (j - 1) * c:j * c]
+                        gb = p["{}/spatial/conv{}/biases".format(nm, i + 1)][(j - 1) * c:j * c]
+                        x = self._unit(x, scope, spec, out, guides[i], gw, gb)
+                    else:
+                        x = self._unit(x, scope, spec, out)
+                if i < nds:
+                    skips[i] = x
+                    x = ops.MaxPool2x2.apply(x)
+                    hh //= 2
+                    ww //= 2
+
+            for i in reversed(range(nds)):
+                d = "{}/Decode/up{}".format(nm, i + 1)
+                x = ops.DeconvConcat.apply(x, p[d + "/weights"], p[d + "/biases"], skips[i], cats[i])
+                for j in (1, 2):
+                    x = self._unit(x, "{0}/Decode/up_conv{1}/up_conv{1}_{2}".format(nm, i + 1, j), self._spec())
+
+            c = base_channels
+            self.ret_prob = kwargs.get("ret_prob", False)
+            self.ret_pred = kwargs.get("ret_pred", False)
+            labels = self._inputs.get("labels")
+            if labels is not None:
+                labels = labels.to(torch.int32).contiguous()
+            pixel_w = self._inputs.get("pixel_weights")
+            desc = build_head_desc(self.args, n, h * w, c, self.num_classes, explicit_map=pixel_w is not None) \
+                if labels is not None else ops.head_desc(n, h * w, c, self.num_classes)
+            want_probs = bool(self.ret_prob or self.ret_pred or self.mode != ModeKeys.TRAIN)
+            xent, dice, logits, probs, result = ops.HeadLoss.apply(
+                x, p[nm + "/AdjustChannels/weights"], p[nm + "/AdjustChannels/biases"], labels, pixel_w, desc,
+                want_probs)
+            self._head = (xent, dice, result)
+            self._layers["logits"] = logits.view(n, h, w, self.num_classes)
+            if want_probs:
+                self.probability = probs.view(n, h, w, self.num_classes)
+                if self.ret_prob:                                           # GUNet.py:382-384
+                    for i in range(1, self.num_classes):
+                        self.predictions[self.classes[i] + "Prob"] = self.probability[..., i:i + 1]
+                if self.ret_pred:
+                    _, preds = ops.head_predict(probs, self.num_classes, want_preds=True)
+                    for i in range(1, self.num_classes):
+                        obj = self.classes[i] + "Pred"
+                        self.predictions[obj] = preds[i - 1].view(n, h, w, 1)
+                        self._image_summaries[obj] = self.predictions[obj]
+
+    def _build_loss(self):
+        """GUNet.py:394-413: xentropy and/or dice by substring, + L2 regularisers."""
+        xent, dice, _ = self._head
+        data_loss = None
+        if "xentropy" in self.args.loss_type:
+            data_loss = xent
+        if "dice" in self.args.loss_type:
+            data_loss = dice if data_loss is None else data_loss + dice
+        if data_loss is None:
+            raise ValueError("Not supported loss_type: {}".format(self.args.loss_type))
+        w_reg, _ = self._get_regularizer()
+        reg = None
+        if w_reg is not None:
+            reg = ops.sumsq(self.params.flat["reg"])[0] * (0.5 * w_reg)
+        self.loss_terms = {"data": data_loss.detach(), "regularization": reg}
+        return data_loss if reg is None else data_loss + reg
+
+    def _build_metrics(self):
+        if not self.ret_pred or self._inputs.get("labels") is None:
+            return
+        _, _, result = self._head
+        n = self._inputs["images"].shape[0]
+        for i in range(1, self.num_classes):
+            obj = self.classes[i]
+            for met in self.args.metrics_train:
+                self.metrics_dict["{}/{}".format(obj, met)] = metric_from_sums(result, n, self.num_classes, i, met)
+
+    def _build_summaries(self):
+        return

@@ -70,6 +70,9 @@ class ParamStore(object):
     def __getitem__(self, name):
         return self.tensors[name]
 
+    def get(self, name, default=None):
+        return self.tensors.get(name, default)
+
     def trainable_names(self):
         return [n for n in self.tensors if self.where[n][0] != "stats"]
 

@@ -21,6 +21,13 @@ def add_arguments(parser):
     group.add_argument("--noise_scale", type=float, default=0.1)
     group.add_argument("--random_flip", type=int, default=1)
     group.add_argument("--eval_num_batches_per_epoch", type=int, default=100)
+    # guided pipeline flags the GUNet plugin reads (DataLoader/Liver/input_pipeline_g.py:71-125; --guide_channel
+    # comes from the NF pipelines, DataLoader/NF/input_pipeline_g_simply.py:106 -- the liver pipeline emits 1 channel)
+    group.add_argument("--use_spatial", action="store_true")
+    group.add_argument("--use_context", action="store_true")
+    group.add_argument("--side_dropout", type=float, default=0.5)
+    group.add_argument("--use_se", action="store_true")
+    group.add_argument("--guide_channel", type=int, default=1)
     group.add_argument("--synthetic_batches", type=int, default=2, help="distinct synthetic batches kept on device")
     group.add_argument("--seed", type=int, default=1234)
 
@@ -44,6 +51,29 @@ def make_batch(bs, height, width, channel, num_classes, seed=1234, noise_scale=0
     return images, labels, names
 
 
+def make_guide(labels, guide_channel=1, seed=1234):
+    """Spatial guide like DataLoader/Liver/input_pipeline_g.py:382-394 / utils/image_ops.py:431-434:
+    g/2 + 0.5 with g = max_k exp(-|p - c_k|^2 / (2 sigma^2)), 1-3 centres inside the foreground, sigma ~ U(2, 8)
+    (pixels, scaled with the image).  Returns float32 [bs, H, W, guide_channel]."""
+    rng = np.random.default_rng(seed + 77)
+    bs, height, width = labels.shape
+    yy, xx = np.meshgrid(np.arange(height, dtype=np.float32), np.arange(width, dtype=np.float32), indexing="ij")
+    out = np.zeros((bs, height, width, guide_channel), dtype=np.float32)
+    fg_cls = labels.max()
+    for b in range(bs):
+        ys, xs = np.nonzero(labels[b] == fg_cls) if fg_cls > 0 else (np.array([height // 2]), np.array([width // 2]))
+        if len(ys) == 0:
+            ys, xs = np.array([height // 2]), np.array([width // 2])
+        for ch in range(guide_channel):
+            g = np.zeros((height, width), dtype=np.float32)
+            for _ in range(int(rng.integers(1, 4))):
+                k = int(rng.integers(0, len(ys)))
+                sigma = rng.uniform(2.0, 8.0) * height / 256.0 + 0.5
+                g = np.maximum(g, np.exp(-((yy - ys[k]) ** 2 + (xx - xs[k]) ** 2) / (2 * sigma ** 2)))
+            out[b, ..., ch] = g / 2 + 0.5
+    return out
+
+
 def input_fn(mode, params):
     """input_fn(mode, params) -> iterator of (features, labels), modes train / eval_online / eval
     (reference contract: DataLoader/Liver/input_pipeline.py:199-203)."""
@@ -61,8 +91,10 @@ def input_fn(mode, params):
         seed = base_seed + 1000 * rank + i + (0 if mode == "train" else 500)
         images, labels, names = make_batch(bs, args.im_height, args.im_width, args.im_channel, ncls, seed,
                                            getattr(args, "noise_scale", 0.05))
-        pool.append(({"images": torch.from_numpy(images).to(device), "names": torch.from_numpy(names)},
-                     torch.from_numpy(labels).to(device)))
+        feats = {"images": torch.from_numpy(images).to(device), "names": torch.from_numpy(names)}
+        if getattr(args, "use_spatial", False):
+            feats["sp_guide"] = torch.from_numpy(make_guide(labels, int(getattr(args, "guide_channel", 1)), seed)).to(device)
+        pool.append((feats, torch.from_numpy(labels).to(device)))
 
     def gen():
         if mode == "train":

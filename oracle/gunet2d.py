@@ -1,0 +1,178 @@
+"""Guided U-Net (spatial-guide path) forward / loss / gradients with the reference's TF semantics.
+
+TEST INFRASTRUCTURE ONLY -- PARITY UNPINNED (see oracle/__init__.py).
+
+Follows /root/reference/NetworksV2/GUNet.py:
+  _spatial_subnets      :136-159  guide pyramid: per modulated level a 1x1 conv (bias, linear) of the guide,
+                                  2*C_i channels, avg_pool2d(2, SAME) between levels
+  modulated_conv_block  :162-217  conv3x3 (no activation) -> norm -> [+ spatial params slice] -> ReLU, twice
+  _net_arg_scope        :240-257  default norm for plain conv2d (decoder): BN scale=True / IN defaults
+  _build_network        :259-392  encoder norm params: center = norm_with_center, scale = norm_with_scale,
+                                  BN decay .99 (:313-330); level 0 un-modulated with (scale=True | IN defaults)
+                                  (:183-188); decoder = deconv(+bias, ReLU) -> concat(skip, up) -> 2 conv units
+  _build_loss           :394-413  'xentropy' and/or 'dice' by substring, + regularisers
+The context (density) branch, SE and after_affine variants are not restated.
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import losses, tf_ops
+from .unet2d import TRAINABLE_KINDS  # noqa: F401
+
+
+def param_specs(in_channels, num_classes, guide_channel=1, init_channels=64, num_down_samples=4,
+                mod_layers=(1, 2, 3, 4), normalizer="instance_norm", norm_with_center=True, norm_with_scale=False,
+                name="GUNet"):
+    specs = []
+    bn = normalizer == "batch_norm"
+    norm_scope = "BatchNorm" if bn else "InstanceNorm"
+
+    def norm_vars(scope, center, scale):
+        if center:
+            specs.append(("{}/{}/beta".format(scope, norm_scope), None, "beta"))
+        if scale:
+            specs.append(("{}/{}/gamma".format(scope, norm_scope), None, "gamma"))
+        if bn:
+            specs.append(("{}/{}/moving_mean".format(scope, norm_scope), None, "moving_mean"))
+            specs.append(("{}/{}/moving_variance".format(scope, norm_scope), None, "moving_var"))
+
+    def fix_shapes(c, start):
+        for k in range(start, len(specs)):
+            if specs[k][1] is None:
+                specs[k] = (specs[k][0], (c,), specs[k][2])
+
+    for i in range(num_down_samples + 1):
+        if i in mod_layers:
+            c2 = 2 * init_channels * 2 ** i
+            specs.append(("{}/spatial/conv{}/weights".format(name, i + 1), (1, 1, guide_channel, c2), "conv_w"))
+            specs.append(("{}/spatial/conv{}/biases".format(name, i + 1), (c2,), "bias"))
+    cin = in_channels
+    for i in range(num_down_samples + 1):
+        c = init_channels * 2 ** i
+        for j in (1, 2):
+            scope = "{}/Encode/down_conv{}/mod_conv{}".format(name, i + 1, j)
+            specs.append((scope + "/weights", (3, 3, cin, c), "conv_w"))
+            start = len(specs)
+            if i in mod_layers:
+                norm_vars(scope, norm_with_center, norm_with_scale)
+            else:
+                norm_vars(scope, True, True)
+            fix_shapes(c, start)
+            cin = c
+    c = init_channels * 2 ** num_down_samples
+    for i in reversed(range(num_down_samples)):
+        c //= 2
+        d = "{}/Decode/up{}".format(name, i + 1)
+        specs.append((d + "/weights", (2, 2, c, 2 * c), "deconv_w"))
+        specs.append((d + "/biases", (c,), "bias"))
+        for j in (1, 2):
+            scope = "{0}/Decode/up_conv{1}/up_conv{1}_{2}".format(name, i + 1, j)
+            specs.append((scope + "/weights", (3, 3, 2 * c if j == 1 else c, c), "conv_w"))
+            start = len(specs)
+            norm_vars(scope, True, True)
+            fix_shapes(c, start)
+    specs.append((name + "/AdjustChannels/weights", (1, 1, c, num_classes), "conv_w"))
+    specs.append((name + "/AdjustChannels/biases", (num_classes,), "bias"))
+    return specs
+
+
+class GUNet2DOracle(object):
+    def __init__(self, in_channels, num_classes, guide_channel=1, init_channels=64, num_down_samples=4,
+                 mod_layers=(1, 2, 3, 4), normalizer="instance_norm", norm_with_center=True, norm_with_scale=False,
+                 name="GUNet"):
+        self.name, self.num_classes = name, num_classes
+        self.init_channels, self.nds = init_channels, num_down_samples
+        self.mod_layers = tuple(mod_layers)
+        self.normalizer = normalizer
+        self.specs = param_specs(in_channels, num_classes, guide_channel, init_channels, num_down_samples, mod_layers,
+                                 normalizer, norm_with_center, norm_with_scale, name)
+        self.kinds = {n: k for n, _, k in self.specs}
+
+    def _unit(self, x, p, scope, is_training, new_stats, decay, sp=None):
+        y = tf_ops.conv_nd_same(x, p[scope + "/weights"])
+        if self.normalizer == "batch_norm":
+            ns = scope + "/BatchNorm"
+            y, mm, mv = tf_ops.batch_norm(y, p.get(ns + "/gamma"), p.get(ns + "/beta"), p[ns + "/moving_mean"],
+                                          p[ns + "/moving_variance"], is_training, eps=1e-3, decay=decay)
+            new_stats[ns + "/moving_mean"], new_stats[ns + "/moving_variance"] = mm, mv
+        else:
+            ns = scope + "/InstanceNorm"
+            y = tf_ops.instance_norm(y, p.get(ns + "/gamma"), p.get(ns + "/beta"), eps=1e-6)
+        if sp is not None:
+            y = y + sp
+        return torch.relu(y)
+
+    def forward(self, p, images, sp_guide, is_training):
+        n = self.name
+        new_stats = OrderedDict()
+        # spatial subnets (GUNet.py:136-159)
+        sp_params = {}
+        gs = sp_guide
+        for i in range(self.nds + 1):
+            if i in self.mod_layers:
+                w = p["{}/spatial/conv{}/weights".format(n, i + 1)]
+                sp_params[i] = gs @ w.reshape(w.shape[2], w.shape[3]) + p["{}/spatial/conv{}/biases".format(n, i + 1)]
+            if i < self.nds:
+                gs = tf_ops.avg_pool2x2_same(gs)
+        x = images
+        skips = []
+        for i in range(self.nds + 1):
+            c = self.init_channels * 2 ** i
+            mod = i in self.mod_layers
+            for j in (1, 2):
+                scope = "{}/Encode/down_conv{}/mod_conv{}".format(n, i + 1, j)
+                sp = sp_params[i][..., (j - 1) * c:j * c] if mod else None
+                x = self._unit(x, p, scope, is_training, new_stats, 0.99 if mod else 0.999, sp)
+            if i < self.nds:
+                skips.append(x)
+                x = tf_ops.max_pool2x2(x)
+        for i in reversed(range(self.nds)):
+            d = "{}/Decode/up{}".format(n, i + 1)
+            up = torch.relu(tf_ops.conv_transpose_ks(x, p[d + "/weights"], (2, 2), bias=p[d + "/biases"]))
+            x = torch.cat((skips[i], up), dim=-1)
+            for j in (1, 2):
+                x = self._unit(x, p, "{0}/Decode/up_conv{1}/up_conv{1}_{2}".format(n, i + 1, j), is_training,
+                               new_stats, 0.999)
+        logits = tf_ops.conv_nd_same(x, p[n + "/AdjustChannels/weights"]) + p[n + "/AdjustChannels/biases"]
+        return logits, new_stats
+
+    def regularization_loss(self, p, wd, bias_decay=False):
+        total = torch.zeros((), dtype=torch.float32)
+        if not wd or wd <= 0:
+            return total
+        for name, _, kind in self.specs:
+            if kind in ("conv_w", "deconv_w") or (kind == "bias" and not bias_decay):
+                total = total + wd * 0.5 * (p[name].to(torch.float32) ** 2).sum()
+        return total
+
+    def loss(self, p, images, sp_guide, labels, loss_type="xentropy", loss_weight_type="none", numeric_w=None,
+             proportion_decay=None, weight_decay_rate=0.0, bias_decay=False, is_training=True):
+        logits, new_stats = self.forward(p, images, sp_guide, is_training)
+        kw = {}
+        if loss_weight_type == "numerical":
+            kw["numeric_w"] = numeric_w
+        elif loss_weight_type == "proportion" and proportion_decay and proportion_decay > 0:
+            kw["proportion_decay"] = proportion_decay
+        data_loss, has = 0.0, False
+        if "xentropy" in loss_type:                                   # GUNet.py:399-403 (substring match)
+            data_loss = data_loss + losses.weighted_sparse_softmax_cross_entropy(logits, labels, loss_weight_type, **kw)
+            has = True
+        if "dice" in loss_type:                                       # :404-408
+            data_loss = data_loss + losses.sparse_dice_loss(torch.softmax(logits, -1), labels)
+            has = True
+        if not has:
+            raise ValueError("Not supported loss_type: {}".format(loss_type))
+        return data_loss + self.regularization_loss(p, weight_decay_rate, bias_decay), data_loss, logits, new_stats
+
+    def loss_and_grads(self, p, images, sp_guide, labels, **kw):
+        q = OrderedDict()
+        for name, t in p.items():
+            t = t.detach().clone()
+            if self.kinds[name] in TRAINABLE_KINDS:
+                t.requires_grad_(True)
+            q[name] = t
+        total, data_loss, logits, new_stats = self.loss(q, images, sp_guide, labels, **kw)
+        total.backward()
+        grads = OrderedDict((n, t.grad.detach()) for n, t in q.items() if t.requires_grad)
+        return total.detach(), data_loss.detach(), logits.detach(), grads, new_stats
