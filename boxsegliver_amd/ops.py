@@ -431,6 +431,7 @@ class DeconvConcat(torch.autograd.Function):
         ctx.save_for_backward(x, cat)
         ctx.wp_d = wp_d
         ctx.cout, ctx.coff = cout, coff
+        ctx.wb_dbg = (w.detach(), b.detach()) if DEBUG_CAPTURE is not None else None
         return alias(cat)
 
     @staticmethod
@@ -439,6 +440,9 @@ class DeconvConcat(torch.autograd.Function):
         dcat = dcat.contiguous()
         dx, dw, db = deconv2x2_bwd(x, ctx.wp_d, cat, dcat, ctx.coff, ctx.cout)
         dskip = dcat[..., :ctx.coff]
+        if DEBUG_CAPTURE is not None:
+            DEBUG_CAPTURE.append(dict(kind="deconv", x=x, w=ctx.wb_dbg[0], b=ctx.wb_dbg[1], cat=cat.clone(),
+                                      dcat=dcat, dx=dx, dw=dw, db=db, coff=ctx.coff))
         return dx, dw, db, dskip, None
 
 

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import gunet2d
-from test_gpu_unet import check_unit_backward, rel
+from test_gpu_unet import check_deconv_backward, check_unit_backward, rel
 
 pytestmark = pytest.mark.gpu
 
@@ -88,17 +88,24 @@ def test_gunet_matches_oracle(normalizer, loss_type, g_ch):
     safe = (srt[..., -1] - srt[..., -2]) > 1e-3
     assert (got.argmax(-1) == logits.numpy().argmax(-1))[safe].all()
     # every backward kernel on identical operands (18 units: 8 modulated, centre-only)
-    assert len(captured) == 18
-    assert sum(1 for c in captured if c["gw"] is not None) == 8
-    for c in captured:
+    units = [c for c in captured if c.get("kind") != "deconv"]
+    assert len(units) == 18 and len(captured) == 22
+    assert sum(1 for c in units if c["gw"] is not None) == 8
+    for c in units:
         check_unit_backward(c)
+    for c in captured:
+        if c.get("kind") == "deconv":
+            check_deconv_backward(c)
     # end-to-end gradients in L2 (mask flips, see test_gpu_unet.py)
+    num = den = 0.0
     for name in model.params.trainable_names():
         g = model.params[name].grad.cpu().numpy().astype(np.float64)
         ref = grads64[name].numpy()
         l2 = np.linalg.norm(g - ref) / max(np.linalg.norm(ref), 1e-30)
-        l2_cpu32 = np.linalg.norm(grads[name].numpy() - ref) / max(np.linalg.norm(ref), 1e-30)
-        assert l2 < max(1e-2, 5 * l2_cpu32) and l2 < 3e-2, (name, l2, l2_cpu32)
+        assert l2 < 1e-1, (name, l2)            # tiny tensors fed by 4..32 pixels feel single mask flips
+        num += np.sum((g - ref) ** 2)
+        den += np.sum(ref ** 2)
+    assert (num / den) ** 0.5 < 5e-3           # whole gradient vector
     for name, ref in new_stats.items():
         np.testing.assert_allclose(model.params[name].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-6)
     assert ("UNet" not in model.name) and model.metrics_dict["Liver/Dice"].item() >= 0.0
