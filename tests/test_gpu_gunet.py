@@ -108,7 +108,7 @@ def test_gunet_matches_oracle(normalizer, loss_type, g_ch):
     assert (num / den) ** 0.5 < 5e-3           # whole gradient vector
     for name, ref in new_stats.items():
         np.testing.assert_allclose(model.params[name].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-6)
-    assert ("UNet" not in model.name) and model.metrics_dict["Liver/Dice"].item() >= 0.0
+    assert model.name == "GUNet" and model.metrics_dict["Liver/Dice"].item() >= 0.0
 
 
 def test_gunet_trains_and_checkpoint_names():
