@@ -84,19 +84,29 @@ class UNet(base.BaseNet):
     def _net_arg_scope(self, *args, **kwargs):
         """UNet.py:41-56: conv2d -> normaliser (no bias) + ReLU; conv2d_transpose -> bias + ReLU."""
         if getattr(self.args, "without_norm", False):
-            raise NotImplementedError("--without_norm (conv + bias + ReLU) has no HIP kernel yet")
-        self._norm = self._get_normalization()
-        if self._norm[0] != "batch_norm":
-            raise NotImplementedError("--normalizer instance_norm has no HIP kernel yet in the 2-D UNet")
+            self._norm = ("none", {})
+        else:
+            self._norm = self._get_normalization()
         return self._norm
 
     def _conv_unit(self, x, scope, out=None):
         p = self.params
-        bn = scope + "/BatchNorm"
-        nparams = self._norm[1]
-        spec = ops.NormSpec("batch_norm", nparams["eps"], nparams["decay"], bool(nparams["is_training"]))
-        z = ops.Conv3x3NormRelu.apply(x, p[scope + "/weights"], p[bn + "/gamma"], p[bn + "/beta"],
-                                      p[bn + "/moving_mean"], p[bn + "/moving_variance"], spec, out, None, None, None)
+        kind, nparams = self._norm
+        if kind == "none":           # UNet.py:47-48: conv + bias + ReLU
+            spec = ops.NormSpec("none", 0.0, 0.0, self.is_training)
+            z = ops.Conv3x3NormRelu.apply(x, p[scope + "/weights"], None, p[scope + "/biases"], None, None, spec, out,
+                                          None, None, None)
+        elif kind == "batch_norm":
+            bn = scope + "/BatchNorm"
+            spec = ops.NormSpec("batch_norm", nparams["eps"], nparams["decay"], bool(nparams["is_training"]))
+            z = ops.Conv3x3NormRelu.apply(x, p[scope + "/weights"], p[bn + "/gamma"], p[bn + "/beta"],
+                                          p[bn + "/moving_mean"], p[bn + "/moving_variance"], spec, out, None, None,
+                                          None)
+        else:                        # slim.instance_norm defaults: centre + scale, eps 1e-6
+            inn = scope + "/InstanceNorm"
+            spec = ops.NormSpec("instance_norm", nparams["eps"], 0.0, self.is_training)
+            z = ops.Conv3x3NormRelu.apply(x, p[scope + "/weights"], p[inn + "/gamma"], p[inn + "/beta"], None, None,
+                                          spec, out, None, None, None)
         if self._taps is not None:
             self._taps[scope] = z
         return z

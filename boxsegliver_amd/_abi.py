@@ -28,7 +28,7 @@ class DeconvDesc(Structure):
 
 class NormDesc(Structure):
     _fields_ = [("N", c_int32), ("HW", c_int32), ("C", c_int32), ("per_sample", c_int32), ("z_stride", c_int32),
-                ("guide_ch", c_int32), ("gw_stride", c_int32), ("gw_coff", c_int32)]
+                ("guide_ch", c_int32), ("gw_stride", c_int32), ("gw_coff", c_int32), ("affine_only", c_int32)]
 
 
 class HeadDesc(Structure):
@@ -65,7 +65,7 @@ _SIGNATURES = {
     "unetk_head_fwd": (c_int, [POINTER(HeadDesc), P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "unetk_head_bwd": (c_int, [POINTER(HeadDesc), P, P, P, P, P, P, c_float, c_float, P, P, P, P, P, c_size_t, P]),
     "unetk_head_predict": (c_int, [P, c_int64, c_int, P, P, P]),
-    "unetk_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, P]),
+    "unetk_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_float, P]),
     "unetk_momentum_step": (c_int, [P, P, P, c_int64, c_float, c_float, c_int, c_float, c_float, P]),
     "unetk_sumsq": (c_int, [P, c_int64, P, P, c_size_t, P]),
 }

@@ -141,14 +141,16 @@ class Solver(object):
         if self.optimizer == "momentum":
             return self.optimizer_params or {"momentum": 0.9}
         if self.optimizer == "adamw":
-            raise NotImplementedError("AdamW (tf.contrib.opt) is not built yet")
+            # solver.py:212-216: contrib_opt.AdamWOptimizer(weight_decay=--weight_decay_rate, beta1 .9, beta2 .99);
+            # decoupled decay var -= weight_decay * var on EVERY variable, on top of the L2 regularisers
+            return self.optimizer_params or {"weight_decay": self._args.weight_decay_rate, "beta1": 0.9, "beta2": 0.99}
         raise ValueError("Not supported optimizer: " + self.optimizer)
 
     def _ensure_state(self, store):
         if self._state is None:
             self._state = {}
             for grp in ("reg", "noreg"):
-                if self.optimizer == "adam":
+                if self.optimizer in ("adam", "adamw"):
                     self._state[grp] = (torch.zeros_like(store.flat[grp]), torch.zeros_like(store.flat[grp]))
                 else:
                     self._state[grp] = (torch.zeros_like(store.flat[grp]),)
@@ -179,12 +181,13 @@ class Solver(object):
         state = self._ensure_state(store)
         t = self.global_step + 1
         for grp, wd in (("reg", l2 or 0.0), ("noreg", 0.0)):
-            if self.optimizer == "adam":
+            if self.optimizer in ("adam", "adamw"):
                 b1, b2 = hp.get("beta1", 0.9), hp.get("beta2", 0.999)
                 eps = hp.get("epsilon", 1e-8)
                 lr_t = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
                 m, v = state[grp]
-                ops.adam_step(store.flat[grp], store.grad[grp], m, v, lr_t, b1, b2, eps, gscale, wd)
+                dwd = float(hp.get("weight_decay", 0.0) or 0.0) if self.optimizer == "adamw" else 0.0
+                ops.adam_step(store.flat[grp], store.grad[grp], m, v, lr_t, b1, b2, eps, gscale, wd, dwd)
             else:
                 (acc,) = state[grp]
                 ops.momentum_step(store.flat[grp], store.grad[grp], acc, lr, hp.get("momentum", 0.9),

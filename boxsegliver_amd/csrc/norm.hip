@@ -127,7 +127,7 @@ struct BwdArgs {
   float* partial;       // [K][Ns][nblk][C] (reduce pass)
   float* dy;
   int64_t P;
-  int C, dzs, cq_n, rpi, gw_stride, gw_coff, Ns;
+  int C, dzs, cq_n, rpi, gw_stride, gw_coff, Ns, plain;
 };
 
 // pass 1: partial[0] = sum du, partial[1] = sum du*xhat, partial[2+g] = sum du*guide_g   (du = dz * (u > 0))
@@ -205,6 +205,10 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdArgs a) {
   float4 k1 = ldg4(a.sums + so), k2 = ldg4(a.sums + (int64_t)a.Ns * a.C + so);
   k1.x *= inv_p; k1.y *= inv_p; k1.z *= inv_p; k1.w *= inv_p;
   k2.x *= inv_p; k2.y *= inv_p; k2.z *= inv_p; k2.w *= inv_p;
+  if (a.plain) {   // no normalisation (--without_norm): dy = du * scale
+    k1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    k2 = k1;
+  }
   const int64_t base = (int64_t)n * a.P;
   for (int64_t pix = (int64_t)blockIdx.x * a.rpi + rl; pix < a.P; pix += (int64_t)gridDim.x * a.rpi) {
     const float4 v = ldg4(a.y + (base + pix) * a.C + cq * 4);
@@ -353,7 +357,7 @@ extern "C" int unetk_norm_relu_bwd(const unetk_norm_desc* d, const float* y, con
   float* tmp1 = psum + (size_t)K * d->C;
   float* tmp2 = tmp1 + unetk_rows_reduce_tmp_floats(K * g.Ns, nblk, d->C);
   BwdArgs a{y, dz, scale, shift, mean, rstd, guide, gw, gb, sums, partial, dy, g.P, d->C, dz_stride, g.cq_n, g.rpi,
-            d->gw_stride, d->gw_coff, g.Ns};
+            d->gw_stride, d->gw_coff, g.Ns, d->affine_only};
   const size_t lds = (size_t)K * g.rpi * d->C * sizeof(float);
   G_DISPATCH(G, hipLaunchKernelGGL(norm_bwd_reduce_kernel<GG>, dim3(nblk, g.Ns), dim3(256), lds, st, a));
   UNETK_LAUNCH_CHECK();

@@ -9,8 +9,9 @@ namespace {
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, float lr_t, float b1, float b2,
-                                                   float eps, float gscale, float l2) {
+                                                   float eps, float gscale, float l2, float dwd) {
   const int64_t n4 = n >> 2;
+  const float keep = 1.f - dwd;   // tf.contrib.opt.AdamWOptimizer: var -= weight_decay * var, then the Adam update
   const float c1 = 1.f - b1, c2 = 1.f - b2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 pv = ldg4(p + i * 4), mv = ldg4(m + i * 4), vv = ldg4(v + i * 4);
@@ -20,7 +21,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const float gg = fmaf(l2, pv.f, gv.f * gscale); \
     mv.f += c1 * (gg - mv.f);                     \
     vv.f += c2 * (gg * gg - vv.f);                \
-    pv.f -= lr_t * mv.f / (sqrtf(vv.f) + eps);    \
+    pv.f = pv.f * keep - lr_t * mv.f / (sqrtf(vv.f) + eps); \
   }
     ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
 #undef ADAM1
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const float gg = fmaf(l2, p[t], g[t] * gscale);
     m[t] += c1 * (gg - m[t]);
     v[t] += c2 * (gg * gg - v[t]);
-    p[t] -= lr_t * m[t] / (sqrtf(v[t]) + eps);
+    p[t] = p[t] * keep - lr_t * m[t] / (sqrtf(v[t]) + eps);
   }
 }
 
@@ -80,11 +81,11 @@ inline int flat_grid(int64_t n4) {
 }  // namespace
 
 extern "C" int unetk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,
-                               float beta2, float eps, float gscale, float l2, void* stream) {
+                               float beta2, float eps, float gscale, float l2, float decoupled_wd, void* stream) {
   UNETK_REQUIRE(p && g && m && v && n > 0);
   UNETK_REQUIRE(unetk_aligned16(p) && unetk_aligned16(g) && unetk_aligned16(m) && unetk_aligned16(v));
   hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(n >> 2)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, beta1,
-                     beta2, eps, gscale, l2);
+                     beta2, eps, gscale, l2, decoupled_wd);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }

@@ -319,9 +319,9 @@ def head_predict(probs, ncls, want_preds=True):
     return amax, preds
 
 
-def adam_step(p, g, m, v, lr_t, beta1, beta2, eps, gscale=1.0, l2=0.0):
+def adam_step(p, g, m, v, lr_t, beta1, beta2, eps, gscale=1.0, l2=0.0, decoupled_wd=0.0):
     check(_abi.lib().unetk_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr_t, beta1, beta2, eps, gscale, l2,
-                                     stream_ptr()), "adam_step")
+                                     decoupled_wd, stream_ptr()), "adam_step")
 
 
 def momentum_step(p, g, acc, lr, mom, nesterov, gscale=1.0, l2=0.0):
@@ -341,7 +341,7 @@ class NormSpec(object):
     """How a conv unit is normalised (the slim arg_scope state around slim.conv2d)."""
 
     def __init__(self, kind="batch_norm", eps=1e-3, decay=0.999, training=True):
-        assert kind in ("batch_norm", "instance_norm")
+        assert kind in ("batch_norm", "instance_norm", "none")   # "none" = --without_norm: conv + bias + ReLU
         self.kind, self.eps, self.decay, self.training = kind, eps, decay, training
 
     @property
@@ -367,7 +367,8 @@ class Conv3x3NormRelu(torch.autograd.Function):
             if need_dx:
                 raise _abi.UnetkError("conv3x3 input gradient needs Cin%64==0 and Cout%16==0 "
                                       "(got {}->{})".format(cin, cout))
-        use_batch_stats = spec.training or spec.per_sample
+        plain = spec.kind == "none"
+        use_batch_stats = (spec.training or spec.per_sample) and not plain
         y, stats, rows = conv3x3_fwd(x, wp_f, cout, want_stats=use_batch_stats)
         z = out if out is not None else torch.empty_like(y)
         g_ch = 0 if guide is None else guide.shape[-1]
@@ -375,8 +376,14 @@ class Conv3x3NormRelu(torch.autograd.Function):
             gw = gw.contiguous()
             gb = gb.contiguous()
         d = norm_desc(y.shape, spec.per_sample, _pix_stride(z), g_ch, cout if g_ch else 0, 0)
-        aff = norm_finalize(d, stats, rows, gamma, beta, spec.eps, spec.decay, spec.training, moving_mean, moving_var,
-                            y.device)
+        if plain:
+            # --without_norm (UNet.py:47-48): z = relu(y + bias); `beta` carries the conv bias
+            d.affine_only = 1
+            one, zero = torch.ones_like(beta), torch.zeros_like(beta)
+            aff = torch.stack([zero, one, one, beta.detach()]).reshape(4, 1, cout).contiguous()
+        else:
+            aff = norm_finalize(d, stats, rows, gamma, beta, spec.eps, spec.decay, spec.training, moving_mean,
+                                moving_var, y.device)
         norm_apply_relu(d, y, aff, z, guide, gw, gb)
         if spec.training:
             ctx.save_for_backward(x, y, aff, guide, gw, gb)

@@ -98,6 +98,8 @@ typedef struct unetk_norm_desc {
   int32_t per_sample;          /* 0 = batch norm (one statistic group), 1 = instance norm (N groups) */
   int32_t z_stride;            /* pixel stride of the activated output (concat placement) */
   int32_t guide_ch, gw_stride, gw_coff;
+  int32_t affine_only;         /* 1 = no normalisation (--without_norm, UNet.py:47-48: conv + bias + ReLU):
+                                  backward skips the statistics terms, dbeta is the bias gradient */
 } unetk_norm_desc;
 
 /* Finalise the conv's statistic partials ([2][stat_rows][C], each image's tiles contiguous) into
@@ -196,9 +198,11 @@ int unetk_head_predict(const float* probs, int64_t npix, int ncls, uint8_t* argm
 /* ---------------------------------------------------------------- optimiser  core/solver.py:204-243
  * tf.train.AdamOptimizer on a flat parameter buffer.  g' = g*gscale + l2*p  (slim.l2_regularizer
  * gradient, base.py:128-135);  m += (1-b1)(g'-m);  v += (1-b2)(g'^2-v);
- * p -= lr_t * m / (sqrt(v) + eps)  with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller. */
+ * p -= lr_t * m / (sqrt(v) + eps)  with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller.
+ * decoupled_wd > 0 = tf.contrib.opt.AdamWOptimizer (solver.py:212-216): p <- p*(1 - wd) first. */
 int unetk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t,
-                    float beta1, float beta2, float eps, float gscale, float l2, void* stream);
+                    float beta1, float beta2, float eps, float gscale, float l2, float decoupled_wd,
+                    void* stream);
 /* tf.train.MomentumOptimizer: acc = mom*acc + g'; p -= lr*acc (nesterov: lr*(g' + mom*acc)). */
 int unetk_momentum_step(float* p, const float* g, float* acc, int64_t n, float lr, float mom,
                         int nesterov, float gscale, float l2, void* stream);

@@ -40,10 +40,11 @@ class _FakeStore(object):
         self.grad = {"reg": torch.zeros(n), "noreg": torch.zeros(8)}
 
 
-def _cpu_adam(p, g, m, v, lr_t, b1, b2, eps, gscale=1.0, l2=0.0):
+def _cpu_adam(p, g, m, v, lr_t, b1, b2, eps, gscale=1.0, l2=0.0, decoupled_wd=0.0):
     gg = g * gscale + l2 * p
     m += (1 - b1) * (gg - m)
     v += (1 - b2) * (gg * gg - v)
+    p.mul_(1.0 - decoupled_wd)
     p -= lr_t * m / (v.sqrt() + eps)
 
 

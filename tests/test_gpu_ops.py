@@ -393,3 +393,16 @@ def test_adam_and_momentum_match_tf_formulas(ops):
     np.testing.assert_allclose(pd2.cpu().numpy(), pm["w"], rtol=2e-5, atol=2e-6)
     s = ops.sumsq(pd2).item()
     assert abs(s - float((pd2.double() ** 2).sum())) < 1e-3 * s
+    # AdamW (tf.contrib.opt.AdamWOptimizer, solver.py:212-216): var <- var*(1 - wd), then the Adam update
+    pw = rng.standard_normal(n).astype(np.float32)
+    g = rng.standard_normal(n).astype(np.float32)
+    ref = {"w": pw.astype(np.float64).copy()}
+    ref["w"] *= (1 - 0.05)
+    opt2 = osolver.TFAdam(0.9, 0.99, 1e-8)
+    dec = pw.astype(np.float64) * (1 - 0.05)
+    tmp = {"w": pw.astype(np.float64).copy()}
+    opt2.step(tmp, {"w": g.astype(np.float64)}, 1e-3)
+    expect = dec + (tmp["w"] - pw.astype(np.float64))
+    pd3, m3, v3 = dev(pw), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    ops.adam_step(pd3, dev(g), m3, v3, 1e-3 * math.sqrt(1 - 0.99) / (1 - 0.9), 0.9, 0.99, 1e-8, 1.0, 0.0, 0.05)
+    np.testing.assert_allclose(pd3.cpu().numpy(), expect, rtol=2e-5, atol=2e-6)

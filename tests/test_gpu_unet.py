@@ -290,3 +290,47 @@ def test_full_size_properties_bs32_256():
         solver(loss, model)
     assert model(inputs, "train", **yml).item() < loss1.item()
     assert len(mm_before) == 36
+
+
+@pytest.mark.parametrize("variant", ["instance_norm", "without_norm"])
+def test_unet_norm_variants_match_oracle(variant):
+    """--normalizer instance_norm (base.py:163-165) and --without_norm (UNet.py:47-48: conv + bias + ReLU)."""
+    from boxsegliver_amd import ops
+    over = dict(normalizer="instance_norm") if variant == "instance_norm" else dict(without_norm=True)
+    args = make_args(**over)
+    images, labels = synth(2, 32, 32, 3)
+    model, inputs = build(args, images, labels)
+    ncls = 3
+    net = unet2d.UNet2DOracle(3, ncls, normalizer=args.normalizer, without_norm=args.without_norm)
+    assert [(n, tuple(s), k) for n, s, k in net.specs] == [(n, tuple(s), k) for n, s, k in model.params.specs]
+    params = unet2d.init_params(net.specs, seed=21)
+    g = torch.Generator().manual_seed(6)
+    for name, _, kind in net.specs:
+        if kind == "gamma":
+            params[name] = 0.5 + torch.rand(params[name].shape, generator=g)
+        elif kind in ("beta", "bias"):
+            params[name] = 0.1 * torch.randn(params[name].shape, generator=g)
+    model.params.load_state(params)
+    total, _, logits, grads, _ = net.loss_and_grads(params, torch.from_numpy(images), torch.from_numpy(labels).long(),
+                                                    **loss_kwargs(args))
+    ops.DEBUG_CAPTURE = []
+    try:
+        model.params.zero_grad()
+        loss = model(inputs, "train", **YML)
+        loss.backward()
+        torch.cuda.synchronize()
+        captured = ops.DEBUG_CAPTURE
+    finally:
+        ops.DEBUG_CAPTURE = None
+    assert abs(loss.item() - total.item()) < 1e-4 * max(1.0, abs(total.item()))
+    assert np.abs(model.layers["logits"].cpu().numpy() - logits.numpy()).max() < 1e-3
+    if variant == "instance_norm":
+        for c in [c for c in captured if c.get("kind") != "deconv"]:
+            check_unit_backward(c)
+    num = den = 0.0
+    for name in model.params.trainable_names():
+        gg = model.params[name].grad.cpu().numpy().astype(np.float64)
+        ref = grads[name].numpy().astype(np.float64)
+        num += np.sum((gg - ref) ** 2)
+        den += np.sum(ref ** 2)
+    assert (num / den) ** 0.5 < 1e-2
