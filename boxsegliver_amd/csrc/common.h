@@ -48,6 +48,47 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 // ---- internal cross-file helpers (not part of the C ABI)
+// Operand of the 2-D conv kernels.  "Images" are (n, d) planes of an N(D)HWC tensor: image i lives at
+//   (i / group) * group_stride + (i % group) * img_stride   floats,
+// so a depth-sliced / depth-strided view of a 5-D tensor (the taps of a 3-D conv) is addressed without copies.
+struct ImgAddr {
+  int64_t img_stride, group_stride;
+  int group;
+  __host__ __device__ int64_t off(int i) const { return (int64_t)(i / group) * group_stride + (int64_t)(i % group) * img_stride; }
+};
+static inline ImgAddr unetk_dense_addr(int H, int W, int pix_stride) {
+  ImgAddr a;
+  a.img_stride = (int64_t)H * W * pix_stride;
+  a.group_stride = 0;
+  a.group = 1 << 30;
+  return a;
+}
+
+struct ConvParams {
+  const float* x;
+  const float* wp;
+  float* y;
+  float* stat;
+  int N, H, W, Cin, Cout, xs, ys;   // N = number of images (planes)
+  int tiles_h, tiles_w, n_ntiles, stat_rows;
+  ImgAddr xa, ya;
+  int accumulate;                    // epilogue: y += acc (depth taps of a 3-D conv), statistics on the sum
+};
+int unetk_conv_run(ConvParams p, hipStream_t st);          // conv_igemm.hip: picks the tile configuration
+int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout);
+
+struct WgParams {
+  const float* x;
+  const float* dy;
+  const float* zeros;  // >= 256 B of zeros in global memory: source of out-of-image halo pixels
+  float* slab;
+  int N, H, W, Cin, Cout, xs, ys;
+  int tiles_h, tiles_w, total_tiles, tiles_per_split, n_ci_tiles, n_co_tiles;
+  ImgAddr xa, ya;
+};
+// conv_wgrad.hip: dw[9][Cin][Cout] = filter gradient of one 2-D tap plane; ws layout as unetk_conv3x3_wgrad
+size_t unetk_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout);
+int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
 // dst[i] = sum_s slab[s*n + i] in fixed order (n % 4 == 0).
 int unetk_launch_slab_reduce(const float* slab, int S, int64_t n, float* dst, hipStream_t st);
 // dst[k][c] = sum_rows src[k][row][c] (fp64 accumulate).  tmp: K*64*C floats when rows > 256.

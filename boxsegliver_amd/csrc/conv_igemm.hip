@@ -22,15 +22,6 @@ constexpr int PS = 20;   // LDS pixel stride (floats): 16 + 4 pad -> conflict-fr
 constexpr int TW = 16;   // spatial tile width
 constexpr int HWD = TW + 2;
 
-struct ConvParams {
-  const float* x;
-  const float* wp;
-  float* y;
-  float* stat;
-  int N, H, W, Cin, Cout, xs, ys;
-  int tiles_h, tiles_w, n_ntiles, stat_rows;
-};
-
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p) {
   constexpr int NT = WM * WN * 64;
@@ -40,8 +31,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
   constexpr int HALO_F = HALO_PIX * PS;
   constexpr int WB_F = CK * BN;
   constexpr int HR = (HALO_PIX * 4 + NT - 1) / NT;   // float4 halo loads per thread
-  constexpr int WR = (CK / 4 * BN) / NT;             // float4 weight loads per thread
-  static_assert((CK / 4 * BN) % NT == 0, "weight panel must split evenly");
+  constexpr int WR = (CK / 4 * BN + NT - 1) / NT;    // float4 weight loads per thread
+  constexpr int WF4 = CK / 4 * BN;                   // float4s in one weight panel
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* halo = smem;               // [2][HALO_F]
@@ -61,6 +52,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
   const int n_img = mtile / (p.tiles_w * p.tiles_h);
   const int h0 = th_i * TH, w0 = tw_i * TW, n0 = ntile * BN;
 
+  const int64_t ximg = p.xa.off(n_img), yimg = p.ya.off(n_img);
+
   // ---- per-thread staging geometry (fixed across the K loop)
   int64_t hoff[HR];
   bool hok[HR];
@@ -72,7 +65,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
     const int hh = pix / HWD, ww = pix - hh * HWD;
     const int gh = h0 - 1 + hh, gw = w0 - 1 + ww;
     hok[r] = (idx < HALO_PIX * 4) && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
-    hoff[r] = (((int64_t)n_img * p.H + gh) * p.W + gw) * p.xs + q * 4;
+    hoff[r] = ximg + ((int64_t)gh * p.W + gw) * p.xs + q * 4;
     hlds[r] = (idx < HALO_PIX * 4) ? pix * PS + q * 4 : -1;
   }
   const int cin4 = p.Cin >> 2;
@@ -98,12 +91,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
   auto load_w = [&](int c, int t) {
     const float* base = p.wp + ((int64_t)t * cin4 + c * (CK / 4)) * p.Cout * 4;
 #pragma unroll
-    for (int r = 0; r < WR; ++r) wreg[r] = ldg4(base + woff[r]);
+    for (int r = 0; r < WR; ++r)
+      if (tid + r * NT < WF4) wreg[r] = ldg4(base + woff[r]);
   };
   auto store_w = [&](int buf) {
 #pragma unroll
     for (int r = 0; r < WR; ++r)
-      *reinterpret_cast<float4*>(&wbuf[buf * WB_F + (tid + r * NT) * 4]) = wreg[r];
+      if (tid + r * NT < WF4) *reinterpret_cast<float4*>(&wbuf[buf * WB_F + (tid + r * NT) * 4]) = wreg[r];
   };
 
   // ---- fragment addresses
@@ -181,10 +175,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
       const int i = mfma32_row(r, h);
       const int gh = h0 + 2 * sub + (i >> 4), gw = w0 + (i & 15);
       if (gh < p.H && gw < p.W) {
-        float* yp = p.y + (((int64_t)n_img * p.H + gh) * p.W + gw) * p.ys + n0 + wn * TN * 32 + l31;
+        float* yp = p.y + yimg + ((int64_t)gh * p.W + gw) * p.ys + n0 + wn * TN * 32 + l31;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-          const float v = acc[tm][tn][r];
+          float v = acc[tm][tn][r];
+          if (p.accumulate) v += yp[tn * 32];
           yp[tn * 32] = v;
           ssum[tn] += v;
           ssq[tn] += v * v;
@@ -240,7 +235,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvParams p) {
         for (int kw = 0; kw < 3; ++kw) {
           const int iw = gw + kw - 1;
           if (iw < 0 || iw >= p.W) continue;
-          const float* xp = p.x + (((int64_t)n_img * p.H + ih) * p.W + iw) * p.xs;
+          const float* xp = p.x + p.xa.off(n_img) + ((int64_t)ih * p.W + iw) * p.xs;
           const float* wq = p.wp + ((int64_t)(kh * 3 + kw) * p.Cin) * p.Cout + cq * 4;
           for (int ci = 0; ci < p.Cin; ++ci) {
             const float xv = xp[ci];
@@ -252,7 +247,12 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvParams p) {
           }
         }
       }
-      stg4(p.y + (((int64_t)n_img * p.H + gh) * p.W + gw) * p.ys + cq * 4, a);
+      float* yp = p.y + p.ya.off(n_img) + ((int64_t)gh * p.W + gw) * p.ys + cq * 4;
+      if (p.accumulate) {
+        const float4 o = ldg4(yp);
+        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+      }
+      stg4(yp, a);
       s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
       sq.x += a.x * a.x; sq.y += a.y * a.y; sq.z += a.z * a.z; sq.w += a.w * a.w;
     }
@@ -304,13 +304,14 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, int Cin, int Co
 }
 
 struct ConvCfg {
-  int id;  // 0: 128x128 tile, 1: 128x64 tile, -1: direct
+  int id;  // 0: 128x128 tile, 1: 128x64 tile, 2: 256x32 tile (UNet3D's 30-channel levels, padded to 32), -1: direct
   int th;
 };
 
 inline ConvCfg pick_cfg(int Cin, int Cout) {
   if (Cin % CK == 0 && Cout % 128 == 0) return {0, 8};
   if (Cin % CK == 0 && Cout % 64 == 0) return {1, 8};
+  if (Cin % CK == 0 && Cout % 32 == 0) return {2, 16};
   return {-1, 8};
 }
 
@@ -333,7 +334,14 @@ int launch_igemm(const ConvParams& p, int n_mtiles, hipStream_t st) {
   return UNETK_OK;
 }
 
-int conv_run(ConvParams p, hipStream_t st) {
+}  // namespace
+
+int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout) {
+  const ConvCfg cfg = pick_cfg(Cin, Cout);
+  return N * ((H + cfg.th - 1) / cfg.th) * ((W + TW - 1) / TW);
+}
+
+int unetk_conv_run(ConvParams p, hipStream_t st) {
   const ConvCfg cfg = pick_cfg(p.Cin, p.Cout);
   p.tiles_h = (p.H + cfg.th - 1) / cfg.th;
   p.tiles_w = (p.W + TW - 1) / TW;
@@ -347,6 +355,10 @@ int conv_run(ConvParams p, hipStream_t st) {
     p.n_ntiles = p.Cout / 64;
     return launch_igemm<4, 1, 1, 2>(p, n_mtiles, st);
   }
+  if (cfg.id == 2) {
+    p.n_ntiles = p.Cout / 32;
+    return launch_igemm<4, 1, 2, 1>(p, n_mtiles, st);
+  }
   if (p.Cout % 4 != 0 || p.Cout > 1024) return UNETK_E_UNSUPPORTED;
   const int PL = 256 / (p.Cout / 4);
   const size_t lds = p.stat ? (size_t)2 * PL * p.Cout * sizeof(float) : 0;
@@ -355,6 +367,8 @@ int conv_run(ConvParams p, hipStream_t st) {
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
+
+namespace {
 
 bool conv_desc_ok(const unetk_conv_desc* d) {
   return d && d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->x_stride >= d->Cin &&
@@ -391,7 +405,9 @@ extern "C" int unetk_conv3x3_fwd(const unetk_conv_desc* d, const float* x, const
   ConvParams p{};
   p.x = x; p.wp = w; p.y = y; p.stat = stat_partials;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.xs = d->x_stride; p.ys = d->y_stride;
-  return conv_run(p, (hipStream_t)stream);
+  p.xa = unetk_dense_addr(p.H, p.W, p.xs);
+  p.ya = unetk_dense_addr(p.H, p.W, p.ys);
+  return unetk_conv_run(p, (hipStream_t)stream);
 }
 
 extern "C" int unetk_conv3x3_dgrad(const unetk_conv_desc* d, const float* dy, const float* w, float* dx,
@@ -404,5 +420,7 @@ extern "C" int unetk_conv3x3_dgrad(const unetk_conv_desc* d, const float* dy, co
   ConvParams p{};
   p.x = dy; p.wp = w; p.y = dx; p.stat = nullptr;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cout; p.Cout = d->Cin; p.xs = d->y_stride; p.ys = d->x_stride;
-  return conv_run(p, (hipStream_t)stream);
+  p.xa = unetk_dense_addr(p.H, p.W, p.xs);
+  p.ya = unetk_dense_addr(p.H, p.W, p.ys);
+  return unetk_conv_run(p, (hipStream_t)stream);
 }

@@ -1,86 +1,92 @@
-// conv3x3 filter gradient (Conv2DBackpropFilter of slim.conv2d(x, C, 3), NetworksV2/UNet.py:79,85,94)
-// as a split-K GEMM on the fp32 matrix cores: dW[tap][ci][co] = sum_pixels x[pixel + tap][ci] * dy[pixel][co].
+// conv3x3 filter gradient (Conv2DBackpropFilter of slim.conv2d(x, C, 3), NetworksV2/UNet.py:79,85,94; one
+// depth tap of slim.conv3d, UNet3D.py:153,165) as a split-K GEMM on the fp32 matrix cores:
+//   dW[tap][ci][co] = sum_pixels x[pixel + tap][ci] * dy[pixel][co].
 //
-// GEMM view: M = ci, N = co, K = pixels.  A 512-thread block owns a 64(ci) x 64(co) x 9(taps) output
-// panel and walks a contiguous range of 8x16 pixel tiles.  Per tile the 10x18 x-halo and the 8x16 dy tile
-// (77 KB) are brought in by ASYNC direct-to-LDS loads (global_load_lds_dwordx4: no VGPRs, 1 KiB per
-// wave-instruction) into the OTHER half of a 2-stage LDS ring while all eight waves run MFMAs on the
-// current half: one barrier per tile, global latency fully behind 576 MFMAs per wave-pair.  ALL NINE taps
-// accumulate from the one staged halo (9 x 16 accumulator registers per wave); waves 0-3 take pixel rows
-// 0-3 of the tile, waves 4-7 rows 4-7 (two waves per SIMD), and are summed through LDS once at the end.
-// Partial panels go to a workspace slab per split; a fixed-order reduction sums the slabs ->
-// bit-reproducible, no atomics (SURVEY.md 7 "wgrad").
+// GEMM view: M = ci, N = co, K = pixels.  A 512-thread block owns a CIT(ci) x COT(co) x 9(taps) output panel
+// (CIT, COT in {32, 64}) and walks a contiguous range of 8x16 pixel tiles.  Per tile the 10x18 x-halo and the
+// 8x16 dy tile are brought in by ASYNC direct-to-LDS loads (global_load_lds_dwordx4: no VGPRs, 1 KiB per
+// wave-instruction) into the OTHER half of a 2-stage LDS ring while all eight waves run MFMAs on the current
+// half: one barrier per tile, global latency fully behind the MFMAs.  ALL NINE taps accumulate from the one
+// staged halo (9 x 16 accumulator registers per wave); the eight waves split (pixel rows) x (ci half) x (co half)
+// and the pixel-row slices are summed through LDS in a fixed-order tree at the end.  Partial panels go to a
+// workspace slab per split; a fixed-order reduction sums the slabs -> bit-reproducible, no atomics.
 #include "common.h"
 
 namespace {
 
 constexpr int TW = 16, TH = 8, HWD = TW + 2, HH = TH + 2;
-constexpr int CT = 64;                                   // channel tile (both ci and co)
-constexpr int XH_F = HH * HWD * CT;                      // 11520 floats: x halo   [180 pixels][64]
-constexpr int STAGE_F = XH_F + TH * TW * CT;             // 19712 floats: + dy tile [128 pixels][64]
-constexpr int NI_X = HH * HWD / 4;                       // 45 wave-instructions (4 pixels x 256 B each)
-constexpr int NI = NI_X + TH * TW / 4;                   // 77 per tile
-constexpr int IPW = (NI + 7) / 8;                        // 10 per wave
-static_assert(HH * HWD % 4 == 0 && XH_F == NI_X * 256, "halo must be a whole number of 1 KiB pieces");
+constexpr int HALO_PIX = HH * HWD;   // 180
+constexpr int CT = 64;
+constexpr size_t WG_LDS_BYTES = 157696;   // 2 stages of the 64x64 panel; also holds the 147 KB reduction scratch
 
-struct WgParams {
-  const float* x;
-  const float* dy;
-  const float* zeros;  // >= 256 B of zeros in global memory: source of out-of-image halo pixels
-  float* slab;
-  int N, H, W, Cin, Cout, xs, ys;
-  int tiles_h, tiles_w, total_tiles, tiles_per_split, n_ci_tiles, n_co_tiles;
+template <int CIT, int COT>
+struct WgGeom {
+  static constexpr int WCI = CIT / 32, WCO = COT / 32;
+  static constexpr int KS = 8 / (WCI * WCO);            // pixel-row slices
+  static constexpr int RPW = TH / KS;                   // tile rows per wave
+  static constexpr int PPX = 256 / CIT;                 // pixels per 1-KiB piece of the x halo
+  static constexpr int PPY = 256 / COT;
+  static constexpr int NI_X = (HALO_PIX + PPX - 1) / PPX;   // 45 (CIT 64) / 23 (CIT 32, last piece half dummy)
+  static constexpr int NI_Y = TH * TW / PPY;
+  static constexpr int NI = NI_X + NI_Y;
+  static constexpr int IPW = (NI + 7) / 8;
+  static constexpr int XH_F = NI_X * 256;
+  static constexpr int STAGE_F = XH_F + NI_Y * 256;
+  static_assert(2 * STAGE_F * sizeof(float) <= WG_LDS_BYTES, "ring must fit");
 };
 
+template <int CIT, int COT>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
+  using G = WgGeom<CIT, COT>;
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][STAGE_F]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int khalf = wave >> 2, wci = (wave >> 1) & 1, wco = wave & 1;
+  const int wco = wave % G::WCO, wci = (wave / G::WCO) % G::WCI, ks = wave / (G::WCO * G::WCI);
   const int l31 = lane & 31, h = lane >> 5;
 
   int bid = blockIdx.x;
   const int co_t = bid % p.n_co_tiles; bid /= p.n_co_tiles;
   const int ci_t = bid % p.n_ci_tiles; bid /= p.n_ci_tiles;
   const int split = bid;
-  const int ci0 = ci_t * CT, co0 = co_t * CT;
+  const int ci0 = ci_t * CIT, co0 = co_t * COT;
 
-  // ---- staging geometry: wave w issues pieces j = w + 8 i; lane = (pixel lp of the piece, float4 q)
-  const int lp = lane >> 4, q = lane & 15;
-  int rel_h[IPW], rel_w[IPW];   // pixel position relative to the tile origin
+  // ---- staging geometry: wave w issues pieces j = w + 8 i; lane = (pixel of the piece, float4 of the pixel)
+  const int lpx = lane / (CIT / 4), qx = lane % (CIT / 4);
+  const int lpy = lane / (COT / 4), qy = lane % (COT / 4);
+  int rel_h[G::IPW], rel_w[G::IPW];   // pixel position relative to the tile origin; rel_h = 1<<20 marks a dummy
 #pragma unroll
-  for (int i = 0; i < IPW; ++i) {
+  for (int i = 0; i < G::IPW; ++i) {
     const int j = wave + 8 * i;
-    if (j < NI_X) {
-      const int pix = 4 * j + lp;
-      rel_h[i] = pix / HWD - 1;
+    if (j < G::NI_X) {
+      const int pix = G::PPX * j + lpx;
+      rel_h[i] = pix < HALO_PIX ? pix / HWD - 1 : (1 << 20);
       rel_w[i] = pix % HWD - 1;
     } else {
-      const int pix = 4 * (j - NI_X) + lp;
+      const int pix = G::PPY * (j - G::NI_X) + lpy;
       rel_h[i] = pix >> 4;
       rel_w[i] = pix & 15;
     }
   }
-  const float* zsrc = p.zeros + q * 4;
 
   auto issue_tile = [&](int tile, int stage) {
     const int tw_i = tile % p.tiles_w;
     const int th_i = (tile / p.tiles_w) % p.tiles_h;
     const int n_img = tile / (p.tiles_w * p.tiles_h);
     const int h0 = th_i * TH, w0 = tw_i * TW;
-    const int64_t img_base = (int64_t)n_img * p.H;
+    const int64_t ximg = p.xa.off(n_img), yimg = p.ya.off(n_img);
 #pragma unroll
-    for (int i = 0; i < IPW; ++i) {
+    for (int i = 0; i < G::IPW; ++i) {
       const int j = wave + 8 * i;
-      if (j < NI) {   // wave-uniform
+      if (j < G::NI) {   // wave-uniform
         const int gh = h0 + rel_h[i], gw = w0 + rel_w[i];
         const bool ok = gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
-        const int64_t pixoff = (img_base + gh) * p.W + gw;
-        const float* src = (j < NI_X) ? p.x + pixoff * p.xs + ci0 + q * 4 : p.dy + pixoff * p.ys + co0 + q * 4;
-        if (!ok) src = zsrc;
-        float* dst = smem + stage * STAGE_F + j * 256;   // wave-uniform; lanes land at dst + lane*16 B
+        const int64_t pixoff = (int64_t)gh * p.W + gw;
+        const float* src = (j < G::NI_X) ? p.x + ximg + pixoff * p.xs + ci0 + qx * 4
+                                          : p.dy + yimg + pixoff * p.ys + co0 + qy * 4;
+        if (!ok) src = p.zeros + (lane & 15) * 4;
+        float* dst = smem + stage * G::STAGE_F + j * 256;   // wave-uniform; lanes land at dst + lane*16 B
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       }
@@ -106,56 +112,66 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
     __syncthreads();
     if (tile + 1 < t_end) issue_tile(tile + 1, stage ^ 1);
 
-    const float* xh = smem + stage * STAGE_F;
-    const float* dyt = xh + XH_F;
-    // this wave's 32 k-steps (rows 4*khalf .. +3); lane half h takes the odd/even column of a pixel pair
+    const float* xh = smem + stage * G::STAGE_F;
+    const float* dyt = xh + G::XH_F;
+    // this wave's k-steps (rows RPW*ks .. +RPW); lane half h takes the odd/even column of a pixel pair
 #pragma unroll 1
-    for (int rr = 0; rr < TH / 2; ++rr) {
-      const int r = khalf * (TH / 2) + rr;
+    for (int rr = 0; rr < G::RPW; ++rr) {
+      const int r = ks * G::RPW + rr;
 #pragma unroll
       for (int c2 = 0; c2 < TW / 2; ++c2) {
         const int col = 2 * c2 + h;
-        const float b = dyt[(r * TW + col) * CT + b_lane];
-        const float* xa = &xh[(r * HWD + col) * CT + a_lane];
+        const float b = dyt[(r * TW + col) * COT + b_lane];
+        const float* xa = &xh[(r * HWD + col) * CIT + a_lane];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
-            const float a = xa[(kh * HWD + kw) * CT];
+            const float a = xa[(kh * HWD + kw) * CIT];
             acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[kh * 3 + kw], 0, 0, 0);
           }
       }
     }
   }
 
-  // ---- sum the two pixel-row halves through LDS (fixed order), then write the slab
-  __syncthreads();
-  float* red = smem;  // [4 wave pairs][144][64 lanes] = 147456 B <= 2 * STAGE_F * 4
-  const int pair = wave & 3;
-  if (khalf == 1) {
+  // ---- sum the pixel-row slices through LDS: fixed-order binary tree over ks, <= 4 writer waves per round
+  float* red = smem;  // [<=4 waves][144][64 lanes] = 147456 B
+  const int pidx = wci * G::WCO + wco;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+  for (int step = G::KS / 2; step >= 1; step >>= 1) {
+    __syncthreads();
+    if (ks >= step && ks < 2 * step) {
+      const int slot = (ks - step) * (G::WCI * G::WCO) + pidx;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[(pair * 144 + t * 16 + r) * 64 + lane] = acc[t][r];
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(slot * 144 + t * 16 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (ks < step) {
+      const int slot = ks * (G::WCI * G::WCO) + pidx;
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] += red[(slot * 144 + t * 16 + r) * 64 + lane];
+    }
   }
-  __syncthreads();
-  if (khalf == 0) {
+  if (ks == 0) {
     float* out = p.slab + (int64_t)split * 9 * p.Cin * p.Cout;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = ci0 + wci * 32 + mfma32_row(r, h);
-        out[((int64_t)t * p.Cin + ci) * p.Cout + co0 + b_lane] = acc[t][r] + red[(pair * 144 + t * 16 + r) * 64 + lane];
+        out[((int64_t)t * p.Cin + ci) * p.Cout + co0 + b_lane] = acc[t][r];
       }
   }
 }
 
-
-// Small-Cin filter gradient for Cout = 64 and 9*Cin <= 32 (Encode1/conv1: Cin = 3).  HBM-bound on
-// reading dy once (537 MB at cfg1); the 27 x 64 contraction over pixels still goes through the matrix
-// cores (M = (tap, ci) padded to 32, N = co, K = pixels) because the scalar version is VALU-issue bound
-// (27 FMAs + 27 loads per pixel per lane), ~15x off the HBM roofline.
+// Small-Cin filter gradient for Cout = 64 and 9*Cin <= 32 (Encode1/conv1: Cin = 3; UNet3D conv_e0/conv1:
+// Cin = 1).  HBM-bound on reading dy once (537 MB at cfg1); the 27 x 64 contraction over pixels still goes
+// through the matrix cores (M = (tap, ci) padded to 32, N = co, K = pixels) because the scalar version is
+// VALU-issue bound (27 FMAs + 27 loads per pixel per lane), ~15x off the HBM roofline.
 // 4 waves = (pixel-row half) x (co half); dy tile by direct-to-LDS loads, x halo (Cin floats / pixel).
 __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_kernel(WgParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -185,23 +201,23 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_kernel(WgParams p) {
     const int th_i = (tile / p.tiles_w) % p.tiles_h;
     const int n_img = tile / (p.tiles_w * p.tiles_h);
     const int h0 = th_i * TH, w0 = tw_i * TW;
-    const int64_t img_base = (int64_t)n_img * p.H;
+    const int64_t ximg = p.xa.off(n_img), yimg = p.ya.off(n_img);
     __syncthreads();   // previous tile's fragment reads are done
 #pragma unroll
     for (int i = 0; i < 8; ++i) {          // dy: piece j = wave + 4 i covers pixels 4j .. 4j+3
       const int j = wave + 4 * i;
       const int pix = 4 * j + lp;
       const int gh = h0 + (pix >> 4), gw = w0 + (pix & 15);
-      const float* src = (gh < p.H && gw < p.W) ? p.dy + ((img_base + gh) * p.W + gw) * p.ys + q * 4
+      const float* src = (gh < p.H && gw < p.W) ? p.dy + yimg + ((int64_t)gh * p.W + gw) * p.ys + q * 4
                                                 : p.zeros + q * 4;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(dyt + j * 256), 16, 0, 0);
     }
-    for (int idx = tid; idx < HH * HWD * 4; idx += 256) {
+    for (int idx = tid; idx < HALO_PIX * 4; idx += 256) {
       const int pix = idx >> 2, c = idx & 3;
       const int gh = h0 - 1 + pix / HWD, gw = w0 - 1 + pix % HWD;
       float v = 0.f;
-      if (c < cin && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W) v = p.x[((img_base + gh) * p.W + gw) * p.xs + c];
+      if (c < cin && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W) v = p.x[ximg + ((int64_t)gh * p.W + gw) * p.xs + c];
       xh[idx] = v;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -254,10 +270,11 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(WgParams p) {
       const int th_i = (tile / p.tiles_w) % p.tiles_h;
       const int n_img = tile / (p.tiles_w * p.tiles_h);
       const int h0 = th_i * TH, w0 = tw_i * TW;
+      const int64_t ximg = p.xa.off(n_img), yimg = p.ya.off(n_img);
       for (int pix = pl; pix < TH * TW; pix += PL) {
         const int gh = h0 + (pix >> 4), gw = w0 + (pix & 15);
         if (gh >= p.H || gw >= p.W) continue;
-        const float g = p.dy[(((int64_t)n_img * p.H + gh) * p.W + gw) * p.ys + co];
+        const float g = p.dy[yimg + ((int64_t)gh * p.W + gw) * p.ys + co];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
           const int ih = gh + kh - 1;
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(WgParams p) {
           for (int kw = 0; kw < 3; ++kw) {
             const int iw = gw + kw - 1;
             if (iw < 0 || iw >= p.W) continue;
-            const float* xp = p.x + (((int64_t)n_img * p.H + ih) * p.W + iw) * p.xs;
+            const float* xp = p.x + ximg + ((int64_t)ih * p.W + iw) * p.xs;
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) acc[(kh * 3 + kw) * CIN + ci] = fmaf(xp[ci], g, acc[(kh * 3 + kw) * CIN + ci]);
           }
@@ -342,25 +359,28 @@ namespace {
 
 struct WgPlan {
   int mode;  // 0 mfma, 1 small-Cin, -1 unsupported
+  int cit, cot;
   int tiles_h, tiles_w, total_tiles, S, tiles_per_split, n_ci_tiles, n_co_tiles;
 };
 
-WgPlan wg_plan(const unetk_conv_desc* d) {
+WgPlan wg_plan(int N, int H, int W, int Cin, int Cout) {
   WgPlan pl{};
-  pl.tiles_h = (d->H + TH - 1) / TH;
-  pl.tiles_w = (d->W + TW - 1) / TW;
-  pl.total_tiles = d->N * pl.tiles_h * pl.tiles_w;
-  if (d->Cin % CT == 0 && d->Cout % CT == 0) {
+  pl.tiles_h = (H + TH - 1) / TH;
+  pl.tiles_w = (W + TW - 1) / TW;
+  pl.total_tiles = N * pl.tiles_h * pl.tiles_w;
+  if (Cin % 32 == 0 && Cout % 32 == 0) {
     pl.mode = 0;
-    pl.n_ci_tiles = d->Cin / CT;
-    pl.n_co_tiles = d->Cout / CT;
+    pl.cit = Cin % 64 == 0 ? 64 : 32;
+    pl.cot = Cout % 64 == 0 ? 64 : 32;
+    pl.n_ci_tiles = Cin / pl.cit;
+    pl.n_co_tiles = Cout / pl.cot;
     const int panels = pl.n_ci_tiles * pl.n_co_tiles;
-    int S = (512 + panels - 1) / panels;  // one 512-thread block per CU (155 KB of LDS) x 256 CUs x 2 rounds
+    int S = (512 + panels - 1) / panels;  // one 512-thread block per CU (154 KB of LDS) x 256 CUs x 2 rounds
     if (S > pl.total_tiles) S = pl.total_tiles;
     if (S < 1) S = 1;
     pl.tiles_per_split = (pl.total_tiles + S - 1) / S;
     pl.S = (pl.total_tiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
-  } else if (d->Cin <= 4 && d->Cout <= 256 && 256 % d->Cout == 0) {
+  } else if (Cin <= 4 && Cout <= 256 && 256 % Cout == 0) {
     pl.mode = 1;
     int S = 2048;
     if (S > pl.total_tiles) S = pl.total_tiles;
@@ -372,13 +392,69 @@ WgPlan wg_plan(const unetk_conv_desc* d) {
   return pl;
 }
 
+template <int CIT, int COT>
+int launch_wgrad(const WgParams& p, int grid, hipStream_t st) {
+  auto kern = conv3x3_wgrad_kernel<CIT, COT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), WG_LDS_BYTES, st, p);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
 }  // namespace
+
+size_t unetk_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout) {
+  const WgPlan pl = wg_plan(N, H, W, Cin, Cout);
+  if (pl.mode < 0) return 0;
+  return 256 + (size_t)pl.S * 9 * Cin * Cout * sizeof(float);  // 256 B zero page + slabs
+}
+
+int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
+  const WgPlan pl = wg_plan(p.N, p.H, p.W, p.Cin, p.Cout);
+  if (pl.mode < 0) return UNETK_E_UNSUPPORTED;
+  if (ws_bytes < unetk_wgrad_ws_bytes(p.N, p.H, p.W, p.Cin, p.Cout)) return UNETK_E_WORKSPACE;
+  p.zeros = (const float*)ws;
+  p.slab = (float*)ws + 64;
+  p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.total_tiles = pl.total_tiles;
+  p.tiles_per_split = pl.tiles_per_split; p.n_ci_tiles = pl.n_ci_tiles; p.n_co_tiles = pl.n_co_tiles;
+  hipError_t ez = hipMemsetAsync(ws, 0, 256, st);
+  if (ez != hipSuccess) return (int)ez;
+  int rc = UNETK_OK;
+  if (pl.mode == 0) {
+    if (p.xs % 4 != 0 || p.ys % 4 != 0) return UNETK_E_BADARG;
+    const int grid = pl.S * pl.n_ci_tiles * pl.n_co_tiles;
+    if (pl.cit == 64 && pl.cot == 64) rc = launch_wgrad<64, 64>(p, grid, st);
+    else if (pl.cit == 64) rc = launch_wgrad<64, 32>(p, grid, st);
+    else if (pl.cot == 64) rc = launch_wgrad<32, 64>(p, grid, st);
+    else rc = launch_wgrad<32, 32>(p, grid, st);
+    if (rc != UNETK_OK) return rc;
+  } else if (9 * p.Cin <= 32 && p.Cout == CT && p.ys % 4 == 0) {
+    const size_t lds3 = (size_t)(TH * TW * CT + HALO_PIX * 4) * sizeof(float);
+    hipLaunchKernelGGL(conv3x3_wgrad_c3_kernel, dim3(pl.S), dim3(256), lds3, st, p);
+    UNETK_LAUNCH_CHECK();
+  } else {
+    const int PL = 256 / p.Cout;
+    const size_t lds = (size_t)PL * 9 * p.Cin * p.Cout * sizeof(float);
+    if (lds > 64 * 1024) return UNETK_E_UNSUPPORTED;
+    switch (p.Cin) {
+      case 1: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<1>, dim3(pl.S), dim3(256), lds, st, p); break;
+      case 2: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<2>, dim3(pl.S), dim3(256), lds, st, p); break;
+      case 3: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<3>, dim3(pl.S), dim3(256), lds, st, p); break;
+      default: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<4>, dim3(pl.S), dim3(256), lds, st, p); break;
+    }
+    UNETK_LAUNCH_CHECK();
+  }
+  return unetk_launch_slab_reduce((const float*)ws + 64, pl.S, (int64_t)9 * p.Cin * p.Cout, dw, st);
+}
 
 extern "C" size_t unetk_conv3x3_wgrad_ws_bytes(const unetk_conv_desc* d) {
   if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return 0;
-  const WgPlan pl = wg_plan(d);
-  if (pl.mode < 0) return 0;
-  return 256 + (size_t)pl.S * 9 * d->Cin * d->Cout * sizeof(float);  // 256 B zero page + slabs
+  return unetk_wgrad_ws_bytes(d->N, d->H, d->W, d->Cin, d->Cout);
 }
 
 extern "C" int unetk_conv3x3_wgrad(const unetk_conv_desc* d, const float* x, const float* dy, float* dw,
@@ -387,49 +463,10 @@ extern "C" int unetk_conv3x3_wgrad(const unetk_conv_desc* d, const float* x, con
   UNETK_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0);
   UNETK_REQUIRE(d->x_stride >= d->Cin && d->y_stride >= d->Cout);
   UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(dy) && unetk_aligned16(dw) && unetk_aligned16(ws));
-  const WgPlan pl = wg_plan(d);
-  if (pl.mode < 0) return UNETK_E_UNSUPPORTED;
-  if (ws_bytes < unetk_conv3x3_wgrad_ws_bytes(d)) return UNETK_E_WORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
   WgParams p{};
-  p.x = x; p.dy = dy; p.zeros = (const float*)ws; p.slab = (float*)ws + 64;
+  p.x = x; p.dy = dy;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.xs = d->x_stride; p.ys = d->y_stride;
-  p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.total_tiles = pl.total_tiles;
-  p.tiles_per_split = pl.tiles_per_split; p.n_ci_tiles = pl.n_ci_tiles; p.n_co_tiles = pl.n_co_tiles;
-  if (pl.mode == 0) {
-    UNETK_REQUIRE(d->x_stride % 4 == 0 && d->y_stride % 4 == 0);
-    constexpr size_t lds = (size_t)2 * STAGE_F * sizeof(float);  // 157696 B: one block per CU
-    hipError_t ez = hipMemsetAsync(ws, 0, 256, st);
-    if (ez != hipSuccess) return (int)ez;
-    static bool attr_done = false;
-    if (!attr_done) {
-      hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-      attr_done = true;
-    }
-    const int grid = pl.S * pl.n_ci_tiles * pl.n_co_tiles;
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(grid), dim3(512), lds, st, p);
-    UNETK_LAUNCH_CHECK();
-  } else {
-    hipError_t ez = hipMemsetAsync(ws, 0, 256, st);
-    if (ez != hipSuccess) return (int)ez;
-    if (9 * d->Cin <= 32 && d->Cout == CT && d->y_stride % 4 == 0) {
-      const size_t lds3 = (size_t)(TH * TW * CT + HH * HWD * 4) * sizeof(float);
-      hipLaunchKernelGGL(conv3x3_wgrad_c3_kernel, dim3(pl.S), dim3(256), lds3, st, p);
-      UNETK_LAUNCH_CHECK();
-      return unetk_launch_slab_reduce((const float*)ws + 64, pl.S, (int64_t)9 * d->Cin * d->Cout, dw, st);
-    }
-    const int PL = 256 / d->Cout;
-    const size_t lds = (size_t)PL * 9 * d->Cin * d->Cout * sizeof(float);
-    if (lds > 64 * 1024) return UNETK_E_UNSUPPORTED;
-    switch (d->Cin) {
-      case 1: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<1>, dim3(pl.S), dim3(256), lds, st, p); break;
-      case 2: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<2>, dim3(pl.S), dim3(256), lds, st, p); break;
-      case 3: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<3>, dim3(pl.S), dim3(256), lds, st, p); break;
-      default: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<4>, dim3(pl.S), dim3(256), lds, st, p); break;
-    }
-    UNETK_LAUNCH_CHECK();
-  }
-  return unetk_launch_slab_reduce((const float*)ws + 64, pl.S, (int64_t)9 * d->Cin * d->Cout, dw, st);
+  p.xa = unetk_dense_addr(p.H, p.W, p.xs);
+  p.ya = unetk_dense_addr(p.H, p.W, p.ys);
+  return unetk_wgrad_run(p, dw, ws, ws_bytes, (hipStream_t)stream);
 }

@@ -68,6 +68,8 @@ def _igemm_tag(cin, cout):
         return "conv3x3_igemm_kernel<2,2,2,2>"
     if cin % 16 == 0 and cout % 64 == 0:
         return "conv3x3_igemm_kernel<4,1,1,2>"
+    if cin % 16 == 0 and cout % 32 == 0:
+        return "conv3x3_igemm_kernel<4,1,2,1>"
     return "conv3x3_direct_kernel"
 
 
@@ -109,7 +111,7 @@ def conv3x3_pack(w, want_dgrad=True):
 
 
 def conv_uses_mfma(cin, cout):
-    return cin % 16 == 0 and cout % 64 == 0
+    return cin % 16 == 0 and cout % 32 == 0
 
 
 def conv3x3_fwd(x, w, cout, want_stats=True, y=None):

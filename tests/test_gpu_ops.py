@@ -41,6 +41,8 @@ CONV_SHAPES = [
     (1, 16, 16, 128, 64),
     (3, 8, 48, 64, 64),
     (1, 4, 4, 32, 256),        # image smaller than a tile
+    (2, 16, 32, 32, 32),       # 256x32 tile path (UNet3D's 30-channel levels padded to 32)
+    (1, 24, 20, 64, 32),
 ]
 
 
@@ -87,7 +89,8 @@ def test_conv3x3_direct_first_layer(ops):
     np.testing.assert_allclose(s[1].sum(0), (ref ** 2).sum((0, 1, 2)), rtol=2e-5)
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 32, 64, 64), (1, 8, 16, 128, 64), (2, 12, 20, 64, 128), (1, 16, 16, 64, 16 * 8)])
+@pytest.mark.parametrize("shape", [(2, 16, 32, 64, 64), (1, 8, 16, 128, 64), (2, 12, 20, 64, 128), (1, 16, 16, 64, 16 * 8),
+                                   (2, 16, 32, 32, 32), (1, 8, 16, 32, 64), (2, 12, 20, 64, 32), (3, 9, 17, 96, 32)])
 def test_conv3x3_dgrad_wgrad(ops, shape):
     n, h, w, cin, cout = shape
     rng = np.random.default_rng(11 + cin + cout)
