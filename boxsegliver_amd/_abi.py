@@ -26,6 +26,16 @@ class DeconvDesc(Structure):
                 ("out_stride", c_int32), ("out_coff", c_int32)]
 
 
+class Conv3dDesc(Structure):
+    _fields_ = [("N", c_int32), ("D", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
+                ("kd", c_int32), ("sd", c_int32), ("shw", c_int32), ("x_stride", c_int32), ("y_stride", c_int32)]
+
+
+class Deconv3dDesc(Structure):
+    _fields_ = [("N", c_int32), ("D", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
+                ("kd", c_int32), ("out_stride", c_int32), ("out_coff", c_int32)]
+
+
 class NormDesc(Structure):
     _fields_ = [("N", c_int32), ("HW", c_int32), ("C", c_int32), ("per_sample", c_int32), ("z_stride", c_int32),
                 ("guide_ch", c_int32), ("gw_stride", c_int32), ("gw_coff", c_int32), ("affine_only", c_int32)]
@@ -47,6 +57,13 @@ _SIGNATURES = {
     "unetk_conv3x3_dgrad": (c_int, [POINTER(ConvDesc), P, P, P, P]),
     "unetk_conv3x3_wgrad_ws_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "unetk_conv3x3_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, c_size_t, P]),
+    "unetk_conv3d_pack": (c_int, [P, c_int, c_int, c_int, P, P, P]),
+    "unetk_conv3d_out_dims": (c_int, [POINTER(Conv3dDesc), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "unetk_conv3d_stat_rows": (c_int, [POINTER(Conv3dDesc)]),
+    "unetk_conv3d_ws_bytes": (c_size_t, [POINTER(Conv3dDesc)]),
+    "unetk_conv3d_fwd": (c_int, [POINTER(Conv3dDesc), P, P, P, P, P, c_size_t, P]),
+    "unetk_conv3d_dgrad": (c_int, [POINTER(Conv3dDesc), P, P, P, P, c_size_t, P]),
+    "unetk_conv3d_wgrad": (c_int, [POINTER(Conv3dDesc), P, P, P, P, c_size_t, P]),
     "unetk_norm_finalize_ws_bytes": (c_size_t, [POINTER(NormDesc), c_int]),
     "unetk_norm_finalize": (c_int, [POINTER(NormDesc), P, c_int, P, P, c_float, c_float, c_int, P, P, P, P, P, P,
                                     P, c_size_t, P]),
@@ -60,6 +77,10 @@ _SIGNATURES = {
     "unetk_deconv2x2_fwd": (c_int, [POINTER(DeconvDesc), P, P, P, P, P]),
     "unetk_deconv2x2_bwd_ws_bytes": (c_size_t, [POINTER(DeconvDesc)]),
     "unetk_deconv2x2_bwd": (c_int, [POINTER(DeconvDesc), P, P, P, P, P, P, P, P, c_size_t, P]),
+    "unetk_deconv3d_pack": (c_int, [P, c_int, c_int, c_int, P, P, P]),
+    "unetk_deconv3d_fwd": (c_int, [POINTER(Deconv3dDesc), P, P, P, P, P]),
+    "unetk_deconv3d_bwd_ws_bytes": (c_size_t, [POINTER(Deconv3dDesc)]),
+    "unetk_deconv3d_bwd": (c_int, [POINTER(Deconv3dDesc), P, P, P, P, P, P, P, P, c_size_t, P]),
     "unetk_head_result_floats": (c_size_t, [POINTER(HeadDesc)]),
     "unetk_head_ws_bytes": (c_size_t, [POINTER(HeadDesc)]),
     "unetk_head_fwd": (c_int, [POINTER(HeadDesc), P, P, P, P, P, P, P, P, P, c_size_t, P]),

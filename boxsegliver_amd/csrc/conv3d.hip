@@ -1,0 +1,324 @@
+// slim.conv3d (NetworksV2/UNet3D.py:153,165) with kernels (1,3,3) / (3,3,3), strides 1 / (1,2,2) / (2,2,2),
+// TF `SAME` padding (asymmetric for even sizes at stride 2: 0 before, 1 after -- SURVEY.md B2), no bias.
+//
+// Composition over the 2-D fp32-MFMA kernels instead of a separate 3-D kernel family:
+//   * a (kd,3,3) conv is the sum over depth taps dt of (1,3,3) convs on depth-shifted planes; each tap is ONE
+//     launch of conv3x3_igemm over the (n, d_out) planes, addressed in place through ImgAddr (depth slices /
+//     depth-strided views, no copies), accumulating into the output (epilogue y += acc); the tap that covers
+//     every output plane runs last and produces the norm statistics.  Depth stride 2 is just a plane stride.
+//   * H/W stride 2 (10.7 % of UNet3D's FLOPs): forward = stride-1 conv into a scratch tensor + subsample
+//     (which also emits the statistic partials); backward = dilate dy (zero insertion) + the stride-1
+//     dgrad / wgrad kernels -- the identities  dx = conv_s1(dilate(dy), flip(w))  and
+//     dW = wgrad_s1(x, dilate(dy))  hold exactly, at 4x MFMA work on those layers (a native strided tile
+//     is the next optimisation).
+#include "common.h"
+
+namespace {
+
+struct Geo3 {
+  int Do, Ho, Wo;       // output extents
+  int pb_d;             // SAME pad-before in depth
+  int off_h, off_w;     // position of output (ho, wo) in the stride-1 result: 2*ho + off  (stride 2 only)
+};
+
+inline int same_pb(int in, int k, int s) {
+  const int out = (in + s - 1) / s;
+  int total = (out - 1) * s + k - in;
+  if (total < 0) total = 0;
+  return total / 2;
+}
+
+Geo3 geo3(const unetk_conv3d_desc* d) {
+  Geo3 g;
+  g.Do = (d->D + d->sd - 1) / d->sd;
+  g.Ho = (d->H + d->shw - 1) / d->shw;
+  g.Wo = (d->W + d->shw - 1) / d->shw;
+  g.pb_d = same_pb(d->D, d->kd, d->sd);
+  // stride-1 conv pads 1 before; stride-2 SAME pads pb before => y_s2[o] = y_s1[2*o + 1 - pb]
+  g.off_h = 1 - same_pb(d->H, 3, 2);
+  g.off_w = 1 - same_pb(d->W, 3, 2);
+  return g;
+}
+
+// valid output-plane range of depth tap dt: 0 <= do*sd - pb + dt < D
+inline void tap_range(const unetk_conv3d_desc* d, const Geo3& g, int dt, int* lo, int* hi) {
+  int l = g.pb_d - dt;
+  l = l <= 0 ? 0 : (l + d->sd - 1) / d->sd;
+  int h = (d->D - 1 + g.pb_d - dt);
+  h = h < 0 ? -1 : h / d->sd;
+  if (h > g.Do - 1) h = g.Do - 1;
+  *lo = l;
+  *hi = h;
+}
+
+bool desc_ok(const unetk_conv3d_desc* d) {
+  return d && d->N > 0 && d->D > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 &&
+         (d->kd == 1 || d->kd == 3) && (d->sd == 1 || d->sd == 2) && (d->shw == 1 || d->shw == 2) &&
+         !(d->kd == 1 && d->sd != 1) && d->x_stride >= d->Cin && d->y_stride >= d->Cout;
+}
+
+// y[n, do, ho, wo, :] = t[n, do, 2ho+off_h, 2wo+off_w, :]; statistic partials per block, blocks grouped per sample
+__global__ __launch_bounds__(256) void subsample2_stats_kernel(const float* __restrict__ t, float* __restrict__ y,
+                                                               float* __restrict__ stat, int planes_per_sample, int H,
+                                                               int W, int Ho, int Wo, int C, int ys, int off_h,
+                                                               int off_w, int cq_n, int rpi, int bps, int stat_rows) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][rpi][C]
+  const int cq = threadIdx.x % cq_n, rl = threadIdx.x / cq_n;
+  const int n = blockIdx.x / bps, blk = blockIdx.x % bps;
+  const int64_t P = (int64_t)planes_per_sample * Ho * Wo;       // output pixels of this sample
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), sq = s;
+  if (rl < rpi) {
+    for (int64_t pix = (int64_t)blk * rpi + rl; pix < P; pix += (int64_t)bps * rpi) {
+      const int wo = (int)(pix % Wo);
+      const int64_t r = pix / Wo;
+      const int ho = (int)(r % Ho);
+      const int64_t plane = (int64_t)n * planes_per_sample + r / Ho;
+      const float4 v = ldg4(t + ((plane * H + 2 * ho + off_h) * W + 2 * wo + off_w) * C + cq * 4);
+      stg4(y + ((int64_t)n * P + pix) * ys + cq * 4, v);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
+    }
+    if (stat != nullptr) {
+      stg4(&smem[(0 * rpi + rl) * C + cq * 4], s);
+      stg4(&smem[(1 * rpi + rl) * C + cq * 4], sq);
+    }
+  }
+  if (stat == nullptr) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int k = i / C, c = i - k * C;
+    float v = 0.f;
+    for (int j = 0; j < rpi; ++j) v += smem[(k * rpi + j) * C + c];
+    stat[((int64_t)k * stat_rows + blockIdx.x) * C + c] = v;
+  }
+}
+
+// z (pre-zeroed) [planes, H, W, C]: z[p, 2ho+off_h, 2wo+off_w, :] = dy[p, ho, wo, :]
+__global__ __launch_bounds__(256) void dilate2_kernel(const float* __restrict__ dy, int dys, float* __restrict__ z,
+                                                      int64_t npix_out, int H, int W, int Ho, int Wo, int C, int off_h,
+                                                      int off_w) {
+  const int cq_n = C >> 2;
+  const int64_t total = npix_out * cq_n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % cq_n);
+    int64_t r = i / cq_n;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int64_t plane = r / Ho;
+    const float4 v = ldg4(dy + ((plane * Ho + ho) * Wo + wo) * dys + cq * 4);
+    stg4(z + ((plane * H + 2 * ho + off_h) * W + 2 * wo + off_w) * C + cq * 4, v);
+  }
+}
+
+inline ImgAddr planes(int HW_floats, int group, int step, int planes_total) {
+  ImgAddr a;
+  a.img_stride = (int64_t)step * HW_floats;
+  a.group_stride = (int64_t)planes_total * HW_floats;
+  a.group = group;
+  return a;
+}
+
+const int SUB_BPS = 64;   // subsample blocks per sample
+
+}  // namespace
+
+extern "C" int unetk_conv3d_pack(const float* w, int kd, int Cin, int Cout, float* wp_fwd, float* wp_dgrad,
+                                 void* stream) {
+  UNETK_REQUIRE(w && (kd == 1 || kd == 3) && Cin > 0 && Cout > 0);
+  for (int dt = 0; dt < kd; ++dt) {
+    const int64_t o = (int64_t)dt * 9 * Cin * Cout;
+    int rc = unetk_conv3x3_pack(w + o, Cin, Cout, wp_fwd ? wp_fwd + o : nullptr, wp_dgrad ? wp_dgrad + o : nullptr, stream);
+    if (rc != UNETK_OK) return rc;
+  }
+  return UNETK_OK;
+}
+
+extern "C" int unetk_conv3d_out_dims(const unetk_conv3d_desc* d, int* Do, int* Ho, int* Wo) {
+  if (!desc_ok(d)) return UNETK_E_BADARG;
+  const Geo3 g = geo3(d);
+  if (Do) *Do = g.Do;
+  if (Ho) *Ho = g.Ho;
+  if (Wo) *Wo = g.Wo;
+  return UNETK_OK;
+}
+
+extern "C" int unetk_conv3d_stat_rows(const unetk_conv3d_desc* d) {
+  if (!desc_ok(d)) return UNETK_E_BADARG;
+  const Geo3 g = geo3(d);
+  if (d->shw == 2) return d->N * SUB_BPS;
+  return unetk_conv_stat_rows(d->N * g.Do, d->H, d->W, d->Cin, d->Cout);
+}
+
+extern "C" size_t unetk_conv3d_ws_bytes(const unetk_conv3d_desc* d) {
+  if (!desc_ok(d)) return 0;
+  const Geo3 g = geo3(d);
+  size_t f = 0;
+  if (d->shw == 2) f += (size_t)d->N * g.Do * d->H * d->W * d->Cout;          // stride-1 result / dilated dy
+  f = (f + 63) & ~(size_t)63;
+  return f * sizeof(float) + unetk_wgrad_ws_bytes(d->N * g.Do, d->H, d->W, d->Cin, d->Cout);
+}
+
+extern "C" int unetk_conv3d_fwd(const unetk_conv3d_desc* d, const float* x, const float* wp, float* y,
+                                float* stat_partials, void* ws, size_t ws_bytes, void* stream) {
+  UNETK_REQUIRE(desc_ok(d) && x && wp && y);
+  UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(wp) && unetk_aligned16(y) && d->y_stride % 4 == 0);
+  hipStream_t st = (hipStream_t)stream;
+  const Geo3 g = geo3(d);
+  const bool strided = d->shw == 2;
+  float* T = y;
+  int ts = d->y_stride;
+  if (strided) {
+    UNETK_REQUIRE(ws && unetk_aligned16(ws) && d->Cout % 4 == 0);
+    if (ws_bytes < unetk_conv3d_ws_bytes(d)) return UNETK_E_WORKSPACE;
+    T = (float*)ws;
+    ts = d->Cout;
+  }
+  const int HWx = d->H * d->W * d->x_stride, HWt = d->H * d->W * ts;
+  // order: partial-coverage taps first, a full-coverage tap last (it emits the statistics)
+  int order[3], n_taps = 0, full = -1;
+  for (int dt = 0; dt < d->kd; ++dt) {
+    int lo, hi;
+    tap_range(d, g, dt, &lo, &hi);
+    if (lo == 0 && hi == g.Do - 1 && full < 0) full = dt;
+  }
+  if (full < 0) return UNETK_E_UNSUPPORTED;
+  for (int dt = 0; dt < d->kd; ++dt)
+    if (dt != full) order[n_taps++] = dt;
+  order[n_taps++] = full;
+  if (d->kd > 1) {
+    hipError_t e = hipMemsetAsync(T, 0, (size_t)d->N * g.Do * HWt * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+  }
+  for (int i = 0; i < n_taps; ++i) {
+    const int dt = order[i];
+    int lo, hi;
+    tap_range(d, g, dt, &lo, &hi);
+    if (hi < lo) continue;
+    ConvParams p{};
+    p.x = x + (int64_t)(lo * d->sd - g.pb_d + dt) * HWx;
+    p.wp = wp + (int64_t)dt * 9 * d->Cin * d->Cout;
+    p.y = T + (int64_t)lo * HWt;
+    p.stat = (i == n_taps - 1 && !strided) ? stat_partials : nullptr;
+    p.N = d->N * (hi - lo + 1); p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
+    p.xs = d->x_stride; p.ys = ts;
+    p.xa = planes(HWx, hi - lo + 1, d->sd, d->D);
+    p.ya = planes(HWt, hi - lo + 1, 1, g.Do);
+    p.accumulate = d->kd > 1 ? 1 : 0;
+    int rc = unetk_conv_run(p, st);
+    if (rc != UNETK_OK) return rc;
+  }
+  if (strided) {
+    const ColMap m = unetk_colmap(d->Cout);
+    if (d->Cout > 1024) return UNETK_E_UNSUPPORTED;
+    const size_t lds = stat_partials ? (size_t)2 * m.rows_per_iter * d->Cout * sizeof(float) : 0;
+    hipLaunchKernelGGL(subsample2_stats_kernel, dim3(d->N * SUB_BPS), dim3(256), lds, st, T, y, stat_partials, g.Do,
+                       d->H, d->W, g.Ho, g.Wo, d->Cout, d->y_stride, g.off_h, g.off_w, m.cq_n, m.rows_per_iter, SUB_BPS,
+                       d->N * SUB_BPS);
+    UNETK_LAUNCH_CHECK();
+  }
+  return UNETK_OK;
+}
+
+namespace {
+// dy -> (Z, stride) usable by the stride-1 backward kernels
+int dilated_dy(const unetk_conv3d_desc* d, const Geo3& g, const float* dy, void* ws, hipStream_t st, const float** z,
+               int* zs) {
+  if (d->shw == 1) {
+    *z = dy;
+    *zs = d->y_stride;
+    return UNETK_OK;
+  }
+  float* Z = (float*)ws;
+  const size_t n = (size_t)d->N * g.Do * d->H * d->W * d->Cout;
+  hipError_t e = hipMemsetAsync(Z, 0, n * sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  const int64_t npix_out = (int64_t)d->N * g.Do * g.Ho * g.Wo;
+  int64_t grid = (npix_out * (d->Cout / 4) + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(dilate2_kernel, dim3((int)grid), dim3(256), 0, st, dy, d->y_stride, Z, npix_out, d->H, d->W, g.Ho,
+                     g.Wo, d->Cout, g.off_h, g.off_w);
+  UNETK_LAUNCH_CHECK();
+  *z = Z;
+  *zs = d->Cout;
+  return UNETK_OK;
+}
+}  // namespace
+
+extern "C" int unetk_conv3d_dgrad(const unetk_conv3d_desc* d, const float* dy, const float* wp_dgrad, float* dx,
+                                  void* ws, size_t ws_bytes, void* stream) {
+  UNETK_REQUIRE(desc_ok(d) && dy && wp_dgrad && dx);
+  UNETK_REQUIRE(unetk_aligned16(dy) && unetk_aligned16(wp_dgrad) && unetk_aligned16(dx));
+  UNETK_REQUIRE(d->x_stride % 4 == 0 && d->y_stride % 4 == 0 && d->Cout % 4 == 0);
+  hipStream_t st = (hipStream_t)stream;
+  const Geo3 g = geo3(d);
+  if (d->shw == 2) {
+    UNETK_REQUIRE(ws && unetk_aligned16(ws));
+    if (ws_bytes < unetk_conv3d_ws_bytes(d)) return UNETK_E_WORKSPACE;
+  }
+  const float* Z;
+  int zs;
+  int rc = dilated_dy(d, g, dy, ws, st, &Z, &zs);
+  if (rc != UNETK_OK) return rc;
+  const int HWx = d->H * d->W * d->x_stride, HWz = d->H * d->W * zs;
+  const bool multi = d->kd > 1 || d->sd > 1;
+  if (multi) {
+    hipError_t e = hipMemsetAsync(dx, 0, (size_t)d->N * d->D * HWx * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+  }
+  for (int dt = 0; dt < d->kd; ++dt) {
+    int lo, hi;
+    tap_range(d, g, dt, &lo, &hi);
+    if (hi < lo) continue;
+    ConvParams p{};
+    p.x = Z + (int64_t)lo * HWz;                                              // input of the dgrad conv = dy planes
+    p.wp = wp_dgrad + (int64_t)dt * 9 * d->Cin * d->Cout;
+    p.y = dx + (int64_t)(lo * d->sd - g.pb_d + dt) * HWx;                      // output = dx planes di = do*sd - pb + dt
+    p.stat = nullptr;
+    p.N = d->N * (hi - lo + 1); p.H = d->H; p.W = d->W; p.Cin = d->Cout; p.Cout = d->Cin;
+    p.xs = zs; p.ys = d->x_stride;
+    p.xa = planes(HWz, hi - lo + 1, 1, g.Do);
+    p.ya = planes(HWx, hi - lo + 1, d->sd, d->D);
+    p.accumulate = multi ? 1 : 0;
+    rc = unetk_conv_run(p, st);
+    if (rc != UNETK_OK) return rc;
+  }
+  return UNETK_OK;
+}
+
+extern "C" int unetk_conv3d_wgrad(const unetk_conv3d_desc* d, const float* x, const float* dy, float* dw, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  UNETK_REQUIRE(desc_ok(d) && x && dy && dw && ws && unetk_aligned16(ws));
+  UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(dy) && unetk_aligned16(dw) && d->y_stride % 4 == 0);
+  if (ws_bytes < unetk_conv3d_ws_bytes(d)) return UNETK_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const Geo3 g = geo3(d);
+  const float* Z;
+  int zs;
+  int rc = dilated_dy(d, g, dy, ws, st, &Z, &zs);
+  if (rc != UNETK_OK) return rc;
+  size_t zf = d->shw == 2 ? (size_t)d->N * g.Do * d->H * d->W * d->Cout : 0;
+  zf = (zf + 63) & ~(size_t)63;
+  float* wws = (float*)ws + zf;
+  const size_t wws_bytes = ws_bytes - zf * sizeof(float);
+  const int HWx = d->H * d->W * d->x_stride, HWz = d->H * d->W * zs;
+  for (int dt = 0; dt < d->kd; ++dt) {
+    int lo, hi;
+    tap_range(d, g, dt, &lo, &hi);
+    float* dw_t = dw + (int64_t)dt * 9 * d->Cin * d->Cout;
+    if (hi < lo) {
+      hipError_t e = hipMemsetAsync(dw_t, 0, (size_t)9 * d->Cin * d->Cout * sizeof(float), st);
+      if (e != hipSuccess) return (int)e;
+      continue;
+    }
+    WgParams p{};
+    p.x = x + (int64_t)(lo * d->sd - g.pb_d + dt) * HWx;
+    p.dy = Z + (int64_t)lo * HWz;
+    p.N = d->N * (hi - lo + 1); p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
+    p.xs = d->x_stride; p.ys = zs;
+    p.xa = planes(HWx, hi - lo + 1, d->sd, d->D);
+    p.ya = planes(HWz, hi - lo + 1, 1, g.Do);
+    rc = unetk_wgrad_run(p, dw_t, wws, wws_bytes, st);
+    if (rc != UNETK_OK) return rc;
+  }
+  return UNETK_OK;
+}

@@ -1,12 +1,15 @@
-// Transposed conv k=2 s=2 (+bias, ReLU) written straight into the skip-concat buffer, and its backward.
+// Transposed conv with kernel == stride (+bias, ReLU) written straight into the skip-concat buffer, and its
+// backward.  2-D: slim.conv2d_transpose(x, C/2, 2, 2) + tf.concat((skip, up), -1) at NetworksV2/UNet.py:91-93.
+// 3-D: slim.conv3d_transpose(x, c, (1,2,2)|(2,2,2), stride = kernel, biases_initializer=None) + tf.concat at
+// NetworksV2/UNet3D.py:161-163.
 //
-// Replaces slim.conv2d_transpose(x, C/2, 2, 2) + tf.concat((skip, up), -1) at NetworksV2/UNet.py:91-93.
-// With kernel == stride there is no overlap: out[n,2y+a,2x+b,co] = sum_ci x[n,y,x,ci] * w[a,b,co,ci], i.e.
-// ONE dense GEMM  [pixels x Cin] . [Cin x (4*Cout)]  whose epilogue scatters each (a,b) column group to
-// its output pixel -- genuinely dense, so it runs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
-//   forward : M = input pixels, N = (a,b,co), K = ci      epilogue: +bias, ReLU, scatter into concat buffer
-//   dgrad   : M = input pixels, N = ci,       K = (a,b,co) A rows gathered from the 4 output pixels
-//   wgrad   : per (a,b): [co x ci] = sum_pixels dpre[pix(a,b)][co] * x[pix][ci]   (split-K slabs, fixed order)
+// With kernel == stride there is no overlap: out[n,(kd z+a),2y+b,2x+c,co] = sum_ci x[n,z,y,x,ci] * w[a,b,c,co,ci],
+// i.e. per depth tap a ONE dense GEMM  [pixels x Cin] . [Cin x (4*Cout)]  whose epilogue scatters each (b,c)
+// column group to its output pixel -- genuinely dense, so it runs on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32).  Depth taps address their output planes in place (ImgAddr), no copies.
+//   forward : M = input pixels, N = (b,c,co), K = ci      epilogue: +bias, ReLU, scatter into the concat buffer
+//   dgrad   : M = input pixels, N = ci,       K = (b,c,co) A rows gathered from the 4 output pixels
+//   wgrad   : per (a,b,c): [co x ci] = sum_pixels dpre[pix(a,b,c)][co] * x[pix][ci]  (split-K slabs, fixed order)
 #include "common.h"
 
 namespace {
@@ -14,14 +17,16 @@ namespace {
 constexpr int CK = 16, PS = 20;
 
 struct PwParams {
-  const float* a;     // fwd: x [M][Cin]; dgrad: dpre [N,2H,2W,Cout]
+  const float* a;     // fwd: x [M][Cin]; dgrad: dpre planes [.,2H,2W,Cout]
   const float* wp;    // K4-interleaved [K/4][Ncols][4]
   const float* bias;  // fwd only
   float* out;
   int M, K, Ncols;
-  int H, W, Cout;     // input spatial dims, deconv output channels
+  int H, W, Cout;     // input spatial dims (per plane), deconv output channels
   int out_stride, out_coff;
   int n_ntiles;
+  ImgAddr oa;         // fwd: output plane of input plane nn;  dgrad: dpre plane of input plane nn
+  int accumulate;     // dgrad: dx += (second depth tap)
 };
 
 // MODE 0: forward (scatter epilogue), MODE 1: dgrad (gather prologue)
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_gemm_kernel(PwParams p) {
       const int xx = m % p.W;
       const int yy = (m / p.W) % p.H;
       const int nn = m / (p.W * p.H);
-      aoff[r] = (((int64_t)nn * 2 * p.H + 2 * yy) * 2 * p.W + 2 * xx) * p.Cout + q * 4;
+      aoff[r] = p.oa.off(nn) + ((int64_t)(2 * yy) * 2 * p.W + 2 * xx) * p.Cout + q * 4;
     }
   }
   int64_t woff[WR];
@@ -174,10 +179,11 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_gemm_kernel(PwParams p) {
           const int xx = m % p.W;
           const int yy = (m / p.W) % p.H;
           const int nn = m / (p.W * p.H);
-          const int64_t opix = ((int64_t)nn * 2 * p.H + 2 * yy + (ab >> 1)) * 2 * p.W + 2 * xx + (ab & 1);
-          p.out[opix * p.out_stride + p.out_coff + co] = fmaxf(acc[tm][tn][r] + bv, 0.f);
+          const int64_t o = p.oa.off(nn) + ((int64_t)(2 * yy + (ab >> 1)) * 2 * p.W + 2 * xx + (ab & 1)) * p.out_stride;
+          p.out[o + p.out_coff + co] = fmaxf(acc[tm][tn][r] + bv, 0.f);
         } else {
-          p.out[(int64_t)m * p.Ncols + n] = acc[tm][tn][r];
+          float* o = p.out + (int64_t)m * p.Ncols + n;
+          *o = p.accumulate ? *o + acc[tm][tn][r] : acc[tm][tn][r];
         }
       }
   }
@@ -213,13 +219,14 @@ __global__ __launch_bounds__(256) void relu_bwd_bias_kernel(const float* __restr
   }
 }
 
-// wgrad: slab[split][ab][co][ci] = sum over the split's pixels of dpre[pix(m,ab)][co] * x[m][ci]
+// wgrad: slab[split][bc][co][ci] = sum over the split's pixels of dpre[pix(m,bc)][co] * x[m][ci]
 struct DwParams {
   const float* x;
   const float* dpre;
   float* slab;
   int M, H, W, Cin, Cout;
   int m_per_split, n_co_tiles, n_ci_tiles;
+  ImgAddr da;   // dpre plane of input plane nn
 };
 
 __global__ __launch_bounds__(256) void deconv_wgrad_kernel(DwParams p) {
@@ -252,8 +259,8 @@ __global__ __launch_bounds__(256) void deconv_wgrad_kernel(DwParams p) {
         const int xx = m % p.W;
         const int yy = (m / p.W) % p.H;
         const int nn = m / (p.W * p.H);
-        const int64_t opix = ((int64_t)nn * 2 * p.H + 2 * yy + (ab >> 1)) * 2 * p.W + 2 * xx + (ab & 1);
-        va = ldg4(p.dpre + opix * p.Cout + co0 + q * 4);
+        const int64_t o = p.da.off(nn) + ((int64_t)(2 * yy + (ab >> 1)) * 2 * p.W + 2 * xx + (ab & 1)) * p.Cout;
+        if (co0 + q * 4 < p.Cout) va = ldg4(p.dpre + o + co0 + q * 4);      // Cout may be 32: half a co tile
         vb = ldg4(p.x + (int64_t)m * p.Cin + ci0 + q * 4);
       }
       *reinterpret_cast<float4*>(&at[row * CT + q * 4]) = va;
@@ -271,12 +278,12 @@ __global__ __launch_bounds__(256) void deconv_wgrad_kernel(DwParams p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int co = co0 + wco * 32 + mfma32_row(r, h);
-    out[(int64_t)co * p.Cin + ci0 + wci * 32 + l31] = acc[r];
+    if (co < p.Cout) out[(int64_t)co * p.Cin + ci0 + wci * 32 + l31] = acc[r];
   }
 }
 
-// wp_fwd[q][n=(ab,co)][j] = w[ab][co][4q+j]   (K = Cin)
-// wp_dgrad[q][n=ci][j]    = w_flat[(4q+j)][ci] with w_flat = [(ab,co)][ci]   (K = 4*Cout)
+// wp_fwd[q][n=(bc,co)][j] = w[bc][co][4q+j]   (K = Cin)
+// wp_dgrad[q][n=ci][j]    = w_flat[(4q+j)][ci] with w_flat = [(bc,co)][ci]   (K = 4*Cout)
 __global__ void pack_deconv_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ wp_fwd,
                                    float* __restrict__ wp_dgrad) {
   const int64_t total = (int64_t)Cin * Cout;  // float4 count = 4*Cin*Cout/4
@@ -306,18 +313,28 @@ int launch_pw(const PwParams& p, hipStream_t st) {
   return UNETK_OK;
 }
 
-bool deconv_desc_ok(const unetk_deconv_desc* d) {
-  return d && d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->out_coff >= 0 &&
-         d->out_stride >= d->out_coff + d->Cout;
+template <int MODE>
+int run_pw(PwParams& p, hipStream_t st) {
+  if (p.Ncols % 128 == 0) {
+    p.n_ntiles = p.Ncols / 128;
+    return launch_pw<MODE, 2, 2, 2, 2>(p, st);
+  }
+  p.n_ntiles = p.Ncols / 64;
+  return launch_pw<MODE, 4, 1, 1, 2>(p, st);
+}
+
+bool deconv_desc_ok(const unetk_deconv3d_desc* d) {
+  return d && d->N > 0 && d->D > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && (d->kd == 1 || d->kd == 2) &&
+         d->out_coff >= 0 && d->out_stride >= d->out_coff + d->Cout;
 }
 
 struct DwPlan {
   int S, m_per_split, nblk_bias;
 };
-DwPlan dw_plan(const unetk_deconv_desc* d) {
+DwPlan dw_plan(const unetk_deconv3d_desc* d) {
   DwPlan pl{};
-  const int M = d->N * d->H * d->W;
-  const int panels = 4 * (d->Cin / 64) * (d->Cout / 64);
+  const int M = d->N * d->D * d->H * d->W;
+  const int panels = 4 * (d->Cin / 64) * ((d->Cout + 63) / 64);
   int S = (1024 + panels - 1) / panels;
   const int mtiles = (M + 127) / 128;
   if (S > mtiles) S = mtiles;
@@ -326,107 +343,152 @@ DwPlan dw_plan(const unetk_deconv_desc* d) {
   pl.m_per_split = tiles_per * 128;
   pl.S = (mtiles + tiles_per - 1) / tiles_per;
   const ColMap m = unetk_colmap(d->Cout);
-  int64_t g = ((int64_t)4 * M + m.rows_per_iter - 1) / m.rows_per_iter;
+  int64_t g = ((int64_t)4 * d->kd * M + m.rows_per_iter - 1) / m.rows_per_iter;
   if (g > UNETK_COL_BLOCKS) g = UNETK_COL_BLOCKS;
   pl.nblk_bias = (int)g;
   return pl;
 }
 
+unetk_deconv3d_desc from2d(const unetk_deconv_desc* d) {
+  unetk_deconv3d_desc e;
+  e.N = d->N; e.D = 1; e.H = d->H; e.W = d->W; e.Cin = d->Cin; e.Cout = d->Cout; e.kd = 1;
+  e.out_stride = d->out_stride; e.out_coff = d->out_coff;
+  return e;
+}
+
 }  // namespace
 
-extern "C" int unetk_deconv2x2_pack(const float* w, int Cin, int Cout, float* wp_fwd, float* wp_dgrad,
-                                    void* stream) {
-  UNETK_REQUIRE(w && Cin > 0 && Cout > 0);
+extern "C" int unetk_deconv3d_pack(const float* w, int kd, int Cin, int Cout, float* wp_fwd, float* wp_dgrad,
+                                   void* stream) {
+  UNETK_REQUIRE(w && (kd == 1 || kd == 2) && Cin > 0 && Cout > 0);
   if (Cin % 4 != 0 || Cout % 4 != 0) return UNETK_E_UNSUPPORTED;
   UNETK_REQUIRE(unetk_aligned16(w) && unetk_aligned16(wp_fwd) && unetk_aligned16(wp_dgrad));
   const int64_t total = (int64_t)Cin * Cout;
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(pack_deconv_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, wp_fwd, wp_dgrad);
-  UNETK_LAUNCH_CHECK();
+  for (int a = 0; a < kd; ++a) {
+    const int64_t o = (int64_t)a * 4 * Cin * Cout;
+    hipLaunchKernelGGL(pack_deconv_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w + o, Cin, Cout,
+                       wp_fwd ? wp_fwd + o : nullptr, wp_dgrad ? wp_dgrad + o : nullptr);
+    UNETK_LAUNCH_CHECK();
+  }
   return UNETK_OK;
 }
 
-extern "C" int unetk_deconv2x2_fwd(const unetk_deconv_desc* d, const float* x, const float* wp_fwd,
-                                   const float* bias, float* out, void* stream) {
+extern "C" int unetk_deconv3d_fwd(const unetk_deconv3d_desc* d, const float* x, const float* wp_fwd,
+                                  const float* bias, float* out, void* stream) {
   UNETK_REQUIRE(deconv_desc_ok(d) && x && wp_fwd && out);
   UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(wp_fwd));
   if (d->Cin % CK != 0 || d->Cout % 16 != 0) return UNETK_E_UNSUPPORTED;
-  PwParams p{};
-  p.a = x; p.wp = wp_fwd; p.bias = bias; p.out = out;
-  p.M = d->N * d->H * d->W; p.K = d->Cin; p.Ncols = 4 * d->Cout;
-  p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.out_stride = d->out_stride; p.out_coff = d->out_coff;
-  if (p.Ncols % 128 == 0) {
-    p.n_ntiles = p.Ncols / 128;
-    return launch_pw<0, 2, 2, 2, 2>(p, (hipStream_t)stream);
+  const int64_t plane = (int64_t)4 * d->H * d->W * d->out_stride;      // one output depth plane
+  for (int a = 0; a < d->kd; ++a) {
+    PwParams p{};
+    p.a = x; p.wp = wp_fwd + (int64_t)a * 4 * d->Cin * d->Cout; p.bias = bias; p.out = out + a * plane;
+    p.M = d->N * d->D * d->H * d->W; p.K = d->Cin; p.Ncols = 4 * d->Cout;
+    p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.out_stride = d->out_stride; p.out_coff = d->out_coff;
+    p.oa.group = d->D; p.oa.img_stride = d->kd * plane; p.oa.group_stride = (int64_t)d->kd * d->D * plane;
+    int rc = run_pw<0>(p, (hipStream_t)stream);
+    if (rc != UNETK_OK) return rc;
   }
-  p.n_ntiles = p.Ncols / 64;
-  return launch_pw<0, 4, 1, 1, 2>(p, (hipStream_t)stream);
+  return UNETK_OK;
 }
 
-extern "C" size_t unetk_deconv2x2_bwd_ws_bytes(const unetk_deconv_desc* d) {
-  if (!deconv_desc_ok(d) || d->Cin % 64 != 0 || d->Cout % 64 != 0) return 0;
+extern "C" size_t unetk_deconv3d_bwd_ws_bytes(const unetk_deconv3d_desc* d) {
+  if (!deconv_desc_ok(d) || d->Cin % 64 != 0 || d->Cout % 32 != 0) return 0;
   const DwPlan pl = dw_plan(d);
-  const size_t M = (size_t)d->N * d->H * d->W;
-  size_t f = 4 * M * d->Cout;                               // dpre
+  const size_t M = (size_t)d->N * d->D * d->H * d->W;
+  size_t f = 4 * d->kd * M * d->Cout;                       // dpre
   f += (size_t)pl.nblk_bias * d->Cout;                      // bias partials
   f += unetk_rows_reduce_tmp_floats(1, pl.nblk_bias, d->Cout);
+  f += (size_t)d->Cout;                                     // dbias sink when the caller passes NULL
+  f = (f + 3) & ~(size_t)3;
   f += (size_t)pl.S * 4 * d->Cin * d->Cout;                 // wgrad slabs
   return f * sizeof(float);
 }
 
-extern "C" int unetk_deconv2x2_bwd(const unetk_deconv_desc* d, const float* x, const float* wp_dgrad,
-                                   const float* cat, const float* dcat, float* dx, float* dw, float* dbias,
-                                   void* ws, size_t ws_bytes, void* stream) {
-  UNETK_REQUIRE(deconv_desc_ok(d) && x && wp_dgrad && cat && dcat && dx && dw && dbias && ws);
-  if (d->Cin % 64 != 0 || d->Cout % 64 != 0 || d->out_stride % 4 != 0 || d->out_coff % 4 != 0)
+extern "C" int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const float* x, const float* wp_dgrad,
+                                  const float* cat, const float* dcat, float* dx, float* dw, float* dbias, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  UNETK_REQUIRE(deconv_desc_ok(d) && x && wp_dgrad && cat && dcat && dx && dw && ws);
+  if (d->Cin % 64 != 0 || d->Cout % 32 != 0 || d->out_stride % 4 != 0 || d->out_coff % 4 != 0)
     return UNETK_E_UNSUPPORTED;
   UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(wp_dgrad) && unetk_aligned16(cat) && unetk_aligned16(dcat) &&
                 unetk_aligned16(dx) && unetk_aligned16(dw) && unetk_aligned16(ws));
-  if (ws_bytes < unetk_deconv2x2_bwd_ws_bytes(d)) return UNETK_E_WORKSPACE;
+  if (ws_bytes < unetk_deconv3d_bwd_ws_bytes(d)) return UNETK_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const DwPlan pl = dw_plan(d);
-  const int M = d->N * d->H * d->W;
+  const int M = d->N * d->D * d->H * d->W;
   float* dpre = (float*)ws;
-  float* bpart = dpre + (size_t)4 * M * d->Cout;
+  float* bpart = dpre + (size_t)4 * d->kd * M * d->Cout;
   float* btmp = bpart + (size_t)pl.nblk_bias * d->Cout;
-  float* slab = btmp + unetk_rows_reduce_tmp_floats(1, pl.nblk_bias, d->Cout);
+  float* bsink = btmp + unetk_rows_reduce_tmp_floats(1, pl.nblk_bias, d->Cout);
+  size_t off = (size_t)(bsink + d->Cout - dpre);
+  off = (off + 3) & ~(size_t)3;
+  float* slab = dpre + off;
 
-  // 1. ReLU backward + bias-grad partials
+  // 1. ReLU backward over the whole up half + bias-grad partials
   const ColMap cm = unetk_colmap(d->Cout);
   hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3(pl.nblk_bias), dim3(256), (size_t)cm.rows_per_iter * d->Cout * sizeof(float),
-                     st, cat, dcat, d->out_stride, d->out_coff, dpre, bpart, (int64_t)4 * M, d->Cout, cm.cq_n,
+                     st, cat, dcat, d->out_stride, d->out_coff, dpre, bpart, (int64_t)4 * d->kd * M, d->Cout, cm.cq_n,
                      cm.rows_per_iter);
   UNETK_LAUNCH_CHECK();
-  int rc = unetk_rows_reduce(bpart, 1, pl.nblk_bias, d->Cout, dbias, btmp, st);
+  int rc = unetk_rows_reduce(bpart, 1, pl.nblk_bias, d->Cout, dbias ? dbias : bsink, btmp, st);
   if (rc != UNETK_OK) return rc;
 
-  // 2. input gradient: [M x 4Cout] . [4Cout x Cin]
-  PwParams p{};
-  p.a = dpre; p.wp = wp_dgrad; p.bias = nullptr; p.out = dx;
-  p.M = M; p.K = 4 * d->Cout; p.Ncols = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout;
-  if (p.Ncols % 128 == 0) {
-    p.n_ntiles = p.Ncols / 128;
-    rc = launch_pw<1, 2, 2, 2, 2>(p, st);
-  } else {
-    p.n_ntiles = p.Ncols / 64;
-    rc = launch_pw<1, 4, 1, 1, 2>(p, st);
-  }
-  if (rc != UNETK_OK) return rc;
+  const int64_t plane = (int64_t)4 * d->H * d->W * d->Cout;            // one dpre depth plane
+  ImgAddr da;
+  da.group = d->D; da.img_stride = d->kd * plane; da.group_stride = (int64_t)d->kd * d->D * plane;
+  for (int a = 0; a < d->kd; ++a) {
+    // 2. input gradient: [M x 4Cout] . [4Cout x Cin], accumulated over depth taps
+    PwParams p{};
+    p.a = dpre + a * plane; p.wp = wp_dgrad + (int64_t)a * 4 * d->Cin * d->Cout; p.bias = nullptr; p.out = dx;
+    p.M = M; p.K = 4 * d->Cout; p.Ncols = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout;
+    p.oa = da; p.accumulate = a > 0 ? 1 : 0;
+    rc = run_pw<1>(p, st);
+    if (rc != UNETK_OK) return rc;
 
-  // 3. filter gradient
-  DwParams q{};
-  q.x = x; q.dpre = dpre; q.slab = slab; q.M = M; q.H = d->H; q.W = d->W; q.Cin = d->Cin; q.Cout = d->Cout;
-  q.m_per_split = pl.m_per_split; q.n_co_tiles = d->Cout / 64; q.n_ci_tiles = d->Cin / 64;
-  const int grid = pl.S * 4 * q.n_co_tiles * q.n_ci_tiles;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)deconv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       2 * 128 * 64 * (int)sizeof(float));
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    // 3. filter gradient of this depth tap
+    DwParams q{};
+    q.x = x; q.dpre = dpre + a * plane; q.slab = slab; q.M = M; q.H = d->H; q.W = d->W; q.Cin = d->Cin; q.Cout = d->Cout;
+    q.m_per_split = pl.m_per_split; q.n_co_tiles = (d->Cout + 63) / 64; q.n_ci_tiles = d->Cin / 64; q.da = da;
+    const int grid = pl.S * 4 * q.n_co_tiles * q.n_ci_tiles;
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute((const void*)deconv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         2 * 128 * 64 * (int)sizeof(float));
+      if (e != hipSuccess) return (int)e;
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(deconv_wgrad_kernel, dim3(grid), dim3(256), (size_t)2 * 128 * 64 * sizeof(float), st, q);
+    UNETK_LAUNCH_CHECK();
+    rc = unetk_launch_slab_reduce(slab, pl.S, (int64_t)4 * d->Cin * d->Cout, dw + (int64_t)a * 4 * d->Cin * d->Cout, st);
+    if (rc != UNETK_OK) return rc;
   }
-  hipLaunchKernelGGL(deconv_wgrad_kernel, dim3(grid), dim3(256), (size_t)2 * 128 * 64 * sizeof(float), st, q);
-  UNETK_LAUNCH_CHECK();
-  return unetk_launch_slab_reduce(slab, pl.S, (int64_t)4 * d->Cin * d->Cout, dw, st);
+  return UNETK_OK;
+}
+
+// ---- 2-D entry points (UNet / GUNet): depth 1, one depth tap
+extern "C" int unetk_deconv2x2_pack(const float* w, int Cin, int Cout, float* wp_fwd, float* wp_dgrad, void* stream) {
+  return unetk_deconv3d_pack(w, 1, Cin, Cout, wp_fwd, wp_dgrad, stream);
+}
+
+extern "C" int unetk_deconv2x2_fwd(const unetk_deconv_desc* d, const float* x, const float* wp_fwd, const float* bias,
+                                   float* out, void* stream) {
+  UNETK_REQUIRE(d);
+  const unetk_deconv3d_desc e = from2d(d);
+  return unetk_deconv3d_fwd(&e, x, wp_fwd, bias, out, stream);
+}
+
+extern "C" size_t unetk_deconv2x2_bwd_ws_bytes(const unetk_deconv_desc* d) {
+  if (!d) return 0;
+  const unetk_deconv3d_desc e = from2d(d);
+  return unetk_deconv3d_bwd_ws_bytes(&e);
+}
+
+extern "C" int unetk_deconv2x2_bwd(const unetk_deconv_desc* d, const float* x, const float* wp_dgrad, const float* cat,
+                                   const float* dcat, float* dx, float* dw, float* dbias, void* ws, size_t ws_bytes,
+                                   void* stream) {
+  UNETK_REQUIRE(d && dbias);
+  const unetk_deconv3d_desc e = from2d(d);
+  return unetk_deconv3d_bwd(&e, x, wp_dgrad, cat, dcat, dx, dw, dbias, ws, ws_bytes, stream);
 }

@@ -16,7 +16,7 @@ import ctypes
 import torch
 
 from . import _abi
-from ._abi import ConvDesc, DeconvDesc, HeadDesc, NormDesc, check, ptr, stream_ptr
+from ._abi import Conv3dDesc, ConvDesc, Deconv3dDesc, DeconvDesc, HeadDesc, NormDesc, check, ptr, stream_ptr
 
 
 # ----------------------------------------------------------------------------- memory helpers
@@ -163,6 +163,77 @@ def conv3x3_wgrad(x, dy):
     return dw
 
 
+def conv3d_desc(x_shape, cout, kd, stride, x_stride=None, y_stride=None):
+    n, dd, h, w, cin = x_shape
+    sd, sh, sw = stride
+    assert sh == sw, "H and W strides must match"
+    return Conv3dDesc(n, dd, h, w, cin, cout, kd, sd, sh, x_stride or cin, y_stride or cout)
+
+
+def conv3d_out_shape(d):
+    do, ho, wo = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    check(_abi.lib().unetk_conv3d_out_dims(ctypes.byref(d), ctypes.byref(do), ctypes.byref(ho), ctypes.byref(wo)),
+          "conv3d_out_dims")
+    return (d.N, do.value, ho.value, wo.value, d.Cout)
+
+
+def conv3d_pack(w, want_dgrad=True):
+    """w: TF DHWIO [kd,3,3,Cin,Cout] (Cin % 4 == 0 for the MFMA path)."""
+    _require_cuda(w)
+    kd, kh, kw, cin, cout = w.shape
+    assert kh == 3 and kw == 3
+    wp_f = torch.empty(kd * 9 * cin * cout, dtype=torch.float32, device=w.device)
+    wp_d = torch.empty_like(wp_f) if want_dgrad else None
+    check(_abi.lib().unetk_conv3d_pack(ptr(w), kd, cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()), "conv3d_pack")
+    return wp_f, wp_d
+
+
+def _ws3d(d, device):
+    nbytes = _abi.lib().unetk_conv3d_ws_bytes(ctypes.byref(d))
+    return WORKSPACE.get(nbytes, device), nbytes
+
+
+def conv3d_fwd(x, w, d, want_stats=True):
+    """x [N,D,H,W,Cin] dense; w = packed filter when conv_uses_mfma(Cin, Cout) else raw DHWIO (kd == 1)."""
+    _require_cuda(x, w)
+    assert x.is_contiguous()
+    y = torch.empty(conv3d_out_shape(d), dtype=torch.float32, device=x.device)
+    stats, rows = None, 0
+    if want_stats:
+        rows = _abi.lib().unetk_conv3d_stat_rows(ctypes.byref(d))
+        if rows <= 0:
+            check(rows, "conv3d_stat_rows")
+        stats = torch.empty((2, rows, d.Cout), dtype=torch.float32, device=x.device)
+    ws, nbytes = _ws3d(d, x.device)
+    flops = 2.0 * y.numel() / d.Cout * d.kd * 9 * d.Cin * d.Cout
+    with _Timed("conv3d_fwd", flops, "k{}s{}{} {}".format(d.kd, d.sd, d.shw, tuple(x.shape))):
+        check(_abi.lib().unetk_conv3d_fwd(ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(stats), ptr(ws), nbytes,
+                                          stream_ptr()), "conv3d_fwd")
+    return y, stats, rows
+
+
+def conv3d_dgrad(dy, wp_dgrad, d):
+    assert dy.is_contiguous()
+    dx = torch.empty((d.N, d.D, d.H, d.W, d.Cin), dtype=torch.float32, device=dy.device)
+    ws, nbytes = _ws3d(d, dy.device)
+    flops = 2.0 * dy.numel() / d.Cout * d.kd * 9 * d.Cin * d.Cout
+    with _Timed("conv3d_dgrad", flops, "k{}s{}{} {}".format(d.kd, d.sd, d.shw, tuple(dx.shape))):
+        check(_abi.lib().unetk_conv3d_dgrad(ctypes.byref(d), ptr(dy), ptr(wp_dgrad), ptr(dx), ptr(ws), nbytes,
+                                            stream_ptr()), "conv3d_dgrad")
+    return dx
+
+
+def conv3d_wgrad(x, dy, d):
+    assert x.is_contiguous() and dy.is_contiguous()
+    dw = torch.empty((d.kd, 3, 3, d.Cin, d.Cout), dtype=torch.float32, device=x.device)
+    ws, nbytes = _ws3d(d, x.device)
+    flops = 2.0 * dy.numel() / d.Cout * d.kd * 9 * d.Cin * d.Cout
+    with _Timed("conv3d_wgrad", flops, "k{}s{}{} {}".format(d.kd, d.sd, d.shw, tuple(x.shape))):
+        check(_abi.lib().unetk_conv3d_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes, stream_ptr()),
+              "conv3d_wgrad")
+    return dw
+
+
 def norm_desc(y_shape, per_sample, z_stride=None, guide_ch=0, gw_stride=0, gw_coff=0):
     n, c = y_shape[0], y_shape[-1]
     hw = 1
@@ -268,6 +339,50 @@ def deconv2x2_bwd(x, wp_dgrad, cat, dcat, coff, cout):
                 "{}x{}x{} {}->{}".format(n, h, w, cin, cout)):
         check(_abi.lib().unetk_deconv2x2_bwd(ctypes.byref(d), ptr(x), ptr(wp_dgrad), ptr(cat), ptr(dcat), ptr(dx),
                                              ptr(dw), ptr(db), ptr(ws), nbytes, stream_ptr()), "deconv2x2_bwd")
+    return dx, dw, db
+
+
+def deconv3d_pack(w):
+    """w: TF [kd,2,2,Cout,Cin] with kd in {1, 2}."""
+    _require_cuda(w)
+    kd, kh, kw, cout, cin = w.shape
+    assert kh == 2 and kw == 2 and kd in (1, 2)
+    wp_f = torch.empty(kd * 4 * cin * cout, dtype=torch.float32, device=w.device)
+    wp_d = torch.empty_like(wp_f)
+    check(_abi.lib().unetk_deconv3d_pack(ptr(w), kd, cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()), "deconv3d_pack")
+    return wp_f, wp_d
+
+
+def _pix_stride_nd(t):
+    """Pixel stride of a channel-slice view of a dense N...C tensor."""
+    assert t.stride(-1) == 1
+    return t.stride(-2)
+
+
+def deconv3d_fwd(x, wp_fwd, bias, cat, coff, cout, kd):
+    n, dd, h, w, cin = x.shape
+    assert x.is_contiguous()
+    d = Deconv3dDesc(n, dd, h, w, cin, cout, kd, _pix_stride_nd(cat), coff)
+    with _Timed("deconv3d_fwd", 8.0 * kd * n * dd * h * w * cin * cout, "kd{} {}".format(kd, tuple(x.shape))):
+        check(_abi.lib().unetk_deconv3d_fwd(ctypes.byref(d), ptr(x), ptr(wp_fwd), ptr(bias), ptr(cat), stream_ptr()),
+              "deconv3d_fwd")
+    return cat
+
+
+def deconv3d_bwd(x, wp_dgrad, cat, dcat, coff, cout, kd, want_dbias):
+    n, dd, h, w, cin = x.shape
+    d = Deconv3dDesc(n, dd, h, w, cin, cout, kd, _pix_stride_nd(cat), coff)
+    assert _pix_stride_nd(dcat) == _pix_stride_nd(cat)
+    nbytes = _abi.lib().unetk_deconv3d_bwd_ws_bytes(ctypes.byref(d))
+    if nbytes == 0:
+        raise _abi.UnetkError("deconv3d_bwd: unsupported shape Cin={} Cout={}".format(cin, cout))
+    ws = WORKSPACE.get(nbytes, x.device)
+    dx = torch.empty_like(x)
+    dw = torch.empty((kd, 2, 2, cout, cin), dtype=torch.float32, device=x.device)
+    db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_dbias else None
+    with _Timed("deconv3d_bwd", 16.0 * kd * n * dd * h * w * cin * cout, "kd{} {}".format(kd, tuple(x.shape))):
+        check(_abi.lib().unetk_deconv3d_bwd(ctypes.byref(d), ptr(x), ptr(wp_dgrad), ptr(cat), ptr(dcat), ptr(dx),
+                                            ptr(dw), ptr(db), ptr(ws), nbytes, stream_ptr()), "deconv3d_bwd")
     return dx, dw, db
 
 

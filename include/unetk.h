@@ -84,6 +84,31 @@ size_t unetk_conv3x3_wgrad_ws_bytes(const unetk_conv_desc* d);
 int unetk_conv3x3_wgrad(const unetk_conv_desc* d, const float* x, const float* dy, float* dw,
                         void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------- slim.conv3d  (NetworksV2/UNet3D.py:153,165)
+ * Kernels (1,3,3) / (3,3,3) from _ModelConfig (UNet3D.py:31-91), strides 1 / (1,2,2) / (2,2,2), TF SAME
+ * padding (asymmetric at stride 2 on even sizes: 0 before, 1 after), no bias.
+ * x [N,D,H,W,Cin] (pixel stride x_stride), y [N,Do,Ho,Wo,Cout] (pixel stride y_stride), Do = ceil(D/sd), ...
+ * Filters: TF DHWIO [kd,3,3,Cin,Cout]; packed per depth tap like unetk_conv3x3_pack. */
+typedef struct unetk_conv3d_desc {
+  int32_t N, D, H, W, Cin, Cout;
+  int32_t kd;   /* 1 or 3 */
+  int32_t sd;   /* depth stride 1 or 2 (kd == 3 only) */
+  int32_t shw;  /* H and W stride, 1 or 2 */
+  int32_t x_stride, y_stride;
+} unetk_conv3d_desc;
+
+int unetk_conv3d_pack(const float* w, int kd, int Cin, int Cout, float* wp_fwd, float* wp_dgrad,
+                      void* stream);
+int unetk_conv3d_out_dims(const unetk_conv3d_desc* d, int* Do, int* Ho, int* Wo);
+int unetk_conv3d_stat_rows(const unetk_conv3d_desc* d);      /* rows of the statistic partials */
+size_t unetk_conv3d_ws_bytes(const unetk_conv3d_desc* d);    /* one size serves fwd / dgrad / wgrad */
+int unetk_conv3d_fwd(const unetk_conv3d_desc* d, const float* x, const float* wp_fwd, float* y,
+                     float* stat_partials, void* ws, size_t ws_bytes, void* stream);
+int unetk_conv3d_dgrad(const unetk_conv3d_desc* d, const float* dy, const float* wp_dgrad, float* dx,
+                       void* ws, size_t ws_bytes, void* stream);
+int unetk_conv3d_wgrad(const unetk_conv3d_desc* d, const float* x, const float* dy, float* dw,
+                       void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------- normalisation + ReLU after each 3x3 conv
  * slim.batch_norm   NetworksV2/base.py:153-162 -- TF defaults eps 1e-3, decay .999 (GUNet encoder .99,
  *                   GUNet.py:321-325); training: batch mean + biased variance, unbiased variance into
@@ -157,6 +182,23 @@ size_t unetk_deconv2x2_bwd_ws_bytes(const unetk_deconv_desc* d);
 int unetk_deconv2x2_bwd(const unetk_deconv_desc* d, const float* x, const float* wp_dgrad,
                         const float* cat, const float* dcat, float* dx, float* dw, float* dbias,
                         void* ws, size_t ws_bytes, void* stream);
+
+/* slim.conv3d_transpose(x, c, kernel == stride in {(1,2,2), (2,2,2)}, biases_initializer=None) + tf.concat,
+ * NetworksV2/UNet3D.py:161-163.  x [N,D,H,W,Cin]; out [N,kd*D,2H,2W,...]; filter TF [kd,2,2,Cout,Cin];
+ * bias / dbias may be NULL (UNet3D has none).  The 2-D functions above are the D = 1, kd = 1 case. */
+typedef struct unetk_deconv3d_desc {
+  int32_t N, D, H, W, Cin, Cout;
+  int32_t kd; /* depth kernel == depth stride: 1 or 2 */
+  int32_t out_stride, out_coff;
+} unetk_deconv3d_desc;
+int unetk_deconv3d_pack(const float* w, int kd, int Cin, int Cout, float* wp_fwd, float* wp_dgrad,
+                        void* stream);
+int unetk_deconv3d_fwd(const unetk_deconv3d_desc* d, const float* x, const float* wp_fwd,
+                       const float* bias, float* out, void* stream);
+size_t unetk_deconv3d_bwd_ws_bytes(const unetk_deconv3d_desc* d);
+int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const float* x, const float* wp_dgrad,
+                       const float* cat, const float* dcat, float* dx, float* dw, float* dbias,
+                       void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------- logits + loss head
  * UNet.py:97-135 + loss_metrics.py:115-231,261-339.

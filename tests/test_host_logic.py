@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_header_symbols_all_exported_and_bound():
     hdr = open(os.path.join(ROOT, "include", "unetk.h")).read()
     declared = set(re.findall(r"\b(unetk_[a-z0-9_]+)\s*\(", hdr))
-    declared -= {"unetk_conv_desc", "unetk_deconv_desc", "unetk_head_desc", "unetk_norm_desc"}
+    declared -= {"unetk_conv_desc", "unetk_deconv_desc", "unetk_head_desc", "unetk_norm_desc", "unetk_conv3d_desc", "unetk_deconv3d_desc"}
     lib = _abi.lib()
     for name in declared:
         assert hasattr(lib, name), name
