@@ -1,0 +1,92 @@
+"""ParamStore whose device tensors are channel-padded for the MFMA tiles while the checkpoint / TF view keeps
+the reference's logical shapes.
+
+UNet3D's channel counts (30, 60, 120, 240, 320 -- NetworksV2/UNet3D.py:155) are not multiples of the 32-wide
+fp32-MFMA tile, so the kernels run on variables padded to 32 / 64 / 128 / 256 / 320 channels.  The padding is
+exact, not an approximation: padded filter rows / columns are zero, so padded channels carry exactly 0 through
+conv -> norm (beta_pad = 0) -> ReLU, their gradients are exactly 0 (du = dz * (u > 0) with u = 0), and Adam /
+L2 leave a zero parameter with zero gradient at zero.  `state_dict` / `load_state` / `num_trainable` speak the
+logical shapes (TF variable shapes), so checkpoints are interchangeable with the reference's.
+
+A concat input (skip, up) pads each half separately: logical input channel c < C maps to c, c >= C maps to
+P + (c - C) -- described per axis as segments (logical start, length, physical start).
+"""
+import itertools
+from collections import OrderedDict
+
+import torch
+
+from .base import ParamStore
+
+
+def pad_to(c, mult=32):
+    return (c + mult - 1) // mult * mult
+
+
+class PaddedParamStore(ParamStore):
+    def __init__(self, specs, pads, device, bias_decay=False):
+        """specs: logical (name, shape, kind); pads: {name: (phys_shape, {axis: [(lstart, length, pstart), ...]})}."""
+        self.logical_specs = list(specs)
+        self.pads = dict(pads)
+        phys = [(n, tuple(self.pads[n][0]) if n in self.pads else tuple(s), k) for n, s, k in specs]
+        super(PaddedParamStore, self).__init__(phys, device, bias_decay)
+        self.logical_shape = {n: tuple(s) for n, s, _ in specs}
+
+    def _blocks(self, name):
+        """Yield (logical index tuple, physical index tuple) of every dense block of the variable."""
+        lshape = self.logical_shape[name]
+        axis_maps = self.pads[name][1] if name in self.pads else {}
+        per_axis = []
+        for ax, n in enumerate(lshape):
+            segs = axis_maps.get(ax, [(0, n, 0)])
+            per_axis.append([(slice(ls, ls + ln), slice(ps, ps + ln)) for ls, ln, ps in segs])
+        for combo in itertools.product(*per_axis):
+            yield tuple(c[0] for c in combo), tuple(c[1] for c in combo)
+
+    def num_trainable(self):
+        total = 0
+        for n in self.trainable_names():
+            k = 1
+            for s in self.logical_shape[n]:
+                k *= s
+            total += k
+        return total
+
+    @torch.no_grad()
+    def load_state(self, state, strict=True):
+        for name in self.tensors:
+            if name in state:
+                v = state[name]
+                v = (v if torch.is_tensor(v) else torch.as_tensor(v)).to(torch.float32).reshape(self.logical_shape[name])
+                t = self.tensors[name]
+                t.zero_()
+                v = v.to(t.device)
+                for lidx, pidx in self._blocks(name):
+                    t[pidx] = v[lidx]
+            elif strict:
+                raise KeyError("missing variable " + name)
+
+    def state_dict(self):
+        out = OrderedDict()
+        for name, t in self.tensors.items():
+            v = torch.zeros(self.logical_shape[name], dtype=torch.float32)
+            tc = t.detach().cpu()
+            for lidx, pidx in self._blocks(name):
+                v[lidx] = tc[pidx]
+            out[name] = v
+        return out
+
+    def logical_grad(self, name):
+        """Gradient of a variable in its logical (TF) shape."""
+        g = self.tensors[name].grad.detach().cpu()
+        v = torch.zeros(self.logical_shape[name], dtype=torch.float32)
+        for lidx, pidx in self._blocks(name):
+            v[lidx] = g[pidx]
+        return v
+
+    @torch.no_grad()
+    def initialize(self, weight_init="xavier", seed=None):
+        """Initialise the LOGICAL variables exactly as ParamStore would (fans from the TF shapes), then scatter."""
+        tmp = ParamStore(self.logical_specs, torch.device("cpu"))
+        tmp.initialize(weight_init, seed)
+        self.load_state(tmp.state_dict())

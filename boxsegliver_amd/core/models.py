@@ -11,12 +11,13 @@ import yaml
 
 from ..NetworksV2.GUNet import GUNet
 from ..NetworksV2.UNet import UNet
+from ..NetworksV2.UNet3D import UNet3D
 from ..NetworksV2.base import ModeKeys
 
 # Available models (reference models.py:36-38 lists UNet, GUNet, UNetInter, LGNet, UNet3D, SmallUNet,
 # InterUNet; this build ships UNet and GUNet (spatial-guide path) -- the others are SURVEY.md 8f "next").
 MODEL_ZOO = [
-    UNet, GUNet,
+    UNet, GUNet, UNet3D,
 ]
 
 EstimatorSpec = namedtuple("EstimatorSpec", ["mode", "loss", "train_op", "predictions", "model"])

@@ -15,6 +15,7 @@ def add_arguments(parser):
     """The liver pipeline flags the model reads (DataLoader/Liver/input_pipeline.py:54-70)."""
     group = parser.add_argument_group(title="Input Pipeline Arguments")
     group.add_argument("--test_fold", type=int, default=2)
+    group.add_argument("--im_depth", type=int, default=10, help="UNet3D patch depth (DataLoader/NF/input_pipeline_3d.py:56)")
     group.add_argument("--im_height", type=int, default=256)
     group.add_argument("--im_width", type=int, default=256)
     group.add_argument("--im_channel", type=int, default=3)
@@ -49,6 +50,52 @@ def make_batch(bs, height, width, channel, num_classes, seed=1234, noise_scale=0
             labels[b][disk & ell] = 2
     names = np.arange(bs, dtype=np.int64) + seed
     return images, labels, names
+
+
+def make_batch_3d(bs, depth, height, width, channel, num_classes, seed=1234):
+    """NF-style 3-D patches (DataLoader/NF/input_pipeline_3d.py): z-scored images ~ N(0,1) (the NF pipeline
+    z-scores, input_pipeline_g_simply.py:436-442), labels = ellipsoid of ~3 % of the voxels (class 1)."""
+    rng = np.random.default_rng(seed)
+    images = rng.standard_normal((bs, depth, height, width, channel)).astype(np.float32)
+    zz, yy, xx = np.meshgrid(np.arange(depth, dtype=np.float32), np.arange(height, dtype=np.float32),
+                             np.arange(width, dtype=np.float32), indexing="ij")
+    labels = np.zeros((bs, depth, height, width), dtype=np.int32)
+    for b in range(bs):
+        cz, cy, cx = (rng.uniform(0.35, 0.65, size=3) * np.array([depth, height, width])).astype(np.float32)
+        ell = ((zz - cz) / max(0.3 * depth, 1.0)) ** 2 + ((yy - cy) / (0.2 * height)) ** 2 + \
+            ((xx - cx) / (0.2 * width)) ** 2 <= 1.0
+        labels[b][ell] = 1 if num_classes == 2 else int(rng.integers(1, num_classes))
+    names = np.arange(bs, dtype=np.int64) + seed
+    return images, labels, names
+
+
+def input_fn_3d(mode, params):
+    """input_fn for --model UNet3D (`nf_3d` sub-command of entry/main.py:53-77): features["images"] f32
+    [bs,D,H,W,C], labels int32 [bs,D,H,W]."""
+    args = params["args"]
+    num_gpus = max(getattr(args, "num_gpus", 1), 1)
+    bs = args.batch_size // num_gpus if num_gpus > 1 else args.batch_size
+    ncls = len(args.classes) + 1
+    rank = int(params.get("rank", 0))
+    device = params.get("device", torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available()
+                        else torch.device("cpu"))
+    nb = max(int(getattr(args, "synthetic_batches", 2)), 1)
+    base_seed = int(getattr(args, "seed", 1234) or 1234)
+    pool = []
+    for i in range(nb):
+        seed = base_seed + 1000 * rank + i + (0 if mode == "train" else 500)
+        images, labels, names = make_batch_3d(bs, args.im_depth, args.im_height, args.im_width, args.im_channel, ncls, seed)
+        pool.append(({"images": torch.from_numpy(images).to(device), "names": torch.from_numpy(names)},
+                     torch.from_numpy(labels).to(device)))
+
+    def gen():
+        i = 0
+        n = None if mode == "train" else int(getattr(args, "eval_num_batches_per_epoch", nb) or nb)
+        while n is None or i < n:
+            yield pool[i % nb]
+            i += 1
+
+    return gen()
 
 
 def make_guide(labels, guide_channel=1, seed=1234):

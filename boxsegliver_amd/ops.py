@@ -273,11 +273,14 @@ def norm_relu_bwd(d, y, dz, aff, has_gamma, has_beta, guide=None, gw=None, gb=No
     if nbytes == 0:
         raise _abi.UnetkError("norm_relu_bwd: unsupported channel count {}".format(d.C))
     ws = WORKSPACE.get(nbytes, dev)
-    check(_abi.lib().unetk_norm_relu_bwd(ctypes.byref(d), ptr(y), ptr(dz), _pix_stride(dz), ptr(aff[2]), ptr(aff[3]),
+    check(_abi.lib().unetk_norm_relu_bwd(ctypes.byref(d), ptr(y), ptr(dz), _pix_stride_nd(dz), ptr(aff[2]), ptr(aff[3]),
                                          ptr(aff[0]), ptr(aff[1]), ptr(guide), ptr(gw), ptr(gb), ptr(dy), ptr(dgamma),
                                          ptr(dbeta), ptr(dgw), ptr(dgb), ptr(ws), nbytes, stream_ptr()),
           "norm_relu_bwd")
     return dy, dgamma, dbeta, dgw, dgb
+
+
+norm_relu_bwd_nd = norm_relu_bwd     # rank-agnostic (dz pixel stride = stride of the second-to-last axis)
 
 
 def avgpool2_fwd(x):
@@ -525,6 +528,80 @@ class Conv3x3NormRelu(torch.autograd.Function):
                                       dx=dx, dgamma=dgamma, dbeta=dbeta, w=ctx.w_dbg, guide=guide, gw=gw, gb=gb,
                                       dgw=dgw, dgb=dgb, per_sample=bool(ctx.desc.per_sample)))
         return dx, dw, dgamma, dbeta, None, None, None, None, None, dgw, dgb
+
+
+class Conv3dNormRelu(torch.autograd.Function):
+    """z = relu(norm(conv3d(x, w))) -- one slim.conv3d unit of UNet3D (UNet3D.py:108-121,153,165): kernel
+    (1,3,3) or (3,3,3), stride 1 / (1,2,2) / (2,2,2), SAME, no bias, instance or batch norm, ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, moving_mean, moving_var, spec, stride, out):
+        _require_cuda(x, w)
+        kd, cin, cout = w.shape[0], w.shape[3], w.shape[4]
+        mfma = conv_uses_mfma(cin, cout)
+        need_dx = ctx.needs_input_grad[0]
+        d = conv3d_desc(x.shape, cout, kd, stride)
+        if mfma:
+            wp_f, wp_d = conv3d_pack(w, want_dgrad=need_dx)
+        else:
+            if kd != 1 or need_dx:
+                raise _abi.UnetkError("conv3d with Cin={} Cout={} needs the MFMA path (Cin%16, Cout%32)".format(cin, cout))
+            wp_f, wp_d = w, None
+        use_batch_stats = spec.training or spec.per_sample
+        y, stats, rows = conv3d_fwd(x, wp_f, d, want_stats=use_batch_stats)
+        z = out if out is not None else torch.empty_like(y)
+        nd = norm_desc(y.shape, spec.per_sample, _pix_stride_nd(z))
+        aff = norm_finalize(nd, stats, rows, gamma, beta, spec.eps, spec.decay, spec.training, moving_mean, moving_var,
+                            y.device)
+        norm_apply_relu(nd, y, aff, z)
+        if spec.training:
+            ctx.save_for_backward(x, y, aff)
+            ctx.wp_d, ctx.need_dx, ctx.d, ctx.nd = wp_d, need_dx, d, nd
+            ctx.has = (gamma is not None, beta is not None)
+            ctx.dbg = (w.detach(), gamma, beta, stride) if DEBUG_CAPTURE is not None else None
+        return alias(z) if out is not None else z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, y, aff = ctx.saved_tensors
+        if dz.stride(-1) != 1:
+            dz = dz.contiguous()
+        dy, dgamma, dbeta, _, _ = norm_relu_bwd_nd(ctx.nd, y, dz, aff, ctx.has[0], ctx.has[1])
+        dw = conv3d_wgrad(x, dy, ctx.d)
+        dx = conv3d_dgrad(dy, ctx.wp_d, ctx.d) if ctx.need_dx else None
+        if DEBUG_CAPTURE is not None:
+            DEBUG_CAPTURE.append(dict(kind="conv3d", x=x, y=y, w=ctx.dbg[0], gamma=ctx.dbg[1], beta=ctx.dbg[2],
+                                      stride=ctx.dbg[3], dz=dz, dy=dy, dw=dw, dx=dx, dgamma=dgamma, dbeta=dbeta,
+                                      per_sample=bool(ctx.nd.per_sample)))
+        return dx, dw, dgamma, dbeta, None, None, None, None, None
+
+
+class Deconv3dConcat(torch.autograd.Function):
+    """cat = concat(skip, relu(conv3d_transpose(x, w, kernel == stride))) -- UNet3D.py:161-163 (no bias);
+    `skip` already lives in cat[..., :C], the kernel fills cat[..., C:]."""
+
+    @staticmethod
+    def forward(ctx, x, w, skip, cat):
+        _require_cuda(x, w, cat)
+        kd, cout = w.shape[0], w.shape[3]
+        coff = cat.shape[-1] - cout
+        assert skip.data_ptr() == cat.data_ptr() and skip.shape[-1] == coff
+        wp_f, wp_d = deconv3d_pack(w)
+        deconv3d_fwd(x, wp_f, None, cat, coff, cout, kd)
+        ctx.save_for_backward(x, cat)
+        ctx.wp_d, ctx.cout, ctx.coff, ctx.kd = wp_d, cout, coff, kd
+        ctx.w_dbg = w.detach() if DEBUG_CAPTURE is not None else None
+        return alias(cat)
+
+    @staticmethod
+    def backward(ctx, dcat):
+        x, cat = ctx.saved_tensors
+        dcat = dcat.contiguous()
+        dx, dw, _ = deconv3d_bwd(x, ctx.wp_d, cat, dcat, ctx.coff, ctx.cout, ctx.kd, want_dbias=False)
+        if DEBUG_CAPTURE is not None:
+            DEBUG_CAPTURE.append(dict(kind="deconv3d", x=x, w=ctx.w_dbg, cat=cat.clone(), dcat=dcat, dx=dx, dw=dw,
+                                      coff=ctx.coff, kd=ctx.kd))
+        return dx, dw, dcat[..., :ctx.coff], None
 
 
 class MaxPool2x2(torch.autograd.Function):
