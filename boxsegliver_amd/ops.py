@@ -196,7 +196,7 @@ def _ws3d(d, device):
 def conv3d_fwd(x, w, d, want_stats=True):
     """x [N,D,H,W,Cin] dense; w = packed filter when conv_uses_mfma(Cin, Cout) else raw DHWIO (kd == 1)."""
     _require_cuda(x, w)
-    assert x.is_contiguous()
+    assert x.stride(-1) == 1 and x.stride(-2) == d.x_stride        # dense, or a channel slice of a concat buffer
     y = torch.empty(conv3d_out_shape(d), dtype=torch.float32, device=x.device)
     stats, rows = None, 0
     if want_stats:
@@ -224,7 +224,7 @@ def conv3d_dgrad(dy, wp_dgrad, d):
 
 
 def conv3d_wgrad(x, dy, d):
-    assert x.is_contiguous() and dy.is_contiguous()
+    assert x.stride(-2) == d.x_stride and dy.is_contiguous()
     dw = torch.empty((d.kd, 3, 3, d.Cin, d.Cout), dtype=torch.float32, device=x.device)
     ws, nbytes = _ws3d(d, x.device)
     flops = 2.0 * dy.numel() / d.Cout * d.kd * 9 * d.Cin * d.Cout
@@ -540,7 +540,7 @@ class Conv3dNormRelu(torch.autograd.Function):
         kd, cin, cout = w.shape[0], w.shape[3], w.shape[4]
         mfma = conv_uses_mfma(cin, cout)
         need_dx = ctx.needs_input_grad[0]
-        d = conv3d_desc(x.shape, cout, kd, stride)
+        d = conv3d_desc(x.shape, cout, kd, stride, x_stride=_pix_stride_nd(x))
         if mfma:
             wp_f, wp_d = conv3d_pack(w, want_dgrad=need_dx)
         else:
@@ -568,7 +568,8 @@ class Conv3dNormRelu(torch.autograd.Function):
             dz = dz.contiguous()
         dy, dgamma, dbeta, _, _ = norm_relu_bwd_nd(ctx.nd, y, dz, aff, ctx.has[0], ctx.has[1])
         dw = conv3d_wgrad(x, dy, ctx.d)
-        dx = conv3d_dgrad(dy, ctx.wp_d, ctx.d) if ctx.need_dx else None
+        dense = conv3d_desc(x.shape, ctx.d.Cout, ctx.d.kd, (ctx.d.sd, ctx.d.shw, ctx.d.shw))   # dx is dense
+        dx = conv3d_dgrad(dy, ctx.wp_d, dense) if ctx.need_dx else None
         if DEBUG_CAPTURE is not None:
             DEBUG_CAPTURE.append(dict(kind="conv3d", x=x, y=y, w=ctx.dbg[0], gamma=ctx.dbg[1], beta=ctx.dbg[2],
                                       stride=ctx.dbg[3], dz=dz, dy=dy, dw=dw, dx=dx, dgamma=dgamma, dbeta=dbeta,
