@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP-event timing")
     ap.add_argument("--detail", action="store_true", help="break the kernel table down by layer shape")
+    ap.add_argument("--model", default="UNet", choices=["UNet", "GUNet", "UNet3D"],
+                    help="UNet = the headline workload (BASELINE.json configs[1]); GUNet / UNet3D = configs[3] / [4] "
+                         "(use --batch 8 / --size 96 --batch 1..4)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,26 +110,47 @@ def main():
         dist.init_process_group(backend="nccl")            # RCCL over xGMI
 
     from boxsegliver_amd import ops
-    from boxsegliver_amd.NetworksV2.UNet import UNet
+    from boxsegliver_amd.core import models
     from boxsegliver_amd.core.solver import Solver
-    from boxsegliver_amd.data.synthetic import input_fn
+    from boxsegliver_amd.data import synthetic
     from boxsegliver_amd.utils.distribution_utils import DistributionStrategy
 
+    global YML
     args = make_args(a.batch, world, a.size)
+    args.model, args.model_config = a.model, None
+    input_fn = synthetic.input_fn
+    gflop_unit, workload_name = GFLOP_PER_SLICE_FWD_BWD * (a.size / 256.0) ** 2, None
+    if a.model == "GUNet":          # BASELINE.json configs[3]: spatial guide, instance norm (002_gnet.sh:39)
+        args.use_spatial, args.use_context, args.guide_channel, args.normalizer = True, False, 1, "instance_norm"
+        args.side_dropout, args.dropout, args.use_se, args.fix = 0.5, None, False, False
+        gflop_unit = 288.9 * (a.size / 256.0) ** 2
+        workload_name = "GUNet + 1-ch spatial guide {0}x{0}x3 bs={1}/GPU fp32 instance_norm (BASELINE.json configs[3])"
+    elif a.model == "UNet3D":       # BASELINE.json configs[4]: 96^3 patches, instance norm (201_unet_v1.sh:39)
+        args.classes, args.im_channel, args.im_depth, args.normalizer = ["NF"], 1, a.size, "instance_norm"
+        args.loss_numeric_w, args.use_spatial, args.weight_decay_rate = [1.0, 1.0], False, 3e-5
+        input_fn = synthetic.input_fn_3d
+        gflop_unit = 1612.92 * (a.size / 96.0) ** 3
+        workload_name = "UNet3D {0}x{0}x{0}x1 bs={1}/GPU fp32 instance_norm (BASELINE.json configs[4])"
+    YML = models.get_model_params(args, build_metrics=True)["model_kwargs"]
     params = {"args": args, "rank": rank, "device": torch.device("cuda", local_rank)}
     data = input_fn("train", params)
-    model = UNet(args)
+    model = {c.__name__: c for c in models.MODEL_ZOO}[a.model](args)
     solver = Solver(args)
     strategy = DistributionStrategy("mirrored", world, rank) if world > 1 else None
     solver.strategy = strategy
-    features, labels = next(data)
-    model({"images": features["images"], "labels": labels}, "eval", **YML)        # create variables
+
+    def inputs_of(batch):
+        features, labels = batch
+        inp = {k: v for k, v in features.items() if k != "names"}
+        inp["labels"] = labels
+        return inp
+
+    model(inputs_of(next(data)), "eval", **YML)                                   # create variables
     if strategy is not None:
         strategy.broadcast_(list(model.params.flat.values()))                      # identical replicas
 
     def one_step():
-        features, labels = next(data)
-        loss = model({"images": features["images"], "labels": labels}, "train", **YML)
+        loss = model(inputs_of(next(data)), "train", **YML)
         solver(loss, model)
         return loss
 
@@ -156,18 +180,17 @@ def main():
     if rank == 0:
         ms = elapsed / a.steps * 1e3
         slices = a.batch * world * a.steps / elapsed
+        wl = (workload_name or "UNet 2D Liver+Tumor {0}x{0}x3 bs={1}/GPU fp32 (BASELINE.json configs[1])").format(
+            a.size, a.batch) + ", fwd+bwd+TF-Adam" + ("+RCCL grad all-reduce" if world > 1 else "")
         out = {
-            "metric": METRIC, "value": round(slices, 2), "unit": "slices/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "UNet 2D Liver+Tumor {0}x{0}x3 bs={1}/GPU fp32, fwd+bwd+TF-Adam{2} "
-                                   "(BASELINE.json configs[1])".format(a.size, a.batch,
-                                                                       "+RCCL grad all-reduce" if world > 1 else ""),
-                       "global_batch": a.batch * world, "parallelism": "dp{}".format(world), "classes": 3,
-                       "final_loss": round(loss_val, 5)},
-            "whole_step_tflops": round(slices * GFLOP_PER_SLICE_FWD_BWD * (a.size / 256.0) ** 2 / 1e3, 2),
-            "whole_step_frac_of_fp32_peak": round(slices * GFLOP_PER_SLICE_FWD_BWD * (a.size / 256.0) ** 2 / 1e3
-                                                  / (FP32_PEAK_TFLOPS * world), 4),
+            "metric": METRIC if a.model == "UNet" else "{} units/sec/node (fwd+bwd)".format(a.model),
+            "value": round(slices, 2), "unit": "slices/s" if a.model != "UNet3D" else "patches/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl, "global_batch": a.batch * world, "parallelism": "dp{}".format(world),
+                       "classes": len(args.classes) + 1, "final_loss": round(loss_val, 5)},
+            "whole_step_tflops": round(slices * gflop_unit / 1e3, 2),
+            "whole_step_frac_of_fp32_peak": round(slices * gflop_unit / 1e3 / (FP32_PEAK_TFLOPS * world), 4),
         }
         if prof:
             agg = {}
@@ -194,12 +217,12 @@ def main():
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
                 key = {k.replace(" ", ""): v for k, v in pmc.items()}.get(top["kernel"].replace(" ", ""))
-                if key and a.size == 256 and a.batch == 32:
+                if key and a.size == 256 and a.batch == 32 and a.model == "UNet":
                     out["roofline"]["traffic"] = round(key["hbm_bytes_per_launch_corrected"])
                     out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE)"
             except (OSError, KeyError, ValueError):
                 pass
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline and world == 1 and a.model == "UNet":
             out["cpu_baseline"] = cpu_baseline(a.size)
         print(json.dumps(out, ensure_ascii=False), flush=True)
     if world > 1:
