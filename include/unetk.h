@@ -68,7 +68,7 @@ int unetk_conv3x3_stat_rows(const unetk_conv_desc* d);
 /* y = conv3x3(x, w).  If stat_partials != NULL also writes per-pixel-tile partial sums for the
  * following norm: stat_partials[0][row][c] = sum y, stat_partials[1][row][c] = sum y^2
  * (2 * stat_rows * Cout floats; deterministic, no atomics).
- * `w` is wp_fwd from unetk_conv3x3_pack when Cin % 16 == 0 && Cout % 64 == 0, else the raw
+ * `w` is wp_fwd from unetk_conv3x3_pack when Cin % 16 == 0 && Cout % 32 == 0, else the raw
  * HWIO filter (direct kernel; used by Encode1/conv1 where Cin = 3). */
 int unetk_conv3x3_fwd(const unetk_conv_desc* d, const float* x, const float* w, float* y,
                       float* stat_partials, void* stream);
