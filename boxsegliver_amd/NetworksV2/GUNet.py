@@ -13,7 +13,7 @@ Not built yet (raise NotImplementedError): the context (density) branch --use_co
 import torch
 
 from .. import ops
-from ..loss_metrics import build_head_desc, metric_from_sums
+from ..loss_metrics import build_head_desc, metric_from_sums, pixel_weights
 from ..utils import distribution_utils
 from . import base
 from .base import ModeKeys, ParamStore
@@ -133,9 +133,8 @@ class GUNet(base.BaseNet):
         nm = self.name
         g_ch = int(getattr(self.args, "guide_channel", 1)) if self.use_spatial_guide else 0
         if self.params is None:
-            if getattr(self.args, "img_grad", False):
-                raise NotImplementedError("--img_grad has no HIP kernel yet")
-            specs = param_specs(self.channel, self.num_classes, g_ch, base_channels, nds, mod_layers,
+            in_ch = self.channel * (3 if getattr(self.args, "img_grad", False) else 1)      # GUNet.py:335-338
+            specs = param_specs(in_ch, self.num_classes, g_ch, base_channels, nds, mod_layers,
                                 self.args.normalizer, norm_with_center, norm_with_scale, self.use_spatial_guide, nm)
             self.params = ParamStore(specs, dev, bias_decay=getattr(self.args, "bias_decay", False))
             self.params.initialize(self._get_initializer()[0], seed=getattr(self.args, "seed", None))
@@ -154,7 +153,10 @@ class GUNet(base.BaseNet):
                     if i < nds:
                         gs = ops.avgpool2_fwd(gs)
 
-            x = images.contiguous()
+            if getattr(self.args, "img_grad", False):
+                x = ops.image_gradients(images.to(torch.float32))
+            else:
+                x = images.contiguous()
             cats, skips = {}, {}
             hh, ww = h, w
             for i in range(nds + 1):
@@ -192,7 +194,7 @@ class GUNet(base.BaseNet):
             labels = self._inputs.get("labels")
             if labels is not None:
                 labels = labels.to(torch.int32).contiguous()
-            pixel_w = self._inputs.get("pixel_weights")
+            pixel_w = pixel_weights(self.args, self._inputs, labels)
             desc = build_head_desc(self.args, n, h * w, c, self.num_classes, explicit_map=pixel_w is not None) \
                 if labels is not None else ops.head_desc(n, h * w, c, self.num_classes)
             want_probs = bool(self.ret_prob or self.ret_pred or self.mode != ModeKeys.TRAIN)

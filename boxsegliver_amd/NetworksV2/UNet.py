@@ -12,7 +12,7 @@ transposed conv writes channels [C,2C) -- tf.concat (UNet.py:93) costs zero byte
 import torch
 
 from .. import ops
-from ..loss_metrics import build_head_desc, metric_from_sums
+from ..loss_metrics import build_head_desc, metric_from_sums, pixel_weights
 from ..utils import distribution_utils
 from . import base
 from .base import ModeKeys, ParamStore
@@ -128,8 +128,9 @@ class UNet(base.BaseNet):
         nm = self.name
 
         if getattr(self.args, "img_grad", False):
-            raise NotImplementedError("--img_grad has no HIP kernel yet")
-        tensor_out = images.contiguous()
+            tensor_out = ops.image_gradients(images.to(torch.float32))        # UNet.py:69-71
+        else:
+            tensor_out = images.contiguous()
 
         grad_mode = self.mode == ModeKeys.TRAIN
         with torch.set_grad_enabled(grad_mode):
@@ -167,7 +168,7 @@ class UNet(base.BaseNet):
             labels = self._inputs.get("labels")
             if labels is not None:
                 labels = labels.to(torch.int32).contiguous()
-            pixel_w = self._inputs.get("pixel_weights")
+            pixel_w = pixel_weights(self.args, self._inputs, labels)
             desc = build_head_desc(self.args, n, h * w, c, self.num_classes,
                                    explicit_map=pixel_w is not None) if labels is not None else \
                 ops.head_desc(n, h * w, c, self.num_classes)

@@ -146,7 +146,9 @@ class UNet3D(base.BaseNet):
         if images.dim() != 5 or images.shape[4] != self.channel:
             raise ValueError("images must be [bs, D, H, W, {}], got {}".format(self.channel, tuple(images.shape)))
         if getattr(self.args, "img_grad", False):
-            raise NotImplementedError("--img_grad has no HIP kernel yet")
+            # reference UNet3D.py:138-140 unpacks three values from tf.image.image_gradients on a 5-D tensor; that op
+            # takes 4-D input and returns (dy, dx), so the reference's own path raises at graph build
+            raise ValueError("--img_grad is not defined for UNet3D (tf.image.image_gradients is 4-D only)")
         n, dd, h, w, _ = images.shape
         if h % (1 << npl) or w % (1 << npl) or dd % 2:
             raise ValueError("H, W must be divisible by 2**num_pool_layers and D by 2")

@@ -73,6 +73,7 @@ _SIGNATURES = {
     "unetk_maxpool2_fwd": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, P]),
     "unetk_maxpool2_bwd": (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
     "unetk_avgpool2_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "unetk_image_gradients": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "unetk_deconv2x2_pack": (c_int, [P, c_int, c_int, P, P, P]),
     "unetk_deconv2x2_fwd": (c_int, [POINTER(DeconvDesc), P, P, P, P, P]),
     "unetk_deconv2x2_bwd_ws_bytes": (c_size_t, [POINTER(DeconvDesc)]),
@@ -89,6 +90,8 @@ _SIGNATURES = {
     "unetk_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_float, P]),
     "unetk_momentum_step": (c_int, [P, P, P, c_int64, c_float, c_float, c_int, c_float, c_float, P]),
     "unetk_sumsq": (c_int, [P, c_int64, P, P, c_size_t, P]),
+    "unetk_boundary_weights_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "unetk_boundary_weights": (c_int, [P, c_int, c_int, c_int, P, P, c_size_t, P]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))

@@ -12,6 +12,7 @@ import torch
 
 from .. import ops
 from ..config import CustomKeys
+from ..utils import distribution_utils
 
 
 def add_arguments(parser):
@@ -96,6 +97,9 @@ class Solver(object):
         self.collections = {CustomKeys.LEARNING_RATE: None}
         self._state = None
         self.strategy = None                # set by the estimator for data parallelism
+        self.overlap_allreduce = True       # bucketed all-reduce launched from backward (distribution_utils.GradBuckets)
+        self.bucket_bytes = 32 << 20
+        self._buckets = None
 
     @property
     def args(self):
@@ -175,7 +179,10 @@ class Solver(object):
         """One optimiser step on the flat buffers; gradients are already in store.grad."""
         world = self.strategy.num_replicas_in_sync if self.strategy is not None else 1
         if world > 1:
-            self.strategy.all_reduce_sum_([store.grad["reg"], store.grad["noreg"]])
+            if self._buckets is not None and self._buckets.store is store:
+                self._buckets.finish()              # buckets were all-reduced while backward ran
+            else:
+                self.strategy.all_reduce_sum_([store.grad["reg"], store.grad["noreg"]])
         gscale = 1.0 / world
         hp = self._optimizer_hparams()
         state = self._ensure_state(store)
@@ -208,6 +215,13 @@ class Solver(object):
         lr = self._get_model_learning_rate(**lr_params)
         store = model.params
         store.zero_grad()
+        world = self.strategy.num_replicas_in_sync if self.strategy is not None else 1
+        if world > 1 and self.overlap_allreduce and hasattr(store, "tensors"):
+            if self._buckets is None or self._buckets.store is not store:
+                if self._buckets is not None:
+                    self._buckets.remove()
+                self._buckets = distribution_utils.GradBuckets(store, self.strategy, self.bucket_bytes)
+            self._buckets.arm()
         loss.backward()
         w_reg, _ = model._get_regularizer()
         self.apply_gradients(store, w_reg, lr)

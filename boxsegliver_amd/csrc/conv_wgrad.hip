@@ -380,7 +380,7 @@ WgPlan wg_plan(int N, int H, int W, int Cin, int Cout) {
     if (S < 1) S = 1;
     pl.tiles_per_split = (pl.total_tiles + S - 1) / S;
     pl.S = (pl.total_tiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
-  } else if (Cin <= 4 && Cout <= 256 && 256 % Cout == 0) {
+  } else if ((Cin <= 4 || Cin == 9) && Cout <= 256 && 256 % Cout == 0) {  // 9 = 3 channels x (image, dy, dx): --img_grad
     pl.mode = 1;
     int S = 2048;
     if (S > pl.total_tiles) S = pl.total_tiles;
@@ -440,12 +440,24 @@ int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_
   } else {
     const int PL = 256 / p.Cout;
     const size_t lds = (size_t)PL * 9 * p.Cin * p.Cout * sizeof(float);
-    if (lds > 64 * 1024) return UNETK_E_UNSUPPORTED;
+    if (lds > (p.Cin == 9 ? 150 : 64) * 1024) return UNETK_E_UNSUPPORTED;
     switch (p.Cin) {
       case 1: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<1>, dim3(pl.S), dim3(256), lds, st, p); break;
       case 2: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<2>, dim3(pl.S), dim3(256), lds, st, p); break;
       case 3: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<3>, dim3(pl.S), dim3(256), lds, st, p); break;
-      default: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<4>, dim3(pl.S), dim3(256), lds, st, p); break;
+      case 4: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<4>, dim3(pl.S), dim3(256), lds, st, p); break;
+      case 9: {
+        static bool attr_done = false;
+        if (!attr_done) {
+          hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_smallc_kernel<9>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+          if (e != hipSuccess) return (int)e;
+          attr_done = true;
+        }
+        hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<9>, dim3(pl.S), dim3(256), lds, st, p);
+        break;
+      }
+      default: return UNETK_E_UNSUPPORTED;
     }
     UNETK_LAUNCH_CHECK();
   }

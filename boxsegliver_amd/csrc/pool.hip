@@ -88,7 +88,32 @@ __global__ void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restri
   }
 }
 
+// tf.image.image_gradients + concat (UNet.py:69-71): out[..., 0:C] = x, [C:2C] = x[h+1] - x[h] (last row 0),
+// [2C:3C] = x[w+1] - x[w] (last column 0).  Few channels (C = 1..3) -> scalar, HBM-bound on the 3C write.
+__global__ void image_gradients_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int H, int W, int C) {
+  const int64_t total = (int64_t)N * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t pix = i / C;
+    const int w = (int)(pix % W);
+    const int h = (int)((pix / W) % H);
+    const float v = x[i];
+    float* o = out + pix * 3 * C + c;
+    o[0] = v;
+    o[C] = h + 1 < H ? x[i + (int64_t)W * C] - v : 0.f;
+    o[2 * C] = w + 1 < W ? x[i + C] - v : 0.f;
+  }
+}
+
 }  // namespace
+
+extern "C" int unetk_image_gradients(const float* x, float* out, int N, int H, int W, int C, void* stream) {
+  UNETK_REQUIRE(x && out && N > 0 && H > 0 && W > 0 && C > 0);
+  const int64_t total = (int64_t)N * H * W * C;
+  hipLaunchKernelGGL(image_gradients_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, out, N, H, W, C);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
 
 extern "C" int unetk_maxpool2_fwd(const float* x, int x_stride, float* p, int N, int H, int W, int C,
                                   void* stream) {

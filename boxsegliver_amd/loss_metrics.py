@@ -54,10 +54,22 @@ def build_head_desc(args, n, hw, c, ncls, explicit_map=False):
         decay = getattr(args, "loss_proportion_decay", 0) or 0
         return ops.head_desc(n, hw, c, ncls, "proportion", proportion_decay=decay if decay > 0 else 0.0)
     if w_type == "boundary":
-        # the reference computes this map on the HOST (scipy EDT through tf.py_func,
-        # loss_metrics.py:149-159); feed it as inputs["pixel_weights"] (already normalised)
-        raise ValueError("loss_weight_type `boundary` needs inputs['pixel_weights'] (host-computed map)")
+        # resolved by pixel_weights() below into an explicit map (the reference round-trips to scipy on the host,
+        # loss_metrics.py:149-159); reaching this line means 3-D labels, which the reference cannot handle either
+        raise ValueError("loss_weight_type `boundary` is defined for 2-D labels only")
     raise ValueError("Not supported weight type: " + w_type)
+
+
+def pixel_weights(args, inputs, labels):
+    """Explicit per-pixel loss weights: a caller-provided inputs["pixel_weights"] map, or the `boundary` map
+    (loss_metrics.py:149-165) computed on the device from the labels; None for the table-driven weight types."""
+    explicit = inputs.get("pixel_weights")
+    if explicit is not None or labels is None:
+        return explicit
+    w_type = (getattr(args, "loss_weight_type", "none") or "none").lower()
+    if w_type == "boundary" and labels.dim() == 3:
+        return ops.boundary_weights(labels)
+    return None
 
 
 def _class_sums(result, n, ncls, cls):

@@ -283,6 +283,15 @@ def norm_relu_bwd(d, y, dz, aff, has_gamma, has_beta, guide=None, gw=None, gb=No
 norm_relu_bwd_nd = norm_relu_bwd     # rank-agnostic (dz pixel stride = stride of the second-to-last axis)
 
 
+def image_gradients(x):
+    """--img_grad: concat(x, dy, dx) along channels (UNet.py:69-71); the input needs no gradient."""
+    _require_cuda(x)
+    n, h, w, c = x.shape
+    out = torch.empty((n, h, w, 3 * c), dtype=torch.float32, device=x.device)
+    check(_abi.lib().unetk_image_gradients(ptr(x.contiguous()), ptr(out), n, h, w, c, stream_ptr()), "image_gradients")
+    return out
+
+
 def avgpool2_fwd(x):
     _require_cuda(x)
     n, h, w, c = x.shape
@@ -437,6 +446,21 @@ def head_predict(probs, ncls, want_preds=True):
     preds = torch.empty((ncls - 1, npix), dtype=torch.uint8, device=probs.device) if want_preds else None
     check(_abi.lib().unetk_head_predict(ptr(probs), npix, ncls, ptr(amax), ptr(preds), stream_ptr()), "head_predict")
     return amax, preds
+
+
+def boundary_weights(labels):
+    """--loss_weight_type boundary (loss_metrics.py:149-165): labels int32 [N,H,W] -> normalised weight map f32."""
+    _require_cuda(labels)
+    if labels.dim() != 3:
+        raise ValueError("loss_weight_type `boundary` is defined for [bs, H, W] labels only (loss_metrics.py:150-151)")
+    labels = labels.to(torch.int32).contiguous()
+    n, h, w = labels.shape
+    wmap = torch.empty((n, h, w), dtype=torch.float32, device=labels.device)
+    nbytes = _abi.lib().unetk_boundary_weights_ws_bytes(n, h, w)
+    ws = WORKSPACE.get(nbytes, labels.device)
+    check(_abi.lib().unetk_boundary_weights(ptr(labels), n, h, w, ptr(wmap), ptr(ws), nbytes, stream_ptr()),
+          "boundary_weights")
+    return wmap
 
 
 def adam_step(p, g, m, v, lr_t, beta1, beta2, eps, gscale=1.0, l2=0.0, decoupled_wd=0.0):

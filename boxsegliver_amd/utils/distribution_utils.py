@@ -56,6 +56,76 @@ class DistributionStrategy(object):
                 dist.broadcast(t, src=src)
 
 
+class GradBuckets(object):
+    """Gradient all-reduce overlapped with backward.
+
+    Each flat gradient buffer (ParamStore.grad) is cut into contiguous buckets of about `bucket_bytes`, walking
+    the variables from the END of the buffer (= forward order reversed: backward finishes the logits / decoder
+    gradients first).  A post-accumulate hook on every variable counts arrivals; the moment a bucket's last
+    gradient has landed its slice is all-reduced asynchronously -- on RCCL's own stream, ordered after the
+    kernels already queued on the compute stream -- while backward keeps running on the encoder.  finish()
+    launches whatever did not fire (variables that received no gradient) and makes the compute stream wait.
+    The reference packs into num_packs=2 tensors (distribution_utils.py:94-95) and leaves the overlap to TF."""
+
+    def __init__(self, store, strategy, bucket_bytes=32 << 20):
+        self.store, self.strategy = store, strategy
+        self.buckets = []                     # (group, lo, hi, n_vars)
+        self._bucket_of = {}
+        self._hooks = []
+        for grp in ("reg", "noreg"):
+            names = sorted((n for n in store.trainable_names() if store.where[n][0] == grp),
+                           key=lambda n: -store.where[n][1])
+            hi, members = store.grad[grp].numel(), []
+            for k, name in enumerate(names):
+                off = store.where[name][1]
+                members.append(name)
+                if (hi - off) * 4 >= bucket_bytes or k == len(names) - 1:
+                    lo = 0 if k == len(names) - 1 else off
+                    for m in members:
+                        self._bucket_of[m] = len(self.buckets)
+                    self.buckets.append((grp, lo, hi, len(members)))
+                    hi, members = lo, []
+        for name in store.trainable_names():
+            t = store.tensors[name]
+            self._hooks.append(t.register_post_accumulate_grad_hook(self._make_hook(self._bucket_of[name])))
+        self.arm()
+
+    def _make_hook(self, b):
+        def hook(_param):
+            if self._armed:
+                self._pending[b] -= 1
+                if self._pending[b] == 0:
+                    self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        grp, lo, hi, _ = self.buckets[b]
+        self._fired[b] = True
+        self._works.append(dist.all_reduce(self.store.grad[grp][lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def arm(self):
+        """Call before backward of every step."""
+        self._pending = [b[3] for b in self.buckets]
+        self._fired = [False] * len(self.buckets)
+        self._works = []
+        self._armed = True
+
+    def finish(self):
+        """Call after backward: every bucket reduced and visible to the compute stream."""
+        self._armed = False
+        for b in range(len(self.buckets)):
+            if not self._fired[b]:
+                self._launch(b)
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
 def init_process_group_from_env(backend=None):
     """One process per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from torchrun."""
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -161,6 +161,9 @@ int unetk_maxpool2_bwd(const float* x, int x_stride, const float* p, const float
                        int N, int H, int W, int C, void* stream);
 /* slim.avg_pool2d(gs, 2) of GUNet's spatial-guide pyramid (GUNet.py:157-158); x, p dense, any C. */
 int unetk_avgpool2_fwd(const float* x, float* p, int N, int H, int W, int C, void* stream);
+/* --img_grad (UNet.py:69-71, GUNet.py:335-338): out [N,H,W,3C] = concat(x, dy, dx) with
+ * tf.image.image_gradients' forward differences (dy[h] = x[h+1] - x[h], last row 0; dx likewise). */
+int unetk_image_gradients(const float* x, float* out, int N, int H, int W, int C, void* stream);
 
 /* ---------------------------------------------------------------- slim.conv2d_transpose(x, C, 2, 2)
  * UNet.py:91-93: kernel 2 stride 2, bias, ReLU, then tf.concat((skip, up), -1).
@@ -236,6 +239,14 @@ int unetk_head_bwd(const unetk_head_desc* d, const float* z, const float* w,
  * and UNet.py:112-118 Pred_c = prob_c > 0.5 (uint8).  preds is [ncls-1][npix] or NULL. */
 int unetk_head_predict(const float* probs, int64_t npix, int ncls, uint8_t* argmax,
                        uint8_t* preds, void* stream);
+
+/* --loss_weight_type boundary (loss_metrics.py:149-165; 2-D only, as in the reference): labels int32
+ * [N,H,W] -> wmap f32 [N,H,W] = normalised exp(-EDT/25) + 1, EDT = exact Euclidean distance to the nearest
+ * pixel of the 3x3 dilation ring of any class (the reference round-trips to scipy on the host through
+ * tf.py_func; this runs on the device).  Feed wmap to unetk_head_fwd/bwd as UNETK_W_PIXELMAP. */
+size_t unetk_boundary_weights_ws_bytes(int N, int H, int W);
+int unetk_boundary_weights(const int32_t* labels, int N, int H, int W, float* wmap, void* ws,
+                           size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------- optimiser  core/solver.py:204-243
  * tf.train.AdamOptimizer on a flat parameter buffer.  g' = g*gscale + l2*p  (slim.l2_regularizer

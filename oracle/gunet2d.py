@@ -80,8 +80,9 @@ def param_specs(in_channels, num_classes, guide_channel=1, init_channels=64, num
 class GUNet2DOracle(object):
     def __init__(self, in_channels, num_classes, guide_channel=1, init_channels=64, num_down_samples=4,
                  mod_layers=(1, 2, 3, 4), normalizer="instance_norm", norm_with_center=True, norm_with_scale=False,
-                 name="GUNet"):
+                 name="GUNet", img_grad=False):
         self.name, self.num_classes = name, num_classes
+        self.img_grad = img_grad                                       # GUNet.py:335-338
         self.init_channels, self.nds = init_channels, num_down_samples
         self.mod_layers = tuple(mod_layers)
         self.normalizer = normalizer
@@ -115,7 +116,7 @@ class GUNet2DOracle(object):
                 sp_params[i] = gs @ w.reshape(w.shape[2], w.shape[3]) + p["{}/spatial/conv{}/biases".format(n, i + 1)]
             if i < self.nds:
                 gs = tf_ops.avg_pool2x2_same(gs)
-        x = images
+        x = torch.cat((images,) + tf_ops.image_gradients(images), dim=-1) if self.img_grad else images
         skips = []
         for i in range(self.nds + 1):
             c = self.init_channels * 2 ** i

@@ -37,6 +37,17 @@ def compute_weights(w_type, labels, num_classes, numeric_w=None, proportion_deca
         pw = proportions / proportions.sum(dim=1, keepdim=True)
         shape = (labels.shape[0],) + (1,) * (labels.dim() - 1) + (num_classes,)
         w = (one_hot * pw.reshape(shape)).sum(-1)
+    elif w_type == "boundary":                               # :149-159 (4-D one-hot only)
+        import numpy as np
+        from scipy.ndimage import distance_transform_edt
+        if labels.dim() != 3:
+            raise ValueError("boundary weights are 2-D only in the reference (loss_metrics.py:150-151)")
+        # per class: clip(conv3x3_SAME(onehot), 0, 1) - onehot; summed over classes; EDT of its complement
+        oh = one_hot.permute(0, 3, 1, 2).reshape(-1, 1, labels.shape[1], labels.shape[2])
+        dil = F.conv2d(oh, torch.ones(1, 1, 3, 3), padding=1).clamp(0, 1) - oh
+        ring = dil.reshape(labels.shape[0], num_classes, labels.shape[1], labels.shape[2]).sum(1) > 0
+        dist = np.stack([distance_transform_edt(~r.numpy()).astype(np.float32) for r in ring])
+        w = torch.exp(-torch.from_numpy(dist) / 25) + 1
     else:
         raise ValueError("Not supported weight type: " + w_type)
     # :163-165 per-sample renormalisation to mean 1

@@ -88,8 +88,10 @@ TRAINABLE_KINDS = ("conv_w", "deconv_w", "bias", "gamma", "beta")
 class UNet2DOracle(object):
     def __init__(self, in_channels, num_classes, init_channels=64, num_down_samples=4,
                  normalizer="batch_norm", without_norm=False, name="UNet",
-                 bn_decay=0.999, bn_eps=1e-3, in_eps=1e-6):
+                 bn_decay=0.999, bn_eps=1e-3, in_eps=1e-6, img_grad=False):
+        """img_grad (UNet.py:69-71): the net sees concat(images, dy, dx); in_channels is then 3 x image channels."""
         self.name = name
+        self.img_grad = img_grad
         self.in_channels = in_channels
         self.num_classes = num_classes
         self.init_channels = init_channels
@@ -127,7 +129,7 @@ class UNet2DOracle(object):
         """Returns (logits, new_moving_stats).  images: [bs,H,W,C] float."""
         new_stats = OrderedDict()
         n = self.name
-        x = images
+        x = torch.cat((images,) + tf_ops.image_gradients(images), dim=-1) if self.img_grad else images
         skips = []
         for i in range(self.num_down_samples):
             s = "{}/Encode{}/Repeat/convolution2d_".format(n, i + 1)

@@ -96,6 +96,86 @@ def test_dp_host_logic_gloo_world2():
     np.testing.assert_allclose(r[0]["noreg"].numpy(), p["noreg"].numpy(), rtol=1e-6, atol=1e-7)
 
 
+SPECS = [("T/a/weights", (3, 3, 2, 4), "conv_w"), ("T/a/beta", (4,), "beta"), ("T/b/weights", (3, 3, 4, 5), "conv_w"),
+         ("T/b/gamma", (5,), "gamma"), ("T/unused/weights", (1, 1, 5, 7), "conv_w"), ("T/c/weights", (2, 2, 3, 5), "deconv_w"),
+         ("T/c/biases", (3,), "bias"), ("T/a/moving_mean", (4,), "moving_mean")]
+
+
+class _ToyModel(object):
+    """A ParamStore-backed stand-in for a plugin: plain torch ops on the CPU, one variable never used."""
+
+    def __init__(self):
+        from boxsegliver_amd.NetworksV2.base import ParamStore
+        self.params = ParamStore(SPECS, torch.device("cpu"))
+        self.params.initialize("xavier", seed=3)
+
+    def _get_regularizer(self):
+        return 1e-2, None
+
+    def loss(self, seed):
+        gen = torch.Generator().manual_seed(seed)
+        p, total = self.params, 0.0
+        for name in ("T/a/weights", "T/a/beta", "T/b/weights", "T/b/gamma", "T/c/weights", "T/c/biases"):
+            x = torch.randn(p[name].shape, generator=gen)
+            total = total + ((p[name] * x).sum() + 0.3) ** 2
+        return total
+
+
+def _bucket_worker(rank, world, port, out_dir, overlap):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from boxsegliver_amd import ops
+    from boxsegliver_amd.core.solver import Solver
+    from boxsegliver_amd.utils.distribution_utils import DistributionStrategy
+    ops.adam_step = _cpu_adam
+    model = _ToyModel()
+    solver = Solver(_solver_args())
+    solver.strategy = DistributionStrategy("mirrored", world, rank)
+    solver.overlap_allreduce = overlap
+    solver.bucket_bytes = 256                      # several buckets per buffer
+    fired = []
+    for step in range(3):
+        solver(model.loss(10 * step + rank), model)
+        if overlap:
+            fired.append(list(solver._buckets._fired))
+    torch.save({"flat": model.params.flat, "n_buckets": len(solver._buckets.buckets) if overlap else 0, "fired": fired},
+               os.path.join(out_dir, "r{}.pt".format(rank)))
+    dist.destroy_process_group()
+
+
+def test_bucketed_overlapped_allreduce_equals_plain_allreduce_gloo_world2():
+    """GradBuckets: hooks fire the per-bucket all-reduce during backward; the result is bit-identical to one
+    all-reduce per buffer after backward, covers a variable that never receives a gradient, and equals Adam on
+    the mean of the replica gradients."""
+    world, res = 2, {}
+    for overlap in (True, False):
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(_bucket_worker, args=(world, _free_port(), d, overlap), nprocs=world, join=True)
+            res[overlap] = [torch.load(os.path.join(d, "r{}.pt".format(i))) for i in range(world)]
+    assert res[True][0]["n_buckets"] >= 4
+    assert all(all(f) for f in res[True][0]["fired"])
+    for g in ("reg", "noreg", "stats"):
+        assert torch.equal(res[True][0]["flat"][g], res[True][1]["flat"][g])
+        assert torch.equal(res[True][0]["flat"][g], res[False][0]["flat"][g])
+    # single-process reference
+    model = _ToyModel()
+    st = {g: (torch.zeros_like(model.params.flat[g]), torch.zeros_like(model.params.flat[g])) for g in ("reg", "noreg")}
+    for step in range(3):
+        grads = {g: torch.zeros_like(model.params.flat[g]) for g in ("reg", "noreg")}
+        for rank in range(world):
+            model.params.zero_grad()
+            model.loss(10 * step + rank).backward()
+            for g in grads:
+                grads[g] += model.params.grad[g] / world
+        t = step + 1
+        lr_t = 1e-3 * math.sqrt(1 - 0.99 ** t) / (1 - 0.9 ** t)
+        with torch.no_grad():
+            _cpu_adam(model.params.flat["reg"], grads["reg"], *st["reg"], lr_t, 0.9, 0.99, 1e-8, 1.0, 1e-2)
+            _cpu_adam(model.params.flat["noreg"], grads["noreg"], *st["noreg"], lr_t, 0.9, 0.99, 1e-8, 1.0, 0.0)
+    for g in ("reg", "noreg"):
+        np.testing.assert_allclose(res[True][0]["flat"][g].numpy(), model.params.flat[g].detach().numpy(), rtol=1e-5, atol=1e-7)
+
+
 # ----------------------------------------------------------------------------------------- GPU
 YML = dict(init_channels=64, num_down_samples=2, ret_prob=False, ret_pred=True, build_metrics=True)
 

@@ -409,3 +409,23 @@ def test_adam_and_momentum_match_tf_formulas(ops):
     pd3, m3, v3 = dev(pw), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
     ops.adam_step(pd3, dev(g), m3, v3, 1e-3 * math.sqrt(1 - 0.99) / (1 - 0.9), 0.9, 0.99, 1e-8, 1.0, 0.0, 0.05)
     np.testing.assert_allclose(pd3.cpu().numpy(), expect, rtol=2e-5, atol=2e-6)
+
+
+def test_boundary_weights_match_oracle_incl_single_label_slice():
+    """unetk_boundary_weights vs the oracle's scipy restatement (loss_metrics.py:149-165): 3-class synthetic labels,
+    a slice with one label only (no ring: scipy's no-background convention) and a non-square ragged size."""
+    from boxsegliver_amd import ops
+    from boxsegliver_amd.data.synthetic import make_batch
+    from oracle import losses
+    _, labels, _ = make_batch(3, 64, 48, 3, 3, 99)
+    labels[1] = 0
+    lab = torch.from_numpy(labels)
+    got = ops.boundary_weights(lab.cuda()).cpu().numpy()
+    ref = losses.compute_weights("boundary", lab.long(), 3).numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-6)
+    again = ops.boundary_weights(lab.cuda()).cpu().numpy()
+    assert np.array_equal(got, again)
+    rng = np.random.default_rng(3)
+    lab = torch.from_numpy(rng.integers(0, 3, size=(2, 37, 301)).astype(np.int32))
+    np.testing.assert_allclose(ops.boundary_weights(lab.cuda()).cpu().numpy(),
+                               losses.compute_weights("boundary", lab.long(), 3).numpy(), rtol=2e-6)

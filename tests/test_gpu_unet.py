@@ -334,3 +334,58 @@ def test_unet_norm_variants_match_oracle(variant):
         num += np.sum((gg - ref) ** 2)
         den += np.sum(ref ** 2)
     assert (num / den) ** 0.5 < 1e-2
+
+
+def test_unet_img_grad_matches_oracle():
+    """--img_grad (UNet.py:69-71): concat(images, dy, dx) -> 9 input channels; the HIP image-gradient kernel is exact,
+    the 9-channel first layer (direct forward, small-Cin filter gradient) matches fp64 on identical operands."""
+    from boxsegliver_amd import ops
+    from oracle import tf_ops
+    args = make_args(img_grad=True)
+    images, labels = synth(2, 32, 32, 3)
+    t = torch.from_numpy(images)
+    got = ops.image_gradients(t.cuda()).cpu()
+    assert torch.equal(got, torch.cat((t,) + tf_ops.image_gradients(t), dim=-1))
+    model, inputs = build(args, images, labels)
+    net = unet2d.UNet2DOracle(9, 3, img_grad=True)
+    assert [(n, tuple(s), k) for n, s, k in net.specs] == [(n, tuple(s), k) for n, s, k in model.params.specs]
+    params = unet2d.init_params(net.specs, seed=33)
+    model.params.load_state(params)
+    total, _, logits, grads, _ = net.loss_and_grads(params, t, torch.from_numpy(labels).long(), **loss_kwargs(args))
+    ops.DEBUG_CAPTURE = []
+    try:
+        model.params.zero_grad()
+        loss = model(inputs, "train", **YML)
+        loss.backward()
+        torch.cuda.synchronize()
+        captured = ops.DEBUG_CAPTURE
+    finally:
+        ops.DEBUG_CAPTURE = None
+    assert abs(loss.item() - total.item()) < 1e-4 * max(1.0, abs(total.item()))
+    assert np.abs(model.layers["logits"].cpu().numpy() - logits.numpy()).max() < 1e-3
+    first = [c for c in captured if c.get("kind") != "deconv" and c["x"].shape[-1] == 9]
+    assert len(first) == 1 and first[0]["dx"] is None
+    check_unit_backward(first[0])
+    name = "UNet/Encode1/Repeat/convolution2d_1/weights"
+    assert model.params[name].shape == (3, 3, 9, 64)
+    ref = grads[name].numpy().astype(np.float64)
+    gg = model.params[name].grad.cpu().numpy().astype(np.float64)
+    assert np.linalg.norm(gg - ref) / np.linalg.norm(ref) < 1e-2
+
+
+def test_unet_boundary_weight_loss_matches_oracle():
+    """--loss_weight_type boundary: the device EDT map feeds the head as an explicit pixel map."""
+    args = make_args(loss_weight_type="boundary")
+    images, labels = synth(2, 64, 64, 3)
+    model, inputs = build(args, images, labels)
+    net, params = oracle_for(args)
+    model.params.load_state(params)
+    total, data_loss, logits, grads, _ = net.loss_and_grads(
+        params, torch.from_numpy(images), torch.from_numpy(labels).long(), **loss_kwargs(args))
+    model.params.zero_grad()
+    loss = model(inputs, "train", **YML)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - total.item()) < 1e-4 * max(1.0, abs(total.item()))
+    name = "UNet/AdjustChannels/biases"
+    np.testing.assert_allclose(model.params[name].grad.cpu().numpy(), grads[name].numpy(), rtol=2e-3, atol=1e-6)

@@ -184,3 +184,31 @@ def test_unet_regularisation_literal_bias_rule():
     without_b = net.regularization_loss(p, 1e-2, bias_decay=True).item()
     nb = sum(v.numel() for k, v in p.items() if k.endswith("biases"))
     assert math.isclose(with_b - without_b, 1e-2 * 0.5 * nb, rel_tol=1e-5)
+
+
+def test_boundary_weights_against_brute_force():
+    """loss_metrics.py:149-165: ring = pixels with a differently-labelled 3x3 neighbour; w = exp(-EDT/25) + 1,
+    normalised to mean 1 per sample.  Brute-force distances on a hand-made map."""
+    import numpy as np
+    import torch
+    from oracle import losses
+    lab = np.zeros((1, 7, 9), dtype=np.int64)
+    lab[0, 2:5, 3:6] = 1
+    lab[0, 3, 4] = 2
+    w = losses.compute_weights("boundary", torch.from_numpy(lab), 3).numpy()[0]
+    ring = np.zeros((7, 9), bool)
+    for h in range(7):
+        for x in range(9):
+            for dh in (-1, 0, 1):
+                for dw in (-1, 0, 1):
+                    hh, ww = h + dh, x + dw
+                    if 0 <= hh < 7 and 0 <= ww < 9 and lab[0, hh, ww] != lab[0, h, x]:
+                        ring[h, x] = True
+    ys, xs = np.nonzero(ring)
+    ref = np.zeros((7, 9))
+    for h in range(7):
+        for x in range(9):
+            ref[h, x] = np.exp(-np.sqrt(((ys - h) ** 2 + (xs - x) ** 2).min()) / 25) + 1
+    ref = ref / ref.sum() * 63
+    np.testing.assert_allclose(w, ref, rtol=1e-6)
+    assert abs(w.mean() - 1.0) < 1e-6
