@@ -18,7 +18,10 @@ W_NONE, W_NUMERICAL, W_PROPORTION, W_PIXELMAP = 0, 1, 2, 3
 
 class ConvDesc(Structure):
     _fields_ = [("N", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
-                ("x_stride", c_int32), ("y_stride", c_int32)]
+                ("x_stride", c_int32), ("y_stride", c_int32), ("precision", c_int32)]
+
+
+FP32, BF16 = 0, 1
 
 
 class DeconvDesc(Structure):
@@ -52,6 +55,7 @@ _SIGNATURES = {
     "unetk_abi_version": (c_int, []),
     "unetk_error_string": (c_char_p, [c_int]),
     "unetk_conv3x3_pack": (c_int, [P, c_int, c_int, P, P, P]),
+    "unetk_conv3x3_pack_bf16": (c_int, [P, c_int, c_int, P, P, P]),
     "unetk_conv3x3_stat_rows": (c_int, [POINTER(ConvDesc)]),
     "unetk_conv3x3_fwd": (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
     "unetk_conv3x3_dgrad": (c_int, [POINTER(ConvDesc), P, P, P, P]),

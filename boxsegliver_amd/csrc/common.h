@@ -73,9 +73,14 @@ struct ConvParams {
   int tiles_h, tiles_w, n_ntiles, stat_rows;
   ImgAddr xa, ya;
   int accumulate;                    // epilogue: y += acc (depth taps of a 3-D conv), statistics on the sum
+  int bf16;                          // operands rounded to bf16 for v_mfma_f32_32x32x16_bf16 (wp = bf16 K8 pack)
 };
 int unetk_conv_run(ConvParams p, hipStream_t st);          // conv_igemm.hip: picks the tile configuration
 int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout);
+// conv_igemm_bf16.hip
+bool unetk_conv_bf16_ok(int Cin, int Cout);
+int unetk_conv_run_bf16(ConvParams p, hipStream_t st);
+int unetk_conv_stat_rows_bf16(int N, int H, int W, int Cin, int Cout);
 
 struct WgParams {
   const float* x;
@@ -85,6 +90,7 @@ struct WgParams {
   int N, H, W, Cin, Cout, xs, ys;
   int tiles_h, tiles_w, total_tiles, tiles_per_split, n_ci_tiles, n_co_tiles;
   ImgAddr xa, ya;
+  int bf16;            // x and dy rounded to bf16 on their way out of LDS, v_mfma_f32_32x32x16_bf16
 };
 // conv_wgrad.hip: dw[9][Cin][Cout] = filter gradient of one 2-D tap plane; ws layout as unetk_conv3x3_wgrad
 size_t unetk_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout);

@@ -342,6 +342,7 @@ int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout) {
 }
 
 int unetk_conv_run(ConvParams p, hipStream_t st) {
+  if (p.bf16) return unetk_conv_run_bf16(p, st);
   const ConvCfg cfg = pick_cfg(p.Cin, p.Cout);
   p.tiles_h = (p.H + cfg.th - 1) / cfg.th;
   p.tiles_w = (p.W + TW - 1) / TW;
@@ -392,6 +393,7 @@ extern "C" int unetk_conv3x3_pack(const float* w, int Cin, int Cout, float* wp_f
 
 extern "C" int unetk_conv3x3_stat_rows(const unetk_conv_desc* d) {
   if (!conv_desc_ok(d)) return UNETK_E_BADARG;
+  if (d->precision == UNETK_BF16) return unetk_conv_stat_rows_bf16(d->N, d->H, d->W, d->Cin, d->Cout);
   const ConvCfg cfg = pick_cfg(d->Cin, d->Cout);
   return d->N * ((d->H + cfg.th - 1) / cfg.th) * ((d->W + TW - 1) / TW);
 }
@@ -402,7 +404,9 @@ extern "C" int unetk_conv3x3_fwd(const unetk_conv_desc* d, const float* x, const
   UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(w) && unetk_aligned16(y));
   UNETK_REQUIRE(d->y_stride % 4 == 0);
   if (pick_cfg(d->Cin, d->Cout).id >= 0) UNETK_REQUIRE(d->x_stride % 4 == 0);
+  if (d->precision == UNETK_BF16 && !unetk_conv_bf16_ok(d->Cin, d->Cout)) return UNETK_E_UNSUPPORTED;
   ConvParams p{};
+  p.bf16 = d->precision == UNETK_BF16;
   p.x = x; p.wp = w; p.y = y; p.stat = stat_partials;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.xs = d->x_stride; p.ys = d->y_stride;
   p.xa = unetk_dense_addr(p.H, p.W, p.xs);
@@ -417,7 +421,9 @@ extern "C" int unetk_conv3x3_dgrad(const unetk_conv_desc* d, const float* dy, co
   // dgrad = conv3x3 with Cin <-> Cout on the packed, tap-flipped filters
   if (pick_cfg(d->Cout, d->Cin).id < 0) return UNETK_E_UNSUPPORTED;
   UNETK_REQUIRE(d->x_stride % 4 == 0 && d->y_stride % 4 == 0);
+  if (d->precision == UNETK_BF16 && !unetk_conv_bf16_ok(d->Cout, d->Cin)) return UNETK_E_UNSUPPORTED;
   ConvParams p{};
+  p.bf16 = d->precision == UNETK_BF16;
   p.x = dy; p.wp = w; p.y = dx; p.stat = nullptr;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cout; p.Cout = d->Cin; p.xs = d->y_stride; p.ys = d->x_stride;
   p.xa = unetk_dense_addr(p.H, p.W, p.xs);

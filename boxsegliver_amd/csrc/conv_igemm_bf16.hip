@@ -1,0 +1,332 @@
+// conv3x3 (stride 1, SAME) forward / input-gradient on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16) with
+// fp32 accumulation -- the mixed-precision mode of BASELINE.json configs[2] ("UNet 512x512x3 bs=64 bf16").
+//
+// Same implicit-GEMM structure as conv_igemm.hip (M = a TH x 16 pixel tile, N = Cout tile, K = 9 taps x Cin; the
+// input halo staged once per channel chunk, all nine taps read shifted A fragments from it), re-proportioned for a
+// matrix pipe that is 16x faster than the fp32 one:
+//   * activations stay fp32 in HBM (round 1); the staging pass rounds them to bf16 (RNE, v_cvt_pk_bf16_f32) on
+//     the way into LDS, so an LDS pixel row holds 32 channels in the 64 B the fp32 kernel needs for 16;
+//   * filters are pre-packed to bf16 "K8-interleaved" [tap][Cin/8][Cout][8], so that -- exactly like the fp32
+//     kernel's K4 layout -- every A and every B fragment of a 32x32x16 MFMA is ONE conflict-free ds_read_b128;
+//   * per (chunk, tap) a wave issues TM + TN ds_read_b128 for TM x TN MFMAs of 32 cycles, and what bounds the
+//     kernel is the L2 -> LDS stream (halo + the nine filter panels of the chunk), which scales as 1/BM for the
+//     filters and 1/BN for the halo: hence the tall 512 x 128 block tile (8 waves, 4 x 2 MFMA tiles per wave).
+// Statistics for the following norm come from the fp32 accumulators, as in the fp32 kernel.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int CKB = 32;  // input channels per K-chunk
+constexpr int PSQ = 5;   // LDS pixel stride in 16-B units: 64 B of bf16 + 16 B pad -> conflict-free ds_read_b128
+constexpr int TW = 16;
+constexpr int HWD = TW + 2;
+
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvParams p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int TH = BM / TW, HH = TH + 2;
+  constexpr int HALO_PIX = HH * HWD;
+  constexpr int HALO_Q = HALO_PIX * PSQ;          // 16-B units per halo buffer
+  constexpr int WB_Q = CKB / 8 * BN;              // 16-B units per filter panel
+  constexpr int HR = (HALO_PIX * 4 + NT - 1) / NT;  // (pixel, 8-channel group) items per thread
+  constexpr int WR = (WB_Q + NT - 1) / NT;
+
+  extern __shared__ __attribute__((aligned(16))) uint4 smem_q[];
+  uint4* halo = smem_q;               // [2][HALO_Q]
+  uint4* wbuf = smem_q + 2 * HALO_Q;  // [2][WB_Q]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = bid % p.n_ntiles;
+  const int mtile = bid / p.n_ntiles;
+  const int tw_i = mtile % p.tiles_w;
+  const int th_i = (mtile / p.tiles_w) % p.tiles_h;
+  const int n_img = mtile / (p.tiles_w * p.tiles_h);
+  const int h0 = th_i * TH, w0 = tw_i * TW, n0 = ntile * BN;
+  const int64_t ximg = p.xa.off(n_img), yimg = p.ya.off(n_img);
+
+  int64_t hoff[HR];
+  bool hok[HR];
+  int hlds[HR];
+#pragma unroll
+  for (int r = 0; r < HR; ++r) {
+    const int idx = tid + r * NT;
+    const int pix = idx >> 2, q = idx & 3;
+    const int hh = pix / HWD, ww = pix - hh * HWD;
+    const int gh = h0 - 1 + hh, gw = w0 - 1 + ww;
+    hok[r] = (idx < HALO_PIX * 4) && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+    hoff[r] = ximg + ((int64_t)gh * p.W + gw) * p.xs + q * 8;
+    hlds[r] = (idx < HALO_PIX * 4) ? pix * PSQ + q : -1;
+  }
+  const int cin8 = p.Cin >> 3;
+  const uint4* wq = reinterpret_cast<const uint4*>(p.wp);
+  int woff[WR];
+#pragma unroll
+  for (int r = 0; r < WR; ++r) {
+    const int idx = tid + r * NT;
+    const int q = idx / BN, n = idx - q * BN;
+    woff[r] = q * p.Cout + n0 + n;
+  }
+
+  float4 hreg[HR][2];
+  uint4 wreg[WR];
+  auto load_halo = [&](int c) {
+#pragma unroll
+    for (int r = 0; r < HR; ++r) {
+      if (hok[r]) {
+        hreg[r][0] = ldg4(p.x + hoff[r] + c * CKB);
+        hreg[r][1] = ldg4(p.x + hoff[r] + c * CKB + 4);
+      } else {
+        hreg[r][0] = hreg[r][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  auto store_halo = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < HR; ++r)
+      if (hlds[r] >= 0) {
+        uint4 v;
+        v.x = pk_bf16(hreg[r][0].x, hreg[r][0].y);
+        v.y = pk_bf16(hreg[r][0].z, hreg[r][0].w);
+        v.z = pk_bf16(hreg[r][1].x, hreg[r][1].y);
+        v.w = pk_bf16(hreg[r][1].z, hreg[r][1].w);
+        halo[buf * HALO_Q + hlds[r]] = v;
+      }
+  };
+  auto load_w = [&](int c, int t) {
+    const uint4* base = wq + ((int64_t)t * cin8 + c * (CKB / 8)) * p.Cout;
+#pragma unroll
+    for (int r = 0; r < WR; ++r)
+      if (tid + r * NT < WB_Q) wreg[r] = base[woff[r]];
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < WR; ++r)
+      if (tid + r * NT < WB_Q) wbuf[buf * WB_Q + tid + r * NT] = wreg[r];
+  };
+
+  int abase[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int sub = wm * TM + tm;
+    abase[tm] = ((2 * sub + (l31 >> 4)) * HWD + (l31 & 15)) * PSQ + h;
+  }
+  const int bbase = h * BN + wn * TN * 32 + l31;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+  const int nchunks = p.Cin / CKB;
+
+  load_halo(0);
+  load_w(0, 0);
+  store_halo(0);
+  store_w(0);
+  __syncthreads();
+
+  int step = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const uint4* hb = halo + (c & 1) * HALO_Q;
+    const bool more_chunks = (c + 1 < nchunks);
+#pragma unroll
+    for (int t = 0; t < 9; ++t, ++step) {
+      const bool has_next = (t < 8) || more_chunks;
+      if (has_next) load_w(t < 8 ? c : c + 1, t < 8 ? t + 1 : 0);
+      if (t == 0 && more_chunks) load_halo(c + 1);   // HBM latency >> one tap step: a whole chunk of slack
+
+      const uint4* wb = wbuf + (step & 1) * WB_Q;
+      const int toff = ((t / 3) * HWD + (t % 3)) * PSQ;
+#pragma unroll
+      for (int g = 0; g < CKB / 16; ++g) {
+        uint4 a[TM], b[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) a[tm] = hb[abase[tm] + toff + 2 * g];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) b[tn] = wb[bbase + 2 * g * BN + tn * 32];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[tm]),
+                                                                  __builtin_bit_cast(bf16x8, b[tn]), acc[tm][tn], 0, 0, 0);
+      }
+
+      if (has_next) store_w((step + 1) & 1);
+      if (t == 8 && more_chunks) store_halo((c + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: raw conv output (fp32) + per-channel statistics from the fp32 accumulators
+  float ssum[TN], ssq[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) ssum[tn] = ssq[tn] = 0.f;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int sub = wm * TM + tm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = mfma32_row(r, h);
+      const int gh = h0 + 2 * sub + (i >> 4), gw = w0 + (i & 15);
+      if (gh < p.H && gw < p.W) {
+        float* yp = p.y + yimg + ((int64_t)gh * p.W + gw) * p.ys + n0 + wn * TN * 32 + l31;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          float v = acc[tm][tn][r];
+          if (p.accumulate) v += yp[tn * 32];
+          yp[tn * 32] = v;
+          ssum[tn] += v;
+          ssq[tn] += v * v;
+        }
+      }
+    }
+  }
+  if (p.stat != nullptr) {
+    float* red = reinterpret_cast<float*>(smem_q);  // [2][WM][BN]; behind the main loop's last barrier
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      ssum[tn] += __shfl_xor(ssum[tn], 32);
+      ssq[tn] += __shfl_xor(ssq[tn], 32);
+      if (h == 0) {
+        red[(0 * WM + wm) * BN + (wn * TN + tn) * 32 + l31] = ssum[tn];
+        red[(1 * WM + wm) * BN + (wn * TN + tn) * 32 + l31] = ssq[tn];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * BN; i += NT) {
+      const int k = i / BN, n = i - k * BN;
+      float s = 0.f;
+#pragma unroll
+      for (int m = 0; m < WM; ++m) s += red[(k * WM + m) * BN + n];
+      p.stat[((int64_t)k * p.stat_rows + mtile) * p.Cout + n0 + n] = s;
+    }
+  }
+}
+
+// Filter re-layout + rounding.  K8-interleaved panel: wp[t][q][n][j] = bf16(B_t[k = 8q + j][n]).
+//   forward : B_t[k = ci][n = co] = w[t][ci][co]
+//   dgrad   : B_t[k = co][n = ci] = w[8 - t][ci][co]
+__global__ void pack_conv3x3_bf16_kernel(const float* __restrict__ w, int Cin, int Cout, uint4* __restrict__ wp_fwd,
+                                         uint4* __restrict__ wp_dgrad) {
+  const int64_t total = (int64_t)9 * Cin * Cout / 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    if (wp_fwd != nullptr) {
+      const int n = (int)(i % Cout);
+      const int64_t r = i / Cout;
+      const int q = (int)(r % (Cin / 8));
+      const int t = (int)(r / (Cin / 8));
+      const float* s = w + ((int64_t)t * Cin + 8 * q) * Cout + n;
+      const int64_t cs = Cout;
+      uint4 v;
+      v.x = pk_bf16(s[0], s[cs]);
+      v.y = pk_bf16(s[2 * cs], s[3 * cs]);
+      v.z = pk_bf16(s[4 * cs], s[5 * cs]);
+      v.w = pk_bf16(s[6 * cs], s[7 * cs]);
+      wp_fwd[i] = v;
+    }
+    if (wp_dgrad != nullptr) {
+      const int n = (int)(i % Cin);
+      const int64_t r = i / Cin;
+      const int q = (int)(r % (Cout / 8));
+      const int t = (int)(r / (Cout / 8));
+      const float* s = w + ((int64_t)(8 - t) * Cin + n) * Cout + 8 * q;
+      uint4 v;
+      v.x = pk_bf16(s[0], s[1]);
+      v.y = pk_bf16(s[2], s[3]);
+      v.z = pk_bf16(s[4], s[5]);
+      v.w = pk_bf16(s[6], s[7]);
+      wp_dgrad[i] = v;
+    }
+  }
+}
+
+struct BfCfg {
+  int id, th;
+};
+
+// 0: 512x128 (8 waves)  1: 128x128  2: 512x64 (8 waves)  3: 128x64  4: 256x32
+inline BfCfg pick_bf16(int H, int Cin, int Cout) {
+  if (Cin % CKB != 0 || Cout % 32 != 0) return {-1, 8};
+  const bool tall = H >= 24;
+  if (Cout % 128 == 0) return tall ? BfCfg{0, 32} : BfCfg{1, 8};
+  if (Cout % 64 == 0) return tall ? BfCfg{2, 32} : BfCfg{3, 8};
+  return {4, 16};
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_bf16(const ConvParams& p, int n_mtiles, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int TH = BM / TW;
+  constexpr size_t lds = (size_t)(2 * (TH + 2) * HWD * PSQ + 2 * (CKB / 8) * BN) * 16;
+  static_assert(lds >= 2 * WM * BN * sizeof(float), "stat scratch must fit");
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto kern = conv3x3_igemm_bf16_kernel<WM, WN, TM, TN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(n_mtiles * p.n_ntiles), dim3(WM * WN * 64), lds, st, p);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+}  // namespace
+
+bool unetk_conv_bf16_ok(int Cin, int Cout) { return Cin % CKB == 0 && Cout % 32 == 0; }
+
+int unetk_conv_stat_rows_bf16(int N, int H, int W, int Cin, int Cout) {
+  const BfCfg cfg = pick_bf16(H, Cin, Cout);
+  if (cfg.id < 0) return UNETK_E_UNSUPPORTED;
+  return N * ((H + cfg.th - 1) / cfg.th) * ((W + TW - 1) / TW);
+}
+
+int unetk_conv_run_bf16(ConvParams p, hipStream_t st) {
+  const BfCfg cfg = pick_bf16(p.H, p.Cin, p.Cout);
+  if (cfg.id < 0) return UNETK_E_UNSUPPORTED;
+  if (p.xs % 4 != 0) return UNETK_E_BADARG;
+  p.tiles_h = (p.H + cfg.th - 1) / cfg.th;
+  p.tiles_w = (p.W + TW - 1) / TW;
+  const int n_mtiles = p.N * p.tiles_h * p.tiles_w;
+  p.stat_rows = n_mtiles;
+  switch (cfg.id) {
+    case 0: p.n_ntiles = p.Cout / 128; return launch_bf16<4, 2, 4, 2>(p, n_mtiles, st);
+    case 1: p.n_ntiles = p.Cout / 128; return launch_bf16<2, 2, 2, 2>(p, n_mtiles, st);
+    case 2: p.n_ntiles = p.Cout / 64; return launch_bf16<4, 2, 4, 1>(p, n_mtiles, st);
+    case 3: p.n_ntiles = p.Cout / 64; return launch_bf16<4, 1, 1, 2>(p, n_mtiles, st);
+    default: p.n_ntiles = p.Cout / 32; return launch_bf16<4, 1, 2, 1>(p, n_mtiles, st);
+  }
+}
+
+extern "C" int unetk_conv3x3_pack_bf16(const float* w_hwio, int Cin, int Cout, void* wp_fwd, void* wp_dgrad,
+                                       void* stream) {
+  UNETK_REQUIRE(w_hwio && Cin > 0 && Cout > 0 && (wp_fwd || wp_dgrad));
+  if (Cin % 8 != 0 || Cout % 8 != 0) return UNETK_E_UNSUPPORTED;
+  UNETK_REQUIRE((!wp_fwd || unetk_aligned16(wp_fwd)) && (!wp_dgrad || unetk_aligned16(wp_dgrad)));
+  const int64_t total = (int64_t)9 * Cin * Cout / 8;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_conv3x3_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_hwio, Cin, Cout,
+                     (uint4*)wp_fwd, (uint4*)wp_dgrad);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}

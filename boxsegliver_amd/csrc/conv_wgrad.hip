@@ -35,7 +35,26 @@ struct WgGeom {
   static_assert(2 * STAGE_F * sizeof(float) <= WG_LDS_BYTES, "ring must fit");
 };
 
-template <int CIT, int COT>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+  uint4 q;
+  q.x = pk_bf16(v[0], v[1]);
+  q.y = pk_bf16(v[2], v[3]);
+  q.z = pk_bf16(v[4], v[5]);
+  q.w = pk_bf16(v[6], v[7]);
+  return __builtin_bit_cast(bf16x8, q);
+}
+
+// BF = UNETK_BF16: same staging (fp32 tiles by direct-to-LDS loads); a k-step is one 16-pixel tile row, each lane
+// gathers its 8 pixels (lane half h -> columns 8h..8h+7) of x (10 per filter row: the three kw taps share them) and
+// dy from LDS, rounds them to bf16 and issues v_mfma_f32_32x32x16_bf16: 9 MFMAs of 32 cycles per 38 ds_read_b32.
+template <int CIT, int COT, bool BF>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
   using G = WgGeom<CIT, COT>;
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][STAGE_F]
@@ -118,6 +137,22 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
 #pragma unroll 1
     for (int rr = 0; rr < G::RPW; ++rr) {
       const int r = ks * G::RPW + rr;
+      if constexpr (BF) {
+        float bv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv[j] = dyt[(r * TW + 8 * h + j) * COT + b_lane];
+        const bf16x8 b = pack8(bv);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          float av[10];
+#pragma unroll
+          for (int j = 0; j < 10; ++j) av[j] = xh[((r + kh) * HWD + 8 * h + j) * CIT + a_lane];
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw)
+            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(av + kw), b, acc[kh * 3 + kw], 0, 0, 0);
+        }
+        continue;
+      }
 #pragma unroll
       for (int c2 = 0; c2 < TW / 2; ++c2) {
         const int col = 2 * c2 + h;
@@ -392,9 +427,9 @@ WgPlan wg_plan(int N, int H, int W, int Cin, int Cout) {
   return pl;
 }
 
-template <int CIT, int COT>
+template <int CIT, int COT, bool BF>
 int launch_wgrad(const WgParams& p, int grid, hipStream_t st) {
-  auto kern = conv3x3_wgrad_kernel<CIT, COT>;
+  auto kern = conv3x3_wgrad_kernel<CIT, COT, BF>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_BYTES);
@@ -428,10 +463,15 @@ int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_
   if (pl.mode == 0) {
     if (p.xs % 4 != 0 || p.ys % 4 != 0) return UNETK_E_BADARG;
     const int grid = pl.S * pl.n_ci_tiles * pl.n_co_tiles;
-    if (pl.cit == 64 && pl.cot == 64) rc = launch_wgrad<64, 64>(p, grid, st);
-    else if (pl.cit == 64) rc = launch_wgrad<64, 32>(p, grid, st);
-    else if (pl.cot == 64) rc = launch_wgrad<32, 64>(p, grid, st);
-    else rc = launch_wgrad<32, 32>(p, grid, st);
+    if (p.bf16) {
+      if (pl.cit == 64 && pl.cot == 64) rc = launch_wgrad<64, 64, true>(p, grid, st);
+      else if (pl.cit == 64) rc = launch_wgrad<64, 32, true>(p, grid, st);
+      else if (pl.cot == 64) rc = launch_wgrad<32, 64, true>(p, grid, st);
+      else rc = launch_wgrad<32, 32, true>(p, grid, st);
+    } else if (pl.cit == 64 && pl.cot == 64) rc = launch_wgrad<64, 64, false>(p, grid, st);
+    else if (pl.cit == 64) rc = launch_wgrad<64, 32, false>(p, grid, st);
+    else if (pl.cot == 64) rc = launch_wgrad<32, 64, false>(p, grid, st);
+    else rc = launch_wgrad<32, 32, false>(p, grid, st);
     if (rc != UNETK_OK) return rc;
   } else if (9 * p.Cin <= 32 && p.Cout == CT && p.ys % 4 == 0) {
     const size_t lds3 = (size_t)(TH * TW * CT + HALO_PIX * 4) * sizeof(float);
@@ -478,6 +518,7 @@ extern "C" int unetk_conv3x3_wgrad(const unetk_conv_desc* d, const float* x, con
   WgParams p{};
   p.x = x; p.dy = dy;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.xs = d->x_stride; p.ys = d->y_stride;
+  p.bf16 = d->precision == UNETK_BF16;     // small-Cin layers (first conv) ignore it: they run the fp32 kernels
   p.xa = unetk_dense_addr(p.H, p.W, p.xs);
   p.ya = unetk_dense_addr(p.H, p.W, p.ys);
   return unetk_wgrad_run(p, dw, ws, ws_bytes, (hipStream_t)stream);

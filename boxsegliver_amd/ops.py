@@ -63,7 +63,14 @@ class _Timed(object):
         return False
 
 
-def _igemm_tag(cin, cout):
+def _igemm_tag(cin, cout, bf16=False, h=0):
+    if bf16 and cin % 32 == 0 and cout % 32 == 0:
+        tall = h >= 24
+        if cout % 128 == 0:
+            return "conv3x3_igemm_bf16_kernel<4,2,4,2>" if tall else "conv3x3_igemm_bf16_kernel<2,2,2,2>"
+        if cout % 64 == 0:
+            return "conv3x3_igemm_bf16_kernel<4,2,4,1>" if tall else "conv3x3_igemm_bf16_kernel<4,1,1,2>"
+        return "conv3x3_igemm_bf16_kernel<4,1,2,1>"
     if cin % 16 == 0 and cout % 128 == 0:
         return "conv3x3_igemm_kernel<2,2,2,2>"
     if cin % 16 == 0 and cout % 64 == 0:
@@ -100,10 +107,21 @@ def _pix_stride(t):
 
 
 # ----------------------------------------------------------------------------- raw op wrappers
-def conv3x3_pack(w, want_dgrad=True):
+def conv_uses_bf16(cin, cout):
+    """UNETK_BF16 kernels exist for Cin % 32 == 0 and Cout % 32 == 0; other layers (the first conv) stay fp32."""
+    return cin % 32 == 0 and cout % 32 == 0
+
+
+def conv3x3_pack(w, want_dgrad=True, bf16=False):
     _require_cuda(w)
     kh, kw, cin, cout = w.shape
     assert kh == 3 and kw == 3
+    if bf16:
+        wp_f = torch.empty(9 * cin * cout, dtype=torch.bfloat16, device=w.device)
+        wp_d = torch.empty_like(wp_f) if want_dgrad else None
+        check(_abi.lib().unetk_conv3x3_pack_bf16(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()),
+              "conv3x3_pack_bf16")
+        return wp_f, wp_d
     wp_f = torch.empty(9 * cin * cout, dtype=torch.float32, device=w.device)
     wp_d = torch.empty_like(wp_f) if want_dgrad else None
     check(_abi.lib().unetk_conv3x3_pack(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()), "conv3x3_pack")
@@ -114,13 +132,13 @@ def conv_uses_mfma(cin, cout):
     return cin % 16 == 0 and cout % 32 == 0
 
 
-def conv3x3_fwd(x, w, cout, want_stats=True, y=None):
+def conv3x3_fwd(x, w, cout, want_stats=True, y=None, bf16=False):
     """x NHWC (pixel-strided ok); w = packed filter if conv_uses_mfma(cin, cout) else raw HWIO."""
     _require_cuda(x, w)
     n, h, wd, cin = x.shape
     if y is None:
         y = torch.empty((n, h, wd, cout), dtype=torch.float32, device=x.device)
-    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(x), _pix_stride(y))
+    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(x), _pix_stride(y), _abi.BF16 if bf16 else _abi.FP32)
     stats = None
     rows = 0
     if want_stats:
@@ -128,35 +146,38 @@ def conv3x3_fwd(x, w, cout, want_stats=True, y=None):
         if rows <= 0:
             check(rows, "conv3x3_stat_rows")
         stats = torch.empty((2, rows, cout), dtype=torch.float32, device=x.device)
-    with _Timed(_igemm_tag(cin, cout), 18.0 * n * h * wd * cin * cout, "fwd {}x{}x{} {}->{}".format(n, h, wd, cin, cout)):
+    with _Timed(_igemm_tag(cin, cout, bf16, h), 18.0 * n * h * wd * cin * cout,
+                "fwd {}x{}x{} {}->{}".format(n, h, wd, cin, cout)):
         check(_abi.lib().unetk_conv3x3_fwd(ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(stats), stream_ptr()),
               "conv3x3_fwd")
     return y, stats, rows
 
 
-def conv3x3_dgrad(dy, wp_dgrad, cin, x_stride=None, dx=None):
+def conv3x3_dgrad(dy, wp_dgrad, cin, x_stride=None, dx=None, bf16=False):
     _require_cuda(dy, wp_dgrad)
     n, h, wd, cout = dy.shape
     if dx is None:
         dx = torch.empty((n, h, wd, cin), dtype=torch.float32, device=dy.device)
-    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(dx), _pix_stride(dy))
-    with _Timed(_igemm_tag(cout, cin), 18.0 * n * h * wd * cin * cout, "dgrad {}x{}x{} {}->{}".format(n, h, wd, cout, cin)):
+    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(dx), _pix_stride(dy), _abi.BF16 if bf16 else _abi.FP32)
+    with _Timed(_igemm_tag(cout, cin, bf16, h), 18.0 * n * h * wd * cin * cout, "dgrad {}x{}x{} {}->{}".format(n, h, wd, cout, cin)):
         check(_abi.lib().unetk_conv3x3_dgrad(ctypes.byref(d), ptr(dy), ptr(wp_dgrad), ptr(dx), stream_ptr()),
               "conv3x3_dgrad")
     return dx
 
 
-def conv3x3_wgrad(x, dy):
+def conv3x3_wgrad(x, dy, bf16=False):
     _require_cuda(x, dy)
     n, h, wd, cin = x.shape
     cout = dy.shape[3]
-    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(x), _pix_stride(dy))
+    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(x), _pix_stride(dy), _abi.BF16 if bf16 else _abi.FP32)
     nbytes = _abi.lib().unetk_conv3x3_wgrad_ws_bytes(ctypes.byref(d))
     if nbytes == 0:
         raise _abi.UnetkError("conv3x3_wgrad: unsupported shape Cin={} Cout={}".format(cin, cout))
     ws = WORKSPACE.get(nbytes, x.device)
     dw = torch.empty((3, 3, cin, cout), dtype=torch.float32, device=x.device)
     tag = "conv3x3_wgrad_kernel(+slab_reduce)" if cin % 64 == 0 else "conv3x3_wgrad_c3_kernel(+slab_reduce)"
+    if bf16 and cin % 32 == 0:
+        tag = "conv3x3_wgrad_kernel<bf16>(+slab_reduce)"
     with _Timed(tag, 18.0 * n * h * wd * cin * cout, "{}x{}x{} {}->{}".format(n, h, wd, cin, cout)):
         check(_abi.lib().unetk_conv3x3_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes,
                                              stream_ptr()), "conv3x3_wgrad")
@@ -484,9 +505,10 @@ def sumsq(p):
 class NormSpec(object):
     """How a conv unit is normalised (the slim arg_scope state around slim.conv2d)."""
 
-    def __init__(self, kind="batch_norm", eps=1e-3, decay=0.999, training=True):
+    def __init__(self, kind="batch_norm", eps=1e-3, decay=0.999, training=True, bf16=False):
         assert kind in ("batch_norm", "instance_norm", "none")   # "none" = --without_norm: conv + bias + ReLU
         self.kind, self.eps, self.decay, self.training = kind, eps, decay, training
+        self.bf16 = bf16        # UNETK_BF16 contractions (operands rounded to bf16, fp32 accumulate / storage)
 
     @property
     def per_sample(self):
@@ -503,9 +525,10 @@ class Conv3x3NormRelu(torch.autograd.Function):
         _require_cuda(x, w)
         cin, cout = w.shape[2], w.shape[3]
         mfma = conv_uses_mfma(cin, cout)
+        bf16 = bool(getattr(spec, "bf16", False)) and conv_uses_bf16(cin, cout)
         need_dx = ctx.needs_input_grad[0]
         if mfma:
-            wp_f, wp_d = conv3x3_pack(w, want_dgrad=need_dx)
+            wp_f, wp_d = conv3x3_pack(w, want_dgrad=need_dx, bf16=bf16)
         else:
             wp_f, wp_d = w, None
             if need_dx:
@@ -513,7 +536,7 @@ class Conv3x3NormRelu(torch.autograd.Function):
                                       "(got {}->{})".format(cin, cout))
         plain = spec.kind == "none"
         use_batch_stats = (spec.training or spec.per_sample) and not plain
-        y, stats, rows = conv3x3_fwd(x, wp_f, cout, want_stats=use_batch_stats)
+        y, stats, rows = conv3x3_fwd(x, wp_f, cout, want_stats=use_batch_stats, bf16=bf16)
         z = out if out is not None else torch.empty_like(y)
         g_ch = 0 if guide is None else guide.shape[-1]
         if g_ch:
@@ -533,6 +556,7 @@ class Conv3x3NormRelu(torch.autograd.Function):
             ctx.save_for_backward(x, y, aff, guide, gw, gb)
             ctx.wp_d = wp_d
             ctx.need_dx = need_dx
+            ctx.bf16 = bf16
             ctx.desc = d
             ctx.has = (gamma is not None, beta is not None)
             ctx.w_dbg = w.detach() if DEBUG_CAPTURE is not None else None
@@ -545,12 +569,12 @@ class Conv3x3NormRelu(torch.autograd.Function):
         if dz.stride(3) != 1:
             dz = dz.contiguous()
         dy, dgamma, dbeta, dgw, dgb = norm_relu_bwd(ctx.desc, y, dz, aff, ctx.has[0], ctx.has[1], guide, gw, gb)
-        dw = conv3x3_wgrad(x, dy)
-        dx = conv3x3_dgrad(dy, ctx.wp_d, x.shape[3]) if ctx.need_dx else None
+        dw = conv3x3_wgrad(x, dy, bf16=ctx.bf16)
+        dx = conv3x3_dgrad(dy, ctx.wp_d, x.shape[3], bf16=ctx.bf16) if ctx.need_dx else None
         if DEBUG_CAPTURE is not None:
             DEBUG_CAPTURE.append(dict(x=x, y=y, gamma=ctx.gb_dbg[0], beta=ctx.gb_dbg[1], aff=aff, dz=dz, dy=dy, dw=dw,
                                       dx=dx, dgamma=dgamma, dbeta=dbeta, w=ctx.w_dbg, guide=guide, gw=gw, gb=gb,
-                                      dgw=dgw, dgb=dgb, per_sample=bool(ctx.desc.per_sample)))
+                                      dgw=dgw, dgb=dgb, per_sample=bool(ctx.desc.per_sample), bf16=ctx.bf16))
         return dx, dw, dgamma, dbeta, None, None, None, None, None, dgw, dgb
 
 

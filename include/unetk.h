@@ -54,13 +54,27 @@ const char* unetk_error_string(int code);
 typedef struct unetk_conv_desc {
   int32_t N, H, W, Cin, Cout;
   int32_t x_stride, y_stride;
+  int32_t precision; /* UNETK_FP32 (exact fp32 MFMA) or UNETK_BF16 */
 } unetk_conv_desc;
+
+/* Arithmetic of the dense contractions.  UNETK_FP32: v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain.
+ * UNETK_BF16 (BASELINE.json configs[2], "bf16"): both operands rounded to bf16 (RNE) on their way into the
+ * matrix cores (v_mfma_f32_32x32x16_bf16), fp32 accumulation, fp32 tensors in memory, fp32 statistics, master
+ * weights and optimiser.  Needs Cin % 32 == 0 and Cout % 32 == 0 (else UNETK_E_UNSUPPORTED: use UNETK_FP32 for
+ * that layer) and filters packed by unetk_conv3x3_pack_bf16. */
+#define UNETK_FP32 0
+#define UNETK_BF16 1
 
 /* Re-layout HWIO filters for the MFMA kernels ("K4-interleaved": [tap][Cin/4][Cout][4]).
  * wp_fwd feeds unetk_conv3x3_fwd; wp_dgrad (taps flipped, Cin<->Cout swapped) feeds
  * unetk_conv3x3_dgrad.  Either output may be NULL.  Each holds 9*Cin*Cout floats. */
 int unetk_conv3x3_pack(const float* w_hwio, int Cin, int Cout, float* wp_fwd, float* wp_dgrad,
                        void* stream);
+
+/* UNETK_BF16 filters: bf16 "K8-interleaved" [tap][Cin/8][Cout][8]; each output holds 9*Cin*Cout bf16
+ * (2 bytes each), 16-byte aligned.  Cin % 8 == 0 and Cout % 8 == 0. */
+int unetk_conv3x3_pack_bf16(const float* w_hwio, int Cin, int Cout, void* wp_fwd, void* wp_dgrad,
+                            void* stream);
 
 /* Number of per-channel statistic partial rows unetk_conv3x3_fwd writes (one per pixel tile). */
 int unetk_conv3x3_stat_rows(const unetk_conv_desc* d);

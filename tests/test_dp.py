@@ -266,3 +266,45 @@ def test_dp_two_replicas_equal_per_chunk_bn_emulation():
     np.testing.assert_allclose(r[0]["losses"], emu_losses, rtol=1e-6)
     for g in ("reg", "noreg", "stats"):
         np.testing.assert_allclose(r[0]["flat"][g].numpy(), model.params.flat[g].cpu().numpy(), rtol=2e-5, atol=2e-7)
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    """RCCL itself (backend "nccl") with the one GPU of the test box: a world of 1 cannot test the sum, but it
+    runs the exact production code path -- per-bucket async all-reduce launched from the autograd thread's hooks
+    on RCCL's stream, finish() joining the compute stream -- which gloo does not."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    from boxsegliver_amd.NetworksV2.UNet import UNet
+    from boxsegliver_amd.utils.distribution_utils import DistributionStrategy, GradBuckets
+    args = _unet_args(2, 1)
+    model = UNet(args)
+    inputs = _shard(0)
+    model(inputs, "eval", **YML)
+    strategy = DistributionStrategy("mirrored", world, rank)
+    strategy.broadcast_(list(model.params.flat.values()))
+    model.params.zero_grad()
+    model(inputs, "train", **YML).backward()
+    plain = {k: v.clone() for k, v in model.params.grad.items()}
+    buckets = GradBuckets(model.params, strategy, bucket_bytes=1 << 20)
+    for _ in range(2):
+        model.params.zero_grad()
+        buckets.arm()
+        model(inputs, "train", **YML).backward()
+        fired_in_backward = sum(buckets._fired)
+        buckets.finish()
+    torch.cuda.synchronize()
+    same = all(torch.equal(plain[k], model.params.grad[k]) for k in plain)
+    mean = strategy.reduce_mean(torch.tensor(3.0, device="cuda")).item()
+    torch.save({"same": same, "n": len(buckets.buckets), "fired": fired_in_backward, "mean": mean},
+               os.path.join(out_dir, "r0.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_bucketed_allreduce_from_backward_hooks_world1():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_rccl_worker, args=(1, _free_port(), d), nprocs=1, join=True)
+        r = torch.load(os.path.join(d, "r0.pt"))
+    assert r["same"] and r["n"] >= 3 and r["fired"] == r["n"] and r["mean"] == 3.0
