@@ -27,6 +27,7 @@ import torch.distributed as dist  # noqa: E402
 # SURVEY.md 8d / BASELINE.md 3: conv / deconv / 1x1 FLOPs only, 2 per MAC, bwd = dgrad + wgrad
 GFLOP_PER_SLICE_FWD_BWD = 288.828
 FP32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 matrix (= vector) peak
+BF16_PEAK_TFLOPS = 2516.6         # dense bf16 MFMA: 256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz (16x the fp32 rate)
 METRIC = "CT slices/sec/node (fwd+bwd) UNet 256×256 bs=32; Dice vs ref"
 
 
@@ -94,6 +95,9 @@ def main():
     ap.add_argument("--model", default="UNet", choices=["UNet", "GUNet", "UNet3D"],
                     help="UNet = the headline workload (BASELINE.json configs[1]); GUNet / UNet3D = configs[3] / [4] "
                          "(use --batch 8 / --size 96 --batch 1..4)")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = the headline configuration (exact fp32 MFMA); bf16 = BASELINE.json configs[2]'s mode: "
+                         "3x3 contractions on the bf16 matrix cores, fp32 accumulate/storage (use --size 512 --batch 8)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,6 +122,7 @@ def main():
     global YML
     args = make_args(a.batch, world, a.size)
     args.model, args.model_config = a.model, None
+    args.compute_dtype = a.dtype
     input_fn = synthetic.input_fn
     gflop_unit, workload_name = GFLOP_PER_SLICE_FWD_BWD * (a.size / 256.0) ** 2, None
     if a.model == "GUNet":          # BASELINE.json configs[3]: spatial guide, instance norm (002_gnet.sh:39)
@@ -180,17 +185,24 @@ def main():
     if rank == 0:
         ms = elapsed / a.steps * 1e3
         slices = a.batch * world * a.steps / elapsed
-        wl = (workload_name or "UNet 2D Liver+Tumor {0}x{0}x3 bs={1}/GPU fp32 (BASELINE.json configs[1])").format(
-            a.size, a.batch) + ", fwd+bwd+TF-Adam" + ("+RCCL grad all-reduce" if world > 1 else "")
+        if workload_name is None:
+            cfg = "configs[1]" if (a.size == 256 and a.dtype == "fp32") else \
+                ("configs[2] shape" if (a.size == 512 and a.batch == 8) else "off-config shape")
+            workload_name = "UNet 2D Liver+Tumor {0}x{0}x3 bs={1}/GPU fp32 (BASELINE.json " + cfg + ")"
+        wl = workload_name.format(a.size, a.batch) + ", fwd+bwd+TF-Adam" + ("+RCCL grad all-reduce" if world > 1 else "")
+        if a.dtype == "bf16":
+            wl = wl.replace(" fp32", " bf16-MFMA/fp32-accumulate+storage")
+        peak = FP32_PEAK_TFLOPS if a.dtype == "fp32" else BF16_PEAK_TFLOPS
         out = {
             "metric": METRIC if a.model == "UNet" else "{} units/sec/node (fwd+bwd)".format(a.model),
             "value": round(slices, 2), "unit": "slices/s" if a.model != "UNet3D" else "patches/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.dtype == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": wl, "global_batch": a.batch * world, "parallelism": "dp{}".format(world),
                        "classes": len(args.classes) + 1, "final_loss": round(loss_val, 5)},
             "whole_step_tflops": round(slices * gflop_unit / 1e3, 2),
             "whole_step_frac_of_fp32_peak": round(slices * gflop_unit / 1e3 / (FP32_PEAK_TFLOPS * world), 4),
+            "whole_step_frac_of_dtype_peak": round(slices * gflop_unit / 1e3 / (peak * world), 4),
         }
         if prof:
             agg = {}
@@ -206,9 +218,10 @@ def main():
                              "achieved_tflops": round(flops / secs / 1e12, 2), "total_ms_per_step": round(secs / a.steps * 1e3, 3)})
             kern.sort(key=lambda k: -k["total_ms_per_step"])
             top = kern[0]
+            kpeak = BF16_PEAK_TFLOPS if "bf16" in top["kernel"] else FP32_PEAK_TFLOPS
             out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved_tflops"],
-                               "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(top["achieved_tflops"] / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                               "peak": kpeak, "unit": "TFLOP/s",
+                               "frac": round(top["achieved_tflops"] / kpeak, 4), "traffic": None,
                                "avg_launch_ms": top["avg_launch_ms"], "avg_launch_gflop": top["avg_launch_gflop"]}
             out["kernels"] = kern
             # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside the

@@ -102,8 +102,8 @@ class GUNet(base.BaseNet):
         kind, np_ = self._norm
         if kind == "batch_norm":
             return ops.NormSpec("batch_norm", np_["eps"], decay if decay is not None else np_["decay"],
-                                bool(np_["is_training"]))
-        return ops.NormSpec("instance_norm", np_["eps"], 0.0, self.is_training)
+                                bool(np_["is_training"]), self.compute_bf16)
+        return ops.NormSpec("instance_norm", np_["eps"], 0.0, self.is_training, self.compute_bf16)
 
     def _unit(self, x, scope, spec, out=None, guide=None, gw=None, gb=None):
         p = self.params
@@ -184,7 +184,7 @@ class GUNet(base.BaseNet):
 
             for i in reversed(range(nds)):
                 d = "{}/Decode/up{}".format(nm, i + 1)
-                x = ops.DeconvConcat.apply(x, p[d + "/weights"], p[d + "/biases"], skips[i], cats[i])
+                x = ops.DeconvConcat.apply(x, p[d + "/weights"], p[d + "/biases"], skips[i], cats[i], self.compute_bf16)
                 for j in (1, 2):
                     x = self._unit(x, "{0}/Decode/up_conv{1}/up_conv{1}_{2}".format(nm, i + 1, j), self._spec())
 

@@ -93,18 +93,19 @@ class UNet(base.BaseNet):
         p = self.params
         kind, nparams = self._norm
         if kind == "none":           # UNet.py:47-48: conv + bias + ReLU
-            spec = ops.NormSpec("none", 0.0, 0.0, self.is_training)
+            spec = ops.NormSpec("none", 0.0, 0.0, self.is_training, self.compute_bf16)
             z = ops.Conv3x3NormRelu.apply(x, p[scope + "/weights"], None, p[scope + "/biases"], None, None, spec, out,
                                           None, None, None)
         elif kind == "batch_norm":
             bn = scope + "/BatchNorm"
-            spec = ops.NormSpec("batch_norm", nparams["eps"], nparams["decay"], bool(nparams["is_training"]))
+            spec = ops.NormSpec("batch_norm", nparams["eps"], nparams["decay"], bool(nparams["is_training"]),
+                                self.compute_bf16)
             z = ops.Conv3x3NormRelu.apply(x, p[scope + "/weights"], p[bn + "/gamma"], p[bn + "/beta"],
                                           p[bn + "/moving_mean"], p[bn + "/moving_variance"], spec, out, None, None,
                                           None)
         else:                        # slim.instance_norm defaults: centre + scale, eps 1e-6
             inn = scope + "/InstanceNorm"
-            spec = ops.NormSpec("instance_norm", nparams["eps"], 0.0, self.is_training)
+            spec = ops.NormSpec("instance_norm", nparams["eps"], 0.0, self.is_training, self.compute_bf16)
             z = ops.Conv3x3NormRelu.apply(x, p[scope + "/weights"], p[inn + "/gamma"], p[inn + "/beta"], None, None,
                                           spec, out, None, None, None)
         if self._taps is not None:
@@ -158,7 +159,8 @@ class UNet(base.BaseNet):
                 c //= 2
                 d = "{}/Decode{}".format(nm, i + 1)
                 tensor_out = ops.DeconvConcat.apply(tensor_out, self.params[d + "/Conv2d_transpose/weights"],
-                                                    self.params[d + "/Conv2d_transpose/biases"], skips[i], cats[i])
+                                                    self.params[d + "/Conv2d_transpose/biases"], skips[i], cats[i],
+                                                    self.compute_bf16)
                 tensor_out = self._conv_unit(tensor_out, d + "/Repeat/convolution2d_1")
                 tensor_out = self._conv_unit(tensor_out, d + "/Repeat/convolution2d_2")
 

@@ -177,6 +177,12 @@ class BaseNet(object):
         return self._args
 
     @property
+    def compute_bf16(self):
+        """--compute_dtype bf16 (not a reference flag; BASELINE.json configs[2]): the 3x3 contractions round their
+        operands to bf16 for the bf16 matrix cores; tensors, statistics, master weights and the optimiser stay fp32."""
+        return str(getattr(self._args, "compute_dtype", "fp32") or "fp32").lower() in ("bf16", "bfloat16")
+
+    @property
     def num_classes(self):
         return len(self.classes)
 

@@ -26,7 +26,7 @@ FP32, BF16 = 0, 1
 
 class DeconvDesc(Structure):
     _fields_ = [("N", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
-                ("out_stride", c_int32), ("out_coff", c_int32)]
+                ("out_stride", c_int32), ("out_coff", c_int32), ("precision", c_int32)]
 
 
 class Conv3dDesc(Structure):
@@ -36,7 +36,7 @@ class Conv3dDesc(Structure):
 
 class Deconv3dDesc(Structure):
     _fields_ = [("N", c_int32), ("D", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
-                ("kd", c_int32), ("out_stride", c_int32), ("out_coff", c_int32)]
+                ("kd", c_int32), ("out_stride", c_int32), ("out_coff", c_int32), ("precision", c_int32)]
 
 
 class NormDesc(Structure):
@@ -79,6 +79,8 @@ _SIGNATURES = {
     "unetk_avgpool2_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "unetk_image_gradients": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "unetk_deconv2x2_pack": (c_int, [P, c_int, c_int, P, P, P]),
+    "unetk_deconv2x2_pack_bf16": (c_int, [P, c_int, c_int, P, P, P]),
+    "unetk_deconv3d_pack_bf16": (c_int, [P, c_int, c_int, c_int, P, P, P]),
     "unetk_deconv2x2_fwd": (c_int, [POINTER(DeconvDesc), P, P, P, P, P]),
     "unetk_deconv2x2_bwd_ws_bytes": (c_size_t, [POINTER(DeconvDesc)]),
     "unetk_deconv2x2_bwd": (c_int, [POINTER(DeconvDesc), P, P, P, P, P, P, P, P, c_size_t, P]),

@@ -263,12 +263,13 @@ struct BfCfg {
   int id, th;
 };
 
-// 0: 512x128 (8 waves)  1: 128x128  2: 512x64 (8 waves)  3: 128x64  4: 256x32
+// 0: 512x128 (8 waves)  1: 128x128  2: 256x64 (60 KB of LDS: two blocks per CU -- the Cout = 64 layers are
+// HBM-bound, and a second resident block overlaps one block's halo load / output store with the other's MFMAs)
+// 3: 128x64  4: 256x32
 inline BfCfg pick_bf16(int H, int Cin, int Cout) {
   if (Cin % CKB != 0 || Cout % 32 != 0) return {-1, 8};
-  const bool tall = H >= 24;
-  if (Cout % 128 == 0) return tall ? BfCfg{0, 32} : BfCfg{1, 8};
-  if (Cout % 64 == 0) return tall ? BfCfg{2, 32} : BfCfg{3, 8};
+  if (Cout % 128 == 0) return H >= 24 ? BfCfg{0, 32} : BfCfg{1, 8};
+  if (Cout % 64 == 0) return H >= 12 ? BfCfg{2, 16} : BfCfg{3, 8};
   return {4, 16};
 }
 
@@ -312,7 +313,7 @@ int unetk_conv_run_bf16(ConvParams p, hipStream_t st) {
   switch (cfg.id) {
     case 0: p.n_ntiles = p.Cout / 128; return launch_bf16<4, 2, 4, 2>(p, n_mtiles, st);
     case 1: p.n_ntiles = p.Cout / 128; return launch_bf16<2, 2, 2, 2>(p, n_mtiles, st);
-    case 2: p.n_ntiles = p.Cout / 64; return launch_bf16<4, 2, 4, 1>(p, n_mtiles, st);
+    case 2: p.n_ntiles = p.Cout / 64; return launch_bf16<4, 1, 2, 2>(p, n_mtiles, st);
     case 3: p.n_ntiles = p.Cout / 64; return launch_bf16<4, 1, 1, 2>(p, n_mtiles, st);
     default: p.n_ntiles = p.Cout / 32; return launch_bf16<4, 1, 2, 1>(p, n_mtiles, st);
   }

@@ -27,6 +27,7 @@ struct PwParams {
   int n_ntiles;
   ImgAddr oa;         // fwd: output plane of input plane nn;  dgrad: dpre plane of input plane nn
   int accumulate;     // dgrad: dx += (second depth tap)
+  int bf16;           // UNETK_BF16: wp is the bf16 K8 pack
 };
 
 // MODE 0: forward (scatter epilogue), MODE 1: dgrad (gather prologue)
@@ -189,6 +190,186 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_gemm_kernel(PwParams p) {
   }
 }
 
+// ---- UNETK_BF16 variant: same GEMM, operands rounded to bf16 on their way into LDS (A) / pre-packed bf16
+// K8-interleaved [K/8][Ncols][8] (B), v_mfma_f32_32x32x16_bf16, fp32 accumulate; K chunk = 32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int CKB = 32, PSQ = 5;   // LDS row stride in 16-B units: 64 B of bf16 + 16 B pad
+
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+template <int MODE, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM* WN * 64) void pw_gemm_bf16_kernel(PwParams p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int A_Q = BM * PSQ, WB_Q = CKB / 8 * BN;
+  constexpr int AR = (BM * 4) / NT, WR = WB_Q / NT;
+  static_assert((BM * 4) % NT == 0 && WB_Q % NT == 0, "tile must split evenly");
+
+  extern __shared__ __attribute__((aligned(16))) uint4 smem_q[];
+  uint4* abuf = smem_q;              // [2][A_Q]
+  uint4* wbuf = smem_q + 2 * A_Q;    // [2][WB_Q]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = bid % p.n_ntiles, mtile = bid / p.n_ntiles;
+  const int m0 = mtile * BM, n0 = ntile * BN;
+
+  int64_t aoff[AR];
+  bool aok[AR];
+#pragma unroll
+  for (int r = 0; r < AR; ++r) {
+    const int idx = tid + r * NT;
+    const int row = idx >> 2, q = idx & 3;
+    const int m = m0 + row;
+    aok[r] = m < p.M;
+    if (MODE == 0) {
+      aoff[r] = (int64_t)m * p.K + q * 8;
+    } else {
+      const int xx = m % p.W;
+      const int yy = (m / p.W) % p.H;
+      const int nn = m / (p.W * p.H);
+      aoff[r] = p.oa.off(nn) + ((int64_t)(2 * yy) * 2 * p.W + 2 * xx) * p.Cout + q * 8;
+    }
+  }
+  const uint4* wq = reinterpret_cast<const uint4*>(p.wp);
+  int woff[WR];
+#pragma unroll
+  for (int r = 0; r < WR; ++r) {
+    const int idx = tid + r * NT;
+    const int q = idx / BN, n = idx - q * BN;
+    woff[r] = q * p.Ncols + n0 + n;
+  }
+
+  float4 areg[AR][2];
+  uint4 wreg[WR];
+  auto load_a = [&](int s) {
+    int64_t koff;
+    if (MODE == 0) {
+      koff = (int64_t)s * CKB;
+    } else {
+      const int k0 = s * CKB;
+      const int ab = k0 / p.Cout, co0 = k0 - ab * p.Cout;
+      koff = ((int64_t)(ab >> 1) * 2 * p.W + (ab & 1)) * p.Cout + co0;
+    }
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      if (aok[r]) {
+        areg[r][0] = ldg4(p.a + aoff[r] + koff);
+        areg[r][1] = ldg4(p.a + aoff[r] + koff + 4);
+      } else {
+        areg[r][0] = areg[r][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      const int idx = tid + r * NT;
+      uint4 v;
+      v.x = pk_bf16(areg[r][0].x, areg[r][0].y);
+      v.y = pk_bf16(areg[r][0].z, areg[r][0].w);
+      v.z = pk_bf16(areg[r][1].x, areg[r][1].y);
+      v.w = pk_bf16(areg[r][1].z, areg[r][1].w);
+      abuf[buf * A_Q + (idx >> 2) * PSQ + (idx & 3)] = v;
+    }
+  };
+  auto load_w = [&](int s) {
+    const uint4* base = wq + (int64_t)s * (CKB / 8) * p.Ncols;
+#pragma unroll
+    for (int r = 0; r < WR; ++r) wreg[r] = base[woff[r]];
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < WR; ++r) wbuf[buf * WB_Q + tid + r * NT] = wreg[r];
+  };
+
+  int abase[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) abase[tm] = ((wm * TM + tm) * 32 + l31) * PSQ + h;
+  const int bbase = h * BN + wn * TN * 32 + l31;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+  const int nsteps = p.K / CKB;
+  load_a(0);
+  load_w(0);
+  store_a(0);
+  store_w(0);
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const bool has_next = s + 1 < nsteps;
+    if (has_next) {
+      load_a(s + 1);
+      load_w(s + 1);
+    }
+    const uint4* ab_ = abuf + (s & 1) * A_Q;
+    const uint4* wb = wbuf + (s & 1) * WB_Q;
+#pragma unroll
+    for (int g = 0; g < CKB / 16; ++g) {
+      uint4 a[TM], b[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) a[tm] = ab_[abase[tm] + 2 * g];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) b[tn] = wb[bbase + 2 * g * BN + tn * 32];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[tm]),
+                                                                __builtin_bit_cast(bf16x8, b[tn]), acc[tm][tn], 0, 0, 0);
+    }
+    if (has_next) {
+      store_a((s + 1) & 1);
+      store_w((s + 1) & 1);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + (wn * TN + tn) * 32 + l31;
+    int ab = 0, co = n;
+    float bv = 0.f;
+    if (MODE == 0) {
+      ab = n / p.Cout;
+      co = n - ab * p.Cout;
+      bv = p.bias ? p.bias[co] : 0.f;
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + tm) * 32 + mfma32_row(r, h);
+        if (m >= p.M) continue;
+        if (MODE == 0) {
+          const int xx = m % p.W;
+          const int yy = (m / p.W) % p.H;
+          const int nn = m / (p.W * p.H);
+          const int64_t o = p.oa.off(nn) + ((int64_t)(2 * yy + (ab >> 1)) * 2 * p.W + 2 * xx + (ab & 1)) * p.out_stride;
+          p.out[o + p.out_coff + co] = fmaxf(acc[tm][tn][r] + bv, 0.f);
+        } else {
+          float* o = p.out + (int64_t)m * p.Ncols + n;
+          *o = p.accumulate ? *o + acc[tm][tn][r] : acc[tm][tn][r];
+        }
+      }
+  }
+}
+
 // dpre[pix][co] = dcat[pix][coff+co] * (cat[pix][coff+co] > 0); partial[blk][co] = column sums (bias grad)
 __global__ __launch_bounds__(256) void relu_bwd_bias_kernel(const float* __restrict__ cat, const float* __restrict__ dcat,
                                                             int stride, int coff, float* __restrict__ dpre,
@@ -227,7 +408,17 @@ struct DwParams {
   int M, H, W, Cin, Cout;
   int m_per_split, n_co_tiles, n_ci_tiles;
   ImgAddr da;   // dpre plane of input plane nn
+  int bf16;     // UNETK_BF16: a k-step is 16 pixels, each lane rounds its 8 rows of dpre / x to bf16
 };
+
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+  uint4 q;
+  q.x = pk_bf16(v[0], v[1]);
+  q.y = pk_bf16(v[2], v[3]);
+  q.z = pk_bf16(v[4], v[5]);
+  q.w = pk_bf16(v[6], v[7]);
+  return __builtin_bit_cast(bf16x8, q);
+}
 
 __global__ __launch_bounds__(256) void deconv_wgrad_kernel(DwParams p) {
   constexpr int KT = 128, CT = 64;
@@ -267,6 +458,19 @@ __global__ __launch_bounds__(256) void deconv_wgrad_kernel(DwParams p) {
       *reinterpret_cast<float4*>(&bt[row * CT + q * 4]) = vb;
     }
     __syncthreads();
+    if (p.bf16) {
+#pragma unroll 2
+      for (int s = 0; s < KT / 16; ++s) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          av[j] = at[(16 * s + 8 * h + j) * CT + wco * 32 + l31];
+          bv[j] = bt[(16 * s + 8 * h + j) * CT + wci * 32 + l31];
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(av), pack8(bv), acc, 0, 0, 0);
+      }
+      continue;
+    }
 #pragma unroll 8
     for (int s = 0; s < KT / 2; ++s) {
       const float a = at[(2 * s + h) * CT + wco * 32 + l31];
@@ -303,6 +507,44 @@ __global__ void pack_deconv_kernel(const float* __restrict__ w, int Cin, int Cou
   }
 }
 
+// bf16 packs: wp_fwd[q][n=(bc,co)][j] = bf16(w[bc][co][8q+j]) (K = Cin); wp_dgrad[q][n=ci][j] = bf16(w_flat[8q+j][ci])
+__global__ void pack_deconv_bf16_kernel(const float* __restrict__ w, int Cin, int Cout, uint4* __restrict__ wp_fwd,
+                                        uint4* __restrict__ wp_dgrad) {
+  const int64_t total = (int64_t)Cin * Cout / 2;  // 16-B units = 4*Cin*Cout/8
+  const int Nf = 4 * Cout;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    if (wp_fwd != nullptr) {
+      const int n = (int)(i % Nf);
+      const int q = (int)(i / Nf);
+      const float* s = w + (int64_t)n * Cin + 8 * q;
+      uint4 v;
+      v.x = pk_bf16(s[0], s[1]); v.y = pk_bf16(s[2], s[3]); v.z = pk_bf16(s[4], s[5]); v.w = pk_bf16(s[6], s[7]);
+      wp_fwd[i] = v;
+    }
+    if (wp_dgrad != nullptr) {
+      const int n = (int)(i % Cin);
+      const int q = (int)(i / Cin);
+      const float* s = w + (int64_t)(8 * q) * Cin + n;
+      const int64_t cs = Cin;
+      uint4 v;
+      v.x = pk_bf16(s[0], s[cs]); v.y = pk_bf16(s[2 * cs], s[3 * cs]);
+      v.z = pk_bf16(s[4 * cs], s[5 * cs]); v.w = pk_bf16(s[6 * cs], s[7 * cs]);
+      wp_dgrad[i] = v;
+    }
+  }
+}
+
+template <int MODE, int WM, int WN, int TM, int TN>
+int launch_pw_bf16(const PwParams& p, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr size_t lds = (size_t)(2 * BM * PSQ + 2 * (CKB / 8) * BN) * 16;
+  const int n_mtiles = (p.M + BM - 1) / BM;
+  hipLaunchKernelGGL((pw_gemm_bf16_kernel<MODE, WM, WN, TM, TN>), dim3(n_mtiles * p.n_ntiles), dim3(WM * WN * 64), lds, st,
+                     p);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
 template <int MODE, int WM, int WN, int TM, int TN>
 int launch_pw(const PwParams& p, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -317,10 +559,10 @@ template <int MODE>
 int run_pw(PwParams& p, hipStream_t st) {
   if (p.Ncols % 128 == 0) {
     p.n_ntiles = p.Ncols / 128;
-    return launch_pw<MODE, 2, 2, 2, 2>(p, st);
+    return p.bf16 ? launch_pw_bf16<MODE, 2, 2, 2, 2>(p, st) : launch_pw<MODE, 2, 2, 2, 2>(p, st);
   }
   p.n_ntiles = p.Ncols / 64;
-  return launch_pw<MODE, 4, 1, 1, 2>(p, st);
+  return p.bf16 ? launch_pw_bf16<MODE, 4, 1, 1, 2>(p, st) : launch_pw<MODE, 4, 1, 1, 2>(p, st);
 }
 
 bool deconv_desc_ok(const unetk_deconv3d_desc* d) {
@@ -352,11 +594,40 @@ DwPlan dw_plan(const unetk_deconv3d_desc* d) {
 unetk_deconv3d_desc from2d(const unetk_deconv_desc* d) {
   unetk_deconv3d_desc e;
   e.N = d->N; e.D = 1; e.H = d->H; e.W = d->W; e.Cin = d->Cin; e.Cout = d->Cout; e.kd = 1;
-  e.out_stride = d->out_stride; e.out_coff = d->out_coff;
+  e.out_stride = d->out_stride; e.out_coff = d->out_coff; e.precision = d->precision;
   return e;
 }
 
+// filter panel of depth tap a: 4*Cin*Cout elements per tap, 4 bytes (fp32 K4 pack) or 2 bytes (bf16 K8 pack) each
+inline const float* tap_panel(const float* wp, int a, const unetk_deconv3d_desc* d) {
+  const int64_t elems = (int64_t)a * 4 * d->Cin * d->Cout;
+  return d->precision == UNETK_BF16 ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(wp) + elems)
+                                    : wp + elems;
+}
+
 }  // namespace
+
+extern "C" int unetk_deconv3d_pack_bf16(const float* w, int kd, int Cin, int Cout, void* wp_fwd, void* wp_dgrad,
+                                        void* stream) {
+  UNETK_REQUIRE(w && (kd == 1 || kd == 2) && Cin > 0 && Cout > 0 && (wp_fwd || wp_dgrad));
+  if (Cin % 8 != 0 || Cout % 8 != 0) return UNETK_E_UNSUPPORTED;
+  UNETK_REQUIRE((!wp_fwd || unetk_aligned16(wp_fwd)) && (!wp_dgrad || unetk_aligned16(wp_dgrad)));
+  const int64_t total = (int64_t)Cin * Cout / 2;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  for (int a = 0; a < kd; ++a) {
+    const int64_t o = (int64_t)a * Cin * Cout / 2;        // 16-B units per tap
+    hipLaunchKernelGGL(pack_deconv_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       w + (int64_t)a * 4 * Cin * Cout, Cin, Cout, wp_fwd ? (uint4*)wp_fwd + o : nullptr,
+                       wp_dgrad ? (uint4*)wp_dgrad + o : nullptr);
+    UNETK_LAUNCH_CHECK();
+  }
+  return UNETK_OK;
+}
+
+extern "C" int unetk_deconv2x2_pack_bf16(const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad, void* stream) {
+  return unetk_deconv3d_pack_bf16(w, 1, Cin, Cout, wp_fwd, wp_dgrad, stream);
+}
 
 extern "C" int unetk_deconv3d_pack(const float* w, int kd, int Cin, int Cout, float* wp_fwd, float* wp_dgrad,
                                    void* stream) {
@@ -380,10 +651,12 @@ extern "C" int unetk_deconv3d_fwd(const unetk_deconv3d_desc* d, const float* x, 
   UNETK_REQUIRE(deconv_desc_ok(d) && x && wp_fwd && out);
   UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(wp_fwd));
   if (d->Cin % CK != 0 || d->Cout % 16 != 0) return UNETK_E_UNSUPPORTED;
+  if (d->precision == UNETK_BF16 && (d->Cin % CKB != 0 || d->Cout % 32 != 0)) return UNETK_E_UNSUPPORTED;
   const int64_t plane = (int64_t)4 * d->H * d->W * d->out_stride;      // one output depth plane
   for (int a = 0; a < d->kd; ++a) {
     PwParams p{};
-    p.a = x; p.wp = wp_fwd + (int64_t)a * 4 * d->Cin * d->Cout; p.bias = bias; p.out = out + a * plane;
+    p.bf16 = d->precision == UNETK_BF16;
+    p.a = x; p.wp = tap_panel(wp_fwd, a, d); p.bias = bias; p.out = out + a * plane;
     p.M = d->N * d->D * d->H * d->W; p.K = d->Cin; p.Ncols = 4 * d->Cout;
     p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.out_stride = d->out_stride; p.out_coff = d->out_coff;
     p.oa.group = d->D; p.oa.img_stride = d->kd * plane; p.oa.group_stride = (int64_t)d->kd * d->D * plane;
@@ -441,7 +714,8 @@ extern "C" int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const float* x, 
   for (int a = 0; a < d->kd; ++a) {
     // 2. input gradient: [M x 4Cout] . [4Cout x Cin], accumulated over depth taps
     PwParams p{};
-    p.a = dpre + a * plane; p.wp = wp_dgrad + (int64_t)a * 4 * d->Cin * d->Cout; p.bias = nullptr; p.out = dx;
+    p.bf16 = d->precision == UNETK_BF16;
+    p.a = dpre + a * plane; p.wp = tap_panel(wp_dgrad, a, d); p.bias = nullptr; p.out = dx;
     p.M = M; p.K = 4 * d->Cout; p.Ncols = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout;
     p.oa = da; p.accumulate = a > 0 ? 1 : 0;
     rc = run_pw<1>(p, st);
@@ -449,6 +723,7 @@ extern "C" int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const float* x, 
 
     // 3. filter gradient of this depth tap
     DwParams q{};
+    q.bf16 = d->precision == UNETK_BF16;
     q.x = x; q.dpre = dpre + a * plane; q.slab = slab; q.M = M; q.H = d->H; q.W = d->W; q.Cin = d->Cin; q.Cout = d->Cout;
     q.m_per_split = pl.m_per_split; q.n_co_tiles = (d->Cout + 63) / 64; q.n_ci_tiles = d->Cin / 64; q.da = da;
     const int grid = pl.S * 4 * q.n_co_tiles * q.n_ci_tiles;

@@ -65,11 +65,10 @@ class _Timed(object):
 
 def _igemm_tag(cin, cout, bf16=False, h=0):
     if bf16 and cin % 32 == 0 and cout % 32 == 0:
-        tall = h >= 24
         if cout % 128 == 0:
-            return "conv3x3_igemm_bf16_kernel<4,2,4,2>" if tall else "conv3x3_igemm_bf16_kernel<2,2,2,2>"
+            return "conv3x3_igemm_bf16_kernel<4,2,4,2>" if h >= 24 else "conv3x3_igemm_bf16_kernel<2,2,2,2>"
         if cout % 64 == 0:
-            return "conv3x3_igemm_bf16_kernel<4,2,4,1>" if tall else "conv3x3_igemm_bf16_kernel<4,1,1,2>"
+            return "conv3x3_igemm_bf16_kernel<4,1,2,2>" if h >= 12 else "conv3x3_igemm_bf16_kernel<4,1,1,2>"
         return "conv3x3_igemm_bf16_kernel<4,1,2,1>"
     if cin % 16 == 0 and cout % 128 == 0:
         return "conv3x3_igemm_kernel<2,2,2,2>"
@@ -337,29 +336,35 @@ def maxpool2_bwd(x, p, dp):
     return dx
 
 
-def deconv2x2_pack(w):
+def deconv2x2_pack(w, bf16=False):
     _require_cuda(w)
     kh, kw, cout, cin = w.shape
     assert kh == 2 and kw == 2
+    if bf16:
+        wp_f = torch.empty(4 * cin * cout, dtype=torch.bfloat16, device=w.device)
+        wp_d = torch.empty_like(wp_f)
+        check(_abi.lib().unetk_deconv2x2_pack_bf16(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()),
+              "deconv2x2_pack_bf16")
+        return wp_f, wp_d
     wp_f = torch.empty(4 * cin * cout, dtype=torch.float32, device=w.device)
     wp_d = torch.empty_like(wp_f)
     check(_abi.lib().unetk_deconv2x2_pack(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()), "deconv2x2_pack")
     return wp_f, wp_d
 
 
-def deconv2x2_fwd(x, wp_fwd, bias, cat, coff, cout):
+def deconv2x2_fwd(x, wp_fwd, bias, cat, coff, cout, bf16=False):
     n, h, w, cin = x.shape
     assert x.is_contiguous()
-    d = DeconvDesc(n, h, w, cin, cout, _pix_stride(cat), coff)
-    with _Timed("pw_gemm_kernel<fwd>", 8.0 * n * h * w * cin * cout, "{}x{}x{} {}->{}".format(n, h, w, cin, cout)):
+    d = DeconvDesc(n, h, w, cin, cout, _pix_stride(cat), coff, _abi.BF16 if bf16 else _abi.FP32)
+    with _Timed("pw_gemm_bf16_kernel<fwd>" if bf16 else "pw_gemm_kernel<fwd>", 8.0 * n * h * w * cin * cout, "{}x{}x{} {}->{}".format(n, h, w, cin, cout)):
         check(_abi.lib().unetk_deconv2x2_fwd(ctypes.byref(d), ptr(x), ptr(wp_fwd), ptr(bias), ptr(cat), stream_ptr()),
               "deconv2x2_fwd")
     return cat
 
 
-def deconv2x2_bwd(x, wp_dgrad, cat, dcat, coff, cout):
+def deconv2x2_bwd(x, wp_dgrad, cat, dcat, coff, cout, bf16=False):
     n, h, w, cin = x.shape
-    d = DeconvDesc(n, h, w, cin, cout, _pix_stride(cat), coff)
+    d = DeconvDesc(n, h, w, cin, cout, _pix_stride(cat), coff, _abi.BF16 if bf16 else _abi.FP32)
     assert _pix_stride(dcat) == _pix_stride(cat)
     nbytes = _abi.lib().unetk_deconv2x2_bwd_ws_bytes(ctypes.byref(d))
     if nbytes == 0:
@@ -368,7 +373,8 @@ def deconv2x2_bwd(x, wp_dgrad, cat, dcat, coff, cout):
     dx = torch.empty_like(x)
     dw = torch.empty((2, 2, cout, cin), dtype=torch.float32, device=x.device)
     db = torch.empty((cout,), dtype=torch.float32, device=x.device)
-    with _Timed("deconv2x2_bwd(relu_bwd+pw_gemm<dgrad>+deconv_wgrad)", 16.0 * n * h * w * cin * cout,
+    with _Timed("deconv2x2_bwd{}(relu_bwd+pw_gemm<dgrad>+deconv_wgrad)".format("<bf16>" if bf16 else ""),
+                16.0 * n * h * w * cin * cout,
                 "{}x{}x{} {}->{}".format(n, h, w, cin, cout)):
         check(_abi.lib().unetk_deconv2x2_bwd(ctypes.byref(d), ptr(x), ptr(wp_dgrad), ptr(cat), ptr(dcat), ptr(dx),
                                              ptr(dw), ptr(db), ptr(ws), nbytes, stream_ptr()), "deconv2x2_bwd")
@@ -671,15 +677,17 @@ class DeconvConcat(torch.autograd.Function):
     cat[..., :C] (the encoder wrote it there), the kernel fills cat[..., C:] -- zero-copy concat."""
 
     @staticmethod
-    def forward(ctx, x, w, b, skip, cat):
+    def forward(ctx, x, w, b, skip, cat, bf16=False):
         _require_cuda(x, w, b, cat)
         cout = w.shape[2]
         coff = cat.shape[3] - cout
         assert skip.data_ptr() == cat.data_ptr() and skip.shape[3] == coff
-        wp_f, wp_d = deconv2x2_pack(w)
-        deconv2x2_fwd(x, wp_f, b, cat, coff, cout)
+        bf16 = bool(bf16) and conv_uses_bf16(w.shape[3], cout)
+        wp_f, wp_d = deconv2x2_pack(w, bf16)
+        deconv2x2_fwd(x, wp_f, b, cat, coff, cout, bf16)
         ctx.save_for_backward(x, cat)
         ctx.wp_d = wp_d
+        ctx.bf16 = bf16
         ctx.cout, ctx.coff = cout, coff
         ctx.wb_dbg = (w.detach(), b.detach()) if DEBUG_CAPTURE is not None else None
         return alias(cat)
@@ -688,12 +696,12 @@ class DeconvConcat(torch.autograd.Function):
     def backward(ctx, dcat):
         x, cat = ctx.saved_tensors
         dcat = dcat.contiguous()
-        dx, dw, db = deconv2x2_bwd(x, ctx.wp_d, cat, dcat, ctx.coff, ctx.cout)
+        dx, dw, db = deconv2x2_bwd(x, ctx.wp_d, cat, dcat, ctx.coff, ctx.cout, ctx.bf16)
         dskip = dcat[..., :ctx.coff]
         if DEBUG_CAPTURE is not None:
             DEBUG_CAPTURE.append(dict(kind="deconv", x=x, w=ctx.wb_dbg[0], b=ctx.wb_dbg[1], cat=cat.clone(),
-                                      dcat=dcat, dx=dx, dw=dw, db=db, coff=ctx.coff))
-        return dx, dw, db, dskip, None
+                                      dcat=dcat, dx=dx, dw=dw, db=db, coff=ctx.coff, bf16=ctx.bf16))
+        return dx, dw, db, dskip, None, None
 
 
 class HeadLoss(torch.autograd.Function):

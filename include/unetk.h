@@ -186,11 +186,15 @@ int unetk_image_gradients(const float* x, float* out, int N, int H, int W, int C
 typedef struct unetk_deconv_desc {
   int32_t N, H, W, Cin, Cout; /* input geometry; output is [N,2H,2W,Cout] */
   int32_t out_stride, out_coff;
+  int32_t precision; /* UNETK_FP32 / UNETK_BF16 (Cin % 32 == 0 and Cout % 32 == 0; filters from *_pack_bf16) */
 } unetk_deconv_desc;
 
 /* wp_fwd: [Cin/4][4*Cout][4]; wp_dgrad: [4*Cout/4][Cin][4]; each 4*Cin*Cout floats. */
 int unetk_deconv2x2_pack(const float* w, int Cin, int Cout, float* wp_fwd, float* wp_dgrad,
                          void* stream);
+/* UNETK_BF16: wp_fwd [Cin/8][4*Cout][8], wp_dgrad [4*Cout/8][Cin][8], each 4*Cin*Cout bf16. */
+int unetk_deconv2x2_pack_bf16(const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad,
+                              void* stream);
 int unetk_deconv2x2_fwd(const unetk_deconv_desc* d, const float* x, const float* wp_fwd,
                         const float* bias, float* out, void* stream);
 /* Backward.  dcat/cat: gradient and forward value of the concat buffer (same strides/offset as
@@ -207,9 +211,12 @@ typedef struct unetk_deconv3d_desc {
   int32_t N, D, H, W, Cin, Cout;
   int32_t kd; /* depth kernel == depth stride: 1 or 2 */
   int32_t out_stride, out_coff;
+  int32_t precision; /* UNETK_FP32 / UNETK_BF16 */
 } unetk_deconv3d_desc;
 int unetk_deconv3d_pack(const float* w, int kd, int Cin, int Cout, float* wp_fwd, float* wp_dgrad,
                         void* stream);
+int unetk_deconv3d_pack_bf16(const float* w, int kd, int Cin, int Cout, void* wp_fwd, void* wp_dgrad,
+                             void* stream);
 int unetk_deconv3d_fwd(const unetk_deconv3d_desc* d, const float* x, const float* wp_fwd,
                        const float* bias, float* out, void* stream);
 size_t unetk_deconv3d_bwd_ws_bytes(const unetk_deconv3d_desc* d);

@@ -57,6 +57,37 @@ def conv_nd_same(x, w, stride=None, bias=None):
     return y.permute(*perm_out).contiguous()
 
 
+def bf16_round(t):
+    """Round-to-nearest-even to bfloat16, kept in t's dtype (bf16 values are exact in fp32 / fp64)."""
+    return t.detach().to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+class _ConvSameBf16Operands(torch.autograd.Function):
+    """Restatement of the UNETK_BF16 arithmetic (include/unetk.h; not a reference mode -- BASELINE.json configs[2]):
+    every contraction rounds BOTH operands to bf16 and accumulates exactly; forward y = conv(r(x), r(w)), backward
+    dx = conv^T(r(dy), r(w)) and dw = corr(r(x), r(dy)) -- i.e. the gradient is NOT the derivative of the rounded
+    forward but what mixed-precision kernels compute."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return conv_nd_same(bf16_round(x), bf16_round(w))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        with torch.enable_grad():
+            xr = bf16_round(x).requires_grad_(True)
+            wr = bf16_round(w).requires_grad_(True)
+            y = conv_nd_same(xr, wr)
+            dx, dw = torch.autograd.grad(y, (xr, wr), bf16_round(dy))
+        return dx, dw
+
+
+def conv_same_bf16_operands(x, w):
+    return _ConvSameBf16Operands.apply(x, w)
+
+
 def conv_transpose_ks(x, w, stride, bias=None):
     """slim.conv2d_transpose / conv3d_transpose with kernel == stride, SAME (B5).
 
@@ -73,6 +104,31 @@ def conv_transpose_ks(x, w, stride, bias=None):
     y = convt(xc, wc, bias=bias, stride=stride)
     perm_out = (0,) + tuple(range(2, nsp + 2)) + (1,)
     return y.permute(*perm_out).contiguous()
+
+
+class _ConvTransposeBf16Operands(torch.autograd.Function):
+    """UNETK_BF16 arithmetic of the k = s transposed conv (bias is added outside, in full precision)."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride):
+        ctx.save_for_backward(x, w)
+        ctx.stride = stride
+        return conv_transpose_ks(bf16_round(x), bf16_round(w), stride)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        with torch.enable_grad():
+            xr = bf16_round(x).requires_grad_(True)
+            wr = bf16_round(w).requires_grad_(True)
+            y = conv_transpose_ks(xr, wr, ctx.stride)
+            dx, dw = torch.autograd.grad(y, (xr, wr), bf16_round(dy))
+        return dx, dw, None
+
+
+def conv_transpose_bf16_operands(x, w, stride, bias=None):
+    y = _ConvTransposeBf16Operands.apply(x, w, tuple(stride))
+    return y if bias is None else y + bias
 
 
 def max_pool2x2(x):

@@ -105,7 +105,11 @@ class UNet2DOracle(object):
 
     # ------------------------------------------------------------------ layers
     def _conv_norm_relu(self, x, p, scope, is_training, new_stats, taps):
-        y = tf_ops.conv_nd_same(x, p[scope + "/weights"])
+        w = p[scope + "/weights"]
+        if getattr(self, "bf16", False) and w.shape[2] % 32 == 0 and w.shape[3] % 32 == 0:
+            y = tf_ops.conv_same_bf16_operands(x, w)      # UNETK_BF16 emulation (3x3 units with Cin, Cout % 32 == 0)
+        else:
+            y = tf_ops.conv_nd_same(x, w)
         if taps is not None:
             taps[scope + "/conv"] = y
         if self.without_norm:
@@ -143,8 +147,10 @@ class UNet2DOracle(object):
         x = self._conv_norm_relu(x, p, n + "/ED-Bridge/ED-Bridge_2", is_training, new_stats, taps)
         for i in reversed(range(self.num_down_samples)):
             d = "{}/Decode{}".format(n, i + 1)
-            up = tf_ops.conv_transpose_ks(x, p[d + "/Conv2d_transpose/weights"], (2, 2),
-                                          bias=p[d + "/Conv2d_transpose/biases"])
+            wt = p[d + "/Conv2d_transpose/weights"]
+            convt = tf_ops.conv_transpose_bf16_operands if (getattr(self, "bf16", False) and wt.shape[2] % 32 == 0
+                                                            and wt.shape[3] % 32 == 0) else tf_ops.conv_transpose_ks
+            up = convt(x, wt, (2, 2), bias=p[d + "/Conv2d_transpose/biases"])
             up = torch.relu(up)
             if taps is not None:
                 taps[d + "/up"] = up
