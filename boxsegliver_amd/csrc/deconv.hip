@@ -440,24 +440,37 @@ __global__ __launch_bounds__(256) void deconv_wgrad_kernel(DwParams p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int mb = split * p.m_per_split, me = min(mb + p.m_per_split, p.M);
-  for (int mt = mb; mt < me; mt += KT) {
-    __syncthreads();
-    for (int idx = tid; idx < KT * (CT / 4); idx += 256) {
+  // register prefetch: the next 128-pixel tile is in flight while the MFMAs of the current one run
+  constexpr int LR = KT * (CT / 4) / 256;   // 8 float4 of each operand per thread
+  float4 va[LR], vb[LR];
+  auto load_tile = [&](int mt) {
+#pragma unroll
+    for (int i = 0; i < LR; ++i) {
+      const int idx = tid + i * 256;
       const int row = idx >> 4, q = idx & 15;
       const int m = mt + row;
-      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+      va[i] = vb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < me) {
         const int xx = m % p.W;
         const int yy = (m / p.W) % p.H;
         const int nn = m / (p.W * p.H);
         const int64_t o = p.da.off(nn) + ((int64_t)(2 * yy + (ab >> 1)) * 2 * p.W + 2 * xx + (ab & 1)) * p.Cout;
-        if (co0 + q * 4 < p.Cout) va = ldg4(p.dpre + o + co0 + q * 4);      // Cout may be 32: half a co tile
-        vb = ldg4(p.x + (int64_t)m * p.Cin + ci0 + q * 4);
+        if (co0 + q * 4 < p.Cout) va[i] = ldg4(p.dpre + o + co0 + q * 4);      // Cout may be 32: half a co tile
+        vb[i] = ldg4(p.x + (int64_t)m * p.Cin + ci0 + q * 4);
       }
-      *reinterpret_cast<float4*>(&at[row * CT + q * 4]) = va;
-      *reinterpret_cast<float4*>(&bt[row * CT + q * 4]) = vb;
+    }
+  };
+  if (mb < me) load_tile(mb);
+  for (int mt = mb; mt < me; mt += KT) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < LR; ++i) {
+      const int idx = tid + i * 256;
+      *reinterpret_cast<float4*>(&at[(idx >> 4) * CT + (idx & 15) * 4]) = va[i];
+      *reinterpret_cast<float4*>(&bt[(idx >> 4) * CT + (idx & 15) * 4]) = vb[i];
     }
     __syncthreads();
+    if (mt + KT < me) load_tile(mt + KT);
     if (p.bf16) {
 #pragma unroll 2
       for (int s = 0; s < KT / 16; ++s) {
