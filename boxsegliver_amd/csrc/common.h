@@ -74,9 +74,15 @@ struct ConvParams {
   ImgAddr xa, ya;
   int accumulate;                    // epilogue: y += acc (depth taps of a 3-D conv), statistics on the sum
   int bf16;                          // operands rounded to bf16 for v_mfma_f32_32x32x16_bf16 (wp = bf16 K8 pack)
+  int spg;                           // planes per statistics group (a 3-D sample's depth planes); 0/1 = every plane
+  int lin_pix;                       // conv_igemm_lin.hip: padded pixels a block may stage (sizes its LDS)
 };
 int unetk_conv_run(ConvParams p, hipStream_t st);          // conv_igemm.hip: picks the tile configuration
-int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout);
+int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout, int spg = 1);
+// conv_igemm_lin.hip: linear-pixel variant for planes narrower than 32 pixels (same packed filters)
+bool unetk_conv_lin_ok(int N, int H, int W, int Cin, int Cout, int spg);
+int unetk_conv_stat_rows_lin(int N, int H, int W, int spg);
+int unetk_conv_run_lin(ConvParams p, hipStream_t st);
 // conv_igemm_bf16.hip
 bool unetk_conv_bf16_ok(int Cin, int Cout);
 int unetk_conv_run_bf16(ConvParams p, hipStream_t st);

@@ -146,7 +146,7 @@ extern "C" int unetk_conv3d_stat_rows(const unetk_conv3d_desc* d) {
   if (!desc_ok(d)) return UNETK_E_BADARG;
   const Geo3 g = geo3(d);
   if (d->shw == 2) return d->N * SUB_BPS;
-  return unetk_conv_stat_rows(d->N * g.Do, d->H, d->W, d->Cin, d->Cout);
+  return unetk_conv_stat_rows(d->N * g.Do, d->H, d->W, d->Cin, d->Cout, g.Do);
 }
 
 extern "C" size_t unetk_conv3d_ws_bytes(const unetk_conv3d_desc* d) {
@@ -204,6 +204,7 @@ extern "C" int unetk_conv3d_fwd(const unetk_conv3d_desc* d, const float* x, cons
     p.xa = planes(HWx, hi - lo + 1, d->sd, d->D);
     p.ya = planes(HWt, hi - lo + 1, 1, g.Do);
     p.accumulate = d->kd > 1 ? 1 : 0;
+    p.spg = hi - lo + 1;
     int rc = unetk_conv_run(p, st);
     if (rc != UNETK_OK) return rc;
   }
@@ -249,6 +250,7 @@ extern "C" int unetk_conv3d_dgrad(const unetk_conv3d_desc* d, const float* dy, c
   UNETK_REQUIRE(desc_ok(d) && dy && wp_dgrad && dx);
   UNETK_REQUIRE(unetk_aligned16(dy) && unetk_aligned16(wp_dgrad) && unetk_aligned16(dx));
   UNETK_REQUIRE(d->x_stride % 4 == 0 && d->y_stride % 4 == 0 && d->Cout % 4 == 0);
+  if (d->Cout % 16 != 0 || d->Cin % 32 != 0) return UNETK_E_UNSUPPORTED;   // the MFMA kernels' K and N granularity
   hipStream_t st = (hipStream_t)stream;
   const Geo3 g = geo3(d);
   if (d->shw == 2) {
@@ -279,6 +281,7 @@ extern "C" int unetk_conv3d_dgrad(const unetk_conv3d_desc* d, const float* dy, c
     p.xa = planes(HWz, hi - lo + 1, 1, g.Do);
     p.ya = planes(HWx, hi - lo + 1, d->sd, d->D);
     p.accumulate = multi ? 1 : 0;
+    p.spg = hi - lo + 1;
     rc = unetk_conv_run(p, st);
     if (rc != UNETK_OK) return rc;
   }

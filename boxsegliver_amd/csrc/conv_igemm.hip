@@ -336,13 +336,16 @@ int launch_igemm(const ConvParams& p, int n_mtiles, hipStream_t st) {
 
 }  // namespace
 
-int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout) {
+int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout, int spg) {
+  if (unetk_conv_lin_ok(N, H, W, Cin, Cout, spg)) return unetk_conv_stat_rows_lin(N, H, W, spg);
   const ConvCfg cfg = pick_cfg(Cin, Cout);
   return N * ((H + cfg.th - 1) / cfg.th) * ((W + TW - 1) / TW);
 }
 
 int unetk_conv_run(ConvParams p, hipStream_t st) {
   if (p.bf16) return unetk_conv_run_bf16(p, st);
+  if (p.spg < 1) p.spg = 1;
+  if (unetk_conv_lin_ok(p.N, p.H, p.W, p.Cin, p.Cout, p.spg)) return unetk_conv_run_lin(p, st);   // small planes: linear M
   const ConvCfg cfg = pick_cfg(p.Cin, p.Cout);
   p.tiles_h = (p.H + cfg.th - 1) / cfg.th;
   p.tiles_w = (p.W + TW - 1) / TW;
@@ -394,8 +397,7 @@ extern "C" int unetk_conv3x3_pack(const float* w, int Cin, int Cout, float* wp_f
 extern "C" int unetk_conv3x3_stat_rows(const unetk_conv_desc* d) {
   if (!conv_desc_ok(d)) return UNETK_E_BADARG;
   if (d->precision == UNETK_BF16) return unetk_conv_stat_rows_bf16(d->N, d->H, d->W, d->Cin, d->Cout);
-  const ConvCfg cfg = pick_cfg(d->Cin, d->Cout);
-  return d->N * ((d->H + cfg.th - 1) / cfg.th) * ((d->W + TW - 1) / TW);
+  return unetk_conv_stat_rows(d->N, d->H, d->W, d->Cin, d->Cout);
 }
 
 extern "C" int unetk_conv3x3_fwd(const unetk_conv_desc* d, const float* x, const float* w, float* y,

@@ -1,0 +1,264 @@
+// conv3x3 (stride 1, SAME) forward / input-gradient for SMALL planes (W < 32): UNet3D's 24x24, 12x12 and 6x6
+// levels (NetworksV2/UNet3D.py:153,165 via csrc/conv3d.hip) and any 2-D level below 32 pixels wide.
+//
+// The tiled kernel of conv_igemm.hip gives every block an 8 x 16 pixel tile of ONE plane, so a 12 x 12 plane fills
+// 56 % of its MFMA rows and a 6 x 6 plane 28 %.  Here the M dimension is the LINEAR pixel index over the whole list of
+// planes: block b owns pixels [128 b, 128 b + 128) whatever planes and rows they fall in, so every MFMA row is a real
+// pixel (except in the last block).  The trick that keeps the inner loop identical to the tiled kernel -- one shifted
+// ds_read_b128 per tap with a tap offset that is uniform across lanes -- is a VIRTUAL PADDED ROW SPACE: plane i, row r
+// lives in padded row G = i (H + 2) + r + 1, each plane carrying one zero row above and below and one zero column left
+// and right.  The block stages padded rows G0 .. G1 (all rows its pixels touch, +-1) into LDS, zero rows/columns
+// included, and pixel (i, r, c) reads tap (kh, kw) at LDS slot ((G - 1 - G0 + kh) (W + 2) + c + kw): plane boundaries
+// need no special case.  Same fp32 MFMA (v_mfma_f32_32x32x2_f32, exact), K4-interleaved filters, register prefetch,
+// double-buffered LDS and statistics epilogue as the tiled kernel; same packed filters.
+#include "common.h"
+
+namespace {
+
+constexpr int CK = 16;
+constexpr int PS = 20;
+constexpr int LIN_MAXPIX = 416;   // staged padded pixels per block (host guarantees the bound)
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvParams p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  const int HALO_F = p.lin_pix * PS;   // LDS is sized per launch for the plane shape: 2-3 resident blocks per CU
+  constexpr int WB_F = CK * BN;
+  constexpr int HR = (LIN_MAXPIX * 4 + NT - 1) / NT;
+  constexpr int WR = (CK / 4 * BN + NT - 1) / NT;
+  constexpr int WF4 = CK / 4 * BN;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* halo = smem;               // [2][HALO_F]
+  float* wbuf = smem + 2 * HALO_F;  // [2][WB_F]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = bid % p.n_ntiles;
+  const int mtile = bid / p.n_ntiles;
+  const int n0 = ntile * BN;
+
+  const int HW = p.H * p.W, WP = p.W + 2, HP = p.H + 2;
+  // blocks never straddle a statistics group (= the spg planes of one sample): per-sample statistics stay exact
+  const int gpix = p.spg * HW;
+  const int bpg = (gpix + BM - 1) / BM;
+  const int grp = mtile / bpg, lb = mtile - grp * bpg;
+  const int P0 = grp * gpix + lb * BM;
+  const int P1 = min(P0 + BM, (grp + 1) * gpix);   // exclusive
+  const int pl0 = P0 / HW, r0 = (P0 - pl0 * HW) / p.W;
+  const int pl1 = (P1 - 1) / HW, r1 = (P1 - 1 - pl1 * HW) / p.W;
+  const int G0 = pl0 * HP + r0;
+  const int npix = (pl1 * HP + r1 + 2 - G0 + 1) * WP;
+
+  int64_t hoff[HR];
+  bool hok[HR];
+  int hlds[HR];
+#pragma unroll
+  for (int r = 0; r < HR; ++r) {
+    const int idx = tid + r * NT;
+    const int slot = idx >> 2, q = idx & 3;
+    const int gi = slot / WP, c = slot - gi * WP;
+    const int g = G0 + gi;
+    const int plane = g / HP, rr = g - plane * HP - 1, col = c - 1;
+    hok[r] = slot < npix && plane < p.N && rr >= 0 && rr < p.H && col >= 0 && col < p.W;
+    hoff[r] = p.xa.off(plane) + ((int64_t)rr * p.W + col) * p.xs + q * 4;
+    hlds[r] = slot < npix ? slot * PS + q * 4 : -1;
+  }
+  const int cin4 = p.Cin >> 2;
+  int64_t woff[WR];
+#pragma unroll
+  for (int r = 0; r < WR; ++r) {
+    const int idx = tid + r * NT;
+    const int q = idx / BN, n = idx - q * BN;
+    woff[r] = ((int64_t)q * p.Cout + n0 + n) * 4;
+  }
+
+  float4 hreg[HR], wreg[WR];
+  auto load_halo = [&](int c) {
+#pragma unroll
+    for (int r = 0; r < HR; ++r)
+      hreg[r] = hok[r] ? ldg4(p.x + hoff[r] + c * CK) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto store_halo = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < HR; ++r)
+      if (hlds[r] >= 0) *reinterpret_cast<float4*>(&halo[buf * HALO_F + hlds[r]]) = hreg[r];
+  };
+  auto load_w = [&](int c, int t) {
+    const float* base = p.wp + ((int64_t)t * cin4 + c * (CK / 4)) * p.Cout * 4;
+#pragma unroll
+    for (int r = 0; r < WR; ++r)
+      if (tid + r * NT < WF4) wreg[r] = ldg4(base + woff[r]);
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < WR; ++r)
+      if (tid + r * NT < WF4) *reinterpret_cast<float4*>(&wbuf[buf * WB_F + (tid + r * NT) * 4]) = wreg[r];
+  };
+
+  // A fragment base of this lane's pixel (clamped into the block's range; out-of-range rows are masked in the epilogue)
+  int abase[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int pix = min(P0 + (wm * TM + tm) * 32 + l31, P1 - 1);
+    const int plane = pix / HW, rem = pix - plane * HW;
+    const int hh = rem / p.W, ww = rem - hh * p.W;
+    abase[tm] = ((plane * HP + hh - G0) * WP + ww) * PS + 4 * h;
+  }
+  const int bbase = (h * BN + wn * TN * 32 + l31) * 4;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+  const int nchunks = p.Cin / CK;
+
+  load_halo(0);
+  load_w(0, 0);
+  store_halo(0);
+  store_w(0);
+  __syncthreads();
+
+  int step = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const float* hb = halo + (c & 1) * HALO_F;
+    const bool more_chunks = (c + 1 < nchunks);
+#pragma unroll
+    for (int t = 0; t < 9; ++t, ++step) {
+      const bool has_next = (t < 8) || more_chunks;
+      if (has_next) load_w(t < 8 ? c : c + 1, t < 8 ? t + 1 : 0);
+      if (t == 5 && more_chunks) load_halo(c + 1);
+
+      const float* wb = wbuf + (step & 1) * WB_F;
+      const int toff = ((t / 3) * WP + (t % 3)) * PS;
+#pragma unroll
+      for (int g = 0; g < CK / 8; ++g) {
+        float4 a[TM], b[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          a[tm] = *reinterpret_cast<const float4*>(&hb[abase[tm] + toff + 8 * g]);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          b[tn] = *reinterpret_cast<const float4*>(&wb[bbase + (2 * g * BN + tn * 32) * 4]);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].z, b[tn].z, acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].w, b[tn].w, acc[tm][tn], 0, 0, 0);
+          }
+      }
+
+      if (has_next) store_w((step + 1) & 1);
+      if (t == 5 && more_chunks) store_halo((c + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  float ssum[TN], ssq[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) ssum[tn] = ssq[tn] = 0.f;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pix = P0 + (wm * TM + tm) * 32 + mfma32_row(r, h);
+      if (pix < P1) {
+        const int plane = pix / HW, rem = pix - plane * HW;
+        float* yp = p.y + p.ya.off(plane) + (int64_t)rem * p.ys + n0 + wn * TN * 32 + l31;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          float v = acc[tm][tn][r];
+          if (p.accumulate) v += yp[tn * 32];
+          yp[tn * 32] = v;
+          ssum[tn] += v;
+          ssq[tn] += v * v;
+        }
+      }
+    }
+  }
+  if (p.stat != nullptr) {
+    float* red = smem;  // [2][WM][BN]; behind the main loop's last barrier
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      ssum[tn] += __shfl_xor(ssum[tn], 32);
+      ssq[tn] += __shfl_xor(ssq[tn], 32);
+      if (h == 0) {
+        red[(0 * WM + wm) * BN + (wn * TN + tn) * 32 + l31] = ssum[tn];
+        red[(1 * WM + wm) * BN + (wn * TN + tn) * 32 + l31] = ssq[tn];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * BN; i += NT) {
+      const int k = i / BN, n = i - k * BN;
+      float s = 0.f;
+#pragma unroll
+      for (int m = 0; m < WM; ++m) s += red[(k * WM + m) * BN + n];
+      p.stat[((int64_t)k * p.stat_rows + mtile) * p.Cout + n0 + n] = s;
+    }
+  }
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_lin(const ConvParams& p, int n_mtiles, hipStream_t st) {
+  constexpr int BN = WN * TN * 32;
+  constexpr size_t lds_max = (size_t)(2 * LIN_MAXPIX * PS + 2 * CK * BN) * sizeof(float);
+  const size_t lds = (size_t)(2 * p.lin_pix * PS + 2 * CK * BN) * sizeof(float);
+  auto kern = conv3x3_igemm_lin_kernel<WM, WN, TM, TN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(n_mtiles * p.n_ntiles), dim3(WM * WN * 64), lds, st, p);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+constexpr int LIN_BM = 128;
+
+}  // namespace
+
+// Use the linear-pixel kernel when the tiled one would leave > 10 % of its MFMA rows empty and the padded rows a
+// 128-pixel block can touch fit the LDS budget.
+// spg = planes per statistics group (one sample of a 3-D tensor; 1 for 2-D images).
+bool unetk_conv_lin_ok(int N, int H, int W, int Cin, int Cout, int spg) {
+  if (Cin % CK != 0 || Cout % 64 != 0 || W >= 32 || spg < 1 || N % spg != 0) return false;
+  const int64_t gpix = (int64_t)spg * H * W;
+  const int64_t lin = (gpix + LIN_BM - 1) / LIN_BM * LIN_BM;                                   // MFMA rows issued per group
+  const int64_t tiled = (int64_t)spg * ((H + 7) / 8) * 8 * ((W + 15) / 16) * 16;
+  if (lin * 10 > tiled * 9) return false;
+  const int rows = (LIN_BM + W - 1) / W + 1 + 2 + 2 * ((LIN_BM + H * W - 1) / (H * W));
+  return rows * (W + 2) <= LIN_MAXPIX;
+}
+
+int unetk_conv_stat_rows_lin(int N, int H, int W, int spg) {
+  return (N / spg) * (int)(((int64_t)spg * H * W + LIN_BM - 1) / LIN_BM);
+}
+
+int unetk_conv_run_lin(ConvParams p, hipStream_t st) {
+  const int n_mtiles = unetk_conv_stat_rows_lin(p.N, p.H, p.W, p.spg);
+  p.stat_rows = n_mtiles;
+  p.tiles_h = p.tiles_w = 0;
+  p.lin_pix = ((LIN_BM + p.W - 1) / p.W + 1 + 2 + 2 * ((LIN_BM + p.H * p.W - 1) / (p.H * p.W))) * (p.W + 2);
+  if (p.xs % 4 != 0) return UNETK_E_BADARG;
+  if (p.Cout % 128 == 0) {
+    p.n_ntiles = p.Cout / 128;
+    return launch_lin<2, 2, 2, 2>(p, n_mtiles, st);
+  }
+  p.n_ntiles = p.Cout / 64;
+  return launch_lin<4, 1, 1, 2>(p, n_mtiles, st);
+}

@@ -43,6 +43,11 @@ CONV_SHAPES = [
     (1, 4, 4, 32, 256),        # image smaller than a tile
     (2, 16, 32, 32, 32),       # 256x32 tile path (UNet3D's 30-channel levels padded to 32)
     (1, 24, 20, 64, 32),
+    # small planes -> linear-pixel kernel (conv_igemm_lin.hip): blocks span rows and planes
+    (5, 12, 12, 64, 128),      # UNet3D e3 shape; 720 pixels = 5.6 blocks, plane boundaries inside blocks
+    (9, 6, 6, 32, 64),         # bridge shape: a block covers 3.6 planes
+    (2, 24, 24, 48, 128),      # 24 wide: 75 % fill in the tiled kernel
+    (3, 11, 13, 16, 64),       # odd sizes, last block partial
 ]
 
 
@@ -90,7 +95,8 @@ def test_conv3x3_direct_first_layer(ops):
 
 
 @pytest.mark.parametrize("shape", [(2, 16, 32, 64, 64), (1, 8, 16, 128, 64), (2, 12, 20, 64, 128), (1, 16, 16, 64, 16 * 8),
-                                   (2, 16, 32, 32, 32), (1, 8, 16, 32, 64), (2, 12, 20, 64, 32), (3, 9, 17, 96, 32)])
+                                   (2, 16, 32, 32, 32), (1, 8, 16, 32, 64), (2, 12, 20, 64, 32), (3, 9, 17, 96, 32),
+                                   (5, 12, 12, 128, 64), (9, 6, 6, 64, 64), (2, 24, 24, 128, 64)])   # linear-pixel dgrad
 def test_conv3x3_dgrad_wgrad(ops, shape):
     n, h, w, cin, cout = shape
     rng = np.random.default_rng(11 + cin + cout)

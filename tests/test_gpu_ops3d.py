@@ -37,6 +37,11 @@ CASES = [
     (1, 6, 8, 16, 64, 64, 3, (2, 2, 2)),       # bridge/conv1: (3,3,3) stride (2,2,2), even depth
     (1, 5, 6, 6, 64, 64, 3, (2, 2, 2)),        # odd depth / odd result sizes
     (1, 2, 8, 16, 128, 32, 1, (1, 1, 1)),      # 64 -> 30 style (conv_d0/conv1)
+    # small planes -> linear-pixel kernel (conv_igemm_lin.hip): blocks span rows and planes, never samples
+    (2, 8, 12, 12, 64, 128, 3, (1, 1, 1)),     # conv_e3 / conv_d3 shape: 1152 pixels per sample = 9 blocks
+    (2, 7, 6, 6, 64, 64, 3, (1, 1, 1)),        # bridge shape: 252 pixels per sample (last block partial)
+    (1, 5, 24, 24, 32, 64, 3, (1, 1, 1)),      # conv_e2 shape
+    (3, 4, 11, 13, 32, 64, 1, (1, 1, 1)),      # odd plane, three samples, (1,3,3)
 ]
 
 
