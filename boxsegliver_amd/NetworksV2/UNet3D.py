@@ -145,6 +145,8 @@ class UNet3D(base.BaseNet):
             raise ops._abi.UnetkError("UNet3D runs on the GPU only: move `images` to cuda (no CPU path)")
         if images.dim() != 5 or images.shape[4] != self.channel:
             raise ValueError("images must be [bs, D, H, W, {}], got {}".format(self.channel, tuple(images.shape)))
+        if self.compute_bf16:
+            raise NotImplementedError("--compute_dtype bf16 is built for the 2-D nets (UNet, GUNet); UNet3D runs fp32")
         if getattr(self.args, "img_grad", False):
             # reference UNet3D.py:138-140 unpacks three values from tf.image.image_gradients on a 5-D tensor; that op
             # takes 4-D input and returns (dy, dx), so the reference's own path raises at graph build

@@ -76,9 +76,12 @@ struct ConvParams {
   int bf16;                          // operands rounded to bf16 for v_mfma_f32_32x32x16_bf16 (wp = bf16 K8 pack)
   int spg;                           // planes per statistics group (a 3-D sample's depth planes); 0/1 = every plane
   int lin_pix;                       // conv_igemm_lin.hip: padded pixels a block may stage (sizes its LDS)
+  int stride;                        // 2: TF SAME stride-2 conv; H x W = OUTPUT extent and the four fields below are set
+  int Hin, Win, pbh, pbw;            // input extent and SAME pad-before (0 on even, 1 on odd input extents)
 };
 int unetk_conv_run(ConvParams p, hipStream_t st);          // conv_igemm.hip: picks the tile configuration
-int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout, int spg = 1);
+int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout, int spg = 1, int stride = 1);
+bool unetk_conv_stride2_ok(int Cin, int Cout);
 // conv_igemm_lin.hip: linear-pixel variant for planes narrower than 32 pixels (same packed filters)
 bool unetk_conv_lin_ok(int N, int H, int W, int Cin, int Cout, int spg);
 int unetk_conv_stat_rows_lin(int N, int H, int W, int spg);

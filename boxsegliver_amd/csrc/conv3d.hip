@@ -145,7 +145,10 @@ extern "C" int unetk_conv3d_out_dims(const unetk_conv3d_desc* d, int* Do, int* H
 extern "C" int unetk_conv3d_stat_rows(const unetk_conv3d_desc* d) {
   if (!desc_ok(d)) return UNETK_E_BADARG;
   const Geo3 g = geo3(d);
-  if (d->shw == 2) return d->N * SUB_BPS;
+  if (d->shw == 2) {
+    if (unetk_conv_stride2_ok(d->Cin, d->Cout)) return unetk_conv_stat_rows(d->N * g.Do, g.Ho, g.Wo, d->Cin, d->Cout, g.Do, 2);
+    return d->N * SUB_BPS;
+  }
   return unetk_conv_stat_rows(d->N * g.Do, d->H, d->W, d->Cin, d->Cout, g.Do);
 }
 
@@ -164,7 +167,9 @@ extern "C" int unetk_conv3d_fwd(const unetk_conv3d_desc* d, const float* x, cons
   UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(wp) && unetk_aligned16(y) && d->y_stride % 4 == 0);
   hipStream_t st = (hipStream_t)stream;
   const Geo3 g = geo3(d);
-  const bool strided = d->shw == 2;
+  // stride (.,2,2): natively strided tiles when the MFMA kernel covers the channel counts, else stride-1 + subsample
+  const bool native = d->shw == 2 && unetk_conv_stride2_ok(d->Cin, d->Cout);
+  const bool strided = d->shw == 2 && !native;
   float* T = y;
   int ts = d->y_stride;
   if (strided) {
@@ -173,7 +178,7 @@ extern "C" int unetk_conv3d_fwd(const unetk_conv3d_desc* d, const float* x, cons
     T = (float*)ws;
     ts = d->Cout;
   }
-  const int HWx = d->H * d->W * d->x_stride, HWt = d->H * d->W * ts;
+  const int HWx = d->H * d->W * d->x_stride, HWt = (native ? g.Ho * g.Wo : d->H * d->W) * ts;
   // order: partial-coverage taps first, a full-coverage tap last (it emits the statistics)
   int order[3], n_taps = 0, full = -1;
   for (int dt = 0; dt < d->kd; ++dt) {
@@ -205,6 +210,11 @@ extern "C" int unetk_conv3d_fwd(const unetk_conv3d_desc* d, const float* x, cons
     p.ya = planes(HWt, hi - lo + 1, 1, g.Do);
     p.accumulate = d->kd > 1 ? 1 : 0;
     p.spg = hi - lo + 1;
+    if (native) {
+      p.stride = 2;
+      p.H = g.Ho; p.W = g.Wo; p.Hin = d->H; p.Win = d->W;
+      p.pbh = 1 - g.off_h; p.pbw = 1 - g.off_w;
+    }
     int rc = unetk_conv_run(p, st);
     if (rc != UNETK_OK) return rc;
   }

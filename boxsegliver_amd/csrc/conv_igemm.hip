@@ -20,13 +20,17 @@ namespace {
 constexpr int CK = 16;   // input channels per K-chunk
 constexpr int PS = 20;   // LDS pixel stride (floats): 16 + 4 pad -> conflict-free ds_read_b128
 constexpr int TW = 16;   // spatial tile width
-constexpr int HWD = TW + 2;
 
-template <int WM, int WN, int TM, int TN>
+// S = 1: the SAME stride-1 conv (p.H x p.W = input = output extent, pad 1).  S = 2: TF SAME stride-2 conv (UNet3D's
+// (1,2,2) / (2,2,2) layers, UNet3D.py:31-91): tiles walk the p.H x p.W OUTPUT, the staged halo is the
+// (2 TH + 2) x 34 input window starting at 2 h0 - pbh (pad-before 0 on even, 1 on odd input extents), and pixel (r, c)
+// reads tap (kh, kw) at halo (2 r + kh, 2 c + kw): same inner loop, A reads 2-way bank-conflicted (LDS has the slack).
+template <int WM, int WN, int TM, int TN, int S = 1>
 __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int TH = BM / TW, HH = TH + 2;
+  constexpr int TH = BM / TW, HH = S * TH + 2;
+  constexpr int HWD = S * TW + 2;
   constexpr int HALO_PIX = HH * HWD;
   constexpr int HALO_F = HALO_PIX * PS;
   constexpr int WB_F = CK * BN;
@@ -63,9 +67,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
     const int idx = tid + r * NT;
     const int pix = idx >> 2, q = idx & 3;
     const int hh = pix / HWD, ww = pix - hh * HWD;
-    const int gh = h0 - 1 + hh, gw = w0 - 1 + ww;
-    hok[r] = (idx < HALO_PIX * 4) && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
-    hoff[r] = ximg + ((int64_t)gh * p.W + gw) * p.xs + q * 4;
+    const int gh = S * h0 - (S == 1 ? 1 : p.pbh) + hh, gw = S * w0 - (S == 1 ? 1 : p.pbw) + ww;
+    const int Hin = S == 1 ? p.H : p.Hin, Win = S == 1 ? p.W : p.Win;
+    hok[r] = (idx < HALO_PIX * 4) && gh >= 0 && gh < Hin && gw >= 0 && gw < Win;
+    hoff[r] = ximg + ((int64_t)gh * Win + gw) * p.xs + q * 4;
     hlds[r] = (idx < HALO_PIX * 4) ? pix * PS + q * 4 : -1;
   }
   const int cin4 = p.Cin >> 2;
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int sub = wm * TM + tm;
-    abase[tm] = ((2 * sub + (l31 >> 4)) * HWD + (l31 & 15)) * PS + 4 * h;
+    abase[tm] = (S * (2 * sub + (l31 >> 4)) * HWD + S * (l31 & 15)) * PS + 4 * h;
   }
   const int bbase = (h * BN + wn * TN * 32 + l31) * 4;
 
@@ -315,13 +320,14 @@ inline ConvCfg pick_cfg(int Cin, int Cout) {
   return {-1, 8};
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int S = 1>
 int launch_igemm(const ConvParams& p, int n_mtiles, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int TH = BM / TW;
-  constexpr size_t lds = (2 * (TH + 2) * HWD * PS + 2 * CK * BN) * sizeof(float);
+  constexpr size_t lds = (2 * (S * TH + 2) * (S * TW + 2) * PS + 2 * CK * BN) * sizeof(float);
   static_assert(lds >= 2 * WM * BN * sizeof(float), "stat scratch must fit");
-  auto kern = conv3x3_igemm_kernel<WM, WN, TM, TN>;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto kern = conv3x3_igemm_kernel<WM, WN, TM, TN, S>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -336,13 +342,30 @@ int launch_igemm(const ConvParams& p, int n_mtiles, hipStream_t st) {
 
 }  // namespace
 
-int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout, int spg) {
+// H, W = OUTPUT extent; stride 2 always takes the tiled kernel (8-row tiles).
+int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout, int spg, int stride) {
+  if (stride == 2) return N * ((H + 7) / 8) * ((W + TW - 1) / TW);
   if (unetk_conv_lin_ok(N, H, W, Cin, Cout, spg)) return unetk_conv_stat_rows_lin(N, H, W, spg);
   const ConvCfg cfg = pick_cfg(Cin, Cout);
   return N * ((H + cfg.th - 1) / cfg.th) * ((W + TW - 1) / TW);
 }
 
+bool unetk_conv_stride2_ok(int Cin, int Cout) { return Cin % CK == 0 && Cout % 64 == 0; }
+
 int unetk_conv_run(ConvParams p, hipStream_t st) {
+  if (p.stride == 2) {   // p.H x p.W = output extent, p.Hin x p.Win = input extent
+    if (p.bf16 || !unetk_conv_stride2_ok(p.Cin, p.Cout) || p.xs % 4 != 0) return UNETK_E_UNSUPPORTED;
+    p.tiles_h = (p.H + 7) / 8;
+    p.tiles_w = (p.W + TW - 1) / TW;
+    const int n_mt = p.N * p.tiles_h * p.tiles_w;
+    p.stat_rows = n_mt;
+    if (p.Cout % 128 == 0) {
+      p.n_ntiles = p.Cout / 128;
+      return launch_igemm<2, 2, 2, 2, 2>(p, n_mt, st);
+    }
+    p.n_ntiles = p.Cout / 64;
+    return launch_igemm<4, 1, 1, 2, 2>(p, n_mt, st);
+  }
   if (p.bf16) return unetk_conv_run_bf16(p, st);
   if (p.spg < 1) p.spg = 1;
   if (unetk_conv_lin_ok(p.N, p.H, p.W, p.Cin, p.Cout, p.spg)) return unetk_conv_run_lin(p, st);   // small planes: linear M
