@@ -107,6 +107,34 @@ __global__ void image_gradients_kernel(const float* __restrict__ x, float* __res
 
 }  // namespace
 
+// out[n,h,w,:] (+)= scale * x[n, fh ? H-1-h : h, fw ? W-1-w : w, :] -- mirror test-time augmentation on the device:
+// flips the slab fed to the net and un-flips + accumulates the class probabilities (np.flip(...) / mirror_div at
+// evaluators/evaluator_liver.py:648-655).
+__global__ void flip_axpy_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int H, int W, int C, int fh,
+                                 int fw, float scale, int accumulate) {
+  const int64_t total = (int64_t)N * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    const int sh = fh ? H - 1 - h : h, sw = fw ? W - 1 - w : w;
+    const float v = scale * x[(((int64_t)n * H + sh) * W + sw) * C + c];
+    out[i] = accumulate ? out[i] + v : v;
+  }
+}
+
+extern "C" int unetk_flip_axpy(const float* x, float* out, int N, int H, int W, int C, int flip_h, int flip_w, float scale,
+                               int accumulate, void* stream) {
+  UNETK_REQUIRE(x && out && x != out && N > 0 && H > 0 && W > 0 && C > 0);
+  const int64_t total = (int64_t)N * H * W * C;
+  hipLaunchKernelGGL(flip_axpy_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, out, N, H, W, C, flip_h,
+                     flip_w, scale, accumulate);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
 extern "C" int unetk_image_gradients(const float* x, float* out, int N, int H, int W, int C, void* stream) {
   UNETK_REQUIRE(x && out && N > 0 && H > 0 && W > 0 && C > 0);
   const int64_t total = (int64_t)N * H * W * C;

@@ -98,6 +98,39 @@ def input_fn_3d(mode, params):
     return gen()
 
 
+def input_fn_eval_volumes(mode, params):
+    """Eval generator with the contract of DataLoader/Liver/input_pipeline_li.py:398-456 on synthetic cases:
+    `(features, None)` slabs of batch_size slices -- features["images"] f32 [bs,H,W,C] on the device,
+    features["names"] PID (+ "mirror" and mirrored copies iff params["pipeline_mirror"], the reference's host-side
+    TTA) -- then `(None, (segmentation [D,H,W] uint8, vol_path, pads, bbox, resize))` per case.  The last slab of a
+    case is zero-padded to the batch size (pads).  params["eval_cases"] = [(pid, depth), ...]."""
+    args = params["args"]
+    bs, h, w, c = args.batch_size, args.im_height, args.im_width, args.im_channel
+    ncls = len(args.classes) + 1
+    device = params.get("device", torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available()
+                        else torch.device("cpu"))
+    cases = params.get("eval_cases") or [(1000 + i, 2 * bs + 3) for i in range(2)]
+    rf = int(getattr(args, "random_flip", 0) or 0)
+    for pid, depth in cases:
+        images, labels, _ = make_batch(depth, h, w, c, ncls, int(getattr(args, "seed", 1234) or 1234) + int(pid))
+        pads = (bs - depth % bs) % bs
+        if pads:
+            images = np.concatenate((images, np.zeros((pads, h, w, c), np.float32)))
+        for i in range(0, depth + pads, bs):
+            feats = {"images": torch.from_numpy(images[i:i + bs]).to(device), "names": pid}
+            if params.get("pipeline_mirror"):
+                feats["mirror"] = 0
+                yield feats, None
+                if getattr(args, "eval_mirror", False):
+                    for m, axes in ((1, (2,)), (2, (1,)), (3, (2, 1))):
+                        if rf & m > 0:                      # m = 3: rf & 3 (input_pipeline_li.py:451)
+                            flipped = np.ascontiguousarray(np.flip(images[i:i + bs], axis=axes))
+                            yield {"images": torch.from_numpy(flipped).to(device), "names": pid, "mirror": m}, None
+            else:
+                yield feats, None
+        yield None, (labels.astype(np.uint8), "synthetic-{}".format(pid), pads, (0, 0, 0, w - 1, h - 1, depth - 1), True)
+
+
 def make_guide(labels, guide_channel=1, seed=1234):
     """Spatial guide like DataLoader/Liver/input_pipeline_g.py:382-394 / utils/image_ops.py:431-434:
     g/2 + 0.5 with g = max_k exp(-|p - c_k|^2 / (2 sigma^2)), 1-3 centres inside the foreground, sigma ~ U(2, 8)

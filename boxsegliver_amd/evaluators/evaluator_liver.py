@@ -1,0 +1,316 @@
+"""Volume evaluator for liver / tumor segmentation -- host-side mirror of the reference's
+evaluators/evaluator_liver.py (`EvaluateVolume`: run :704-766, _predict_case :616-678, _postprocess :680-702,
+_run_actual :906-996, _compare :1193-1227) on the libunetk HIP kernels.
+
+What runs where (MI355X-first):
+  * DEVICE: the forward passes of every slab, the mirror test-time augmentation (flip of the input slab, un-flip and
+    `/ mirror_div` accumulation of the class probabilities: `unetk_flip_axpy`; the reference does this with np.flip
+    on the host, :648-655), the concatenation of a case's slabs, and the final `np.argmax(volume, -1)` (:663,
+    `unetk_head_predict`, lowest index on ties like numpy).  One device->host copy per case (uint8 mask).
+  * HOST, as in the reference: zoom back to the original shape (scipy.ndimage.zoom), merge tumor into liver, largest
+    connected component, the per-case volume metrics (loss_metrics.metric_3d) and the global Dice accumulators.
+
+The input contract is the reference's eval generator (DataLoader/Liver/input_pipeline_li.py:398-456): a stream of
+`(features, None)` slabs -- features["images"] [bs,H,W,C], features["names"], optional features["mirror"] in {0,1,2,3}
+-- closed per case by `(None, (segmentation, vol_path, pads, bbox, resize))`.  When --eval_mirror is set and the
+pipeline does NOT emit mirrored copies (no "mirror" key), the evaluator mirrors on the device itself, which saves the
+host flips and three host->device copies per slab.
+"""
+import json
+import time
+from collections import defaultdict
+from pathlib import Path
+
+import numpy as np
+import scipy.ndimage as ndi
+import torch
+
+from .. import loss_metrics as metric_ops
+from .. import ops
+from ..NetworksV2.base import ModeKeys
+from ..utils import array_kits as arr_ops
+from .evaluator_base import EvaluateBase
+
+
+def add_arguments(parser):
+    """evaluators/evaluator_liver.py:36-71 (names / defaults verbatim)."""
+    group = parser.add_argument_group(title="Evaluation Arguments")
+    group.add_argument("--primary_metric", type=str, required=False,
+                       help="Primary metric for evaluation. Typically it has format <class>/<metric>")
+    group.add_argument("--secondary_metric", type=str, required=False,
+                       help="Secondary metric for evaluation. Typically it has format <class>/<metric>")
+    group.add_argument("--eval_final", action="store_true", required=False,
+                       help="Evaluate with final checkpoint. If not set, then evaluate with best checkpoint(default).")
+    group.add_argument("--ckpt_path", type=str, required=False,
+                       help="Given a specified checkpoint for evaluation. (default best checkpoint)")
+    group.add_argument("--evaluator", type=str, choices=["Volume"])
+    group.add_argument("--eval_num", type=int, default=-1, required=False, help="Number of cases for evaluation")
+    group.add_argument("--eval_skip_num", type=int, default=0, required=False,
+                       help="Skip some cases for evaluating determined case")
+    group.add_argument("--eval_3d", action="store_true", required=False,
+                       help="Evaluate in 2D slices or 3D volume when training. Default in 2D slices")
+    group.add_argument("--pred_type", type=str, choices=["pred", "prob"], default="pred",
+                       help="Generate prediction or probability")
+    group.add_argument("--save_path", type=str, default="prediction")
+    group.add_argument("--use_global_dice", action="store_true")
+
+
+def get_evaluator(evaluator, estimator=None, model_dir=None, params=None, merge_tumor_to_liver=True, largest=True,
+                  use_sg_reduce_fp=False):
+    if evaluator == "Volume":
+        return EvaluateVolume(estimator, model_dir=model_dir, params=params, merge_tumor_to_liver=merge_tumor_to_liver,
+                              largest=largest, use_sg_reduce_fp=use_sg_reduce_fp)
+    raise ValueError("Unsupported evaluator: {}. Must be [Volume, ]".format(evaluator))
+
+
+def mirror_plan(config):
+    """(variants, divisor) of the mirror TTA exactly as the reference emits / averages them:
+    variants after the un-mirrored slab are 1 = flip W if random_flip & 1, 2 = flip H if random_flip & 2,
+    3 = both if random_flip & 3 (input_pipeline_li.py:440-455 -- so random_flip 1 or 2 yields TWO extra variants);
+    divisor 2 for random_flip in {1, 2}, 4 for 3, else 1 (evaluator_liver.py:114-122)."""
+    if not getattr(config, "eval_mirror", False):
+        return [], 1
+    rf = int(getattr(config, "random_flip", 0) or 0)
+    variants = []
+    if rf & 1 > 0:
+        variants.append(1)
+    if rf & 2 > 0:
+        variants.append(2)
+    if rf & 3 > 0:
+        variants.append(3)
+    div = 2 if rf in (1, 2) else (4 if rf == 3 else 1)
+    return variants, div
+
+
+_FLIPS = {0: (False, False), 1: (False, True), 2: (True, False), 3: (True, True)}   # mirror id -> (flip H, flip W)
+
+
+class EvaluateVolume(EvaluateBase):
+    """Evaluate a model case by case (volume by volume)."""
+
+    def __init__(self, estimator=None, model_dir=None, params=None, merge_tumor_to_liver=True, largest=True,
+                 use_sg_reduce_fp=False):
+        super(EvaluateVolume, self).__init__()
+        self.estimator = estimator
+        self.model_dir = model_dir or (estimator.model_dir if estimator is not None else None)
+        self.params = params or estimator.params
+        self.config = self.params["args"]
+        self.do_mirror = bool(getattr(self.config, "eval_mirror", False))
+        self.mirror_variants, self.mirror_div = mirror_plan(self.config)
+        self.merge_tumor_to_liver = merge_tumor_to_liver
+        self.largest = largest
+        self.use_sg_reduce_fp = bool(use_sg_reduce_fp and getattr(self.config, "use_spatial", False))
+        self.calls = 0
+        self.seconds = 0.0
+
+    @property
+    def classes(self):
+        return self.params["model_instances"][0].classes[1:]          # without background
+
+    @property
+    def metrics_str(self):
+        return list(getattr(self.config, "metrics_eval", ["Dice"]))
+
+    # ------------------------------------------------------------------ device side
+    def _model(self):
+        if not self.params.get("model_instances"):
+            self.params["model_instances"] = [self.params["model"](self.config)]
+        return self.params["model_instances"][0]
+
+    def _forward(self, model, features):
+        inputs = {k: v for k, v in features.items() if torch.is_tensor(v) and k not in ("names",)}
+        model(inputs, ModeKeys.EVAL, *self.params.get("model_args", ()), **self.params.get("model_kwargs", {}))
+        return model.probability
+
+    def _slab_probability(self, model, features):
+        """Class probabilities of one slab, already divided by mirror_div; with device-side mirroring also averaged
+        over the mirrored variants."""
+        prob = self._forward(model, features)
+        own_mirror = self.do_mirror and "mirror" not in features
+        acc = torch.empty_like(prob)
+        ops.flip_axpy(prob, acc, False, False, 1.0 / self.mirror_div, accumulate=False)
+        if own_mirror:
+            for m in self.mirror_variants:
+                fh, fw = _FLIPS[m]
+                flipped = dict(features)
+                flipped["images"] = ops.flip_axpy(features["images"], None, fh, fw)
+                if torch.is_tensor(features.get("sp_guide")):
+                    flipped["sp_guide"] = ops.flip_axpy(features["sp_guide"], None, fh, fw)
+                ops.flip_axpy(self._forward(model, flipped), acc, fh, fw, 1.0 / self.mirror_div, accumulate=True)
+        return acc
+
+    def _predict_case(self, predicts, cases=-1, dtype="pred", resize=False, save_path=None):
+        """evaluator_liver.py:616-678 with the accumulation on the device.  Yields
+        (case, segmentation, volume, post_processed)."""
+        slabs = []
+        cur_case = None
+        counter = 0
+        for predict, labels in predicts:
+            if predict is not None:
+                new_case = str(predict["names"])
+                cur_case = cur_case or new_case
+                assert cur_case == new_case, (cur_case, new_case)
+                m = int(predict.get("mirror", 0))
+                if m == 0:
+                    slabs.append(predict["Prob"])                       # already / mirror_div
+                else:                                                   # a mirrored copy emitted by the pipeline
+                    fh, fw = _FLIPS[m]
+                    ops.flip_axpy(predict["Prob"], slabs[-1], fh, fw, 1.0, accumulate=True)
+            else:
+                assert isinstance(labels, tuple), type(labels)
+                segmentation, vol_path, pads, bbox, reshape_ori = labels
+                volume = torch.cat(slabs)                               # [d, h, w, c] on the device
+                if pads > 0:
+                    volume = volume[:-pads]
+                if dtype == "pred":
+                    amax, _ = ops.head_predict(volume.contiguous(), volume.shape[-1], want_preds=False)
+                    volume = amax.view(volume.shape[:-1]).cpu().numpy()  # np.argmax(volume, -1).astype(uint8)
+                else:
+                    volume = volume.cpu().numpy()
+                if resize and reshape_ori:
+                    ori_shape = (volume.shape[0],) + arr_ops.bbox_to_shape(bbox)[1:]
+                    if volume.ndim == 4:
+                        ori_shape = ori_shape + (volume.shape[-1],)
+                    scales = np.array(ori_shape) / np.array(volume.shape)
+                    if np.any(scales != 1):
+                        volume = ndi.zoom(volume, scales, order=0 if dtype == "pred" else 1)
+                yield cur_case, segmentation, volume, False
+                slabs.clear()
+                cur_case = None
+                counter += 1
+                if 0 < cases <= counter:
+                    break
+
+    # ------------------------------------------------------------------ host side
+    def _postprocess(self, volume, is_label=False, ori_shape=None):
+        """evaluator_liver.py:680-702."""
+        if not isinstance(volume, dict):
+            decouple_volume = {cls: volume == i + 1 for i, cls in enumerate(self.classes)}
+        else:
+            decouple_volume = volume
+        if ori_shape is not None:
+            cur_shape = decouple_volume[self.classes[0]].shape
+            ori_shape = [cur_shape[0]] + list(ori_shape)
+            scales = np.array(ori_shape) / np.array(cur_shape)
+            for cls in self.classes:
+                decouple_volume[cls] = ndi.zoom(decouple_volume[cls], scales, order=0)
+        if self.merge_tumor_to_liver and "Tumor" in decouple_volume and "Liver" in decouple_volume:
+            decouple_volume["Liver"] = decouple_volume["Liver"] + decouple_volume["Tumor"]     # bool OR
+        if self.largest and "Liver" in decouple_volume and not is_label:
+            decouple_volume["Liver"] = arr_ops.get_largest_component(decouple_volume["Liver"], rank=3)
+            if self.merge_tumor_to_liver and "Tumor" in decouple_volume:
+                decouple_volume["Tumor"] = decouple_volume["Tumor"] * \
+                    decouple_volume["Liver"].astype(decouple_volume["Tumor"].dtype)
+        return decouple_volume
+
+    def run(self, input_fn, checkpoint_path=None, latest_filename=None, save=False, hooks=None, cases=None):
+        """evaluator_liver.py:704-766: build the model, restore the checkpoint, stream the cases."""
+        model = self._model()
+        restored = [False]
+        mode = getattr(self.config, "mode", ModeKeys.EVAL)
+
+        def run_pred():
+            for features, labels in input_fn(mode, self.params):
+                if features:
+                    if not restored[0]:
+                        restored[0] = True
+                        if model.params is None:
+                            self._forward(model, features)              # creates the variables
+                        if checkpoint_path and self.estimator is not None and Path(str(checkpoint_path)).exists():
+                            self.estimator._restore(checkpoint_path, model, None)
+                    preds_eval = {k: v for k, v in features.items() if not torch.is_tensor(v) or k == "names"}
+                    preds_eval["Prob"] = self._slab_probability(model, features)
+                    yield preds_eval, None
+                else:
+                    yield None, labels
+
+        resize = getattr(self.config, "im_height", 0) > 0 and getattr(self.config, "im_width", 0) > 0
+        n_cases = cases if cases is not None else getattr(self.config, "eval_num", -1)
+        return self._run_actual(self._predict_case, run_pred, save, cases=n_cases, resize=resize)
+
+    def _run_actual(self, predict_fn, run_fn, save, cases=-1, **run_kwargs):
+        """evaluator_liver.py:906-996; returns the averaged results (the reference only logs them)."""
+        do_eval = getattr(self.config, "mode", ModeKeys.EVAL) != "predict"
+        save_path = None
+        if save:
+            save_path = Path(self.model_dir) / (getattr(self.config, "save_path", None) or "prediction")
+            save_path.mkdir(parents=True, exist_ok=True)
+        accumulator = defaultdict(int)
+        use_global = bool(getattr(self.config, "use_global_dice", False))
+        self.clear_metrics()
+        self.calls, self.seconds = 0, 0.0
+        tic = time.perf_counter()
+        for cur_case, labels, volume, post_processed in predict_fn(run_fn(), cases=cases,
+                                                                   dtype=getattr(self.config, "pred_type", "pred"),
+                                                                   save_path=save_path, **run_kwargs):
+            results = {}
+            if do_eval:
+                if not post_processed:
+                    volume = self._postprocess(volume)
+                labels = self._postprocess(labels, is_label=True)
+                for cls in self.classes:
+                    conf = metric_ops.ConfusionMatrix(volume[cls].astype(int), labels[cls].astype(int))
+                    conf.compute()
+                    accumulator[cls + "_fn"] += conf.fn
+                    accumulator[cls + "_fp"] += conf.fp
+                    accumulator[cls + "_tp"] += conf.tp
+                if not use_global:
+                    for cls in self.classes:
+                        pairs = metric_ops.metric_3d(volume[cls], labels[cls], required=self.metrics_str)
+                        for met, value in pairs.items():
+                            results["{}/{}".format(cls, met)] = value
+                    self.append_metrics(results)
+            self.calls += 1
+            self.seconds += time.perf_counter() - tic
+            tic = time.perf_counter()
+
+        def gdice(cls):
+            den = 2 * accumulator[cls + "_tp"] + accumulator[cls + "_fn"] + accumulator[cls + "_fp"]
+            return 2 * accumulator[cls + "_tp"] / den if den else 0.0
+
+        if use_global:
+            results = {cls + "Dice": gdice(cls) for cls in self.classes}
+        else:
+            results = {key: float(np.mean(values)) for key, values in self._metric_values.items()}
+            if accumulator:
+                results.update({"G" + cls + "Dice": gdice(cls) for cls in self.classes})
+        if save_path is not None:
+            with (save_path / "results.json").open("w") as f:
+                json.dump(results, f)
+        return results
+
+    def compare(self, *args_, **kwargs):
+        return _compare(*args_, **kwargs)
+
+
+def _compare(cur_result, ori_result, primary_metric=None, secondary_metric=None):
+    """evaluator_liver.py:1193-1227: lexicographic "is cur better than ori" with the primary / secondary metric
+    first; larger is better for every key."""
+    if not isinstance(cur_result, dict):
+        raise TypeError("`cur_result` should be dict, but got {}".format(type(cur_result)))
+    if not isinstance(ori_result, dict):
+        raise TypeError("`ori_result` should be dict, but got {}".format(type(ori_result)))
+    if set(cur_result) != set(ori_result):
+        raise ValueError("Dicts with different keys can not be compared. cur_result({}) vs ori_result({})"
+                         .format(list(cur_result.keys()), list(ori_result.keys())))
+    if primary_metric and primary_metric not in cur_result:
+        raise KeyError("`primary_metric` not in valid result key: {}".format(primary_metric))
+    if secondary_metric and secondary_metric not in cur_result:
+        raise KeyError("`secondary_metric` not in valid result key: {}".format(secondary_metric))
+    if primary_metric == secondary_metric:
+        raise ValueError("`primary_metric` can not be equal to `secondary_metric`")
+    keys = list(cur_result.keys())
+    if primary_metric:
+        keys.remove(primary_metric)
+        keys.insert(0, primary_metric)
+        if secondary_metric:
+            keys.remove(secondary_metric)
+            keys.insert(1, secondary_metric)
+    for key in keys:
+        if cur_result[key] > ori_result[key]:
+            return True
+        elif cur_result[key] == ori_result[key]:
+            continue
+        else:
+            return False
+    return False

@@ -91,3 +91,111 @@ def metric_from_sums(result, n, ncls, cls, met):
     if met == "vd":
         return (100 * ((left - right).abs() / (right + eps))).mean()
     raise ValueError("Not supported metric: " + met)
+
+
+# --------------------------------------------------------------------------- volume metrics (host, per case)
+def metric_3d(logits3d, labels3d, required=None, **kwargs):
+    """loss_metrics.py:342-452: Dice / VOE / RVD (medpy's `dc`, `1 - jc`, `|ravd|`) and ASSD / RMSD / MSD
+    (utils/surface.py) of a binary 3-D prediction against its label, on the host as in the reference.
+
+    medpy 0.4 semantics restated: dc = 2|A&B| / (|A| + |B|), 0.0 when both are empty; jc = |A&B| / |A|B|
+    (0/0 -> nan, like medpy's float division); ravd = (|A| - |B|) / |B|, RuntimeError on an empty reference.
+    ASSD and MSD are 0 when either object is empty (:419-421); the reference leaves RMSD unset in that case."""
+    import numpy as np
+    metrics = ["Dice", "VOE", "RVD", "ASSD", "RMSD", "MSD"]
+    if required is None:
+        required = list(metrics)
+    elif isinstance(required, str):
+        required = [required]
+    else:
+        required = list(required)
+    for req in required:
+        if req not in metrics:
+            raise ValueError("Not supported metric: %s" % req)
+    need_dist_map = any(req in metrics[3:] for req in required)
+    logits3d, labels3d = np.asarray(logits3d), np.asarray(labels3d)
+    if logits3d.ndim > 3:
+        logits3d = np.squeeze(logits3d)
+    if labels3d.ndim > 3:
+        labels3d = np.squeeze(labels3d)
+    assert logits3d.shape == labels3d.shape, ("Shape mismatch of logits3D and labels3D. \n"
+                                              "Logits3D has shape %r while labels3D has "
+                                              "shape %r" % (logits3d.shape, labels3d.shape))
+    a, b = logits3d.astype(bool), labels3d.astype(bool)
+    out = {}
+    sampling = kwargs.get("sampling", [1., 1., 1.])
+    if need_dist_map:
+        from .utils.surface import Surface
+        if np.count_nonzero(a) == 0 or np.count_nonzero(b) == 0:
+            out["ASSD"] = 0
+            out["MSD"] = 0
+        else:
+            surf = Surface(a, b, physical_voxel_spacing=sampling, mask_offset=[0., 0., 0.], reference_offset=[0., 0., 0.])
+            if "ASSD" in required:
+                out["ASSD"] = surf.get_average_symmetric_surface_distance()
+            if "MSD" in required:
+                out["MSD"] = surf.get_maximum_symmetric_surface_distance()
+            if "RMSD" in required:
+                out["RMSD"] = surf.get_root_mean_square_symmetric_surface_distance()
+    inter = int(np.count_nonzero(a & b))
+    na, nb = int(np.count_nonzero(a)), int(np.count_nonzero(b))
+    if "Dice" in required:
+        out["Dice"] = 2.0 * inter / float(na + nb) if na + nb > 0 else 0.0
+    if "VOE" in required:
+        union = int(np.count_nonzero(a | b))
+        out["VOE"] = 1.0 - (inter / float(union) if union > 0 else float("nan"))
+    if "RVD" in required:
+        if nb == 0:
+            raise RuntimeError("The second supplied array does not contain any binary object.")
+        out["RVD"] = abs((na - nb) / float(nb))
+    return out
+
+
+class ConfusionMatrix(object):
+    """loss_metrics.py:506-580: tp / fp / tn / fn counts of a test volume against a reference volume."""
+
+    def __init__(self, test=None, reference=None):
+        self.test, self.reference = test, reference
+        self.reset()
+
+    def set_test(self, test):
+        self.test = test
+        self.reset()
+
+    def set_reference(self, reference):
+        self.reference = reference
+        self.reset()
+
+    def reset(self):
+        self.tp = self.fp = self.tn = self.fn = self.size = None
+        self.test_empty = self.test_full = self.reference_empty = self.reference_full = None
+
+    def compute(self):
+        import numpy as np
+        if self.test is None or self.reference is None:
+            raise ValueError("'test' and 'reference' must both be set to compute confusion matrix.")
+        assert self.test.shape == self.reference.shape, "Shape mismatch: {} and {}".format(
+            self.test.shape, self.reference.shape)
+        t, r = self.test != 0, self.reference != 0
+        self.tp = int((t & r).sum())
+        self.fp = int((t & ~r).sum())
+        self.tn = int((~t & ~r).sum())
+        self.fn = int((~t & r).sum())
+        self.size = self.reference.size
+        self.test_empty, self.test_full = not np.any(self.test), bool(np.all(self.test))
+        self.reference_empty, self.reference_full = not np.any(self.reference), bool(np.all(self.reference))
+
+    def get_matrix(self):
+        if None in (self.tp, self.fp, self.tn, self.fn):
+            self.compute()
+        return self.tp, self.fp, self.tn, self.fn
+
+    def get_size(self):
+        if self.size is None:
+            self.compute()
+        return self.size
+
+    def get_existence(self):
+        if None in (self.test_empty, self.test_full, self.reference_empty, self.reference_full):
+            self.compute()
+        return self.test_empty, self.test_full, self.reference_empty, self.reference_full

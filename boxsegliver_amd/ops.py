@@ -312,6 +312,20 @@ def image_gradients(x):
     return out
 
 
+def flip_axpy(x, out=None, flip_h=False, flip_w=False, scale=1.0, accumulate=False):
+    """out (+)= scale * flip(x) over H and/or W of an NHWC tensor (mirror TTA, evaluator_liver.py:648-655)."""
+    _require_cuda(x)
+    x = x.contiguous()
+    n, h, w, c = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+        accumulate = False
+    assert out.is_contiguous() and out.shape == x.shape and out.data_ptr() != x.data_ptr()
+    check(_abi.lib().unetk_flip_axpy(ptr(x), ptr(out), n, h, w, c, int(bool(flip_h)), int(bool(flip_w)), float(scale),
+                                     int(bool(accumulate)), stream_ptr()), "flip_axpy")
+    return out
+
+
 def avgpool2_fwd(x):
     _require_cuda(x)
     n, h, w, c = x.shape

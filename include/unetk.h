@@ -178,6 +178,10 @@ int unetk_avgpool2_fwd(const float* x, float* p, int N, int H, int W, int C, voi
 /* --img_grad (UNet.py:69-71, GUNet.py:335-338): out [N,H,W,3C] = concat(x, dy, dx) with
  * tf.image.image_gradients' forward differences (dy[h] = x[h+1] - x[h], last row 0; dx likewise). */
 int unetk_image_gradients(const float* x, float* out, int N, int H, int W, int C, void* stream);
+/* Mirror test-time augmentation (evaluators/evaluator_liver.py:648-655; the reference flips on the host with
+ * np.flip): out[n,h,w,:] (+)= scale * x[n, flip_h ? H-1-h : h, flip_w ? W-1-w : w, :].  x != out. */
+int unetk_flip_axpy(const float* x, float* out, int N, int H, int W, int C, int flip_h, int flip_w,
+                    float scale, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------- slim.conv2d_transpose(x, C, 2, 2)
  * UNet.py:91-93: kernel 2 stride 2, bias, ReLU, then tf.concat((skip, up), -1).
