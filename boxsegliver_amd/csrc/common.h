@@ -78,7 +78,14 @@ struct ConvParams {
   int lin_pix;                       // conv_igemm_lin.hip: padded pixels a block may stage (sizes its LDS)
   int stride;                        // 2: TF SAME stride-2 conv; H x W = OUTPUT extent and the four fields below are set
   int Hin, Win, pbh, pbw;            // input extent and SAME pad-before (0 on even, 1 on odd input extents)
+  // conv_igemm_lin.hip GEN variant (stride-2 input gradient): the four output-parity classes in one launch,
+  // class q = blockIdx-derived; tap_off = 4 * (row offset 0..2) + (column offset 0..2) in the padded halo
+  int ntaps[4], tap_off[4][4], tap_panel[4][4];
+  int ooh[4], oow[4];                    // class q: output pixel (a, b) -> (os a + ooh[q], os b + oow[q])
+  int os, Hd, Wd;                        // of an Hd x Wd plane
 };
+bool unetk_conv_lin_gen_ok(int H, int W, int Cin, int Cout);
+int unetk_conv_run_lin_gen(ConvParams p, hipStream_t st);
 int unetk_conv_run(ConvParams p, hipStream_t st);          // conv_igemm.hip: picks the tile configuration
 int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout, int spg = 1, int stride = 1);
 bool unetk_conv_stride2_ok(int Cin, int Cout);

@@ -263,6 +263,48 @@ extern "C" int unetk_conv3d_dgrad(const unetk_conv3d_desc* d, const float* dy, c
   if (d->Cout % 16 != 0 || d->Cin % 32 != 0) return UNETK_E_UNSUPPORTED;   // the MFMA kernels' K and N granularity
   hipStream_t st = (hipStream_t)stream;
   const Geo3 g = geo3(d);
+  if (d->shw == 2 && unetk_conv_lin_gen_ok(g.Ho, g.Wo, d->Cout, d->Cin)) {
+    // native: one launch per output-parity class of dx, each contracting the undilated dy over its 4 / 2 / 2 / 1 taps
+    //   dx[hi] = sum_{kh = ph, ph+2} dy[a - (kh - ph)/2] w[kh],  ph = (hi + pbh) & 1,  a = (hi + pbh - ph) / 2
+    const int pbh = 1 - g.off_h, pbw = 1 - g.off_w;
+    const int HWx = d->H * d->W * d->x_stride, HWy = g.Ho * g.Wo * d->y_stride;
+    const bool multi = d->kd > 1 || d->sd > 1;
+    if (multi) {
+      hipError_t e = hipMemsetAsync(dx, 0, (size_t)d->N * d->D * HWx * sizeof(float), st);
+      if (e != hipSuccess) return (int)e;
+    }
+    for (int dt = 0; dt < d->kd; ++dt) {
+      int lo, hi;
+      tap_range(d, g, dt, &lo, &hi);
+      if (hi < lo) continue;
+      ConvParams p{};
+      p.x = dy + (int64_t)lo * HWy;
+      p.wp = wp_dgrad + (int64_t)dt * 9 * d->Cin * d->Cout;
+      p.y = dx + (int64_t)(lo * d->sd - g.pb_d + dt) * HWx;
+      p.N = d->N * (hi - lo + 1); p.H = g.Ho; p.W = g.Wo; p.Cin = d->Cout; p.Cout = d->Cin;
+      p.xs = d->y_stride; p.ys = d->x_stride;
+      p.xa = planes(HWy, hi - lo + 1, 1, g.Do);
+      p.ya = planes(HWx, hi - lo + 1, d->sd, d->D);
+      p.accumulate = multi ? 1 : 0;
+      p.spg = hi - lo + 1;
+      p.os = 2; p.Hd = d->H; p.Wd = d->W;
+      for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+          const int q = ph * 2 + pw;
+          p.ooh[q] = ph - pbh;
+          p.oow[q] = pw - pbw;
+          for (int kh = ph; kh < 3; kh += 2)
+            for (int kw = pw; kw < 3; kw += 2) {
+              p.tap_off[q][p.ntaps[q]] = 4 * ((ph - kh) / 2 + 1) + ((pw - kw) / 2 + 1);
+              p.tap_panel[q][p.ntaps[q]] = 8 - (kh * 3 + kw);
+              ++p.ntaps[q];
+            }
+        }
+      int rc = unetk_conv_run_lin_gen(p, st);
+      if (rc != UNETK_OK) return rc;
+    }
+    return UNETK_OK;
+  }
   if (d->shw == 2) {
     UNETK_REQUIRE(ws && unetk_aligned16(ws));
     if (ws_bytes < unetk_conv3d_ws_bytes(d)) return UNETK_E_WORKSPACE;

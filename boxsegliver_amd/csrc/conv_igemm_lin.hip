@@ -19,7 +19,12 @@ constexpr int CK = 16;
 constexpr int PS = 20;
 constexpr int LIN_MAXPIX = 416;   // staged padded pixels per block (host guarantees the bound)
 
-template <int WM, int WN, int TM, int TN>
+// GEN = a SUBSET of the taps with an output scatter: the input gradient of a stride-2 conv, one output-parity class per
+// launch.  dx[hi, wi] only receives taps with kh = (hi + pbh) mod 2 (+2), so class (ph, pw) is a stride-1 contraction of
+// the UNDILATED dy over 4 / 2 / 2 / 1 taps (p.ntaps entries: halo offset + filter panel) whose result lands on every
+// second dx pixel (p.os, p.ooh, p.oow; p.Hd x p.Wd = dx plane).  Exactly the 9 tap-products of the layer in total,
+// instead of 36 on a zero-dilated dy.
+template <int WM, int WN, int TM, int TN, bool GEN = false>
 __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -41,7 +46,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
 
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int ntile = bid % p.n_ntiles;
-  const int mtile = bid / p.n_ntiles;
+  const int mtile_all = bid / p.n_ntiles;
+  const int q = GEN ? (mtile_all & 3) : 0;                      // parity class; its 4 blocks of a tile are neighbours (L2)
+  const int mtile = GEN ? (mtile_all >> 2) : mtile_all;
   const int n0 = ntile * BN;
 
   const int HW = p.H * p.W, WP = p.W + 2, HP = p.H + 2;
@@ -124,10 +131,67 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
   const int nchunks = p.Cin / CK;
 
   load_halo(0);
-  load_w(0, 0);
+  load_w(0, GEN ? p.tap_panel[q][0] : 0);
   store_halo(0);
   store_w(0);
   __syncthreads();
+
+  if constexpr (GEN) {
+    const int ntaps = p.ntaps[q], nsteps = nchunks * ntaps;
+    int c = 0, ti = 0;
+    for (int s = 0; s < nsteps; ++s) {
+      const bool has_next = s + 1 < nsteps;
+      const int ti2 = ti + 1 < ntaps ? ti + 1 : 0, c2 = ti + 1 < ntaps ? c : c + 1;
+      if (has_next) load_w(c2, p.tap_panel[q][ti2]);
+      const bool more_chunks = c + 1 < nchunks;
+      if (ti == 0 && more_chunks) load_halo(c + 1);
+      const float* hb = halo + (c & 1) * HALO_F;
+      const float* wb = wbuf + (s & 1) * WB_F;
+      const int toff = ((p.tap_off[q][ti] >> 2) * WP + (p.tap_off[q][ti] & 3)) * PS;
+#pragma unroll
+      for (int g = 0; g < CK / 8; ++g) {
+        float4 a[TM], b[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const float4*>(&hb[abase[tm] + toff + 8 * g]);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const float4*>(&wb[bbase + (2 * g * BN + tn * 32) * 4]);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].z, b[tn].z, acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].w, b[tn].w, acc[tm][tn], 0, 0, 0);
+          }
+      }
+      if (has_next) store_w((s + 1) & 1);
+      if (ti == ntaps - 1 && more_chunks) store_halo((c + 1) & 1);
+      __syncthreads();
+      ti = ti2;
+      c = c2;
+    }
+    // scatter epilogue: phase pixel (a, b) -> dx pixel (os a + ooh, os b + oow)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pix = P0 + (wm * TM + tm) * 32 + mfma32_row(r, h);
+        if (pix >= P1) continue;
+        const int plane = pix / HW, rem = pix - plane * HW;
+        const int aa = rem / p.W, bb = rem - aa * p.W;
+        const int hi = p.os * aa + p.ooh[q], wi = p.os * bb + p.oow[q];
+        if (hi < 0 || hi >= p.Hd || wi < 0 || wi >= p.Wd) continue;
+        float* yp = p.y + p.ya.off(plane) + ((int64_t)hi * p.Wd + wi) * p.ys + n0 + wn * TN * 32 + l31;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const float v = acc[tm][tn][r];
+          yp[tn * 32] = p.accumulate ? yp[tn * 32] + v : v;
+        }
+      }
+    }
+    return;
+  }
 
   int step = 0;
   for (int c = 0; c < nchunks; ++c) {
@@ -211,12 +275,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
   }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool GEN = false>
 int launch_lin(const ConvParams& p, int n_mtiles, hipStream_t st) {
   constexpr int BN = WN * TN * 32;
   constexpr size_t lds_max = (size_t)(2 * LIN_MAXPIX * PS + 2 * CK * BN) * sizeof(float);
   const size_t lds = (size_t)(2 * p.lin_pix * PS + 2 * CK * BN) * sizeof(float);
-  auto kern = conv3x3_igemm_lin_kernel<WM, WN, TM, TN>;
+  auto kern = conv3x3_igemm_lin_kernel<WM, WN, TM, TN, GEN>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
@@ -247,6 +311,31 @@ bool unetk_conv_lin_ok(int N, int H, int W, int Cin, int Cout, int spg) {
 
 int unetk_conv_stat_rows_lin(int N, int H, int W, int spg) {
   return (N / spg) * (int)(((int64_t)spg * H * W + LIN_BM - 1) / LIN_BM);
+}
+
+static int lin_rows_bound(int H, int W) { return (LIN_BM + W - 1) / W + 1 + 2 + 2 * ((LIN_BM + H * W - 1) / (H * W)); }
+
+// Tap-subset / scatter variant (input gradient of a stride-2 conv): p.H x p.W = dy plane, p.Cin = dy channels,
+// p.Cout = dx channels, p.ntaps / tap_off / tap_panel / os / ooh / oow / Hd / Wd set by the caller.
+bool unetk_conv_lin_gen_ok(int H, int W, int Cin, int Cout) {
+  return Cin % CK == 0 && Cout % 64 == 0 && lin_rows_bound(H, W) * (W + 2) <= LIN_MAXPIX;
+}
+
+int unetk_conv_run_lin_gen(ConvParams p, hipStream_t st) {
+  if (!unetk_conv_lin_gen_ok(p.H, p.W, p.Cin, p.Cout) || p.xs % 4 != 0) return UNETK_E_UNSUPPORTED;
+  for (int q = 0; q < 4; ++q)
+    if (p.ntaps[q] < 1 || p.ntaps[q] > 4) return UNETK_E_BADARG;
+  if (p.spg < 1) p.spg = 1;
+  const int n_mtiles = unetk_conv_stat_rows_lin(p.N, p.H, p.W, p.spg);
+  p.stat_rows = n_mtiles;
+  p.stat = nullptr;
+  p.lin_pix = lin_rows_bound(p.H, p.W) * (p.W + 2);
+  if (p.Cout % 128 == 0) {
+    p.n_ntiles = p.Cout / 128;
+    return launch_lin<2, 2, 2, 2, true>(p, 4 * n_mtiles, st);     // x4: the parity classes
+  }
+  p.n_ntiles = p.Cout / 64;
+  return launch_lin<4, 1, 1, 2, true>(p, 4 * n_mtiles, st);
 }
 
 int unetk_conv_run_lin(ConvParams p, hipStream_t st) {
