@@ -228,11 +228,15 @@ def main():
             # process, so it comes from the committed rocprofv3 --pmc summary of this same command
             # (profiles/r01_pmc_traffic.json, produced by tools/pmc_summary.py), else null.
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-                key = {k.replace(" ", ""): v for k, v in pmc.items()}.get(top["kernel"].replace(" ", ""))
+                fname = "r01_pmc_traffic.json" if a.dtype == "fp32" else "r01_pmc_traffic_bf16.json"
+                pmc = json.load(open(os.path.join(ROOT, "profiles", fname)))["kernels"]
+                norm = {k.replace(" ", "").replace(",1>", ">"): v for k, v in pmc.items()}   # <..., S=1> == the tag
+                key = norm.get(top["kernel"].split("(")[0].replace(" ", "").replace(",false>", ">").replace(",true>", ">"))
+                if key is None and "wgrad_kernel" in top["kernel"]:
+                    key = next((v for k, v in norm.items() if k.startswith("conv3x3_wgrad_kernel<64,64")), None)
                 if key and a.size == 256 and a.batch == 32 and a.model == "UNet":
                     out["roofline"]["traffic"] = round(key["hbm_bytes_per_launch_corrected"])
-                    out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE)"
+                    out["roofline"]["traffic_source"] = "profiles/" + fname + " (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE)"
             except (OSError, KeyError, ValueError):
                 pass
         if not a.no_cpu_baseline and world == 1 and a.model == "UNet":
