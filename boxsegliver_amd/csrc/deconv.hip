@@ -420,6 +420,11 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
   return __builtin_bit_cast(bf16x8, q);
 }
 
+// BF is a template parameter, not a run-time branch: with both MFMA loops in one kernel the compiler shuttled the
+// accumulator between VGPRs and AGPRs once per tile and read a15 back ten wait-states after the last 16-pass MFMA of
+// the loop -- too early (rows 27 / 31 of each 32-row panel lost the final k-step, non-reproducibly).  One loop per
+// instantiation keeps the accumulator in place for the whole split.
+template <bool BF>
 __global__ __launch_bounds__(256) void deconv_wgrad_kernel(DwParams p) {
   constexpr int KT = 128, CT = 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -471,7 +476,7 @@ __global__ __launch_bounds__(256) void deconv_wgrad_kernel(DwParams p) {
     }
     __syncthreads();
     if (mt + KT < me) load_tile(mt + KT);
-    if (p.bf16) {
+    if constexpr (BF) {
 #pragma unroll 2
       for (int s = 0; s < KT / 16; ++s) {
         float av[8], bv[8];
@@ -742,12 +747,18 @@ extern "C" int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const float* x, 
     const int grid = pl.S * 4 * q.n_co_tiles * q.n_ci_tiles;
     static bool attr_done = false;
     if (!attr_done) {
-      hipError_t e = hipFuncSetAttribute((const void*)deconv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         2 * 128 * 64 * (int)sizeof(float));
+      hipError_t e = hipFuncSetAttribute((const void*)deconv_wgrad_kernel<false>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 64 * (int)sizeof(float));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)deconv_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * 128 * 64 * (int)sizeof(float));
       if (e != hipSuccess) return (int)e;
       attr_done = true;
     }
-    hipLaunchKernelGGL(deconv_wgrad_kernel, dim3(grid), dim3(256), (size_t)2 * 128 * 64 * sizeof(float), st, q);
+    if (q.bf16)
+      hipLaunchKernelGGL(deconv_wgrad_kernel<true>, dim3(grid), dim3(256), (size_t)2 * 128 * 64 * sizeof(float), st, q);
+    else
+      hipLaunchKernelGGL(deconv_wgrad_kernel<false>, dim3(grid), dim3(256), (size_t)2 * 128 * 64 * sizeof(float), st, q);
     UNETK_LAUNCH_CHECK();
     rc = unetk_launch_slab_reduce(slab, pl.S, (int64_t)4 * d->Cin * d->Cout, dw + (int64_t)a * 4 * d->Cin * d->Cout, st);
     if (rc != UNETK_OK) return rc;

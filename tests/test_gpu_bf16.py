@@ -206,6 +206,23 @@ def test_unet_bf16_no_norm_matches_the_bf16_arithmetic_oracle():
     assert dist[True][1] < dist[False][1] and dist[True][2] < dist[False][2]
 
 
+def test_unet_bf16_full_width_step_is_bit_reproducible():
+    """bs 8 at 256x256 (every kernel walks many tiles per block / split, as at BASELINE.json's sizes): two runs of the
+    same bf16 step give bit-identical loss and gradients (fixed-order reductions, no atomics, no read-before-ready)."""
+    t, args, model, inputs, *_ = _unet_pair("bf16", size=256, batch_size=8)
+    images, labels = t.synth(8, 256, 256, 3)
+    inputs = {"images": torch.from_numpy(images).cuda(), "labels": torch.from_numpy(labels).cuda()}
+    runs = []
+    for _ in range(2):
+        model.params.zero_grad()
+        loss = model(inputs, "train", **t.YML)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((loss.item(), model.params.grad["reg"].clone(), model.params.grad["noreg"].clone()))
+    assert np.isfinite(runs[0][0]) and runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+
+
 def test_unet_bf16_trains_like_fp32():
     """Five Adam steps in each mode from the same variables: the bf16 loss curve stays within 3 % of the fp32 one."""
     from boxsegliver_amd.core.solver import Solver

@@ -288,6 +288,32 @@ def test_deconv_concat_forward_backward(ops, shape):
     assert rel_err(db.cpu().numpy(), b.grad.numpy()) < 5e-6
 
 
+def test_deconv_backward_many_pixel_tiles_per_split_exact_and_reproducible(ops):
+    """32768 input pixels = 256 pixel tiles over 128 splits: the filter-gradient kernel walks SEVERAL tiles per block
+    (register-prefetched), which the small shapes above never do.  Checked against float64 and run-to-run bit equality
+    (a mis-scheduled accumulator read-back once lost the last k-step of rows 27 / 31 of every 32-row panel here)."""
+    n, h, w, cin, cout = 8, 64, 64, 128, 64
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn((n, h, w, cin), device="cuda", generator=g)
+    wt = torch.randn((2, 2, cout, cin), device="cuda", generator=g) / math.sqrt(cin)
+    b = torch.randn((cout,), device="cuda", generator=g) * 0.1
+    cat = torch.zeros((n, 2 * h, 2 * w, 2 * cout), device="cuda")
+    dcat = torch.randn(cat.shape, device="cuda", generator=g)
+    for bf16 in (False, True):
+        wp_f, wp_d = ops.deconv2x2_pack(wt, bf16)
+        ops.deconv2x2_fwd(x, wp_f, b, cat, cout, cout, bf16)
+        dx, dw, db = ops.deconv2x2_bwd(x, wp_d, cat, dcat, cout, cout, bf16)
+        dx2, dw2, db2 = ops.deconv2x2_bwd(x, wp_d, cat, dcat, cout, cout, bf16)
+        assert torch.equal(dw, dw2) and torch.equal(dx, dx2) and torch.equal(db, db2)
+        dpre = dcat[..., cout:].double() * (cat[..., cout:] > 0).double()
+        xr = x.double()
+        if bf16:
+            dpre, xr = dpre.float().bfloat16().double(), x.bfloat16().double()
+        ref = torch.stack([torch.stack([torch.einsum("nhwo,nhwi->oi", dpre[:, a::2, c::2], xr) for c in range(2)])
+                           for a in range(2)])
+        assert rel_err(dw.cpu().numpy(), ref.cpu().numpy()) < 5e-6
+
+
 HEAD_CASES = [
     ("none", None, 0.0, 3, "xentropy"),
     ("numerical", [0.2, 0.4, 4.4], 0.0, 3, "xentropy"),

@@ -130,6 +130,27 @@ def test_unet3d_matches_oracle_and_padding_is_exact():
     assert model.metrics_dict["NF/Dice"].item() >= 0.0
 
 
+def test_unet3d_step_is_bit_reproducible_at_a_many_tile_size():
+    """A 16 x 64 x 64 patch (every level walks many tiles / linear blocks / parity classes): two runs of the same step
+    give bit-identical loss and gradients."""
+    from boxsegliver_amd.NetworksV2.UNet3D import UNet3D
+    from boxsegliver_amd.data.synthetic import make_batch_3d
+    args = make_args(batch_size=1, im_depth=16, im_height=64, im_width=64)
+    images, labels, _ = make_batch_3d(1, 16, 64, 64, 1, 2, 77)
+    inputs = {"images": torch.from_numpy(images).cuda(), "labels": torch.from_numpy(labels).cuda()}
+    model = UNet3D(args)
+    runs = []
+    for _ in range(2):
+        if model.params is not None:
+            model.params.zero_grad()
+        loss = model(inputs, "train", **YML)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((loss.item(), model.params.grad["reg"].clone(), model.params.grad["noreg"].clone()))
+    assert np.isfinite(runs[0][0]) and runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+
+
 def test_unet3d_checkpoint_roundtrip_and_training():
     from boxsegliver_amd.core.solver import Solver
     args = make_args()
