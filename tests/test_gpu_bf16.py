@@ -77,6 +77,33 @@ def test_bf16_conv_fwd_dgrad_wgrad_match_fp64_on_rounded_operands(shape):
     assert torch.equal(dw, dw2)                                        # bit-reproducible split-K
 
 
+@pytest.mark.parametrize("shape", [(8, 128, 128, 64, 128), (4, 64, 64, 256, 256), (8, 256, 256, 64, 64)])
+def test_bf16_conv_large_shapes_against_on_device_float64(shape):
+    """BASELINE-sized layers in UNETK_BF16 against PyTorch's float64 convolution of the bf16-rounded operands, evaluated
+    on the device; filter gradient bit-reproducible."""
+    import torch.nn.functional as F
+    from boxsegliver_amd import ops
+    n, h, w, cin, cout = shape
+    g = torch.Generator(device="cuda").manual_seed(n + cin)
+    x = torch.randn((n, h, w, cin), device="cuda", generator=g)
+    wt = torch.randn((3, 3, cin, cout), device="cuda", generator=g) / math.sqrt(9 * cin)
+    dy = torch.randn((n, h, w, cout), device="cuda", generator=g)
+    r = lambda t: t.bfloat16().double()
+    x64 = r(x).permute(0, 3, 1, 2).requires_grad_(True)
+    w64 = r(wt).permute(3, 2, 0, 1).requires_grad_(True)
+    y64 = F.conv2d(x64, w64, padding=1)
+    y64.backward(r(dy).permute(0, 3, 1, 2))
+    wp_f, wp_d = ops.conv3x3_pack(wt, bf16=True)
+    y, _, _ = ops.conv3x3_fwd(x, wp_f, cout, want_stats=False, bf16=True)
+    dx = ops.conv3x3_dgrad(dy, wp_d, cin, bf16=True)
+    dw = ops.conv3x3_wgrad(x, dy, bf16=True)
+    rel = lambda a, b: ((a.double() - b).abs().max() / b.abs().max()).item()
+    assert rel(y, y64.detach().permute(0, 2, 3, 1)) < 3e-6
+    assert rel(dx, x64.grad.permute(0, 2, 3, 1)) < 3e-6
+    assert rel(dw, w64.grad.permute(2, 3, 1, 0)) < 1e-5
+    assert torch.equal(dw, ops.conv3x3_wgrad(x, dy, bf16=True))
+
+
 def test_bf16_mode_is_close_to_fp32_and_rejects_unsupported_channels():
     from boxsegliver_amd import _abi, ops
     rng = np.random.default_rng(11)

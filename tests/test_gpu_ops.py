@@ -115,6 +115,34 @@ def test_conv3x3_dgrad_wgrad(ops, shape):
     assert torch.equal(dw, dw2)
 
 
+@pytest.mark.parametrize("shape", [(8, 128, 128, 64, 128), (4, 64, 64, 256, 256), (16, 256, 256, 64, 64)])
+def test_conv3x3_large_shapes_against_on_device_float64(ops, shape):
+    """BASELINE-sized layers (thousands of tiles, many tiles per split-K block): forward, input gradient and filter
+    gradient against PyTorch's float64 convolution evaluated ON THE DEVICE (a checker the CPU oracle is too slow for;
+    SURVEY.md 8c), plus run-to-run bit equality of the filter gradient."""
+    n, h, w, cin, cout = shape
+    g = torch.Generator(device="cuda").manual_seed(n + cin)
+    x = torch.randn((n, h, w, cin), device="cuda", generator=g)
+    wt = torch.randn((3, 3, cin, cout), device="cuda", generator=g) / math.sqrt(9 * cin)
+    dy = torch.randn((n, h, w, cout), device="cuda", generator=g)
+    x64 = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    w64 = wt.double().permute(3, 2, 0, 1).requires_grad_(True)
+    y64 = F.conv2d(x64, w64, padding=1)
+    y64.backward(dy.double().permute(0, 3, 1, 2))
+    wp_f, wp_d = ops.conv3x3_pack(wt)
+    y, _, _ = ops.conv3x3_fwd(x, wp_f, cout, want_stats=False)
+    dx = ops.conv3x3_dgrad(dy, wp_d, cin)
+    dw = ops.conv3x3_wgrad(x, dy)
+
+    def rel(a, b):
+        return ((a.double() - b).abs().max() / b.abs().max()).item()
+
+    assert rel(y, y64.detach().permute(0, 2, 3, 1)) < 3e-6
+    assert rel(dx, x64.grad.permute(0, 2, 3, 1)) < 3e-6
+    assert rel(dw, w64.grad.permute(2, 3, 1, 0)) < 1e-5
+    assert torch.equal(dw, ops.conv3x3_wgrad(x, dy))
+
+
 def test_conv3x3_wgrad_first_layer(ops):
     rng = np.random.default_rng(13)
     x = torch.tensor(rng.random((2, 16, 32, 3)), dtype=torch.float64)
