@@ -27,7 +27,7 @@ def compute_weights(w_type, labels, num_classes, numeric_w=None, proportion_deca
     if w_type == "numerical":                                # :125-133
         if numeric_w is None:
             raise KeyError("w_type `numerical` need keyword argument `numeric_w`")
-        nw = torch.tensor(numeric_w, dtype=torch.float32)
+        nw = torch.tensor(numeric_w, dtype=torch.float32, device=labels.device)
         w = (one_hot * nw).sum(-1)
     elif w_type == "proportion":                             # :134-143
         num_labels = one_hot.sum(dim=sp_axes)                # [bs, ncls]

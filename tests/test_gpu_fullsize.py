@@ -1,0 +1,107 @@
+"""GPU: BASELINE.json's own per-GPU shapes against the oracle evaluated ON THE DEVICE in float64.
+
+The oracle is a torch restatement, so it runs unchanged on cuda tensors; in float64 on the GPU it becomes a checker
+fast enough for the real sizes, where every kernel walks thousands of tiles and many tiles per split (the CPU oracle
+needs minutes per step there).  configs[1] (UNet bs 32) lives in test_gpu_unet.py; here:
+  configs[3]  GUNet + 1-channel spatial guide, instance norm, 256x256, bs 8 per GPU
+  configs[2]  UNet 512x512, bs 8 per GPU, bf16 mode -- against the oracle restating the SAME bf16 arithmetic
+  configs[4]  UNet3D, one 96^3 patch per GPU (the 8-GPU layout of SURVEY.md 8e)
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _grad_l2(model, grads, logical=False):
+    num = den = 0.0
+    for name in model.params.trainable_names():
+        g = (model.params.logical_grad(name).cuda() if logical else model.params[name].grad).double()
+        d = g - grads[name]
+        num += float((d * d).sum())
+        den += float((grads[name] * grads[name]).sum())
+    return (num / den) ** 0.5
+
+
+def _check_logits(got, ref, tol, frac=0.99):
+    assert (got - ref).abs().max().item() < tol
+    srt = torch.sort(ref, -1).values
+    safe = (srt[..., -1] - srt[..., -2]) > tol
+    assert bool((got.argmax(-1) == ref.argmax(-1))[safe].all()) and safe.double().mean().item() > frac
+
+
+def test_gunet_config3_shape_against_device_float64_oracle():
+    import test_gpu_gunet as t
+    from boxsegliver_amd.data.synthetic import make_batch, make_guide
+    args = t.make_args(batch_size=8, im_height=256, im_width=256)
+    model, _, net, params, _ = t.setup(args, size=256)
+    images, labels, _ = make_batch(8, 256, 256, 3, 3, 4321)
+    guide = make_guide(labels, 1, 4321)
+    inputs = {"images": torch.from_numpy(images).cuda(), "labels": torch.from_numpy(labels).cuda(),
+              "sp_guide": torch.from_numpy(guide).cuda()}
+    p64 = {k: v.double().cuda() for k, v in params.items()}
+    total, _, logits, grads, _ = net.loss_and_grads(p64, inputs["images"].double(), inputs["sp_guide"].double(),
+                                                    inputs["labels"].long(), **t.kwargs_of(args))
+    model.params.zero_grad()
+    loss = model(inputs, "train", **t.YML)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - total.item()) < 1e-4 * max(1.0, abs(total.item()))
+    _check_logits(model.layers["logits"].double(), logits, 1e-3)
+    assert _grad_l2(model, grads) < 5e-3
+
+
+def test_unet_config2_shape_bf16_against_device_float64_oracle_of_the_same_arithmetic():
+    import test_gpu_unet as t
+    args = t.make_args(batch_size=8, im_height=512, im_width=512, compute_dtype="bf16")
+    images, labels = t.synth(8, 512, 512, 3)
+    model, inputs = t.build(args, images, labels)
+    net, params = t.oracle_for(args)
+    model.params.load_state(params)
+    net.bf16 = True
+    p64 = {k: v.double().cuda() for k, v in params.items()}
+    total, _, logits, grads, _ = net.loss_and_grads(p64, inputs["images"].double(), inputs["labels"].long(),
+                                                    **t.loss_kwargs(args))
+    model.params.zero_grad()
+    loss = model(inputs, "train", **t.YML)
+    loss.backward()
+    torch.cuda.synchronize()
+    # bf16 rounding is discontinuous: two correct executions differ by isolated one-ulp operand flips (see
+    # tests/test_gpu_bf16.py); at this size (batch statistics over 2M pixels) the net is well conditioned
+    assert abs(loss.item() - total.item()) < 1e-3 * max(1.0, abs(total.item()))
+    d = (model.layers["logits"].double() - logits).abs()
+    assert d.max().item() < 5e-2 and d.mean().item() < 5e-3
+    assert (model.layers["logits"].argmax(-1) == logits.argmax(-1)).double().mean().item() > 0.995
+    assert _grad_l2(model, grads) < 0.1
+
+
+def test_unet3d_config4_patch_against_device_float64_oracle():
+    import test_gpu_unet3d as t
+    from boxsegliver_amd.NetworksV2.UNet3D import UNet3D
+    from boxsegliver_amd.data.synthetic import make_batch_3d
+    from oracle import unet3d
+    args = t.make_args(batch_size=1, im_depth=96, im_height=96, im_width=96)
+    images, labels, _ = make_batch_3d(1, 96, 96, 96, 1, 2, 99)
+    inputs = {"images": torch.from_numpy(images).cuda(), "labels": torch.from_numpy(labels).cuda()}
+    model = UNet3D(args)
+    model(inputs, "eval", **t.YML)
+    net = unet3d.UNet3DOracle(1, 2, normalizer=args.normalizer)
+    params = unet3d.init_params(net.specs, seed=5)
+    g = torch.Generator().manual_seed(9)
+    for name, _, kind in net.specs:
+        if kind == "gamma":
+            params[name] = 0.5 + torch.rand(params[name].shape, generator=g)
+        elif kind in ("beta", "bias"):
+            params[name] = 0.1 * torch.randn(params[name].shape, generator=g)
+    model.params.load_state(params)
+    p64 = {k: v.double().cuda() for k, v in params.items()}
+    total, _, logits, grads, _ = net.loss_and_grads(p64, inputs["images"].double(), inputs["labels"].long(),
+                                                    **t.kwargs_of(args))
+    model.params.zero_grad()
+    loss = model(inputs, "train", **t.YML)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - total.item()) < 1e-4 * max(1.0, abs(total.item()))
+    _check_logits(model.layers["logits"].double(), logits, 1e-3)
+    assert _grad_l2(model, grads, logical=True) < 5e-3

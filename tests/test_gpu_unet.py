@@ -389,3 +389,37 @@ def test_unet_boundary_weight_loss_matches_oracle():
     assert abs(loss.item() - total.item()) < 1e-4 * max(1.0, abs(total.item()))
     name = "UNet/AdjustChannels/biases"
     np.testing.assert_allclose(model.params[name].grad.cpu().numpy(), grads[name].numpy(), rtol=2e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("bs", [4, 32])
+def test_unet_256x256_against_the_oracle_evaluated_on_the_device_in_float64(bs):
+    """BASELINE.json configs[1] itself at bs 32 (256x256x3, 3 classes, numerical weights; and bs 4): the oracle's torch
+    restatement runs unchanged on cuda tensors in float64, which makes a checker fast enough for the real sizes (every
+    kernel walks thousands of tiles).  North-star bars: logits within 1e-3, loss within 1e-4, argmax masks equal
+    outside 1e-3 margins; whole-gradient L2 < 5e-3."""
+    args = make_args(batch_size=bs, im_height=256, im_width=256)
+    images, labels = synth(bs, 256, 256, 3)
+    model, inputs = build(args, images, labels)
+    net, params = oracle_for(args)
+    model.params.load_state(params)
+    p64 = {k: v.double().cuda() for k, v in params.items()}
+    total, _, logits, grads, new_stats = net.loss_and_grads(
+        p64, torch.from_numpy(images).double().cuda(), torch.from_numpy(labels).long().cuda(), **loss_kwargs(args))
+    model.params.zero_grad()
+    loss = model(inputs, "train", **YML)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - total.item()) < 1e-4 * max(1.0, abs(total.item()))
+    got = model.layers["logits"].double()
+    assert (got - logits).abs().max().item() < 1e-3
+    srt = torch.sort(logits, -1).values
+    safe = (srt[..., -1] - srt[..., -2]) > 1e-3
+    assert bool((got.argmax(-1) == logits.argmax(-1))[safe].all()) and safe.double().mean().item() > 0.99
+    num = den = 0.0
+    for name in model.params.trainable_names():
+        d = model.params[name].grad.double() - grads[name]
+        num += float((d * d).sum())
+        den += float((grads[name] * grads[name]).sum())
+    assert (num / den) ** 0.5 < 5e-3
+    for name, ref in new_stats.items():
+        assert torch.allclose(model.params[name].double(), ref, rtol=1e-4, atol=1e-6), name
