@@ -108,10 +108,12 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node {} bench.py --gpus {} ..."
                              .format(a.gpus, a.gpus))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product has no CPU path)"
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; the modulo only matters for rehearsals of the multi-rank path on a box with fewer GPUs than
+    # ranks (UNETK_DIST_BACKEND=gloo: RCCL refuses two ranks on one device)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")            # RCCL over xGMI
+        dist.init_process_group(backend=os.environ.get("UNETK_DIST_BACKEND", "nccl"))   # "nccl" = RCCL over xGMI
 
     from boxsegliver_amd import ops
     from boxsegliver_amd.core import models
@@ -137,7 +139,7 @@ def main():
         gflop_unit = 1612.92 * (a.size / 96.0) ** 3
         workload_name = "UNet3D {0}x{0}x{0}x1 bs={1}/GPU fp32 instance_norm (BASELINE.json configs[4])"
     YML = models.get_model_params(args, build_metrics=True)["model_kwargs"]
-    params = {"args": args, "rank": rank, "device": torch.device("cuda", local_rank)}
+    params = {"args": args, "rank": rank, "device": torch.device("cuda", torch.cuda.current_device())}
     data = input_fn("train", params)
     model = {c.__name__: c for c in models.MODEL_ZOO}[a.model](args)
     solver = Solver(args)
@@ -186,7 +188,7 @@ def main():
         ms = elapsed / a.steps * 1e3
         slices = a.batch * world * a.steps / elapsed
         if workload_name is None:
-            cfg = "configs[1]" if (a.size == 256 and a.dtype == "fp32") else \
+            cfg = "configs[1]" if (a.size == 256 and a.batch == 32 and a.dtype == "fp32") else \
                 ("configs[2] shape" if (a.size == 512 and a.batch == 8) else "off-config shape")
             workload_name = "UNet 2D Liver+Tumor {0}x{0}x3 bs={1}/GPU fp32 (BASELINE.json " + cfg + ")"
         wl = workload_name.format(a.size, a.batch) + ", fwd+bwd+TF-Adam" + ("+RCCL grad all-reduce" if world > 1 else "")
