@@ -6,11 +6,12 @@
 //     launch of conv3x3_igemm over the (n, d_out) planes, addressed in place through ImgAddr (depth slices /
 //     depth-strided views, no copies), accumulating into the output (epilogue y += acc); the tap that covers
 //     every output plane runs last and produces the norm statistics.  Depth stride 2 is just a plane stride.
-//   * H/W stride 2 (10.7 % of UNet3D's FLOPs): forward = stride-1 conv into a scratch tensor + subsample
-//     (which also emits the statistic partials); backward = dilate dy (zero insertion) + the stride-1
-//     dgrad / wgrad kernels -- the identities  dx = conv_s1(dilate(dy), flip(w))  and
-//     dW = wgrad_s1(x, dilate(dy))  hold exactly, at 4x MFMA work on those layers (a native strided tile
-//     is the next optimisation).
+//   * H/W stride 2 (10.7 % of UNet3D's FLOPs): forward = the igemm kernel's native stride-2 tile (conv_igemm.hip,
+//     S = 2) when Cin % 16 == 0 and Cout % 64 == 0, else stride-1 conv into a scratch tensor + subsample (which also
+//     emits the statistic partials); input gradient = four output-parity classes contracted from the UNDILATED dy
+//     (conv_igemm_lin.hip, GEN variant) when Cin % 64 == 0, else dilate dy + the stride-1 kernel; filter gradient =
+//     dilate dy (zero insertion) + the stride-1 kernel, dW = wgrad_s1(x, dilate(dy)) exactly, at 4x MFMA work (a
+//     parity-plane variant was measured and dropped: it stages the same bytes, which is what bounds that kernel).
 #include "common.h"
 
 namespace {
