@@ -241,7 +241,7 @@ class CustomEstimator(object):
             done += 1
             step = solver.global_step
             if step % log_step == 0 or done == 1:
-                loss_val = float(spec.loss)           # host sync only at log steps
+                loss_val = float(spec.loss.detach())  # host sync only at log steps
                 if math.isnan(loss_val):
                     raise NanLossDuringTrainingError()          # NanTensorHook, estimator.py:676
                 last_loss = loss_val

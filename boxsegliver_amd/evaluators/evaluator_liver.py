@@ -203,6 +203,34 @@ class EvaluateVolume(EvaluateBase):
                     decouple_volume["Liver"].astype(decouple_volume["Tumor"].dtype)
         return decouple_volume
 
+    def run_with_session(self, session=None):
+        """evaluator_liver.py:164-169,286-330 (2-D): evaluate on the `eval_online` batches from inside training, with
+        the live variables and moving statistics -- the mean of the in-graph "<Class>/<Metric>" values per batch, or
+        with --use_global_dice the Dice of the summed confusion counts of the thresholded predictions."""
+        if getattr(self.config, "eval_3d", False):
+            raise NotImplementedError("online 3-D evaluation needs the LiTS volume pipeline (SURVEY.md 8f2)")
+        model = self._model()
+        if not getattr(self.config, "use_global_dice", False):
+            keys = list(model.metrics_dict)
+            acc = defaultdict(list)
+            for x in self.estimator.evaluate_online(session, keys, yield_single_examples=False):
+                for k, v in x.items():
+                    acc[k].append(float(v))
+            return {k: float(np.mean(v)) for k, v in acc.items()}
+        acc = defaultdict(int)
+        keys = ["labels"] + list(model.predictions)
+        for x in self.estimator.evaluate_online(session, keys, yield_single_examples=False):
+            labels = x["labels"].cpu().numpy()
+            for i, cls in enumerate(self.classes):
+                pred = np.squeeze(x[cls + "Pred"].cpu().numpy(), axis=-1).astype(int)
+                conf = metric_ops.ConfusionMatrix(pred, (labels == i + 1).astype(int))
+                conf.compute()
+                acc[cls + "_fn"] += conf.fn
+                acc[cls + "_fp"] += conf.fp
+                acc[cls + "_tp"] += conf.tp
+        return {cls + "/Dice": 2 * acc[cls + "_tp"] / max(2 * acc[cls + "_tp"] + acc[cls + "_fn"] + acc[cls + "_fp"], 1)
+                for cls in self.classes}
+
     def run(self, input_fn, checkpoint_path=None, latest_filename=None, save=False, hooks=None, cases=None):
         """evaluator_liver.py:704-766: build the model, restore the checkpoint, stream the cases."""
         model = self._model()
