@@ -50,8 +50,14 @@ class HeadDesc(Structure):
                 ("proportion_decay", c_float)]
 
 
+class LitsDesc(Structure):
+    _fields_ = [("N", c_int32), ("H", c_int32), ("W", c_int32), ("C", c_int32), ("n_slices", c_int32), ("src_h", c_int32),
+                ("src_w", c_int32), ("lab_scale", c_int32), ("seed", ctypes.c_uint32), ("noise_scale", c_float)]
+
+
 P = c_void_p
 _SIGNATURES = {
+    "unetk_lits_batch": (c_int, [POINTER(LitsDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "unetk_abi_version": (c_int, []),
     "unetk_error_string": (c_char_p, [c_int]),
     "unetk_conv3x3_pack": (c_int, [P, c_int, c_int, P, P, P]),

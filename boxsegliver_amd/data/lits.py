@@ -1,0 +1,328 @@
+"""LiTS training input pipeline -- MI355X-first restatement of the reference's
+DataLoader/Liver/input_pipeline.py (dataset collection :73-198, sampler `gen_train_batch` :285-378, per-sample processing
+`data_processing_train` :243-284) and DataLoader/misc.py (`read_or_create_k_folds` :45-74).
+
+On-disk format (the reference's own): `<root>/png/volume-<PID>/<slice:03d>_im.png` 16-bit grayscale = (HU clipped to
+[-200, 250] + 200) * IM_SCALE, `<slice:03d>_lb.png` 8-bit = label * LB_SCALE (IM_SCALE = LB_SCALE = 64, :47-48);
+`meta.json` (shipped with the reference: 131 cases) and `k_folds.txt` ("Fold i:pid pid ...").
+
+Design: the reference feeds the GPU from tf.data CPU threads (PNG decode + crop + resize per sample per step).  An
+MI355X has 288 GB of HBM and the whole decoded training set is ~35 GB as uint16, so `SliceStore` decodes every slice ONCE
+and keeps it on the device; a step's batch is then the host-side sampler (a few hundred integer operations) + one gather
+kernel (`unetk_lits_batch`).  The PNG codec is a small pure-Python/zlib one (no cv2 / PIL in this image).
+
+The sampler restates the reference's selection logic literally (forced tumor / liver shares, crop placement around the
+object box, random zoom and window level) on a `random.Random(seed)` / `numpy.random.RandomState(seed)` pair instead
+of the reference's unseeded global generators.
+"""
+import copy
+import json
+import math
+import random
+import struct
+import zlib
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..utils import distribution_utils
+
+IM_SCALE = 64
+LB_SCALE = 64
+LIVER_PERCENT = 0.66
+TUMOR_PERCENT = 0.5
+RND_SCALE = (1.0, 1.4)
+
+
+def add_arguments(parser):
+    """DataLoader/Liver/input_pipeline.py:54-70 (names / defaults verbatim) + --lits_root (where png/, meta.json and
+    k_folds.txt live; the reference hard-codes <project>/data/LiTS)."""
+    group = parser.add_argument_group(title="Input Pipeline Arguments")
+    group.add_argument("--test_fold", type=int, default=2)
+    group.add_argument("--im_height", type=int, default=256)
+    group.add_argument("--im_width", type=int, default=256)
+    group.add_argument("--im_channel", type=int, default=3)
+    group.add_argument("--filter_size", type=int, default=0, help="Filter tumors small than the given size")
+    group.add_argument("--noise_scale", type=float, default=0.1)
+    group.add_argument("--zoom_scale", type=float, nargs=2, default=RND_SCALE)
+    group.add_argument("--random_flip", type=int, default=1,
+                       help="Random flip while training. 0 for no flip, 1 for flip only left/right, "
+                            "2 for only up/down, 3 for left/right and up/down")
+    group.add_argument("--eval_in_patches", action="store_true")
+    group.add_argument("--eval_num_batches_per_epoch", type=int, default=100)
+    group.add_argument("--eval_mirror", action="store_true")
+    group.add_argument("--liver_percent", type=float, default=LIVER_PERCENT)
+    group.add_argument("--tumor_percent", type=float, default=TUMOR_PERCENT)
+    group.add_argument("--lits_root", type=str, default="data/LiTS")
+
+
+# ------------------------------------------------------------------------------------------------- PNG codec
+def png_decode(data):
+    """8- or 16-bit grayscale, non-interlaced PNG -> ndarray (uint8 / uint16)."""
+    if data[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError("not a PNG file")
+    pos, idat, hdr = 8, [], None
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        pos += 12 + n
+        if typ == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif typ == b"IDAT":
+            idat.append(body)
+        elif typ == b"IEND":
+            break
+    w, h, depth, ctype, _, _, interlace = hdr
+    if ctype != 0 or interlace != 0 or depth not in (8, 16):
+        raise ValueError("only non-interlaced 8/16-bit grayscale PNGs are supported")
+    bpp = depth // 8
+    stride = w * bpp
+    raw = np.frombuffer(zlib.decompress(b"".join(idat)), dtype=np.uint8).reshape(h, stride + 1)
+    out = np.zeros((h, stride), dtype=np.uint8)
+    prev = np.zeros(stride, dtype=np.int32)
+    for y in range(h):
+        ft = int(raw[y, 0])
+        line = raw[y, 1:].astype(np.int32)
+        if ft == 0:
+            cur = line
+        elif ft == 2:
+            cur = (line + prev) & 255
+        elif ft == 1:                                       # Sub: byte lanes are independent running sums mod 256
+            cur = line.copy()
+            for k in range(bpp):
+                cur[k::bpp] = np.cumsum(line[k::bpp]) & 255
+        else:                                               # Average / Paeth: sequential
+            cur = np.zeros(stride, dtype=np.int32)
+            for i in range(stride):
+                a = cur[i - bpp] if i >= bpp else 0
+                b = prev[i]
+                c = prev[i - bpp] if i >= bpp else 0
+                if ft == 3:
+                    pred = (a + b) >> 1
+                else:
+                    p = a + b - c
+                    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[i] = (line[i] + pred) & 255
+        out[y] = cur
+        prev = cur
+    if depth == 8:
+        return out.copy()
+    return (out[:, 0::2].astype(np.uint16) << 8 | out[:, 1::2].astype(np.uint16)).copy()
+
+
+def png_encode(arr):
+    """ndarray uint8 / uint16 [h, w] -> PNG bytes (filter 0; used to write synthetic datasets in tests / tools)."""
+    arr = np.ascontiguousarray(arr)
+    h, w = arr.shape
+    depth = 16 if arr.dtype == np.uint16 else 8
+    body = arr.astype(">u2").tobytes() if depth == 16 else arr.astype(np.uint8).tobytes()
+    stride = w * depth // 8
+    raw = b"".join(b"\x00" + body[y * stride:(y + 1) * stride] for y in range(h))
+
+    def chunk(typ, payload):
+        return struct.pack(">I", len(payload)) + typ + payload + struct.pack(">I", zlib.crc32(typ + payload) & 0xffffffff)
+
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, 0, 0, 0, 0)) + \
+        chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
+
+
+# ------------------------------------------------------------------------------------------------- dataset lists
+def read_or_create_k_folds(path, list_, k_split=None, seed=None):
+    """DataLoader/misc.py:45-74 (the shipped data/LiTS/k_folds.txt came from k_split=5, seed=1357)."""
+    path = Path(path)
+    if path.exists():
+        with path.open() as f:
+            return [line[line.find(":") + 1:].strip().split(" ") for line in f.readlines()]
+    if not isinstance(k_split, int) or k_split <= 0:
+        raise ValueError("Wrong `k_split` value. Need a positive integer, got {}".format(k_split))
+    items = list(list_)
+    np.random.RandomState(seed).shuffle(items)
+    k_folds = [[str(x) for x in items[i::k_split]] for i in range(k_split)]
+    with path.open("w") as f:
+        for i, fold in enumerate(k_folds):
+            f.write("Fold %d:" % i + " ".join(fold) + "\n")
+    return k_folds
+
+
+def parse_case(case, filter_size=0):
+    """input_pipeline.py:92-119: group the per-slice tumor boxes by slice, drop tumors not larger than filter_size."""
+    case = copy.deepcopy(case)
+    for k in ("tumors", "tumor_areas", "tumor_centers", "tumor_stddevs"):
+        case.pop(k, None)
+    ft = case.pop("tumor_slices_from_to")
+    assert len(ft) == len(case["tumor_slices_index"]) + 1
+    centers, stddevs = _maybe_json(case.pop("tumor_slices_centers")), _maybe_json(case.pop("tumor_slices_stddevs"))
+    areas, coords = _maybe_json(case.pop("tumor_slices_areas")), _maybe_json(case.pop("tumor_slices"))
+    case["centers"], case["stddevs"], case["slices"] = [], [], []
+    slices = copy.deepcopy(case["tumor_slices_index"])
+    for ii in range(len(ft) - 1):
+        sel = [j for j, a in enumerate(areas[ft[ii]:ft[ii + 1]]) if a > filter_size]
+        if not sel:
+            case["tumor_slices_index"].remove(slices[ii])
+        else:
+            case["centers"].append([centers[ft[ii] + j] for j in sel])
+            case["stddevs"].append([stddevs[ft[ii] + j] for j in sel])
+            case["slices"].append([coords[ft[ii] + j] for j in sel])
+    return case
+
+
+def _maybe_json(v):
+    return json.loads(v) if isinstance(v, str) else v      # the shipped meta.json stores the nested lists as strings
+
+
+def collect_datasets(root, test_fold, mode, filter_tumor_size=0, filter_only_liver_in_val=True):
+    """input_pipeline.py:73-198: meta.json + k_folds.txt -> the list of cases of `mode` ("train" / anything else = val)."""
+    root = Path(root)
+    with (root / "meta.json").open() as f:
+        meta = {int(c["PID"]): c for c in json.load(f)}
+    k_folds = read_or_create_k_folds(root / "k_folds.txt", sorted(meta), k_split=5, seed=1357)
+    if test_fold + 1 > len(k_folds):
+        raise ValueError("test_fold too large")
+    test = k_folds[test_fold] if test_fold >= 0 else []
+    train = [x for i, fold in enumerate(k_folds) if i != test_fold for x in fold]
+    if mode == "train":
+        return [parse_case(meta[i], filter_tumor_size) for i in sorted(int(x) for x in train)]
+    val = [parse_case(meta[i], filter_tumor_size) for i in sorted(int(x) for x in test)]
+    return [c for c in val if len(c["slices"]) > 0] if filter_only_liver_in_val else val
+
+
+# ------------------------------------------------------------------------------------------------- resident slices
+class SliceStore(object):
+    """Every slice of the given cases decoded once and kept in device memory: `im` int16-typed storage of the uint16
+    pixels [n_slices, h, w], `lb` uint8 [n_slices, h, w]; `offset[pid] + z` indexes slice z of case pid."""
+
+    def __init__(self, root, cases, device):
+        root = Path(root)
+        self.offset, ims, lbs, n = {}, [], [], 0
+        for case in cases:
+            pid, depth = int(case["PID"]), int(case["size"][0])
+            self.offset[pid] = n
+            for z in range(depth):
+                ims.append(png_decode((root / "png" / "volume-{:d}".format(pid) / "{:03d}_im.png".format(z)).read_bytes()))
+                lbs.append(png_decode((root / "png" / "volume-{:d}".format(pid) / "{:03d}_lb.png".format(z)).read_bytes()))
+            n += depth
+        self.im = torch.from_numpy(np.stack(ims).view(np.int16)).to(device)
+        self.lb = torch.from_numpy(np.stack(lbs)).to(device)
+        self.device = device
+
+
+# ------------------------------------------------------------------------------------------------- sampler
+def gen_train_batch(data_list, batch_size, liver_percent=0., tumor_percent=0., random_scale=(1., 1.),
+                    random_window_level=False, config=None, seed=None):
+    """input_pipeline.py:285-378.  Yields per sample (slice indices [C] with -1 for zero padding, label slice index,
+    [off_y, off_x, crop_h, crop_w], pid, (clip_lo, clip_hi)); indices are slice numbers WITHIN the case."""
+    rnd, nrs = random.Random(seed), np.random.RandomState(seed)
+    d = data_list
+    keys = np.arange(len(d))
+    tumor_keys = [i for i in keys if len(d[i]["slices"]) > 0]
+    target_size = np.asarray((config.im_height, config.im_width), dtype=np.float32)
+    force_liver = math.ceil(batch_size * liver_percent)
+    force_tumor = math.ceil(batch_size * tumor_percent)
+    while True:
+        ci = np.concatenate((nrs.choice(tumor_keys, force_tumor, True) if force_tumor else np.zeros(0, np.int64),
+                             nrs.choice(keys, batch_size - force_tumor, True)), axis=0).astype(np.int64)
+        liver_counter = tumor_counter = 0
+        for i in ci:
+            case = d[int(i)]
+            crop_size = (target_size * nrs.uniform(*random_scale, size=2)).astype(np.int32).tolist()
+            size, pid = case["size"], case["PID"]
+            if tumor_counter < force_tumor:
+                tumor_slices = case["slices"]
+                ind = int(nrs.choice(np.arange(len(tumor_slices))))
+                selected = case["tumor_slices_index"][ind]
+                tumor_counter += 1
+                liver_counter += 1
+                obj_bb = tumor_slices[ind][rnd.randint(0, len(tumor_slices[ind]) - 1)]
+            elif liver_counter < force_liver:
+                selected = rnd.randint(case["bbox"][0], case["bbox"][3] - 1)
+                liver_counter += 1
+                obj_bb = case["bbox"][1:3] + case["bbox"][4:6]
+            else:
+                selected = rnd.randint(0, size[0] - 1)
+                obj_bb = [size[1], size[2], 0, 0]                           # object does not exist
+            rng_yl = max(obj_bb[2] + 5 - crop_size[0], 0)
+            rng_yr = min(obj_bb[0] - 5, size[1] - crop_size[0])
+            if rng_yl + 20 < rng_yr:
+                off_y = rnd.randint(rng_yl, rng_yr)
+            else:
+                off_y = rnd.randint(max(obj_bb[0] - 20, 0), min(int(obj_bb[0] * .75 + obj_bb[2] * .25), size[1] - crop_size[0]))
+            rng_xl = max(obj_bb[3] + 5 - crop_size[1], 0)
+            rng_xr = min(obj_bb[1] - 5, size[2] - crop_size[1])
+            if rng_xl + 20 < rng_xr:
+                off_x = rnd.randint(rng_xl, rng_xr)
+            else:
+                off_x = rnd.randint(max(obj_bb[1] - 20, 0), min((obj_bb[1] + obj_bb[3]) // 2, size[2] - crop_size[1]))
+            chans = [selected]
+            if config.im_channel > 1:
+                left = (config.im_channel - 1) // 2
+                for k in range(1, left + 1):
+                    chans.insert(0, selected - k if selected - k >= 0 else -1)
+                for k in range(1, config.im_channel - left):
+                    chans.append(selected + k if selected + k < size[0] else -1)
+            if random_window_level:
+                clip = (rnd.randint(10, 50) * IM_SCALE * 1., rnd.randint(500, 540) * IM_SCALE * 1.)
+            else:
+                clip = (50 * IM_SCALE * 1., 500 * IM_SCALE * 1.)
+            yield chans, selected, [off_y, off_x] + crop_size, pid, clip
+
+
+def batches(store, data_list, config, training, seed=1234, liver_percent=0., tumor_percent=0., random_scale=(1., 1.)):
+    """The tf.data pipelines get_dataset_for_train / get_dataset_for_eval_online (:381-430) as a generator of
+    (features, labels) device batches: the sampler on the host, everything else in `unetk_lits_batch`."""
+    bs = distribution_utils.per_device_batch_size(config.batch_size, config.num_gpus)
+    c = config.im_channel
+    gen = gen_train_batch(data_list, bs, liver_percent, tumor_percent, random_scale if training else (1., 1.),
+                          random_window_level=training, config=config, seed=seed)
+    rnd = random.Random(seed + 1)
+    rf = int(getattr(config, "random_flip", 0) or 0)
+    step = 0
+    while True:
+        tab = np.zeros((bs, c + 7), dtype=np.int32)
+        clip = np.zeros((bs, 2), dtype=np.float32)
+        names = np.zeros((bs,), dtype=np.int64)
+        for j in range(bs):
+            chans, lab, box, pid, cl = next(gen)
+            off = store.offset[int(pid)]
+            tab[j, :c] = [off + z if z >= 0 else -1 for z in chans]
+            tab[j, c] = off + lab
+            tab[j, c + 1:c + 5] = box
+            if training:                                                     # image_ops.random_flip_*: one coin per sample
+                tab[j, c + 5] = int(rf & 1 > 0 and rnd.random() < 0.5)
+                tab[j, c + 6] = int(rf & 2 > 0 and rnd.random() < 0.5)
+            clip[j] = cl
+            names[j] = pid
+        images, labels = ops.lits_batch(store.im, store.lb, torch.from_numpy(tab).to(store.device),
+                                        torch.from_numpy(clip).to(store.device), (config.im_height, config.im_width), c,
+                                        LB_SCALE, float(config.noise_scale) if training else 0.0, seed * 7919 + step)
+        step += 1
+        yield {"images": images, "names": torch.from_numpy(names)}, labels
+
+
+def input_fn(mode, params):
+    """input_pipeline.py:199-241 for the modes train / eval_online; params["lits_root"] holds png/, meta.json,
+    k_folds.txt.  (Offline volume evaluation: data/synthetic.input_fn_eval_volumes shows the contract; a LiTS-backed
+    eval generator is the remaining part of SURVEY.md 8f2.)"""
+    args = params["args"]
+    root = params["lits_root"]
+    device = params.get("device", torch.device("cuda", torch.cuda.current_device()))
+    key = ("lits_store", mode == "train")
+    if key not in params:
+        cases = collect_datasets(root, args.test_fold, "train" if mode == "train" else "val",
+                                 filter_tumor_size=getattr(args, "filter_size", 0))
+        params[key] = (SliceStore(root, cases, device), cases)
+    store, cases = params[key]
+    if len(cases) == 0:
+        raise ValueError("No valid dataset found!")
+    rs = tuple(getattr(args, "zoom_scale", (1., 1.)))                        # --zoom_scale (input_pipeline.py:62)
+    seed = int(getattr(args, "seed", 1234) or 1234) + 1000 * int(params.get("rank", 0))
+    if mode == "train":
+        return batches(store, cases, args, True, seed, getattr(args, "liver_percent", 0.), getattr(args, "tumor_percent", 0.), rs)
+    if mode == "eval_online":
+        gen = batches(store, cases, args, False, seed + 500, getattr(args, "liver_percent", 0.),
+                      getattr(args, "tumor_percent", 0.))
+        n = int(getattr(args, "eval_num_batches_per_epoch", 100))
+        return (next(gen) for _ in range(n))
+    raise ValueError("lits.input_fn handles the modes `train` and `eval_online`, got {}".format(mode))

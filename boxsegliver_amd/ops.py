@@ -504,6 +504,25 @@ def boundary_weights(labels):
     return wmap
 
 
+def lits_batch(slices, seg_slices, sample_tab, clip, out_hw, channels, lab_scale=64, noise_scale=0.0, seed=0):
+    """One training batch from device-resident decoded slices (input_pipeline.py:243-284): slices uint16 / seg_slices
+    uint8 [n, src_h, src_w] (stored as int16 / uint8 tensors), sample_tab int32 [N, C+7], clip f32 [N, 2]."""
+    _require_cuda(slices, seg_slices, sample_tab, clip)
+    n = sample_tab.shape[0]
+    h, w = out_hw
+    assert slices.dtype in (torch.int16, torch.uint16) and seg_slices.dtype == torch.uint8
+    assert sample_tab.dtype == torch.int32 and sample_tab.shape[1] == channels + 7 and sample_tab.is_contiguous()
+    assert clip.dtype == torch.float32 and tuple(clip.shape) == (n, 2) and clip.is_contiguous()
+    assert slices.is_contiguous() and seg_slices.is_contiguous() and slices.shape == seg_slices.shape
+    d = _abi.LitsDesc(n, h, w, channels, slices.shape[0], slices.shape[1], slices.shape[2], int(lab_scale),
+                      int(seed) & 0xffffffff, float(noise_scale))
+    images = torch.empty((n, h, w, channels), dtype=torch.float32, device=slices.device)
+    labels = torch.empty((n, h, w), dtype=torch.int32, device=slices.device)
+    check(_abi.lib().unetk_lits_batch(ctypes.byref(d), ptr(slices), ptr(seg_slices), ptr(sample_tab), ptr(clip), ptr(images),
+                                      ptr(labels), stream_ptr()), "lits_batch")
+    return images, labels
+
+
 def adam_step(p, g, m, v, lr_t, beta1, beta2, eps, gscale=1.0, l2=0.0, decoupled_wd=0.0):
     check(_abi.lib().unetk_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr_t, beta1, beta2, eps, gscale, l2,
                                      decoupled_wd, stream_ptr()), "adam_step")

@@ -273,6 +273,26 @@ size_t unetk_boundary_weights_ws_bytes(int N, int H, int W);
 int unetk_boundary_weights(const int32_t* labels, int N, int H, int W, float* wmap, void* ws,
                            size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------- LiTS training batch  
+ * DataLoader/Liver/input_pipeline.py:243-284 `data_processing_train` for a whole batch, gathering from decoded slices
+ * that are RESIDENT in device memory: per sample crop_to_bounding_box -> resize_bilinear(align_corners) -> window clip
+ * -> normalise (images), crop -> resize_nearest_neighbor(align_corners) -> / lab_scale (labels), uniform noise
+ * U(-noise_scale, noise_scale) on non-padding slices (counter-based generator keyed by `seed`), random flips.
+ * slices: uint16 [n_slices, src_h, src_w]; seg_slices: uint8 [n_slices, src_h, src_w];
+ * sample_tab int32 [N][C + 7] = {slice index x C (-1 = zero padding), label slice index (-1 = zeros), off_y, off_x,
+ * crop_h, crop_w, flip_left_right, flip_up_down}; clip float [N][2] = {lo, hi};
+ * images f32 [N,H,W,C]; labels int32 [N,H,W].  The caller guarantees crops inside the source slice. */
+typedef struct unetk_lits_desc {
+  int32_t N, H, W, C;
+  int32_t n_slices, src_h, src_w; /* extent of the resident store; indices outside [0, n_slices) read as zeros */
+  int32_t lab_scale; /* LB_SCALE = 64 */
+  uint32_t seed;
+  float noise_scale; /* 0 = no noise (eval_online) */
+} unetk_lits_desc;
+int unetk_lits_batch(const unetk_lits_desc* d, const uint16_t* slices, const uint8_t* seg_slices,
+                     const int32_t* sample_tab, const float* clip, float* images, int32_t* labels,
+                     void* stream);
+
 /* ---------------------------------------------------------------- optimiser  core/solver.py:204-243
  * tf.train.AdamOptimizer on a flat parameter buffer.  g' = g*gscale + l2*p  (slim.l2_regularizer
  * gradient, base.py:128-135);  m += (1-b1)(g'-m);  v += (1-b2)(g'^2-v);
