@@ -7,7 +7,12 @@ i are a 1x1 conv of the avg-pooled guide with 2*C_i channels (`_spatial_subnets`
 1x1 conv is never materialised: the norm-apply kernel adds guide[n,pix,:] . gw[:, c] + gb[c] on the fly and
 the norm-backward kernel reduces the gradients of gw / gb in the same pass.
 
-Not built yet (raise NotImplementedError): the context (density) branch --use_context, --use_se,
+The context (density) branch --use_context (`_context_subnets` with context_model "fc", GUNet.py:31-60, and
+`conditional_normalization`, :119-133,203-206): a 3-layer MLP on the context vector (ops.FullyConnected) yields
+per-sample channel gains; each modulated conv unit multiplies its normalised output by its slice of them inside
+the same norm-apply / norm-backward kernels (no extra pass over the activations).
+
+Not built (raise NotImplementedError): --use_se, context_model vgg16*, the conv context subnet (`ct_conv`),
 `after_affine`, --fix, --dropout.
 """
 import torch
@@ -19,8 +24,13 @@ from . import base
 from .base import ModeKeys, ParamStore
 
 
+def n_modulator_params(init_channels, num_down_samples, mod_layers):
+    """GUNet.py:47-48: two conv units per modulated level, C_i gains each."""
+    return init_channels * sum(2 ** i for i in range(num_down_samples + 1) if i in mod_layers) * 2
+
+
 def param_specs(in_channels, num_classes, guide_channel, init_channels, num_down_samples, mod_layers, normalizer,
-                norm_with_center, norm_with_scale, use_spatial, name):
+                norm_with_center, norm_with_scale, use_spatial, name, context_dims=None):
     """Variables with the reference's TF names: <name>/spatial/conv{i}/{weights,biases},
     <name>/Encode/down_conv{i}/mod_conv{j}/{weights,<Norm>/...}, <name>/Decode/up{i}/{weights,biases},
     <name>/Decode/up_conv{i}/up_conv{i}_{j}/..., <name>/AdjustChannels/{weights,biases}."""
@@ -37,6 +47,12 @@ def param_specs(in_channels, num_classes, guide_channel, init_channels, num_down
             specs.append(("{}/{}/moving_mean".format(scope, ns), (c,), "moving_mean"))
             specs.append(("{}/{}/moving_variance".format(scope, ns), (c,), "moving_var"))
 
+    if context_dims:      # [context length, fc channels ..., n_modulator_param]: <name>/context/fc{i}/{weights,biases}
+        for i in range(1, len(context_dims)):
+            last = i == len(context_dims) - 1
+            specs.append(("{}/context/fc{}/weights".format(name, i), (context_dims[i - 1], context_dims[i]),
+                          "fc_w_he" if last else "fc_w"))
+            specs.append(("{}/context/fc{}/biases".format(name, i), (context_dims[i],), "fc_b"))
     if use_spatial:
         for i in range(num_down_samples + 1):
             if i in mod_layers:
@@ -46,7 +62,7 @@ def param_specs(in_channels, num_classes, guide_channel, init_channels, num_down
     cin = in_channels
     for i in range(num_down_samples + 1):
         c = init_channels * 2 ** i
-        mod = use_spatial and i in mod_layers
+        mod = (use_spatial or bool(context_dims)) and i in mod_layers
         for j in (1, 2):
             scope = "{}/Encode/down_conv{}/mod_conv{}".format(name, i + 1, j)
             specs.append((scope + "/weights", (3, 3, cin, c), "conv_w"))
@@ -91,8 +107,8 @@ class GUNet(base.BaseNet):
         """GUNet.py:240-257: as UNet (decoder norm = _get_normalization defaults), pools with SAME."""
         if getattr(self.args, "without_norm", False):
             raise NotImplementedError("--without_norm has no HIP kernel yet")
-        if self.use_context_guide or self.use_se:
-            raise NotImplementedError("GUNet context branch (--use_context / --use_se) is not built yet")
+        if self.use_se or hasattr(self.args, "ct_conv"):
+            raise NotImplementedError("GUNet --use_se / ct_conv context variants are not built yet")
         if getattr(self.args, "fix", False) or self.dropout:
             raise NotImplementedError("GUNet --fix / --dropout are not built yet")
         self._norm = self._get_normalization()
@@ -105,12 +121,12 @@ class GUNet(base.BaseNet):
                                 bool(np_["is_training"]), self.compute_bf16)
         return ops.NormSpec("instance_norm", np_["eps"], 0.0, self.is_training, self.compute_bf16)
 
-    def _unit(self, x, scope, spec, out=None, guide=None, gw=None, gb=None):
+    def _unit(self, x, scope, spec, out=None, guide=None, gw=None, gb=None, den=None):
         p = self.params
         ns = scope + ("/BatchNorm" if spec.kind == "batch_norm" else "/InstanceNorm")
         z = ops.Conv3x3NormRelu.apply(x, p[scope + "/weights"], p.get(ns + "/gamma"), p.get(ns + "/beta"),
                                       p.get(ns + "/moving_mean"), p.get(ns + "/moving_variance"), spec, out, guide, gw,
-                                      gb)
+                                      gb, den)
         if self._taps is not None:
             self._taps[scope] = z
         return z
@@ -132,10 +148,21 @@ class GUNet(base.BaseNet):
         dev = images.device
         nm = self.name
         g_ch = int(getattr(self.args, "guide_channel", 1)) if self.use_spatial_guide else 0
+        context_dims = None
+        if self.use_context_guide:
+            if kwargs.get("context_model", "fc") != "fc":
+                raise NotImplementedError("GUNet context_model {} is not built (only \"fc\")".format(
+                    kwargs.get("context_model")))
+            context = self._inputs["context"]
+            if context.dim() != 2 or context.shape[0] != n or not context.is_cuda:
+                raise ValueError("context must be a [bs, L] device tensor, got {}".format(tuple(context.shape)))
+            context_dims = [int(context.shape[1])] + list(kwargs.get("context_fc_channels", [256])) + \
+                [n_modulator_params(base_channels, nds, mod_layers)]
         if self.params is None:
             in_ch = self.channel * (3 if getattr(self.args, "img_grad", False) else 1)      # GUNet.py:335-338
             specs = param_specs(in_ch, self.num_classes, g_ch, base_channels, nds, mod_layers,
-                                self.args.normalizer, norm_with_center, norm_with_scale, self.use_spatial_guide, nm)
+                                self.args.normalizer, norm_with_center, norm_with_scale, self.use_spatial_guide, nm,
+                                context_dims)
             self.params = ParamStore(specs, dev, bias_decay=getattr(self.args, "bias_decay", False))
             self.params.initialize(self._get_initializer()[0], seed=getattr(self.args, "seed", None))
         p = self.params
@@ -153,6 +180,21 @@ class GUNet(base.BaseNet):
                     if i < nds:
                         gs = ops.avgpool2_fwd(gs)
 
+            # context MLP (GUNet.py:31-60; slim_nets.py:34-57): ReLU fc + dropout per hidden layer, linear last layer
+            den_all, den_off = None, 0
+            if context_dims and context_dims[-1] > 0:
+                den_all = self._inputs["context"].to(torch.float32).contiguous()
+                training = self.mode == ModeKeys.TRAIN
+                keep = 1.0 - self.side_dropout if (self.side_dropout and training) else None
+                self._dropout_calls = getattr(self, "_dropout_calls", 0) + 1
+                for li in range(1, len(context_dims)):
+                    last = li == len(context_dims) - 1
+                    seed = (int(getattr(self.args, "seed", None) or 1234) * 1000003 + self._dropout_calls * 101 + li)
+                    den_all = ops.FullyConnected.apply(
+                        den_all, p["{}/context/fc{}/weights".format(nm, li)], p["{}/context/fc{}/biases".format(nm, li)],
+                        not last, None if last else keep, seed)
+                self._layers["context_params"] = den_all
+
             if getattr(self.args, "img_grad", False):
                 x = ops.image_gradients(images.to(torch.float32))
             else:
@@ -162,7 +204,8 @@ class GUNet(base.BaseNet):
             for i in range(nds + 1):
                 c = base_channels * 2 ** i
                 mod = i in guides
-                spec = self._spec(0.99) if mod else self._spec()           # GUNet.py:313-330 decay .99
+                dens = den_all is not None and i in mod_layers
+                spec = self._spec(0.99) if (mod or dens) else self._spec()  # GUNet.py:313-330 decay .99
                 for j in (1, 2):
                     scope = "{}/Encode/down_conv{}/mod_conv{}".format(nm, i + 1, j)
                     out = None
@@ -170,12 +213,16 @@ class GUNet(base.BaseNet):
                         cat = torch.empty((n, hh, ww, 2 * c), dtype=torch.float32, device=dev)
                         out = ops.alias(cat, 0, (n, hh, ww, c), cat.stride())
                         cats[i] = cat
+                    den = None
+                    if dens:                                                 # GUNet.py:203-206
+                        den = den_all[:, den_off:den_off + c]
+                        den_off += c
                     if mod:
                         gw = p["{}/spatial/conv{}/weights".format(nm, i + 1)].view(g_ch, 2 * c)[:, (j - 1) * c:j * c]
                         gb = p["{}/spatial/conv{}/biases".format(nm, i + 1)][(j - 1) * c:j * c]
-                        x = self._unit(x, scope, spec, out, guides[i], gw, gb)
+                        x = self._unit(x, scope, spec, out, guides[i], gw, gb, den)
                     else:
-                        x = self._unit(x, scope, spec, out)
+                        x = self._unit(x, scope, spec, out, den=den)
                 if i < nds:
                     skips[i] = x
                     x = ops.MaxPool2x2.apply(x)

@@ -106,6 +106,14 @@ class ParamStore(object):
                 else:
                     raise ValueError("Not supported weight initializer: " + str(weight_init))
                 t.copy_(v.to(torch.float32))
+            elif kind == "fc_w":        # slim.fully_connected default: Glorot uniform, [in, out], no regulariser
+                limit = (6.0 / (shape[0] + shape[1])) ** 0.5
+                t.copy_(((torch.rand(shape, generator=gen, dtype=torch.float64) * 2 - 1) * limit).to(torch.float32))
+            elif kind == "fc_w_he":     # tf.keras.initializers.he_normal: truncated normal, var 2/fan_in (GUNet.py:59)
+                std = (2.0 / shape[0]) ** 0.5 / 0.87962566103423978
+                v = torch.empty(shape, dtype=torch.float64)
+                torch.nn.init.trunc_normal_(v, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=gen)
+                t.copy_(v.to(torch.float32))
             elif kind in ("gamma", "moving_var"):
                 t.fill_(1.0)
             else:

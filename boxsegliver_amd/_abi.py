@@ -12,6 +12,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 _LIB = None
 LIB_PATH = os.environ.get("UNETK_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libunetk.so")
 
+ABI_VERSION = 3            # must equal unetk_abi_version() of the loaded library (checked in lib())
 UNETK_MAX_CLASSES = 8
 W_NONE, W_NUMERICAL, W_PROPORTION, W_PIXELMAP = 0, 1, 2, 3
 
@@ -77,9 +78,12 @@ _SIGNATURES = {
     "unetk_norm_finalize_ws_bytes": (c_size_t, [POINTER(NormDesc), c_int]),
     "unetk_norm_finalize": (c_int, [POINTER(NormDesc), P, c_int, P, P, c_float, c_float, c_int, P, P, P, P, P, P,
                                     P, c_size_t, P]),
-    "unetk_norm_apply_relu": (c_int, [POINTER(NormDesc), P, P, P, P, P, P, P, P]),
+    "unetk_norm_apply_relu": (c_int, [POINTER(NormDesc), P, P, P, P, P, P, P, P, P]),
     "unetk_norm_bwd_ws_bytes": (c_size_t, [POINTER(NormDesc)]),
-    "unetk_norm_relu_bwd": (c_int, [POINTER(NormDesc), P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
+    "unetk_norm_relu_bwd": (c_int, [POINTER(NormDesc), P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
+                                    c_size_t, P]),
+    "unetk_fc_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, P]),
+    "unetk_fc_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "unetk_maxpool2_fwd": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, P]),
     "unetk_maxpool2_bwd": (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
     "unetk_avgpool2_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
@@ -131,6 +135,9 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        if handle.unetk_abi_version() != ABI_VERSION:
+            raise UnetkError("{} has ABI version {}, this package binds version {} -- rebuild it".format(
+                LIB_PATH, handle.unetk_abi_version(), ABI_VERSION))
         _LIB = handle
     return _LIB
 

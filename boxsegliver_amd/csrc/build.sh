@@ -8,7 +8,7 @@ mkdir -p "$OUT" "$ROOT/build"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function"
 objs=()
-for src in conv_igemm conv_igemm_lin conv_igemm_bf16 conv_wgrad conv3d deconv norm reduce pool head weights lits optim; do
+for src in conv_igemm conv_igemm_lin conv_igemm_bf16 conv_wgrad conv3d deconv norm reduce pool head weights lits fc optim; do
   o="$ROOT/build/$src.o"
   if [[ ! -f "$o" || "$HERE/$src.hip" -nt "$o" || "$HERE/common.h" -nt "$o" || "$ROOT/include/unetk.h" -nt "$o" ]]; then
     "$HIPCC" $FLAGS -c "$HERE/$src.hip" -o "$o" &

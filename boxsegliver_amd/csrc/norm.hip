@@ -5,13 +5,18 @@
 //                       training: batch mean + biased variance, unbiased variance into the moving average)
 //   slim.instance_norm (base.py:163-165: eps 1e-6, moments over the spatial axes per (n, c))
 //   optional centre / scale (GUNet.yml: norm_with_center true, norm_with_scale false, GUNet.py:313-330)
+//   GUNet's density modulation  net * den[b, c]  (`conditional_normalization`, GUNet.py:119-133,203-206; den = a slice of
+//     the context MLP's output) -- template flag D
 //   GUNet's spatial modulation  net + sp_params[..., slice]  (GUNet.py:207-212) where sp_params is the
 //     1x1 conv of the pooled guide (GUNet.py:154-156): computed on the fly, never materialised
 //   ReLU
+// i.e.  t = (y - mean) rstd gamma + beta,  u = t * den[b,c] + guide . gw + gb,  z = relu(u).
 // The conv epilogue already produced per-tile sum / sum-of-squares partials, so the forward is one tiny
 // finalise + ONE read-modify-write pass; the backward is two passes over (y, dz).
 //
-// One descriptor drives all of them: statistics groups Ns = per_sample ? N : 1, each over P pixels.
+// One descriptor drives all of them.  STATISTICS groups: Ns = per_sample ? N : 1, each over P_stat pixels.  LAUNCH
+// groups (blockIdx.y): L = N when the pass needs the sample index (instance norm, or density modulation under batch
+// norm), else 1; a launch group indexes the statistics with stride sst (C or 0).
 #include "common.h"
 
 namespace {
@@ -20,14 +25,20 @@ constexpr int MAXG = 4;   // guide channels
 
 struct NormGeom {
   int Ns;        // statistic groups (1 for batch norm, N for instance norm)
-  int64_t P;     // pixels per group
+  int64_t Ps;    // pixels per statistic group
+  int L;         // launch groups
+  int64_t P;     // pixels per launch group
+  int sst;       // statistics stride of a launch group (C or 0)
   int C, cq_n, rpi;
 };
 
-NormGeom geom(const unetk_norm_desc* d) {
+NormGeom geom(const unetk_norm_desc* d, bool density) {
   NormGeom g;
   g.Ns = d->per_sample ? d->N : 1;
-  g.P = d->per_sample ? (int64_t)d->HW : (int64_t)d->N * d->HW;
+  g.Ps = d->per_sample ? (int64_t)d->HW : (int64_t)d->N * d->HW;
+  g.L = (d->per_sample || density) ? d->N : 1;
+  g.P = g.L > 1 ? (int64_t)d->HW : (int64_t)d->N * d->HW;
+  g.sst = d->per_sample ? d->C : 0;
   g.C = d->C;
   const ColMap m = unetk_colmap(d->C);
   g.cq_n = m.cq_n;
@@ -75,26 +86,34 @@ struct ApplyArgs {
   const float* y;
   const float* scale;   // [Ns][C]
   const float* shift;
+  const float* den;     // [N][C] or null
   const float* guide;   // [N*HW][G] or null
   const float* gw;      // [G][gw_stride], columns gw_coff ..
   const float* gb;      // [gw_stride]
   float* z;
   int64_t P;
-  int C, zs, cq_n, rpi, gw_stride, gw_coff;
+  int C, zs, cq_n, rpi, gw_stride, gw_coff, sst;
 };
 
-// z = relu(y*scale + shift [+ guide . gw + gb])
-template <int G>
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// z = relu((y*scale + shift) [* den] [+ guide . gw + gb])
+template <int G, bool D>
 __global__ __launch_bounds__(256) void norm_apply_relu_kernel(ApplyArgs a) {
   const int cq = threadIdx.x % a.cq_n, rl = threadIdx.x / a.cq_n;
   if (rl >= a.rpi) return;
   const int n = blockIdx.y;
-  const float4 sc = ldg4(a.scale + (int64_t)n * a.C + cq * 4);
-  float4 sh = ldg4(a.shift + (int64_t)n * a.C + cq * 4);
+  float4 sc = ldg4(a.scale + (int64_t)n * a.sst + cq * 4);
+  float4 sh = ldg4(a.shift + (int64_t)n * a.sst + cq * 4);
+  if (D) {
+    const float4 dn = ldg4(a.den + (int64_t)n * a.C + cq * 4);
+    sc = mul4(sc, dn);
+    sh = mul4(sh, dn);
+  }
   float4 gwv[G > 0 ? G : 1];
   if (G > 0) {
-    const float4 gbv = ldg4(a.gb + a.gw_coff + cq * 4);
-    sh.x += gbv.x; sh.y += gbv.y; sh.z += gbv.z; sh.w += gbv.w;
+    sh = add4(sh, ldg4(a.gb + a.gw_coff + cq * 4));
 #pragma unroll
     for (int g = 0; g < G; ++g) gwv[g] = ldg4(a.gw + (int64_t)g * a.gw_stride + a.gw_coff + cq * 4);
   }
@@ -120,20 +139,24 @@ struct BwdArgs {
   const float* shift;
   const float* mean;
   const float* rstd;
+  const float* den;     // [N][C] or null
   const float* guide;
   const float* gw;
   const float* gb;
-  const float* sums;    // [K][Ns][C]   (apply pass)
-  float* partial;       // [K][Ns][nblk][C] (reduce pass)
+  const float* ksum;    // apply pass: k = 0 row at ksum + n*kst, k = 1 row at ksum + krow + n*kst
+  float* partial;       // [K][L][nblk][C] (reduce pass)
   float* dy;
   int64_t P;
-  int C, dzs, cq_n, rpi, gw_stride, gw_coff, Ns, plain;
+  float inv_ps;         // 1 / pixels per STATISTICS group
+  int C, dzs, cq_n, rpi, gw_stride, gw_coff, L, plain, sst, kst, krow;
 };
 
-// pass 1: partial[0] = sum du, partial[1] = sum du*xhat, partial[2+g] = sum du*guide_g   (du = dz * (u > 0))
-template <int G>
+// pass 1.  With dt = du * den (dt = du without density), du = dz * (u > 0), xhat = (y - mean) rstd, t = y*scale + shift:
+//   partial[0] = sum dt, partial[1] = sum dt*xhat, partial[2+g] = sum du*guide_g,
+//   D only: partial[2+G] = sum du (guide bias gradient), partial[3+G] = sum du*t (density gradient, per sample)
+template <int G, bool D>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
-  constexpr int K = 2 + G;
+  constexpr int K = 2 + G + (D ? 2 : 0);
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [K][rpi][C]
   const int cq = threadIdx.x % a.cq_n, rl = threadIdx.x / a.cq_n;
   const int n = blockIdx.y;
@@ -141,13 +164,15 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
 #pragma unroll
   for (int k = 0; k < K; ++k) s[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (rl < a.rpi) {
-    const int64_t so = (int64_t)n * a.C + cq * 4;
-    const float4 mu = ldg4(a.mean + so), rs = ldg4(a.rstd + so), sc = ldg4(a.scale + so);
-    float4 sh = ldg4(a.shift + so);
+    const int64_t so = (int64_t)n * a.sst + cq * 4;
+    const float4 mu = ldg4(a.mean + so), rs = ldg4(a.rstd + so), sc0 = ldg4(a.scale + so), sh0 = ldg4(a.shift + so);
+    float4 dn = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (D) dn = ldg4(a.den + (int64_t)n * a.C + cq * 4);
+    const float4 sc = D ? mul4(sc0, dn) : sc0;
+    float4 sh = D ? mul4(sh0, dn) : sh0;
     float4 gwv[G > 0 ? G : 1];
     if (G > 0) {
-      const float4 gbv = ldg4(a.gb + a.gw_coff + cq * 4);
-      sh.x += gbv.x; sh.y += gbv.y; sh.z += gbv.z; sh.w += gbv.w;
+      sh = add4(sh, ldg4(a.gb + a.gw_coff + cq * 4));
 #pragma unroll
       for (int g = 0; g < G; ++g) gwv[g] = ldg4(a.gw + (int64_t)g * a.gw_stride + a.gw_coff + cq * 4);
     }
@@ -163,12 +188,17 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
         gg[g] = a.guide[(base + pix) * G + g];
         u.x = fmaf(gg[g], gwv[g].x, u.x); u.y = fmaf(gg[g], gwv[g].y, u.y); u.z = fmaf(gg[g], gwv[g].z, u.z); u.w = fmaf(gg[g], gwv[g].w, u.w);
       }
-#define NBR(f)                                       \
-  {                                                  \
-    const float du = u.f > 0.f ? d.f : 0.f;          \
-    s[0].f += du;                                    \
-    s[1].f += du * ((v.f - mu.f) * rs.f);            \
-    _Pragma("unroll") for (int g = 0; g < G; ++g) s[2 + g].f += du * gg[g]; \
+#define NBR(f)                                                                \
+  {                                                                           \
+    const float du = u.f > 0.f ? d.f : 0.f;                                   \
+    const float dt = D ? du * dn.f : du;                                      \
+    s[0].f += dt;                                                             \
+    s[1].f += dt * ((v.f - mu.f) * rs.f);                                     \
+    _Pragma("unroll") for (int g = 0; g < G; ++g) s[2 + g].f += du * gg[g];  \
+    if (D) {                                                                  \
+      s[2 + G].f += du;                                                       \
+      s[3 + G].f += du * fmaf(v.f, sc0.f, sh0.f);                             \
+    }                                                                         \
   }
       NBR(x) NBR(y) NBR(z) NBR(w)
 #undef NBR
@@ -181,31 +211,32 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
     const int k = i / a.C, c = i - k * a.C;
     float t = 0.f;
     for (int j = 0; j < a.rpi; ++j) t += smem[(k * a.rpi + j) * a.C + c];
-    a.partial[(((int64_t)k * a.Ns + n) * gridDim.x + blockIdx.x) * a.C + c] = t;
+    a.partial[(((int64_t)k * a.L + n) * gridDim.x + blockIdx.x) * a.C + c] = t;
   }
 }
 
-// pass 2: dy = scale * (du - sum_du/P - xhat * sum_du_xhat/P)
-template <int G>
+// pass 2: dy = scale * (dt - sum_dt/Ps - xhat * sum_dt_xhat/Ps)   (sums over the STATISTICS group)
+template <int G, bool D>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdArgs a) {
   const int cq = threadIdx.x % a.cq_n, rl = threadIdx.x / a.cq_n;
   if (rl >= a.rpi) return;
   const int n = blockIdx.y;
-  const float inv_p = 1.0f / (float)a.P;
-  const int64_t so = (int64_t)n * a.C + cq * 4;
-  const float4 mu = ldg4(a.mean + so), rs = ldg4(a.rstd + so), sc = ldg4(a.scale + so);
-  float4 sh = ldg4(a.shift + so);
+  const int64_t so = (int64_t)n * a.sst + cq * 4;
+  const float4 mu = ldg4(a.mean + so), rs = ldg4(a.rstd + so), sc0 = ldg4(a.scale + so), sh0 = ldg4(a.shift + so);
+  float4 dn = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (D) dn = ldg4(a.den + (int64_t)n * a.C + cq * 4);
+  const float4 sc = D ? mul4(sc0, dn) : sc0;
+  float4 sh = D ? mul4(sh0, dn) : sh0;
   float4 gwv[G > 0 ? G : 1];
   if (G > 0) {
-    const float4 gbv = ldg4(a.gb + a.gw_coff + cq * 4);
-    sh.x += gbv.x; sh.y += gbv.y; sh.z += gbv.z; sh.w += gbv.w;
+    sh = add4(sh, ldg4(a.gb + a.gw_coff + cq * 4));
 #pragma unroll
     for (int g = 0; g < G; ++g) gwv[g] = ldg4(a.gw + (int64_t)g * a.gw_stride + a.gw_coff + cq * 4);
   }
-  float4 k1 = ldg4(a.sums + so), k2 = ldg4(a.sums + (int64_t)a.Ns * a.C + so);
-  k1.x *= inv_p; k1.y *= inv_p; k1.z *= inv_p; k1.w *= inv_p;
-  k2.x *= inv_p; k2.y *= inv_p; k2.z *= inv_p; k2.w *= inv_p;
-  if (a.plain) {   // no normalisation (--without_norm): dy = du * scale
+  float4 k1 = ldg4(a.ksum + (int64_t)n * a.kst + cq * 4), k2 = ldg4(a.ksum + a.krow + (int64_t)n * a.kst + cq * 4);
+  k1.x *= a.inv_ps; k1.y *= a.inv_ps; k1.z *= a.inv_ps; k1.w *= a.inv_ps;
+  k2.x *= a.inv_ps; k2.y *= a.inv_ps; k2.z *= a.inv_ps; k2.w *= a.inv_ps;
+  if (a.plain) {   // no normalisation (--without_norm): dy = dt * scale
     k1 = make_float4(0.f, 0.f, 0.f, 0.f);
     k2 = k1;
   }
@@ -223,8 +254,9 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdArgs a) {
 #define NBA(f)                                          \
   {                                                     \
     const float du = u.f > 0.f ? d.f : 0.f;             \
+    const float dt = D ? du * dn.f : du;                \
     const float xh = (v.f - mu.f) * rs.f;               \
-    o.f = sc.f * (du - k1.f - xh * k2.f);               \
+    o.f = sc0.f * (dt - k1.f - xh * k2.f);              \
   }
     NBA(x) NBA(y) NBA(z) NBA(w)
 #undef NBA
@@ -232,14 +264,14 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdArgs a) {
   }
 }
 
-// parameter gradients from psum[k][c] = sum over statistic groups of sums[k][g][c]
-__global__ void norm_bwd_params_kernel(const float* __restrict__ psum, int C, int G, float* __restrict__ dgamma,
+// parameter gradients from psum[k][c] = sum over launch groups of sums[k][l][c]
+__global__ void norm_bwd_params_kernel(const float* __restrict__ psum, int C, int G, int density, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ dgw, float* __restrict__ dgb) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   if (dbeta) dbeta[c] = psum[c];
   if (dgamma) dgamma[c] = psum[C + c];
-  if (dgb) dgb[c] = psum[c];
+  if (dgb) dgb[c] = density ? psum[(int64_t)(2 + G) * C + c] : psum[c];
   for (int g = 0; g < G; ++g) dgw[(int64_t)g * C + c] = psum[(int64_t)(2 + g) * C + c];
 }
 
@@ -250,7 +282,7 @@ bool norm_supported(const unetk_norm_desc* d) { return d->C % 4 == 0 && d->C <= 
 
 int bwd_blocks(const NormGeom& g) {
   int64_t b = (g.P + g.rpi - 1) / g.rpi;
-  const int64_t cap = g.Ns > 1 ? 64 : UNETK_COL_BLOCKS;
+  const int64_t cap = g.L > 1 ? 64 : UNETK_COL_BLOCKS;
   if (b > cap) b = cap;
   return (int)b;
 }
@@ -263,12 +295,15 @@ int bwd_blocks(const NormGeom& g) {
     case 3: { constexpr int GG = 3; CALL; } break; \
     default: { constexpr int GG = 4; CALL; } break; \
   }
+#define GD_DISPATCH(G_, D_, KERN, ...)                                                  \
+  if (D_) { G_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, true>), __VA_ARGS__)); }         \
+  else { G_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, false>), __VA_ARGS__)); }
 
 }  // namespace
 
 extern "C" size_t unetk_norm_finalize_ws_bytes(const unetk_norm_desc* d, int stat_rows) {
   if (!norm_desc_ok(d) || stat_rows <= 0) return 0;
-  const NormGeom g = geom(d);
+  const NormGeom g = geom(d, false);
   const int rows_per_group = stat_rows / g.Ns;
   return (2 * (size_t)g.Ns * d->C + unetk_rows_reduce_tmp_floats(2 * g.Ns, rows_per_group, d->C)) * sizeof(float);
 }
@@ -279,7 +314,7 @@ extern "C" int unetk_norm_finalize(const unetk_norm_desc* d, const float* stat_p
                                    float* scale_out, float* shift_out, void* ws, size_t ws_bytes, void* stream) {
   UNETK_REQUIRE(norm_desc_ok(d) && mean_out && rstd_out && scale_out && shift_out);
   hipStream_t st = (hipStream_t)stream;
-  const NormGeom g = geom(d);
+  const NormGeom g = geom(d, false);
   const int use_moving = (!d->per_sample && !training) ? 1 : 0;
   float* sums = nullptr;
   if (!use_moving) {
@@ -294,7 +329,7 @@ extern "C" int unetk_norm_finalize(const unetk_norm_desc* d, const float* stat_p
   }
   const int update_moving = (!d->per_sample && training && moving_mean && moving_var) ? 1 : 0;
   const int total = g.Ns * d->C;
-  hipLaunchKernelGGL(norm_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sums, g.Ns, d->C, (double)g.P,
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sums, g.Ns, d->C, (double)g.Ps,
                      gamma, beta, eps, decay, use_moving, update_moving, moving_mean, moving_var, mean_out, rstd_out,
                      scale_out, shift_out);
   UNETK_LAUNCH_CHECK();
@@ -302,76 +337,96 @@ extern "C" int unetk_norm_finalize(const unetk_norm_desc* d, const float* stat_p
 }
 
 extern "C" int unetk_norm_apply_relu(const unetk_norm_desc* d, const float* y, const float* scale, const float* shift,
-                                     const float* guide, const float* gw, const float* gb, float* z, void* stream) {
+                                     const float* den, const float* guide, const float* gw, const float* gb, float* z,
+                                     void* stream) {
   UNETK_REQUIRE(norm_desc_ok(d) && y && scale && shift && z && d->z_stride >= d->C);
   if (!norm_supported(d) || d->z_stride % 4 != 0) return UNETK_E_UNSUPPORTED;
   UNETK_REQUIRE(unetk_aligned16(y) && unetk_aligned16(z) && unetk_aligned16(scale) && unetk_aligned16(shift));
+  UNETK_REQUIRE(!den || unetk_aligned16(den));
   if (d->guide_ch > 0) {
     UNETK_REQUIRE(guide && gw && gb && d->gw_stride >= d->gw_coff + d->C);
     UNETK_REQUIRE(d->gw_stride % 4 == 0 && d->gw_coff % 4 == 0 && unetk_aligned16(gw) && unetk_aligned16(gb));
   }
-  const NormGeom g = geom(d);
-  ApplyArgs a{y, scale, shift, guide, gw, gb, z, g.P, d->C, d->z_stride, g.cq_n, g.rpi, d->gw_stride, d->gw_coff};
+  const NormGeom g = geom(d, den != nullptr);
+  ApplyArgs a{y, scale, shift, den, guide, gw, gb, z, g.P, d->C, d->z_stride, g.cq_n, g.rpi, d->gw_stride, d->gw_coff, g.sst};
   int64_t gx = (g.P + g.rpi - 1) / g.rpi;
-  const int64_t cap = g.Ns > 1 ? (4096 + g.Ns - 1) / g.Ns : 4096;
+  const int64_t cap = g.L > 1 ? (4096 + g.L - 1) / g.L : 4096;
   if (gx > cap) gx = cap;
-  G_DISPATCH(d->guide_ch, hipLaunchKernelGGL(norm_apply_relu_kernel<GG>, dim3((int)gx, g.Ns), dim3(256), 0,
-                                             (hipStream_t)stream, a));
+  GD_DISPATCH(d->guide_ch, den != nullptr, norm_apply_relu_kernel, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, a);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
 
 extern "C" size_t unetk_norm_bwd_ws_bytes(const unetk_norm_desc* d) {
   if (!norm_desc_ok(d) || !norm_supported(d)) return 0;
-  const NormGeom g = geom(d);
-  const int K = 2 + d->guide_ch;
-  const int nblk = bwd_blocks(g);
-  size_t f = (size_t)K * g.Ns * nblk * d->C;                         // partials
-  f += (size_t)K * g.Ns * d->C;                                      // sums per group
+  // sized for the density variant (K + 2 rows, N launch groups): a superset of every other case
+  const NormGeom g = geom(d, true);
+  const int K = 4 + d->guide_ch;
+  NormGeom g1 = geom(d, false);
+  int nblk = bwd_blocks(g);
+  const int nblk1 = bwd_blocks(g1);
+  size_t f = (size_t)K * ((size_t)g.L * nblk > (size_t)g1.L * nblk1 ? (size_t)g.L * nblk : (size_t)g1.L * nblk1) * d->C;
+  f += (size_t)K * g.L * d->C;                                       // sums per launch group
   f += (size_t)K * d->C;                                             // sums over groups
-  f += unetk_rows_reduce_tmp_floats(K * g.Ns, nblk, d->C);
-  f += unetk_rows_reduce_tmp_floats(K, g.Ns, d->C);
+  if (nblk1 > nblk) nblk = nblk1;
+  f += unetk_rows_reduce_tmp_floats(K * g.L, nblk, d->C);
+  f += unetk_rows_reduce_tmp_floats(K, g.L, d->C);
   return f * sizeof(float);
 }
 
 extern "C" int unetk_norm_relu_bwd(const unetk_norm_desc* d, const float* y, const float* dz, int dz_stride,
                                    const float* scale, const float* shift, const float* mean, const float* rstd,
-                                   const float* guide, const float* gw, const float* gb, float* dy, float* dgamma,
-                                   float* dbeta, float* dgw, float* dgb, void* ws, size_t ws_bytes, void* stream) {
+                                   const float* den, const float* guide, const float* gw, const float* gb, float* dy,
+                                   float* dgamma, float* dbeta, float* dden, float* dgw, float* dgb, void* ws,
+                                   size_t ws_bytes, void* stream) {
   UNETK_REQUIRE(norm_desc_ok(d) && y && dz && scale && shift && mean && rstd && dy && ws && dz_stride >= d->C);
   if (!norm_supported(d) || dz_stride % 4 != 0) return UNETK_E_UNSUPPORTED;
   UNETK_REQUIRE(unetk_aligned16(y) && unetk_aligned16(dz) && unetk_aligned16(dy) && unetk_aligned16(ws));
   const int G = d->guide_ch;
+  const bool D = den != nullptr;
+  UNETK_REQUIRE(!D || (dden && unetk_aligned16(den)));
   if (G > 0) {
     UNETK_REQUIRE(guide && gw && gb && dgw && dgb && d->gw_stride >= d->gw_coff + d->C);
     UNETK_REQUIRE(d->gw_stride % 4 == 0 && d->gw_coff % 4 == 0 && unetk_aligned16(gw) && unetk_aligned16(gb));
   }
   if (ws_bytes < unetk_norm_bwd_ws_bytes(d)) return UNETK_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  const NormGeom g = geom(d);
-  const int K = 2 + G;
+  const NormGeom g = geom(d, D);
+  const int K = 2 + G + (D ? 2 : 0);
   const int nblk = bwd_blocks(g);
   float* partial = (float*)ws;
-  float* sums = partial + (size_t)K * g.Ns * nblk * d->C;
-  float* psum = sums + (size_t)K * g.Ns * d->C;
+  float* sums = partial + (size_t)K * g.L * nblk * d->C;
+  float* psum = sums + (size_t)K * g.L * d->C;
   float* tmp1 = psum + (size_t)K * d->C;
-  float* tmp2 = tmp1 + unetk_rows_reduce_tmp_floats(K * g.Ns, nblk, d->C);
-  BwdArgs a{y, dz, scale, shift, mean, rstd, guide, gw, gb, sums, partial, dy, g.P, d->C, dz_stride, g.cq_n, g.rpi,
-            d->gw_stride, d->gw_coff, g.Ns, d->affine_only};
+  float* tmp2 = tmp1 + unetk_rows_reduce_tmp_floats(K * g.L, nblk, d->C);
+  BwdArgs a{};
+  a.y = y; a.dz = dz; a.scale = scale; a.shift = shift; a.mean = mean; a.rstd = rstd; a.den = den;
+  a.guide = guide; a.gw = gw; a.gb = gb; a.partial = partial; a.dy = dy;
+  a.P = g.P; a.inv_ps = 1.0f / (float)g.Ps; a.C = d->C; a.dzs = dz_stride; a.cq_n = g.cq_n; a.rpi = g.rpi;
+  a.gw_stride = d->gw_stride; a.gw_coff = d->gw_coff; a.L = g.L; a.plain = d->affine_only; a.sst = g.sst;
+  // the statistics sums of the dy formula: per launch group when the statistics are per sample, else the batch totals
+  if (d->per_sample) { a.ksum = sums; a.kst = d->C; a.krow = g.L * d->C; }
+  else if (g.L == 1) { a.ksum = sums; a.kst = 0; a.krow = d->C; }
+  else { a.ksum = psum; a.kst = 0; a.krow = d->C; }
   const size_t lds = (size_t)K * g.rpi * d->C * sizeof(float);
-  G_DISPATCH(G, hipLaunchKernelGGL(norm_bwd_reduce_kernel<GG>, dim3(nblk, g.Ns), dim3(256), lds, st, a));
+  GD_DISPATCH(G, D, norm_bwd_reduce_kernel, dim3(nblk, g.L), dim3(256), lds, st, a);
   UNETK_LAUNCH_CHECK();
-  int rc = unetk_rows_reduce(partial, K * g.Ns, nblk, d->C, sums, tmp1, st);   // -> sums[K][Ns][C]
+  int rc = unetk_rows_reduce(partial, K * g.L, nblk, d->C, sums, tmp1, st);   // -> sums[K][L][C]
   if (rc != UNETK_OK) return rc;
-  rc = unetk_rows_reduce(sums, K, g.Ns, d->C, psum, tmp2, st);                 // -> psum[K][C]
+  rc = unetk_rows_reduce(sums, K, g.L, d->C, psum, tmp2, st);                 // -> psum[K][C]
   if (rc != UNETK_OK) return rc;
-  hipLaunchKernelGGL(norm_bwd_params_kernel, dim3((d->C + 255) / 256), dim3(256), 0, st, psum, d->C, G, dgamma, dbeta,
-                     dgw, dgb);
+  hipLaunchKernelGGL(norm_bwd_params_kernel, dim3((d->C + 255) / 256), dim3(256), 0, st, psum, d->C, G, D ? 1 : 0, dgamma,
+                     dbeta, dgw, dgb);
   UNETK_LAUNCH_CHECK();
+  if (D) {   // density gradient: the per-sample row sum du * t
+    hipError_t e = hipMemcpyAsync(dden, sums + (size_t)(3 + G) * g.L * d->C, (size_t)d->N * d->C * sizeof(float),
+                                  hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return (int)e;
+  }
   int64_t gx = (g.P + g.rpi - 1) / g.rpi;
-  const int64_t cap = g.Ns > 1 ? (4096 + g.Ns - 1) / g.Ns : 4096;
+  const int64_t cap = g.L > 1 ? (4096 + g.L - 1) / g.L : 4096;
   if (gx > cap) gx = cap;
-  G_DISPATCH(G, hipLaunchKernelGGL(norm_bwd_apply_kernel<GG>, dim3((int)gx, g.Ns), dim3(256), 0, st, a));
+  GD_DISPATCH(G, D, norm_bwd_apply_kernel, dim3((int)gx, g.L), dim3(256), 0, st, a);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }

@@ -111,7 +111,7 @@ extern "C" int unetk_sumsq(const float* p, int64_t n, float* out, void* ws, size
   return UNETK_OK;
 }
 
-extern "C" int unetk_abi_version(void) { return 2; }   // 2: unetk_conv_desc.precision, UNETK_BF16
+extern "C" int unetk_abi_version(void) { return 3; }   // 2: unetk_conv_desc.precision, UNETK_BF16; 3: density modulation, unetk_fc_*
 
 extern "C" const char* unetk_error_string(int code) {
   switch (code) {

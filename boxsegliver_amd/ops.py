@@ -275,16 +275,19 @@ def norm_finalize(d, stats, rows, gamma, beta, eps, decay, training, moving_mean
     return out
 
 
-def norm_apply_relu(d, y, aff, z, guide=None, gw=None, gb=None):
+def norm_apply_relu(d, y, aff, z, guide=None, gw=None, gb=None, den=None):
     assert y.is_contiguous()
-    check(_abi.lib().unetk_norm_apply_relu(ctypes.byref(d), ptr(y), ptr(aff[2]), ptr(aff[3]), ptr(guide), ptr(gw),
-                                           ptr(gb), ptr(z), stream_ptr()), "norm_apply_relu")
+    if den is not None:
+        assert den.is_contiguous() and tuple(den.shape) == (d.N, d.C), (tuple(den.shape), d.N, d.C)
+    check(_abi.lib().unetk_norm_apply_relu(ctypes.byref(d), ptr(y), ptr(aff[2]), ptr(aff[3]), ptr(den), ptr(guide),
+                                           ptr(gw), ptr(gb), ptr(z), stream_ptr()), "norm_apply_relu")
     return z
 
 
-def norm_relu_bwd(d, y, dz, aff, has_gamma, has_beta, guide=None, gw=None, gb=None):
+def norm_relu_bwd(d, y, dz, aff, has_gamma, has_beta, guide=None, gw=None, gb=None, den=None):
     dev = y.device
     dy = torch.empty_like(y)
+    dden = torch.empty_like(den) if den is not None else None
     dgamma = torch.empty((d.C,), dtype=torch.float32, device=dev) if has_gamma else None
     dbeta = torch.empty((d.C,), dtype=torch.float32, device=dev) if has_beta else None
     dgw = torch.empty((d.guide_ch, d.C), dtype=torch.float32, device=dev) if d.guide_ch else None
@@ -294,9 +297,12 @@ def norm_relu_bwd(d, y, dz, aff, has_gamma, has_beta, guide=None, gw=None, gb=No
         raise _abi.UnetkError("norm_relu_bwd: unsupported channel count {}".format(d.C))
     ws = WORKSPACE.get(nbytes, dev)
     check(_abi.lib().unetk_norm_relu_bwd(ctypes.byref(d), ptr(y), ptr(dz), _pix_stride_nd(dz), ptr(aff[2]), ptr(aff[3]),
-                                         ptr(aff[0]), ptr(aff[1]), ptr(guide), ptr(gw), ptr(gb), ptr(dy), ptr(dgamma),
-                                         ptr(dbeta), ptr(dgw), ptr(dgb), ptr(ws), nbytes, stream_ptr()),
+                                         ptr(aff[0]), ptr(aff[1]), ptr(den), ptr(guide), ptr(gw), ptr(gb), ptr(dy),
+                                         ptr(dgamma), ptr(dbeta), ptr(dden), ptr(dgw), ptr(dgb), ptr(ws), nbytes,
+                                         stream_ptr()),
           "norm_relu_bwd")
+    if den is not None:
+        return dy, dgamma, dbeta, dgw, dgb, dden
     return dy, dgamma, dbeta, dgw, dgb
 
 
@@ -560,9 +566,11 @@ class Conv3x3NormRelu(torch.autograd.Function):
     ReLU (NetworksV2/UNet.py:41-56,79; GUNet.py:162-217 `modulated_conv_block`)."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, moving_mean, moving_var, spec, out, guide, gw, gb):
+    def forward(ctx, x, w, gamma, beta, moving_mean, moving_var, spec, out, guide, gw, gb, den=None):
         _require_cuda(x, w)
         cin, cout = w.shape[2], w.shape[3]
+        if den is not None:
+            den = den.contiguous()
         mfma = conv_uses_mfma(cin, cout)
         bf16 = bool(getattr(spec, "bf16", False)) and conv_uses_bf16(cin, cout)
         need_dx = ctx.needs_input_grad[0]
@@ -590,9 +598,9 @@ class Conv3x3NormRelu(torch.autograd.Function):
         else:
             aff = norm_finalize(d, stats, rows, gamma, beta, spec.eps, spec.decay, spec.training, moving_mean,
                                 moving_var, y.device)
-        norm_apply_relu(d, y, aff, z, guide, gw, gb)
+        norm_apply_relu(d, y, aff, z, guide, gw, gb, den)
         if spec.training:
-            ctx.save_for_backward(x, y, aff, guide, gw, gb)
+            ctx.save_for_backward(x, y, aff, guide, gw, gb, den)
             ctx.wp_d = wp_d
             ctx.need_dx = need_dx
             ctx.bf16 = bf16
@@ -604,17 +612,60 @@ class Conv3x3NormRelu(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz):
-        x, y, aff, guide, gw, gb = ctx.saved_tensors
+        x, y, aff, guide, gw, gb, den = ctx.saved_tensors
         if dz.stride(3) != 1:
             dz = dz.contiguous()
-        dy, dgamma, dbeta, dgw, dgb = norm_relu_bwd(ctx.desc, y, dz, aff, ctx.has[0], ctx.has[1], guide, gw, gb)
+        dden = None
+        if den is None:
+            dy, dgamma, dbeta, dgw, dgb = norm_relu_bwd(ctx.desc, y, dz, aff, ctx.has[0], ctx.has[1], guide, gw, gb)
+        else:
+            dy, dgamma, dbeta, dgw, dgb, dden = norm_relu_bwd(ctx.desc, y, dz, aff, ctx.has[0], ctx.has[1], guide, gw, gb,
+                                                              den)
         dw = conv3x3_wgrad(x, dy, bf16=ctx.bf16)
         dx = conv3x3_dgrad(dy, ctx.wp_d, x.shape[3], bf16=ctx.bf16) if ctx.need_dx else None
         if DEBUG_CAPTURE is not None:
             DEBUG_CAPTURE.append(dict(x=x, y=y, gamma=ctx.gb_dbg[0], beta=ctx.gb_dbg[1], aff=aff, dz=dz, dy=dy, dw=dw,
                                       dx=dx, dgamma=dgamma, dbeta=dbeta, w=ctx.w_dbg, guide=guide, gw=gw, gb=gb,
-                                      dgw=dgw, dgb=dgb, per_sample=bool(ctx.desc.per_sample), bf16=ctx.bf16))
-        return dx, dw, dgamma, dbeta, None, None, None, None, None, dgw, dgb
+                                      dgw=dgw, dgb=dgb, per_sample=bool(ctx.desc.per_sample), bf16=ctx.bf16, den=den,
+                                      dden=dden))
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, dgw, dgb, dden
+
+
+class FullyConnected(torch.autograd.Function):
+    """y = dropout(act(x . w + b)) -- one slim.fully_connected (+ slim.dropout) of GUNet's context MLP
+    (NetworksV2/Backbone/slim_nets.py:43-56; GUNet.py:50-60).  w is TF's [in, out].  keep_prob None = no dropout;
+    the mask (0 or 1/keep_prob per element, counter RNG keyed by `seed`) is kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu, keep_prob, seed):
+        _require_cuda(x, w)
+        x = x.contiguous()
+        bsz, k = x.shape
+        n = w.shape[1]
+        assert w.shape[0] == k and w.is_contiguous()
+        y = torch.empty((bsz, n), dtype=torch.float32, device=x.device)
+        mask = torch.empty_like(y) if keep_prob is not None else None
+        check(_abi.lib().unetk_fc_fwd(ptr(x), ptr(w), ptr(b), ptr(y), ptr(mask), bsz, k, n, 1 if relu else 0,
+                                      float(keep_prob) if keep_prob is not None else 1.0, int(seed) & 0xFFFFFFFF,
+                                      stream_ptr()), "fc_fwd")
+        ctx.save_for_backward(x, w, y, mask)
+        ctx.relu = relu
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y, mask = ctx.saved_tensors
+        dy = dy.contiguous()
+        bsz, k = x.shape
+        n = w.shape[1]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        db = torch.empty((n,), dtype=torch.float32, device=x.device) if ctx.has_b else None
+        ws = torch.empty_like(y)
+        check(_abi.lib().unetk_fc_bwd(ptr(x), ptr(w), ptr(y), ptr(mask), ptr(dy), ptr(dx), ptr(dw), ptr(db), ptr(ws), bsz, k,
+                                      n, 1 if ctx.relu else 0, stream_ptr()), "fc_bwd")
+        return dx, dw, db, None, None, None
 
 
 class Conv3dNormRelu(torch.autograd.Function):

@@ -151,20 +151,34 @@ int unetk_norm_finalize(const unetk_norm_desc* d, const float* stat_partials, in
                         float* moving_mean, float* moving_var, float* mean_out, float* rstd_out,
                         float* scale_out, float* shift_out, void* ws, size_t ws_bytes, void* stream);
 
-/* z = relu(y*scale + shift [+ guide modulation]); z has pixel stride d->z_stride. */
+/* z = relu((y*scale + shift) [* den[n][c]] [+ guide modulation]); z has pixel stride d->z_stride.
+ * den (nullable, [N][C]) is GUNet's density modulation `conditional_normalization` (GUNet.py:119-133,203-206):
+ * the per-sample channel gains the context MLP (unetk_fc_*) produced. */
 int unetk_norm_apply_relu(const unetk_norm_desc* d, const float* y, const float* scale,
-                          const float* shift, const float* guide, const float* gw, const float* gb,
-                          float* z, void* stream);
+                          const float* shift, const float* den, const float* guide, const float* gw,
+                          const float* gb, float* z, void* stream);
 
-/* Backward of z = relu(norm(y) [+ modulation]).  Pass 1: per-group column sums of du and du*xhat
- * (du = dz * (z > 0)) [and du*guide_g]; pass 2: dy.  dz has pixel stride dz_stride.  Outputs (nullable
- * when the parameter does not exist): dgamma[C], dbeta[C], dgw[guide_ch][C], dgb[C]. */
+/* Backward of z = relu(norm(y) [* den] [+ modulation]).  Pass 1: per-group column sums of dt and dt*xhat
+ * (du = dz * (z > 0), dt = du * den) [and du*guide_g, du, du*t]; pass 2: dy.  dz has pixel stride dz_stride.
+ * Outputs (nullable when the parameter does not exist): dgamma[C], dbeta[C], dden[N][C] (required with den),
+ * dgw[guide_ch][C], dgb[C]. */
 size_t unetk_norm_bwd_ws_bytes(const unetk_norm_desc* d);
 int unetk_norm_relu_bwd(const unetk_norm_desc* d, const float* y, const float* dz, int dz_stride,
                         const float* scale, const float* shift, const float* mean, const float* rstd,
-                        const float* guide, const float* gw, const float* gb, float* dy,
-                        float* dgamma, float* dbeta, float* dgw, float* dgb, void* ws,
+                        const float* den, const float* guide, const float* gw, const float* gb, float* dy,
+                        float* dgamma, float* dbeta, float* dden, float* dgw, float* dgb, void* ws,
                         size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- GUNet's context MLP (GUNet.py:136-150 `_context_subnets`)
+ * slim.fully_connected(x, n): y[B][n] = act(x[B][k] . w[k][n] + b[n]), TF weight layout [in, out]; relu = 1 for the
+ * hidden layers, 0 for the last (activation_fn=None).  slim.dropout(keep_prob) in training: mask from a counter
+ * RNG keyed by (seed, element), kept entries scaled by 1/keep_prob; `mask` ([B][n] floats, 0 or 1/keep_prob,
+ * nullable = no dropout) is written by the forward and read by the backward.
+ * Backward: dx[B][k] (nullable), dw[k][n], db[n] from dy[B][n] (gated by y > 0 when relu, times the mask). */
+int unetk_fc_fwd(const float* x, const float* w, const float* b, float* y, float* mask, int B, int k, int n,
+                 int relu, float keep_prob, uint32_t seed, void* stream);
+int unetk_fc_bwd(const float* x, const float* w, const float* y, const float* mask, const float* dy, float* dx,
+                 float* dw, float* db, float* dpre_ws, int B, int k, int n, int relu, void* stream);
 
 /* ---------------------------------------------------------------- slim.max_pool2d(x, [2,2])  UNet.py:81
  * VALID, stride 2.  x [N,H,W,C] with pixel stride x_stride; p dense [N,H/2,W/2,C].

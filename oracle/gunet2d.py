@@ -1,4 +1,4 @@
-"""Guided U-Net (spatial-guide path) forward / loss / gradients with the reference's TF semantics.
+"""Guided U-Net (spatial-guide and context paths) forward / loss / gradients with the reference's TF semantics.
 
 TEST INFRASTRUCTURE ONLY -- PARITY UNPINNED (see oracle/__init__.py).
 
@@ -11,7 +11,12 @@ Follows /root/reference/NetworksV2/GUNet.py:
                                   BN decay .99 (:313-330); level 0 un-modulated with (scale=True | IN defaults)
                                   (:183-188); decoder = deconv(+bias, ReLU) -> concat(skip, up) -> 2 conv units
   _build_loss           :394-413  'xentropy' and/or 'dice' by substring, + regularisers
-The context (density) branch, SE and after_affine variants are not restated.
+  _context_subnets      :31-60    context_model "fc" = slim_nets.mlp (Backbone/slim_nets.py:34-57): ReLU fully_connected
+                                  (+ dropout) per hidden width, linear he_normal last layer -> [bs, n_modulator_param]
+  conditional_normalization :119-133,203-206  net * den[:, None, None, slice] after the norm, before the spatial add
+The dropout masks are an INPUT here (`drop_masks`: one [bs, width] tensor of 0 / 1/keep_prob per hidden layer):
+TF's own mask stream is not reproducible, so parity is on the arithmetic given the mask.
+SE, vgg context models, ct_conv and after_affine variants are not restated.
 """
 from collections import OrderedDict
 
@@ -23,7 +28,8 @@ from .unet2d import TRAINABLE_KINDS  # noqa: F401
 
 def param_specs(in_channels, num_classes, guide_channel=1, init_channels=64, num_down_samples=4,
                 mod_layers=(1, 2, 3, 4), normalizer="instance_norm", norm_with_center=True, norm_with_scale=False,
-                name="GUNet"):
+                name="GUNet", use_spatial=True, context_dims=None):
+    """context_dims = [context length, fc widths ..., n_modulator_param] enables the context branch."""
     specs = []
     bn = normalizer == "batch_norm"
     norm_scope = "BatchNorm" if bn else "InstanceNorm"
@@ -42,8 +48,14 @@ def param_specs(in_channels, num_classes, guide_channel=1, init_channels=64, num
             if specs[k][1] is None:
                 specs[k] = (specs[k][0], (c,), specs[k][2])
 
+    if context_dims:
+        for i in range(1, len(context_dims)):
+            last = i == len(context_dims) - 1
+            specs.append(("{}/context/fc{}/weights".format(name, i), (context_dims[i - 1], context_dims[i]),
+                          "fc_w_he" if last else "fc_w"))
+            specs.append(("{}/context/fc{}/biases".format(name, i), (context_dims[i],), "fc_b"))
     for i in range(num_down_samples + 1):
-        if i in mod_layers:
+        if use_spatial and i in mod_layers:
             c2 = 2 * init_channels * 2 ** i
             specs.append(("{}/spatial/conv{}/weights".format(name, i + 1), (1, 1, guide_channel, c2), "conv_w"))
             specs.append(("{}/spatial/conv{}/biases".format(name, i + 1), (c2,), "bias"))
@@ -54,7 +66,7 @@ def param_specs(in_channels, num_classes, guide_channel=1, init_channels=64, num
             scope = "{}/Encode/down_conv{}/mod_conv{}".format(name, i + 1, j)
             specs.append((scope + "/weights", (3, 3, cin, c), "conv_w"))
             start = len(specs)
-            if i in mod_layers:
+            if (use_spatial or context_dims) and i in mod_layers:
                 norm_vars(scope, norm_with_center, norm_with_scale)
             else:
                 norm_vars(scope, True, True)
@@ -80,17 +92,22 @@ def param_specs(in_channels, num_classes, guide_channel=1, init_channels=64, num
 class GUNet2DOracle(object):
     def __init__(self, in_channels, num_classes, guide_channel=1, init_channels=64, num_down_samples=4,
                  mod_layers=(1, 2, 3, 4), normalizer="instance_norm", norm_with_center=True, norm_with_scale=False,
-                 name="GUNet", img_grad=False):
+                 name="GUNet", img_grad=False, use_spatial=True, context_length=None, context_fc_channels=(256, 256)):
         self.name, self.num_classes = name, num_classes
+        self.use_spatial = use_spatial
+        self.context_dims = None
+        if context_length:                                             # GUNet.py:47-48
+            n_mod = init_channels * sum(2 ** i for i in range(num_down_samples + 1) if i in mod_layers) * 2
+            self.context_dims = [context_length] + list(context_fc_channels) + [n_mod]
         self.img_grad = img_grad                                       # GUNet.py:335-338
         self.init_channels, self.nds = init_channels, num_down_samples
         self.mod_layers = tuple(mod_layers)
         self.normalizer = normalizer
         self.specs = param_specs(in_channels, num_classes, guide_channel, init_channels, num_down_samples, mod_layers,
-                                 normalizer, norm_with_center, norm_with_scale, name)
+                                 normalizer, norm_with_center, norm_with_scale, name, use_spatial, self.context_dims)
         self.kinds = {n: k for n, _, k in self.specs}
 
-    def _unit(self, x, p, scope, is_training, new_stats, decay, sp=None):
+    def _unit(self, x, p, scope, is_training, new_stats, decay, sp=None, den=None):
         y = tf_ops.conv_nd_same(x, p[scope + "/weights"])
         if self.normalizer == "batch_norm":
             ns = scope + "/BatchNorm"
@@ -100,18 +117,35 @@ class GUNet2DOracle(object):
         else:
             ns = scope + "/InstanceNorm"
             y = tf_ops.instance_norm(y, p.get(ns + "/gamma"), p.get(ns + "/beta"), eps=1e-6)
+        if den is not None:                                            # conditional_normalization, GUNet.py:129-133
+            y = y * den[:, None, None, :]
         if sp is not None:
             y = y + sp
         return torch.relu(y)
 
-    def forward(self, p, images, sp_guide, is_training):
+    def context_params(self, p, context, drop_masks=None):
+        """slim_nets.mlp (slim_nets.py:43-56) as called from GUNet.py:51-60."""
+        net = context
+        dims = self.context_dims
+        for li in range(1, len(dims)):
+            net = net @ p["{}/context/fc{}/weights".format(self.name, li)] + p["{}/context/fc{}/biases".format(self.name, li)]
+            if li < len(dims) - 1:
+                net = torch.relu(net)
+                if drop_masks is not None:
+                    net = net * drop_masks[li - 1]
+        return net
+
+    def forward(self, p, images, sp_guide, is_training, context=None, drop_masks=None):
         n = self.name
         new_stats = OrderedDict()
+        den_all, den_off = None, 0
+        if self.context_dims:
+            den_all = self.context_params(p, context, drop_masks)
         # spatial subnets (GUNet.py:136-159)
         sp_params = {}
         gs = sp_guide
         for i in range(self.nds + 1):
-            if i in self.mod_layers:
+            if self.use_spatial and i in self.mod_layers:
                 w = p["{}/spatial/conv{}/weights".format(n, i + 1)]
                 sp_params[i] = gs @ w.reshape(w.shape[2], w.shape[3]) + p["{}/spatial/conv{}/biases".format(n, i + 1)]
             if i < self.nds:
@@ -120,11 +154,15 @@ class GUNet2DOracle(object):
         skips = []
         for i in range(self.nds + 1):
             c = self.init_channels * 2 ** i
-            mod = i in self.mod_layers
+            mod = i in self.mod_layers and (self.use_spatial or den_all is not None)
             for j in (1, 2):
                 scope = "{}/Encode/down_conv{}/mod_conv{}".format(n, i + 1, j)
-                sp = sp_params[i][..., (j - 1) * c:j * c] if mod else None
-                x = self._unit(x, p, scope, is_training, new_stats, 0.99 if mod else 0.999, sp)
+                sp = sp_params[i][..., (j - 1) * c:j * c] if (mod and self.use_spatial) else None
+                den = None
+                if mod and den_all is not None:
+                    den = den_all[:, den_off:den_off + c]
+                    den_off += c
+                x = self._unit(x, p, scope, is_training, new_stats, 0.99 if mod else 0.999, sp, den)
             if i < self.nds:
                 skips.append(x)
                 x = tf_ops.max_pool2x2(x)
@@ -148,8 +186,9 @@ class GUNet2DOracle(object):
         return total
 
     def loss(self, p, images, sp_guide, labels, loss_type="xentropy", loss_weight_type="none", numeric_w=None,
-             proportion_decay=None, weight_decay_rate=0.0, bias_decay=False, is_training=True):
-        logits, new_stats = self.forward(p, images, sp_guide, is_training)
+             proportion_decay=None, weight_decay_rate=0.0, bias_decay=False, is_training=True, context=None,
+             drop_masks=None):
+        logits, new_stats = self.forward(p, images, sp_guide, is_training, context, drop_masks)
         kw = {}
         if loss_weight_type == "numerical":
             kw["numeric_w"] = numeric_w

@@ -75,6 +75,13 @@ def init_params(specs, seed=1234, dtype=torch.float32):
             # slim conv2d_transpose: fan computed on [kh,kw,Cout,Cin] as fan_in=k*k*Cout, fan_out=k*k*Cin
             rf = shape[0] * shape[1]
             params[name] = tf_ops.xavier_uniform_(shape, rf * shape[2], rf * shape[3], gen, dtype)
+        elif kind == "fc_w":          # slim.fully_connected default (slim_nets.py:45): Glorot uniform on [in, out]
+            params[name] = tf_ops.xavier_uniform_(shape, shape[0], shape[1], gen, dtype)
+        elif kind == "fc_w_he":       # tf.keras.initializers.he_normal (GUNet.py:59): truncated normal, var 2/fan_in
+            std = (2.0 / shape[0]) ** 0.5 / 0.87962566103423978
+            v = torch.empty(shape, dtype=torch.float64)
+            torch.nn.init.trunc_normal_(v, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=gen)
+            params[name] = v.to(dtype)
         elif kind in ("gamma", "moving_var"):
             params[name] = torch.ones(shape, dtype=dtype)
         else:
@@ -82,7 +89,7 @@ def init_params(specs, seed=1234, dtype=torch.float32):
     return params
 
 
-TRAINABLE_KINDS = ("conv_w", "deconv_w", "bias", "gamma", "beta")
+TRAINABLE_KINDS = ("conv_w", "deconv_w", "bias", "gamma", "beta", "fc_w", "fc_w_he", "fc_b")
 
 
 class UNet2DOracle(object):

@@ -129,3 +129,232 @@ def test_gunet_trains_and_checkpoint_names():
     assert model(inputs, "train", **YML).item() < first
     model(inputs, "eval", **YML)
     assert model.probability.shape == (2, 32, 32, 3)
+
+
+# ----------------------------------------------------------------------------- context (density) branch, GUNet.py:31-60
+def fc_uniform_host(seed, idx):
+    """The counter RNG of unetk_fc_fwd's dropout mask (csrc/fc.hip), restated in numpy."""
+    h = (idx.astype(np.uint64) * 0x9E3779B1 + seed) & 0xFFFFFFFF
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+    h ^= h >> 16
+    return (h >> 8).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+
+@pytest.mark.parametrize("bsz,k,n,relu,keep", [(2, 10, 256, True, None), (8, 256, 1000, True, 0.5), (3, 256, 3968, False, None),
+                                               (5, 33, 70, True, 0.8)])
+def test_fully_connected_forward_backward_and_dropout_mask(bsz, k, n, relu, keep):
+    from boxsegliver_amd import ops
+    gen = torch.Generator().manual_seed(bsz * 1000 + n)
+    x = torch.randn(bsz, k, generator=gen)
+    w = torch.randn(k, n, generator=gen) / k ** 0.5
+    b = torch.randn(n, generator=gen)
+    dy = torch.randn(bsz, n, generator=gen)
+    xd, wd, bd = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    seed = 77
+    y = ops.FullyConnected.apply(xd, wd, bd, relu, keep, seed)
+    y.backward(dy.cuda())
+    mask = None
+    if keep is not None:
+        u = fc_uniform_host(seed, np.arange(bsz * n, dtype=np.uint64)).reshape(bsz, n)
+        mask = torch.from_numpy(np.where(u < np.float32(keep), np.float32(1.0) / np.float32(keep), np.float32(0)))
+        assert abs((mask > 0).float().mean().item() - keep) < 0.05
+    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, b))
+    ref = x64 @ w64 + b64
+    if relu:
+        ref = torch.relu(ref)
+    if mask is not None:
+        ref = ref * mask.double()
+    ref.backward(dy.double())
+    assert rel(y.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
+    if mask is not None:                                   # the mask itself: dropped entries are exact zeros
+        np.testing.assert_array_equal(y.detach().cpu().numpy()[mask.numpy() == 0], 0.0)
+    assert rel(xd.grad.cpu().numpy(), x64.grad.numpy()) < 1e-5
+    assert rel(wd.grad.cpu().numpy(), w64.grad.numpy()) < 1e-5
+    assert rel(bd.grad.cpu().numpy(), b64.grad.numpy()) < 1e-5
+    # bit-reproducible
+    xd2, wd2, bd2 = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    y2 = ops.FullyConnected.apply(xd2, wd2, bd2, relu, keep, seed)
+    y2.backward(dy.cuda())
+    assert torch.equal(y, y2) and torch.equal(wd.grad, wd2.grad) and torch.equal(xd.grad, xd2.grad)
+
+
+@pytest.mark.parametrize("per_sample,g_ch,n,hw,c", [(True, 0, 3, 24 * 24, 64), (False, 0, 4, 16 * 16, 128), (False, 2, 2, 32 * 32, 64),
+                                                    (True, 1, 2, 8 * 8, 512), (False, 0, 32, 16 * 16, 1024)])
+def test_norm_density_modulation_forward_backward(per_sample, g_ch, n, hw, c):
+    """z = relu(norm(y) * den[b, c] [+ guide . gw + gb]) and its backward (dy, dgamma, dbeta, dden, dgw, dgb) against
+    float64 autograd on the same operands -- the kernels of csrc/norm.hip with the D flag."""
+    from boxsegliver_amd import ops
+    from oracle import tf_ops
+    gen = torch.Generator().manual_seed(c + n)
+    h = int(hw ** 0.5)
+    y = torch.randn(n, h, h, c, generator=gen) * 2 + 0.5
+    gamma = 0.5 + torch.rand(c, generator=gen)
+    beta = 0.3 * torch.randn(c, generator=gen)
+    den = 1.0 + 0.5 * torch.randn(n, c, generator=gen)       # signs included
+    dz = torch.randn(n, h, h, c, generator=gen)
+    guide = torch.rand(n, h, h, g_ch, generator=gen) if g_ch else None
+    gw = torch.randn(g_ch, c, generator=gen) if g_ch else None
+    gb = 0.1 * torch.randn(c, generator=gen) if g_ch else None
+    yd = y.cuda()
+    d = ops.norm_desc(y.shape, per_sample, c, g_ch, c if g_ch else 0, 0)
+    # statistics partials: one row per sample (sum, sum of squares)
+    flat = yd.reshape(n, hw, c)
+    stats = torch.stack([flat.sum(1), (flat * flat).sum(1)]).contiguous()
+    aff = ops.norm_finalize(d, stats, n, gamma.cuda(), beta.cuda(), 1e-3 if not per_sample else 1e-6, 0.99, True,
+                            torch.zeros(c).cuda(), torch.ones(c).cuda(), yd.device)
+    cu = lambda t: None if t is None else t.cuda().contiguous()
+    z = torch.empty_like(yd)
+    ops.norm_apply_relu(d, yd, aff, z, cu(guide), cu(gw), cu(gb), cu(den))
+    dy, dgamma, dbeta, dgw, dgb, dden = ops.norm_relu_bwd(d, yd, cu(dz), aff, True, True, cu(guide), cu(gw), cu(gb), cu(den))
+    d64 = lambda t: None if t is None else t.double().requires_grad_(True)
+    y64, g64, b64, den64, gw64, gb64 = d64(y), d64(gamma), d64(beta), d64(den), d64(gw), d64(gb)
+    if per_sample:
+        t = tf_ops.instance_norm(y64, g64, b64, eps=1e-6)
+    else:
+        t, _, _ = tf_ops.batch_norm(y64, g64, b64, torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64), True)
+    u = t * den64[:, None, None, :]
+    if g_ch:
+        u = u + (guide.double() @ gw64 + gb64)
+    ref = torch.relu(u)
+    ref.backward(dz.double())
+    tol = 2e-5
+    assert rel(z.cpu().numpy(), ref.detach().numpy()) < tol
+    assert rel(dy.cpu().numpy(), y64.grad.numpy()) < tol
+    assert rel(dgamma.cpu().numpy(), g64.grad.numpy()) < tol
+    assert rel(dbeta.cpu().numpy(), b64.grad.numpy()) < tol
+    assert rel(dden.cpu().numpy(), den64.grad.numpy()) < tol
+    if g_ch:
+        assert rel(dgw.cpu().numpy(), gw64.grad.numpy()) < tol
+        assert rel(dgb.cpu().numpy(), gb64.grad.numpy()) < tol
+    # reproducible, and den = 1 reduces bit-exactly to the un-modulated kernels
+    again = ops.norm_relu_bwd(d, yd, cu(dz), aff, True, True, cu(guide), cu(gw), cu(gb), cu(den))
+    assert all(torch.equal(a, b) for a, b in zip((dy, dgamma, dbeta, dden), (again[0], again[1], again[2], again[5])))
+    ones = torch.ones(n, c).cuda()
+    z1, z0 = torch.empty_like(yd), torch.empty_like(yd)
+    ops.norm_apply_relu(d, yd, aff, z1, cu(guide), cu(gw), cu(gb), ones)
+    ops.norm_apply_relu(d, yd, aff, z0, cu(guide), cu(gw), cu(gb))
+    assert torch.equal(z1, z0)
+
+
+def setup_context(args, size=32, bsz=2, ctx_len=10, use_spatial=True):
+    from boxsegliver_amd.NetworksV2.GUNet import GUNet
+    from boxsegliver_amd.data.synthetic import make_batch, make_guide
+    images, labels, _ = make_batch(bsz, size, size, 3, 3, 1234)
+    guide = make_guide(labels, args.guide_channel, 1234)
+    gen = torch.Generator().manual_seed(5)
+    context = torch.rand(bsz, ctx_len, generator=gen)
+    model = GUNet(args)
+    inputs = {"images": torch.from_numpy(images).cuda(), "labels": torch.from_numpy(labels).cuda(),
+              "sp_guide": torch.from_numpy(guide).cuda(), "context": context.cuda()}
+    model(inputs, "eval", **YML)
+    net = gunet2d.GUNet2DOracle(3, 3, guide_channel=args.guide_channel, normalizer=args.normalizer, use_spatial=use_spatial,
+                                context_length=ctx_len, context_fc_channels=YML["context_fc_channels"])
+    assert [(n, tuple(s), k) for n, s, k in net.specs] == [(n, tuple(s), k) for n, s, k in model.params.specs]
+    params = {}
+    for name, t in model.params.state_dict().items():
+        kind = net.kinds[name]
+        if kind == "gamma":
+            params[name] = 0.5 + torch.rand(t.shape, generator=gen)
+        elif kind in ("beta", "bias", "fc_b"):
+            params[name] = 0.2 * torch.randn(t.shape, generator=gen)
+        elif "spatial" in name:
+            params[name] = 0.5 * torch.randn(t.shape, generator=gen)
+        else:
+            params[name] = t.clone()
+    last = "GUNet/context/fc3/biases"
+    params[last] = params[last] + 1.0                          # gains around 1 (he_normal weights, unit offset)
+    model.params.load_state(params)
+    return model, inputs, net, params, (torch.from_numpy(images), torch.from_numpy(guide), torch.from_numpy(labels).long(),
+                                        context)
+
+
+@pytest.mark.parametrize("normalizer,use_spatial,side_dropout", [("instance_norm", True, 0.0), ("batch_norm", False, 0.0),
+                                                                 ("instance_norm", True, 0.5)])
+def test_gunet_context_branch_matches_oracle(normalizer, use_spatial, side_dropout):
+    """--use_context: the MLP's gains modulate every encoder unit of the mod_layers (GUNet.py:203-206).  With dropout
+    the oracle is fed the masks the device drew (read back from the autograd nodes), so the arithmetic is compared."""
+    from boxsegliver_amd import ops
+    args = make_args(normalizer=normalizer, use_context=True, use_spatial=use_spatial, side_dropout=side_dropout)
+    model, inputs, net, params, (images, guide, labels, context) = setup_context(args, use_spatial=use_spatial)
+    names = list(model.params.state_dict())
+    assert "GUNet/context/fc1/weights" in names and "GUNet/context/fc3/biases" in names
+    assert model.params["GUNet/context/fc3/weights"].shape == (256, 64 * (2 + 4 + 8 + 16) * 2)
+    assert ("GUNet/spatial/conv2/weights" in names) == use_spatial
+    ops.DEBUG_CAPTURE = []
+    try:
+        model.params.zero_grad()
+        loss = model(inputs, "train", **YML)
+        masks = None
+        if side_dropout:
+            # walk the autograd graph of the context params for the two dropout masks (fc1, fc2 order)
+            fn, found = model.layers["context_params"].grad_fn, []
+            while fn is not None and type(fn).__name__ == "FullyConnectedBackward":
+                found.append(fn.saved_tensors[3])
+                fn = fn.next_functions[0][0]
+            masks = [m.cpu() for m in reversed(found) if m is not None]
+            assert len(masks) == 2 and all(0.3 < (m > 0).float().mean().item() < 0.7 for m in masks)
+            assert all(set(np.unique(m.numpy()).tolist()) <= {0.0, 2.0} for m in masks)
+        loss.backward()
+        torch.cuda.synchronize()
+        captured = ops.DEBUG_CAPTURE
+    finally:
+        ops.DEBUG_CAPTURE = None
+    kw = dict(kwargs_of(args), context=context, drop_masks=masks)
+    total, _, logits, grads, new_stats = net.loss_and_grads(params, images, guide, labels, **kw)
+    p64 = {k: v.double() for k, v in params.items()}
+    kw64 = dict(kw, context=context.double(), drop_masks=None if masks is None else [m.double() for m in masks])
+    _, _, _, grads64, _ = net.loss_and_grads(p64, images.double(), guide.double(), labels, **kw64)
+    assert abs(loss.item() - total.item()) < 1e-4 * max(1.0, abs(total.item()))
+    assert np.abs(model.layers["logits"].cpu().numpy() - logits.numpy()).max() < 1e-3
+    den_ref = net.context_params(p64, context.double(), kw64["drop_masks"]).numpy()
+    assert rel(model.layers["context_params"].detach().cpu().numpy(), den_ref) < 1e-5
+    units = [c for c in captured if c.get("kind") != "deconv"]
+    assert sum(1 for c in units if c.get("den") is not None) == 8
+    for c in units:
+        check_unit_backward(c)
+    num = den = 0.0
+    for name in model.params.trainable_names():
+        g = model.params[name].grad.cpu().numpy().astype(np.float64)
+        ref = grads64[name].numpy()
+        l2 = np.linalg.norm(g - ref) / max(np.linalg.norm(ref), 1e-30)
+        # (the 2x2-pixel level's tensors feel single ReLU flips; the kernels are pinned on identical operands above)
+        assert l2 < (2e-1 if ("conv5" in name or "down_conv5" in name) else 1e-1), (name, l2)
+        num += np.sum((g - ref) ** 2)
+        den += np.sum(ref ** 2)
+    assert (num / den) ** 0.5 < 5e-3
+    for name in ("GUNet/context/fc1/weights", "GUNet/context/fc2/weights", "GUNet/context/fc3/weights",
+                 "GUNet/context/fc3/biases"):
+        g = model.params[name].grad.cpu().numpy()
+        assert np.abs(g).max() > 0 and rel(g, grads64[name].numpy()) < 2e-2, name
+    for name, ref in new_stats.items():
+        np.testing.assert_allclose(model.params[name].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_gunet_context_trains_eval_has_no_dropout_and_masks_change_per_step():
+    from boxsegliver_amd.core.solver import Solver
+    args = make_args(use_context=True, side_dropout=0.5)
+    model, inputs, net, params, (images, guide, labels, context) = setup_context(args)
+    # eval: no dropout -> equals the oracle without masks, and is deterministic
+    model(inputs, "eval", **YML)
+    lg, _ = net.forward(params, images, guide, False, context, None)
+    assert np.abs(model.layers["logits"].cpu().numpy() - lg.numpy()).max() < 1e-3
+    a = model.layers["context_params"].clone()
+    model(inputs, "eval", **YML)
+    assert torch.equal(a, model.layers["context_params"])
+    # train: a fresh mask every call
+    model(inputs, "train", **YML)
+    t1 = model.layers["context_params"].detach().clone()
+    model(inputs, "train", **YML)
+    assert not torch.equal(t1, model.layers["context_params"].detach())
+    solver = Solver(args)
+    losses = []
+    for _ in range(6):
+        loss = model(inputs, "train", **YML)
+        losses.append(loss.item())
+        solver(loss, model)
+    assert min(losses[3:]) < losses[0]
+    # FC variables are not L2-regularised (slim.fully_connected has no regulariser in _net_arg_scope, GUNet.py:244-248)
+    assert model.params.where["GUNet/context/fc1/weights"][0] == "noreg"

@@ -178,7 +178,7 @@ def check_unit_backward(c, tol=1e-5):
     from oracle import tf_ops
     d64 = lambda t: None if t is None else t.detach().cpu().double().requires_grad_(True)
     y, g, b = d64(c["y"]), d64(c["gamma"]), d64(c["beta"])
-    gw, gb = d64(c.get("gw")), d64(c.get("gb"))
+    gw, gb, den = d64(c.get("gw")), d64(c.get("gb")), d64(c.get("den"))
     if c.get("per_sample") and y.shape[1] * y.shape[2] <= 16:
         # instance norm over <= 16 pixels with eps 1e-6 (the 2x2 / 4x4 levels of these reduced-size test nets):
         # rstd ~ 1e3 amplifies the fp32 rounding of the one-pass variance; real configs have >= 256 pixels here
@@ -188,9 +188,13 @@ def check_unit_backward(c, tol=1e-5):
     else:
         z, _, _ = tf_ops.batch_norm(y, g, b, torch.zeros(y.shape[-1], dtype=torch.float64),
                                     torch.ones(y.shape[-1], dtype=torch.float64), True)
+    if den is not None:
+        z = z * den[:, None, None, :]
     if gw is not None:
         z = z + (c["guide"].detach().cpu().double() @ gw + gb)
     torch.relu(z).backward(c["dz"].detach().cpu().double())
+    if den is not None:
+        assert rel(c["dden"].cpu().numpy(), den.grad.numpy()) < tol
     assert rel(c["dy"].cpu().numpy(), y.grad.numpy()) < tol
     if g is not None:
         assert rel(c["dgamma"].cpu().numpy(), g.grad.numpy()) < tol
