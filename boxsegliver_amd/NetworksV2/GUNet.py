@@ -12,8 +12,11 @@ The context (density) branch --use_context (`_context_subnets` with context_mode
 per-sample channel gains; each modulated conv unit multiplies its normalised output by its slice of them inside
 the same norm-apply / norm-backward kernels (no extra pass over the activations).
 
+`after_affine` (GUNetV2.yml and the *_AA.yml configs; GUNet.py:213-214, slim_nets.channel_wise_affine): the per-channel
+gamma' / beta' after the modulation fold into the gains / guide weights / post-shift of the same kernels.
+
 Not built (raise NotImplementedError): --use_se, context_model vgg16*, the conv context subnet (`ct_conv`),
-`after_affine`, --fix, --dropout.
+--fix, --dropout (no shipped script uses them).
 """
 import torch
 
@@ -30,7 +33,7 @@ def n_modulator_params(init_channels, num_down_samples, mod_layers):
 
 
 def param_specs(in_channels, num_classes, guide_channel, init_channels, num_down_samples, mod_layers, normalizer,
-                norm_with_center, norm_with_scale, use_spatial, name, context_dims=None):
+                norm_with_center, norm_with_scale, use_spatial, name, context_dims=None, after_affine=False):
     """Variables with the reference's TF names: <name>/spatial/conv{i}/{weights,biases},
     <name>/Encode/down_conv{i}/mod_conv{j}/{weights,<Norm>/...}, <name>/Decode/up{i}/{weights,biases},
     <name>/Decode/up_conv{i}/up_conv{i}_{j}/..., <name>/AdjustChannels/{weights,biases}."""
@@ -66,10 +69,13 @@ def param_specs(in_channels, num_classes, guide_channel, init_channels, num_down
         for j in (1, 2):
             scope = "{}/Encode/down_conv{}/mod_conv{}".format(name, i + 1, j)
             specs.append((scope + "/weights", (3, 3, cin, c), "conv_w"))
-            if mod:
-                norm_vars(scope, c, norm_with_center, norm_with_scale)
+            if mod:                                   # GUNet.py:317-320: no centre / scale under after_affine
+                norm_vars(scope, c, norm_with_center and not after_affine, norm_with_scale and not after_affine)
             else:
                 norm_vars(scope, c, True, True)       # GUNet.py:183-188: scale=True (BN) / IN defaults
+            if after_affine:                          # slim_nets.channel_wise_affine (slim_nets.py:152-212), GUNet.py:213-214
+                specs.append((scope + "/ChannelWiseAffine/beta", (c,), "beta"))
+                specs.append((scope + "/ChannelWiseAffine/gamma", (c,), "gamma"))
             cin = c
     c = init_channels * 2 ** num_down_samples
     for i in reversed(range(num_down_samples)):
@@ -102,6 +108,8 @@ class GUNet(base.BaseNet):
         self.dropout = getattr(args, "dropout", None)
         self.use_se = getattr(args, "use_se", False)
         self._taps = None
+        self._concat_guide = False          # UNetInter: the guide joins the input channels instead of modulating
+        self._encoder_decay = None          # UNetInter: BN decay of every encoder unit
 
     def _net_arg_scope(self, *args, **kwargs):
         """GUNet.py:240-257: as UNet (decoder norm = _get_normalization defaults), pools with SAME."""
@@ -137,8 +145,7 @@ class GUNet(base.BaseNet):
         mod_layers = list(kwargs.get("mod_layers", []))
         norm_with_center = kwargs.get("norm_with_center", False)
         norm_with_scale = kwargs.get("norm_with_scale", False)
-        if kwargs.get("after_affine", False):
-            raise NotImplementedError("GUNet after_affine is not built yet")
+        after_affine = bool(kwargs.get("after_affine", False))
         images = self._inputs["images"]
         if not images.is_cuda:
             raise ops._abi.UnetkError("GUNet runs on the GPU only: move `images` to cuda (no CPU path)")
@@ -147,7 +154,7 @@ class GUNet(base.BaseNet):
             raise ValueError("H and W must be divisible by 2**num_down_samples")
         dev = images.device
         nm = self.name
-        g_ch = int(getattr(self.args, "guide_channel", 1)) if self.use_spatial_guide else 0
+        g_ch = int(getattr(self.args, "guide_channel", 1)) if (self.use_spatial_guide and not self._concat_guide) else 0
         context_dims = None
         if self.use_context_guide:
             if kwargs.get("context_model", "fc") != "fc":
@@ -160,9 +167,11 @@ class GUNet(base.BaseNet):
                 [n_modulator_params(base_channels, nds, mod_layers)]
         if self.params is None:
             in_ch = self.channel * (3 if getattr(self.args, "img_grad", False) else 1)      # GUNet.py:335-338
+            if self._concat_guide:                                                          # UNetInter.py:87-88
+                in_ch = self.channel + int(getattr(self.args, "guide_channel", 1))
             specs = param_specs(in_ch, self.num_classes, g_ch, base_channels, nds, mod_layers,
-                                self.args.normalizer, norm_with_center, norm_with_scale, self.use_spatial_guide, nm,
-                                context_dims)
+                                self.args.normalizer, norm_with_center, norm_with_scale, g_ch > 0, nm,
+                                context_dims, after_affine)
             self.params = ParamStore(specs, dev, bias_decay=getattr(self.args, "bias_decay", False))
             self.params.initialize(self._get_initializer()[0], seed=getattr(self.args, "seed", None))
         p = self.params
@@ -170,7 +179,7 @@ class GUNet(base.BaseNet):
         with torch.set_grad_enabled(self.mode == ModeKeys.TRAIN):
             # spatial guide pyramid (GUNet.py:136-159): avg-pool between levels; the 1x1 conv is fused downstream
             guides = {}
-            if self.use_spatial_guide:
+            if g_ch:
                 gs = self._inputs["sp_guide"].to(torch.float32).contiguous()
                 if gs.shape != (n, h, w, g_ch):
                     raise ValueError("sp_guide must be [bs, H, W, {}], got {}".format(g_ch, tuple(gs.shape)))
@@ -195,7 +204,12 @@ class GUNet(base.BaseNet):
                         not last, None if last else keep, seed)
                 self._layers["context_params"] = den_all
 
-            if getattr(self.args, "img_grad", False):
+            if self._concat_guide:
+                gs = self._inputs["sp_guide"].to(torch.float32)
+                if gs.shape[:3] != images.shape[:3]:
+                    raise ValueError("sp_guide must be [bs, H, W, g], got {}".format(tuple(gs.shape)))
+                x = torch.cat((images.to(torch.float32), gs), dim=-1).contiguous()
+            elif getattr(self.args, "img_grad", False):
                 x = ops.image_gradients(images.to(torch.float32))
             else:
                 x = images.contiguous()
@@ -205,7 +219,7 @@ class GUNet(base.BaseNet):
                 c = base_channels * 2 ** i
                 mod = i in guides
                 dens = den_all is not None and i in mod_layers
-                spec = self._spec(0.99) if (mod or dens) else self._spec()  # GUNet.py:313-330 decay .99
+                spec = self._spec(0.99) if (mod or dens) else self._spec(self._encoder_decay)  # GUNet.py:313-330 decay .99
                 for j in (1, 2):
                     scope = "{}/Encode/down_conv{}/mod_conv{}".format(nm, i + 1, j)
                     out = None
@@ -217,12 +231,21 @@ class GUNet(base.BaseNet):
                     if dens:                                                 # GUNet.py:203-206
                         den = den_all[:, den_off:den_off + c]
                         den_off += c
+                    guide = gw = gb = None
                     if mod:
+                        guide = guides[i]
                         gw = p["{}/spatial/conv{}/weights".format(nm, i + 1)].view(g_ch, 2 * c)[:, (j - 1) * c:j * c]
                         gb = p["{}/spatial/conv{}/biases".format(nm, i + 1)][(j - 1) * c:j * c]
-                        x = self._unit(x, scope, spec, out, guides[i], gw, gb, den)
-                    else:
-                        x = self._unit(x, scope, spec, out, den=den)
+                    if after_affine:
+                        # (t * den + sp) * ga + ba == t * (den ga) + guide . (gw ga) + (gb ga + ba): the channel-wise affine
+                        # folds into the gains / guide weights the kernel already takes (tiny [bs, C] / [g, C] products)
+                        ga, ba = p[scope + "/ChannelWiseAffine/gamma"], p[scope + "/ChannelWiseAffine/beta"]
+                        den = ga.expand(n, c) if den is None else den * ga
+                        if mod:
+                            gw, gb = gw * ga, gb * ga + ba
+                        else:
+                            gb = ba
+                    x = self._unit(x, scope, spec, out, guide, gw, gb, den)
                 if i < nds:
                     skips[i] = x
                     x = ops.MaxPool2x2.apply(x)

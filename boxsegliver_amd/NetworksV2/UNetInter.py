@@ -1,0 +1,35 @@
+"""UNetInter plugin -- host-side mirror of the reference's NetworksV2/UNetInter.py:31-200 on the libunetk HIP kernels.
+
+A U-Net whose INPUT is concat(images, sp_guide) (UNetInter.py:87-88): the interaction guide joins the image channels
+instead of modulating the encoder.  Topology, scopes and variable names are GUNet's (`<name>/Encode/down_conv{i}/
+mod_conv{j}`, `<name>/Decode/up{i}`, `up_conv{i}`, `AdjustChannels`) with no modulation; every encoder unit is
+conv -> norm(centre, scale; BN decay .99, UNetInter.py:98-113) -> ReLU, the decoder uses the `_get_normalization`
+defaults.  So this class is GUNet with the guide routed to the input -- same kernels, nothing new on the device.
+
+Not built: --mid_cat (the guide concatenated after level 0 makes Encode2's Cin = 64 + g, not a multiple of the MFMA
+K-chunk) and `use_2d`.  --img_grad computes dy / dx in the reference but never feeds them to the net (:82-85): ignored.
+"""
+from .GUNet import GUNet
+
+
+class UNetInter(GUNet):
+    def __init__(self, args, name=None):
+        """Don't create tensors in __init__() (reference UNetInter.py:32-43)."""
+        super(UNetInter, self).__init__(args, name or "UNetInter")
+        self.use_context_guide = False
+        self.use_se = False
+        self.dropout = None
+        self._concat_guide = True
+        self._encoder_decay = 0.99
+
+    def _net_arg_scope(self, *args, **kwargs):
+        if getattr(self.args, "mid_cat", False) or getattr(self.args, "use_2d", False):
+            raise NotImplementedError("UNetInter --mid_cat / use_2d are not built")
+        if getattr(self.args, "without_norm", False):
+            raise NotImplementedError("--without_norm has no HIP kernel yet")
+        self._norm = self._get_normalization()
+        return self._norm
+
+    def _build_network(self, *args, **kwargs):
+        kwargs = dict(kwargs, mod_layers=[], after_affine=False)
+        return super(UNetInter, self)._build_network(*args, **kwargs)

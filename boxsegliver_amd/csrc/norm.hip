@@ -11,6 +11,8 @@
 //     1x1 conv of the pooled guide (GUNet.py:154-156): computed on the fly, never materialised
 //   ReLU
 // i.e.  t = (y - mean) rstd gamma + beta,  u = t * den[b,c] + guide . gw + gb,  z = relu(u).
+// gb without a guide (guide_ch == 0) is a bare per-channel shift after the gain: with den = gain * affine-gamma that is
+// `after_affine` (slim_nets.channel_wise_affine, GUNet.py:213-214) folded into the same pass.
 // The conv epilogue already produced per-tile sum / sum-of-squares partials, so the forward is one tiny
 // finalise + ONE read-modify-write pass; the backward is two passes over (y, dz).
 //
@@ -112,8 +114,8 @@ __global__ __launch_bounds__(256) void norm_apply_relu_kernel(ApplyArgs a) {
     sh = mul4(sh, dn);
   }
   float4 gwv[G > 0 ? G : 1];
+  if (a.gb) sh = add4(sh, ldg4(a.gb + a.gw_coff + cq * 4));   // guide bias, or a bare post-shift when G == 0
   if (G > 0) {
-    sh = add4(sh, ldg4(a.gb + a.gw_coff + cq * 4));
 #pragma unroll
     for (int g = 0; g < G; ++g) gwv[g] = ldg4(a.gw + (int64_t)g * a.gw_stride + a.gw_coff + cq * 4);
   }
@@ -171,8 +173,8 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
     const float4 sc = D ? mul4(sc0, dn) : sc0;
     float4 sh = D ? mul4(sh0, dn) : sh0;
     float4 gwv[G > 0 ? G : 1];
+    if (a.gb) sh = add4(sh, ldg4(a.gb + a.gw_coff + cq * 4));
     if (G > 0) {
-      sh = add4(sh, ldg4(a.gb + a.gw_coff + cq * 4));
 #pragma unroll
       for (int g = 0; g < G; ++g) gwv[g] = ldg4(a.gw + (int64_t)g * a.gw_stride + a.gw_coff + cq * 4);
     }
@@ -228,8 +230,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdArgs a) {
   const float4 sc = D ? mul4(sc0, dn) : sc0;
   float4 sh = D ? mul4(sh0, dn) : sh0;
   float4 gwv[G > 0 ? G : 1];
+  if (a.gb) sh = add4(sh, ldg4(a.gb + a.gw_coff + cq * 4));   // guide bias, or a bare post-shift when G == 0
   if (G > 0) {
-    sh = add4(sh, ldg4(a.gb + a.gw_coff + cq * 4));
 #pragma unroll
     for (int g = 0; g < G; ++g) gwv[g] = ldg4(a.gw + (int64_t)g * a.gw_stride + a.gw_coff + cq * 4);
   }
@@ -345,8 +347,9 @@ extern "C" int unetk_norm_apply_relu(const unetk_norm_desc* d, const float* y, c
   UNETK_REQUIRE(!den || unetk_aligned16(den));
   if (d->guide_ch > 0) {
     UNETK_REQUIRE(guide && gw && gb && d->gw_stride >= d->gw_coff + d->C);
-    UNETK_REQUIRE(d->gw_stride % 4 == 0 && d->gw_coff % 4 == 0 && unetk_aligned16(gw) && unetk_aligned16(gb));
+    UNETK_REQUIRE(d->gw_stride % 4 == 0 && unetk_aligned16(gw));
   }
+  UNETK_REQUIRE(!gb || (d->gw_coff % 4 == 0 && d->gw_coff >= 0 && unetk_aligned16(gb)));
   const NormGeom g = geom(d, den != nullptr);
   ApplyArgs a{y, scale, shift, den, guide, gw, gb, z, g.P, d->C, d->z_stride, g.cq_n, g.rpi, d->gw_stride, d->gw_coff, g.sst};
   int64_t gx = (g.P + g.rpi - 1) / g.rpi;
@@ -386,9 +389,10 @@ extern "C" int unetk_norm_relu_bwd(const unetk_norm_desc* d, const float* y, con
   const bool D = den != nullptr;
   UNETK_REQUIRE(!D || (dden && unetk_aligned16(den)));
   if (G > 0) {
-    UNETK_REQUIRE(guide && gw && gb && dgw && dgb && d->gw_stride >= d->gw_coff + d->C);
-    UNETK_REQUIRE(d->gw_stride % 4 == 0 && d->gw_coff % 4 == 0 && unetk_aligned16(gw) && unetk_aligned16(gb));
+    UNETK_REQUIRE(guide && gw && gb && dgw && d->gw_stride >= d->gw_coff + d->C);
+    UNETK_REQUIRE(d->gw_stride % 4 == 0 && unetk_aligned16(gw));
   }
+  UNETK_REQUIRE(!gb || (dgb && d->gw_coff % 4 == 0 && d->gw_coff >= 0 && unetk_aligned16(gb)));
   if (ws_bytes < unetk_norm_bwd_ws_bytes(d)) return UNETK_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const NormGeom g = geom(d, D);

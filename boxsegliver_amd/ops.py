@@ -291,7 +291,7 @@ def norm_relu_bwd(d, y, dz, aff, has_gamma, has_beta, guide=None, gw=None, gb=No
     dgamma = torch.empty((d.C,), dtype=torch.float32, device=dev) if has_gamma else None
     dbeta = torch.empty((d.C,), dtype=torch.float32, device=dev) if has_beta else None
     dgw = torch.empty((d.guide_ch, d.C), dtype=torch.float32, device=dev) if d.guide_ch else None
-    dgb = torch.empty((d.C,), dtype=torch.float32, device=dev) if d.guide_ch else None
+    dgb = torch.empty((d.C,), dtype=torch.float32, device=dev) if (d.guide_ch or gb is not None) else None
     nbytes = _abi.lib().unetk_norm_bwd_ws_bytes(ctypes.byref(d))
     if nbytes == 0:
         raise _abi.UnetkError("norm_relu_bwd: unsupported channel count {}".format(d.C))
@@ -588,6 +588,7 @@ class Conv3x3NormRelu(torch.autograd.Function):
         g_ch = 0 if guide is None else guide.shape[-1]
         if g_ch:
             gw = gw.contiguous()
+        if gb is not None:                  # without a guide: a bare per-channel shift after the gain (after_affine)
             gb = gb.contiguous()
         d = norm_desc(y.shape, spec.per_sample, _pix_stride(z), g_ch, cout if g_ch else 0, 0)
         if plain:

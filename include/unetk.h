@@ -153,7 +153,9 @@ int unetk_norm_finalize(const unetk_norm_desc* d, const float* stat_partials, in
 
 /* z = relu((y*scale + shift) [* den[n][c]] [+ guide modulation]); z has pixel stride d->z_stride.
  * den (nullable, [N][C]) is GUNet's density modulation `conditional_normalization` (GUNet.py:119-133,203-206):
- * the per-sample channel gains the context MLP (unetk_fc_*) produced. */
+ * the per-sample channel gains the context MLP (unetk_fc_*) produced.  gb may be given with guide_ch == 0: a bare
+ * per-channel shift after the gain -- with den = gain * gamma' this is `after_affine` (slim_nets.channel_wise_affine,
+ * GUNet.py:213-214: (net) * gamma' + beta') in the same pass. */
 int unetk_norm_apply_relu(const unetk_norm_desc* d, const float* y, const float* scale,
                           const float* shift, const float* den, const float* guide, const float* gw,
                           const float* gb, float* z, void* stream);

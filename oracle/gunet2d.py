@@ -28,7 +28,7 @@ from .unet2d import TRAINABLE_KINDS  # noqa: F401
 
 def param_specs(in_channels, num_classes, guide_channel=1, init_channels=64, num_down_samples=4,
                 mod_layers=(1, 2, 3, 4), normalizer="instance_norm", norm_with_center=True, norm_with_scale=False,
-                name="GUNet", use_spatial=True, context_dims=None):
+                name="GUNet", use_spatial=True, context_dims=None, after_affine=False):
     """context_dims = [context length, fc widths ..., n_modulator_param] enables the context branch."""
     specs = []
     bn = normalizer == "batch_norm"
@@ -67,9 +67,12 @@ def param_specs(in_channels, num_classes, guide_channel=1, init_channels=64, num
             specs.append((scope + "/weights", (3, 3, cin, c), "conv_w"))
             start = len(specs)
             if (use_spatial or context_dims) and i in mod_layers:
-                norm_vars(scope, norm_with_center, norm_with_scale)
+                norm_vars(scope, norm_with_center and not after_affine, norm_with_scale and not after_affine)   # :317-320
             else:
                 norm_vars(scope, True, True)
+            if after_affine:                                           # slim_nets.py:152-212 via GUNet.py:213-214
+                specs.append((scope + "/ChannelWiseAffine/beta", None, "beta"))
+                specs.append((scope + "/ChannelWiseAffine/gamma", None, "gamma"))
             fix_shapes(c, start)
             cin = c
     c = init_channels * 2 ** num_down_samples
@@ -92,8 +95,14 @@ def param_specs(in_channels, num_classes, guide_channel=1, init_channels=64, num
 class GUNet2DOracle(object):
     def __init__(self, in_channels, num_classes, guide_channel=1, init_channels=64, num_down_samples=4,
                  mod_layers=(1, 2, 3, 4), normalizer="instance_norm", norm_with_center=True, norm_with_scale=False,
-                 name="GUNet", img_grad=False, use_spatial=True, context_length=None, context_fc_channels=(256, 256)):
+                 name="GUNet", img_grad=False, use_spatial=True, context_length=None, context_fc_channels=(256, 256),
+                 after_affine=False, concat_guide=False, encoder_decay=0.999):
+        """concat_guide + mod_layers=() + encoder_decay=.99 + name="UNetInter" is the reference's UNetInter
+        (NetworksV2/UNetInter.py:76-141): the guide joins the input channels, encoder BN decay .99 (:98-113)."""
         self.name, self.num_classes = name, num_classes
+        self.after_affine, self.concat_guide, self.encoder_decay = after_affine, concat_guide, encoder_decay
+        if concat_guide:
+            use_spatial, mod_layers = False, ()
         self.use_spatial = use_spatial
         self.context_dims = None
         if context_length:                                             # GUNet.py:47-48
@@ -104,7 +113,8 @@ class GUNet2DOracle(object):
         self.mod_layers = tuple(mod_layers)
         self.normalizer = normalizer
         self.specs = param_specs(in_channels, num_classes, guide_channel, init_channels, num_down_samples, mod_layers,
-                                 normalizer, norm_with_center, norm_with_scale, name, use_spatial, self.context_dims)
+                                 normalizer, norm_with_center, norm_with_scale, name, use_spatial, self.context_dims,
+                                 after_affine)
         self.kinds = {n: k for n, _, k in self.specs}
 
     def _unit(self, x, p, scope, is_training, new_stats, decay, sp=None, den=None):
@@ -121,6 +131,8 @@ class GUNet2DOracle(object):
             y = y * den[:, None, None, :]
         if sp is not None:
             y = y + sp
+        if self.after_affine and "/Encode/" in scope:                  # GUNet.py:213-214
+            y = y * p[scope + "/ChannelWiseAffine/gamma"] + p[scope + "/ChannelWiseAffine/beta"]
         return torch.relu(y)
 
     def context_params(self, p, context, drop_masks=None):
@@ -151,6 +163,8 @@ class GUNet2DOracle(object):
             if i < self.nds:
                 gs = tf_ops.avg_pool2x2_same(gs)
         x = torch.cat((images,) + tf_ops.image_gradients(images), dim=-1) if self.img_grad else images
+        if self.concat_guide:                                          # UNetInter.py:87-88
+            x = torch.cat((images, sp_guide), dim=-1)
         skips = []
         for i in range(self.nds + 1):
             c = self.init_channels * 2 ** i
@@ -162,7 +176,7 @@ class GUNet2DOracle(object):
                 if mod and den_all is not None:
                     den = den_all[:, den_off:den_off + c]
                     den_off += c
-                x = self._unit(x, p, scope, is_training, new_stats, 0.99 if mod else 0.999, sp, den)
+                x = self._unit(x, p, scope, is_training, new_stats, 0.99 if mod else self.encoder_decay, sp, den)
             if i < self.nds:
                 skips.append(x)
                 x = tf_ops.max_pool2x2(x)

@@ -358,3 +358,190 @@ def test_gunet_context_trains_eval_has_no_dropout_and_masks_change_per_step():
     assert min(losses[3:]) < losses[0]
     # FC variables are not L2-regularised (slim.fully_connected has no regulariser in _net_arg_scope, GUNet.py:244-248)
     assert model.params.where["GUNet/context/fc1/weights"][0] == "noreg"
+
+
+# ----------------------------------------------------------------------------- after_affine (GUNetV2.yml, *_AA.yml)
+@pytest.mark.parametrize("per_sample,with_den", [(True, True), (False, True), (False, False)])
+def test_norm_post_shift_without_guide(per_sample, with_den):
+    """gb with guide_ch == 0: z = relu(norm(y) [* den] + gb) -- the kernel form of after_affine (csrc/norm.hip)."""
+    from boxsegliver_amd import ops
+    from oracle import tf_ops
+    n, h, c = 3, 16, 128
+    gen = torch.Generator().manual_seed(3)
+    y = torch.randn(n, h, h, c, generator=gen) + 0.3
+    den = (1.0 + 0.5 * torch.randn(n, c, generator=gen)) if with_den else None
+    gb = 0.3 * torch.randn(c, generator=gen)
+    dz = torch.randn(n, h, h, c, generator=gen)
+    yd = y.cuda()
+    d = ops.norm_desc(y.shape, per_sample, c)
+    flat = yd.reshape(n, h * h, c)
+    stats = torch.stack([flat.sum(1), (flat * flat).sum(1)]).contiguous()
+    aff = ops.norm_finalize(d, stats, n, None, None, 1e-6 if per_sample else 1e-3, 0.99, True, torch.zeros(c).cuda(),
+                            torch.ones(c).cuda(), yd.device)
+    cu = lambda t: None if t is None else t.cuda().contiguous()
+    z = torch.empty_like(yd)
+    ops.norm_apply_relu(d, yd, aff, z, None, None, cu(gb), cu(den))
+    out = ops.norm_relu_bwd(d, yd, cu(dz), aff, False, False, None, None, cu(gb), cu(den))
+    y64, gb64 = y.double().requires_grad_(True), gb.double().requires_grad_(True)
+    den64 = den.double().requires_grad_(True) if with_den else None
+    if per_sample:
+        t = tf_ops.instance_norm(y64, None, None, eps=1e-6)
+    else:
+        t, _, _ = tf_ops.batch_norm(y64, None, None, torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64), True)
+    u = (t * den64[:, None, None, :] if with_den else t) + gb64
+    ref = torch.relu(u)
+    ref.backward(dz.double())
+    assert rel(z.cpu().numpy(), ref.detach().numpy()) < 2e-5
+    assert rel(out[0].cpu().numpy(), y64.grad.numpy()) < 2e-5
+    assert out[3] is None and rel(out[4].cpu().numpy(), gb64.grad.numpy()) < 2e-5
+    if with_den:
+        assert rel(out[5].cpu().numpy(), den64.grad.numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("normalizer,use_spatial,use_context", [("instance_norm", True, True), ("batch_norm", True, False),
+                                                               ("instance_norm", False, True)])
+def test_gunet_after_affine_matches_oracle(normalizer, use_spatial, use_context):
+    """ext_config/GUNetV2.yml: norm without centre / scale on the modulated levels, channel-wise affine after the
+    modulation of every encoder unit (GUNet.py:213-214, 317-320)."""
+    import yaml
+    from pathlib import Path
+    from boxsegliver_amd import ops
+    from boxsegliver_amd.NetworksV2.GUNet import GUNet
+    from boxsegliver_amd.data.synthetic import make_batch, make_guide
+    cfg = yaml.safe_load((Path(ops.__file__).parent / "NetworksV2" / "ext_config" / "GUNetV2.yml").read_text())
+    assert cfg["after_affine"] is True and cfg["context_fc_channels"] == [200, 200]
+    yml = dict(cfg, build_metrics=True, build_summaries=False)
+    args = make_args(normalizer=normalizer, use_spatial=use_spatial, use_context=use_context, side_dropout=0.0)
+    images, labels, _ = make_batch(2, 32, 32, 3, 3, 1234)
+    guide = make_guide(labels, args.guide_channel, 1234)
+    gen = torch.Generator().manual_seed(9)
+    context = torch.rand(2, 12, generator=gen)
+    model = GUNet(args)
+    inputs = {"images": torch.from_numpy(images).cuda(), "labels": torch.from_numpy(labels).cuda(),
+              "sp_guide": torch.from_numpy(guide).cuda(), "context": context.cuda()}
+    model(inputs, "eval", **yml)
+    net = gunet2d.GUNet2DOracle(3, 3, guide_channel=1, normalizer=normalizer, norm_with_center=False, norm_with_scale=False,
+                                use_spatial=use_spatial, context_length=12 if use_context else None,
+                                context_fc_channels=(200, 200), after_affine=True)
+    assert [(n, tuple(s), k) for n, s, k in net.specs] == [(n, tuple(s), k) for n, s, k in model.params.specs]
+    names = list(model.params.state_dict())
+    assert "GUNet/Encode/down_conv1/mod_conv1/ChannelWiseAffine/gamma" in names
+    ns = "BatchNorm" if normalizer == "batch_norm" else "InstanceNorm"
+    assert "GUNet/Encode/down_conv2/mod_conv1/{}/beta".format(ns) not in names
+    assert "GUNet/Encode/down_conv1/mod_conv1/{}/beta".format(ns) in names          # level 0 keeps its own centre / scale
+    params = {}
+    for name, t in model.params.state_dict().items():
+        kind = net.kinds[name]
+        if kind == "gamma":
+            params[name] = 0.5 + torch.rand(t.shape, generator=gen)
+        elif kind in ("beta", "bias", "fc_b"):
+            params[name] = 0.2 * torch.randn(t.shape, generator=gen)
+        elif "spatial" in name:
+            params[name] = 0.5 * torch.randn(t.shape, generator=gen)
+        else:
+            params[name] = t.clone()
+    if use_context:
+        params["GUNet/context/fc3/biases"] = params["GUNet/context/fc3/biases"] + 1.0
+    model.params.load_state(params)
+    kw = dict(kwargs_of(args), context=context if use_context else None)
+    total, _, logits, _, new_stats = net.loss_and_grads(params, torch.from_numpy(images), torch.from_numpy(guide),
+                                                        torch.from_numpy(labels).long(), **kw)
+    p64 = {k: v.double() for k, v in params.items()}
+    kw64 = dict(kw, context=context.double() if use_context else None)
+    _, _, _, grads64, _ = net.loss_and_grads(p64, torch.from_numpy(images).double(), torch.from_numpy(guide).double(),
+                                             torch.from_numpy(labels).long(), **kw64)
+    ops.DEBUG_CAPTURE = []
+    try:
+        model.params.zero_grad()
+        loss = model(inputs, "train", **yml)
+        loss.backward()
+        torch.cuda.synchronize()
+        captured = ops.DEBUG_CAPTURE
+    finally:
+        ops.DEBUG_CAPTURE = None
+    assert abs(loss.item() - total.item()) < 1e-4 * max(1.0, abs(total.item()))
+    assert np.abs(model.layers["logits"].cpu().numpy() - logits.numpy()).max() < 1e-3
+    # every unit's backward on identical operands: the folded gains (den * gamma'), guide weights and post-shift
+    units = [c for c in captured if c.get("kind") != "deconv"]
+    assert sum(1 for c in units if c.get("den") is not None) == 10          # all ten encoder units carry the affine
+    assert sum(1 for c in units if c.get("gb") is not None) == 10
+    for c in units:
+        check_unit_backward(c)
+    num = den = 0.0
+    for name in model.params.trainable_names():
+        g = model.params[name].grad.cpu().numpy().astype(np.float64)
+        ref = grads64[name].numpy()
+        l2 = np.linalg.norm(g - ref) / max(np.linalg.norm(ref), 1e-30)
+        assert l2 < (2e-1 if ("conv5" in name or "down_conv5" in name) else 1e-1), (name, l2)
+        num += np.sum((g - ref) ** 2)
+        den += np.sum(ref ** 2)
+    # whole gradient vector; instance norm over the 2x2 / 4x4 levels of this reduced-size net (eps 1e-6, no scale of its
+    # own under after_affine) amplifies single ReLU flips -- the kernels themselves are pinned just above
+    assert (num / den) ** 0.5 < (1e-2 if normalizer == "instance_norm" else 5e-3)
+    for name in names:
+        if "ChannelWiseAffine" in name and "down_conv5" not in name:
+            assert rel(model.params[name].grad.cpu().numpy(), grads64[name].numpy()) < 2e-2, name
+    for name, ref in new_stats.items():
+        np.testing.assert_allclose(model.params[name].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- UNetInter (NetworksV2/UNetInter.py)
+@pytest.mark.parametrize("normalizer", ["batch_norm", "instance_norm"])
+def test_unetinter_matches_oracle_and_trains(normalizer):
+    from boxsegliver_amd.core import models
+    from boxsegliver_amd.core.solver import Solver
+    from boxsegliver_amd.data.synthetic import make_batch, make_guide
+    zoo = {cls.__name__: cls for cls in models.MODEL_ZOO}
+    assert "UNetInter" in zoo
+    args = make_args(normalizer=normalizer, use_spatial=True, guide_channel=1, mid_cat=False)
+    yml = dict(init_channels=64, num_down_samples=4, ret_prob=False, ret_pred=True, build_metrics=True, build_summaries=False)
+    images, labels, _ = make_batch(2, 32, 32, 3, 3, 1234)
+    guide = make_guide(labels, 1, 1234)
+    model = zoo["UNetInter"](args)
+    inputs = {"images": torch.from_numpy(images).cuda(), "labels": torch.from_numpy(labels).cuda(),
+              "sp_guide": torch.from_numpy(guide).cuda()}
+    model(inputs, "eval", **yml)
+    net = gunet2d.GUNet2DOracle(4, 3, guide_channel=1, normalizer=normalizer, name="UNetInter", concat_guide=True,
+                                encoder_decay=0.99)
+    assert [(n, tuple(s), k) for n, s, k in net.specs] == [(n, tuple(s), k) for n, s, k in model.params.specs]
+    assert model.name == "UNetInter" and model.params["UNetInter/Encode/down_conv1/mod_conv1/weights"].shape == (3, 3, 4, 64)
+    gen = torch.Generator().manual_seed(4)
+    params = {}
+    for name, t in model.params.state_dict().items():
+        kind = net.kinds[name]
+        if kind == "gamma":
+            params[name] = 0.5 + torch.rand(t.shape, generator=gen)
+        elif kind in ("beta", "bias"):
+            params[name] = 0.2 * torch.randn(t.shape, generator=gen)
+        else:
+            params[name] = t.clone()
+    model.params.load_state(params)
+    total, _, logits, _, new_stats = net.loss_and_grads(params, torch.from_numpy(images), torch.from_numpy(guide),
+                                                        torch.from_numpy(labels).long(), **kwargs_of(args))
+    p64 = {k: v.double() for k, v in params.items()}
+    _, _, _, grads64, _ = net.loss_and_grads(p64, torch.from_numpy(images).double(), torch.from_numpy(guide).double(),
+                                             torch.from_numpy(labels).long(), **kwargs_of(args))
+    model.params.zero_grad()
+    loss = model(inputs, "train", **yml)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - total.item()) < 1e-4 * max(1.0, abs(total.item()))
+    assert np.abs(model.layers["logits"].cpu().numpy() - logits.numpy()).max() < 1e-3
+    num = den = 0.0
+    for name in model.params.trainable_names():
+        g = model.params[name].grad.cpu().numpy().astype(np.float64)
+        ref = grads64[name].numpy()
+        num += np.sum((g - ref) ** 2)
+        den += np.sum(ref ** 2)
+    assert (num / den) ** 0.5 < 5e-3
+    for name, ref in new_stats.items():                     # encoder BN decay .99, decoder .999
+        np.testing.assert_allclose(model.params[name].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-6)
+    solver = Solver(args)
+    first = model(inputs, "train", **yml)
+    f0 = first.item()
+    solver(first, model)
+    for _ in range(4):
+        solver(model(inputs, "train", **yml), model)
+    assert model(inputs, "train", **yml).item() < f0
+    with pytest.raises(NotImplementedError):
+        zoo["UNetInter"](make_args(use_spatial=True, guide_channel=1, mid_cat=True))(inputs, "eval", **yml)

@@ -192,6 +192,8 @@ def check_unit_backward(c, tol=1e-5):
         z = z * den[:, None, None, :]
     if gw is not None:
         z = z + (c["guide"].detach().cpu().double() @ gw + gb)
+    elif gb is not None:                                   # bare post-shift (after_affine without a guide)
+        z = z + gb
     torch.relu(z).backward(c["dz"].detach().cpu().double())
     if den is not None:
         assert rel(c["dden"].cpu().numpy(), den.grad.numpy()) < tol
@@ -202,6 +204,7 @@ def check_unit_backward(c, tol=1e-5):
         assert rel(c["dbeta"].cpu().numpy(), b.grad.numpy()) < tol
     if gw is not None:
         assert rel(c["dgw"].cpu().numpy(), gw.grad.numpy()) < tol
+    if gb is not None:
         assert rel(c["dgb"].cpu().numpy(), gb.grad.numpy()) < tol
     x = c["x"].detach().cpu().double().contiguous().requires_grad_(True)
     w = c["w"].cpu().double().requires_grad_(True)
