@@ -247,8 +247,7 @@ class GUNet(base.BaseNet):
                             gb = ba
                     x = self._unit(x, scope, spec, out, guide, gw, gb, den)
                 if i < nds:
-                    skips[i] = x
-                    x = ops.MaxPool2x2.apply(x)
+                    x, skips[i] = ops.MaxPoolSkip.apply(x)
                     hh //= 2
                     ww //= 2
 

@@ -146,8 +146,8 @@ class UNet(base.BaseNet):
                 skip_view = ops.alias(cat, 0, (n, hh, ww, c), cat.stride())
                 tensor_out = self._conv_unit(tensor_out, s + "2", out=skip_view)
                 self._layers["Encode{:d}".format(i + 1)] = tensor_out
-                cats[i], skips[i] = cat, tensor_out
-                tensor_out = ops.MaxPool2x2.apply(tensor_out)
+                cats[i] = cat
+                tensor_out, skips[i] = ops.MaxPoolSkip.apply(tensor_out)
                 c *= 2
                 hh //= 2
                 ww //= 2

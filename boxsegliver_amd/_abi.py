@@ -85,7 +85,7 @@ _SIGNATURES = {
     "unetk_fc_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, P]),
     "unetk_fc_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "unetk_maxpool2_fwd": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, P]),
-    "unetk_maxpool2_bwd": (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "unetk_maxpool2_bwd": (c_int, [P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P]),
     "unetk_avgpool2_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "unetk_image_gradients": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "unetk_flip_axpy": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),

@@ -28,8 +28,8 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restri
 }
 
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ x, int xs, const float* __restrict__ p,
-                                                           const float* __restrict__ dp, float* __restrict__ dx, int N,
-                                                           int H, int W, int C) {
+                                                           const float* __restrict__ dp, const float* __restrict__ add,
+                                                           int as, float* __restrict__ dx, int N, int H, int W, int C) {
   const int Ho = H >> 1, Wo = W >> 1, cq_n = C >> 2;
   const int64_t total = (int64_t)N * Ho * Wo * cq_n;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -57,6 +57,14 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
   }
     MPB(x) MPB(y) MPB(z) MPB(w)
 #undef MPB
+    if (add) {   // the skip connection's gradient (the other consumer of x), summed here instead of in a separate pass
+      const float* s = add + pix * as + cq * 4;
+      const float4 s0 = ldg4(s), s1 = ldg4(s + as), s2 = ldg4(s + (int64_t)W * as), s3 = ldg4(s + (int64_t)W * as + as);
+      o0.x += s0.x; o0.y += s0.y; o0.z += s0.z; o0.w += s0.w;
+      o1.x += s1.x; o1.y += s1.y; o1.z += s1.z; o1.w += s1.w;
+      o2.x += s2.x; o2.y += s2.y; o2.z += s2.z; o2.w += s2.w;
+      o3.x += s3.x; o3.y += s3.y; o3.z += s3.z; o3.w += s3.w;
+    }
     float* d = dx + pix * C + cq * 4;
     stg4(d, o0);
     stg4(d + C, o1);
@@ -155,14 +163,15 @@ extern "C" int unetk_maxpool2_fwd(const float* x, int x_stride, float* p, int N,
   return UNETK_OK;
 }
 
-extern "C" int unetk_maxpool2_bwd(const float* x, int x_stride, const float* p, const float* dp, float* dx, int N,
-                                  int H, int W, int C, void* stream) {
+extern "C" int unetk_maxpool2_bwd(const float* x, int x_stride, const float* p, const float* dp, const float* add,
+                                  int add_stride, float* dx, int N, int H, int W, int C, void* stream) {
   UNETK_REQUIRE(x && p && dp && dx && N > 0 && H > 1 && W > 1 && C > 0 && x_stride >= C);
   if (C % 4 != 0 || x_stride % 4 != 0 || (H & 1) || (W & 1)) return UNETK_E_UNSUPPORTED;
   UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(p) && unetk_aligned16(dp) && unetk_aligned16(dx));
+  UNETK_REQUIRE(!add || (add_stride >= C && add_stride % 4 == 0 && unetk_aligned16(add)));
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
   hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_stride, p, dp,
-                     dx, N, H, W, C);
+                     add, add_stride, dx, N, H, W, C);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }

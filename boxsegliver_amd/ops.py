@@ -348,10 +348,14 @@ def maxpool2_fwd(x):
     return p
 
 
-def maxpool2_bwd(x, p, dp):
+def maxpool2_bwd(x, p, dp, add=None):
+    """dx = route(dp) [+ add]; `add` may be a channel slice of a wider NHWC buffer (the concat buffer's gradient)."""
     n, h, w, c = x.shape
     dx = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
-    check(_abi.lib().unetk_maxpool2_bwd(ptr(x), _pix_stride(x), ptr(p), ptr(dp.contiguous()), ptr(dx), n, h, w, c,
+    if add is not None:
+        assert tuple(add.shape) == (n, h, w, c) and add.stride(3) == 1
+    check(_abi.lib().unetk_maxpool2_bwd(ptr(x), _pix_stride(x), ptr(p), ptr(dp.contiguous()), ptr(add),
+                                        _pix_stride(add) if add is not None else 0, ptr(dx), n, h, w, c,
                                         stream_ptr()), "maxpool2_bwd")
     return dx
 
@@ -755,6 +759,28 @@ class MaxPool2x2(torch.autograd.Function):
     def backward(ctx, dp):
         x, p = ctx.saved_tensors
         return maxpool2_bwd(x, p, dp)
+
+
+class MaxPoolSkip(torch.autograd.Function):
+    """(p, skip) = (max_pool2d(x), x): the encoder activation feeds both the pool and the skip connection
+    (UNet.py:80-81,93).  Returning the skip from the same node lets the backward sum the two gradients inside the pool
+    backward kernel (dx = route(dp) + dskip, dskip read in place from the concat buffer's gradient) instead of a
+    separate elementwise pass."""
+
+    @staticmethod
+    def forward(ctx, x):
+        p = maxpool2_fwd(x)
+        ctx.save_for_backward(x, p)
+        return p, alias(x)
+
+    @staticmethod
+    def backward(ctx, dp, dskip):
+        x, p = ctx.saved_tensors
+        if dskip is not None and dskip.stride(3) != 1:
+            dskip = dskip.contiguous()
+        if dp is None:
+            return dskip
+        return maxpool2_bwd(x, p, dp, dskip)
 
 
 class DeconvConcat(torch.autograd.Function):

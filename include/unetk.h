@@ -184,11 +184,13 @@ int unetk_fc_bwd(const float* x, const float* w, const float* y, const float* ma
 
 /* ---------------------------------------------------------------- slim.max_pool2d(x, [2,2])  UNet.py:81
  * VALID, stride 2.  x [N,H,W,C] with pixel stride x_stride; p dense [N,H/2,W/2,C].
- * Backward routes dp to the first maximum in window scan order (TF MaxPoolGrad). */
+ * Backward routes dp to the first maximum in window scan order (TF MaxPoolGrad); `add` (nullable, [N,H,W,C] with
+ * pixel stride add_stride) is summed into dx: x's other consumer is the skip connection (UNet.py:93), whose gradient
+ * is the first half of the concat buffer's gradient -- one pass instead of a pool backward plus an add. */
 int unetk_maxpool2_fwd(const float* x, int x_stride, float* p, int N, int H, int W, int C,
                        void* stream);
-int unetk_maxpool2_bwd(const float* x, int x_stride, const float* p, const float* dp, float* dx,
-                       int N, int H, int W, int C, void* stream);
+int unetk_maxpool2_bwd(const float* x, int x_stride, const float* p, const float* dp, const float* add,
+                       int add_stride, float* dx, int N, int H, int W, int C, void* stream);
 /* slim.avg_pool2d(gs, 2) of GUNet's spatial-guide pyramid (GUNet.py:157-158); x, p dense, any C. */
 int unetk_avgpool2_fwd(const float* x, float* p, int N, int H, int W, int C, void* stream);
 /* --img_grad (UNet.py:69-71, GUNet.py:335-338): out [N,H,W,3C] = concat(x, dy, dx) with
