@@ -19,15 +19,19 @@ constexpr int HALO_PIX = HH * HWD;   // 180
 constexpr int CT = 64;
 constexpr size_t WG_LDS_BYTES = 157696;   // 2 stages of the 64x64 panel; also holds the 147 KB reduction scratch
 
-template <int CIT, int COT>
+// Pixel tile TH_ x TW_: 8 x 16 in general; 10 x 12 (STK) for small planes whose width is a multiple of 12 but not of 16
+// (UNet3D's 12^2 / 24^2 levels), where 8 x 16 tiles would be 56 % / 75 % full.
+template <int CIT, int COT, int TH_ = TH, int TW_ = TW>
 struct WgGeom {
   static constexpr int WCI = CIT / 32, WCO = COT / 32;
   static constexpr int KS = 8 / (WCI * WCO);            // pixel-row slices
-  static constexpr int RPW = TH / KS;                   // tile rows per wave
+  static constexpr int RPW = TH_ / KS;                  // tile rows per wave
+  static constexpr int HWD_ = TW_ + 2, HALO_PIX_ = (TH_ + 2) * (TW_ + 2);
   static constexpr int PPX = 256 / CIT;                 // pixels per 1-KiB piece of the x halo
   static constexpr int PPY = 256 / COT;
-  static constexpr int NI_X = (HALO_PIX + PPX - 1) / PPX;   // 45 (CIT 64) / 23 (CIT 32, last piece half dummy)
-  static constexpr int NI_Y = TH * TW / PPY;
+  static constexpr int NI_X = (HALO_PIX_ + PPX - 1) / PPX;  // 45 (CIT 64) / 23 (CIT 32, last piece half dummy)
+  static constexpr int NI_Y = TH_ * TW_ / PPY;
+  static_assert(TH_ % KS == 0 && (TH_ * TW_) % PPY == 0 && TW_ % 2 == 0, "tile shape");
   static constexpr int NI = NI_X + NI_Y;
   static constexpr int IPW = (NI + 7) / 8;
   static constexpr int XH_F = NI_X * 256;
@@ -54,9 +58,16 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 // BF = UNETK_BF16: same staging (fp32 tiles by direct-to-LDS loads); a k-step is one 16-pixel tile row, each lane
 // gathers its 8 pixels (lane half h -> columns 8h..8h+7) of x (10 per filter row: the three kw taps share them) and
 // dy from LDS, rounds them to bf16 and issues v_mfma_f32_32x32x16_bf16: 9 MFMAs of 32 cycles per 38 ds_read_b32.
-template <int CIT, int COT, bool BF>
+//
+// STK ("stacked planes", fp32 only): the planes of the batch are stacked vertically with ONE shared zero row between
+// neighbours -- plane i occupies virtual rows i (H + 1) .. i (H + 1) + H - 1 -- and the tiles walk the virtual rows, so
+// a tile may span two planes and no tile rows are wasted on a 12- or 24-row plane (the shared row is the bottom padding
+// of one plane and the top padding of the next; dy is zero there).
+template <int CIT, int COT, bool BF, int TH_ = TH, int TW_ = TW, bool STK = false>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
-  using G = WgGeom<CIT, COT>;
+  using G = WgGeom<CIT, COT, TH_, TW_>;
+  constexpr int HWD_ = G::HWD_;
+  static_assert(!(BF && STK), "stacked tiles are fp32 only");
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][STAGE_F]
 
   const int tid = threadIdx.x;
@@ -80,27 +91,39 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
     const int j = wave + 8 * i;
     if (j < G::NI_X) {
       const int pix = G::PPX * j + lpx;
-      rel_h[i] = pix < HALO_PIX ? pix / HWD - 1 : (1 << 20);
-      rel_w[i] = pix % HWD - 1;
+      rel_h[i] = pix < G::HALO_PIX_ ? pix / HWD_ - 1 : (1 << 20);
+      rel_w[i] = pix % HWD_ - 1;
     } else {
       const int pix = G::PPY * (j - G::NI_X) + lpy;
-      rel_h[i] = pix >> 4;
-      rel_w[i] = pix & 15;
+      rel_h[i] = pix / TW_;
+      rel_w[i] = pix % TW_;
     }
   }
 
   auto issue_tile = [&](int tile, int stage) {
     const int tw_i = tile % p.tiles_w;
-    const int th_i = (tile / p.tiles_w) % p.tiles_h;
-    const int n_img = tile / (p.tiles_w * p.tiles_h);
-    const int h0 = th_i * TH, w0 = tw_i * TW;
-    const int64_t ximg = p.xa.off(n_img), yimg = p.ya.off(n_img);
+    const int th_i = STK ? tile / p.tiles_w : (tile / p.tiles_w) % p.tiles_h;
+    const int n_tile = STK ? 0 : tile / (p.tiles_w * p.tiles_h);
+    const int h0 = th_i * TH_, w0 = tw_i * TW_;
+    int64_t ximg = 0, yimg = 0;
+    if (!STK) { ximg = p.xa.off(n_tile); yimg = p.ya.off(n_tile); }
 #pragma unroll
     for (int i = 0; i < G::IPW; ++i) {
       const int j = wave + 8 * i;
       if (j < G::NI) {   // wave-uniform
-        const int gh = h0 + rel_h[i], gw = w0 + rel_w[i];
-        const bool ok = gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+        int gh = h0 + rel_h[i];
+        const int gw = w0 + rel_w[i];
+        bool ok;
+        if (STK) {   // virtual row -> (plane, row); row == H is the shared zero row
+          const int v = gh < 0 ? 0 : gh;
+          const int n_img = v / (p.H + 1);
+          const int r = v - n_img * (p.H + 1);
+          ok = gh >= 0 && gh < (1 << 20) && n_img < p.N && r < p.H && gw >= 0 && gw < p.W;
+          gh = r;
+          if (ok) { ximg = p.xa.off(n_img); yimg = p.ya.off(n_img); }
+        } else {
+          ok = gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+        }
         const int64_t pixoff = (int64_t)gh * p.W + gw;
         const float* src = (j < G::NI_X) ? p.x + ximg + pixoff * p.xs + ci0 + qx * 4
                                           : p.dy + yimg + pixoff * p.ys + co0 + qy * 4;
@@ -154,15 +177,15 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
         continue;
       }
 #pragma unroll
-      for (int c2 = 0; c2 < TW / 2; ++c2) {
+      for (int c2 = 0; c2 < TW_ / 2; ++c2) {
         const int col = 2 * c2 + h;
-        const float b = dyt[(r * TW + col) * COT + b_lane];
-        const float* xa = &xh[(r * HWD + col) * CIT + a_lane];
+        const float b = dyt[(r * TW_ + col) * COT + b_lane];
+        const float* xa = &xh[(r * HWD_ + col) * CIT + a_lane];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
-            const float a = xa[(kh * HWD + kw) * CIT];
+            const float a = xa[(kh * HWD_ + kw) * CIT];
             acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[kh * 3 + kw], 0, 0, 0);
           }
       }
@@ -392,19 +415,29 @@ int unetk_launch_slab_reduce(const float* slab, int S, int64_t n, float* dst, hi
 
 namespace {
 
+constexpr int STH = 10, STW = 12;   // stacked-plane tile
+
 struct WgPlan {
-  int mode;  // 0 mfma, 1 small-Cin, -1 unsupported
+  int mode;  // 0 mfma, 1 small-Cin, 2 mfma on stacked planes, -1 unsupported
   int cit, cot;
   int tiles_h, tiles_w, total_tiles, S, tiles_per_split, n_ci_tiles, n_co_tiles;
 };
 
-WgPlan wg_plan(int N, int H, int W, int Cin, int Cout) {
+WgPlan wg_plan(int N, int H, int W, int Cin, int Cout, bool bf16 = false) {
   WgPlan pl{};
   pl.tiles_h = (H + TH - 1) / TH;
   pl.tiles_w = (W + TW - 1) / TW;
   pl.total_tiles = N * pl.tiles_h * pl.tiles_w;
+  // small planes whose width 8 x 16 tiles fill badly: 10 x 12 tiles over the stacked planes (fp32, 64 x 64 panels)
+  const bool stacked = !bf16 && Cin % 64 == 0 && Cout % 64 == 0 && W % STW == 0 && W % TW != 0 && H <= 64 &&
+                       (int64_t)N * (H + 1) < (1 << 20);
+  if (stacked) {
+    pl.tiles_w = W / STW;
+    pl.tiles_h = (int)(((int64_t)N * (H + 1) + STH - 1) / STH);   // over ALL planes
+    pl.total_tiles = pl.tiles_h * pl.tiles_w;
+  }
   if (Cin % 32 == 0 && Cout % 32 == 0) {
-    pl.mode = 0;
+    pl.mode = stacked ? 2 : 0;
     pl.cit = Cin % 64 == 0 ? 64 : 32;
     pl.cot = Cout % 64 == 0 ? 64 : 32;
     pl.n_ci_tiles = Cin / pl.cit;
@@ -427,9 +460,9 @@ WgPlan wg_plan(int N, int H, int W, int Cin, int Cout) {
   return pl;
 }
 
-template <int CIT, int COT, bool BF>
+template <int CIT, int COT, bool BF, int TH_ = TH, int TW_ = TW, bool STK = false>
 int launch_wgrad(const WgParams& p, int grid, hipStream_t st) {
-  auto kern = conv3x3_wgrad_kernel<CIT, COT, BF>;
+  auto kern = conv3x3_wgrad_kernel<CIT, COT, BF, TH_, TW_, STK>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_BYTES);
@@ -444,13 +477,14 @@ int launch_wgrad(const WgParams& p, int grid, hipStream_t st) {
 }  // namespace
 
 size_t unetk_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout) {
-  const WgPlan pl = wg_plan(N, H, W, Cin, Cout);
+  const WgPlan pl = wg_plan(N, H, W, Cin, Cout, false), pb = wg_plan(N, H, W, Cin, Cout, true);
   if (pl.mode < 0) return 0;
-  return 256 + (size_t)pl.S * 9 * Cin * Cout * sizeof(float);  // 256 B zero page + slabs
+  const int S = pl.S > pb.S ? pl.S : pb.S;                     // either precision
+  return 256 + (size_t)S * 9 * Cin * Cout * sizeof(float);    // 256 B zero page + slabs
 }
 
 int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
-  const WgPlan pl = wg_plan(p.N, p.H, p.W, p.Cin, p.Cout);
+  const WgPlan pl = wg_plan(p.N, p.H, p.W, p.Cin, p.Cout, p.bf16 != 0);
   if (pl.mode < 0) return UNETK_E_UNSUPPORTED;
   if (ws_bytes < unetk_wgrad_ws_bytes(p.N, p.H, p.W, p.Cin, p.Cout)) return UNETK_E_WORKSPACE;
   p.zeros = (const float*)ws;
@@ -460,7 +494,11 @@ int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_
   hipError_t ez = hipMemsetAsync(ws, 0, 256, st);
   if (ez != hipSuccess) return (int)ez;
   int rc = UNETK_OK;
-  if (pl.mode == 0) {
+  if (pl.mode == 2) {
+    if (p.xs % 4 != 0 || p.ys % 4 != 0) return UNETK_E_BADARG;
+    rc = launch_wgrad<64, 64, false, STH, STW, true>(p, pl.S * pl.n_ci_tiles * pl.n_co_tiles, st);
+    if (rc != UNETK_OK) return rc;
+  } else if (pl.mode == 0) {
     if (p.xs % 4 != 0 || p.ys % 4 != 0) return UNETK_E_BADARG;
     const int grid = pl.S * pl.n_ci_tiles * pl.n_co_tiles;
     if (p.bf16) {

@@ -30,6 +30,67 @@ struct PwParams {
   int bf16;           // UNETK_BF16: wp is the bf16 K8 pack
 };
 
+// Epilogue shared by the fp32 and bf16 kernels.  Forward: bias + ReLU + scatter of GEMM row m = input pixel (nn, yy, xx),
+// column n = (tap ab, co) to output pixel (2yy + ab/2, 2xx + ab%2).  The (nn, yy, xx) decomposition is done ONCE per
+// 32-row fragment and advanced incrementally along the fragment's rows (a division per stored element used to cost as
+// much VALU time as the whole K = 128 main loop).
+template <int MODE, int TM, int TN>
+__device__ __forceinline__ void pw_epilogue(const PwParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int l31,
+                                            int h) {
+  if (MODE == 0) {
+    int64_t tapoff[TN];
+    float bv[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int n = n0 + (wn * TN + tn) * 32 + l31;
+      const int ab = n / p.Cout, co = n - ab * p.Cout;
+      bv[tn] = p.bias ? p.bias[co] : 0.f;
+      tapoff[tn] = ((int64_t)(ab >> 1) * 2 * p.W + (ab & 1)) * p.out_stride + p.out_coff + co;
+    }
+    const int HW = p.H * p.W;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int mb = m0 + (wm * TM + tm) * 32 + 4 * h;      // fragment row of register 0
+      int nn = mb / HW;
+      const int rem = mb - nn * HW;
+      int yy = rem / p.W, xx = rem - yy * p.W;
+      int64_t img = p.oa.off(nn);
+      int prev = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int delta = (r & 3) + 8 * (r >> 2);           // mfma32_row(r, h) - 4 h
+        xx += delta - prev;
+        prev = delta;
+        while (xx >= p.W) {
+          xx -= p.W;
+          if (++yy == p.H) {
+            yy = 0;
+            img = p.oa.off(++nn);
+          }
+        }
+        if (mb + delta >= p.M) break;
+        const int64_t ob = img + ((int64_t)(2 * yy) * 2 * p.W + 2 * xx) * p.out_stride;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) p.out[ob + tapoff[tn]] = fmaxf(acc[tm][tn][r] + bv[tn], 0.f);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int n = n0 + (wn * TN + tn) * 32 + l31;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (wm * TM + tm) * 32 + mfma32_row(r, h);
+          if (m >= p.M) continue;
+          float* o = p.out + (int64_t)m * p.Ncols + n;
+          *o = p.accumulate ? *o + acc[tm][tn][r] : acc[tm][tn][r];
+        }
+    }
+  }
+}
+
 // MODE 0: forward (scatter epilogue), MODE 1: dgrad (gather prologue)
 template <int MODE, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(WM* WN * 64) void pw_gemm_kernel(PwParams p) {
@@ -160,34 +221,7 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_gemm_kernel(PwParams p) {
   }
 
   // epilogue
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int n = n0 + (wn * TN + tn) * 32 + l31;
-    int ab = 0, co = n;
-    float bv = 0.f;
-    if (MODE == 0) {
-      ab = n / p.Cout;
-      co = n - ab * p.Cout;
-      bv = p.bias ? p.bias[co] : 0.f;
-    }
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * TM + tm) * 32 + mfma32_row(r, h);
-        if (m >= p.M) continue;
-        if (MODE == 0) {
-          const int xx = m % p.W;
-          const int yy = (m / p.W) % p.H;
-          const int nn = m / (p.W * p.H);
-          const int64_t o = p.oa.off(nn) + ((int64_t)(2 * yy + (ab >> 1)) * 2 * p.W + 2 * xx + (ab & 1)) * p.out_stride;
-          p.out[o + p.out_coff + co] = fmaxf(acc[tm][tn][r] + bv, 0.f);
-        } else {
-          float* o = p.out + (int64_t)m * p.Ncols + n;
-          *o = p.accumulate ? *o + acc[tm][tn][r] : acc[tm][tn][r];
-        }
-      }
-  }
+  pw_epilogue<MODE, TM, TN>(p, acc, m0, n0, wm, wn, l31, h);
 }
 
 // ---- UNETK_BF16 variant: same GEMM, operands rounded to bf16 on their way into LDS (A) / pre-packed bf16
@@ -340,34 +374,7 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_gemm_bf16_kernel(PwParams p) {
     __syncthreads();
   }
 
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int n = n0 + (wn * TN + tn) * 32 + l31;
-    int ab = 0, co = n;
-    float bv = 0.f;
-    if (MODE == 0) {
-      ab = n / p.Cout;
-      co = n - ab * p.Cout;
-      bv = p.bias ? p.bias[co] : 0.f;
-    }
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * TM + tm) * 32 + mfma32_row(r, h);
-        if (m >= p.M) continue;
-        if (MODE == 0) {
-          const int xx = m % p.W;
-          const int yy = (m / p.W) % p.H;
-          const int nn = m / (p.W * p.H);
-          const int64_t o = p.oa.off(nn) + ((int64_t)(2 * yy + (ab >> 1)) * 2 * p.W + 2 * xx + (ab & 1)) * p.out_stride;
-          p.out[o + p.out_coff + co] = fmaxf(acc[tm][tn][r] + bv, 0.f);
-        } else {
-          float* o = p.out + (int64_t)m * p.Ncols + n;
-          *o = p.accumulate ? *o + acc[tm][tn][r] : acc[tm][tn][r];
-        }
-      }
-  }
+  pw_epilogue<MODE, TM, TN>(p, acc, m0, n0, wm, wn, l31, h);
 }
 
 // dpre[pix][co] = dcat[pix][coff+co] * (cat[pix][coff+co] > 0); partial[blk][co] = column sums (bias grad)
