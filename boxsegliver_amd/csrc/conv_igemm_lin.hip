@@ -174,15 +174,29 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
     // scatter epilogue: phase pixel (a, b) -> dx pixel (os a + ooh, os b + oow)
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
+      // (plane, row, column) of the fragment's first row by division, then advanced incrementally: a division per
+      // stored row costs as much VALU time as a good part of the main loop on the small-K layers
+      const int pb = P0 + (wm * TM + tm) * 32 + 4 * h;
+      int plane = pb / HW;
+      const int rem0 = pb - plane * HW;
+      int aa = rem0 / p.W, bb = rem0 - aa * p.W, prev = 0;
+      int64_t img = p.ya.off(plane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int pix = P0 + (wm * TM + tm) * 32 + mfma32_row(r, h);
-        if (pix >= P1) continue;
-        const int plane = pix / HW, rem = pix - plane * HW;
-        const int aa = rem / p.W, bb = rem - aa * p.W;
+        const int delta = (r & 3) + 8 * (r >> 2);   // mfma32_row(r, h) - 4 h
+        bb += delta - prev;
+        prev = delta;
+        while (bb >= p.W) {
+          bb -= p.W;
+          if (++aa == p.H) {
+            aa = 0;
+            img = p.ya.off(++plane);
+          }
+        }
+        if (pb + delta >= P1) break;
         const int hi = p.os * aa + p.ooh[q], wi = p.os * bb + p.oow[q];
         if (hi < 0 || hi >= p.Hd || wi < 0 || wi >= p.Wd) continue;
-        float* yp = p.y + p.ya.off(plane) + ((int64_t)hi * p.Wd + wi) * p.ys + n0 + wn * TN * 32 + l31;
+        float* yp = p.y + img + ((int64_t)hi * p.Wd + wi) * p.ys + n0 + wn * TN * 32 + l31;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
           const float v = acc[tm][tn][r];
@@ -236,12 +250,21 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
   for (int tn = 0; tn < TN; ++tn) ssum[tn] = ssq[tn] = 0.f;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
+    const int pb = P0 + (wm * TM + tm) * 32 + 4 * h;   // first row of the fragment; advanced incrementally (see above)
+    int plane = pb / HW;
+    int rem = pb - plane * HW, prev = 0;
+    int64_t img = p.ya.off(plane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int pix = P0 + (wm * TM + tm) * 32 + mfma32_row(r, h);
-      if (pix < P1) {
-        const int plane = pix / HW, rem = pix - plane * HW;
-        float* yp = p.y + p.ya.off(plane) + (int64_t)rem * p.ys + n0 + wn * TN * 32 + l31;
+      const int delta = (r & 3) + 8 * (r >> 2);
+      rem += delta - prev;
+      prev = delta;
+      while (rem >= HW) {
+        rem -= HW;
+        img = p.ya.off(++plane);
+      }
+      if (pb + delta < P1) {
+        float* yp = p.y + img + (int64_t)rem * p.ys + n0 + wn * TN * 32 + l31;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
           float v = acc[tm][tn][r];

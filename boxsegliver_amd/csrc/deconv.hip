@@ -455,20 +455,31 @@ __global__ __launch_bounds__(256) void deconv_wgrad_kernel(DwParams p) {
   // register prefetch: the next 128-pixel tile is in flight while the MFMAs of the current one run
   constexpr int LR = KT * (CT / 4) / 256;   // 8 float4 of each operand per thread
   float4 va[LR], vb[LR];
+  // thread -> rows (tid >> 4) + 16 i of the tile, float4 q = tid & 15.  The pixel decomposition is done once per tile
+  // and advanced by 16 per row: with a division per row the kernel was VALU-bound (5 divisions x 8 rows per 64 MFMAs).
+  const int HWp = p.H * p.W;
   auto load_tile = [&](int mt) {
+    const int m_first = mt + (tid >> 4), q = tid & 15;
+    int nn = m_first / HWp;
+    const int rem = m_first - nn * HWp;
+    int yy = rem / p.W, xx = rem - yy * p.W;
+    int64_t img = p.da.off(nn);
 #pragma unroll
     for (int i = 0; i < LR; ++i) {
-      const int idx = tid + i * 256;
-      const int row = idx >> 4, q = idx & 15;
-      const int m = mt + row;
+      const int m = m_first + 16 * i;
       va[i] = vb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < me) {
-        const int xx = m % p.W;
-        const int yy = (m / p.W) % p.H;
-        const int nn = m / (p.W * p.H);
-        const int64_t o = p.da.off(nn) + ((int64_t)(2 * yy + (ab >> 1)) * 2 * p.W + 2 * xx + (ab & 1)) * p.Cout;
+        const int64_t o = img + ((int64_t)(2 * yy + (ab >> 1)) * 2 * p.W + 2 * xx + (ab & 1)) * p.Cout;
         if (co0 + q * 4 < p.Cout) va[i] = ldg4(p.dpre + o + co0 + q * 4);      // Cout may be 32: half a co tile
         vb[i] = ldg4(p.x + (int64_t)m * p.Cin + ci0 + q * 4);
+      }
+      xx += 16;
+      while (xx >= p.W) {
+        xx -= p.W;
+        if (++yy == p.H) {
+          yy = 0;
+          img = p.da.off(++nn);
+        }
       }
     }
   };
