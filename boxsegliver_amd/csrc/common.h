@@ -107,10 +107,16 @@ struct WgParams {
   int tiles_h, tiles_w, total_tiles, tiles_per_split, n_ci_tiles, n_co_tiles;
   ImgAddr xa, ya;
   int bf16;            // x and dy rounded to bf16 on their way out of LDS, v_mfma_f32_32x32x16_bf16
+  // strided convs (slim.conv3d stride (.,2,2)): H, W are the OUTPUT plane (dy), the input plane is Hin x Win and output
+  // pixel (oh, ow) reads input rows stride*oh - pbh + kh.  stride 0 / 1 = plain conv (Hin = H, Win = W, pb = 1).
+  int stride, Hin, Win, pbh, pbw;
 };
 // conv_wgrad.hip: dw[9][Cin][Cout] = filter gradient of one 2-D tap plane; ws layout as unetk_conv3x3_wgrad
 size_t unetk_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
+// stride-2 variant (p.stride == 2; p.H, p.W = output plane): fp32, Cin % 32 == 0 and Cout % 64 == 0
+bool unetk_wgrad_strided_ok(int Cin, int Cout);
+size_t unetk_wgrad_strided_ws_bytes(int N, int Ho, int Wo, int Cin, int Cout);
 // dst[i] = sum_s slab[s*n + i] in fixed order (n % 4 == 0).
 int unetk_launch_slab_reduce(const float* slab, int S, int64_t n, float* dst, hipStream_t st);
 // dst[k][c] = sum_rows src[k][row][c] (fp64 accumulate).  tmp: K*64*C floats when rows > 256.

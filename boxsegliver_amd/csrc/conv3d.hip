@@ -159,7 +159,12 @@ extern "C" size_t unetk_conv3d_ws_bytes(const unetk_conv3d_desc* d) {
   size_t f = 0;
   if (d->shw == 2) f += (size_t)d->N * g.Do * d->H * d->W * d->Cout;          // stride-1 result / dilated dy
   f = (f + 63) & ~(size_t)63;
-  return f * sizeof(float) + unetk_wgrad_ws_bytes(d->N * g.Do, d->H, d->W, d->Cin, d->Cout);
+  size_t bytes = f * sizeof(float) + unetk_wgrad_ws_bytes(d->N * g.Do, d->H, d->W, d->Cin, d->Cout);
+  if (d->shw == 2) {
+    const size_t sb = unetk_wgrad_strided_ws_bytes(d->N * g.Do, g.Ho, g.Wo, d->Cin, d->Cout);
+    if (sb > bytes) bytes = sb;
+  }
+  return bytes;
 }
 
 extern "C" int unetk_conv3d_fwd(const unetk_conv3d_desc* d, const float* x, const float* wp, float* y,
@@ -348,6 +353,32 @@ extern "C" int unetk_conv3d_wgrad(const unetk_conv3d_desc* d, const float* x, co
   if (ws_bytes < unetk_conv3d_ws_bytes(d)) return UNETK_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const Geo3 g = geo3(d);
+  if (d->shw == 2 && unetk_wgrad_strided_ok(d->Cin, d->Cout)) {
+    // natively strided filter gradient: tiles of OUTPUT pixels, tap (kh, kw) of output (oh, ow) reads input
+    // (2 oh - pb + kh, 2 ow - pb + kw); no zero-dilated copy of dy, a quarter of the MFMA work
+    const int HWx = d->H * d->W * d->x_stride, HWy = g.Ho * g.Wo * d->y_stride;
+    for (int dt = 0; dt < d->kd; ++dt) {
+      int lo, hi;
+      tap_range(d, g, dt, &lo, &hi);
+      float* dw_t = dw + (int64_t)dt * 9 * d->Cin * d->Cout;
+      if (hi < lo) {
+        hipError_t e = hipMemsetAsync(dw_t, 0, (size_t)9 * d->Cin * d->Cout * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+        continue;
+      }
+      WgParams p{};
+      p.x = x + (int64_t)(lo * d->sd - g.pb_d + dt) * HWx;
+      p.dy = dy + (int64_t)lo * HWy;
+      p.N = d->N * (hi - lo + 1); p.H = g.Ho; p.W = g.Wo; p.Cin = d->Cin; p.Cout = d->Cout;
+      p.xs = d->x_stride; p.ys = d->y_stride;
+      p.stride = 2; p.Hin = d->H; p.Win = d->W; p.pbh = same_pb(d->H, 3, 2); p.pbw = same_pb(d->W, 3, 2);
+      p.xa = planes(HWx, hi - lo + 1, d->sd, d->D);
+      p.ya = planes(HWy, hi - lo + 1, 1, g.Do);
+      const int rc = unetk_wgrad_run(p, dw_t, ws, ws_bytes, st);
+      if (rc != UNETK_OK) return rc;
+    }
+    return UNETK_OK;
+  }
   const float* Z;
   int zs;
   int rc = dilated_dy(d, g, dy, ws, st, &Z, &zs);

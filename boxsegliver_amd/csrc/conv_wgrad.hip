@@ -21,12 +21,14 @@ constexpr size_t WG_LDS_BYTES = 157696;   // 2 stages of the 64x64 panel; also h
 
 // Pixel tile TH_ x TW_: 8 x 16 in general; 10 x 12 (STK) for small planes whose width is a multiple of 12 but not of 16
 // (UNet3D's 12^2 / 24^2 levels), where 8 x 16 tiles would be 56 % / 75 % full.
-template <int CIT, int COT, int TH_ = TH, int TW_ = TW>
+// S = 2: stride-2 conv (UNet3D's down-sampling layers): the tile is TH_ x TW_ OUTPUT pixels, its input halo
+// ((TH_-1) 2 + 3) x ((TW_-1) 2 + 3) pixels, and tap (kh, kw) of output pixel (r, c) reads halo pixel (2r + kh, 2c + kw).
+template <int CIT, int COT, int TH_ = TH, int TW_ = TW, int S = 1>
 struct WgGeom {
   static constexpr int WCI = CIT / 32, WCO = COT / 32;
   static constexpr int KS = 8 / (WCI * WCO);            // pixel-row slices
   static constexpr int RPW = TH_ / KS;                  // tile rows per wave
-  static constexpr int HWD_ = TW_ + 2, HALO_PIX_ = (TH_ + 2) * (TW_ + 2);
+  static constexpr int HWD_ = (TW_ - 1) * S + 3, HALO_PIX_ = ((TH_ - 1) * S + 3) * HWD_;
   static constexpr int PPX = 256 / CIT;                 // pixels per 1-KiB piece of the x halo
   static constexpr int PPY = 256 / COT;
   static constexpr int NI_X = (HALO_PIX_ + PPX - 1) / PPX;  // 45 (CIT 64) / 23 (CIT 32, last piece half dummy)
@@ -63,11 +65,11 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 // neighbours -- plane i occupies virtual rows i (H + 1) .. i (H + 1) + H - 1 -- and the tiles walk the virtual rows, so
 // a tile may span two planes and no tile rows are wasted on a 12- or 24-row plane (the shared row is the bottom padding
 // of one plane and the top padding of the next; dy is zero there).
-template <int CIT, int COT, bool BF, int TH_ = TH, int TW_ = TW, bool STK = false>
+template <int CIT, int COT, bool BF, int TH_ = TH, int TW_ = TW, bool STK = false, int S = 1>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
-  using G = WgGeom<CIT, COT, TH_, TW_>;
+  using G = WgGeom<CIT, COT, TH_, TW_, S>;
   constexpr int HWD_ = G::HWD_;
-  static_assert(!(BF && STK), "stacked tiles are fp32 only");
+  static_assert(!(BF && (STK || S != 1)) && !(STK && S != 1), "stacked / strided tiles are fp32 only");
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][STAGE_F]
 
   const int tid = threadIdx.x;
@@ -91,8 +93,8 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
     const int j = wave + 8 * i;
     if (j < G::NI_X) {
       const int pix = G::PPX * j + lpx;
-      rel_h[i] = pix < G::HALO_PIX_ ? pix / HWD_ - 1 : (1 << 20);
-      rel_w[i] = pix % HWD_ - 1;
+      rel_h[i] = pix < G::HALO_PIX_ ? pix / HWD_ : (1 << 20);   // halo coordinates; the tile origin is subtracted below
+      rel_w[i] = pix % HWD_;
     } else {
       const int pix = G::PPY * (j - G::NI_X) + lpy;
       rel_h[i] = pix / TW_;
@@ -111,8 +113,10 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
     for (int i = 0; i < G::IPW; ++i) {
       const int j = wave + 8 * i;
       if (j < G::NI) {   // wave-uniform
-        int gh = h0 + rel_h[i];
-        const int gw = w0 + rel_w[i];
+        const bool is_x = j < G::NI_X;
+        int gh = is_x ? S * h0 - p.pbh + rel_h[i] : h0 + rel_h[i];
+        const int gw = is_x ? S * w0 - p.pbw + rel_w[i] : w0 + rel_w[i];
+        const int ph = (S != 1 && is_x) ? p.Hin : p.H, pw = (S != 1 && is_x) ? p.Win : p.W;
         bool ok;
         if (STK) {   // virtual row -> (plane, row); row == H is the shared zero row
           const int v = gh < 0 ? 0 : gh;
@@ -122,11 +126,10 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
           gh = r;
           if (ok) { ximg = p.xa.off(n_img); yimg = p.ya.off(n_img); }
         } else {
-          ok = gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+          ok = gh >= 0 && gh < ph && gw >= 0 && gw < pw;
         }
-        const int64_t pixoff = (int64_t)gh * p.W + gw;
-        const float* src = (j < G::NI_X) ? p.x + ximg + pixoff * p.xs + ci0 + qx * 4
-                                          : p.dy + yimg + pixoff * p.ys + co0 + qy * 4;
+        const int64_t pixoff = (int64_t)gh * pw + gw;
+        const float* src = is_x ? p.x + ximg + pixoff * p.xs + ci0 + qx * 4 : p.dy + yimg + pixoff * p.ys + co0 + qy * 4;
         if (!ok) src = p.zeros + (lane & 15) * 4;
         float* dst = smem + stage * G::STAGE_F + j * 256;   // wave-uniform; lanes land at dst + lane*16 B
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
       for (int c2 = 0; c2 < TW_ / 2; ++c2) {
         const int col = 2 * c2 + h;
         const float b = dyt[(r * TW_ + col) * COT + b_lane];
-        const float* xa = &xh[(r * HWD_ + col) * CIT + a_lane];
+        const float* xa = &xh[(S * r * HWD_ + S * col) * CIT + a_lane];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -423,6 +426,29 @@ struct WgPlan {
   int tiles_h, tiles_w, total_tiles, S, tiles_per_split, n_ci_tiles, n_co_tiles;
 };
 
+constexpr int S2TH = 4;             // stride-2 tile: 4 x 16 (or 4 x 12) output pixels, 32-channel ci panels
+
+bool wg_strided_ok(int Cin, int Cout) { return Cin % 32 == 0 && Cout % 64 == 0; }
+
+WgPlan wg_plan_strided(int N, int H, int W, int Cin, int Cout) {   // H, W = output plane
+  WgPlan pl{};
+  const int tw = (W % TW != 0 && W % STW == 0) ? STW : TW;
+  pl.mode = tw == STW ? 4 : 3;
+  pl.tiles_h = (H + S2TH - 1) / S2TH;
+  pl.tiles_w = (W + tw - 1) / tw;
+  pl.total_tiles = N * pl.tiles_h * pl.tiles_w;
+  pl.cit = 32; pl.cot = 64;
+  pl.n_ci_tiles = Cin / 32;
+  pl.n_co_tiles = Cout / 64;
+  const int panels = pl.n_ci_tiles * pl.n_co_tiles;
+  int S = (512 + panels - 1) / panels;
+  if (S > pl.total_tiles) S = pl.total_tiles;
+  if (S < 1) S = 1;
+  pl.tiles_per_split = (pl.total_tiles + S - 1) / S;
+  pl.S = (pl.total_tiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
+  return pl;
+}
+
 WgPlan wg_plan(int N, int H, int W, int Cin, int Cout, bool bf16 = false) {
   WgPlan pl{};
   pl.tiles_h = (H + TH - 1) / TH;
@@ -460,9 +486,9 @@ WgPlan wg_plan(int N, int H, int W, int Cin, int Cout, bool bf16 = false) {
   return pl;
 }
 
-template <int CIT, int COT, bool BF, int TH_ = TH, int TW_ = TW, bool STK = false>
+template <int CIT, int COT, bool BF, int TH_ = TH, int TW_ = TW, bool STK = false, int S = 1>
 int launch_wgrad(const WgParams& p, int grid, hipStream_t st) {
-  auto kern = conv3x3_wgrad_kernel<CIT, COT, BF, TH_, TW_, STK>;
+  auto kern = conv3x3_wgrad_kernel<CIT, COT, BF, TH_, TW_, STK, S>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_BYTES);
@@ -483,7 +509,34 @@ size_t unetk_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout) {
   return 256 + (size_t)S * 9 * Cin * Cout * sizeof(float);    // 256 B zero page + slabs
 }
 
+bool unetk_wgrad_strided_ok(int Cin, int Cout) { return wg_strided_ok(Cin, Cout); }
+
+size_t unetk_wgrad_strided_ws_bytes(int N, int Ho, int Wo, int Cin, int Cout) {
+  if (!wg_strided_ok(Cin, Cout)) return 0;
+  const WgPlan pl = wg_plan_strided(N, Ho, Wo, Cin, Cout);
+  return 256 + (size_t)pl.S * 9 * Cin * Cout * sizeof(float);
+}
+
 int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (p.stride == 2) {   // fp32 only: H, W = output plane
+    if (!wg_strided_ok(p.Cin, p.Cout) || p.bf16) return UNETK_E_UNSUPPORTED;
+    if (p.xs % 4 != 0 || p.ys % 4 != 0 || p.pbh < 0 || p.pbh > 1 || p.pbw < 0 || p.pbw > 1) return UNETK_E_BADARG;
+    if (p.Hin < 2 * p.H - 1 || p.Hin > 2 * p.H || p.Win < 2 * p.W - 1 || p.Win > 2 * p.W) return UNETK_E_BADARG;
+    const WgPlan pl = wg_plan_strided(p.N, p.H, p.W, p.Cin, p.Cout);
+    if (ws_bytes < unetk_wgrad_strided_ws_bytes(p.N, p.H, p.W, p.Cin, p.Cout)) return UNETK_E_WORKSPACE;
+    p.zeros = (const float*)ws;
+    p.slab = (float*)ws + 64;
+    p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.total_tiles = pl.total_tiles;
+    p.tiles_per_split = pl.tiles_per_split; p.n_ci_tiles = pl.n_ci_tiles; p.n_co_tiles = pl.n_co_tiles;
+    hipError_t ez = hipMemsetAsync(ws, 0, 256, st);
+    if (ez != hipSuccess) return (int)ez;
+    const int grid = pl.S * pl.n_ci_tiles * pl.n_co_tiles;
+    const int rc = pl.mode == 4 ? launch_wgrad<32, 64, false, S2TH, STW, false, 2>(p, grid, st)
+                                : launch_wgrad<32, 64, false, S2TH, TW, false, 2>(p, grid, st);
+    if (rc != UNETK_OK) return rc;
+    return unetk_launch_slab_reduce((const float*)ws + 64, pl.S, (int64_t)9 * p.Cin * p.Cout, dw, st);
+  }
+  p.stride = 1; p.Hin = p.H; p.Win = p.W; p.pbh = p.pbw = 1;
   const WgPlan pl = wg_plan(p.N, p.H, p.W, p.Cin, p.Cout, p.bf16 != 0);
   if (pl.mode < 0) return UNETK_E_UNSUPPORTED;
   if (ws_bytes < unetk_wgrad_ws_bytes(p.N, p.H, p.W, p.Cin, p.Cout)) return UNETK_E_WORKSPACE;

@@ -43,6 +43,29 @@ def test_stacked_wgrad_on_channel_slices_of_wider_buffers():
     assert rel(dw.double(), w64.grad) < 5e-6
 
 
+@pytest.mark.parametrize("kd,stride,shape", [
+    (3, (1, 2, 2), (2, 5, 48, 48, 64, 128)),      # 4 x 12 output tiles (Wo = 24)
+    (1, (1, 2, 2), (1, 4, 96, 96, 32, 64)),       # 4 x 16 output tiles, 32-channel input panel (UNet3D conv_e1/conv1)
+    (3, (2, 2, 2), (2, 6, 24, 24, 256, 320)),     # bridge: depth stride 2 too, Cout = 5 x 64
+    (3, (1, 2, 2), (1, 3, 23, 21, 64, 64)),       # odd extents: SAME pads 1 before
+    (3, (2, 2, 2), (1, 5, 12, 12, 128, 64)),      # Wo = 6 < tile
+])
+def test_conv3d_strided_wgrad_native(kd, stride, shape):
+    """Stride-2 filter gradient on tiles of output pixels (no zero-dilated dy): csrc/conv_wgrad.hip, S = 2."""
+    from boxsegliver_amd import ops
+    n, d, h, w, cin, cout = shape
+    gen = torch.Generator().manual_seed(h * w + cin)
+    x = torch.randn(n, d, h, w, cin, generator=gen).cuda()
+    desc = ops.conv3d_desc(x.shape, cout, kd, stride)
+    do, ho, wo = -(-d // stride[0]), -(-h // stride[1]), -(-w // stride[2])
+    dy = torch.randn(n, do, ho, wo, cout, generator=gen).cuda()
+    dw = ops.conv3d_wgrad(x, dy, desc)
+    w64 = torch.zeros(kd, 3, 3, cin, cout, dtype=torch.float64, device="cuda", requires_grad=True)
+    tf_ops.conv_nd_same(x.double(), w64, stride).backward(dy.double())
+    assert rel(dw.double(), w64.grad) < 5e-6
+    assert torch.equal(dw, ops.conv3d_wgrad(x, dy, desc))
+
+
 @pytest.mark.parametrize("kd,stride", [(3, (1, 1, 1)), (3, (1, 2, 2)), (1, (1, 1, 1))])
 def test_conv3d_wgrad_on_12x12_and_24x24_planes(kd, stride):
     from boxsegliver_amd import ops
