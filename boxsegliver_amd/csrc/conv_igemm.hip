@@ -342,9 +342,12 @@ int launch_igemm(const ConvParams& p, int n_mtiles, hipStream_t st) {
 
 }  // namespace
 
-// H, W = OUTPUT extent; stride 2 always takes the tiled kernel (8-row tiles).
+// H, W = OUTPUT extent; stride 2 always takes the tiled kernel.  Cout % 128 == 0: 4-row tiles -- the stride-2 halo of an
+// 8-row tile (18 x 34 pixels, 98 KB double-buffered) leaves one block per CU, the 10 x 34 halo of a 4-row tile two
+// (53 -> 69 TFLOP/s on UNet3D's (1,2,2) layers); the 64-wide configuration is better off with 8 rows (measured).
+static int s2_th(int Cout) { return Cout % 128 == 0 ? 4 : 8; }
 int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout, int spg, int stride) {
-  if (stride == 2) return N * ((H + 7) / 8) * ((W + TW - 1) / TW);
+  if (stride == 2) return N * ((H + s2_th(Cout) - 1) / s2_th(Cout)) * ((W + TW - 1) / TW);
   if (unetk_conv_lin_ok(N, H, W, Cin, Cout, spg)) return unetk_conv_stat_rows_lin(N, H, W, spg);
   const ConvCfg cfg = pick_cfg(Cin, Cout);
   return N * ((H + cfg.th - 1) / cfg.th) * ((W + TW - 1) / TW);
@@ -355,13 +358,13 @@ bool unetk_conv_stride2_ok(int Cin, int Cout) { return Cin % CK == 0 && Cout % 6
 int unetk_conv_run(ConvParams p, hipStream_t st) {
   if (p.stride == 2) {   // p.H x p.W = output extent, p.Hin x p.Win = input extent
     if (p.bf16 || !unetk_conv_stride2_ok(p.Cin, p.Cout) || p.xs % 4 != 0) return UNETK_E_UNSUPPORTED;
-    p.tiles_h = (p.H + 7) / 8;
+    p.tiles_h = (p.H + s2_th(p.Cout) - 1) / s2_th(p.Cout);
     p.tiles_w = (p.W + TW - 1) / TW;
     const int n_mt = p.N * p.tiles_h * p.tiles_w;
     p.stat_rows = n_mt;
     if (p.Cout % 128 == 0) {
       p.n_ntiles = p.Cout / 128;
-      return launch_igemm<2, 2, 2, 2, 2>(p, n_mt, st);
+      return launch_igemm<2, 2, 1, 2, 2>(p, n_mt, st);
     }
     p.n_ntiles = p.Cout / 64;
     return launch_igemm<4, 1, 1, 2, 2>(p, n_mt, st);
