@@ -303,8 +303,7 @@ def batches(store, data_list, config, training, seed=1234, liver_percent=0., tum
 
 def input_fn(mode, params):
     """input_pipeline.py:199-241 for the modes train / eval_online; params["lits_root"] holds png/, meta.json,
-    k_folds.txt.  (Offline volume evaluation: data/synthetic.input_fn_eval_volumes shows the contract; a LiTS-backed
-    eval generator is the remaining part of SURVEY.md 8f2.)"""
+    k_folds.txt.  Offline volume evaluation: `input_fn_eval` below."""
     args = params["args"]
     root = params["lits_root"]
     device = params.get("device", torch.device("cuda", torch.cuda.current_device()))
@@ -326,3 +325,204 @@ def input_fn(mode, params):
         n = int(getattr(args, "eval_num_batches_per_epoch", 100))
         return (next(gen) for _ in range(n))
     raise ValueError("lits.input_fn handles the modes `train` and `eval_online`, got {}".format(mode))
+
+
+def input_fn_eval(mode, params):
+    """input_pipeline.py:228-234 for ModeKeys.EVAL / PREDICT: a python generator over the NIfTI volumes of the validation
+    fold (paths in meta.json's vol_case / lab_case, relative to params["proj_root"]).  No device work here: the
+    evaluator uploads each slab and does mirroring / accumulation / argmax on the GPU (evaluators/evaluator_liver.py)."""
+    args = params["args"]
+    cases = collect_datasets(params["lits_root"], args.test_fold, mode, filter_tumor_size=getattr(args, "filter_size", 0),
+                             filter_only_liver_in_val=params.get("filter_only_liver_in_val", True))
+    if len(cases) == 0:
+        raise ValueError("No valid dataset found!")
+    proj_root = params.get("proj_root", ".")
+    if getattr(args, "eval_in_patches", False):
+        raise NotImplementedError("--eval_in_patches (sliding-window evaluation) is not built")
+    if params.get("whole_slices", False):
+        return get_dataset_for_eval_image(cases, args, proj_root)
+    return get_dataset_for_eval_image_v2(cases, args, proj_root)
+
+
+# ------------------------------------------------------------------------------------------------- offline evaluation
+GRAY_MIN, GRAY_MAX = -200, 250       # input_pipeline.py:45-46
+
+
+def cv2_resize_linear(img, dsize):
+    """cv2.resize(img, dsize, interpolation=cv2.INTER_LINEAR) for float arrays [H, W] or [H, W, C]; dsize = (width, height).
+    OpenCV's rule: source coordinate (dst + 0.5) * (src / dst) - 0.5, taps clamped to the image (border replicate)."""
+    dw, dh = int(dsize[0]), int(dsize[1])
+    img = np.asarray(img, np.float32)
+    sh, sw = img.shape[:2]
+
+    def taps(dst_n, src_n):
+        s = (np.arange(dst_n, dtype=np.float64) + 0.5) * (src_n / float(dst_n)) - 0.5
+        i0 = np.floor(s).astype(np.int64)
+        f = (s - i0).astype(np.float32)
+        lo = i0 < 0
+        i0[lo], f[lo] = 0, 0.0
+        hi = i0 >= src_n - 1
+        i0[hi], f[hi] = src_n - 1, 0.0
+        return i0, np.minimum(i0 + 1, src_n - 1), f
+
+    if (sh, sw) == (dh, dw):
+        return img.copy()
+    y0, y1, fy = taps(dh, sh)
+    x0, x1, fx = taps(dw, sw)
+    ex = (Ellipsis,) if img.ndim == 2 else (Ellipsis, None)
+    rows = img[y0] * (1.0 - fy)[(slice(None), None) + ((None,) if img.ndim == 3 else ())] + \
+        img[y1] * fy[(slice(None), None) + ((None,) if img.ndim == 3 else ())]
+    fxb = fx[(None, slice(None)) + ((None,) if img.ndim == 3 else ())]
+    del ex
+    return (rows[:, x0] * (1.0 - fxb) + rows[:, x1] * fxb).astype(np.float32)
+
+
+def parse_case_eval(case, align, padding, padding_z, im_channel, parse_label=True, test_data=False, proj_root="."):
+    """input_pipeline.py:556-612: the liver box (+ padding, sides rounded up to `align`) of one NIfTI case ->
+    normalised float32 volume (y, x, z) with the half-channel context slices, cropped uint8 segmentation (z, y, x)."""
+    from . import nii_kits
+    d, h, w = case["size"]
+    z1 = max(case["bbox"][0] - padding_z, 0)
+    z2 = min(case["bbox"][3] + padding_z, d)
+    y1 = max(case["bbox"][1] - padding, 0)
+    x1 = max(case["bbox"][2] - padding, 0)
+    y2 = min(case["bbox"][4] + padding, h)
+    x2 = min(case["bbox"][5] + padding, w)
+    cy = (y1 + y2 - 1) / 2
+    cx = (x1 + x2 - 1) / 2
+    sz_y = int(math.ceil((y2 - y1) / align)) * align
+    sz_x = int(math.ceil((x2 - x1) / align)) * align
+    y1 = max(int(cy - (sz_y - 1) / 2), 0)
+    x1 = max(int(cx - (sz_x - 1) / 2), 0)
+    y2 = min(y1 + sz_y, h)
+    x2 = min(x1 + sz_x, w)
+    if (y2 - y1) % align != 0 or (x2 - x1) % align != 0:
+        y1 = y2 - sz_y
+        x1 = x2 - sz_x
+        if y1 < 0 or x1 < 0:
+            print("\nWarning: bbox aligns with {} failed! point1 ({}, {}) point2 ({}, {})\n".format(align, x1, y1, x2, y2))
+
+    root = Path(proj_root)
+    obj_num = int(case["vol_case"][:-4].split("-")[-1])
+    if test_data:
+        _, volume = nii_kits.read_nii(root / case["vol_case"])
+    else:
+        _, volume = nii_kits.read_lits(obj_num, "vol", root / case["vol_case"])
+    lhc = (im_channel - 1) // 2
+    rhc = im_channel - 1 - lhc
+    left_pad = lhc - z1 if z1 < lhc else 0
+    right_pad = z2 + rhc - d if z2 + rhc > d else 0
+    volume = volume[max(0, z1 - lhc):min(d, z2 + rhc), y1:y2, x1:x2]
+    cd, ch, cw = volume.shape
+    if left_pad > 0 or right_pad > 0:
+        volume = np.concatenate((np.zeros((left_pad, ch, cw), dtype=volume.dtype), volume,
+                                 np.zeros((right_pad, ch, cw), dtype=volume.dtype)), axis=0)
+        cd, ch, cw = volume.shape
+    volume = (np.clip(volume, GRAY_MIN, GRAY_MAX) - GRAY_MIN) / (GRAY_MAX - GRAY_MIN)
+    volume = volume.transpose((1, 2, 0)).astype(np.float32)
+
+    segmentation, lab_case = None, None
+    if parse_label:
+        _, segmentation = nii_kits.read_lits(obj_num, "lab", root / case["lab_case"])
+        segmentation = segmentation.astype(np.uint8)[z1:z2, y1:y2, x1:x2]
+        lab_case = case["lab_case"]
+    bbox = [x1, y1, z1, x2 - 1, y2 - 1, z2 - 1]
+    return case["PID"], case["vol_case"], lab_case, bbox, [d, h, w], [cd, ch, cw], lhc, rhc, volume, segmentation
+
+
+def _mirrored(eval_batch, config):
+    """input_pipeline.py:538-553 (the `random_flip & 3 > 0` test is the reference's, literally)."""
+    if not getattr(config, "eval_mirror", False):
+        return
+    if config.random_flip & 1 > 0:
+        tmp = copy.copy(eval_batch)
+        tmp["images"] = np.flip(tmp["images"], axis=2)
+        tmp["mirror"] = 1
+        yield tmp, None
+    if config.random_flip & 2 > 0:
+        tmp = copy.copy(eval_batch)
+        tmp["images"] = np.flip(tmp["images"], axis=1)
+        tmp["mirror"] = 2
+        yield tmp, None
+    if config.random_flip & 3 > 0:
+        tmp = copy.copy(eval_batch)
+        tmp["images"] = np.flip(np.flip(tmp["images"], axis=2), axis=1)
+        tmp["mirror"] = 3
+        yield tmp, None
+
+
+def get_dataset_for_eval_image_v2(data_list, config, proj_root="."):
+    """input_pipeline.py:615-668: per case the liver box is cut from the NIfTI volume, padded in z to whole batches,
+    resized to the network size, and served as batch_size-slice slabs (each followed by its mirrored copies under
+    --eval_mirror); a case ends with (None, (segmentation, vol_path, pads, bbox, resize))."""
+    align = 16 if getattr(config, "model", "UNet") != "DenseUNet" else 32
+    padding, padding_z = 25, 0
+    batch_size = config.batch_size
+    c = config.im_channel
+    pshape = config.im_height, config.im_width
+    resize = not (config.im_height <= 0 or config.im_width <= 0)
+    for case in data_list[getattr(config, "eval_skip_num", 0):]:
+        pid, vol_path, _, bbox, _, cshape, lhc, rhc, volume, segmentation = parse_case_eval(
+            case, align, padding, padding_z, c, parse_label=getattr(config, "mode", "eval") != "infer", proj_root=proj_root)
+        if not resize:
+            pshape = tuple(cshape[1:])
+        eval_batch = {"images": np.empty((batch_size,) + tuple(pshape) + (c,), dtype=np.float32), "names": pid, "mirror": 0}
+        pads = (batch_size - ((bbox[5] - bbox[2] + 1) % batch_size)) % batch_size
+        if pads > 0:
+            volume = np.concatenate((volume, np.zeros(tuple(cshape[1:]) + (pads,), volume.dtype)), axis=-1)
+        if resize:
+            volume = cv2_resize_linear(volume, pshape)      # dsize = (im_height, im_width), as the reference passes it
+        nb = (volume.shape[-1] - lhc - rhc) // batch_size
+        assert volume.shape[-1] - lhc - rhc == batch_size * nb, "Wrong padding"
+        for idx in range(lhc, volume.shape[-1] - rhc, batch_size):
+            for j in range(batch_size):
+                eval_batch["images"][j] = volume[:, :, idx + j - lhc:idx + j + rhc + 1]
+            yield copy.copy(eval_batch), None
+            for item in _mirrored(eval_batch, config):
+                yield item
+        yield None, (segmentation, vol_path, pads, bbox, resize)
+
+
+def get_dataset_for_eval_image(data_list, config, proj_root=".", test_data=False):
+    """input_pipeline_li.py:398-456: whole slices (no liver crop)."""
+    from . import nii_kits
+    batch_size = config.batch_size
+    c = config.im_channel
+    pshape = config.im_height, config.im_width
+    resize = not (config.im_height <= 0 or config.im_width <= 0)
+    root = Path(proj_root)
+    parse_label = getattr(config, "mode", "eval") != "infer"
+    for case in data_list[getattr(config, "eval_skip_num", 0):]:
+        obj_num = int(case["vol_case"][:-4].split("-")[-1])
+        if test_data:
+            _, volume = nii_kits.read_nii(root / case["vol_case"])
+        else:
+            _, volume = nii_kits.read_lits(obj_num, "vol", root / case["vol_case"])
+        volume = (np.clip(volume, GRAY_MIN, GRAY_MAX) - GRAY_MIN) / (GRAY_MAX - GRAY_MIN)
+        volume = volume.transpose((1, 2, 0)).astype(np.float32)
+        segmentation, seg_path = None, None
+        if parse_label:
+            _, segmentation = nii_kits.read_lits(obj_num, "lab", root / case["lab_case"])
+            segmentation, seg_path = segmentation.astype(np.uint8), case["lab_case"]
+        lhc = (c - 1) // 2
+        rhc = c - 1 - lhc
+        h, w, ori_d = volume.shape
+        if not resize:
+            pshape = (h, w)
+        eval_batch = {"images": np.empty((batch_size,) + tuple(pshape) + (c,), dtype=np.float32), "names": case["PID"],
+                      "mirror": 0}
+        pads = (batch_size - (ori_d % batch_size)) % batch_size
+        volume = np.concatenate((np.zeros((h, w, lhc), volume.dtype), volume, np.zeros((h, w, pads + rhc), volume.dtype)),
+                                axis=-1)
+        d = volume.shape[-1]
+        if resize:
+            volume = cv2_resize_linear(volume, pshape)
+        nb = (d - lhc - rhc) // batch_size
+        assert d - lhc - rhc == batch_size * nb, "Wrong padding"
+        for idx in range(lhc, d - rhc, batch_size):
+            for j in range(batch_size):
+                eval_batch["images"][j] = volume[:, :, idx + j - lhc:idx + j + rhc + 1]
+            yield copy.copy(eval_batch), None
+            for item in _mirrored(eval_batch, config):
+                yield item
+        yield None, (segmentation, seg_path, pads, (0, 0, 0, w - 1, h - 1, ori_d - 1), resize)

@@ -240,6 +240,9 @@ class EvaluateVolume(EvaluateBase):
         def run_pred():
             for features, labels in input_fn(mode, self.params):
                 if features:
+                    # host generators (the reference's contract: numpy slabs, data/lits.input_fn_eval) -> one upload per slab
+                    features = {k: (torch.from_numpy(np.ascontiguousarray(v)).cuda() if isinstance(v, np.ndarray) else v)
+                                for k, v in features.items()}
                     if not restored[0]:
                         restored[0] = True
                         if model.params is None:

@@ -1,0 +1,47 @@
+#!/usr/bin/env bash
+# Regenerate everything profiles/ holds, on the GPU box (run through gpurun from the repo root):
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh'
+# Outputs land in gpurun_out/refresh/ (merged back by gpurun); copy the summaries into profiles/rNN_*.
+# Each step runs to completion before the next starts (&&): a failed GPU step stops the script.
+set -euo pipefail
+ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
+OUT="$ROOT/gpurun_out/refresh"
+mkdir -p "$OUT"
+cd "$ROOT"
+T="timeout -k 10 300"
+
+$T python bench.py --steps 10 --warmup 3 > "$OUT/bench_n1.json"
+echo "bench_n1 done"
+$T python bench.py --steps 10 --warmup 3 --detail --no-cpu-baseline > "$OUT/bench_n1_by_layer.json"
+$T python bench.py --model GUNet --batch 8 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_gunet_bs8.json"
+$T python bench.py --model UNet3D --size 96 --batch 2 --steps 5 --warmup 2 --detail --no-cpu-baseline > "$OUT/bench_unet3d_96_bs2.json"
+$T python bench.py --model UNet3D --size 96 --batch 1 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_unet3d_96_bs1.json"
+echo "fp32 benches done"
+$T python bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_bf16_256_bs32.json"
+$T python bench.py --dtype bf16 --size 512 --batch 8 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_bf16_512_bs8.json"
+$T python bench.py --dtype bf16 --model GUNet --batch 8 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_bf16_gunet_bs8.json"
+echo "bf16 benches done"
+
+# rocprofv3: kernel trace + stats (own run), then the two PMC passes (own runs, kernel-trace only)
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_fp32" -o fp32 -- \
+  python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/prof_fp32.log" 2>&1
+echo "kernel trace fp32 done"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bf16" -o bf16 -- \
+  python3 "$ROOT/bench.py" --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/prof_bf16.log" 2>&1
+echo "kernel trace bf16 done"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- \
+  python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_fetch.log" 2>&1
+echo "pmc fetch done"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o write -- \
+  python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_write.log" 2>&1
+echo "pmc write done"
+cd "$ROOT"
+F=$(find "$OUT/pmc_fetch" -name '*counter_collection.csv' | head -1)
+W=$(find "$OUT/pmc_write" -name '*counter_collection.csv' | head -1)
+python tools/pmc_summary.py "$F" "$W" "$OUT/pmc_traffic.json" | tee "$OUT/pmc_summary.txt"
+cp "$(find "$OUT/prof_fp32" -name '*kernel_stats.csv' | head -1)" "$OUT/bench_kernel_stats.csv"
+cp "$(find "$OUT/prof_bf16" -name '*kernel_stats.csv' | head -1)" "$OUT/bench_bf16_kernel_stats.csv"
+# keep the merge-back small: drop the raw traces
+rm -rf "$OUT/prof_fp32" "$OUT/prof_bf16" "$OUT/pmc_fetch" "$OUT/pmc_write"
+head -8 "$OUT/bench_kernel_stats.csv"
