@@ -175,6 +175,25 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int sub = wm * TM + tm;
+    // y += acc (depth taps of a 3-D conv): ALL old values of the fragment are loaded first, so their latencies overlap
+    // (a load-add-store per row serialises 16 round trips to memory)
+    float prior[16][TN];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) prior[r][tn] = 0.f;
+    if (p.accumulate) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = mfma32_row(r, h);
+        const int gh = h0 + 2 * sub + (i >> 4), gw = w0 + (i & 15);
+        if (gh < p.H && gw < p.W) {
+          const float* yp = p.y + yimg + ((int64_t)gh * p.W + gw) * p.ys + n0 + wn * TN * 32 + l31;
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) prior[r][tn] = yp[tn * 32];
+        }
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = mfma32_row(r, h);
@@ -183,8 +202,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
         float* yp = p.y + yimg + ((int64_t)gh * p.W + gw) * p.ys + n0 + wn * TN * 32 + l31;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-          float v = acc[tm][tn][r];
-          if (p.accumulate) v += yp[tn * 32];
+          const float v = acc[tm][tn][r] + prior[r][tn];
           yp[tn * 32] = v;
           ssum[tn] += v;
           ssq[tn] += v * v;

@@ -24,8 +24,14 @@ constexpr int LIN_MAXPIX = 416;   // staged padded pixels per block (host guaran
 // the UNDILATED dy over 4 / 2 / 2 / 1 taps (p.ntaps entries: halo offset + filter panel) whose result lands on every
 // second dx pixel (p.os, p.ooh, p.oow; p.Hd x p.Wd = dx plane).  Exactly the 9 tap-products of the layer in total,
 // instead of 36 on a zero-dilated dy.
-template <int WM, int WN, int TM, int TN, bool GEN = false>
+// FUSED (with GEN): ONE block computes all four parity classes of its phase pixels -- four accumulator sets, the dy halo
+// of a 16-channel chunk staged once and contracted with all 9 taps (class of tap (kh, kw) = (kh & 1, kw & 1), i.e.
+// 4 + 2 + 2 + 1 taps in a fixed order) -- instead of four blocks that each re-stage the halo for 1..4 taps (the 1- and
+// 2-tap classes were staging-bound).
+template <int WM, int WN, int TM, int TN, bool GEN = false, bool FUSED = false>
 __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvParams p) {
+  static_assert(GEN || !FUSED, "FUSED is a GEN variant");
+  constexpr int NQ = FUSED ? 4 : 1;
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int HALO_F = p.lin_pix * PS;   // LDS is sized per launch for the plane shape: 2-3 resident blocks per CU
@@ -47,8 +53,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int ntile = bid % p.n_ntiles;
   const int mtile_all = bid / p.n_ntiles;
-  const int q = GEN ? (mtile_all & 3) : 0;                      // parity class; its 4 blocks of a tile are neighbours (L2)
-  const int mtile = GEN ? (mtile_all >> 2) : mtile_all;
+  const int q = (GEN && !FUSED) ? (mtile_all & 3) : 0;          // parity class; its 4 blocks of a tile are neighbours (L2)
+  const int mtile = (GEN && !FUSED) ? (mtile_all >> 2) : mtile_all;
   const int n0 = ntile * BN;
 
   const int HW = p.H * p.W, WP = p.W + 2, HP = p.H + 2;
@@ -120,13 +126,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
   }
   const int bbase = (h * BN + wn * TN * 32 + l31) * 4;
 
-  f32x16 acc[TM][TN];
+  f32x16 accq[NQ][TM][TN];
+  f32x16 (&acc)[TM][TN] = accq[0];
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
+  for (int qq = 0; qq < NQ; ++qq)
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accq[qq][tm][tn][r] = 0.f;
 
   const int nchunks = p.Cin / CK;
 
@@ -136,7 +145,89 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
   store_w(0);
   __syncthreads();
 
-  if constexpr (GEN) {
+  if constexpr (GEN && FUSED) {
+    constexpr int NTAPS[4] = {4, 2, 2, 1}, KBASE[4] = {0, 4, 6, 8};
+    int step = 0;
+    for (int c = 0; c < nchunks; ++c) {
+      const float* hb = halo + (c & 1) * HALO_F;
+      const bool more_chunks = c + 1 < nchunks;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+#pragma unroll
+        for (int ti = 0; ti < NTAPS[qq]; ++ti, ++step) {
+          const int k = KBASE[qq] + ti;                      // position in the chunk's 9-step schedule (static)
+          const bool last = k == 8;
+          const int nq = ti + 1 < NTAPS[qq] ? qq : (qq + 1) & 3, nti = ti + 1 < NTAPS[qq] ? ti + 1 : 0;
+          const bool has_next = !last || more_chunks;
+          if (has_next) load_w(last ? c + 1 : c, p.tap_panel[nq][nti]);
+          if (k == 5 && more_chunks) load_halo(c + 1);
+          const float* wb = wbuf + (step & 1) * WB_F;
+          const int toff = ((p.tap_off[qq][ti] >> 2) * WP + (p.tap_off[qq][ti] & 3)) * PS;
+#pragma unroll
+          for (int g = 0; g < CK / 8; ++g) {
+            float4 a[TM], b[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const float4*>(&hb[abase[tm] + toff + 8 * g]);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const float4*>(&wb[bbase + (2 * g * BN + tn * 32) * 4]);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+              for (int tn = 0; tn < TN; ++tn) {
+                accq[qq][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, accq[qq][tm][tn], 0, 0, 0);
+                accq[qq][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, accq[qq][tm][tn], 0, 0, 0);
+                accq[qq][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].z, b[tn].z, accq[qq][tm][tn], 0, 0, 0);
+                accq[qq][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].w, b[tn].w, accq[qq][tm][tn], 0, 0, 0);
+              }
+          }
+          if (has_next) store_w((step + 1) & 1);
+          if (k == 5 && more_chunks) store_halo((c + 1) & 1);
+          __syncthreads();
+        }
+      }
+    }
+    // scatter epilogue, one class after the other: phase pixel (a, b) -> dx pixel (os a + ooh[q], os b + oow[q])
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int pb = P0 + (wm * TM + tm) * 32 + 4 * h;
+        int plane = pb / HW;
+        const int rem0 = pb - plane * HW;
+        int aa = rem0 / p.W, bb = rem0 - aa * p.W, prev = 0;
+        int64_t img = p.ya.off(plane);
+        float* rowp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int delta = (r & 3) + 8 * (r >> 2);
+          bb += delta - prev;
+          prev = delta;
+          while (bb >= p.W) {
+            bb -= p.W;
+            if (++aa == p.H) {
+              aa = 0;
+              img = p.ya.off(++plane);
+            }
+          }
+          const int hi = p.os * aa + p.ooh[qq], wi = p.os * bb + p.oow[qq];
+          const bool ok = pb + delta < P1 && hi >= 0 && hi < p.Hd && wi >= 0 && wi < p.Wd;
+          rowp[r] = ok ? p.y + img + ((int64_t)hi * p.Wd + wi) * p.ys + n0 + wn * TN * 32 + l31 : nullptr;
+        }
+        float prior[16][TN];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) prior[r][tn] = (p.accumulate && rowp[r]) ? rowp[r][tn * 32] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (rowp[r]) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) rowp[r][tn * 32] = accq[qq][tm][tn][r] + prior[r][tn];
+          }
+      }
+    }
+    return;
+  } else if constexpr (GEN) {
     const int ntaps = p.ntaps[q], nsteps = nchunks * ntaps;
     int c = 0, ti = 0;
     for (int s = 0; s < nsteps; ++s) {
@@ -181,6 +272,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
       const int rem0 = pb - plane * HW;
       int aa = rem0 / p.W, bb = rem0 - aa * p.W, prev = 0;
       int64_t img = p.ya.off(plane);
+      float* rowp[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int delta = (r & 3) + 8 * (r >> 2);   // mfma32_row(r, h) - 4 h
@@ -193,16 +285,21 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
             img = p.ya.off(++plane);
           }
         }
-        if (pb + delta >= P1) break;
         const int hi = p.os * aa + p.ooh[q], wi = p.os * bb + p.oow[q];
-        if (hi < 0 || hi >= p.Hd || wi < 0 || wi >= p.Wd) continue;
-        float* yp = p.y + img + ((int64_t)hi * p.Wd + wi) * p.ys + n0 + wn * TN * 32 + l31;
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          const float v = acc[tm][tn][r];
-          yp[tn * 32] = p.accumulate ? yp[tn * 32] + v : v;
-        }
+        const bool ok = pb + delta < P1 && hi >= 0 && hi < p.Hd && wi >= 0 && wi < p.Wd;
+        rowp[r] = ok ? p.y + img + ((int64_t)hi * p.Wd + wi) * p.ys + n0 + wn * TN * 32 + l31 : nullptr;
       }
+      float prior[16][TN];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) prior[r][tn] = (p.accumulate && rowp[r]) ? rowp[r][tn * 32] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (rowp[r]) {
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) rowp[r][tn * 32] = acc[tm][tn][r] + prior[r][tn];
+        }
     }
     return;
   }
@@ -254,6 +351,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
     int plane = pb / HW;
     int rem = pb - plane * HW, prev = 0;
     int64_t img = p.ya.off(plane);
+    float* rowp[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int delta = (r & 3) + 8 * (r >> 2);
@@ -263,13 +361,21 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
         rem -= HW;
         img = p.ya.off(++plane);
       }
-      if (pb + delta < P1) {
-        float* yp = p.y + img + (int64_t)rem * p.ys + n0 + wn * TN * 32 + l31;
+      rowp[r] = pb + delta < P1 ? p.y + img + (int64_t)rem * p.ys + n0 + wn * TN * 32 + l31 : nullptr;
+    }
+    // y += acc: all old values first, so the load latencies overlap (see conv_igemm.hip)
+    float prior[16][TN];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) prior[r][tn] = (p.accumulate && rowp[r]) ? rowp[r][tn * 32] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (rowp[r]) {
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-          float v = acc[tm][tn][r];
-          if (p.accumulate) v += yp[tn * 32];
-          yp[tn * 32] = v;
+          const float v = acc[tm][tn][r] + prior[r][tn];
+          rowp[r][tn * 32] = v;
           ssum[tn] += v;
           ssq[tn] += v * v;
         }
@@ -298,12 +404,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
   }
 }
 
-template <int WM, int WN, int TM, int TN, bool GEN = false>
+template <int WM, int WN, int TM, int TN, bool GEN = false, bool FUSED = false>
 int launch_lin(const ConvParams& p, int n_mtiles, hipStream_t st) {
   constexpr int BN = WN * TN * 32;
   constexpr size_t lds_max = (size_t)(2 * LIN_MAXPIX * PS + 2 * CK * BN) * sizeof(float);
   const size_t lds = (size_t)(2 * p.lin_pix * PS + 2 * CK * BN) * sizeof(float);
-  auto kern = conv3x3_igemm_lin_kernel<WM, WN, TM, TN, GEN>;
+  auto kern = conv3x3_igemm_lin_kernel<WM, WN, TM, TN, GEN, FUSED>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
@@ -336,7 +442,7 @@ int unetk_conv_stat_rows_lin(int N, int H, int W, int spg) {
   return (N / spg) * (int)(((int64_t)spg * H * W + LIN_BM - 1) / LIN_BM);
 }
 
-static int lin_rows_bound(int H, int W) { return (LIN_BM + W - 1) / W + 1 + 2 + 2 * ((LIN_BM + H * W - 1) / (H * W)); }
+static int lin_rows_bound(int H, int W, int bm = LIN_BM) { return (bm + W - 1) / W + 1 + 2 + 2 * ((bm + H * W - 1) / (H * W)); }
 
 // Tap-subset / scatter variant (input gradient of a stride-2 conv): p.H x p.W = dy plane, p.Cin = dy channels,
 // p.Cout = dx channels, p.ntaps / tap_off / tap_panel / os / ooh / oow / Hd / Wd set by the caller.
@@ -349,9 +455,23 @@ int unetk_conv_run_lin_gen(ConvParams p, hipStream_t st) {
   for (int q = 0; q < 4; ++q)
     if (p.ntaps[q] < 1 || p.ntaps[q] > 4) return UNETK_E_BADARG;
   if (p.spg < 1) p.spg = 1;
+  p.stat = nullptr;
+  if (p.ntaps[0] == 4 && p.ntaps[1] == 2 && p.ntaps[2] == 2 && p.ntaps[3] == 1) {
+    // all four classes in one block: 64-pixel blocks x 128 couts, or 128-pixel blocks x 64 couts (128 accumulator
+    // registers either way)
+    const int bm = p.Cout % 128 == 0 ? 64 : 128;
+    const int n_mt = (p.N / p.spg) * (int)(((int64_t)p.spg * p.H * p.W + bm - 1) / bm);
+    p.stat_rows = n_mt;
+    p.lin_pix = lin_rows_bound(p.H, p.W, bm) * (p.W + 2);
+    if (p.Cout % 128 == 0) {
+      p.n_ntiles = p.Cout / 128;
+      return launch_lin<2, 2, 1, 2, true, true>(p, n_mt, st);
+    }
+    p.n_ntiles = p.Cout / 64;
+    return launch_lin<4, 1, 1, 2, true, true>(p, n_mt, st);
+  }
   const int n_mtiles = unetk_conv_stat_rows_lin(p.N, p.H, p.W, p.spg);
   p.stat_rows = n_mtiles;
-  p.stat = nullptr;
   p.lin_pix = lin_rows_bound(p.H, p.W) * (p.W + 2);
   if (p.Cout % 128 == 0) {
     p.n_ntiles = p.Cout / 128;
