@@ -447,7 +447,7 @@ static int lin_rows_bound(int H, int W, int bm = LIN_BM) { return (bm + W - 1) /
 // Tap-subset / scatter variant (input gradient of a stride-2 conv): p.H x p.W = dy plane, p.Cin = dy channels,
 // p.Cout = dx channels, p.ntaps / tap_off / tap_panel / os / ooh / oow / Hd / Wd set by the caller.
 bool unetk_conv_lin_gen_ok(int H, int W, int Cin, int Cout) {
-  return Cin % CK == 0 && Cout % 64 == 0 && lin_rows_bound(H, W) * (W + 2) <= LIN_MAXPIX;
+  return Cin % CK == 0 && Cout % 32 == 0 && lin_rows_bound(H, W) * (W + 2) <= LIN_MAXPIX;
 }
 
 int unetk_conv_run_lin_gen(ConvParams p, hipStream_t st) {
@@ -467,9 +467,14 @@ int unetk_conv_run_lin_gen(ConvParams p, hipStream_t st) {
       p.n_ntiles = p.Cout / 128;
       return launch_lin<2, 2, 1, 2, true, true>(p, n_mt, st);
     }
-    p.n_ntiles = p.Cout / 64;
-    return launch_lin<4, 1, 1, 2, true, true>(p, n_mt, st);
+    if (p.Cout % 64 == 0) {
+      p.n_ntiles = p.Cout / 64;
+      return launch_lin<4, 1, 1, 2, true, true>(p, n_mt, st);
+    }
+    p.n_ntiles = p.Cout / 32;                                     // UNet3D conv_e1/conv1: dx has 32 channels
+    return launch_lin<4, 1, 1, 1, true, true>(p, n_mt, st);
   }
+  if (p.Cout % 64 != 0) return UNETK_E_UNSUPPORTED;
   const int n_mtiles = unetk_conv_stat_rows_lin(p.N, p.H, p.W, p.spg);
   p.stat_rows = n_mtiles;
   p.lin_pix = lin_rows_bound(p.H, p.W) * (p.W + 2);

@@ -455,15 +455,18 @@ WgPlan wg_plan(int N, int H, int W, int Cin, int Cout, bool bf16 = false) {
   pl.tiles_w = (W + TW - 1) / TW;
   pl.total_tiles = N * pl.tiles_h * pl.tiles_w;
   // small planes whose width 8 x 16 tiles fill badly: 10 x 12 tiles over the stacked planes (fp32, 64 x 64 panels)
-  const bool stacked = !bf16 && Cin % 64 == 0 && Cout % 64 == 0 && W % STW == 0 && W % TW != 0 && H <= 64 &&
-                       (int64_t)N * (H + 1) < (1 << 20);
+  const bool stk_ok = !bf16 && Cin % 64 == 0 && Cout % 64 == 0 && W % TW != 0 && H <= 64 && (int64_t)N * (H + 1) < (1 << 20);
+  const bool stacked12 = stk_ok && W % STW == 0;
+  const bool stacked6 = stk_ok && !stacked12 && W % 6 == 0;       // 20 x 6 tiles: UNet3D's 6 x 6 bridge planes
+  const bool stacked = stacked12 || stacked6;
   if (stacked) {
-    pl.tiles_w = W / STW;
-    pl.tiles_h = (int)(((int64_t)N * (H + 1) + STH - 1) / STH);   // over ALL planes
+    const int sth = stacked12 ? STH : 20, stw = stacked12 ? STW : 6;
+    pl.tiles_w = W / stw;
+    pl.tiles_h = (int)(((int64_t)N * (H + 1) + sth - 1) / sth);   // over ALL planes
     pl.total_tiles = pl.tiles_h * pl.tiles_w;
   }
   if (Cin % 32 == 0 && Cout % 32 == 0) {
-    pl.mode = stacked ? 2 : 0;
+    pl.mode = stacked12 ? 2 : (stacked6 ? 5 : 0);
     pl.cit = Cin % 64 == 0 ? 64 : 32;
     pl.cot = Cout % 64 == 0 ? 64 : 32;
     pl.n_ci_tiles = Cin / pl.cit;
@@ -547,9 +550,11 @@ int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_
   hipError_t ez = hipMemsetAsync(ws, 0, 256, st);
   if (ez != hipSuccess) return (int)ez;
   int rc = UNETK_OK;
-  if (pl.mode == 2) {
+  if (pl.mode == 2 || pl.mode == 5) {
     if (p.xs % 4 != 0 || p.ys % 4 != 0) return UNETK_E_BADARG;
-    rc = launch_wgrad<64, 64, false, STH, STW, true>(p, pl.S * pl.n_ci_tiles * pl.n_co_tiles, st);
+    const int grid = pl.S * pl.n_ci_tiles * pl.n_co_tiles;
+    rc = pl.mode == 2 ? launch_wgrad<64, 64, false, STH, STW, true>(p, grid, st)
+                      : launch_wgrad<64, 64, false, 20, 6, true>(p, grid, st);
     if (rc != UNETK_OK) return rc;
   } else if (pl.mode == 0) {
     if (p.xs % 4 != 0 || p.ys % 4 != 0) return UNETK_E_BADARG;

@@ -16,7 +16,8 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", [(6, 12, 12, 64, 128), (5, 24, 24, 128, 64), (3, 10, 36, 64, 64), (7, 7, 12, 64, 64),
-                                            (1, 12, 12, 64, 64), (192, 12, 12, 256, 256), (2, 64, 24, 64, 64)])
+                                            (1, 12, 12, 64, 64), (192, 12, 12, 256, 256), (2, 64, 24, 64, 64),
+                                            (96, 6, 6, 320, 320), (5, 6, 18, 64, 64), (3, 9, 6, 64, 128)])   # 20 x 6 tiles
 def test_stacked_wgrad_matches_float64(n, h, w, cin, cout):
     from boxsegliver_amd import ops
     gen = torch.Generator().manual_seed(n * 100 + h)
