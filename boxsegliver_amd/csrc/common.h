@@ -83,11 +83,12 @@ struct ConvParams {
   int ntaps[4], tap_off[4][4], tap_panel[4][4];
   int ooh[4], oow[4];                    // class q: output pixel (a, b) -> (os a + ooh[q], os b + oow[q])
   int os, Hd, Wd;                        // of an Hd x Wd plane
+  int dil;                               // 2 = rate-2 atrous conv (taps at (2 kh, 2 kw), SAME pad 2); 0 / 1 = dense
 };
 bool unetk_conv_lin_gen_ok(int H, int W, int Cin, int Cout);
 int unetk_conv_run_lin_gen(ConvParams p, hipStream_t st);
 int unetk_conv_run(ConvParams p, hipStream_t st);          // conv_igemm.hip: picks the tile configuration
-int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout, int spg = 1, int stride = 1);
+int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout, int spg = 1, int stride = 1, int dil = 1);
 bool unetk_conv_stride2_ok(int Cin, int Cout);
 // conv_igemm_lin.hip: linear-pixel variant for planes narrower than 32 pixels (same packed filters)
 bool unetk_conv_lin_ok(int N, int H, int W, int Cin, int Cout, int spg);
@@ -110,6 +111,7 @@ struct WgParams {
   // strided convs (slim.conv3d stride (.,2,2)): H, W are the OUTPUT plane (dy), the input plane is Hin x Win and output
   // pixel (oh, ow) reads input rows stride*oh - pbh + kh.  stride 0 / 1 = plain conv (Hin = H, Win = W, pb = 1).
   int stride, Hin, Win, pbh, pbw;
+  int dil;             // 2 = rate-2 atrous conv (slim.conv2d(..., rate=2), SmallUNet's bridge): taps at (2 kh, 2 kw), pad 2
 };
 // conv_wgrad.hip: dw[9][Cin][Cout] = filter gradient of one 2-D tap plane; ws layout as unetk_conv3x3_wgrad
 size_t unetk_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout);

@@ -25,12 +25,15 @@ constexpr int TW = 16;   // spatial tile width
 // (1,2,2) / (2,2,2) layers, UNet3D.py:31-91): tiles walk the p.H x p.W OUTPUT, the staged halo is the
 // (2 TH + 2) x 34 input window starting at 2 h0 - pbh (pad-before 0 on even, 1 on odd input extents), and pixel (r, c)
 // reads tap (kh, kw) at halo (2 r + kh, 2 c + kw): same inner loop, A reads 2-way bank-conflicted (LDS has the slack).
-template <int WM, int WN, int TM, int TN, int S = 1>
+// DIL = 2 (with S = 1): rate-2 atrous conv (slim.conv2d(x, C, 3, rate=2): SmallUNet.py:44-49 bridge / conv_d3): the staged
+// halo grows to (TH + 4) x (TW + 4) and tap (kh, kw) reads it at (2 kh, 2 kw); everything else is unchanged.
+template <int WM, int WN, int TM, int TN, int S = 1, int DIL = 1>
 __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p) {
+  static_assert(S == 1 || DIL == 1, "strided atrous convs are not needed");
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int TH = BM / TW, HH = S * TH + 2;
-  constexpr int HWD = S * TW + 2;
+  constexpr int TH = BM / TW, HH = S * TH + 2 * DIL;
+  constexpr int HWD = S * TW + 2 * DIL;
   constexpr int HALO_PIX = HH * HWD;
   constexpr int HALO_F = HALO_PIX * PS;
   constexpr int WB_F = CK * BN;
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
     const int idx = tid + r * NT;
     const int pix = idx >> 2, q = idx & 3;
     const int hh = pix / HWD, ww = pix - hh * HWD;
-    const int gh = S * h0 - (S == 1 ? 1 : p.pbh) + hh, gw = S * w0 - (S == 1 ? 1 : p.pbw) + ww;
+    const int gh = S * h0 - (S == 1 ? DIL : p.pbh) + hh, gw = S * w0 - (S == 1 ? DIL : p.pbw) + ww;
     const int Hin = S == 1 ? p.H : p.Hin, Win = S == 1 ? p.W : p.Win;
     hok[r] = (idx < HALO_PIX * 4) && gh >= 0 && gh < Hin && gw >= 0 && gw < Win;
     hoff[r] = ximg + ((int64_t)gh * Win + gw) * p.xs + q * 4;
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
       if (t == 5 && more_chunks) load_halo(c + 1);
 
       const float* wb = wbuf + (step & 1) * WB_F;
-      const int toff = ((t / 3) * HWD + (t % 3)) * PS;
+      const int toff = ((t / 3) * DIL * HWD + (t % 3) * DIL) * PS;
 #pragma unroll
       for (int g = 0; g < CK / 8; ++g) {
         float4 a[TM], b[TN];
@@ -338,14 +341,14 @@ inline ConvCfg pick_cfg(int Cin, int Cout) {
   return {-1, 8};
 }
 
-template <int WM, int WN, int TM, int TN, int S = 1>
+template <int WM, int WN, int TM, int TN, int S = 1, int DIL = 1>
 int launch_igemm(const ConvParams& p, int n_mtiles, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int TH = BM / TW;
-  constexpr size_t lds = (2 * (S * TH + 2) * (S * TW + 2) * PS + 2 * CK * BN) * sizeof(float);
+  constexpr size_t lds = (2 * (S * TH + 2 * DIL) * (S * TW + 2 * DIL) * PS + 2 * CK * BN) * sizeof(float);
   static_assert(lds >= 2 * WM * BN * sizeof(float), "stat scratch must fit");
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = conv3x3_igemm_kernel<WM, WN, TM, TN, S>;
+  auto kern = conv3x3_igemm_kernel<WM, WN, TM, TN, S, DIL>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -364,7 +367,8 @@ int launch_igemm(const ConvParams& p, int n_mtiles, hipStream_t st) {
 // 8-row tile (18 x 34 pixels, 98 KB double-buffered) leaves one block per CU, the 10 x 34 halo of a 4-row tile two
 // (53 -> 69 TFLOP/s on UNet3D's (1,2,2) layers); the 64-wide configuration is better off with 8 rows (measured).
 static int s2_th(int Cout) { return Cout % 128 == 0 ? 4 : 8; }
-int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout, int spg, int stride) {
+int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout, int spg, int stride, int dil) {
+  if (dil == 2) return N * ((H + 7) / 8) * ((W + TW - 1) / TW);
   if (stride == 2) return N * ((H + s2_th(Cout) - 1) / s2_th(Cout)) * ((W + TW - 1) / TW);
   if (unetk_conv_lin_ok(N, H, W, Cin, Cout, spg)) return unetk_conv_stat_rows_lin(N, H, W, spg);
   const ConvCfg cfg = pick_cfg(Cin, Cout);
@@ -387,6 +391,20 @@ int unetk_conv_run(ConvParams p, hipStream_t st) {
     p.n_ntiles = p.Cout / 64;
     return launch_igemm<4, 1, 1, 2, 2>(p, n_mt, st);
   }
+  if (p.dil == 2) {      // atrous: tiled fp32 kernel only (SmallUNet's two 32 x 32 levels)
+    if (p.bf16 || p.Cin % CK != 0 || p.Cout % 64 != 0 || p.xs % 4 != 0) return UNETK_E_UNSUPPORTED;
+    p.tiles_h = (p.H + 7) / 8;
+    p.tiles_w = (p.W + TW - 1) / TW;
+    const int n_mt = p.N * p.tiles_h * p.tiles_w;
+    p.stat_rows = n_mt;
+    if (p.Cout % 128 == 0) {
+      p.n_ntiles = p.Cout / 128;
+      return launch_igemm<2, 2, 2, 2, 1, 2>(p, n_mt, st);
+    }
+    p.n_ntiles = p.Cout / 64;
+    return launch_igemm<4, 1, 1, 2, 1, 2>(p, n_mt, st);
+  }
+  if (p.dil > 2 || p.dil < 0) return UNETK_E_UNSUPPORTED;
   if (p.bf16) return unetk_conv_run_bf16(p, st);
   if (p.spg < 1) p.spg = 1;
   if (unetk_conv_lin_ok(p.N, p.H, p.W, p.Cin, p.Cout, p.spg)) return unetk_conv_run_lin(p, st);   // small planes: linear M
@@ -440,6 +458,7 @@ extern "C" int unetk_conv3x3_pack(const float* w, int Cin, int Cout, float* wp_f
 
 extern "C" int unetk_conv3x3_stat_rows(const unetk_conv_desc* d) {
   if (!conv_desc_ok(d)) return UNETK_E_BADARG;
+  if (d->dilation == 2) return unetk_conv_stat_rows(d->N, d->H, d->W, d->Cin, d->Cout, 1, 1, 2);
   if (d->precision == UNETK_BF16) return unetk_conv_stat_rows_bf16(d->N, d->H, d->W, d->Cin, d->Cout);
   return unetk_conv_stat_rows(d->N, d->H, d->W, d->Cin, d->Cout);
 }
@@ -454,6 +473,7 @@ extern "C" int unetk_conv3x3_fwd(const unetk_conv_desc* d, const float* x, const
   ConvParams p{};
   p.bf16 = d->precision == UNETK_BF16;
   p.x = x; p.wp = w; p.y = y; p.stat = stat_partials;
+  p.dil = d->dilation;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.xs = d->x_stride; p.ys = d->y_stride;
   p.xa = unetk_dense_addr(p.H, p.W, p.xs);
   p.ya = unetk_dense_addr(p.H, p.W, p.ys);
@@ -471,6 +491,7 @@ extern "C" int unetk_conv3x3_dgrad(const unetk_conv_desc* d, const float* dy, co
   ConvParams p{};
   p.bf16 = d->precision == UNETK_BF16;
   p.x = dy; p.wp = w; p.y = dx; p.stat = nullptr;
+  p.dil = d->dilation;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cout; p.Cout = d->Cin; p.xs = d->y_stride; p.ys = d->x_stride;
   p.xa = unetk_dense_addr(p.H, p.W, p.xs);
   p.ya = unetk_dense_addr(p.H, p.W, p.ys);

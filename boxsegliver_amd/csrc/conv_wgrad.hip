@@ -23,12 +23,13 @@ constexpr size_t WG_LDS_BYTES = 157696;   // 2 stages of the 64x64 panel; also h
 // (UNet3D's 12^2 / 24^2 levels), where 8 x 16 tiles would be 56 % / 75 % full.
 // S = 2: stride-2 conv (UNet3D's down-sampling layers): the tile is TH_ x TW_ OUTPUT pixels, its input halo
 // ((TH_-1) 2 + 3) x ((TW_-1) 2 + 3) pixels, and tap (kh, kw) of output pixel (r, c) reads halo pixel (2r + kh, 2c + kw).
-template <int CIT, int COT, int TH_ = TH, int TW_ = TW, int S = 1>
+// DIL = 2 (S = 1): rate-2 atrous conv: halo (TH_ + 4) x (TW_ + 4), tap (kh, kw) reads halo pixel (r + 2 kh, c + 2 kw).
+template <int CIT, int COT, int TH_ = TH, int TW_ = TW, int S = 1, int DIL = 1>
 struct WgGeom {
   static constexpr int WCI = CIT / 32, WCO = COT / 32;
   static constexpr int KS = 8 / (WCI * WCO);            // pixel-row slices
   static constexpr int RPW = TH_ / KS;                  // tile rows per wave
-  static constexpr int HWD_ = (TW_ - 1) * S + 3, HALO_PIX_ = ((TH_ - 1) * S + 3) * HWD_;
+  static constexpr int HWD_ = (TW_ - 1) * S + 2 * DIL + 1, HALO_PIX_ = ((TH_ - 1) * S + 2 * DIL + 1) * HWD_;
   static constexpr int PPX = 256 / CIT;                 // pixels per 1-KiB piece of the x halo
   static constexpr int PPY = 256 / COT;
   static constexpr int NI_X = (HALO_PIX_ + PPX - 1) / PPX;  // 45 (CIT 64) / 23 (CIT 32, last piece half dummy)
@@ -65,9 +66,10 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 // neighbours -- plane i occupies virtual rows i (H + 1) .. i (H + 1) + H - 1 -- and the tiles walk the virtual rows, so
 // a tile may span two planes and no tile rows are wasted on a 12- or 24-row plane (the shared row is the bottom padding
 // of one plane and the top padding of the next; dy is zero there).
-template <int CIT, int COT, bool BF, int TH_ = TH, int TW_ = TW, bool STK = false, int S = 1>
+template <int CIT, int COT, bool BF, int TH_ = TH, int TW_ = TW, bool STK = false, int S = 1, int DIL = 1>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
-  using G = WgGeom<CIT, COT, TH_, TW_, S>;
+  using G = WgGeom<CIT, COT, TH_, TW_, S, DIL>;
+  static_assert(DIL == 1 || (!BF && !STK && S == 1), "atrous tiles are plain fp32 tiles");
   constexpr int HWD_ = G::HWD_;
   static_assert(!(BF && (STK || S != 1)) && !(STK && S != 1), "stacked / strided tiles are fp32 only");
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][STAGE_F]
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
-            const float a = xa[(kh * HWD_ + kw) * CIT];
+            const float a = xa[(kh * DIL * HWD_ + kw * DIL) * CIT];
             acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[kh * 3 + kw], 0, 0, 0);
           }
       }
@@ -489,9 +491,9 @@ WgPlan wg_plan(int N, int H, int W, int Cin, int Cout, bool bf16 = false) {
   return pl;
 }
 
-template <int CIT, int COT, bool BF, int TH_ = TH, int TW_ = TW, bool STK = false, int S = 1>
+template <int CIT, int COT, bool BF, int TH_ = TH, int TW_ = TW, bool STK = false, int S = 1, int DIL = 1>
 int launch_wgrad(const WgParams& p, int grid, hipStream_t st) {
-  auto kern = conv3x3_wgrad_kernel<CIT, COT, BF, TH_, TW_, STK, S>;
+  auto kern = conv3x3_wgrad_kernel<CIT, COT, BF, TH_, TW_, STK, S, DIL>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_BYTES);
@@ -508,7 +510,14 @@ int launch_wgrad(const WgParams& p, int grid, hipStream_t st) {
 size_t unetk_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout) {
   const WgPlan pl = wg_plan(N, H, W, Cin, Cout, false), pb = wg_plan(N, H, W, Cin, Cout, true);
   if (pl.mode < 0) return 0;
-  const int S = pl.S > pb.S ? pl.S : pb.S;                     // either precision
+  int S = pl.S > pb.S ? pl.S : pb.S;                           // either precision
+  if (Cin % 64 == 0 && Cout % 64 == 0) {                       // ... or the atrous variant (6-row tiles: more tiles to split)
+    const int panels = (Cin / 64) * (Cout / 64);
+    int sd = (512 + panels - 1) / panels;
+    const int64_t tiles = (int64_t)N * ((H + 5) / 6) * ((W + TW - 1) / TW);
+    if (sd > tiles) sd = (int)tiles;
+    if (sd > S) S = sd;
+  }
   return 256 + (size_t)S * 9 * Cin * Cout * sizeof(float);    // 256 B zero page + slabs
 }
 
@@ -536,6 +545,32 @@ int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_
     const int grid = pl.S * pl.n_ci_tiles * pl.n_co_tiles;
     const int rc = pl.mode == 4 ? launch_wgrad<32, 64, false, S2TH, STW, false, 2>(p, grid, st)
                                 : launch_wgrad<32, 64, false, S2TH, TW, false, 2>(p, grid, st);
+    if (rc != UNETK_OK) return rc;
+    return unetk_launch_slab_reduce((const float*)ws + 64, pl.S, (int64_t)9 * p.Cin * p.Cout, dw, st);
+  }
+  if (p.dil == 2) {      // atrous: 6 x 16 tiles (the 10 x 20 halo of two stages fits LDS), 64 x 64 panels, fp32
+    if (p.bf16 || p.Cin % 64 != 0 || p.Cout % 64 != 0) return UNETK_E_UNSUPPORTED;
+    if (p.xs % 4 != 0 || p.ys % 4 != 0) return UNETK_E_BADARG;
+    p.stride = 1; p.Hin = p.H; p.Win = p.W; p.pbh = p.pbw = 2;
+    WgPlan pl{};
+    pl.tiles_h = (p.H + 5) / 6;
+    pl.tiles_w = (p.W + TW - 1) / TW;
+    pl.total_tiles = p.N * pl.tiles_h * pl.tiles_w;
+    pl.n_ci_tiles = p.Cin / 64; pl.n_co_tiles = p.Cout / 64;
+    const int panels = pl.n_ci_tiles * pl.n_co_tiles;
+    int S = (512 + panels - 1) / panels;
+    if (S > pl.total_tiles) S = pl.total_tiles;
+    if (S < 1) S = 1;
+    pl.tiles_per_split = (pl.total_tiles + S - 1) / S;
+    pl.S = (pl.total_tiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
+    if (ws_bytes < 256 + (size_t)pl.S * 9 * p.Cin * p.Cout * sizeof(float)) return UNETK_E_WORKSPACE;
+    p.zeros = (const float*)ws;
+    p.slab = (float*)ws + 64;
+    p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.total_tiles = pl.total_tiles;
+    p.tiles_per_split = pl.tiles_per_split; p.n_ci_tiles = pl.n_ci_tiles; p.n_co_tiles = pl.n_co_tiles;
+    hipError_t ez = hipMemsetAsync(ws, 0, 256, st);
+    if (ez != hipSuccess) return (int)ez;
+    const int rc = launch_wgrad<64, 64, false, 6, TW, false, 1, 2>(p, pl.S * panels, st);
     if (rc != UNETK_OK) return rc;
     return unetk_launch_slab_reduce((const float*)ws + 64, pl.S, (int64_t)9 * p.Cin * p.Cout, dw, st);
   }
@@ -615,6 +650,7 @@ extern "C" int unetk_conv3x3_wgrad(const unetk_conv_desc* d, const float* x, con
   p.x = x; p.dy = dy;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.xs = d->x_stride; p.ys = d->y_stride;
   p.bf16 = d->precision == UNETK_BF16;     // small-Cin layers (first conv) ignore it: they run the fp32 kernels
+  p.dil = d->dilation;
   p.xa = unetk_dense_addr(p.H, p.W, p.xs);
   p.ya = unetk_dense_addr(p.H, p.W, p.ys);
   return unetk_wgrad_run(p, dw, ws, ws_bytes, (hipStream_t)stream);

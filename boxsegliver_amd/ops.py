@@ -131,13 +131,13 @@ def conv_uses_mfma(cin, cout):
     return cin % 16 == 0 and cout % 32 == 0
 
 
-def conv3x3_fwd(x, w, cout, want_stats=True, y=None, bf16=False):
+def conv3x3_fwd(x, w, cout, want_stats=True, y=None, bf16=False, dilation=1):
     """x NHWC (pixel-strided ok); w = packed filter if conv_uses_mfma(cin, cout) else raw HWIO."""
     _require_cuda(x, w)
     n, h, wd, cin = x.shape
     if y is None:
         y = torch.empty((n, h, wd, cout), dtype=torch.float32, device=x.device)
-    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(x), _pix_stride(y), _abi.BF16 if bf16 else _abi.FP32)
+    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(x), _pix_stride(y), _abi.BF16 if bf16 else _abi.FP32, int(dilation))
     stats = None
     rows = 0
     if want_stats:
@@ -152,23 +152,23 @@ def conv3x3_fwd(x, w, cout, want_stats=True, y=None, bf16=False):
     return y, stats, rows
 
 
-def conv3x3_dgrad(dy, wp_dgrad, cin, x_stride=None, dx=None, bf16=False):
+def conv3x3_dgrad(dy, wp_dgrad, cin, x_stride=None, dx=None, bf16=False, dilation=1):
     _require_cuda(dy, wp_dgrad)
     n, h, wd, cout = dy.shape
     if dx is None:
         dx = torch.empty((n, h, wd, cin), dtype=torch.float32, device=dy.device)
-    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(dx), _pix_stride(dy), _abi.BF16 if bf16 else _abi.FP32)
+    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(dx), _pix_stride(dy), _abi.BF16 if bf16 else _abi.FP32, int(dilation))
     with _Timed(_igemm_tag(cout, cin, bf16, h), 18.0 * n * h * wd * cin * cout, "dgrad {}x{}x{} {}->{}".format(n, h, wd, cout, cin)):
         check(_abi.lib().unetk_conv3x3_dgrad(ctypes.byref(d), ptr(dy), ptr(wp_dgrad), ptr(dx), stream_ptr()),
               "conv3x3_dgrad")
     return dx
 
 
-def conv3x3_wgrad(x, dy, bf16=False):
+def conv3x3_wgrad(x, dy, bf16=False, dilation=1):
     _require_cuda(x, dy)
     n, h, wd, cin = x.shape
     cout = dy.shape[3]
-    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(x), _pix_stride(dy), _abi.BF16 if bf16 else _abi.FP32)
+    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(x), _pix_stride(dy), _abi.BF16 if bf16 else _abi.FP32, int(dilation))
     nbytes = _abi.lib().unetk_conv3x3_wgrad_ws_bytes(ctypes.byref(d))
     if nbytes == 0:
         raise _abi.UnetkError("conv3x3_wgrad: unsupported shape Cin={} Cout={}".format(cin, cout))
@@ -570,9 +570,12 @@ class Conv3x3NormRelu(torch.autograd.Function):
     ReLU (NetworksV2/UNet.py:41-56,79; GUNet.py:162-217 `modulated_conv_block`)."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, moving_mean, moving_var, spec, out, guide, gw, gb, den=None):
+    def forward(ctx, x, w, gamma, beta, moving_mean, moving_var, spec, out, guide, gw, gb, den=None, dilation=1):
         _require_cuda(x, w)
         cin, cout = w.shape[2], w.shape[3]
+        dilation = int(dilation or 1)
+        if dilation != 1 and (bool(getattr(spec, "bf16", False)) or not conv_uses_mfma(cin, cout)):
+            raise _abi.UnetkError("atrous conv (rate {}) needs the fp32 MFMA path (Cin % 16, Cout % 64)".format(dilation))
         if den is not None:
             den = den.contiguous()
         mfma = conv_uses_mfma(cin, cout)
@@ -587,7 +590,7 @@ class Conv3x3NormRelu(torch.autograd.Function):
                                       "(got {}->{})".format(cin, cout))
         plain = spec.kind == "none"
         use_batch_stats = (spec.training or spec.per_sample) and not plain
-        y, stats, rows = conv3x3_fwd(x, wp_f, cout, want_stats=use_batch_stats, bf16=bf16)
+        y, stats, rows = conv3x3_fwd(x, wp_f, cout, want_stats=use_batch_stats, bf16=bf16, dilation=dilation)
         z = out if out is not None else torch.empty_like(y)
         g_ch = 0 if guide is None else guide.shape[-1]
         if g_ch:
@@ -609,6 +612,7 @@ class Conv3x3NormRelu(torch.autograd.Function):
             ctx.wp_d = wp_d
             ctx.need_dx = need_dx
             ctx.bf16 = bf16
+            ctx.dilation = dilation
             ctx.desc = d
             ctx.has = (gamma is not None, beta is not None)
             ctx.w_dbg = w.detach() if DEBUG_CAPTURE is not None else None
@@ -626,14 +630,14 @@ class Conv3x3NormRelu(torch.autograd.Function):
         else:
             dy, dgamma, dbeta, dgw, dgb, dden = norm_relu_bwd(ctx.desc, y, dz, aff, ctx.has[0], ctx.has[1], guide, gw, gb,
                                                               den)
-        dw = conv3x3_wgrad(x, dy, bf16=ctx.bf16)
-        dx = conv3x3_dgrad(dy, ctx.wp_d, x.shape[3], bf16=ctx.bf16) if ctx.need_dx else None
+        dw = conv3x3_wgrad(x, dy, bf16=ctx.bf16, dilation=ctx.dilation)
+        dx = conv3x3_dgrad(dy, ctx.wp_d, x.shape[3], bf16=ctx.bf16, dilation=ctx.dilation) if ctx.need_dx else None
         if DEBUG_CAPTURE is not None:
-            DEBUG_CAPTURE.append(dict(x=x, y=y, gamma=ctx.gb_dbg[0], beta=ctx.gb_dbg[1], aff=aff, dz=dz, dy=dy, dw=dw,
+            DEBUG_CAPTURE.append(dict(x=x, y=y, dilation=ctx.dilation, gamma=ctx.gb_dbg[0], beta=ctx.gb_dbg[1], aff=aff, dz=dz, dy=dy, dw=dw,
                                       dx=dx, dgamma=dgamma, dbeta=dbeta, w=ctx.w_dbg, guide=guide, gw=gw, gb=gb,
                                       dgw=dgw, dgb=dgb, per_sample=bool(ctx.desc.per_sample), bf16=ctx.bf16, den=den,
                                       dden=dden))
-        return dx, dw, dgamma, dbeta, None, None, None, None, None, dgw, dgb, dden
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, dgw, dgb, dden, None
 
 
 class FullyConnected(torch.autograd.Function):

@@ -55,6 +55,8 @@ typedef struct unetk_conv_desc {
   int32_t N, H, W, Cin, Cout;
   int32_t x_stride, y_stride;
   int32_t precision; /* UNETK_FP32 (exact fp32 MFMA) or UNETK_BF16 */
+  int32_t dilation;  /* 0 / 1 = dense 3x3; 2 = slim.conv2d(..., rate=2) (SmallUNet.py:44-49: bridge, conv_d3/conv1):
+                        taps at (2 kh, 2 kw), SAME pads 2.  fp32 only, Cin % 16 == 0 and Cout % 64 == 0 (wgrad: both % 64) */
 } unetk_conv_desc;
 
 /* Arithmetic of the dense contractions.  UNETK_FP32: v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain.

@@ -32,8 +32,9 @@ def same_pad(in_size, k, s):
     return out, before, total - before
 
 
-def conv_nd_same(x, w, stride=None, bias=None):
-    """slim.conv2d / slim.conv3d with padding='SAME'.
+def conv_nd_same(x, w, stride=None, bias=None, dilation=1):
+    """slim.conv2d / slim.conv3d with padding='SAME' (and `rate=dilation` on the spatial axes: tf.nn.convolution pads
+    SAME for the EFFECTIVE kernel (k - 1) * rate + 1, e.g. 2 on each side for a 3x3 rate-2 conv at stride 1).
 
     x: [N, (D,) H, W, Cin]; w: TF filter [(kd,) kh, kw, Cin, Cout].
     """
@@ -48,11 +49,11 @@ def conv_nd_same(x, w, stride=None, bias=None):
     wc = w.permute(nsp + 1, nsp, *range(nsp))
     pads = []
     for d in reversed(range(nsp)):   # F.pad wants last dim first
-        _, pb, pa = same_pad(x.shape[1 + d], ks[d], stride[d])
+        _, pb, pa = same_pad(x.shape[1 + d], (ks[d] - 1) * dilation + 1, stride[d])
         pads += [pb, pa]
     xc = F.pad(xc, pads)
     conv = F.conv2d if nsp == 2 else F.conv3d
-    y = conv(xc, wc, bias=bias, stride=stride)
+    y = conv(xc, wc, bias=bias, stride=stride, dilation=dilation)
     perm_out = (0,) + tuple(range(2, nsp + 2)) + (1,)
     return y.permute(*perm_out).contiguous()
 

@@ -208,7 +208,7 @@ def check_unit_backward(c, tol=1e-5):
         assert rel(c["dgb"].cpu().numpy(), gb.grad.numpy()) < tol
     x = c["x"].detach().cpu().double().contiguous().requires_grad_(True)
     w = c["w"].cpu().double().requires_grad_(True)
-    tf_ops.conv_nd_same(x, w).backward(c["dy"].detach().cpu().double())
+    tf_ops.conv_nd_same(x, w, dilation=c.get("dilation", 1)).backward(c["dy"].detach().cpu().double())
     assert rel(c["dw"].cpu().numpy(), w.grad.numpy()) < tol
     if c["dx"] is not None:
         assert rel(c["dx"].cpu().numpy(), x.grad.numpy()) < tol
