@@ -13,13 +13,14 @@ from ..NetworksV2.GUNet import GUNet
 from ..NetworksV2.UNet import UNet
 from ..NetworksV2.UNet3D import UNet3D
 from ..NetworksV2.UNetInter import UNetInter
+from ..NetworksV2.SmallUNet import SmallUNet
 from ..NetworksV2.base import ModeKeys
 
 # Available models (reference models.py:36-38 lists UNet, GUNet, UNetInter, LGNet, UNet3D, SmallUNet,
-# InterUNet; this build ships UNet, GUNet, UNetInter and UNet3D -- LGNet / SmallUNet / InterUNet need a leaky-ReLU guide
-# branch and dilated convs the kernels do not have.
+# InterUNet; this build ships UNet, GUNet, UNetInter, UNet3D and SmallUNet -- LGNet needs a leaky-ReLU guide branch the
+# norm kernels do not have, InterUNet is a two-encoder composition of SmallUNet's ops.
 MODEL_ZOO = [
-    UNet, GUNet, UNetInter, UNet3D,
+    UNet, GUNet, UNetInter, UNet3D, SmallUNet,
 ]
 
 EstimatorSpec = namedtuple("EstimatorSpec", ["mode", "loss", "train_op", "predictions", "model"])

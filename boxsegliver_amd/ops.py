@@ -804,7 +804,8 @@ class DeconvConcat(torch.autograd.Function):
         ctx.wp_d = wp_d
         ctx.bf16 = bf16
         ctx.cout, ctx.coff = cout, coff
-        ctx.wb_dbg = (w.detach(), b.detach()) if DEBUG_CAPTURE is not None else None
+        ctx.has_b = b is not None            # SmallUNet's conv2d_transpose has biases_initializer=None
+        ctx.wb_dbg = (w.detach(), b.detach() if b is not None else None) if DEBUG_CAPTURE is not None else None
         return alias(cat)
 
     @staticmethod
@@ -816,7 +817,7 @@ class DeconvConcat(torch.autograd.Function):
         if DEBUG_CAPTURE is not None:
             DEBUG_CAPTURE.append(dict(kind="deconv", x=x, w=ctx.wb_dbg[0], b=ctx.wb_dbg[1], cat=cat.clone(),
                                       dcat=dcat, dx=dx, dw=dw, db=db, coff=ctx.coff, bf16=ctx.bf16))
-        return dx, dw, db, dskip, None, None
+        return dx, dw, (db if ctx.has_b else None), dskip, None, None
 
 
 class HeadLoss(torch.autograd.Function):

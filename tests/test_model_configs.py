@@ -14,7 +14,7 @@ CONFIGS = sorted(p.name for p in list(NETS.glob("*.yml")) + list((NETS / "ext_co
 
 def test_registry_matches_reference_names():
     names = [cls.__name__ for cls in models.MODEL_ZOO]
-    assert names == ["UNet", "GUNet", "UNetInter", "UNet3D"]
+    assert names == ["UNet", "GUNet", "UNetInter", "UNet3D", "SmallUNet"]
     parser = argparse.ArgumentParser()
     models.add_arguments(parser)
     ns = parser.parse_args(["--model", "UNetInter", "--classes", "Liver", "Tumor"])
