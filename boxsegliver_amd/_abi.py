@@ -42,7 +42,8 @@ class Deconv3dDesc(Structure):
 
 class NormDesc(Structure):
     _fields_ = [("N", c_int32), ("HW", c_int32), ("C", c_int32), ("per_sample", c_int32), ("z_stride", c_int32),
-                ("guide_ch", c_int32), ("gw_stride", c_int32), ("gw_coff", c_int32), ("affine_only", c_int32)]
+                ("guide_ch", c_int32), ("gw_stride", c_int32), ("gw_coff", c_int32), ("affine_only", c_int32),
+                ("guide_leaky", c_int32)]
 
 
 class HeadDesc(Structure):

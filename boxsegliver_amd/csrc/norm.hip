@@ -100,9 +100,15 @@ struct ApplyArgs {
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
+// LGNet's guide branch (LGNet.py:30-55): the 1x1 guide conv has a leaky-ReLU activation (tf.nn.leaky_relu, alpha 0.2)
+// before it is added: u = t + lrelu(guide . gw + gb) -- template flag L (without density modulation).
+__device__ __forceinline__ float lrelu(float s) { return s > 0.f ? s : 0.2f * s; }
+__device__ __forceinline__ float lrelu_grad(float s) { return s > 0.f ? 1.f : 0.2f; }
+
 // z = relu((y*scale + shift) [* den] [+ guide . gw + gb])
-template <int G, bool D>
+template <int G, bool D, bool L = false>
 __global__ __launch_bounds__(256) void norm_apply_relu_kernel(ApplyArgs a) {
+  static_assert(!(L && (D || G == 0)), "the leaky guide needs a guide and no density gains");
   const int cq = threadIdx.x % a.cq_n, rl = threadIdx.x / a.cq_n;
   if (rl >= a.rpi) return;
   const int n = blockIdx.y;
@@ -114,7 +120,9 @@ __global__ __launch_bounds__(256) void norm_apply_relu_kernel(ApplyArgs a) {
     sh = mul4(sh, dn);
   }
   float4 gwv[G > 0 ? G : 1];
-  if (a.gb) sh = add4(sh, ldg4(a.gb + a.gw_coff + cq * 4));   // guide bias, or a bare post-shift when G == 0
+  float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.gb) gbv = ldg4(a.gb + a.gw_coff + cq * 4);   // guide bias, or a bare post-shift when G == 0
+  if (!L) sh = add4(sh, gbv);
   if (G > 0) {
 #pragma unroll
     for (int g = 0; g < G; ++g) gwv[g] = ldg4(a.gw + (int64_t)g * a.gw_stride + a.gw_coff + cq * 4);
@@ -124,10 +132,20 @@ __global__ __launch_bounds__(256) void norm_apply_relu_kernel(ApplyArgs a) {
     const float4 v = ldg4(a.y + (base + pix) * a.C + cq * 4);
     float4 u;
     u.x = fmaf(v.x, sc.x, sh.x); u.y = fmaf(v.y, sc.y, sh.y); u.z = fmaf(v.z, sc.z, sh.z); u.w = fmaf(v.w, sc.w, sh.w);
+    if (L) {
+      float4 s = gbv;
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const float gg = a.guide[(base + pix) * G + g];
-      u.x = fmaf(gg, gwv[g].x, u.x); u.y = fmaf(gg, gwv[g].y, u.y); u.z = fmaf(gg, gwv[g].z, u.z); u.w = fmaf(gg, gwv[g].w, u.w);
+      for (int g = 0; g < G; ++g) {
+        const float gg = a.guide[(base + pix) * G + g];
+        s.x = fmaf(gg, gwv[g].x, s.x); s.y = fmaf(gg, gwv[g].y, s.y); s.z = fmaf(gg, gwv[g].z, s.z); s.w = fmaf(gg, gwv[g].w, s.w);
+      }
+      u.x += lrelu(s.x); u.y += lrelu(s.y); u.z += lrelu(s.z); u.w += lrelu(s.w);
+    } else {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float gg = a.guide[(base + pix) * G + g];
+        u.x = fmaf(gg, gwv[g].x, u.x); u.y = fmaf(gg, gwv[g].y, u.y); u.z = fmaf(gg, gwv[g].z, u.z); u.w = fmaf(gg, gwv[g].w, u.w);
+      }
     }
     u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
     stg4(a.z + (base + pix) * a.zs + cq * 4, u);
@@ -156,9 +174,10 @@ struct BwdArgs {
 // pass 1.  With dt = du * den (dt = du without density), du = dz * (u > 0), xhat = (y - mean) rstd, t = y*scale + shift:
 //   partial[0] = sum dt, partial[1] = sum dt*xhat, partial[2+g] = sum du*guide_g,
 //   D only: partial[2+G] = sum du (guide bias gradient), partial[3+G] = sum du*t (density gradient, per sample)
-template <int G, bool D>
+//   L only: partial[2+g] = sum du*lrelu'(s)*guide_g, partial[2+G] = sum du*lrelu'(s)  (s = guide . gw + gb)
+template <int G, bool D, bool L = false>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
-  constexpr int K = 2 + G + (D ? 2 : 0);
+  constexpr int K = 2 + G + (D ? 2 : 0) + (L ? 1 : 0);
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [K][rpi][C]
   const int cq = threadIdx.x % a.cq_n, rl = threadIdx.x / a.cq_n;
   const int n = blockIdx.y;
@@ -173,7 +192,9 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
     const float4 sc = D ? mul4(sc0, dn) : sc0;
     float4 sh = D ? mul4(sh0, dn) : sh0;
     float4 gwv[G > 0 ? G : 1];
-    if (a.gb) sh = add4(sh, ldg4(a.gb + a.gw_coff + cq * 4));
+    float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.gb) gbv = ldg4(a.gb + a.gw_coff + cq * 4);
+    if (!L) sh = add4(sh, gbv);
     if (G > 0) {
 #pragma unroll
       for (int g = 0; g < G; ++g) gwv[g] = ldg4(a.gw + (int64_t)g * a.gw_stride + a.gw_coff + cq * 4);
@@ -185,22 +206,36 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
       float4 u;
       u.x = fmaf(v.x, sc.x, sh.x); u.y = fmaf(v.y, sc.y, sh.y); u.z = fmaf(v.z, sc.z, sh.z); u.w = fmaf(v.w, sc.w, sh.w);
       float gg[G > 0 ? G : 1];
+      float4 ls = make_float4(1.f, 1.f, 1.f, 1.f);   // lrelu'(s) of the leaky guide branch
+      if (L) {
+        float4 sg = gbv;
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        gg[g] = a.guide[(base + pix) * G + g];
-        u.x = fmaf(gg[g], gwv[g].x, u.x); u.y = fmaf(gg[g], gwv[g].y, u.y); u.z = fmaf(gg[g], gwv[g].z, u.z); u.w = fmaf(gg[g], gwv[g].w, u.w);
+        for (int g = 0; g < G; ++g) {
+          gg[g] = a.guide[(base + pix) * G + g];
+          sg.x = fmaf(gg[g], gwv[g].x, sg.x); sg.y = fmaf(gg[g], gwv[g].y, sg.y); sg.z = fmaf(gg[g], gwv[g].z, sg.z); sg.w = fmaf(gg[g], gwv[g].w, sg.w);
+        }
+        u.x += lrelu(sg.x); u.y += lrelu(sg.y); u.z += lrelu(sg.z); u.w += lrelu(sg.w);
+        ls = make_float4(lrelu_grad(sg.x), lrelu_grad(sg.y), lrelu_grad(sg.z), lrelu_grad(sg.w));
+      } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          gg[g] = a.guide[(base + pix) * G + g];
+          u.x = fmaf(gg[g], gwv[g].x, u.x); u.y = fmaf(gg[g], gwv[g].y, u.y); u.z = fmaf(gg[g], gwv[g].z, u.z); u.w = fmaf(gg[g], gwv[g].w, u.w);
+        }
       }
 #define NBR(f)                                                                \
   {                                                                           \
     const float du = u.f > 0.f ? d.f : 0.f;                                   \
     const float dt = D ? du * dn.f : du;                                      \
+    const float dg = L ? du * ls.f : du;                                      \
     s[0].f += dt;                                                             \
     s[1].f += dt * ((v.f - mu.f) * rs.f);                                     \
-    _Pragma("unroll") for (int g = 0; g < G; ++g) s[2 + g].f += du * gg[g];  \
+    _Pragma("unroll") for (int g = 0; g < G; ++g) s[2 + g].f += dg * gg[g];  \
     if (D) {                                                                  \
       s[2 + G].f += du;                                                       \
       s[3 + G].f += du * fmaf(v.f, sc0.f, sh0.f);                             \
     }                                                                         \
+    if (L) s[2 + G].f += dg;                                                  \
   }
       NBR(x) NBR(y) NBR(z) NBR(w)
 #undef NBR
@@ -218,7 +253,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
 }
 
 // pass 2: dy = scale * (dt - sum_dt/Ps - xhat * sum_dt_xhat/Ps)   (sums over the STATISTICS group)
-template <int G, bool D>
+template <int G, bool D, bool L = false>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdArgs a) {
   const int cq = threadIdx.x % a.cq_n, rl = threadIdx.x / a.cq_n;
   if (rl >= a.rpi) return;
@@ -230,7 +265,9 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdArgs a) {
   const float4 sc = D ? mul4(sc0, dn) : sc0;
   float4 sh = D ? mul4(sh0, dn) : sh0;
   float4 gwv[G > 0 ? G : 1];
-  if (a.gb) sh = add4(sh, ldg4(a.gb + a.gw_coff + cq * 4));   // guide bias, or a bare post-shift when G == 0
+  float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.gb) gbv = ldg4(a.gb + a.gw_coff + cq * 4);   // guide bias, or a bare post-shift when G == 0
+  if (!L) sh = add4(sh, gbv);
   if (G > 0) {
 #pragma unroll
     for (int g = 0; g < G; ++g) gwv[g] = ldg4(a.gw + (int64_t)g * a.gw_stride + a.gw_coff + cq * 4);
@@ -248,10 +285,20 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdArgs a) {
     const float4 d = ldg4(a.dz + (base + pix) * a.dzs + cq * 4);
     float4 u, o;
     u.x = fmaf(v.x, sc.x, sh.x); u.y = fmaf(v.y, sc.y, sh.y); u.z = fmaf(v.z, sc.z, sh.z); u.w = fmaf(v.w, sc.w, sh.w);
+    if (L) {
+      float4 sg = gbv;
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const float gg = a.guide[(base + pix) * G + g];
-      u.x = fmaf(gg, gwv[g].x, u.x); u.y = fmaf(gg, gwv[g].y, u.y); u.z = fmaf(gg, gwv[g].z, u.z); u.w = fmaf(gg, gwv[g].w, u.w);
+      for (int g = 0; g < G; ++g) {
+        const float gg = a.guide[(base + pix) * G + g];
+        sg.x = fmaf(gg, gwv[g].x, sg.x); sg.y = fmaf(gg, gwv[g].y, sg.y); sg.z = fmaf(gg, gwv[g].z, sg.z); sg.w = fmaf(gg, gwv[g].w, sg.w);
+      }
+      u.x += lrelu(sg.x); u.y += lrelu(sg.y); u.z += lrelu(sg.z); u.w += lrelu(sg.w);
+    } else {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float gg = a.guide[(base + pix) * G + g];
+        u.x = fmaf(gg, gwv[g].x, u.x); u.y = fmaf(gg, gwv[g].y, u.y); u.z = fmaf(gg, gwv[g].z, u.z); u.w = fmaf(gg, gwv[g].w, u.w);
+      }
     }
 #define NBA(f)                                          \
   {                                                     \
@@ -273,7 +320,7 @@ __global__ void norm_bwd_params_kernel(const float* __restrict__ psum, int C, in
   if (c >= C) return;
   if (dbeta) dbeta[c] = psum[c];
   if (dgamma) dgamma[c] = psum[C + c];
-  if (dgb) dgb[c] = density ? psum[(int64_t)(2 + G) * C + c] : psum[c];
+  if (dgb) dgb[c] = density ? psum[(int64_t)(2 + G) * C + c] : psum[c];   // density | leaky: the separate sum du [* lrelu']
   for (int g = 0; g < G; ++g) dgw[(int64_t)g * C + c] = psum[(int64_t)(2 + g) * C + c];
 }
 
@@ -297,8 +344,16 @@ int bwd_blocks(const NormGeom& g) {
     case 3: { constexpr int GG = 3; CALL; } break; \
     default: { constexpr int GG = 4; CALL; } break; \
   }
-#define GD_DISPATCH(G_, D_, KERN, ...)                                                  \
-  if (D_) { G_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, true>), __VA_ARGS__)); }         \
+#define GL_DISPATCH(G_, CALL) \
+  switch (G_) {              \
+    case 1: { constexpr int GG = 1; CALL; } break; \
+    case 2: { constexpr int GG = 2; CALL; } break; \
+    case 3: { constexpr int GG = 3; CALL; } break; \
+    default: { constexpr int GG = 4; CALL; } break; \
+  }
+#define GD_DISPATCH(G_, D_, L_, KERN, ...)                                               \
+  if (L_) { GL_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, false, true>), __VA_ARGS__)); } \
+  else if (D_) { G_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, true>), __VA_ARGS__)); }     \
   else { G_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, false>), __VA_ARGS__)); }
 
 }  // namespace
@@ -355,7 +410,9 @@ extern "C" int unetk_norm_apply_relu(const unetk_norm_desc* d, const float* y, c
   int64_t gx = (g.P + g.rpi - 1) / g.rpi;
   const int64_t cap = g.L > 1 ? (4096 + g.L - 1) / g.L : 4096;
   if (gx > cap) gx = cap;
-  GD_DISPATCH(d->guide_ch, den != nullptr, norm_apply_relu_kernel, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, a);
+  const bool leaky = d->guide_leaky != 0;
+  if (leaky && (d->guide_ch < 1 || den != nullptr)) return UNETK_E_UNSUPPORTED;
+  GD_DISPATCH(d->guide_ch, den != nullptr, leaky, norm_apply_relu_kernel, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, a);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
@@ -396,7 +453,9 @@ extern "C" int unetk_norm_relu_bwd(const unetk_norm_desc* d, const float* y, con
   if (ws_bytes < unetk_norm_bwd_ws_bytes(d)) return UNETK_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const NormGeom g = geom(d, D);
-  const int K = 2 + G + (D ? 2 : 0);
+  const bool leaky = d->guide_leaky != 0;
+  if (leaky && (G < 1 || D)) return UNETK_E_UNSUPPORTED;
+  const int K = 2 + G + (D ? 2 : 0) + (leaky ? 1 : 0);
   const int nblk = bwd_blocks(g);
   float* partial = (float*)ws;
   float* sums = partial + (size_t)K * g.L * nblk * d->C;
@@ -413,13 +472,13 @@ extern "C" int unetk_norm_relu_bwd(const unetk_norm_desc* d, const float* y, con
   else if (g.L == 1) { a.ksum = sums; a.kst = 0; a.krow = d->C; }
   else { a.ksum = psum; a.kst = 0; a.krow = d->C; }
   const size_t lds = (size_t)K * g.rpi * d->C * sizeof(float);
-  GD_DISPATCH(G, D, norm_bwd_reduce_kernel, dim3(nblk, g.L), dim3(256), lds, st, a);
+  GD_DISPATCH(G, D, leaky, norm_bwd_reduce_kernel, dim3(nblk, g.L), dim3(256), lds, st, a);
   UNETK_LAUNCH_CHECK();
   int rc = unetk_rows_reduce(partial, K * g.L, nblk, d->C, sums, tmp1, st);   // -> sums[K][L][C]
   if (rc != UNETK_OK) return rc;
   rc = unetk_rows_reduce(sums, K, g.L, d->C, psum, tmp2, st);                 // -> psum[K][C]
   if (rc != UNETK_OK) return rc;
-  hipLaunchKernelGGL(norm_bwd_params_kernel, dim3((d->C + 255) / 256), dim3(256), 0, st, psum, d->C, G, D ? 1 : 0, dgamma,
+  hipLaunchKernelGGL(norm_bwd_params_kernel, dim3((d->C + 255) / 256), dim3(256), 0, st, psum, d->C, G, (D || leaky) ? 1 : 0, dgamma,
                      dbeta, dgw, dgb);
   UNETK_LAUNCH_CHECK();
   if (D) {   // density gradient: the per-sample row sum du * t
@@ -430,7 +489,7 @@ extern "C" int unetk_norm_relu_bwd(const unetk_norm_desc* d, const float* y, con
   int64_t gx = (g.P + g.rpi - 1) / g.rpi;
   const int64_t cap = g.L > 1 ? (4096 + g.L - 1) / g.L : 4096;
   if (gx > cap) gx = cap;
-  GD_DISPATCH(G, D, norm_bwd_apply_kernel, dim3((int)gx, g.L), dim3(256), 0, st, a);
+  GD_DISPATCH(G, D, leaky, norm_bwd_apply_kernel, dim3((int)gx, g.L), dim3(256), 0, st, a);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }

@@ -557,6 +557,7 @@ class NormSpec(object):
     def __init__(self, kind="batch_norm", eps=1e-3, decay=0.999, training=True, bf16=False):
         assert kind in ("batch_norm", "instance_norm", "none")   # "none" = --without_norm: conv + bias + ReLU
         self.kind, self.eps, self.decay, self.training = kind, eps, decay, training
+        self.guide_leaky = False   # LGNet: leaky-ReLU on the guide branch before it is added
         self.bf16 = bf16        # UNETK_BF16 contractions (operands rounded to bf16, fp32 accumulate / storage)
 
     @property
@@ -598,6 +599,8 @@ class Conv3x3NormRelu(torch.autograd.Function):
         if gb is not None:                  # without a guide: a bare per-channel shift after the gain (after_affine)
             gb = gb.contiguous()
         d = norm_desc(y.shape, spec.per_sample, _pix_stride(z), g_ch, cout if g_ch else 0, 0)
+        if g_ch and getattr(spec, "guide_leaky", False):      # LGNet: u = t + leaky_relu(guide . gw + gb)
+            d.guide_leaky = 1
         if plain:
             # --without_norm (UNet.py:47-48): z = relu(y + bias); `beta` carries the conv bias
             d.affine_only = 1
@@ -636,7 +639,7 @@ class Conv3x3NormRelu(torch.autograd.Function):
             DEBUG_CAPTURE.append(dict(x=x, y=y, dilation=ctx.dilation, gamma=ctx.gb_dbg[0], beta=ctx.gb_dbg[1], aff=aff, dz=dz, dy=dy, dw=dw,
                                       dx=dx, dgamma=dgamma, dbeta=dbeta, w=ctx.w_dbg, guide=guide, gw=gw, gb=gb,
                                       dgw=dgw, dgb=dgb, per_sample=bool(ctx.desc.per_sample), bf16=ctx.bf16, den=den,
-                                      dden=dden))
+                                      dden=dden, guide_leaky=bool(ctx.desc.guide_leaky)))
         return dx, dw, dgamma, dbeta, None, None, None, None, None, dgw, dgb, dden, None
 
 

@@ -141,6 +141,9 @@ typedef struct unetk_norm_desc {
   int32_t guide_ch, gw_stride, gw_coff;
   int32_t affine_only;         /* 1 = no normalisation (--without_norm, UNet.py:47-48: conv + bias + ReLU):
                                   backward skips the statistics terms, dbeta is the bias gradient */
+  int32_t guide_leaky;         /* 1 = LGNet's guide branch (LGNet.py:30-55): the 1x1 guide conv is followed by
+                                  tf.nn.leaky_relu (alpha 0.2) before the add: u = t + lrelu(guide . gw + gb);
+                                  needs guide_ch > 0, no density gains */
 } unetk_norm_desc;
 
 /* Finalise the conv's statistic partials ([2][stat_rows][C], each image's tiles contiguous) into

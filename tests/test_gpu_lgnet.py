@@ -1,0 +1,140 @@
+"""GPU parity of the LGNet plugin (reference NetworksV2/LGNet.py: guide merged through a leaky-ReLU 1x1 conv after conv2 of
+the encoder levels / after conv1 of the decoder levels) against the oracle; the leaky guide term of the norm kernels
+(unetk_norm_desc.guide_leaky) at op level against float64 autograd."""
+import numpy as np
+import pytest
+import torch
+import yaml
+from pathlib import Path
+
+from oracle import lgnet2d, tf_ops
+from test_gpu_gunet import kwargs_of, make_args
+from test_gpu_unet import check_deconv_backward, check_unit_backward, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("per_sample,g_ch,n,h,c", [(True, 1, 2, 16, 64), (False, 2, 3, 8, 128), (True, 4, 2, 12, 256)])
+def test_norm_leaky_guide_forward_backward(per_sample, g_ch, n, h, c):
+    from boxsegliver_amd import ops
+    gen = torch.Generator().manual_seed(c + g_ch)
+    y = torch.randn(n, h, h, c, generator=gen) * 1.5
+    gamma, beta = 0.5 + torch.rand(c, generator=gen), 0.3 * torch.randn(c, generator=gen)
+    guide = torch.rand(n, h, h, g_ch, generator=gen)
+    gw, gb = torch.randn(g_ch, c, generator=gen), 0.5 * torch.randn(c, generator=gen)      # both signs of s occur
+    dz = torch.randn(n, h, h, c, generator=gen)
+    yd = y.cuda()
+    d = ops.norm_desc(y.shape, per_sample, c, g_ch, c, 0)
+    d.guide_leaky = 1
+    flat = yd.reshape(n, h * h, c)
+    stats = torch.stack([flat.sum(1), (flat * flat).sum(1)]).contiguous()
+    aff = ops.norm_finalize(d, stats, n, gamma.cuda(), beta.cuda(), 1e-6 if per_sample else 1e-3, 0.99, True,
+                            torch.zeros(c).cuda(), torch.ones(c).cuda(), yd.device)
+    z = torch.empty_like(yd)
+    ops.norm_apply_relu(d, yd, aff, z, guide.cuda(), gw.cuda(), gb.cuda())
+    dy, dgamma, dbeta, dgw, dgb = ops.norm_relu_bwd(d, yd, dz.cuda(), aff, True, True, guide.cuda(), gw.cuda(), gb.cuda())
+    d64 = lambda t: t.double().requires_grad_(True)
+    y64, g64, b64, gw64, gb64 = d64(y), d64(gamma), d64(beta), d64(gw), d64(gb)
+    if per_sample:
+        t = tf_ops.instance_norm(y64, g64, b64, eps=1e-6)
+    else:
+        t, _, _ = tf_ops.batch_norm(y64, g64, b64, torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64), True)
+    s = guide.double() @ gw64 + gb64
+    ref = torch.relu(t + torch.nn.functional.leaky_relu(s, 0.2))
+    ref.backward(dz.double())
+    assert float((s.detach() < 0).float().mean()) > 0.1 and float((s.detach() > 0).float().mean()) > 0.1
+    for got, want in ((z, ref.detach()), (dy, y64.grad), (dgamma, g64.grad), (dbeta, b64.grad), (dgw, gw64.grad), (dgb, gb64.grad)):
+        assert rel(got.cpu().numpy(), want.numpy()) < 2e-5
+    # the linear guide (GUNet) differs
+    d.guide_leaky = 0
+    z0 = torch.empty_like(yd)
+    ops.norm_apply_relu(d, yd, aff, z0, guide.cuda(), gw.cuda(), gb.cuda())
+    assert not torch.allclose(z0, z)
+
+
+@pytest.mark.parametrize("cfg,normalizer,loss_type", [("LGNet.yml", "instance_norm", "xentropy"), ("LGNet_v2.yml", "batch_norm", "xentropy+dice"),
+                                                      ("LGNet_v3.yml", "instance_norm", "dice")])
+def test_lgnet_matches_oracle_and_trains(cfg, normalizer, loss_type):
+    from boxsegliver_amd import ops
+    from boxsegliver_amd.core import models
+    from boxsegliver_amd.core.solver import Solver
+    from boxsegliver_amd.data.synthetic import make_batch, make_guide
+    yml = yaml.safe_load((Path(ops.__file__).parent / "NetworksV2" / cfg).read_text())
+    yml.update(build_metrics=True, build_summaries=False)
+    zoo = {cls.__name__: cls for cls in models.MODEL_ZOO}
+    args = make_args(normalizer=normalizer, loss_type=loss_type, use_spatial=True, guide_channel=1)
+    images, labels, _ = make_batch(2, 32, 32, 3, 3, 1234)
+    guide = make_guide(labels, 1, 1234)
+    model = zoo["LGNet"](args)
+    inputs = {"images": torch.from_numpy(images).cuda(), "labels": torch.from_numpy(labels).cuda(),
+              "sp_guide": torch.from_numpy(guide).cuda()}
+    model(inputs, "eval", **yml)
+    net = lgnet2d.LGNetOracle(3, 3, guide_channel=1, mod_layers=yml["mod_layers"], normalizer=normalizer)
+    assert [(n, tuple(s), k) for n, s, k in net.specs] == [(n, tuple(s), k) for n, s, k in model.params.specs]
+    names = list(model.params.state_dict())
+    l0 = yml["mod_layers"][0][0]
+    assert "LGNet/spatial/conv_e{}/weights".format(l0 + 1) in names and "LGNet/ED-Bridge/conv2/weights" in names
+    assert "LGNet/conv_d3/up/biases" in names and "LGNet/logits/weights" in names
+    gen = torch.Generator().manual_seed(16)
+    params = {}
+    for name, t in model.params.state_dict().items():
+        kind = net.kinds[name]
+        if kind == "gamma":
+            params[name] = 0.5 + torch.rand(t.shape, generator=gen)
+        elif kind in ("beta", "bias"):
+            params[name] = 0.2 * torch.randn(t.shape, generator=gen)
+        elif "spatial" in name:
+            params[name] = 0.8 * torch.randn(t.shape, generator=gen)
+        else:
+            params[name] = t.clone()
+    model.params.load_state(params)
+    img, gd, lab = torch.from_numpy(images), torch.from_numpy(guide), torch.from_numpy(labels).long()
+    total, _, logits, _, new_stats = net.loss_and_grads(params, img, gd, lab, **kwargs_of(args))
+    p64 = {k: v.double() for k, v in params.items()}
+    _, _, _, grads64, _ = net.loss_and_grads(p64, img.double(), gd.double(), lab, **kwargs_of(args))
+    ops.DEBUG_CAPTURE = []
+    try:
+        model.params.zero_grad()
+        loss = model(inputs, "train", **yml)
+        loss.backward()
+        torch.cuda.synchronize()
+        captured = ops.DEBUG_CAPTURE
+    finally:
+        ops.DEBUG_CAPTURE = None
+    assert abs(loss.item() - total.item()) < 1e-4 * max(1.0, abs(total.item()))
+    assert np.abs(model.layers["logits"].cpu().numpy() - logits.numpy()).max() < 1e-3
+    units = [c for c in captured if c.get("kind") != "deconv"]
+    assert len(units) == 18 and len(captured) == 22
+    n_mod = len(yml["mod_layers"][0]) + len(yml["mod_layers"][1])
+    assert sum(1 for c in units if c.get("guide_leaky")) == n_mod
+    for c in units:
+        check_unit_backward(c)
+    for c in captured:
+        if c.get("kind") == "deconv":
+            check_deconv_backward(c)
+    num = den = 0.0
+    for name in model.params.trainable_names():
+        g = model.params[name].grad.cpu().numpy().astype(np.float64)
+        ref = grads64[name].numpy()
+        num += np.sum((g - ref) ** 2)
+        den += np.sum(ref ** 2)
+    # whole gradient vector: ReLU / max-pool mask flips amplified by the 2x2 .. 4x4 levels of this reduced-size net
+    # (batch norm over 8 values, instance norm over 4); every kernel is pinned on identical operands just above
+    assert (num / den) ** 0.5 < 1e-2
+    for name in names:
+        if "spatial" in name:       # the guide branch's own parameters (L2: single mask flips upstream move single entries)
+            g = model.params[name].grad.cpu().numpy().astype(np.float64)
+            ref = grads64[name].numpy()
+            level = int(name.split("/conv_")[1][1]) - 1          # levels >= 2 see <= 8 x 8 pixels in this reduced-size net
+            assert np.abs(g).max() > 0 and np.linalg.norm(g - ref) / np.linalg.norm(ref) < (1e-1 if level < 2 else 2.5e-1), name
+    for name, ref in new_stats.items():
+        np.testing.assert_allclose(model.params[name].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-6)
+    solver = Solver(args)
+    first = None
+    for _ in range(4):
+        loss = model(inputs, "train", **yml)
+        first = loss.item() if first is None else first
+        solver(loss, model)
+    assert model(inputs, "train", **yml).item() < first
+    with pytest.raises(ValueError):
+        zoo["LGNet"](args)(inputs, "eval", **dict(yml, mod_layers=[[0, 1], [1, 0]]))

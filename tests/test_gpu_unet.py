@@ -190,7 +190,9 @@ def check_unit_backward(c, tol=1e-5):
                                     torch.ones(y.shape[-1], dtype=torch.float64), True)
     if den is not None:
         z = z * den[:, None, None, :]
-    if gw is not None:
+    if gw is not None and c.get("guide_leaky"):
+        z = z + torch.nn.functional.leaky_relu(c["guide"].detach().cpu().double() @ gw + gb, 0.2)   # LGNet.py:38
+    elif gw is not None:
         z = z + (c["guide"].detach().cpu().double() @ gw + gb)
     elif gb is not None:                                   # bare post-shift (after_affine without a guide)
         z = z + gb

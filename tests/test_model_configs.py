@@ -14,7 +14,7 @@ CONFIGS = sorted(p.name for p in list(NETS.glob("*.yml")) + list((NETS / "ext_co
 
 def test_registry_matches_reference_names():
     names = [cls.__name__ for cls in models.MODEL_ZOO]
-    assert names == ["UNet", "GUNet", "UNetInter", "UNet3D", "SmallUNet"]
+    assert names == ["UNet", "GUNet", "UNetInter", "LGNet", "UNet3D", "SmallUNet"]
     parser = argparse.ArgumentParser()
     models.add_arguments(parser)
     ns = parser.parse_args(["--model", "UNetInter", "--classes", "Liver", "Tumor"])
@@ -30,6 +30,8 @@ def test_shipped_config_resolves(cfg):
     params = models.get_model_params(args, build_metrics=True)
     kw = params["model_kwargs"]
     assert params["model"].__name__ == model and kw["build_metrics"] is True and kw["ret_pred"] is True
+    if model == "LGNet":
+        assert len(kw["mod_layers"]) == 2 and all(br == sorted(br) for br in kw["mod_layers"])
     if model in ("GUNet",):
         assert kw["context_model"] == "fc" and kw["mod_layers"] == [1, 2, 3, 4] and len(kw["context_fc_channels"]) == 2
     if model == "UNet3D":
@@ -43,4 +45,4 @@ def test_default_config_name_and_missing_config():
     args = argparse.Namespace(model="UNet", model_config="does_not_exist.yml")
     assert models.get_model_params(args)["model_kwargs"] == {"build_metrics": False, "build_summaries": False}
     with pytest.raises(NameError):
-        models.get_model_params(argparse.Namespace(model="LGNet", model_config=None))
+        models.get_model_params(argparse.Namespace(model="InterUNet", model_config=None))
