@@ -84,6 +84,10 @@ struct ConvParams {
   int ooh[4], oow[4];                    // class q: output pixel (a, b) -> (os a + ooh[q], os b + oow[q])
   int os, Hd, Wd;                        // of an Hd x Wd plane
   int dil;                               // 2 = rate-2 atrous conv (taps at (2 kh, 2 kw), SAME pad 2); 0 / 1 = dense
+  // fused depth taps (linear-pixel kernel, depth stride 1): kd > 1 contracts kd depth taps in ONE launch -- tap dt reads
+  // the plane (depth index + dshift0 + dt * dstep) of the same sample (zero outside [0, spg)) with the filter panel
+  // wp + dt * 9 * Cin * Cout; no per-tap read-modify-write of the output.  0 / 1 = a plain 2-D conv per plane.
+  int kd, dshift0, dstep;
 };
 bool unetk_conv_lin_gen_ok(int H, int W, int Cin, int Cout);
 int unetk_conv_run_lin_gen(ConvParams p, hipStream_t st);

@@ -185,6 +185,19 @@ extern "C" int unetk_conv3d_fwd(const unetk_conv3d_desc* d, const float* x, cons
     ts = d->Cout;
   }
   const int HWx = d->H * d->W * d->x_stride, HWt = (native ? g.Ho * g.Wo : d->H * d->W) * ts;
+  if (d->kd == 3 && d->sd == 1 && d->shw == 1 && unetk_conv_lin_ok(d->N * d->D, d->H, d->W, d->Cin, d->Cout, d->D)) {
+    // small planes, depth stride 1 (UNet3D's 24^2 / 12^2 / 6^2 levels): the three depth taps are contracted inside ONE
+    // launch of the linear-pixel kernel (K = 27 Cin) -- no memset, no read-modify-write of y per tap
+    ConvParams p{};
+    p.x = x; p.wp = wp; p.y = y; p.stat = stat_partials;
+    p.N = d->N * d->D; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
+    p.xs = d->x_stride; p.ys = d->y_stride;
+    p.xa = planes(HWx, d->D, 1, d->D);
+    p.ya = planes(d->H * d->W * d->y_stride, d->D, 1, d->D);
+    p.spg = d->D;
+    p.kd = 3; p.dshift0 = -g.pb_d; p.dstep = 1;
+    return unetk_conv_run(p, st);
+  }
   // order: partial-coverage taps first, a full-coverage tap last (it emits the statistics)
   int order[3], n_taps = 0, full = -1;
   for (int dt = 0; dt < d->kd; ++dt) {
@@ -314,6 +327,18 @@ extern "C" int unetk_conv3d_dgrad(const unetk_conv3d_desc* d, const float* dy, c
   if (d->shw == 2) {
     UNETK_REQUIRE(ws && unetk_aligned16(ws));
     if (ws_bytes < unetk_conv3d_ws_bytes(d)) return UNETK_E_WORKSPACE;
+  }
+  if (d->kd == 3 && d->sd == 1 && d->shw == 1 && unetk_conv_lin_ok(d->N * d->D, d->H, d->W, d->Cout, d->Cin, d->D)) {
+    // fused depth taps (see unetk_conv3d_fwd): dx[di] = sum_dt dy[di + pb - dt] * w[dt]
+    ConvParams p{};
+    p.x = dy; p.wp = wp_dgrad; p.y = dx; p.stat = nullptr;
+    p.N = d->N * d->D; p.H = d->H; p.W = d->W; p.Cin = d->Cout; p.Cout = d->Cin;
+    p.xs = d->y_stride; p.ys = d->x_stride;
+    p.xa = planes(d->H * d->W * d->y_stride, d->D, 1, d->D);
+    p.ya = planes(d->H * d->W * d->x_stride, d->D, 1, d->D);
+    p.spg = d->D;
+    p.kd = 3; p.dshift0 = g.pb_d; p.dstep = -1;
+    return unetk_conv_run(p, st);
   }
   const float* Z;
   int zs;

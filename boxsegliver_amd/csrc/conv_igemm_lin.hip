@@ -72,6 +72,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
   int64_t hoff[HR];
   bool hok[HR];
   int hlds[HR];
+  int hdep[HR];   // depth index of the staged plane inside its sample (fused depth taps)
 #pragma unroll
   for (int r = 0; r < HR; ++r) {
     const int idx = tid + r * NT;
@@ -82,7 +83,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
     hok[r] = slot < npix && plane < p.N && rr >= 0 && rr < p.H && col >= 0 && col < p.W;
     hoff[r] = p.xa.off(plane) + ((int64_t)rr * p.W + col) * p.xs + q * 4;
     hlds[r] = slot < npix ? slot * PS + q * 4 : -1;
+    hdep[r] = plane % p.spg;
   }
+  const int KD = (!GEN && p.kd > 1) ? p.kd : 1;
   const int cin4 = p.Cin >> 2;
   int64_t woff[WR];
 #pragma unroll
@@ -93,18 +96,26 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
   }
 
   float4 hreg[HR], wreg[WR];
-  auto load_halo = [&](int c) {
+  const int nchunks = p.Cin / CK;
+  // chunk index cc runs over (depth tap, 16-channel chunk); one depth tap = a plane shift inside the sample
+  auto load_halo = [&](int cc) {
+    const int dt = KD > 1 ? cc / nchunks : 0, c = cc - dt * nchunks;
+    const int shift = KD > 1 ? p.dshift0 + dt * p.dstep : 0;
+    const int64_t soff = (int64_t)shift * p.xa.img_stride + c * CK;
 #pragma unroll
-    for (int r = 0; r < HR; ++r)
-      hreg[r] = hok[r] ? ldg4(p.x + hoff[r] + c * CK) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < HR; ++r) {
+      const bool ok = hok[r] && (KD == 1 || (hdep[r] + shift >= 0 && hdep[r] + shift < p.spg));
+      hreg[r] = ok ? ldg4(p.x + hoff[r] + soff) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   };
   auto store_halo = [&](int buf) {
 #pragma unroll
     for (int r = 0; r < HR; ++r)
       if (hlds[r] >= 0) *reinterpret_cast<float4*>(&halo[buf * HALO_F + hlds[r]]) = hreg[r];
   };
-  auto load_w = [&](int c, int t) {
-    const float* base = p.wp + ((int64_t)t * cin4 + c * (CK / 4)) * p.Cout * 4;
+  auto load_w = [&](int cc, int t) {
+    const int dt = KD > 1 ? cc / nchunks : 0, c = cc - dt * nchunks;
+    const float* base = p.wp + ((int64_t)(dt * 9 + t) * cin4 + c * (CK / 4)) * p.Cout * 4;
 #pragma unroll
     for (int r = 0; r < WR; ++r)
       if (tid + r * NT < WF4) wreg[r] = ldg4(base + woff[r]);
@@ -136,8 +147,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accq[qq][tm][tn][r] = 0.f;
-
-  const int nchunks = p.Cin / CK;
 
   load_halo(0);
   load_w(0, GEN ? p.tap_panel[q][0] : 0);
@@ -305,9 +314,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
   }
 
   int step = 0;
-  for (int c = 0; c < nchunks; ++c) {
+  const int nchunks_all = KD * nchunks;
+  for (int c = 0; c < nchunks_all; ++c) {
     const float* hb = halo + (c & 1) * HALO_F;
-    const bool more_chunks = (c + 1 < nchunks);
+    const bool more_chunks = (c + 1 < nchunks_all);
 #pragma unroll
     for (int t = 0; t < 9; ++t, ++step) {
       const bool has_next = (t < 8) || more_chunks;
