@@ -9,15 +9,19 @@ Kernels: stride-1 units = ops.Conv3x3NormRelu (dilation 2 for the atrous ones: u
 = ops.Conv3dNormRelu on [N, 1, H, W, C] views (the natively strided (1,3,3)/(1,2,2) path of UNet3D); decoder =
 ops.DeconvConcat with a NULL bias writing into the zero-copy concat buffers the encoder filled.
 
-Not built: init_channel_factor != 1 (SmallUNet_V2.yml's 0.75 gives 48-channel layers, not a multiple of the MFMA tile),
---without_norm.
+`init_channel_factor` (SmallUNet_V2.yml: 0.75 -> 48 / 96 / 192 / 384 / 768 channels): the device variables are
+channel-padded to multiples of 64 (48 -> 64, 96 -> 128) exactly as UNet3D's are (NetworksV2/padded.py: padded filter rows /
+columns are zero and provably stay zero; checkpoints speak the TF shapes).
+
+Not built: --without_norm.
 """
 import torch
 
 from .. import ops
 from ..loss_metrics import build_head_desc, pixel_weights
 from .UNet import UNet
-from .base import ModeKeys, ParamStore
+from .base import ModeKeys
+from .padded import PaddedParamStore, pad_to
 
 
 def model_config(factor=1.0):
@@ -34,32 +38,55 @@ def model_config(factor=1.0):
             ("conv_d0", [("up", c(64), 2, 1), ("conv1", c(64), 1, 1), ("conv2", c(64), 1, 1)])]
 
 
+PAD = 64     # device channel granularity (the stride-2 / atrous / 64 x 64 filter-gradient tiles)
+
+
 def param_specs(in_channels, num_classes, factor, normalizer, name):
-    """<name>/<block>/<layer>/{weights, BatchNorm|InstanceNorm/...}, <name>/<block>/up/weights, <name>/logits/{weights,biases}."""
-    specs = []
+    """Logical specs <name>/<block>/<layer>/{weights, BatchNorm|InstanceNorm/...}, <name>/<block>/up/weights,
+    <name>/logits/{weights,biases} and the device padding of each variable (empty at factor 1)."""
+    specs, pads = [], {}
     enc_out = {}
-    cin = in_channels
+    cin_parts = [in_channels]
+
+    def vec(vname, c, kind):
+        specs.append((vname, (c,), kind))
+        if pad_to(c, PAD) != c:
+            pads[vname] = ((pad_to(c, PAD),), {})
+
+    def in_layout(parts):
+        segs, lpos, ppos = [], 0, 0
+        for c in parts:
+            segs.append((lpos, c, ppos))
+            lpos += c
+            ppos += pad_to(c, PAD) if c >= 16 else c          # the raw image + guide channels are not padded
+        return ppos, segs
+
     for block, layers in model_config(factor):
         for layer, cout, _, _ in layers:
             scope = "{}/{}/{}".format(name, block, layer)
+            pcin, segs = in_layout(cin_parts)
             if layer == "up":
-                specs.append((scope + "/weights", (2, 2, cout, cin), "deconv_w"))
-                cin = enc_out[block.replace("d", "e")] + cout
+                specs.append((scope + "/weights", (2, 2, cout, sum(cin_parts)), "deconv_w"))
+                pads[scope + "/weights"] = ((2, 2, pad_to(cout, PAD), pcin), {2: [(0, cout, 0)], 3: segs})
+                cin_parts = [enc_out[block.replace("d", "e")], cout]
                 continue
-            specs.append((scope + "/weights", (3, 3, cin, cout), "conv_w"))
+            specs.append((scope + "/weights", (3, 3, sum(cin_parts), cout), "conv_w"))
+            pads[scope + "/weights"] = ((3, 3, pcin, pad_to(cout, PAD)), {2: segs})
             if normalizer == "batch_norm":
                 for leaf, kind in (("gamma", "gamma"), ("beta", "beta"), ("moving_mean", "moving_mean"),
                                    ("moving_variance", "moving_var")):
-                    specs.append(("{}/BatchNorm/{}".format(scope, leaf), (cout,), kind))
+                    vec("{}/BatchNorm/{}".format(scope, leaf), cout, kind)
             else:
-                specs.append((scope + "/InstanceNorm/gamma", (cout,), "gamma"))
-                specs.append((scope + "/InstanceNorm/beta", (cout,), "beta"))
-            cin = cout
+                vec(scope + "/InstanceNorm/gamma", cout, "gamma")
+                vec(scope + "/InstanceNorm/beta", cout, "beta")
+            cin_parts = [cout]
         if block.startswith("conv_e"):
-            enc_out[block] = cin
-    specs.append((name + "/logits/weights", (1, 1, cin, num_classes), "conv_w"))
+            enc_out[block] = cin_parts[0]
+    pcin, segs = in_layout(cin_parts)
+    specs.append((name + "/logits/weights", (1, 1, sum(cin_parts), num_classes), "conv_w"))
+    pads[name + "/logits/weights"] = ((1, 1, pcin, num_classes), {2: segs})
     specs.append((name + "/logits/biases", (num_classes,), "bias"))
-    return specs
+    return specs, pads
 
 
 class SmallUNet(UNet):
@@ -98,9 +125,9 @@ class SmallUNet(UNet):
         factor = kwargs.get("init_channel_factor", 1)
         if kwargs.get("num_pool_layers", 3) != 3:
             raise KeyError(kwargs.get("num_pool_layers"))               # the reference only defines config[3]
-        if factor != 1:
-            raise NotImplementedError("SmallUNet init_channel_factor {} is not built (channel counts must stay multiples "
-                                      "of 64)".format(factor))
+        if any(cout % 16 for _, layers in model_config(factor) for _, cout, _, _ in layers):
+            raise NotImplementedError("SmallUNet init_channel_factor {} gives channel counts that are not multiples of 16"
+                                      .format(factor))
         images = self._inputs["images"]
         if not images.is_cuda:
             raise ops._abi.UnetkError("SmallUNet runs on the GPU only: move `images` to cuda (no CPU path)")
@@ -112,8 +139,8 @@ class SmallUNet(UNet):
             raise ValueError("H and W must be divisible by 8")
         dev, nm = images.device, self.name
         if self.params is None:
-            specs = param_specs(images.shape[3] + guide.shape[3], self.num_classes, factor, self.args.normalizer, nm)
-            self.params = ParamStore(specs, dev, bias_decay=getattr(self.args, "bias_decay", False))
+            specs, pads = param_specs(images.shape[3] + guide.shape[3], self.num_classes, factor, self.args.normalizer, nm)
+            self.params = PaddedParamStore(specs, pads, dev, bias_decay=getattr(self.args, "bias_decay", False))
             self.params.initialize(self._get_initializer()[0], seed=getattr(self.args, "seed", None))
         p = self.params
 
@@ -132,6 +159,7 @@ class SmallUNet(UNet):
                         continue
                     if stride == 2:
                         hh, ww = hh // 2, ww // 2
+                    cout = pad_to(cout, PAD)                     # physical channels
                     out = None
                     if block in ("conv_e0", "conv_e1", "conv_e2") and li == len(layers) - 1:
                         # the block's output is a skip connection: write it straight into its concat buffer

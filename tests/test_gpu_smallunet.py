@@ -15,8 +15,10 @@ pytestmark = pytest.mark.gpu
 YML = dict(init_channel_factor=1, num_pool_layers=3, ret_prob=False, ret_pred=True, build_metrics=True, build_summaries=False)
 
 
-@pytest.mark.parametrize("normalizer,loss_type", [("batch_norm", "xentropy"), ("instance_norm", "dice")])
-def test_smallunet_matches_oracle_and_trains(normalizer, loss_type):
+@pytest.mark.parametrize("normalizer,loss_type,factor", [("batch_norm", "xentropy", 1), ("instance_norm", "dice", 1),
+                                                         ("batch_norm", "xentropy", 0.75)])   # 0.75 = SmallUNet_V2.yml
+def test_smallunet_matches_oracle_and_trains(normalizer, loss_type, factor):
+    YML = dict(globals()["YML"], init_channel_factor=factor)
     from boxsegliver_amd import ops
     from boxsegliver_amd.core import models
     from boxsegliver_amd.core.solver import Solver
@@ -29,12 +31,17 @@ def test_smallunet_matches_oracle_and_trains(normalizer, loss_type):
     inputs = {"images": torch.from_numpy(images).cuda(), "labels": torch.from_numpy(labels).cuda(),
               "sp_guide": torch.from_numpy(guide).cuda()}
     model(inputs, "eval", **YML)
-    net = smallunet2d.SmallUNetOracle(4, 3, normalizer=normalizer)
-    assert [(n, tuple(s), k) for n, s, k in net.specs] == [(n, tuple(s), k) for n, s, k in model.params.specs]
+    net = smallunet2d.SmallUNetOracle(4, 3, factor=factor, normalizer=normalizer)
+    assert [(n, tuple(s), k) for n, s, k in net.specs] == [(n, tuple(s), k) for n, s, k in model.params.logical_specs]
     names = list(model.params.state_dict())
     assert "SmallUNet/conv_e1/conv1/weights" in names and "SmallUNet/conv_d2/up/weights" in names
     assert "SmallUNet/conv_d2/up/biases" not in names and "SmallUNet/logits/biases" in names
-    assert model.params["SmallUNet/conv_d3/conv1/weights"].shape == (3, 3, 1024, 512)
+    c = lambda v: int(round(v * factor))
+    assert model.params.state_dict()["SmallUNet/conv_d3/conv1/weights"].shape == (3, 3, c(1024), c(512))
+    if factor != 1:      # 48 -> 64 and 96 -> 128 channels on the device, TF shapes outside
+        assert model.params["SmallUNet/conv_e0/conv2/weights"].shape == (3, 3, 64, 64)
+        assert model.params["SmallUNet/conv_d0/conv1/weights"].shape == (3, 3, 128, 64)
+        assert model.params.state_dict()["SmallUNet/conv_d0/conv1/weights"].shape == (3, 3, 96, 48)
     # (seed chosen so that no pre-activation of this run lies within fp32 rounding of zero: check_unit_backward compares
     # element-wise against float64, and a single ReLU mask flip at |u| ~ 1e-8 shows up as an O(1) difference there --
     # seed 6 has exactly one such element in conv_e0/conv1; the runs are bit-reproducible, so this is stable)
@@ -79,13 +86,17 @@ def test_smallunet_matches_oracle_and_trains(normalizer, loss_type):
         assert c["b"] is None
     num = den = 0.0
     for name in model.params.trainable_names():
-        g = model.params[name].grad.cpu().numpy().astype(np.float64)
+        g = model.params.logical_grad(name).numpy().astype(np.float64)
         ref = grads64[name].numpy()
         num += np.sum((g - ref) ** 2)
         den += np.sum(ref ** 2)
-    assert (num / den) ** 0.5 < 5e-3
+    assert (num / den) ** 0.5 < 1e-2       # mask flips amplified by the batch-2 norms of the 8x8 levels (see test_gpu_unet.py)
+    state = model.params.state_dict()
     for name, ref in new_stats.items():
-        np.testing.assert_allclose(model.params[name].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(state[name].numpy(), ref.numpy(), rtol=1e-4, atol=1e-6)
+    if factor != 1:      # the padding stays exactly zero through a training step
+        wt = model.params["SmallUNet/conv_e0/conv2/weights"]
+        assert float(wt[:, :, 48:, :].abs().sum()) == 0.0 and float(wt[:, :, :, 48:].abs().sum()) == 0.0
     solver = Solver(args)
     first = None
     for _ in range(4):
@@ -96,4 +107,7 @@ def test_smallunet_matches_oracle_and_trains(normalizer, loss_type):
     model(inputs, "eval", **YML)
     assert model.probability.shape == (2, 64, 64, 3) and model.predictions["LiverPred"].dtype == torch.uint8
     with pytest.raises(NotImplementedError):
-        zoo["SmallUNet"](args)(inputs, "eval", **dict(YML, init_channel_factor=0.75))
+        zoo["SmallUNet"](args)(inputs, "eval", **dict(YML, init_channel_factor=0.3))
+    if factor != 1:
+        wt = model.params["SmallUNet/conv_e0/conv2/weights"]
+        assert float(wt.detach()[:, :, 48:, :].abs().sum()) == 0.0 and float(wt.detach()[:, :, :, 48:].abs().sum()) == 0.0
