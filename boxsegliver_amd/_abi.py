@@ -89,6 +89,7 @@ _SIGNATURES = {
     "unetk_maxpool2_bwd": (c_int, [P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P]),
     "unetk_avgpool2_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "unetk_image_gradients": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "unetk_sobel_concat": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "unetk_flip_axpy": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     "unetk_deconv2x2_pack": (c_int, [P, c_int, c_int, P, P, P]),
     "unetk_deconv2x2_pack_bf16": (c_int, [P, c_int, c_int, P, P, P]),

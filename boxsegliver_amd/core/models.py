@@ -15,13 +15,13 @@ from ..NetworksV2.UNet3D import UNet3D
 from ..NetworksV2.UNetInter import UNetInter
 from ..NetworksV2.SmallUNet import SmallUNet
 from ..NetworksV2.LGNet import LGNet
+from ..NetworksV2.InterUNet import InterUNet
 from ..NetworksV2.base import ModeKeys
 
 # Available models (reference models.py:36-38 lists UNet, GUNet, UNetInter, LGNet, UNet3D, SmallUNet,
-# InterUNet; this build ships all of them but InterUNet (a two-encoder composition of SmallUNet's ops with 32-channel
-# layers and a Sobel input).
+# InterUNet (DenseUNet is commented out there); this build ships all seven.
 MODEL_ZOO = [
-    UNet, GUNet, UNetInter, LGNet, UNet3D, SmallUNet,
+    UNet, GUNet, UNetInter, LGNet, UNet3D, SmallUNet, InterUNet,
 ]
 
 EstimatorSpec = namedtuple("EstimatorSpec", ["mode", "loss", "train_op", "predictions", "model"])

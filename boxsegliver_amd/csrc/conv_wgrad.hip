@@ -479,7 +479,7 @@ WgPlan wg_plan(int N, int H, int W, int Cin, int Cout, bool bf16 = false) {
     if (S < 1) S = 1;
     pl.tiles_per_split = (pl.total_tiles + S - 1) / S;
     pl.S = (pl.total_tiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
-  } else if ((Cin <= 4 || Cin == 9) && Cout <= 256 && 256 % Cout == 0) {  // 9 = 3 channels x (image, dy, dx): --img_grad
+  } else if ((Cin <= 5 || Cin == 9) && Cout <= 256 && 256 % Cout == 0) {  // 9 = 3 channels x (image, dy, dx): --img_grad; 5 = image + Sobel
     pl.mode = 1;
     int S = 2048;
     if (S > pl.total_tiles) S = pl.total_tiles;
@@ -617,6 +617,7 @@ int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_
       case 2: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<2>, dim3(pl.S), dim3(256), lds, st, p); break;
       case 3: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<3>, dim3(pl.S), dim3(256), lds, st, p); break;
       case 4: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<4>, dim3(pl.S), dim3(256), lds, st, p); break;
+      case 5: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<5>, dim3(pl.S), dim3(256), lds, st, p); break;
       case 9: {
         static bool attr_done = false;
         if (!attr_done) {

@@ -113,7 +113,41 @@ __global__ void image_gradients_kernel(const float* __restrict__ x, float* __res
   }
 }
 
+// tf.image.sobel_edges of ONE channel + concat (InterUNet.py:105-109): out[..., 0:C] = x, out[..., C] = dy, out[..., C+1] = dx
+// with the 3x3 Sobel kernels [[-1,-2,-1],[0,0,0],[1,2,1]] (dy) and its transpose (dx) as cross-correlations over the
+// REFLECT-padded image (index -1 -> 1, H -> H-2).
+__global__ void sobel_concat_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int H, int W, int C, int ch) {
+  const int64_t total = (int64_t)N * H * W;
+  for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (int64_t)gridDim.x * blockDim.x) {
+    const int w = (int)(pix % W);
+    const int h = (int)((pix / W) % H);
+    const int64_t img = (pix / ((int64_t)W * H)) * H * W;
+    float v[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        int hh = h + a - 1, ww = w + b - 1;
+        hh = hh < 0 ? -hh : (hh >= H ? 2 * H - 2 - hh : hh);
+        ww = ww < 0 ? -ww : (ww >= W ? 2 * W - 2 - ww : ww);
+        v[a][b] = x[(img + (int64_t)hh * W + ww) * C + ch];
+      }
+    float* o = out + pix * (C + 2);
+    for (int c = 0; c < C; ++c) o[c] = x[pix * C + c];
+    o[C] = (v[2][0] + 2.f * v[2][1] + v[2][2]) - (v[0][0] + 2.f * v[0][1] + v[0][2]);
+    o[C + 1] = (v[0][2] + 2.f * v[1][2] + v[2][2]) - (v[0][0] + 2.f * v[1][0] + v[2][0]);
+  }
+}
+
 }  // namespace
+
+extern "C" int unetk_sobel_concat(const float* x, float* out, int N, int H, int W, int C, int ch, void* stream) {
+  UNETK_REQUIRE(x && out && N > 0 && H > 1 && W > 1 && C > 0 && ch >= 0 && ch < C);
+  hipLaunchKernelGGL(sobel_concat_kernel, dim3(ew_grid((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, x, out, N, H,
+                     W, C, ch);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
 
 // out[n,h,w,:] (+)= scale * x[n, fh ? H-1-h : h, fw ? W-1-w : w, :] -- mirror test-time augmentation on the device:
 // flips the slab fed to the net and un-flips + accumulates the class probabilities (np.flip(...) / mirror_div at

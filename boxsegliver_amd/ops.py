@@ -309,6 +309,16 @@ def norm_relu_bwd(d, y, dz, aff, has_gamma, has_beta, guide=None, gw=None, gb=No
 norm_relu_bwd_nd = norm_relu_bwd     # rank-agnostic (dz pixel stride = stride of the second-to-last axis)
 
 
+def sobel_concat(x, ch):
+    """InterUNet --img_grad: concat(x, sobel_dy(x[..., ch]), sobel_dx(x[..., ch])) (InterUNet.py:105-109); no gradient."""
+    _require_cuda(x)
+    x = x.to(torch.float32).contiguous()
+    n, h, w, c = x.shape
+    out = torch.empty((n, h, w, c + 2), dtype=torch.float32, device=x.device)
+    check(_abi.lib().unetk_sobel_concat(ptr(x), ptr(out), n, h, w, c, int(ch), stream_ptr()), "sobel_concat")
+    return out
+
+
 def image_gradients(x):
     """--img_grad: concat(x, dy, dx) along channels (UNet.py:69-71); the input needs no gradient."""
     _require_cuda(x)
@@ -620,6 +630,7 @@ class Conv3x3NormRelu(torch.autograd.Function):
             ctx.has = (gamma is not None, beta is not None)
             ctx.w_dbg = w.detach() if DEBUG_CAPTURE is not None else None
             ctx.gb_dbg = (gamma, beta) if DEBUG_CAPTURE is not None else None
+            ctx.z_dbg = z.detach() if DEBUG_CAPTURE is not None else None      # the forward's own ReLU mask, for the checkers
         return alias(z) if out is not None else z
 
     @staticmethod
@@ -636,7 +647,7 @@ class Conv3x3NormRelu(torch.autograd.Function):
         dw = conv3x3_wgrad(x, dy, bf16=ctx.bf16, dilation=ctx.dilation)
         dx = conv3x3_dgrad(dy, ctx.wp_d, x.shape[3], bf16=ctx.bf16, dilation=ctx.dilation) if ctx.need_dx else None
         if DEBUG_CAPTURE is not None:
-            DEBUG_CAPTURE.append(dict(x=x, y=y, dilation=ctx.dilation, gamma=ctx.gb_dbg[0], beta=ctx.gb_dbg[1], aff=aff, dz=dz, dy=dy, dw=dw,
+            DEBUG_CAPTURE.append(dict(x=x, y=y, dilation=ctx.dilation, z=ctx.z_dbg, gamma=ctx.gb_dbg[0], beta=ctx.gb_dbg[1], aff=aff, dz=dz, dy=dy, dw=dw,
                                       dx=dx, dgamma=dgamma, dbeta=dbeta, w=ctx.w_dbg, guide=guide, gw=gw, gb=gb,
                                       dgw=dgw, dgb=dgb, per_sample=bool(ctx.desc.per_sample), bf16=ctx.bf16, den=den,
                                       dden=dden, guide_leaky=bool(ctx.desc.guide_leaky)))
@@ -708,7 +719,7 @@ class Conv3dNormRelu(torch.autograd.Function):
             ctx.save_for_backward(x, y, aff)
             ctx.wp_d, ctx.need_dx, ctx.d, ctx.nd = wp_d, need_dx, d, nd
             ctx.has = (gamma is not None, beta is not None)
-            ctx.dbg = (w.detach(), gamma, beta, stride) if DEBUG_CAPTURE is not None else None
+            ctx.dbg = (w.detach(), gamma, beta, stride, z.detach()) if DEBUG_CAPTURE is not None else None
         return alias(z) if out is not None else z
 
     @staticmethod
@@ -722,7 +733,7 @@ class Conv3dNormRelu(torch.autograd.Function):
         dx = conv3d_dgrad(dy, ctx.wp_d, dense) if ctx.need_dx else None
         if DEBUG_CAPTURE is not None:
             DEBUG_CAPTURE.append(dict(kind="conv3d", x=x, y=y, w=ctx.dbg[0], gamma=ctx.dbg[1], beta=ctx.dbg[2],
-                                      stride=ctx.dbg[3], dz=dz, dy=dy, dw=dw, dx=dx, dgamma=dgamma, dbeta=dbeta,
+                                      stride=ctx.dbg[3], z=ctx.dbg[4], dz=dz, dy=dy, dw=dw, dx=dx, dgamma=dgamma, dbeta=dbeta,
                                       per_sample=bool(ctx.nd.per_sample)))
         return dx, dw, dgamma, dbeta, None, None, None, None, None
 
@@ -821,6 +832,37 @@ class DeconvConcat(torch.autograd.Function):
             DEBUG_CAPTURE.append(dict(kind="deconv", x=x, w=ctx.wb_dbg[0], b=ctx.wb_dbg[1], cat=cat.clone(),
                                       dcat=dcat, dx=dx, dw=dw, db=db, coff=ctx.coff, bf16=ctx.bf16))
         return dx, dw, (db if ctx.has_b else None), dskip, None, None
+
+
+class DeconvConcatFront(torch.autograd.Function):
+    """cat = concat(relu(conv2d_transpose(x, w, k=2, s=2) [+ b]), skip_a, skip_b) -- InterUNet's decoder (InterUNet.py:150-155:
+    the up-sampled tensor FIRST, then the skips of the two encoders).  The skips already live in cat[..., C:] (their
+    encoders wrote them there); the kernel fills cat[..., :C]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, skip_a, skip_b, cat):
+        _require_cuda(x, w, cat)
+        cout = w.shape[2]
+        ca, cb = skip_a.shape[3], skip_b.shape[3]
+        assert cat.shape[3] == cout + ca + cb
+        assert skip_a.data_ptr() == cat.data_ptr() + 4 * cout and skip_b.data_ptr() == cat.data_ptr() + 4 * (cout + ca)
+        wp_f, wp_d = deconv2x2_pack(w, False)
+        deconv2x2_fwd(x, wp_f, b, cat, 0, cout, False)
+        ctx.save_for_backward(x, cat)
+        ctx.wp_d, ctx.cout, ctx.ca, ctx.has_b = wp_d, cout, ca, b is not None
+        ctx.wb_dbg = (w.detach(), b.detach() if b is not None else None) if DEBUG_CAPTURE is not None else None
+        return alias(cat)
+
+    @staticmethod
+    def backward(ctx, dcat):
+        x, cat = ctx.saved_tensors
+        dcat = dcat.contiguous()
+        dx, dw, db = deconv2x2_bwd(x, ctx.wp_d, cat, dcat, 0, ctx.cout, False)
+        if DEBUG_CAPTURE is not None:
+            DEBUG_CAPTURE.append(dict(kind="deconv", x=x, w=ctx.wb_dbg[0], b=ctx.wb_dbg[1], cat=cat.clone(), dcat=dcat, dx=dx,
+                                      dw=dw, db=db, coff=0, bf16=False))
+        c0, c1 = ctx.cout, ctx.cout + ctx.ca
+        return dx, dw, (db if ctx.has_b else None), dcat[..., c0:c1], dcat[..., c1:], None
 
 
 class HeadLoss(torch.autograd.Function):

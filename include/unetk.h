@@ -200,6 +200,9 @@ int unetk_maxpool2_bwd(const float* x, int x_stride, const float* p, const float
 int unetk_avgpool2_fwd(const float* x, float* p, int N, int H, int W, int C, void* stream);
 /* --img_grad (UNet.py:69-71, GUNet.py:335-338): out [N,H,W,3C] = concat(x, dy, dx) with
  * tf.image.image_gradients' forward differences (dy[h] = x[h+1] - x[h], last row 0; dx likewise). */
+/* InterUNet's --img_grad input (InterUNet.py:105-109): out [N,H,W,C+2] = concat(x, sobel_dy(x[..., ch]), sobel_dx(x[..., ch]))
+ * with tf.image.sobel_edges' kernels over the REFLECT-padded channel. */
+int unetk_sobel_concat(const float* x, float* out, int N, int H, int W, int C, int ch, void* stream);
 int unetk_image_gradients(const float* x, float* out, int N, int H, int W, int C, void* stream);
 /* Mirror test-time augmentation (evaluators/evaluator_liver.py:648-655; the reference flips on the host with
  * np.flip): out[n,h,w,:] (+)= scale * x[n, flip_h ? H-1-h : h, flip_w ? W-1-w : w, :].  x != out. */

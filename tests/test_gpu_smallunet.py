@@ -42,9 +42,6 @@ def test_smallunet_matches_oracle_and_trains(normalizer, loss_type, factor):
         assert model.params["SmallUNet/conv_e0/conv2/weights"].shape == (3, 3, 64, 64)
         assert model.params["SmallUNet/conv_d0/conv1/weights"].shape == (3, 3, 128, 64)
         assert model.params.state_dict()["SmallUNet/conv_d0/conv1/weights"].shape == (3, 3, 96, 48)
-    # (seed chosen so that no pre-activation of this run lies within fp32 rounding of zero: check_unit_backward compares
-    # element-wise against float64, and a single ReLU mask flip at |u| ~ 1e-8 shows up as an O(1) difference there --
-    # seed 6 has exactly one such element in conv_e0/conv1; the runs are bit-reproducible, so this is stable)
     gen = torch.Generator().manual_seed(16)
     params = {}
     for name, t in model.params.state_dict().items():

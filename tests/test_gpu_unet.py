@@ -162,15 +162,16 @@ def check_deconv_backward(c, tol=1e-5):
     from oracle import tf_ops
     x = c["x"].detach().cpu().double().requires_grad_(True)
     w = c["w"].cpu().double().requires_grad_(True)
-    b = c["b"].cpu().double().requires_grad_(True)
-    coff = c["coff"]
+    b = c["b"].cpu().double().requires_grad_(True) if c["b"] is not None else None      # bias-free: SmallUNet / InterUNet
+    coff, cout = c["coff"], c["w"].shape[2]                                            # the up-sampled slice of the concat buffer
     pre = tf_ops.conv_transpose_ks(x, w, (2, 2), bias=b)
     # ReLU mask from the HIP forward value (identical operands): d relu = 1 where the stored output > 0
-    mask = (c["cat"][..., coff:].cpu() > 0).double()
-    (pre * mask).backward(c["dcat"][..., coff:].detach().cpu().double())
+    mask = (c["cat"][..., coff:coff + cout].cpu() > 0).double()
+    (pre * mask).backward(c["dcat"][..., coff:coff + cout].detach().cpu().double())
     assert rel(c["dx"].cpu().numpy(), x.grad.numpy()) < tol
     assert rel(c["dw"].cpu().numpy(), w.grad.numpy()) < tol
-    assert rel(c["db"].cpu().numpy(), b.grad.numpy()) < tol
+    if b is not None:
+        assert rel(c["db"].cpu().numpy(), b.grad.numpy()) < tol
 
 
 def check_unit_backward(c, tol=1e-5):
@@ -196,7 +197,12 @@ def check_unit_backward(c, tol=1e-5):
         z = z + (c["guide"].detach().cpu().double() @ gw + gb)
     elif gb is not None:                                   # bare post-shift (after_affine without a guide)
         z = z + gb
-    torch.relu(z).backward(c["dz"].detach().cpu().double())
+    # ReLU mask from the HIP forward value when it was captured (identical operands): a pre-activation within fp32 rounding
+    # of zero would otherwise flip between the float64 recomputation and the device and show up as an O(1) difference
+    if c.get("z") is not None:
+        (z * (c["z"].detach().cpu() > 0).double()).backward(c["dz"].detach().cpu().double())
+    else:
+        torch.relu(z).backward(c["dz"].detach().cpu().double())
     if den is not None:
         assert rel(c["dden"].cpu().numpy(), den.grad.numpy()) < tol
     assert rel(c["dy"].cpu().numpy(), y.grad.numpy()) < tol

@@ -14,7 +14,7 @@ CONFIGS = sorted(p.name for p in list(NETS.glob("*.yml")) + list((NETS / "ext_co
 
 def test_registry_matches_reference_names():
     names = [cls.__name__ for cls in models.MODEL_ZOO]
-    assert names == ["UNet", "GUNet", "UNetInter", "LGNet", "UNet3D", "SmallUNet"]
+    assert names == ["UNet", "GUNet", "UNetInter", "LGNet", "UNet3D", "SmallUNet", "InterUNet"]   # reference models.py:36-38
     parser = argparse.ArgumentParser()
     models.add_arguments(parser)
     ns = parser.parse_args(["--model", "UNetInter", "--classes", "Liver", "Tumor"])
@@ -45,4 +45,4 @@ def test_default_config_name_and_missing_config():
     args = argparse.Namespace(model="UNet", model_config="does_not_exist.yml")
     assert models.get_model_params(args)["model_kwargs"] == {"build_metrics": False, "build_summaries": False}
     with pytest.raises(NameError):
-        models.get_model_params(argparse.Namespace(model="InterUNet", model_config=None))
+        models.get_model_params(argparse.Namespace(model="DenseUNet", model_config=None))
