@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP-event timing")
     ap.add_argument("--detail", action="store_true", help="break the kernel table down by layer shape")
-    ap.add_argument("--model", default="UNet", choices=["UNet", "GUNet", "UNet3D"],
+    ap.add_argument("--model", default="UNet", choices=["UNet", "GUNet", "UNet3D", "UNetInter", "LGNet", "SmallUNet", "InterUNet"],
                     help="UNet = the headline workload (BASELINE.json configs[1]); GUNet / UNet3D = configs[3] / [4] "
                          "(use --batch 8 / --size 96 --batch 1..4)")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
@@ -138,6 +138,11 @@ def main():
         input_fn = synthetic.input_fn_3d
         gflop_unit = 1612.92 * (a.size / 96.0) ** 3
         workload_name = "UNet3D {0}x{0}x{0}x1 bs={1}/GPU fp32 instance_norm (BASELINE.json configs[4])"
+    elif a.model in ("UNetInter", "LGNet", "SmallUNet", "InterUNet"):     # the other MODEL_ZOO nets: guide as a second input
+        args.use_spatial, args.use_context, args.guide_channel, args.normalizer = True, False, 1, "instance_norm"
+        args.side_dropout, args.dropout, args.use_se, args.fix, args.mid_cat = 0.5, None, False, False, False
+        gflop_unit = None                                                 # algorithmic FLOPs summed from the kernel events
+        workload_name = a.model + " + 1-ch guide {0}x{0}x3 bs={1}/GPU fp32 instance_norm (not a BASELINE.json config)"
     YML = models.get_model_params(args, build_metrics=True)["model_kwargs"]
     params = {"args": args, "rank": rank, "device": torch.device("cuda", torch.cuda.current_device())}
     data = input_fn("train", params)
@@ -195,6 +200,8 @@ def main():
         if a.dtype == "bf16":
             wl = wl.replace(" fp32", " bf16-MFMA/fp32-accumulate+storage")
         peak = FP32_PEAK_TFLOPS if a.dtype == "fp32" else BF16_PEAK_TFLOPS
+        if gflop_unit is None:      # conv / deconv algorithmic FLOPs (2 per MAC, fwd + dgrad + wgrad) of one unit, from the events
+            gflop_unit = (sum(f for _, f, _, _ in prof) / a.steps / a.batch / 1e9) if prof else 0.0
         out = {
             "metric": METRIC if a.model == "UNet" else "{} units/sec/node (fwd+bwd)".format(a.model),
             "value": round(slices, 2), "unit": "slices/s" if a.model != "UNet3D" else "patches/s", "n_gpus": world,
@@ -232,7 +239,8 @@ def main():
             try:
                 fname = "r01_pmc_traffic.json" if a.dtype == "fp32" else "r01_pmc_traffic_bf16.json"
                 pmc = json.load(open(os.path.join(ROOT, "profiles", fname)))["kernels"]
-                norm = {k.replace(" ", "").replace(",1>", ">"): v for k, v in pmc.items()}   # <..., S=1> == the tag
+                import re
+                norm = {re.sub(r"(,1)+>", ">", k.replace(" ", "")): v for k, v in pmc.items()}   # <..., S=1, DIL=1> == the tag
                 key = norm.get(top["kernel"].split("(")[0].replace(" ", "").replace(",false>", ">").replace(",true>", ">"))
                 if key is None and "wgrad_kernel" in top["kernel"]:
                     key = next((v for k, v in norm.items() if k.startswith("conv3x3_wgrad_kernel<64,64")), None)

@@ -16,6 +16,9 @@ $T python bench.py --steps 10 --warmup 3 --detail --no-cpu-baseline > "$OUT/benc
 $T python bench.py --model GUNet --batch 8 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_gunet_bs8.json"
 $T python bench.py --model UNet3D --size 96 --batch 2 --steps 5 --warmup 2 --detail --no-cpu-baseline > "$OUT/bench_unet3d_96_bs2.json"
 $T python bench.py --model UNet3D --size 96 --batch 1 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_unet3d_96_bs1.json"
+for m in UNetInter LGNet SmallUNet InterUNet; do
+  $T python bench.py --model $m --batch 8 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_${m}_bs8.json"
+done
 echo "fp32 benches done"
 $T python bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_bf16_256_bs32.json"
 $T python bench.py --dtype bf16 --size 512 --batch 8 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_bf16_512_bs8.json"
