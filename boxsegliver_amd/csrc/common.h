@@ -96,7 +96,7 @@ int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout, int spg = 1, in
 bool unetk_conv_stride2_ok(int Cin, int Cout);
 // conv_igemm_lin.hip: linear-pixel variant for planes narrower than 32 pixels (same packed filters)
 bool unetk_conv_lin_ok(int N, int H, int W, int Cin, int Cout, int spg);
-int unetk_conv_stat_rows_lin(int N, int H, int W, int spg);
+int unetk_conv_stat_rows_lin(int N, int H, int W, int spg, int Cout = 0);   // Cout picks the block height (64 / 128 pixels)
 int unetk_conv_run_lin(ConvParams p, hipStream_t st);
 // conv_igemm_bf16.hip
 bool unetk_conv_bf16_ok(int Cin, int Cout);

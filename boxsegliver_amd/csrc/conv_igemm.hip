@@ -334,6 +334,15 @@ struct ConvCfg {
   int th;
 };
 
+// Small grids (deep levels at small batch: 8 x 32^2 pixels x 512 couts = 256 blocks of 128 x 128) leave CUs idle or
+// at one block each: halve the pixel tile (4-row tiles, <2,2,1,2>) when the 128 x 128 grid has fewer than 1.5 blocks
+// per CU.  The statistic rows follow the tile height, so both users go through this one predicate.
+inline bool small_grid(int N, int H, int W, int Cout) {
+  if (Cout % 128 != 0) return false;
+  const int64_t blocks = (int64_t)N * ((H + 7) / 8) * ((W + TW - 1) / TW) * (Cout / 128);
+  return blocks < 384;
+}
+
 inline ConvCfg pick_cfg(int Cin, int Cout) {
   if (Cin % CK == 0 && Cout % 128 == 0) return {0, 8};
   if (Cin % CK == 0 && Cout % 64 == 0) return {1, 8};
@@ -370,9 +379,10 @@ static int s2_th(int Cout) { return Cout % 128 == 0 ? 4 : 8; }
 int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout, int spg, int stride, int dil) {
   if (dil == 2) return N * ((H + 7) / 8) * ((W + TW - 1) / TW);
   if (stride == 2) return N * ((H + s2_th(Cout) - 1) / s2_th(Cout)) * ((W + TW - 1) / TW);
-  if (unetk_conv_lin_ok(N, H, W, Cin, Cout, spg)) return unetk_conv_stat_rows_lin(N, H, W, spg);
+  if (unetk_conv_lin_ok(N, H, W, Cin, Cout, spg)) return unetk_conv_stat_rows_lin(N, H, W, spg, Cout);
   const ConvCfg cfg = pick_cfg(Cin, Cout);
-  return N * ((H + cfg.th - 1) / cfg.th) * ((W + TW - 1) / TW);
+  const int th = (cfg.id == 0 && small_grid(N, H, W, Cout)) ? 4 : cfg.th;
+  return N * ((H + th - 1) / th) * ((W + TW - 1) / TW);
 }
 
 bool unetk_conv_stride2_ok(int Cin, int Cout) { return Cin % CK == 0 && Cout % 64 == 0; }
@@ -409,10 +419,16 @@ int unetk_conv_run(ConvParams p, hipStream_t st) {
   if (p.spg < 1) p.spg = 1;
   if (unetk_conv_lin_ok(p.N, p.H, p.W, p.Cin, p.Cout, p.spg)) return unetk_conv_run_lin(p, st);   // small planes: linear M
   const ConvCfg cfg = pick_cfg(p.Cin, p.Cout);
-  p.tiles_h = (p.H + cfg.th - 1) / cfg.th;
+  const bool small = cfg.id == 0 && small_grid(p.N, p.H, p.W, p.Cout);
+  const int th = small ? 4 : cfg.th;
+  p.tiles_h = (p.H + th - 1) / th;
   p.tiles_w = (p.W + TW - 1) / TW;
   const int n_mtiles = p.N * p.tiles_h * p.tiles_w;
   p.stat_rows = n_mtiles;
+  if (small) {
+    p.n_ntiles = p.Cout / 128;
+    return launch_igemm<2, 2, 1, 2>(p, n_mtiles, st);
+  }
   if (cfg.id == 0) {
     p.n_ntiles = p.Cout / 128;
     return launch_igemm<2, 2, 2, 2>(p, n_mtiles, st);

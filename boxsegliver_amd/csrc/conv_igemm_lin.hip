@@ -448,8 +448,16 @@ bool unetk_conv_lin_ok(int N, int H, int W, int Cin, int Cout, int spg) {
   return rows * (W + 2) <= LIN_MAXPIX;
 }
 
-int unetk_conv_stat_rows_lin(int N, int H, int W, int spg) {
-  return (N / spg) * (int)(((int64_t)spg * H * W + LIN_BM - 1) / LIN_BM);
+// 64-pixel blocks when 128-pixel blocks x 128 couts would give fewer than 1.5 blocks per CU (deep levels at small batch)
+static int lin_bm(int N, int H, int W, int Cout, int spg) {
+  if (Cout % 128 != 0) return LIN_BM;
+  const int64_t blocks = (int64_t)(N / spg) * (((int64_t)spg * H * W + LIN_BM - 1) / LIN_BM) * (Cout / 128);
+  return blocks < 384 ? 64 : LIN_BM;
+}
+
+int unetk_conv_stat_rows_lin(int N, int H, int W, int spg, int Cout) {
+  const int bm = Cout > 0 ? lin_bm(N, H, W, Cout, spg) : LIN_BM;
+  return (N / spg) * (int)(((int64_t)spg * H * W + bm - 1) / bm);
 }
 
 static int lin_rows_bound(int H, int W, int bm = LIN_BM) { return (bm + W - 1) / W + 1 + 2 + 2 * ((bm + H * W - 1) / (H * W)); }
@@ -485,7 +493,7 @@ int unetk_conv_run_lin_gen(ConvParams p, hipStream_t st) {
     return launch_lin<4, 1, 1, 1, true, true>(p, n_mt, st);
   }
   if (p.Cout % 64 != 0) return UNETK_E_UNSUPPORTED;
-  const int n_mtiles = unetk_conv_stat_rows_lin(p.N, p.H, p.W, p.spg);
+  const int n_mtiles = unetk_conv_stat_rows_lin(p.N, p.H, p.W, p.spg, 0);
   p.stat_rows = n_mtiles;
   p.lin_pix = lin_rows_bound(p.H, p.W) * (p.W + 2);
   if (p.Cout % 128 == 0) {
@@ -497,11 +505,16 @@ int unetk_conv_run_lin_gen(ConvParams p, hipStream_t st) {
 }
 
 int unetk_conv_run_lin(ConvParams p, hipStream_t st) {
-  const int n_mtiles = unetk_conv_stat_rows_lin(p.N, p.H, p.W, p.spg);
+  const int n_mtiles = unetk_conv_stat_rows_lin(p.N, p.H, p.W, p.spg, p.Cout);
+  const int bm = lin_bm(p.N, p.H, p.W, p.Cout, p.spg);
   p.stat_rows = n_mtiles;
   p.tiles_h = p.tiles_w = 0;
-  p.lin_pix = ((LIN_BM + p.W - 1) / p.W + 1 + 2 + 2 * ((LIN_BM + p.H * p.W - 1) / (p.H * p.W))) * (p.W + 2);
+  p.lin_pix = lin_rows_bound(p.H, p.W, bm) * (p.W + 2);
   if (p.xs % 4 != 0) return UNETK_E_BADARG;
+  if (bm == 64) {
+    p.n_ntiles = p.Cout / 128;
+    return launch_lin<2, 2, 1, 2>(p, n_mtiles, st);
+  }
   if (p.Cout % 128 == 0) {
     p.n_ntiles = p.Cout / 128;
     return launch_lin<2, 2, 2, 2>(p, n_mtiles, st);
