@@ -266,7 +266,11 @@ struct BfCfg {
 // 0: 512x128 (8 waves)  1: 128x128  2: 256x64 (60 KB of LDS: two blocks per CU -- the Cout = 64 layers are
 // HBM-bound, and a second resident block overlaps one block's halo load / output store with the other's MFMAs)
 // 3: 128x64  4: 256x32
-inline BfCfg pick_bf16(int H, int Cin, int Cout) {
+// (Measured: the tall 512 x 128 tile beats the 128 x 128 one even on grids it under-fills -- 8 x 32^2 pixels x 1024
+// couts = 128 blocks on 256 CUs: 315 vs 277 slices/s at 512^2 bs 8 -- the bf16 kernels are bound by the L2 -> LDS stream,
+// which the tall tile halves per MFMA; so the choice depends on H only.)
+inline BfCfg pick_bf16(int H, int Cin, int Cout, int N = 1 << 20, int W = 1 << 10) {
+  (void)N; (void)W;
   if (Cin % CKB != 0 || Cout % 32 != 0) return {-1, 8};
   if (Cout % 128 == 0) return H >= 24 ? BfCfg{0, 32} : BfCfg{1, 8};
   if (Cout % 64 == 0) return H >= 12 ? BfCfg{2, 16} : BfCfg{3, 8};
@@ -297,13 +301,13 @@ int launch_bf16(const ConvParams& p, int n_mtiles, hipStream_t st) {
 bool unetk_conv_bf16_ok(int Cin, int Cout) { return Cin % CKB == 0 && Cout % 32 == 0; }
 
 int unetk_conv_stat_rows_bf16(int N, int H, int W, int Cin, int Cout) {
-  const BfCfg cfg = pick_bf16(H, Cin, Cout);
+  const BfCfg cfg = pick_bf16(H, Cin, Cout, N, W);
   if (cfg.id < 0) return UNETK_E_UNSUPPORTED;
   return N * ((H + cfg.th - 1) / cfg.th) * ((W + TW - 1) / TW);
 }
 
 int unetk_conv_run_bf16(ConvParams p, hipStream_t st) {
-  const BfCfg cfg = pick_bf16(p.H, p.Cin, p.Cout);
+  const BfCfg cfg = pick_bf16(p.H, p.Cin, p.Cout, p.N, p.W);
   if (cfg.id < 0) return UNETK_E_UNSUPPORTED;
   if (p.xs % 4 != 0) return UNETK_E_BADARG;
   p.tiles_h = (p.H + cfg.th - 1) / cfg.th;

@@ -63,7 +63,10 @@ class _Timed(object):
         return False
 
 
-def _igemm_tag(cin, cout, bf16=False, h=0):
+def _igemm_tag(cin, cout, bf16=False, h=0, n=1 << 20, w=1 << 10):
+    """Kernel name of a conv3x3 forward / input-gradient launch (mirrors the dispatch of conv_igemm*.hip; bench labels)."""
+    def cdiv(a, b):
+        return -(-a // b)
     if bf16 and cin % 32 == 0 and cout % 32 == 0:
         if cout % 128 == 0:
             return "conv3x3_igemm_bf16_kernel<4,2,4,2>" if h >= 24 else "conv3x3_igemm_bf16_kernel<2,2,2,2>"
@@ -71,6 +74,8 @@ def _igemm_tag(cin, cout, bf16=False, h=0):
             return "conv3x3_igemm_bf16_kernel<4,1,2,2>" if h >= 12 else "conv3x3_igemm_bf16_kernel<4,1,1,2>"
         return "conv3x3_igemm_bf16_kernel<4,1,2,1>"
     if cin % 16 == 0 and cout % 128 == 0:
+        if n * cdiv(h, 8) * cdiv(w, 16) * (cout // 128) < 384:      # under-filled grid: half-height tiles
+            return "conv3x3_igemm_kernel<2,2,1,2>"
         return "conv3x3_igemm_kernel<2,2,2,2>"
     if cin % 16 == 0 and cout % 64 == 0:
         return "conv3x3_igemm_kernel<4,1,1,2>"
@@ -145,7 +150,7 @@ def conv3x3_fwd(x, w, cout, want_stats=True, y=None, bf16=False, dilation=1):
         if rows <= 0:
             check(rows, "conv3x3_stat_rows")
         stats = torch.empty((2, rows, cout), dtype=torch.float32, device=x.device)
-    with _Timed(_igemm_tag(cin, cout, bf16, h), 18.0 * n * h * wd * cin * cout,
+    with _Timed(_igemm_tag(cin, cout, bf16, h, n, wd), 18.0 * n * h * wd * cin * cout,
                 "fwd {}x{}x{} {}->{}".format(n, h, wd, cin, cout)):
         check(_abi.lib().unetk_conv3x3_fwd(ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(stats), stream_ptr()),
               "conv3x3_fwd")
@@ -158,7 +163,7 @@ def conv3x3_dgrad(dy, wp_dgrad, cin, x_stride=None, dx=None, bf16=False, dilatio
     if dx is None:
         dx = torch.empty((n, h, wd, cin), dtype=torch.float32, device=dy.device)
     d = ConvDesc(n, h, wd, cin, cout, _pix_stride(dx), _pix_stride(dy), _abi.BF16 if bf16 else _abi.FP32, int(dilation))
-    with _Timed(_igemm_tag(cout, cin, bf16, h), 18.0 * n * h * wd * cin * cout, "dgrad {}x{}x{} {}->{}".format(n, h, wd, cout, cin)):
+    with _Timed(_igemm_tag(cout, cin, bf16, h, n, wd), 18.0 * n * h * wd * cin * cout, "dgrad {}x{}x{} {}->{}".format(n, h, wd, cout, cin)):
         check(_abi.lib().unetk_conv3x3_dgrad(ctypes.byref(d), ptr(dy), ptr(wp_dgrad), ptr(dx), stream_ptr()),
               "conv3x3_dgrad")
     return dx
