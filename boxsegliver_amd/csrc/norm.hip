@@ -331,7 +331,8 @@ bool norm_supported(const unetk_norm_desc* d) { return d->C % 4 == 0 && d->C <= 
 
 int bwd_blocks(const NormGeom& g) {
   int64_t b = (g.P + g.rpi - 1) / g.rpi;
-  const int64_t cap = g.L > 1 ? 64 : UNETK_COL_BLOCKS;
+  // per launch group; few groups (instance norm at batch 1-2: UNet3D's 96^3 tensors) need more blocks each to fill the GPU
+  const int64_t cap = g.L > 1 ? (2048 / g.L > 64 ? 2048 / g.L : 64) : UNETK_COL_BLOCKS;
   if (b > cap) b = cap;
   return (int)b;
 }
