@@ -451,8 +451,14 @@ bool unetk_conv_lin_ok(int N, int H, int W, int Cin, int Cout, int spg) {
 // 64-pixel blocks when 128-pixel blocks x 128 couts would give fewer than 1.5 blocks per CU (deep levels at small batch)
 static int lin_bm(int N, int H, int W, int Cout, int spg) {
   if (Cout % 128 != 0) return LIN_BM;
-  const int64_t blocks = (int64_t)(N / spg) * (((int64_t)spg * H * W + LIN_BM - 1) / LIN_BM) * (Cout / 128);
-  return blocks < 384 ? 64 : LIN_BM;
+  const int64_t nt = Cout / 128, groups = N / spg, gpix = (int64_t)spg * H * W;
+  const int64_t b128 = groups * ((gpix + 127) / 128) * nt, b64 = groups * ((gpix + 63) / 64) * nt;
+  if (b128 < 384) return 64;
+  // ... and when the grid quantises badly over the 256 CUs: 864 blocks of 128 pixels are 3.4 per CU = 84 % of four full
+  // rounds, 1728 blocks of 64 pixels 96 % of seven (measured on UNet3D's 24^2 levels: 108 -> 117 TFLOP/s; the 5 % margin
+  // is what the smaller block costs in filter-panel reuse)
+  auto eff = [](int64_t b) { return (double)b / (double)(((b + 255) / 256) * 256); };
+  return eff(b64) * 0.95 > eff(b128) ? 64 : LIN_BM;
 }
 
 int unetk_conv_stat_rows_lin(int N, int H, int W, int spg, int Cout) {
