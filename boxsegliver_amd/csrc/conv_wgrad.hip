@@ -475,6 +475,8 @@ WgPlan wg_plan(int N, int H, int W, int Cin, int Cout, bool bf16 = false) {
     pl.n_co_tiles = Cout / pl.cot;
     const int panels = pl.n_ci_tiles * pl.n_co_tiles;
     int S = (512 + panels - 1) / panels;  // one 512-thread block per CU (154 KB of LDS) x 256 CUs x 2 rounds
+    // few tiles per block (small layers): one round of 256 blocks halves the per-block epilogue (LDS tree + slab) per tile
+    if (pl.total_tiles / S < 16 && panels <= 256) S = (256 + panels - 1) / panels;
     if (S > pl.total_tiles) S = pl.total_tiles;
     if (S < 1) S = 1;
     pl.tiles_per_split = (pl.total_tiles + S - 1) / S;
