@@ -25,6 +25,7 @@ from ..loss_metrics import build_head_desc, metric_from_sums, pixel_weights
 from ..utils import distribution_utils
 from . import base
 from .base import ModeKeys, ParamStore
+from .padded import PaddedParamStore, pad_to
 
 
 def n_modulator_params(init_channels, num_down_samples, mod_layers):
@@ -33,7 +34,7 @@ def n_modulator_params(init_channels, num_down_samples, mod_layers):
 
 
 def param_specs(in_channels, num_classes, guide_channel, init_channels, num_down_samples, mod_layers, normalizer,
-                norm_with_center, norm_with_scale, use_spatial, name, context_dims=None, after_affine=False):
+                norm_with_center, norm_with_scale, use_spatial, name, context_dims=None, after_affine=False, mid_cat_g=0):
     """Variables with the reference's TF names: <name>/spatial/conv{i}/{weights,biases},
     <name>/Encode/down_conv{i}/mod_conv{j}/{weights,<Norm>/...}, <name>/Decode/up{i}/{weights,biases},
     <name>/Decode/up_conv{i}/up_conv{i}_{j}/..., <name>/AdjustChannels/{weights,biases}."""
@@ -77,6 +78,8 @@ def param_specs(in_channels, num_classes, guide_channel, init_channels, num_down
                 specs.append((scope + "/ChannelWiseAffine/beta", (c,), "beta"))
                 specs.append((scope + "/ChannelWiseAffine/gamma", (c,), "gamma"))
             cin = c
+        if i == 0 and mid_cat_g:            # UNetInter --mid_cat: the guide joins the pooled level-0 output (UNetInter.py:124-127)
+            cin = c + mid_cat_g
     c = init_channels * 2 ** num_down_samples
     for i in reversed(range(num_down_samples)):
         c //= 2
@@ -109,6 +112,7 @@ class GUNet(base.BaseNet):
         self.use_se = getattr(args, "use_se", False)
         self._taps = None
         self._concat_guide = False          # UNetInter: the guide joins the input channels instead of modulating
+        self._mid_cat = False               # UNetInter --mid_cat: ... or the pooled level-0 output
         self._encoder_decay = None          # UNetInter: BN decay of every encoder unit
 
     def _net_arg_scope(self, *args, **kwargs):
@@ -167,12 +171,22 @@ class GUNet(base.BaseNet):
                 [n_modulator_params(base_channels, nds, mod_layers)]
         if self.params is None:
             in_ch = self.channel * (3 if getattr(self.args, "img_grad", False) else 1)      # GUNet.py:335-338
-            if self._concat_guide:                                                          # UNetInter.py:87-88
-                in_ch = self.channel + int(getattr(self.args, "guide_channel", 1))
+            gc = int(getattr(self.args, "guide_channel", 1))
+            if self._concat_guide and not self._mid_cat:                                    # UNetInter.py:87-88
+                in_ch = self.channel + gc
+            mid_g = gc if (self._concat_guide and self._mid_cat) else 0
             specs = param_specs(in_ch, self.num_classes, g_ch, base_channels, nds, mod_layers,
                                 self.args.normalizer, norm_with_center, norm_with_scale, g_ch > 0, nm,
-                                context_dims, after_affine)
-            self.params = ParamStore(specs, dev, bias_decay=getattr(self.args, "bias_decay", False))
+                                context_dims, after_affine, mid_g)
+            if mid_g:
+                # Encode2's first conv sees 64 + g channels: padded with zero filter rows to the filter-gradient tile (32)
+                wname = "{}/Encode/down_conv2/mod_conv1/weights".format(nm)
+                cin_l = base_channels + mid_g
+                self._mid_pad = pad_to(cin_l, 32)
+                pads = {wname: ((3, 3, self._mid_pad, 2 * base_channels), {2: [(0, cin_l, 0)]})}
+                self.params = PaddedParamStore(specs, pads, dev, bias_decay=getattr(self.args, "bias_decay", False))
+            else:
+                self.params = ParamStore(specs, dev, bias_decay=getattr(self.args, "bias_decay", False))
             self.params.initialize(self._get_initializer()[0], seed=getattr(self.args, "seed", None))
         p = self.params
 
@@ -208,7 +222,8 @@ class GUNet(base.BaseNet):
                 gs = self._inputs["sp_guide"].to(torch.float32)
                 if gs.shape[:3] != images.shape[:3]:
                     raise ValueError("sp_guide must be [bs, H, W, g], got {}".format(tuple(gs.shape)))
-                x = torch.cat((images.to(torch.float32), gs), dim=-1).contiguous()
+                x = images.to(torch.float32).contiguous() if self._mid_cat else \
+                    torch.cat((images.to(torch.float32), gs), dim=-1).contiguous()
             elif getattr(self.args, "img_grad", False):
                 x = ops.image_gradients(images.to(torch.float32))
             else:
@@ -247,7 +262,14 @@ class GUNet(base.BaseNet):
                             gb = ba
                     x = self._unit(x, scope, spec, out, guide, gw, gb, den)
                 if i < nds:
-                    x, skips[i] = ops.MaxPoolSkip.apply(x)
+                    if i == 0 and self._concat_guide and self._mid_cat:
+                        # UNetInter.py:124-129: pool(concat(level-0 output, guide)); zero channels up to the padded width
+                        skips[i] = x
+                        gs = self._inputs["sp_guide"].to(torch.float32)
+                        zpad = torch.zeros((n, hh, ww, self._mid_pad - c - gs.shape[3]), dtype=torch.float32, device=dev)
+                        x = ops.MaxPool2x2.apply(torch.cat((x, gs, zpad), dim=-1))
+                    else:
+                        x, skips[i] = ops.MaxPoolSkip.apply(x)
                     hh //= 2
                     ww //= 2
 

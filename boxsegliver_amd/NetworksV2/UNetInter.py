@@ -6,8 +6,11 @@ mod_conv{j}`, `<name>/Decode/up{i}`, `up_conv{i}`, `AdjustChannels`) with no mod
 conv -> norm(centre, scale; BN decay .99, UNetInter.py:98-113) -> ReLU, the decoder uses the `_get_normalization`
 defaults.  So this class is GUNet with the guide routed to the input -- same kernels, nothing new on the device.
 
-Not built: --mid_cat (the guide concatenated after level 0 makes Encode2's Cin = 64 + g, not a multiple of the MFMA
-K-chunk) and `use_2d`.  --img_grad computes dy / dx in the reference but never feeds them to the net (:82-85): ignored.
+--mid_cat (scripts/106_unetinter_v1.sh; UNetInter.py:87-90,124-129): the guide is concatenated to the level-0 output
+before the first pool instead of to the input, so Encode2's first conv sees 64 + g channels; on the device that filter is
+padded with zero rows to 96 input channels (NetworksV2/padded.py) and the pooled tensor with zero channels.
+
+Not built: `use_2d`.  --img_grad computes dy / dx in the reference but never feeds them to the net (:82-85): ignored.
 """
 from .GUNet import GUNet
 
@@ -20,11 +23,12 @@ class UNetInter(GUNet):
         self.use_se = False
         self.dropout = None
         self._concat_guide = True
+        self._mid_cat = bool(getattr(args, "mid_cat", False))
         self._encoder_decay = 0.99
 
     def _net_arg_scope(self, *args, **kwargs):
-        if getattr(self.args, "mid_cat", False) or getattr(self.args, "use_2d", False):
-            raise NotImplementedError("UNetInter --mid_cat / use_2d are not built")
+        if getattr(self.args, "use_2d", False):
+            raise NotImplementedError("UNetInter use_2d is not built")
         if getattr(self.args, "without_norm", False):
             raise NotImplementedError("--without_norm has no HIP kernel yet")
         self._norm = self._get_normalization()

@@ -28,7 +28,7 @@ from .unet2d import TRAINABLE_KINDS  # noqa: F401
 
 def param_specs(in_channels, num_classes, guide_channel=1, init_channels=64, num_down_samples=4,
                 mod_layers=(1, 2, 3, 4), normalizer="instance_norm", norm_with_center=True, norm_with_scale=False,
-                name="GUNet", use_spatial=True, context_dims=None, after_affine=False):
+                name="GUNet", use_spatial=True, context_dims=None, after_affine=False, mid_cat_g=0):
     """context_dims = [context length, fc widths ..., n_modulator_param] enables the context branch."""
     specs = []
     bn = normalizer == "batch_norm"
@@ -75,6 +75,8 @@ def param_specs(in_channels, num_classes, guide_channel=1, init_channels=64, num
                 specs.append((scope + "/ChannelWiseAffine/gamma", None, "gamma"))
             fix_shapes(c, start)
             cin = c
+        if i == 0 and mid_cat_g:                                        # UNetInter --mid_cat (UNetInter.py:124-127)
+            cin = c + mid_cat_g
     c = init_channels * 2 ** num_down_samples
     for i in reversed(range(num_down_samples)):
         c //= 2
@@ -96,11 +98,12 @@ class GUNet2DOracle(object):
     def __init__(self, in_channels, num_classes, guide_channel=1, init_channels=64, num_down_samples=4,
                  mod_layers=(1, 2, 3, 4), normalizer="instance_norm", norm_with_center=True, norm_with_scale=False,
                  name="GUNet", img_grad=False, use_spatial=True, context_length=None, context_fc_channels=(256, 256),
-                 after_affine=False, concat_guide=False, encoder_decay=0.999):
+                 after_affine=False, concat_guide=False, encoder_decay=0.999, mid_cat=False):
         """concat_guide + mod_layers=() + encoder_decay=.99 + name="UNetInter" is the reference's UNetInter
         (NetworksV2/UNetInter.py:76-141): the guide joins the input channels, encoder BN decay .99 (:98-113)."""
         self.name, self.num_classes = name, num_classes
         self.after_affine, self.concat_guide, self.encoder_decay = after_affine, concat_guide, encoder_decay
+        self.mid_cat = bool(mid_cat and concat_guide)
         if concat_guide:
             use_spatial, mod_layers = False, ()
         self.use_spatial = use_spatial
@@ -114,7 +117,7 @@ class GUNet2DOracle(object):
         self.normalizer = normalizer
         self.specs = param_specs(in_channels, num_classes, guide_channel, init_channels, num_down_samples, mod_layers,
                                  normalizer, norm_with_center, norm_with_scale, name, use_spatial, self.context_dims,
-                                 after_affine)
+                                 after_affine, guide_channel if self.mid_cat else 0)
         self.kinds = {n: k for n, _, k in self.specs}
 
     def _unit(self, x, p, scope, is_training, new_stats, decay, sp=None, den=None):
@@ -163,7 +166,7 @@ class GUNet2DOracle(object):
             if i < self.nds:
                 gs = tf_ops.avg_pool2x2_same(gs)
         x = torch.cat((images,) + tf_ops.image_gradients(images), dim=-1) if self.img_grad else images
-        if self.concat_guide:                                          # UNetInter.py:87-88
+        if self.concat_guide and not self.mid_cat:                     # UNetInter.py:87-88
             x = torch.cat((images, sp_guide), dim=-1)
         skips = []
         for i in range(self.nds + 1):
@@ -179,6 +182,8 @@ class GUNet2DOracle(object):
                 x = self._unit(x, p, scope, is_training, new_stats, 0.99 if mod else self.encoder_decay, sp, den)
             if i < self.nds:
                 skips.append(x)
+                if i == 0 and self.mid_cat:                             # UNetInter.py:124-127
+                    x = torch.cat((x, sp_guide), dim=-1)
                 x = tf_ops.max_pool2x2(x)
         for i in reversed(range(self.nds)):
             d = "{}/Decode/up{}".format(n, i + 1)
