@@ -236,10 +236,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
 }
 
 // ------------------------------------------------------------------------------------------------
-// Direct kernel for layers the MFMA path does not cover (Encode1/conv1: Cin = 3, K = 27, HBM-bound:
-// it writes 256 B per pixel against 12 B read).  One block per 8x16 pixel tile; thread = (pixel lane,
-// 4 output channels).  Raw HWIO filters through L1/L2.
+// Direct kernel for layers the MFMA path does not cover (Encode1/conv1: Cin = 3, K = 27; UNet3D conv_e0/conv1: Cin = 1;
+// the guided nets' 4- and 5-channel inputs; --img_grad: 9).  HBM-bound by design: it writes Cout floats per pixel against
+// Cin read.  One block per 8x16 pixel tile; thread = (pixel lane, 4 output channels).  The thread's 9 x CIN x 4 filter
+// taps live in registers and the 10x18xCIN input halo in LDS (read as broadcasts by the Cout/4 threads of a pixel): the
+// first version re-read both through L1 per pixel and ran at 0.9 TB/s of output, VALU / L1-issue bound.
+// CIN = 0: generic fallback (any Cin, filters through L1).
+template <int CIN>
 __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [max(180 * cin, 2 * PL * Cout)]
+  const int cin = CIN > 0 ? CIN : p.Cin;
   const int cq_n = p.Cout >> 2;
   const int PL = 256 / cq_n;
   const int tid = threadIdx.x;
@@ -249,27 +255,45 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvParams p) {
   const int th_i = (mtile / p.tiles_w) % p.tiles_h;
   const int n_img = mtile / (p.tiles_w * p.tiles_h);
   const int h0 = th_i * 8, w0 = tw_i * TW;
+  const int64_t ximg = p.xa.off(n_img);
+  // input halo (10 x 18 pixels x cin) -> LDS, zero outside the image
+  for (int i = tid; i < 180 * cin; i += 256) {
+    const int pix = i / cin, ci = i - pix * cin;
+    const int ih = h0 + pix / 18 - 1, iw = w0 + pix % 18 - 1;
+    smem[i] = (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) ? p.x[ximg + ((int64_t)ih * p.W + iw) * p.xs + ci] : 0.f;
+  }
+  float4 wreg[CIN > 0 ? 9 * CIN : 1];
+  if (CIN > 0 && pl < PL) {
+#pragma unroll
+    for (int k = 0; k < 9 * CIN; ++k) wreg[k] = ldg4(p.wp + (int64_t)k * p.Cout + cq * 4);   // HWIO: k = tap * CIN + ci
+  }
+  __syncthreads();
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f), sq = s;
   if (pl < PL) {
     for (int pix = pl; pix < 128; pix += PL) {
-      const int gh = h0 + (pix >> 4), gw = w0 + (pix & 15);
+      const int r = pix >> 4, c = pix & 15;
+      const int gh = h0 + r, gw = w0 + c;
       if (gh >= p.H || gw >= p.W) continue;
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int kh = 0; kh < 3; ++kh) {
-        const int ih = gh + kh - 1;
-        if (ih < 0 || ih >= p.H) continue;
-        for (int kw = 0; kw < 3; ++kw) {
-          const int iw = gw + kw - 1;
-          if (iw < 0 || iw >= p.W) continue;
-          const float* xp = p.x + p.xa.off(n_img) + ((int64_t)ih * p.W + iw) * p.xs;
-          const float* wq = p.wp + ((int64_t)(kh * 3 + kw) * p.Cin) * p.Cout + cq * 4;
-          for (int ci = 0; ci < p.Cin; ++ci) {
+      if (CIN > 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const float* xp = &smem[((r + t / 3) * 18 + c + t % 3) * CIN];
+#pragma unroll
+          for (int ci = 0; ci < CIN; ++ci) {
+            const float xv = xp[ci];
+            const float4 wv = wreg[t * CIN + ci];
+            a.x = fmaf(xv, wv.x, a.x); a.y = fmaf(xv, wv.y, a.y); a.z = fmaf(xv, wv.z, a.z); a.w = fmaf(xv, wv.w, a.w);
+          }
+        }
+      } else {
+        for (int t = 0; t < 9; ++t) {
+          const float* xp = &smem[((r + t / 3) * 18 + c + t % 3) * cin];
+          const float* wq = p.wp + ((int64_t)t * cin) * p.Cout + cq * 4;
+          for (int ci = 0; ci < cin; ++ci) {
             const float xv = xp[ci];
             const float4 wv = ldg4(wq + (int64_t)ci * p.Cout);
-            a.x = fmaf(xv, wv.x, a.x);
-            a.y = fmaf(xv, wv.y, a.y);
-            a.z = fmaf(xv, wv.z, a.z);
-            a.w = fmaf(xv, wv.w, a.w);
+            a.x = fmaf(xv, wv.x, a.x); a.y = fmaf(xv, wv.y, a.y); a.z = fmaf(xv, wv.z, a.z); a.w = fmaf(xv, wv.w, a.w);
           }
         }
       }
@@ -284,7 +308,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvParams p) {
     }
   }
   if (p.stat != nullptr) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][PL][Cout]
+    __syncthreads();                                             // the halo is dead: reuse LDS as [2][PL][Cout]
     if (pl < PL) {
       stg4(&smem[(0 * PL + pl) * p.Cout + cq * 4], s);
       stg4(&smem[(1 * PL + pl) * p.Cout + cq * 4], sq);
@@ -443,9 +467,18 @@ int unetk_conv_run(ConvParams p, hipStream_t st) {
   }
   if (p.Cout % 4 != 0 || p.Cout > 1024) return UNETK_E_UNSUPPORTED;
   const int PL = 256 / (p.Cout / 4);
-  const size_t lds = p.stat ? (size_t)2 * PL * p.Cout * sizeof(float) : 0;
+  size_t lds = p.stat ? (size_t)2 * PL * p.Cout * sizeof(float) : 0;
+  const size_t halo = (size_t)180 * p.Cin * sizeof(float);
+  if (halo > lds) lds = halo;
   if (lds > 64 * 1024) return UNETK_E_UNSUPPORTED;
-  hipLaunchKernelGGL(conv3x3_direct_kernel, dim3(n_mtiles), dim3(256), lds, st, p);
+  switch (p.Cin) {
+    case 1: hipLaunchKernelGGL(conv3x3_direct_kernel<1>, dim3(n_mtiles), dim3(256), lds, st, p); break;
+    case 2: hipLaunchKernelGGL(conv3x3_direct_kernel<2>, dim3(n_mtiles), dim3(256), lds, st, p); break;
+    case 3: hipLaunchKernelGGL(conv3x3_direct_kernel<3>, dim3(n_mtiles), dim3(256), lds, st, p); break;
+    case 4: hipLaunchKernelGGL(conv3x3_direct_kernel<4>, dim3(n_mtiles), dim3(256), lds, st, p); break;
+    case 5: hipLaunchKernelGGL(conv3x3_direct_kernel<5>, dim3(n_mtiles), dim3(256), lds, st, p); break;
+    default: hipLaunchKernelGGL(conv3x3_direct_kernel<0>, dim3(n_mtiles), dim3(256), lds, st, p); break;
+  }
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
