@@ -29,7 +29,7 @@ inline int head_nq(int ncls) { return 2 + (ncls - 1) * 6; }
 HeadWs head_ws(const unetk_head_desc* d) {
   HeadWs w{};
   const int N = d->N, ncls = d->ncls;
-  int bps = (d->HW + 2047) / 2048;
+  int bps = (d->HW + 1023) / 1024;      // streaming, latency-bound kernels: enough blocks for ~8 waves per SIMD
   if (bps > 64) bps = 64;
   if (bps < 1) bps = 1;
   w.bps = bps;
@@ -42,7 +42,7 @@ HeadWs head_ws(const unetk_head_desc* d) {
   off = (off + 3) & ~(int64_t)3;
   int64_t npix = (int64_t)N * d->HW;
   int64_t nb = (npix + 255) / 256;
-  if (nb > 512) nb = 512;
+  if (nb > 2048) nb = 2048;
   w.bwd_nblk = (int)nb;
   w.pw_off = off; off += (int64_t)w.bwd_nblk * d->C * ncls;
   w.pb_off = off; off += (int64_t)w.bwd_nblk * ncls;
@@ -197,13 +197,19 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(unetk_head_desc d, const 
 // one thread per sample; then thread 0 combines in sample order
 __global__ void head_finalize_kernel(unetk_head_desc d, const float* __restrict__ part, int bps, int nq,
                                      float* __restrict__ result) {
-  extern __shared__ double sh[];  // [N][3]: ce_sum, present, dice_term
+  extern __shared__ double sh[];  // [N][3]: ce_sum, present, dice_term; then [N][nq] column sums
   const int ncls = d.ncls;
+  double* colsum = sh + (int64_t)d.N * 3;
+  // one thread per (sample, quantity): the bps partial rows in fixed order (same sums as a per-sample loop, 8x the threads)
+  for (int t = threadIdx.x; t < d.N * nq; t += blockDim.x) {
+    const int b = t / nq, i = t - b * nq;
+    double a = 0.0;
+    for (int j = 0; j < bps; ++j) a += (double)part[((int64_t)b * bps + j) * nq + i];
+    colsum[t] = a;
+  }
+  __syncthreads();
   for (int b = threadIdx.x; b < d.N; b += blockDim.x) {
-    double acc[2 + (MAXC - 1) * 6];
-    for (int i = 0; i < nq; ++i) acc[i] = 0.0;
-    for (int j = 0; j < bps; ++j)
-      for (int i = 0; i < nq; ++i) acc[i] += (double)part[((int64_t)b * bps + j) * nq + i];
+    const double* acc = colsum + (int64_t)b * nq;
     double I = 0.0, U = 0.0;
     for (int c = 1; c < ncls; ++c) {
       const double* qq = &acc[2 + (c - 1) * 6];
@@ -262,6 +268,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(unetk_head_desc d, const 
   const float* iu = result + 3 + (int64_t)d.N * (NCLS - 1) * 4;
 
   for (int64_t pix = (int64_t)blockIdx.x * gpb + grp; pix < npix; pix += (int64_t)gridDim.x * gpb) {
+    const float4 zv = ldg4(z + pix * d.C + gl * 4);      // issued first: its latency overlaps the softmax arithmetic below
     const int b = (int)(pix / d.HW);
     const int lab = labels[pix];
     float lg[NCLS], p[NCLS], dl[NCLS];
@@ -295,7 +302,6 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(unetk_head_desc d, const 
 #pragma unroll
       for (int k = 0; k < NCLS; ++k) dl[k] += p[k] * (g[k] - pg);
     }
-    const float4 zv = ldg4(z + pix * d.C + gl * 4);
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < NCLS; ++k) {
@@ -424,8 +430,8 @@ extern "C" int unetk_head_fwd(const unetk_head_desc* d, const float* z, const fl
                                             pixel_w, wn, logits, probs, part_eff, bps));
   UNETK_LAUNCH_CHECK();
   if (labels) {
-    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), (size_t)d->N * 3 * sizeof(double), st, *d, part, bps,
-                       L.nq, result);
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), (size_t)d->N * (3 + L.nq) * sizeof(double), st, *d, part,
+                       bps, L.nq, result);
     UNETK_LAUNCH_CHECK();
   }
   return UNETK_OK;
