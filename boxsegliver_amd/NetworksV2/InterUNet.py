@@ -12,7 +12,7 @@ buffer (channel offsets C_up and C_up + C_skip), the two e2 blocks into the halv
 conv into channels [0, C_up) (ops.DeconvConcatFront).  Kernels: SmallUNet's (dense / stride-2 / rate-2 conv units), the
 direct small-Cin kernels for the 4- and 5-channel inputs, unetk_sobel_concat.
 
-Not built: init_channel_factor != 1, --without_norm.
+--without_norm: conv + bias + ReLU units (SmallUNet._unit).  Not built: init_channel_factor != 1.
 """
 import torch
 
@@ -25,12 +25,14 @@ ENC = [("e0", 32, 1), ("e1", 64, 2), ("e2", 128, 2)]
 DEC = [(2, 256, 128), (1, 128, 64), (0, 64, 32)]
 
 
-def param_specs(x_channels, y_channels, num_classes, normalizer, name):
+def param_specs(x_channels, y_channels, num_classes, normalizer, name, without_norm=False):
     specs = []
 
     def unit(scope, cin, cout):
         specs.append((scope + "/weights", (3, 3, cin, cout), "conv_w"))
-        if normalizer == "batch_norm":
+        if without_norm:
+            specs.append((scope + "/biases", (cout,), "bias"))
+        elif normalizer == "batch_norm":
             for leaf, kind in (("gamma", "gamma"), ("beta", "beta"), ("moving_mean", "moving_mean"),
                                ("moving_variance", "moving_var")):
                 specs.append(("{}/BatchNorm/{}".format(scope, leaf), (cout,), kind))
@@ -85,7 +87,8 @@ class InterUNet(SmallUNet):
         img_grad = bool(getattr(self.args, "img_grad", False))
         xc, yc = ch + guide.shape[3], ch + (2 if img_grad else 0)
         if self.params is None:
-            self.params = ParamStore(param_specs(xc, yc, self.num_classes, self.args.normalizer, nm), dev,
+            self.params = ParamStore(param_specs(xc, yc, self.num_classes, self.args.normalizer, nm,
+                                                 bool(getattr(self.args, "without_norm", False))), dev,
                                      bias_decay=getattr(self.args, "bias_decay", False))
             self.params.initialize(self._get_initializer()[0], seed=getattr(self.args, "seed", None))
         p = self.params

@@ -13,7 +13,8 @@ ops.DeconvConcat with a NULL bias writing into the zero-copy concat buffers the 
 channel-padded to multiples of 64 (48 -> 64, 96 -> 128) exactly as UNet3D's are (NetworksV2/padded.py: padded filter rows /
 columns are zero and provably stay zero; checkpoints speak the TF shapes).
 
-Not built: --without_norm.
+--without_norm (:81-82): every unit = conv + bias + ReLU (variables <scope>/biases), through the same kernels with the
+norm stage reduced to the per-channel shift (unetk_norm_desc.affine_only).
 """
 import torch
 
@@ -41,7 +42,7 @@ def model_config(factor=1.0):
 PAD = 64     # device channel granularity (the stride-2 / atrous / 64 x 64 filter-gradient tiles)
 
 
-def param_specs(in_channels, num_classes, factor, normalizer, name):
+def param_specs(in_channels, num_classes, factor, normalizer, name, without_norm=False):
     """Logical specs <name>/<block>/<layer>/{weights, BatchNorm|InstanceNorm/...}, <name>/<block>/up/weights,
     <name>/logits/{weights,biases} and the device padding of each variable (empty at factor 1)."""
     specs, pads = [], {}
@@ -72,7 +73,9 @@ def param_specs(in_channels, num_classes, factor, normalizer, name):
                 continue
             specs.append((scope + "/weights", (3, 3, sum(cin_parts), cout), "conv_w"))
             pads[scope + "/weights"] = ((3, 3, pcin, pad_to(cout, PAD)), {2: segs})
-            if normalizer == "batch_norm":
+            if without_norm:
+                vec(scope + "/biases", cout, "bias")
+            elif normalizer == "batch_norm":
                 for leaf, kind in (("gamma", "gamma"), ("beta", "beta"), ("moving_mean", "moving_mean"),
                                    ("moving_variance", "moving_var")):
                     vec("{}/BatchNorm/{}".format(scope, leaf), cout, kind)
@@ -95,30 +98,33 @@ class SmallUNet(UNet):
         super(SmallUNet, self).__init__(args, name or "SmallUNet")
 
     def _net_arg_scope(self, *args, **kwargs):
-        if getattr(self.args, "without_norm", False):
-            raise NotImplementedError("SmallUNet --without_norm is not built")
-        self._norm = self._get_normalization()
+        self._norm = ("none", {}) if getattr(self.args, "without_norm", False) else self._get_normalization()
         return self._norm
 
     def _unit(self, x, scope, stride, dilation, out=None):
         """slim.conv2d(x, C, 3, stride, rate) = conv (no bias) + norm + ReLU (SmallUNet.py:104-110, 127-131)."""
         p = self.params
         kind, np_ = self._norm
-        if kind == "batch_norm":
+        extra = (None, None)
+        if kind == "none":
+            spec = ops.NormSpec("none", 0.0, 0.0, self.is_training, False)
+            gamma, beta = None, p[scope + "/biases"]
+        elif kind == "batch_norm":
             ns = scope + "/BatchNorm"
             spec = ops.NormSpec("batch_norm", np_["eps"], np_["decay"], bool(np_["is_training"]), False)
             extra = (p[ns + "/moving_mean"], p[ns + "/moving_variance"])
+            gamma, beta = p[ns + "/gamma"], p[ns + "/beta"]
         else:
             ns = scope + "/InstanceNorm"
             spec = ops.NormSpec("instance_norm", np_["eps"], 0.0, self.is_training, False)
-            extra = (None, None)
+            gamma, beta = p[ns + "/gamma"], p[ns + "/beta"]
         w = p[scope + "/weights"]
         if stride == 1:
-            return ops.Conv3x3NormRelu.apply(x, w, p[ns + "/gamma"], p[ns + "/beta"], extra[0], extra[1], spec, out, None,
-                                             None, None, None, dilation)
+            return ops.Conv3x3NormRelu.apply(x, w, gamma, beta, extra[0], extra[1], spec, out, None, None, None, None,
+                                             dilation)
         assert dilation == 1 and out is None
-        z = ops.Conv3dNormRelu.apply(x.unsqueeze(1), w.unsqueeze(0), p[ns + "/gamma"], p[ns + "/beta"], extra[0], extra[1],
-                                     spec, (1, stride, stride), None)
+        z = ops.Conv3dNormRelu.apply(x.unsqueeze(1), w.unsqueeze(0), gamma, beta, extra[0], extra[1], spec,
+                                     (1, stride, stride), None)
         return z.squeeze(1)
 
     def _build_network(self, *args, **kwargs):
@@ -139,7 +145,8 @@ class SmallUNet(UNet):
             raise ValueError("H and W must be divisible by 8")
         dev, nm = images.device, self.name
         if self.params is None:
-            specs, pads = param_specs(images.shape[3] + guide.shape[3], self.num_classes, factor, self.args.normalizer, nm)
+            specs, pads = param_specs(images.shape[3] + guide.shape[3], self.num_classes, factor, self.args.normalizer, nm,
+                                      bool(getattr(self.args, "without_norm", False)))
             self.params = PaddedParamStore(specs, pads, dev, bias_decay=getattr(self.args, "bias_decay", False))
             self.params.initialize(self._get_initializer()[0], seed=getattr(self.args, "seed", None))
         p = self.params

@@ -655,7 +655,7 @@ class Conv3x3NormRelu(torch.autograd.Function):
             DEBUG_CAPTURE.append(dict(x=x, y=y, dilation=ctx.dilation, z=ctx.z_dbg, gamma=ctx.gb_dbg[0], beta=ctx.gb_dbg[1], aff=aff, dz=dz, dy=dy, dw=dw,
                                       dx=dx, dgamma=dgamma, dbeta=dbeta, w=ctx.w_dbg, guide=guide, gw=gw, gb=gb,
                                       dgw=dgw, dgb=dgb, per_sample=bool(ctx.desc.per_sample), bf16=ctx.bf16, den=den,
-                                      dden=dden, guide_leaky=bool(ctx.desc.guide_leaky)))
+                                      dden=dden, guide_leaky=bool(ctx.desc.guide_leaky), plain=bool(ctx.desc.affine_only)))
         return dx, dw, dgamma, dbeta, None, None, None, None, None, dgw, dgb, dden, None
 
 
@@ -713,12 +713,18 @@ class Conv3dNormRelu(torch.autograd.Function):
             if kd != 1 or need_dx:
                 raise _abi.UnetkError("conv3d with Cin={} Cout={} needs the MFMA path (Cin%16, Cout%32)".format(cin, cout))
             wp_f, wp_d = w, None
-        use_batch_stats = spec.training or spec.per_sample
+        plain = spec.kind == "none"                # --without_norm: z = relu(y + bias); `beta` carries the conv bias
+        use_batch_stats = (spec.training or spec.per_sample) and not plain
         y, stats, rows = conv3d_fwd(x, wp_f, d, want_stats=use_batch_stats)
         z = out if out is not None else torch.empty_like(y)
         nd = norm_desc(y.shape, spec.per_sample, _pix_stride_nd(z))
-        aff = norm_finalize(nd, stats, rows, gamma, beta, spec.eps, spec.decay, spec.training, moving_mean, moving_var,
-                            y.device)
+        if plain:
+            nd.affine_only = 1
+            one, zero = torch.ones_like(beta), torch.zeros_like(beta)
+            aff = torch.stack([zero, one, one, beta.detach()]).reshape(4, 1, cout).contiguous()
+        else:
+            aff = norm_finalize(nd, stats, rows, gamma, beta, spec.eps, spec.decay, spec.training, moving_mean, moving_var,
+                                y.device)
         norm_apply_relu(nd, y, aff, z)
         if spec.training:
             ctx.save_for_backward(x, y, aff)
@@ -739,7 +745,7 @@ class Conv3dNormRelu(torch.autograd.Function):
         if DEBUG_CAPTURE is not None:
             DEBUG_CAPTURE.append(dict(kind="conv3d", x=x, y=y, w=ctx.dbg[0], gamma=ctx.dbg[1], beta=ctx.dbg[2],
                                       stride=ctx.dbg[3], z=ctx.dbg[4], dz=dz, dy=dy, dw=dw, dx=dx, dgamma=dgamma, dbeta=dbeta,
-                                      per_sample=bool(ctx.nd.per_sample)))
+                                      per_sample=bool(ctx.nd.per_sample), plain=bool(ctx.nd.affine_only)))
         return dx, dw, dgamma, dbeta, None, None, None, None, None
 
 

@@ -23,12 +23,14 @@ from .unet2d import UNet2DOracle
 ENC = [("e0", 32, 1), ("e1", 64, 2), ("e2", 128, 2)]
 
 
-def param_specs(x_channels, y_channels, num_classes, normalizer="batch_norm", name="SmallUNet"):
+def param_specs(x_channels, y_channels, num_classes, normalizer="batch_norm", name="SmallUNet", without_norm=False):
     specs = []
 
     def unit(scope, cin, cout):
         specs.append((scope + "/weights", (3, 3, cin, cout), "conv_w"))
-        if normalizer == "batch_norm":
+        if without_norm:                                                                   # :91-92: conv + bias + ReLU
+            specs.append((scope + "/biases", (cout,), "bias"))
+        elif normalizer == "batch_norm":
             for leaf, kind in (("gamma", "gamma"), ("beta", "beta"), ("moving_mean", "moving_mean"), ("moving_variance", "moving_var")):
                 specs.append(("{}/BatchNorm/{}".format(scope, leaf), (cout,), kind))
         else:
@@ -60,15 +62,17 @@ def param_specs(x_channels, y_channels, num_classes, normalizer="batch_norm", na
 
 
 class InterUNetOracle(UNet2DOracle):
-    def __init__(self, x_channels, y_channels, num_classes, normalizer="batch_norm", name="SmallUNet"):
+    def __init__(self, x_channels, y_channels, num_classes, normalizer="batch_norm", name="SmallUNet", without_norm=False):
         self.name, self.img_grad, self.num_classes = name, False, num_classes
-        self.normalizer, self.without_norm = normalizer, False
+        self.normalizer, self.without_norm = normalizer, without_norm
         self.bn_decay, self.bn_eps, self.in_eps = 0.999, 1e-3, 1e-6
-        self.specs = param_specs(x_channels, y_channels, num_classes, normalizer, name)
+        self.specs = param_specs(x_channels, y_channels, num_classes, normalizer, name, without_norm)
         self.kinds = {n: k for n, _, k in self.specs}
 
     def _unit(self, x, p, scope, stride, dilation, is_training, new_stats):
         y = tf_ops.conv_nd_same(x, p[scope + "/weights"], stride=(stride, stride), dilation=dilation)
+        if self.without_norm:
+            return torch.relu(y + p[scope + "/biases"])
         if self.normalizer == "batch_norm":
             bn = scope + "/BatchNorm"
             y, mm, mv = tf_ops.batch_norm(y, p[bn + "/gamma"], p[bn + "/beta"], p[bn + "/moving_mean"],

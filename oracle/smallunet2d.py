@@ -35,7 +35,7 @@ def model_config(factor=1.0):
     return enc + dec
 
 
-def param_specs(in_channels, num_classes, factor=1.0, normalizer="batch_norm", name="SmallUNet"):
+def param_specs(in_channels, num_classes, factor=1.0, normalizer="batch_norm", name="SmallUNet", without_norm=False):
     specs = []
     enc_out = {}
     cin = in_channels
@@ -47,7 +47,9 @@ def param_specs(in_channels, num_classes, factor=1.0, normalizer="batch_norm", n
                 cin = enc_out[block.replace("d", "e")] + cout
                 continue
             specs.append((scope + "/weights", (3, 3, cin, cout), "conv_w"))
-            if normalizer == "batch_norm":
+            if without_norm:                                                               # :81-82: conv + bias + ReLU
+                specs.append((scope + "/biases", (cout,), "bias"))
+            elif normalizer == "batch_norm":
                 for leaf, kind in (("gamma", "gamma"), ("beta", "beta"), ("moving_mean", "moving_mean"),
                                    ("moving_variance", "moving_var")):
                     specs.append(("{}/BatchNorm/{}".format(scope, leaf), (cout,), kind))
@@ -64,16 +66,18 @@ def param_specs(in_channels, num_classes, factor=1.0, normalizer="batch_norm", n
 
 class SmallUNetOracle(UNet2DOracle):
     def __init__(self, in_channels, num_classes, factor=1.0, normalizer="batch_norm", name="SmallUNet", bn_decay=0.999,
-                 bn_eps=1e-3, in_eps=1e-6):
+                 bn_eps=1e-3, in_eps=1e-6, without_norm=False):
         self.name, self.img_grad = name, False
         self.in_channels, self.num_classes = in_channels, num_classes
-        self.factor, self.normalizer, self.without_norm = factor, normalizer, False
+        self.factor, self.normalizer, self.without_norm = factor, normalizer, without_norm
         self.bn_decay, self.bn_eps, self.in_eps = bn_decay, bn_eps, in_eps
-        self.specs = param_specs(in_channels, num_classes, factor, normalizer, name)
+        self.specs = param_specs(in_channels, num_classes, factor, normalizer, name, without_norm)
         self.kinds = {n: k for n, _, k in self.specs}
 
     def _unit(self, x, p, scope, stride, dilation, is_training, new_stats):
         y = tf_ops.conv_nd_same(x, p[scope + "/weights"], stride=(stride, stride), dilation=dilation)
+        if self.without_norm:
+            return torch.relu(y + p[scope + "/biases"])
         if self.normalizer == "batch_norm":
             bn = scope + "/BatchNorm"
             y, mm, mv = tf_ops.batch_norm(y, p[bn + "/gamma"], p[bn + "/beta"], p[bn + "/moving_mean"],

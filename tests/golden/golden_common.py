@@ -20,9 +20,16 @@ CASES = OrderedDict([
     ("unet_in_dice", dict(kind="UNet", normalizer="instance_norm", loss_type="dice", w_type="none", size=32)),
     ("gunet_in_xent", dict(kind="GUNet", normalizer="instance_norm", loss_type="xentropy", w_type="numerical", size=32)),
     ("unet3d_in_xent", dict(kind="UNet3D", normalizer="instance_norm", loss_type="xentropy", w_type="numerical", size=32)),
+    # LGNet.yml (leaky-ReLU guide on encoder / decoder levels 0, 1) and SmallUNet.yml (stride-2 + atrous convs, guide concatenated)
+    ("lgnet_in_xent", dict(kind="LGNet", normalizer="instance_norm", loss_type="xentropy", w_type="numerical", size=32,
+                           mod_layers=[[0, 1], [0, 1]])),
+    ("smallunet_bn_xent", dict(kind="SmallUNet", normalizer="batch_norm", loss_type="xentropy", w_type="numerical", size=64,
+                               factor=1)),
 ])
-NUMERIC_W = {"UNet": [0.2, 0.4, 4.4], "GUNet": [0.2, 0.4, 4.4], "UNet3D": [1.0, 1.0]}
-WD = {"UNet": 1e-5, "GUNet": 1e-5, "UNet3D": 3e-5}
+GUIDED = ("GUNet", "LGNet", "SmallUNet")
+NUMERIC_W = {"UNet": [0.2, 0.4, 4.4], "GUNet": [0.2, 0.4, 4.4], "UNet3D": [1.0, 1.0], "LGNet": [0.2, 0.4, 4.4],
+             "SmallUNet": [0.2, 0.4, 4.4]}
+WD = {"UNet": 1e-5, "GUNet": 1e-5, "UNet3D": 3e-5, "LGNet": 1e-5, "SmallUNet": 1e-5}
 LR = 1e-3
 
 
@@ -69,7 +76,7 @@ def make_inputs(case):
         return dict(images=images, labels=labels)
     images, labels, _ = synthetic.make_batch(2, s, s, 3, 3, 1234)
     out = dict(images=images, labels=labels)
-    if c["kind"] == "GUNet":
+    if c["kind"] in GUIDED:
         out["sp_guide"] = synthetic.make_guide(labels, 1, 1234)
     return out
 

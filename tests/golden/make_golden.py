@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import golden_common as gc                                  # noqa: E402
-from oracle import gunet2d, losses, naive, solver, tf_ops, unet2d, unet3d   # noqa: E402
+from oracle import gunet2d, lgnet2d, losses, naive, smallunet2d, solver, tf_ops, unet2d, unet3d   # noqa: E402
 
 
 def oracle_net(case):
@@ -27,6 +27,10 @@ def oracle_net(case):
         return unet2d.UNet2DOracle(3, 3, normalizer=c["normalizer"])
     if c["kind"] == "GUNet":
         return gunet2d.GUNet2DOracle(3, 3, guide_channel=1, normalizer=c["normalizer"])
+    if c["kind"] == "LGNet":
+        return lgnet2d.LGNetOracle(3, 3, guide_channel=1, mod_layers=c["mod_layers"], normalizer=c["normalizer"])
+    if c["kind"] == "SmallUNet":
+        return smallunet2d.SmallUNetOracle(4, 3, factor=c["factor"], normalizer=c["normalizer"])
     return unet3d.UNet3DOracle(1, 2, normalizer=c["normalizer"])
 
 
@@ -37,8 +41,10 @@ def run(net, case, params, inputs, dtype):
     labels = torch.from_numpy(inputs["labels"]).long()
     kw = dict(loss_type=c["loss_type"], loss_weight_type=c["w_type"], numeric_w=gc.NUMERIC_W[c["kind"]],
               weight_decay_rate=gc.WD[c["kind"]])
-    if c["kind"] == "GUNet":
+    if c["kind"] in ("GUNet", "LGNet"):
         return net.loss_and_grads(p, images, torch.from_numpy(inputs["sp_guide"]).to(dtype), labels, **kw)
+    if c["kind"] == "SmallUNet":                                    # input = concat(images, sp_guide), SmallUNet.py:97
+        return net.loss_and_grads(p, torch.cat((images, torch.from_numpy(inputs["sp_guide"]).to(dtype)), -1), labels, **kw)
     return net.loss_and_grads(p, images, labels, **kw)
 
 
@@ -136,6 +142,8 @@ def make_kat():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    make_kat()
-    for case in gc.CASES:
+    only = sys.argv[1:]                                             # e.g. `make_golden.py lgnet_in_xent` adds one case
+    if not only:
+        make_kat()
+    for case in only or gc.CASES:
         make_case(case)

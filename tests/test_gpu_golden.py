@@ -1,4 +1,4 @@
-"""GPU: the three plugins (HIP kernels through the C ABI) against the committed whole-net fixtures of
+"""GPU: the plugins (HIP kernels through the C ABI) against the committed whole-net fixtures of
 tests/golden/ -- logits within the north-star 1e-3, loss, argmax / thresholded masks bit-exact outside rounding-level
 margins, per-variable gradient norms, small gradients in full, moving statistics, a 3-step Adam trajectory."""
 import os
@@ -25,18 +25,31 @@ def build(case):
     elif c["kind"] == "GUNet":
         import test_gpu_gunet as t
         from boxsegliver_amd.NetworksV2.GUNet import GUNet as Net
+    elif c["kind"] == "LGNet":
+        import test_gpu_gunet as t
+        from boxsegliver_amd.NetworksV2.LGNet import LGNet as Net
+        over.update(use_spatial=True, guide_channel=1)
+        yml = dict(mod_layers=c["mod_layers"], ret_prob=False, ret_pred=True, build_metrics=True, build_summaries=False)
+    elif c["kind"] == "SmallUNet":
+        import test_gpu_gunet as t
+        from boxsegliver_amd.NetworksV2.SmallUNet import SmallUNet as Net
+        over.update(use_spatial=True, guide_channel=1, im_height=c["size"], im_width=c["size"])
+        yml = dict(init_channel_factor=c["factor"], num_pool_layers=3, ret_prob=False, ret_pred=True, build_metrics=True,
+                   build_summaries=False)
     else:
         import test_gpu_unet3d as t
         from boxsegliver_amd.NetworksV2.UNet3D import UNet3D as Net
+    if c["kind"] not in ("LGNet", "SmallUNet"):
+        yml = t.YML
     args = t.make_args(**over)
     model = Net(args)
     inputs = {k: torch.from_numpy(g[k]).cuda() for k in ("images", "labels", "sp_guide") if k in g.files}
-    model(inputs, "eval", **t.YML)
+    model(inputs, "eval", **yml)
     specs = getattr(model.params, "logical_specs", model.params.specs)
     params = gc.build_params(specs, seed=2024)
     np.testing.assert_allclose(gc.checksum(params), g["param_checksum"], rtol=1e-12)
     model.params.load_state({k: torch.from_numpy(v) for k, v in params.items()})
-    return model, inputs, args, t.YML, g
+    return model, inputs, args, yml, g
 
 
 @pytest.mark.parametrize("case", list(gc.CASES))

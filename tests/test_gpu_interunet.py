@@ -28,15 +28,17 @@ def test_sobel_concat_kernel():
     assert torch.allclose(e[0, 1:-1, :, 1], torch.full((4, 5), 8.0)) and torch.all(e[..., 2] == 0) and torch.all(e[0, 0, :, 1] == 0)
 
 
-@pytest.mark.parametrize("normalizer,loss_type,img_grad", [("batch_norm", "xentropy", True), ("instance_norm", "dice", False)])
-def test_interunet_matches_oracle_and_trains(normalizer, loss_type, img_grad):
+@pytest.mark.parametrize("normalizer,loss_type,img_grad,without_norm", [("batch_norm", "xentropy", True, False),
+                                                                          ("instance_norm", "dice", False, False),
+                                                                          ("batch_norm", "xentropy", False, True)])
+def test_interunet_matches_oracle_and_trains(normalizer, loss_type, img_grad, without_norm):
     from boxsegliver_amd import ops
     from boxsegliver_amd.core import models
     from boxsegliver_amd.core.solver import Solver
     from boxsegliver_amd.data.synthetic import make_batch, make_guide
     zoo = {cls.__name__: cls for cls in models.MODEL_ZOO}
     args = make_args(normalizer=normalizer, loss_type=loss_type, use_spatial=True, guide_channel=1, im_height=64, im_width=64,
-                     img_grad=img_grad)
+                     img_grad=img_grad, without_norm=without_norm)
     images, labels, _ = make_batch(2, 64, 64, 3, 3, 1234)
     guide = make_guide(labels, 1, 1234)
     model = zoo["InterUNet"](args)
@@ -44,12 +46,14 @@ def test_interunet_matches_oracle_and_trains(normalizer, loss_type, img_grad):
               "sp_guide": torch.from_numpy(guide).cuda()}
     model(inputs, "eval", **YML)
     yc = 5 if img_grad else 3
-    net = interunet2d.InterUNetOracle(4, yc, 3, normalizer=normalizer)
+    net = interunet2d.InterUNetOracle(4, yc, 3, normalizer=normalizer, without_norm=without_norm)
     assert model.name == "SmallUNet"                                       # the reference's default scope (InterUNet.py:74)
     assert [(n, tuple(s), k) for n, s, k in net.specs] == [(n, tuple(s), k) for n, s, k in model.params.specs]
     names = list(model.params.state_dict())
     assert "SmallUNet/inter_e0/conv1/weights" in names and "SmallUNet/merge_e3/conv4/weights" in names
     assert model.params["SmallUNet/inter_e0/conv1/weights"].shape == (3, 3, yc, 32)
+    assert ("SmallUNet/merge_e3/conv1/biases" in names) == without_norm
+    assert ("SmallUNet/merge_e3/conv1/BatchNorm/gamma" in names) == (not without_norm and normalizer == "batch_norm")
     assert model.params["SmallUNet/conv_d1/conv1/weights"].shape == (3, 3, 256, 128) and "SmallUNet/conv_d2/up/biases" not in names
     gen = torch.Generator().manual_seed(16)
     params = {}
@@ -83,6 +87,7 @@ def test_interunet_matches_oracle_and_trains(normalizer, loss_type, img_grad):
     deconvs = [c for c in captured if c.get("kind") == "deconv"]
     assert len(units2d) == 20 and len(strided) == 5 and len(deconvs) == 3
     assert sum(1 for c in units2d if c.get("dilation") == 2) == 3
+    assert all(bool(c.get("plain")) == without_norm for c in units2d + strided)
     for c in units2d:
         check_unit_backward(c)
     for c in strided:

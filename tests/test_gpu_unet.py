@@ -184,7 +184,9 @@ def check_unit_backward(c, tol=1e-5):
         # instance norm over <= 16 pixels with eps 1e-6 (the 2x2 / 4x4 levels of these reduced-size test nets):
         # rstd ~ 1e3 amplifies the fp32 rounding of the one-pass variance; real configs have >= 256 pixels here
         tol = 5e-4
-    if c.get("per_sample"):
+    if c.get("plain"):                                     # --without_norm: conv + bias + ReLU
+        z = y + b
+    elif c.get("per_sample"):
         z = tf_ops.instance_norm(y, g, b, eps=1e-6)
     else:
         z, _, _ = tf_ops.batch_norm(y, g, b, torch.zeros(y.shape[-1], dtype=torch.float64),
