@@ -4,6 +4,8 @@ Registry + `--model/--classes` plugin surface: models.py:36-89; yml lookup `get_
 :92-118; `model_fn` contract: :224-281.
 """
 import copy
+import logging
+import os
 from collections import namedtuple
 from pathlib import Path
 
@@ -17,6 +19,8 @@ from ..NetworksV2.SmallUNet import SmallUNet
 from ..NetworksV2.LGNet import LGNet
 from ..NetworksV2.InterUNet import InterUNet
 from ..NetworksV2.base import ModeKeys
+
+log = logging.getLogger("boxsegliver_amd")
 
 # Available models (reference models.py:36-38 lists UNet, GUNet, UNetInter, LGNet, UNet3D, SmallUNet,
 # InterUNet (DenseUNet is commented out there); this build ships all seven.
@@ -79,6 +83,48 @@ def get_model_params(args, build_metrics=False, build_summaries=False):
     params["model_kwargs"]["build_metrics"] = build_metrics
     params["model_kwargs"]["build_summaries"] = build_summaries
     return params
+
+
+def _find_root_scope(ckpt_filename):
+    """core/models.py:151-157: the model scope of a checkpoint = the second component of its optimiser slot names."""
+    from ..utils import tf_checkpoint
+    if os.path.exists(str(ckpt_filename) + ".index"):
+        variables = list(tf_checkpoint.CheckpointReader(ckpt_filename).get_variable_to_shape_map())
+    else:
+        import torch
+        variables = list(torch.load(ckpt_filename, map_location="cpu", weights_only=False)["variables"])
+        return variables[0].split("/")[0] if variables else None       # this package's files hold no slot names
+    for var in variables:
+        if var.startswith("Optimizer") and not var.endswith("power"):
+            return var.split("/")[1]
+    return None
+
+
+def init_model(model, args):
+    """core/models.py:160-185 (--load_weights / --load_weights_version / --weights_scope): an init_fn(scaffold, session)
+    that loads the model's variables -- renamed from `model.name` to the checkpoint's root scope -- from a checkpoint file
+    or the latest one of a directory next to model_dir; TensorFlow V2 checkpoints of the reference or files of this
+    package.  None without --load_weights."""
+    if not getattr(args, "load_weights", None):
+        return None
+    from ..utils import tf_checkpoint
+    from .estimator import restore_variables
+    weights_dir = Path(args.model_dir).parent / args.load_weights
+    ckpt_filename = args.load_weights
+    if weights_dir.is_dir():
+        latest = tf_checkpoint.get_checkpoint_state(weights_dir, getattr(args, "load_weights_version", None))
+        if latest:
+            ckpt_filename = latest
+    if not tf_checkpoint.checkpoint_exists(ckpt_filename):
+        raise FileNotFoundError("ckpt_filename {} doesn't exist".format(ckpt_filename))
+    root_scope = getattr(args, "weights_scope", None) or _find_root_scope(ckpt_filename)
+    log.info("Create init_fn with checkpoint: " + str(ckpt_filename))
+
+    def init_fn(scaffold, session):
+        _ = scaffold, session
+        restore_variables(ckpt_filename, model, None, root_scope=root_scope)
+
+    return init_fn
 
 
 def model_fn(features, labels, mode, params, config=None):

@@ -8,6 +8,7 @@ all-reduced (sum) over RCCL and scaled by 1/world inside the same kernel.
 """
 import math
 
+import numpy as np
 import torch
 
 from .. import ops
@@ -174,6 +175,26 @@ class Solver(object):
             for g, ts in st["slots"].items():
                 for dst, src in zip(state[g], ts):
                     dst.copy_(src)
+
+    @torch.no_grad()
+    def load_variable_slots(self, store, getter, global_step=0):
+        """Optimiser state from per-variable slots (a TensorFlow checkpoint, core/estimator.restore_variables):
+        getter(variable name, slot name) -> ndarray or None, slot names "Adam" / "Adam_1" (m, v) or "Momentum".  The
+        bias-correction powers are not read: they are functions of global_step here as in TF (beta^t)."""
+        self.global_step = int(global_step)
+        names = ("Adam", "Adam_1") if self.optimizer in ("adam", "adamw") else ("Momentum",)
+        if not hasattr(store, "where") or hasattr(store, "logical_specs"):
+            return 0                               # channel-padded stores keep fresh slots (zeros)
+        state = self._ensure_state(store)
+        loaded = 0
+        for name in store.trainable_names():
+            grp, off, n, _, _ = store.where[name]
+            for k, slot in enumerate(names):
+                v = getter(name, slot)
+                if v is not None:
+                    state[grp][k][off:off + n].copy_(torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)).reshape(-1))
+                    loaded += 1
+        return loaded
 
     def apply_gradients(self, store, l2, lr):
         """One optimiser step on the flat buffers; gradients are already in store.grad."""

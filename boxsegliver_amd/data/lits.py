@@ -338,7 +338,7 @@ def input_fn_eval(mode, params):
         raise ValueError("No valid dataset found!")
     proj_root = params.get("proj_root", ".")
     if getattr(args, "eval_in_patches", False):
-        raise NotImplementedError("--eval_in_patches (sliding-window evaluation) is not built")
+        return get_dataset_for_eval_patches(cases, config=args, proj_root=proj_root)
     if params.get("whole_slices", False):
         return get_dataset_for_eval_image(cases, args, proj_root)
     return get_dataset_for_eval_image_v2(cases, args, proj_root)
@@ -526,3 +526,99 @@ def get_dataset_for_eval_image(data_list, config, proj_root=".", test_data=False
             for item in _mirrored(eval_batch, config):
                 yield item
         yield None, (segmentation, seg_path, pads, (0, 0, 0, w - 1, h - 1, ori_d - 1), resize)
+
+
+def parse_case_patches(case, align, padding, padding_z, min_shape=None):
+    """input_pipeline.py:444-479: the liver box (+ padding) grown to at least `min_shape` (the patch) inside the slice,
+    then its sides rounded up to `align` around the centre."""
+    d, h, w = case["size"]
+    z1 = max(case["bbox"][0] - padding_z, 0)
+    z2 = min(case["bbox"][3] + padding_z, d)
+    y1 = max(case["bbox"][1] - padding, 0)
+    x1 = max(case["bbox"][2] - padding, 0)
+    y2 = min(case["bbox"][4] + padding, h)
+    x2 = min(case["bbox"][5] + padding, w)
+    if min_shape:
+        if min_shape[0] > h or min_shape[1] > w:
+            raise ValueError("Cannot satisfied conditions!")
+        if y2 - y1 < min_shape[0]:
+            y1 = min(max(y1 - (min_shape[0] - (y2 - y1)) // 2, 0), h - min_shape[0])
+            y2 = y1 + min_shape[0]
+        if x2 - x1 < min_shape[1]:
+            x1 = min(max(x1 - (min_shape[1] - (x2 - x1)) // 2, 0), w - min_shape[1])
+            x2 = x1 + min_shape[1]
+    cy = (y1 + y2 - 1) / 2
+    cx = (x1 + x2 - 1) / 2
+    sz_y = int(math.ceil((y2 - y1) / align)) * align
+    sz_x = int(math.ceil((x2 - x1) / align)) * align
+    y1 = max(int(cy - (sz_y - 1) / 2), 0)
+    x1 = max(int(cx - (sz_x - 1) / 2), 0)
+    y2 = min(y1 + sz_y, h)
+    x2 = min(x1 + sz_x, w)
+    if (y2 - y1) % align != 0 or (x2 - x1) % align != 0:
+        y1 = y2 - sz_y
+        x1 = x2 - sz_x
+        if y1 < 0 or x1 < 0:
+            print("\nWarning: bbox aligns with {} failed! point1 ({}, {}) point2 ({}, {})\n".format(align, x1, y1, x2, y2))
+    return case["PID"], d, h, w, z1, y1, x1, z2, y2, x2
+
+
+def patch_centres(extent, psize, step=2):
+    """input_pipeline.py:725-731 along one axis: window centres from psize/2 to extent - psize/2 in equal steps of at most
+    psize/step, rounded -- the windows tile [0, extent) with overlap, first and last flush with the borders."""
+    start, end = psize // 2, extent - psize // 2
+    num = math.ceil((end - start) / (psize / step))
+    size = (end - start) / (num + 1e-8)
+    if size == 0:
+        size = 9999999
+    return np.round(np.arange(start, end + 1e-8, size)).astype(np.int32)
+
+
+def get_dataset_for_eval_patches(data_list, step=2, config=None, proj_root="."):
+    """--eval_in_patches, input_pipeline.py:676-766: the liver box of each case is evaluated at NATIVE resolution by
+    sliding an (im_height, im_width) window over every slice (window stride <= patch / step), batched batch_size windows
+    at a time.  Yields (eval_batch, None) ... and, with the case's last batch, (eval_batch, labels) -- the whole label
+    volume (z, y, x); eval_batch = {images [bs, ph, pw, c], name, pad, bbox, position[(z, lb_y, ub_y, lb_x, ub_x)]}.
+    The reference indexes x windows with the patch HEIGHT (:743-744); identical for the square patches it is used with,
+    restated here with the width."""
+    import itertools
+    from . import nii_kits
+    align, padding, padding_z = 16, 25, 0
+    batch_size = config.batch_size
+    c = config.im_channel
+    psize = int(config.im_height), int(config.im_width)
+    root = Path(proj_root)
+    for case in data_list[getattr(config, "eval_skip_num", 0):]:
+        pid, d, h, w, z1, y1, x1, z2, y2, x2 = parse_case_patches(case, align, padding, padding_z, min_shape=psize)
+        obj_num = int(case["vol_case"][:-4].split("-")[-1])
+        _, volume = nii_kits.read_lits(obj_num, "vol", root / case["vol_case"])
+        lhc = (c - 1) // 2
+        rhc = c - 1 - lhc
+        left_pad = lhc - z1 if z1 < lhc else 0
+        right_pad = z2 + rhc - d if z2 + rhc > d else 0
+        volume = volume[max(0, z1 - lhc):min(d, z2 + rhc), y1:y2, x1:x2]
+        cd, ch, cw = volume.shape
+        if left_pad > 0 or right_pad > 0:
+            volume = np.concatenate((np.zeros((left_pad, ch, cw), dtype=volume.dtype), volume,
+                                     np.zeros((right_pad, ch, cw), dtype=volume.dtype)), axis=0)
+            cd, ch, cw = volume.shape
+        volume = (np.clip(volume, GRAY_MIN, GRAY_MAX) - GRAY_MIN) / (GRAY_MAX - GRAY_MIN)
+        volume = volume.transpose((1, 2, 0)).astype(np.float32)     # (y, x, z)
+        ysteps, xsteps = patch_centres(ch, psize[0], step), patch_centres(cw, psize[1], step)
+        all_patches = list(itertools.product(xsteps, ysteps, range(lhc, cd - rhc)))
+        num_of_batches = (len(all_patches) + (batch_size - 1)) // batch_size
+        for batch in range(num_of_batches):
+            eval_batch = {"images": np.zeros((batch_size,) + psize + (c,), dtype=np.float32), "name": pid, "pad": 0,
+                          "bbox": [x1, y1, z1, x2 - 1, y2 - 1, z2 - 1], "position": [None] * batch_size}
+            chunk = all_patches[batch * batch_size:(batch + 1) * batch_size]
+            for i, (x, y, z) in enumerate(chunk):
+                lb_y, ub_y = y - psize[0] // 2, y + psize[0] // 2
+                lb_x, ub_x = x - psize[1] // 2, x + psize[1] // 2
+                eval_batch["images"][i] = volume[lb_y:ub_y, lb_x:ub_x, z - lhc:z + rhc + 1]
+                eval_batch["position"][i] = (z - lhc, lb_y, ub_y, lb_x, ub_x)
+            if batch < num_of_batches - 1:
+                yield eval_batch, None
+            else:
+                eval_batch["pad"] = batch_size - len(chunk)
+                _, labels = nii_kits.read_lits(obj_num, "lab", root / case["lab_case"])
+                yield eval_batch, labels

@@ -181,6 +181,42 @@ class EvaluateVolume(EvaluateBase):
                 if 0 < cases <= counter:
                     break
 
+    def _predict_case_patches(self, predicts, cases=-1, dtype="pred", save_path=None):
+        """--eval_in_patches, evaluator_liver.py:524-566: window probabilities are written to their place in the liver
+        box (a later window overwrites an earlier one where they overlap -- `result[...] = Prob`, :545 -- so the
+        division by the coverage count the reference adds does not change the argmax and is not done), argmax on the
+        device, labels cropped to the box.  The reference's run() hands this loop (preds, None) tuples it then indexes
+        with strings (:537,763), i.e. its own path raises; this is the evident intent: labels travel with a case's
+        last batch.  Yields like _predict_case."""
+        result, covered = None, None
+        counter = 0
+        for predict, lab in predicts:
+            bbox = predict["bbox"]
+            prob = predict["Prob"]
+            if result is None:
+                shape = tuple(arr_ops.bbox_to_shape(bbox))
+                result = torch.zeros(shape + (prob.shape[-1],), dtype=torch.float32, device=prob.device)
+                covered = torch.zeros(shape, dtype=torch.bool, device=prob.device)
+            positions = predict["position"]
+            for i, (z, lb_y, ub_y, lb_x, ub_x) in enumerate(positions[:len(positions) - int(predict["pad"])]):
+                result[z, lb_y:ub_y, lb_x:ub_x] = prob[i]
+                covered[z, lb_y:ub_y, lb_x:ub_x] = True
+            if lab is None:
+                continue
+            if not bool(covered.all()):
+                raise RuntimeError("--eval_in_patches: windows do not cover the liver box of case {}".format(predict["name"]))
+            segmentation = np.asarray(lab)[arr_ops.bbox_to_slices(bbox)].astype(np.uint8)
+            if dtype == "pred":
+                amax, _ = ops.head_predict(result.view(-1, result.shape[-1]), result.shape[-1], want_preds=False)
+                volume = amax.view(result.shape[:-1]).cpu().numpy()
+            else:
+                volume = result.cpu().numpy()
+            yield str(predict["name"]), segmentation, volume, False
+            result, covered = None, None
+            counter += 1
+            if 0 < cases <= counter:
+                break
+
     # ------------------------------------------------------------------ host side
     def _postprocess(self, volume, is_label=False, ori_shape=None):
         """evaluator_liver.py:680-702."""
@@ -236,6 +272,7 @@ class EvaluateVolume(EvaluateBase):
         model = self._model()
         restored = [False]
         mode = getattr(self.config, "mode", ModeKeys.EVAL)
+        patches = bool(getattr(self.config, "eval_in_patches", False))
 
         def run_pred():
             for features, labels in input_fn(mode, self.params):
@@ -251,12 +288,14 @@ class EvaluateVolume(EvaluateBase):
                             self.estimator._restore(checkpoint_path, model, None)
                     preds_eval = {k: v for k, v in features.items() if not torch.is_tensor(v) or k == "names"}
                     preds_eval["Prob"] = self._slab_probability(model, features)
-                    yield preds_eval, None
+                    yield preds_eval, (labels if patches else None)
                 else:
                     yield None, labels
 
-        resize = getattr(self.config, "im_height", 0) > 0 and getattr(self.config, "im_width", 0) > 0
         n_cases = cases if cases is not None else getattr(self.config, "eval_num", -1)
+        if patches:
+            return self._run_actual(self._predict_case_patches, run_pred, save, cases=n_cases)
+        resize = getattr(self.config, "im_height", 0) > 0 and getattr(self.config, "im_width", 0) > 0
         return self._run_actual(self._predict_case, run_pred, save, cases=n_cases, resize=resize)
 
     def _run_actual(self, predict_fn, run_fn, save, cases=-1, **run_kwargs):

@@ -38,6 +38,14 @@ def bbox_to_shape(bbox):
     return tuple(int(bbox[i + ndim]) - int(bbox[i]) + 1 for i in range(ndim))[::-1]
 
 
+def bbox_to_slices(bbox):
+    """(x1, y1, [z1,] x2, y2[, z2]) inclusive -> index slices in array order ([z,] y, x) (utils/array_kits.py:177-195)."""
+    if len(bbox) % 2 != 0:
+        raise ValueError("`bbox` should have even number of elements, got {}".format(len(bbox)))
+    ndim = len(bbox) // 2
+    return tuple(slice(int(bbox[i]), int(bbox[i + ndim]) + 1) for i in reversed(range(ndim)))
+
+
 def bbox_from_mask(mask, mask_values=1):
     """utils/array_kits.py:85-151 (without min_shape / padding): tight box of the voxels whose value is in mask_values,
     (x1, y1, x2, y2) or (x1, y1, z1, x2, y2, z2), both corners INSIDE the object; zeros for an empty mask."""

@@ -1,0 +1,110 @@
+"""GPU: a model_dir / weights file in the REFERENCE's on-disk format (TensorFlow V2 checkpoint written by tf.train.Saver:
+variables under their graph names, Adam slots "Optimizer/<variable>/Adam{,_1}", `global_step`, the text `checkpoint`
+status file) resumes training here exactly where an uninterrupted run continues (core/estimator.py:52-59,646-741), and
+--load_weights / --weights_scope (core/models.py:151-185) initialise a model under another scope from it."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(tmp_path, **over):
+    import test_gpu_unet as t
+    from boxsegliver_amd.NetworksV2.UNet import UNet
+    from boxsegliver_amd.core.solver import Solver
+    from boxsegliver_amd.data import synthetic
+    args = t.make_args(batch_size=2, im_height=32, im_width=32, model="UNet", noise_scale=0.05, synthetic_batches=2,
+                       log_step=100, model_dir=str(tmp_path / "run"), load_weights=None, load_weights_version="checkpoint",
+                       weights_scope=None, **over)
+    images, labels, _ = synthetic.make_batch(2, 32, 32, 3, 3, 77)
+    inputs = {"images": torch.from_numpy(images).cuda(), "labels": torch.from_numpy(labels).cuda()}
+    return t, UNet, Solver, args, inputs
+
+
+def _export_tf(prefix, model, solver, scope=None):
+    """What tf.train.Saver would have written for this state (names of core/solver.py:232 `Optimizer/` + the graph names)."""
+    from boxsegliver_amd.utils import tf_checkpoint as tfc
+    ren = (lambda n: n) if scope is None else (lambda n: scope + n[len(model.name):])
+    out = {ren(k): v.numpy() for k, v in model.params.state_dict().items()}
+    t = solver.global_step
+    out["global_step"] = np.int64(t)
+    out["Optimizer/beta1_power"], out["Optimizer/beta2_power"] = np.float32(0.9 ** (t + 1)), np.float32(0.99 ** (t + 1))
+    for name in model.params.trainable_names():
+        grp, off, n, shape, _ = model.params.where[name]
+        m, v = solver._state[grp]
+        out["Optimizer/{}/Adam".format(ren(name))] = m[off:off + n].view(shape).cpu().numpy()
+        out["Optimizer/{}/Adam_1".format(ren(name))] = v[off:off + n].view(shape).cpu().numpy()
+    return tfc.write_checkpoint(prefix, out)
+
+
+def test_resume_from_reference_format_checkpoint_is_exact(tmp_path):
+    from boxsegliver_amd.core import estimator as est
+    t, UNet, Solver, args, inputs = _setup(tmp_path)
+    (tmp_path / "run").mkdir()
+    model, solver = UNet(args), Solver(args)
+    for _ in range(3):
+        solver(model(inputs, "train", **t.YML), model)
+    prefix = _export_tf(tmp_path / "run" / "model.ckpt-3", model, solver)
+    (tmp_path / "run" / "checkpoint").write_text('model_checkpoint_path: "model.ckpt-3"\nall_model_checkpoint_paths: "model.ckpt-3"\n')
+    cont = []
+    for _ in range(2):
+        loss = model(inputs, "train", **t.YML)
+        cont.append(loss.item())
+        solver(loss, model)
+    # a fresh process: the estimator finds the TF status file, reads step and variables
+    assert est._load_global_step_from_checkpoint_dir(str(tmp_path / "run")) == 3
+    e = est.CustomEstimator(lambda *a, **k: None, str(tmp_path / "run"), est.RunConfig(model_dir=str(tmp_path / "run")),
+                            {"args": args})
+    assert e.checkpoint_path() == prefix
+    model2, solver2 = UNet(args), Solver(args)
+    model2(inputs, "eval", **t.YML)                                      # creates the variables
+    e._maybe_restore(model2, solver2)
+    assert solver2.global_step == 3
+    resumed = []
+    for _ in range(2):
+        loss = model2(inputs, "train", **t.YML)
+        resumed.append(loss.item())
+        solver2(loss, model2)
+    assert resumed == cont                                               # bit-identical continuation
+    for k, v in model.params.state_dict().items():
+        assert torch.equal(v, model2.params.state_dict()[k]), k
+    # a variable missing from the file is an error, not a silent default
+    from boxsegliver_amd.utils import tf_checkpoint as tfc
+    partial = {k: v for k, v in tfc.read_checkpoint(prefix).items() if "AdjustChannels/biases" not in k}
+    tfc.write_checkpoint(tmp_path / "partial", partial)
+    with pytest.raises(KeyError):
+        est.restore_variables(str(tmp_path / "partial"), model2)
+
+
+def test_load_weights_with_scope_from_reference_checkpoint_dir(tmp_path):
+    from boxsegliver_amd.core import estimator as est
+    from boxsegliver_amd.core import models
+    t, UNet, Solver, args, inputs = _setup(tmp_path)
+    src, solver = UNet(args), Solver(args)
+    solver(src(inputs, "train", **t.YML), src)
+    wdir = tmp_path / "pretrained"
+    wdir.mkdir()
+    _export_tf(wdir / "model.ckpt-1", src, solver, scope="OldNet")
+    (wdir / "checkpoint_best").write_text('model_checkpoint_path: "model.ckpt-1"\n')
+    assert models._find_root_scope(str(wdir / "model.ckpt-1")) == "OldNet"
+    args.load_weights, args.load_weights_version = "pretrained", "checkpoint_best"     # a directory next to model_dir
+    dst = UNet(args)
+    dst(inputs, "eval", **t.YML)
+    init_fn = models.init_model(dst, args)
+    init_fn(None, None)
+    for k, v in src.params.state_dict().items():
+        assert torch.equal(v, dst.params.state_dict()[k]), k
+    # through the estimator: no checkpoint in model_dir -> the init_fn runs after variable creation
+    e = est.CustomEstimator(lambda *a, **k: None, str(tmp_path / "run"), est.RunConfig(model_dir=str(tmp_path / "run")),
+                            {"args": args})
+    dst2, solver2 = UNet(args), Solver(args)
+    dst2(inputs, "eval", **t.YML)
+    e._maybe_restore(dst2, solver2)
+    assert solver2.global_step == 0 and torch.equal(dst2.params.state_dict()["UNet/Encode1/Repeat/convolution2d_1/weights"],
+                                                    src.params.state_dict()["UNet/Encode1/Repeat/convolution2d_1/weights"])
+    args.load_weights = "nowhere"
+    with pytest.raises(FileNotFoundError):
+        models.init_model(dst, args)
+    args.load_weights = None
+    assert models.init_model(dst, args) is None

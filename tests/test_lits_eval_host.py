@@ -231,5 +231,58 @@ def test_eval_skip_num_and_errors(tmp_path):
     cases = lits.collect_datasets(tmp_path, 2, "eval")
     ends = [l for f, l in lits.get_dataset_for_eval_image_v2(cases, _cfg(eval_skip_num=1), tmp_path) if f is None]
     assert len(ends) == 1 and ends[0][1] == "nii/volume-5.nii"
-    with pytest.raises(NotImplementedError):
-        lits.input_fn_eval("eval", {"args": _cfg(eval_in_patches=True), "lits_root": tmp_path, "proj_root": tmp_path})
+
+
+def test_patch_centres_tile_the_extent():
+    # reference rule (input_pipeline.py:725-731): first / last window flush with the borders, stride <= patch / step
+    for extent, psize in ((96, 64), (64, 64), (112, 32), (208, 64), (100, 32)):
+        c = lits.patch_centres(extent, psize, 2)
+        assert c[0] == psize // 2 and c[-1] == extent - psize // 2
+        assert np.all(np.diff(c) <= psize // 2 + 1) and np.all(np.diff(c) > 0) or len(c) == 1
+        cover = np.zeros(extent, bool)
+        for v in c:
+            cover[v - psize // 2:v + psize // 2] = True
+        assert cover.all()
+    assert list(lits.patch_centres(64, 64)) == [32] and list(lits.patch_centres(96, 64)) == [32, 64]
+
+
+def test_eval_patches_generator_contract(tmp_path):
+    """--eval_in_patches (input_pipeline.py:676-766): native-resolution windows over every slice of the liver box."""
+    _write_dataset(tmp_path, size=128)
+    cfg = _cfg(eval_in_patches=True, batch_size=5, im_height=64, im_width=64)
+    items = list(lits.input_fn_eval("eval", {"args": cfg, "lits_root": tmp_path, "proj_root": tmp_path}))
+    last = [i for i, (f, l) in enumerate(items) if l is not None]
+    assert len(last) == 2 and last[-1] == len(items) - 1                     # fold 2 = two cases, labels with the last batch
+    case = items[:last[0] + 1]
+    bbox = case[0][0]["bbox"]
+    x1, y1, z1, x2, y2, z2 = bbox
+    ch, cw, cd = y2 - y1 + 1, x2 - x1 + 1, z2 - z1 + 1
+    assert ch % 16 == 0 and cw % 16 == 0 and ch >= 64 and cw >= 64 and (z1, z2) == (2, 8)
+    ny, nx = len(lits.patch_centres(ch, 64)), len(lits.patch_centres(cw, 64))
+    total = ny * nx * cd
+    assert len(case) == -(-total // 5) and case[-1][0]["pad"] == (5 - total % 5) % 5
+    assert all(f["pad"] == 0 and l is None for f, l in case[:-1])
+    labels = case[-1][1]
+    assert labels.shape == (11, 128, 128)                                    # the WHOLE label volume (z, y, x)
+    _, vol = nii_kits.read_lits(2, "vol", tmp_path / "nii/volume-2.nii")
+    win = ((np.clip(vol.astype(np.float64), -200, 250) + 200) / 450).astype(np.float32)
+    cover = np.zeros((cd, ch, cw), np.int32)
+    seen = 0
+    for f, _ in case:
+        assert f["images"].shape == (5, 64, 64, 3) and f["name"] == 2
+        n = 5 - f["pad"]
+        assert all(p is None for p in f["position"][n:]) and np.all(f["images"][n:] == 0)
+        for i, (z, lb_y, ub_y, lb_x, ub_x) in enumerate(f["position"][:n]):
+            assert ub_y - lb_y == 64 and ub_x - lb_x == 64 and 0 <= lb_y and ub_y <= ch and 0 <= lb_x and ub_x <= cw
+            ref = win[z1 + z - 1:z1 + z + 2, y1 + lb_y:y1 + ub_y, x1 + lb_x:x1 + ub_x].transpose(1, 2, 0)
+            np.testing.assert_array_equal(f["images"][i], ref)
+            cover[z, lb_y:ub_y, lb_x:ub_x] += 1
+            seen += 1
+    assert seen == total and cover.min() >= 1
+    # a box smaller than the patch grows to it (parse_case min_shape), clamped inside the slice
+    small = dict(lits.collect_datasets(tmp_path, 2, "eval")[0])
+    small["bbox"] = [3, 100, 100, 6, 110, 110]
+    pid, d, h, w, z1, y1, x1, z2, y2, x2 = lits.parse_case_patches(small, 16, 0, 0, min_shape=(64, 64))
+    assert (y2 - y1, x2 - x1) == (64, 64) and 0 <= y1 and y2 <= h and 0 <= x1 and x2 <= w
+    with pytest.raises(ValueError):
+        lits.parse_case_patches(small, 16, 0, 0, min_shape=(256, 64))
