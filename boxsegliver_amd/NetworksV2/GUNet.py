@@ -16,7 +16,9 @@ the same norm-apply / norm-backward kernels (no extra pass over the activations)
 gamma' / beta' after the modulation fold into the gains / guide weights / post-shift of the same kernels.
 
 Not built (raise NotImplementedError): --use_se, context_model vgg16*, the conv context subnet (`ct_conv`),
---fix, --dropout (no shipped script uses them).
+--fix, --dropout (no shipped script uses them); after_affine together with --without_norm.
+--without_norm (GUNet.py:251-252,314-315): every unit = conv + bias (* density gain + guide term) + ReLU, the norm stage
+of the fused kernels reduced to the per-channel shift (unetk_norm_desc.affine_only).
 """
 import torch
 
@@ -34,7 +36,8 @@ def n_modulator_params(init_channels, num_down_samples, mod_layers):
 
 
 def param_specs(in_channels, num_classes, guide_channel, init_channels, num_down_samples, mod_layers, normalizer,
-                norm_with_center, norm_with_scale, use_spatial, name, context_dims=None, after_affine=False, mid_cat_g=0):
+                norm_with_center, norm_with_scale, use_spatial, name, context_dims=None, after_affine=False, mid_cat_g=0,
+                without_norm=False):
     """Variables with the reference's TF names: <name>/spatial/conv{i}/{weights,biases},
     <name>/Encode/down_conv{i}/mod_conv{j}/{weights,<Norm>/...}, <name>/Decode/up{i}/{weights,biases},
     <name>/Decode/up_conv{i}/up_conv{i}_{j}/..., <name>/AdjustChannels/{weights,biases}."""
@@ -43,6 +46,9 @@ def param_specs(in_channels, num_classes, guide_channel, init_channels, num_down
     ns = "BatchNorm" if bn else "InstanceNorm"
 
     def norm_vars(scope, c, center, scale):
+        if without_norm:                              # GUNet.py:251-252,314-315: conv + bias, no normaliser
+            specs.append((scope + "/biases", (c,), "bias"))
+            return
         if center:
             specs.append(("{}/{}/beta".format(scope, ns), (c,), "beta"))
         if scale:
@@ -117,17 +123,17 @@ class GUNet(base.BaseNet):
 
     def _net_arg_scope(self, *args, **kwargs):
         """GUNet.py:240-257: as UNet (decoder norm = _get_normalization defaults), pools with SAME."""
-        if getattr(self.args, "without_norm", False):
-            raise NotImplementedError("--without_norm has no HIP kernel yet")
         if self.use_se or hasattr(self.args, "ct_conv"):
             raise NotImplementedError("GUNet --use_se / ct_conv context variants are not built yet")
         if getattr(self.args, "fix", False) or self.dropout:
             raise NotImplementedError("GUNet --fix / --dropout are not built yet")
-        self._norm = self._get_normalization()
+        self._norm = ("none", {}) if getattr(self.args, "without_norm", False) else self._get_normalization()
         return self._norm
 
     def _spec(self, decay=None):
         kind, np_ = self._norm
+        if kind == "none":              # --without_norm: the norm stage is the conv bias (unetk_norm_desc.affine_only)
+            return ops.NormSpec("none", 0.0, 0.0, self.is_training, self.compute_bf16)
         if kind == "batch_norm":
             return ops.NormSpec("batch_norm", np_["eps"], decay if decay is not None else np_["decay"],
                                 bool(np_["is_training"]), self.compute_bf16)
@@ -135,10 +141,14 @@ class GUNet(base.BaseNet):
 
     def _unit(self, x, scope, spec, out=None, guide=None, gw=None, gb=None, den=None):
         p = self.params
-        ns = scope + ("/BatchNorm" if spec.kind == "batch_norm" else "/InstanceNorm")
-        z = ops.Conv3x3NormRelu.apply(x, p[scope + "/weights"], p.get(ns + "/gamma"), p.get(ns + "/beta"),
-                                      p.get(ns + "/moving_mean"), p.get(ns + "/moving_variance"), spec, out, guide, gw,
-                                      gb, den)
+        if spec.kind == "none":
+            z = ops.Conv3x3NormRelu.apply(x, p[scope + "/weights"], None, p[scope + "/biases"], None, None, spec, out,
+                                          guide, gw, gb, den)
+        else:
+            ns = scope + ("/BatchNorm" if spec.kind == "batch_norm" else "/InstanceNorm")
+            z = ops.Conv3x3NormRelu.apply(x, p[scope + "/weights"], p.get(ns + "/gamma"), p.get(ns + "/beta"),
+                                          p.get(ns + "/moving_mean"), p.get(ns + "/moving_variance"), spec, out, guide,
+                                          gw, gb, den)
         if self._taps is not None:
             self._taps[scope] = z
         return z
@@ -150,6 +160,8 @@ class GUNet(base.BaseNet):
         norm_with_center = kwargs.get("norm_with_center", False)
         norm_with_scale = kwargs.get("norm_with_scale", False)
         after_affine = bool(kwargs.get("after_affine", False))
+        if after_affine and getattr(self.args, "without_norm", False):
+            raise NotImplementedError("GUNet after_affine together with --without_norm is not built")
         images = self._inputs["images"]
         if not images.is_cuda:
             raise ops._abi.UnetkError("GUNet runs on the GPU only: move `images` to cuda (no CPU path)")
@@ -177,7 +189,7 @@ class GUNet(base.BaseNet):
             mid_g = gc if (self._concat_guide and self._mid_cat) else 0
             specs = param_specs(in_ch, self.num_classes, g_ch, base_channels, nds, mod_layers,
                                 self.args.normalizer, norm_with_center, norm_with_scale, g_ch > 0, nm,
-                                context_dims, after_affine, mid_g)
+                                context_dims, after_affine, mid_g, bool(getattr(self.args, "without_norm", False)))
             if mid_g:
                 # Encode2's first conv sees 64 + g channels: padded with zero filter rows to the filter-gradient tile (32)
                 wname = "{}/Encode/down_conv2/mod_conv1/weights".format(nm)

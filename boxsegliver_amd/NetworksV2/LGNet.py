@@ -70,6 +70,8 @@ class LGNet(GUNet):
     def _net_arg_scope(self, *args, **kwargs):
         """LGNet.py:108-130: every slim.conv2d = 3x3, normaliser from _get_normalization(), no activation (the ReLUs are
         explicit); pools SAME."""
+        if getattr(self.args, "without_norm", False):
+            raise NotImplementedError("LGNet --without_norm is not built")
         self._norm = self._get_normalization()
         return self._norm
 

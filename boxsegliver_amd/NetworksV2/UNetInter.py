@@ -10,7 +10,7 @@ defaults.  So this class is GUNet with the guide routed to the input -- same ker
 before the first pool instead of to the input, so Encode2's first conv sees 64 + g channels; on the device that filter is
 padded with zero rows to 96 input channels (NetworksV2/padded.py) and the pooled tensor with zero channels.
 
-Not built: `use_2d`.  --img_grad computes dy / dx in the reference but never feeds them to the net (:82-85): ignored.
+`use_2d` (a static-shape hint in the reference) needs nothing here; --without_norm = conv + bias units.  --img_grad computes dy / dx in the reference but never feeds them to the net (:82-85): ignored.
 """
 from .GUNet import GUNet
 
@@ -27,11 +27,8 @@ class UNetInter(GUNet):
         self._encoder_decay = 0.99
 
     def _net_arg_scope(self, *args, **kwargs):
-        if getattr(self.args, "use_2d", False):
-            raise NotImplementedError("UNetInter use_2d is not built")
-        if getattr(self.args, "without_norm", False):
-            raise NotImplementedError("--without_norm has no HIP kernel yet")
-        self._norm = self._get_normalization()
+        # use_2d (UNetInter.py:76-78) only pins the static graph shape to [1, H, W, 3]; shapes are dynamic here
+        self._norm = ("none", {}) if getattr(self.args, "without_norm", False) else self._get_normalization()
         return self._norm
 
     def _build_network(self, *args, **kwargs):

@@ -28,13 +28,17 @@ from .unet2d import TRAINABLE_KINDS  # noqa: F401
 
 def param_specs(in_channels, num_classes, guide_channel=1, init_channels=64, num_down_samples=4,
                 mod_layers=(1, 2, 3, 4), normalizer="instance_norm", norm_with_center=True, norm_with_scale=False,
-                name="GUNet", use_spatial=True, context_dims=None, after_affine=False, mid_cat_g=0):
-    """context_dims = [context length, fc widths ..., n_modulator_param] enables the context branch."""
+                name="GUNet", use_spatial=True, context_dims=None, after_affine=False, mid_cat_g=0, without_norm=False):
+    """context_dims = [context length, fc widths ..., n_modulator_param] enables the context branch.
+    without_norm (GUNet.py:251-252,314-315): every conv unit has a bias and no normaliser."""
     specs = []
     bn = normalizer == "batch_norm"
     norm_scope = "BatchNorm" if bn else "InstanceNorm"
 
     def norm_vars(scope, center, scale):
+        if without_norm:
+            specs.append((scope + "/biases", None, "bias"))
+            return
         if center:
             specs.append(("{}/{}/beta".format(scope, norm_scope), None, "beta"))
         if scale:
@@ -98,7 +102,7 @@ class GUNet2DOracle(object):
     def __init__(self, in_channels, num_classes, guide_channel=1, init_channels=64, num_down_samples=4,
                  mod_layers=(1, 2, 3, 4), normalizer="instance_norm", norm_with_center=True, norm_with_scale=False,
                  name="GUNet", img_grad=False, use_spatial=True, context_length=None, context_fc_channels=(256, 256),
-                 after_affine=False, concat_guide=False, encoder_decay=0.999, mid_cat=False):
+                 after_affine=False, concat_guide=False, encoder_decay=0.999, mid_cat=False, without_norm=False):
         """concat_guide + mod_layers=() + encoder_decay=.99 + name="UNetInter" is the reference's UNetInter
         (NetworksV2/UNetInter.py:76-141): the guide joins the input channels, encoder BN decay .99 (:98-113)."""
         self.name, self.num_classes = name, num_classes
@@ -115,14 +119,17 @@ class GUNet2DOracle(object):
         self.init_channels, self.nds = init_channels, num_down_samples
         self.mod_layers = tuple(mod_layers)
         self.normalizer = normalizer
+        self.without_norm = without_norm
         self.specs = param_specs(in_channels, num_classes, guide_channel, init_channels, num_down_samples, mod_layers,
                                  normalizer, norm_with_center, norm_with_scale, name, use_spatial, self.context_dims,
-                                 after_affine, guide_channel if self.mid_cat else 0)
+                                 after_affine, guide_channel if self.mid_cat else 0, without_norm)
         self.kinds = {n: k for n, _, k in self.specs}
 
     def _unit(self, x, p, scope, is_training, new_stats, decay, sp=None, den=None):
         y = tf_ops.conv_nd_same(x, p[scope + "/weights"])
-        if self.normalizer == "batch_norm":
+        if self.without_norm:
+            y = y + p[scope + "/biases"]
+        elif self.normalizer == "batch_norm":
             ns = scope + "/BatchNorm"
             y, mm, mv = tf_ops.batch_norm(y, p.get(ns + "/gamma"), p.get(ns + "/beta"), p[ns + "/moving_mean"],
                                           p[ns + "/moving_variance"], is_training, eps=1e-3, decay=decay)
