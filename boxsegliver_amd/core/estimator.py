@@ -130,6 +130,31 @@ def restore_variables(path, model, solver=None, root_scope=None, strict=True):
         solver.load_state_dict(ckpt["solver"], model.params)
 
 
+def save_tf_checkpoint(prefix, model, solver=None, root_scope=None):
+    """The way back: write model (and solver) state as a TensorFlow V2 checkpoint with the names tf.train.Saver uses in the
+    reference's graph -- variables under their graph names, `global_step`, and for Adam "Optimizer/<variable>/Adam{,_1}" +
+    "Optimizer/beta{1,2}_power" (= beta^(t+1) as TF keeps them), for Momentum "Optimizer/<variable>/Momentum" -- so the
+    reference's tooling (its evaluators / exporters under TF) can consume a model trained here.  Returns the prefix."""
+    ren = (lambda n: n) if not root_scope or root_scope == model.name else (lambda n: root_scope + n[len(model.name):])
+    out = {ren(k): v.numpy() for k, v in model.params.state_dict().items()}
+    if solver is not None:
+        t = int(solver.global_step)
+        out["global_step"] = np.int64(t)
+        store = model.params
+        state = getattr(solver, "_state", None)
+        adam = solver.optimizer in ("adam", "adamw")
+        if adam:
+            hp = solver._optimizer_hparams()
+            out["Optimizer/beta1_power"] = np.float32(hp.get("beta1", 0.9) ** (t + 1))
+            out["Optimizer/beta2_power"] = np.float32(hp.get("beta2", 0.999) ** (t + 1))
+        if state is not None and hasattr(store, "where") and not hasattr(store, "logical_specs"):
+            for name in store.trainable_names():
+                grp, off, n, shape, _ = store.where[name]
+                for k, slot in enumerate(("Adam", "Adam_1") if adam else ("Momentum",)):
+                    out["Optimizer/{}/{}".format(ren(name), slot)] = state[grp][k][off:off + n].view(shape).cpu().numpy()
+    return tf_checkpoint.write_checkpoint(prefix, out)
+
+
 class CustomEstimator(object):
     def __init__(self, model_fn, model_dir=None, config=None, params=None, warm_start_from=None):
         if model_fn is None:

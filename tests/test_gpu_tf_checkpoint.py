@@ -23,19 +23,17 @@ def _setup(tmp_path, **over):
 
 
 def _export_tf(prefix, model, solver, scope=None):
-    """What tf.train.Saver would have written for this state (names of core/solver.py:232 `Optimizer/` + the graph names)."""
+    """What tf.train.Saver would have written for this state (core/estimator.save_tf_checkpoint)."""
+    from boxsegliver_amd.core import estimator as est
     from boxsegliver_amd.utils import tf_checkpoint as tfc
-    ren = (lambda n: n) if scope is None else (lambda n: scope + n[len(model.name):])
-    out = {ren(k): v.numpy() for k, v in model.params.state_dict().items()}
-    t = solver.global_step
-    out["global_step"] = np.int64(t)
-    out["Optimizer/beta1_power"], out["Optimizer/beta2_power"] = np.float32(0.9 ** (t + 1)), np.float32(0.99 ** (t + 1))
-    for name in model.params.trainable_names():
-        grp, off, n, shape, _ = model.params.where[name]
-        m, v = solver._state[grp]
-        out["Optimizer/{}/Adam".format(ren(name))] = m[off:off + n].view(shape).cpu().numpy()
-        out["Optimizer/{}/Adam_1".format(ren(name))] = v[off:off + n].view(shape).cpu().numpy()
-    return tfc.write_checkpoint(prefix, out)
+    out = est.save_tf_checkpoint(prefix, model, solver, root_scope=scope)
+    names = tfc.CheckpointReader(out).get_variable_to_shape_map()
+    root = scope or model.name
+    assert "global_step" in names and "Optimizer/beta1_power" in names and names["Optimizer/beta2_power"] == []
+    assert names["Optimizer/{}/AdjustChannels/weights/Adam_1".format(root)] == [1, 1, 64, 3]
+    assert names["{}/Encode1/Repeat/convolution2d_1/BatchNorm/moving_variance".format(root)] == [64]
+    assert not any(k.endswith("moving_mean/Adam") for k in names)          # statistics have no slots
+    return out
 
 
 def test_resume_from_reference_format_checkpoint_is_exact(tmp_path):
