@@ -4,6 +4,7 @@
 Liver+Tumor, 256x256x3, bs 32 per GPU, fp32 (BASELINE.json configs[1]) on synthetic LiTS-shaped data.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          # self-launching: spawns one rank per GPU (see launch())
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -14,12 +15,60 @@ the TensorFlow reference -- TF 1.13 cannot run here) on a bounded sample of the 
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+
+def launch(n_gpus, argv):
+    """`python bench.py --gpus N` from a plain shell (no torchrun in front, WORLD_SIZE unset): this parent -- which has
+    NOT touched HIP (torch is not even imported yet) -- starts `python -m torch.distributed.run` with one fresh child
+    process per GPU, relays rank 0's JSON line on stdout (everything else goes to stderr) and exits non-zero if any rank
+    failed or no line came back.  The reference is single-process multi-GPU (MirroredStrategy,
+    utils/distribution_utils.py:85-98); one process per GPU over RCCL is this package's design."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in proc.stdout:
+        if out.startswith('{"metric"'):
+            line = out
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc != 0:
+        raise SystemExit("bench.py: a rank failed (torch.distributed.run exit code {})".format(rc))
+    if line is None:
+        raise SystemExit("bench.py: the ranks finished but rank 0 printed no result line")
+    sys.stdout.write(line)
+    sys.stdout.flush()
+
+
+def _want_launch(argv):
+    if "WORLD_SIZE" in os.environ:
+        return 0
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    n = ap.parse_known_args(argv)[0].gpus
+    return n if n > 1 else 0
+
+
+if __name__ == "__main__" and _want_launch(sys.argv[1:]):
+    launch(_want_launch(sys.argv[1:]), sys.argv[1:])
+    sys.exit(0)
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -46,40 +95,47 @@ YML = dict(init_channels=64, num_down_samples=4, ret_prob=False, ret_pred=True, 
            build_summaries=False)
 
 
-def cpu_baseline(size, target_seconds=20.0):
-    """The CPU oracle (PyTorch-CPU restatement of the reference's TF semantics) timed on this host:
-    fwd + bwd + TF-Adam at batch 2 of the same 256x256x3 / 3-class workload."""
-    import numpy as np
+def _cpu_oracle_steps(size, n_classes, bs, warm, timed):
+    """Median seconds per fwd + bwd + TF-Adam step of the CPU oracle (numpy / PyTorch-CPU restatement; test infrastructure
+    used here only as the timed CPU baseline) at `bs` slices of size x size x 3, n_classes classes."""
     from boxsegliver_amd.data.synthetic import make_batch
     from oracle import solver as osolver
     from oracle import unet2d
-    bs = 2
-    threads = torch.get_num_threads()
-    net = unet2d.UNet2DOracle(3, 3)
+    net = unet2d.UNet2DOracle(3, n_classes)
     params = unet2d.init_params(net.specs, seed=1234)
-    images, labels, _ = make_batch(bs, size, size, 3, 3, 1234)
+    images, labels, _ = make_batch(bs, size, size, 3, n_classes, 1234)
     images, labels = torch.from_numpy(images), torch.from_numpy(labels).long()
     opt = osolver.TFAdam(0.9, 0.99, 1e-8)
-    kw = dict(loss_type="xentropy", loss_weight_type="numerical", numeric_w=[0.2, 0.4, 4.4], weight_decay_rate=1e-6)
-
-    def step():
+    numeric_w = [0.2, 0.4, 4.4][:n_classes]
+    kw = dict(loss_type="xentropy", loss_weight_type="numerical", numeric_w=numeric_w, weight_decay_rate=1e-6)
+    times = []
+    for i in range(warm + timed):
+        t0 = time.perf_counter()
         _, _, _, grads, stats = net.loss_and_grads(params, images, labels, **kw)
         opt.step({k: params[k].numpy() for k in grads}, {k: g.numpy() for k, g in grads.items()}, 1e-3)
         for k, v in stats.items():
             params[k] = v
+        if i >= warm:
+            times.append(time.perf_counter() - t0)
+    return statistics.median(times)
 
-    t0 = time.time()
-    step()                                   # warm-up
-    first = time.time() - t0
-    n = max(1, min(5, int(target_seconds / max(first, 1e-3)) - 1))
-    t0 = time.time()
-    for _ in range(n):
-        step()
-    dt = (time.time() - t0) / n
-    return {"value": bs / dt, "unit": "slices/s", "cores": threads, "kind": "port",
-            "sample": "oracle (PyTorch-CPU restatement, not TF): UNet {0}x{0}x3 3-class bs {1}, fwd+bwd+Adam, "
-                      "{2} timed step(s) after 1 warm-up, {3:.2f} s/step, host os.cpu_count()={4}".format(
-                          size, bs, n, dt, os.cpu_count())}
+
+def cpu_baseline(size, timed=5):
+    """SURVEY.md 8d "CPU baseline beside it": the reference's own TF-1.13 CPU path cannot run (TensorFlow is not
+    installable), so the labelled substitute is the oracle on this host's cores: BASELINE.json configs[0]
+    (Liver only = 2 classes, bs 2) and the configs[1]-shaped workload at bs 2 (3 classes), fwd+bwd+TF-Adam, median of
+    `timed` steps after one warm-up each.  `value` is the configs[1]-shaped one (the metric's workload)."""
+    threads = torch.get_num_threads()
+    bs = 2
+    dt1 = _cpu_oracle_steps(size, 3, bs, 1, timed)
+    dt0 = _cpu_oracle_steps(size, 2, bs, 1, timed)
+    return {"value": round(bs / dt1, 4), "unit": "slices/s", "cores": threads, "kind": "port",
+            "sample": "oracle (PyTorch-CPU restatement, not TF): UNet {0}x{0}x3 3-class bs {1} (configs[1] shape at bs 2), "
+                      "fwd+bwd+Adam, median of {2} timed steps after 1 warm-up, {3:.2f} s/step, {4} torch threads, "
+                      "host os.cpu_count()={5}".format(size, bs, timed, dt1, threads, os.cpu_count()),
+            "cfg0": {"value": round(bs / dt0, 4), "unit": "slices/s",
+                     "sample": "same, BASELINE.json configs[0]: Liver only (2 classes) bs 2, median of {} steps, "
+                               "{:.2f} s/step".format(timed, dt0)}}
 
 
 def main():
@@ -98,22 +154,40 @@ def main():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="fp32 = the headline configuration (exact fp32 MFMA); bf16 = BASELINE.json configs[2]'s mode: "
                          "3x3 contractions on the bf16 matrix cores, fp32 accumulate/storage (use --size 512 --batch 8)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="self-test of the multi-rank launch only (no kernels, no GPU needed): every rank joins the process "
+                         "group, rank 0 prints the ranks it saw as a `launch-check` line")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node {} bench.py --gpus {} ..."
-                             .format(a.gpus, a.gpus))
+        raise SystemExit("bench.py --gpus {} inside a {}-rank launch (WORLD_SIZE): the two must agree".format(a.gpus, world))
+    if a.launch_check:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        seen = [rank]
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+            got = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(got, torch.tensor([rank], dtype=torch.int64))
+            seen = sorted(int(g.item()) for g in got)
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "launch-check", "value": len(seen), "unit": "ranks", "n_gpus": a.gpus,
+                              "n_ranks_seen": len(seen), "ranks": seen}), flush=True)
+        return
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product has no CPU path)"
     # one rank per GPU; the modulo only matters for rehearsals of the multi-rank path on a box with fewer GPUs than
     # ranks (UNETK_DIST_BACKEND=gloo: RCCL refuses two ranks on one device)
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    backend = os.environ.get("UNETK_DIST_BACKEND", "nccl")                               # "nccl" = RCCL over xGMI
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=os.environ.get("UNETK_DIST_BACKEND", "nccl"))   # "nccl" = RCCL over xGMI
+        if backend == "nccl" and torch.cuda.device_count() < world:
+            raise SystemExit("bench.py --gpus {}: only {} GPU(s) visible; RCCL needs one device per rank "
+                             "(UNETK_DIST_BACKEND=gloo rehearses the multi-rank path on fewer)".format(world, torch.cuda.device_count()))
+        dist.init_process_group(backend=backend)
 
     from boxsegliver_amd import ops
     from boxsegliver_amd.core import models
@@ -174,20 +248,32 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]   # per-step HIP events (no host sync)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
         loss = one_step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0                  # this rank's own time for its K steps
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     prof = ops.PROFILE
     ops.PROFILE = None
     loss_val = float(loss.detach())
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
+    rank_ms, n_ranks_seen = [own / a.steps * 1e3], 1
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        n_ranks_seen = dist.get_world_size()
+        tdev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)      # the job's time = the slowest rank's
         elapsed = float(t.item())
+        mine = torch.tensor([own / a.steps * 1e3], dtype=torch.float64, device=tdev)
+        every = [torch.zeros_like(mine) for _ in range(n_ranks_seen)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(v.item()) for v in every]
 
     if rank == 0:
         ms = elapsed / a.steps * 1e3
@@ -205,7 +291,10 @@ def main():
         out = {
             "metric": METRIC if a.model == "UNet" else "{} units/sec/node (fwd+bwd)".format(a.model),
             "value": round(slices, 2), "unit": "slices/s" if a.model != "UNet3D" else "patches/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+            "ms_per_step_median_hipevents": round(statistics.median(step_ms), 3), "n_ranks_seen": n_ranks_seen,
+            "rank_ms_per_step_min": round(min(rank_ms), 3), "rank_ms_per_step_max": round(max(rank_ms), 3),
+            "dist_backend": (backend if world > 1 else None), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.dtype == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": wl, "global_batch": a.batch * world, "parallelism": "dp{}".format(world),
                        "classes": len(args.classes) + 1, "final_loss": round(loss_val, 5)},
@@ -233,21 +322,22 @@ def main():
                                "frac": round(top["achieved_tflops"] / kpeak, 4), "traffic": None,
                                "avg_launch_ms": top["avg_launch_ms"], "avg_launch_gflop": top["avg_launch_gflop"]}
             out["kernels"] = kern
-            # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside the
-            # process, so it comes from the committed rocprofv3 --pmc summary of this same command
-            # (profiles/r01_pmc_traffic.json, produced by tools/pmc_summary.py), else null.
+            # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside the process, so it
+            # comes from the committed rocprofv3 --pmc summary of this same command (profiles/rNN_pmc_traffic*.json,
+            # tools/pmc_summary.py; newest round wins) and ONLY when that file names this exact kernel -- else null.
             try:
-                fname = "r01_pmc_traffic.json" if a.dtype == "fp32" else "r01_pmc_traffic_bf16.json"
-                pmc = json.load(open(os.path.join(ROOT, "profiles", fname)))["kernels"]
+                import glob
                 import re
+                suffix = "" if a.dtype == "fp32" else "_bf16"
+                files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic" + suffix + ".json")))
+                pmc = json.load(open(files[-1]))["kernels"] if files else {}
                 norm = {re.sub(r"(,1)+>", ">", k.replace(" ", "")): v for k, v in pmc.items()}   # <..., S=1, DIL=1> == the tag
-                key = norm.get(top["kernel"].split("(")[0].replace(" ", "").replace(",false>", ">").replace(",true>", ">"))
-                if key is None and "wgrad_kernel" in top["kernel"]:
-                    key = next((v for k, v in norm.items() if k.startswith("conv3x3_wgrad_kernel<64,64")), None)
+                key = norm.get(top["kernel"].split("(")[0].replace(" ", ""))
                 if key and a.size == 256 and a.batch == 32 and a.model == "UNet":
                     out["roofline"]["traffic"] = round(key["hbm_bytes_per_launch_corrected"])
-                    out["roofline"]["traffic_source"] = "profiles/" + fname + " (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE)"
-            except (OSError, KeyError, ValueError):
+                    out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(files[-1]) + \
+                        " (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE)"
+            except (OSError, KeyError, ValueError, IndexError):
                 pass
         if not a.no_cpu_baseline and world == 1 and a.model == "UNet":
             out["cpu_baseline"] = cpu_baseline(a.size)

@@ -132,6 +132,19 @@ class ParamStore(object):
     def state_dict(self):
         return OrderedDict((n, t.detach().cpu().clone()) for n, t in self.tensors.items())
 
+    # optimiser slots (Adam m / v, Momentum accumulator) are flat buffers laid out like self.flat[grp]; checkpoints speak
+    # per-variable tensors in the TF shapes ("Optimizer/<variable>/Adam", core/estimator.py)
+    def read_slot(self, flat, name):
+        """The slice of `flat` (a buffer mirroring self.flat[group of name]) that belongs to variable `name`, TF shape."""
+        _, off, n, shp, _ = self.where[name]
+        return flat[off:off + n].view(shp).detach().cpu().clone()
+
+    @torch.no_grad()
+    def write_slot(self, flat, name, value):
+        _, off, n, shp, _ = self.where[name]
+        v = value if torch.is_tensor(value) else torch.as_tensor(value)
+        flat[off:off + n].view(shp).copy_(v.to(torch.float32).reshape(shp))
+
 
 class BaseNet(object):
     def __init__(self, args):

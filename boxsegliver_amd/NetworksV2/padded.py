@@ -76,6 +76,25 @@ class PaddedParamStore(ParamStore):
             out[name] = v
         return out
 
+    def read_slot(self, flat, name):
+        """Optimiser slot of `name` in its logical (TF) shape: the padded entries (exactly zero) are dropped."""
+        _, off, n, shp, _ = self.where[name]
+        phys = flat[off:off + n].view(shp).detach().cpu()
+        v = torch.zeros(self.logical_shape[name], dtype=torch.float32)
+        for lidx, pidx in self._blocks(name):
+            v[lidx] = phys[pidx]
+        return v
+
+    @torch.no_grad()
+    def write_slot(self, flat, name, value):
+        _, off, n, shp, _ = self.where[name]
+        v = (value if torch.is_tensor(value) else torch.as_tensor(value)).to(torch.float32).reshape(self.logical_shape[name])
+        t = flat[off:off + n].view(shp)
+        t.zero_()
+        v = v.to(t.device)
+        for lidx, pidx in self._blocks(name):
+            t[pidx] = v[lidx]
+
     def logical_grad(self, name):
         """Gradient of a variable in its logical (TF) shape."""
         g = self.tensors[name].grad.detach().cpu()

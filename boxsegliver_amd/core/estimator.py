@@ -119,7 +119,9 @@ def restore_variables(path, model, solver=None, root_scope=None, strict=True):
                 key = "Optimizer/{}/{}".format(rename(name), k)
                 return reader.get_tensor(key) if reader.has_tensor(key) else None
             step = int(reader.get_tensor("global_step")) if reader.has_tensor("global_step") else 0
-            solver.load_variable_slots(model.params, slot, step)
+            lr_key = "{}/learning_rate/value".format(solver.name)           # plateau_decay's variable (solver.py:246-254)
+            plateau = float(reader.get_tensor(lr_key)) if reader.has_tensor(lr_key) else None
+            solver.load_variable_slots(model.params, slot, step, plateau_lr=plateau)
         return
     ckpt = torch.load(path, map_location="cpu", weights_only=False)
     variables = ckpt["variables"]
@@ -135,23 +137,22 @@ def save_tf_checkpoint(prefix, model, solver=None, root_scope=None):
     reference's graph -- variables under their graph names, `global_step`, and for Adam "Optimizer/<variable>/Adam{,_1}" +
     "Optimizer/beta{1,2}_power" (= beta^(t+1) as TF keeps them), for Momentum "Optimizer/<variable>/Momentum" -- so the
     reference's tooling (its evaluators / exporters under TF) can consume a model trained here.  Returns the prefix."""
-    ren = (lambda n: n) if not root_scope or root_scope == model.name else (lambda n: root_scope + n[len(model.name):])
+    ren = (lambda n: n) if not root_scope or root_scope == model.name else \
+        (lambda n: root_scope + n[len(model.name):] if n.startswith(model.name) else n)
     out = {ren(k): v.numpy() for k, v in model.params.state_dict().items()}
     if solver is not None:
         t = int(solver.global_step)
         out["global_step"] = np.int64(t)
-        store = model.params
-        state = getattr(solver, "_state", None)
         adam = solver.optimizer in ("adam", "adamw")
         if adam:
             hp = solver._optimizer_hparams()
             out["Optimizer/beta1_power"] = np.float32(hp.get("beta1", 0.9) ** (t + 1))
             out["Optimizer/beta2_power"] = np.float32(hp.get("beta2", 0.999) ** (t + 1))
-        if state is not None and hasattr(store, "where") and not hasattr(store, "logical_specs"):
-            for name in store.trainable_names():
-                grp, off, n, shape, _ = store.where[name]
-                for k, slot in enumerate(("Adam", "Adam_1") if adam else ("Momentum",)):
-                    out["Optimizer/{}/{}".format(ren(name), slot)] = state[grp][k][off:off + n].view(shape).cpu().numpy()
+        if solver.learning_policy == "plateau":        # the non-trainable `learning_rate/value` variable (solver.py:246-254)
+            lr = solver.plateau_lr if solver.plateau_lr is not None else solver.base_learning_rate
+            out["{}/learning_rate/value".format(solver.name)] = np.float32(lr)
+        for (name, slot), v in solver.variable_slots(model.params).items():
+            out["Optimizer/{}/{}".format(ren(name), slot)] = v.numpy()
     return tf_checkpoint.write_checkpoint(prefix, out)
 
 
@@ -208,16 +209,16 @@ class CustomEstimator(object):
         fname = "{}-{}.pt".format(tag, step)
         torch.save({"variables": model.params.state_dict(), "solver": solver.state_dict() if solver else None},
                    os.path.join(self._model_dir, fname))
-        old = None
         status = os.path.join(self._model_dir, status_file)
-        if os.path.exists(status):
-            with open(status) as f:
-                old = json.load(f).get("model_checkpoint_path")
+        # the previous entry: this package's JSON status file, or TensorFlow's text CheckpointState after a resume from
+        # a model_dir the reference trained (get_checkpoint_state reads both)
+        old = tf_checkpoint.get_checkpoint_state(self._model_dir, status_file)
         with open(status, "w") as f:
             json.dump({"model_checkpoint_path": fname, "global_step": step}, f)
-        if old and old != fname and self._config.keep_checkpoint_max == 1:
+        if old and os.path.basename(old) != fname and self._config.keep_checkpoint_max == 1 and os.path.isfile(old) \
+                and old.endswith(".pt"):                      # never a TensorFlow bundle (prefix.index / .data-*)
             try:
-                os.remove(os.path.join(self._model_dir, old))
+                os.remove(old)
             except OSError:
                 pass
         return fname
@@ -308,13 +309,18 @@ class CustomEstimator(object):
             done += 1
             step = solver.global_step
             if step % log_step == 0 or done == 1:
-                loss_val = float(spec.loss.detach())  # host sync only at log steps
+                # the logged loss and "<Class>/<Metric>" scalars are replica MEANS (strategy.reduce, :576,:585); log steps
+                # are the same on every rank, so the collective is safe; host sync only at log steps
+                dp = self._train_distribution if (self._train_distribution is not None and
+                                                  self._train_distribution.num_replicas_in_sync > 1) else None
+                red = (lambda v: dp.reduce_mean(v.detach().to(torch.float32))) if dp is not None else (lambda v: v)
+                loss_val = float(red(spec.loss).detach())
                 if math.isnan(loss_val):
                     raise NanLossDuringTrainingError()          # NanTensorHook, estimator.py:676
                 last_loss = loss_val
                 vals = {"loss": loss_val, "lr": spec.train_op, "step": step}
                 for k, v in spec.model.metrics_dict.items():
-                    vals[k] = float(v)
+                    vals[k] = float(red(v) if torch.is_tensor(v) else v)
                 now = time.time()
                 msg = ", ".join(("%s = %.4g" if k == "step" else "%s = %.3g") % (k, vals[k]) for k in sorted(vals))
                 if done > 1:
@@ -360,6 +366,8 @@ class CustomEstimator(object):
     def predict(self, input_fn, predict_keys=None, hooks=None, checkpoint_path=None, latest_filename=None,
                 yield_single_examples=True):
         path = self.checkpoint_path(checkpoint_path, latest_filename)
+        if checkpoint_path and not tf_checkpoint.checkpoint_exists(path):
+            raise FileNotFoundError("Missing checkpoint file {}".format(path))     # a TF prefix exists only as .index/.data-*
         restored = False
         for features, labels in input_fn(ModeKeys.EVAL, self._params):
             if not restored:
@@ -369,7 +377,7 @@ class CustomEstimator(object):
                 model = self._params["model_instances"][0]
                 if model.params is None:
                     self._call_model_fn(features, labels, ModeKeys.EVAL)
-                if path and os.path.exists(path):
+                if path and tf_checkpoint.checkpoint_exists(path):
                     self._restore(path, model, None)
             spec = self._call_model_fn(features, labels, ModeKeys.EVAL)
             preds = spec.predictions

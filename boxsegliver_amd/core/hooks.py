@@ -53,6 +53,14 @@ def _global_step(run_context):
     return run_context.session.estimator.params["solver"].global_step
 
 
+def _strategy(session):
+    """The data-parallel strategy of the session's estimator when it spans more than one rank, else None.  The reference
+    runs ONE process for all GPUs (MirroredStrategy), so its hooks see replica-reduced values and act once; with one
+    process per GPU every rank runs the hooks, and anything that changes the training state must be made collective."""
+    st = getattr(getattr(session, "estimator", None), "_train_distribution", None)
+    return st if st is not None and st.num_replicas_in_sync > 1 else None
+
+
 class LogLearningRateHook(SessionRunHook):
     """core/hooks.py:471-518: log (and record) the learning rate every N steps."""
 
@@ -119,12 +127,44 @@ class ReduceLROnPlateauHook(SessionRunHook):
 
     def after_run(self, run_context, run_values):
         step = _global_step(run_context)
+        strategy = _strategy(run_context.session)
+        if strategy is not None and self._timer._every_secs is not None:
+            raise ValueError("ReduceLROnPlateauHook under data parallelism needs a step-based trigger (every_n_steps): a "
+                             "time-based one fires on different steps on different ranks")
         if self._timer.should_trigger_for_step(step) and step > 2:
             self._timer.update_last_triggered_step(step)
             old_lr = float(run_values.train_op)
-            self.try_update_lr(run_context.session, self._monitored(run_values))
-            if self.check_stop(old_lr):
+            current = self._monitored(run_values)
+            if strategy is None:
+                self.try_update_lr(run_context.session, current)
+                stop = self.check_stop(old_lr)
+            else:
+                # the reference monitors the replica-MEAN loss (core/estimator.py:576) and keeps ONE learning-rate
+                # variable (ONLY_FIRST_REPLICA, solver.py:249-250): reduce the value, decide on rank 0, broadcast the
+                # decision -- every rank then applies the same lr and stops at the same step
+                import torch
+                device = run_values.loss.device if hasattr(run_values.loss, "device") else "cpu"
+                current = float(strategy.reduce_mean(torch.tensor(current, dtype=torch.float64, device=device)))
+                solver = run_context.session.estimator.params["solver"]
+                decision = None
+                if strategy.rank == 0:
+                    self.try_update_lr(run_context.session, current)
+                    decision = {"plateau_lr": solver.plateau_lr, "stop": bool(self.check_stop(old_lr)), "state": self._state()}
+                decision = strategy.broadcast_object(decision, src=0)
+                if strategy.rank != 0:
+                    solver.plateau_lr = decision["plateau_lr"]
+                    self._set_state(decision["state"])
+                stop = decision["stop"]
+            if stop:
                 run_context.request_stop()
+
+    def _state(self):
+        return {"best": float(self.best), "total_loss_MA": self.total_loss_MA, "tr_wait": self.tr_wait,
+                "lr_wait": self.lr_wait, "cooldown_counter": self.cooldown_counter}
+
+    def _set_state(self, s):
+        self.best, self.total_loss_MA = s["best"], s["total_loss_MA"]
+        self.tr_wait, self.lr_wait, self.cooldown_counter = s["tr_wait"], s["lr_wait"], s["cooldown_counter"]
 
     def load_lr_schedule(self):
         f = Path(self.save_dir) / "lr_schedule"
@@ -237,6 +277,9 @@ class EvaluatorHook(SessionRunHook):
             self._last_interval_step = step
         else:
             status, best = "checkpoint_best", "best_result"
+        strategy = _strategy(session)
+        if strategy is not None and strategy.rank != 0:
+            return False                      # every rank evaluates (lock-step), rank 0 alone writes checkpoint / best_result
         log.info("Saving (best) checkpoints for %d into %s (%s).", step - 1, self._checkpoint_dir, status)
         session.estimator.save_checkpoint(status_file=status, tag=self._basename)
         with self._best_file(best).open("w") as f:

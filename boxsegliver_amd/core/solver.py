@@ -6,6 +6,7 @@ theta -= lr_t*m/(sqrt(v)+eps) with defaults beta1 .9, **beta2 .99**, eps 1e-8 (s
 plus the slim.l2_regularizer gradient wd*w.  Under data parallelism the two gradient buffers are
 all-reduced (sum) over RCCL and scaled by 1/world inside the same kernel.
 """
+import logging
 import math
 
 import numpy as np
@@ -14,6 +15,8 @@ import torch
 from .. import ops
 from ..config import CustomKeys
 from ..utils import distribution_utils
+
+log = logging.getLogger("boxsegliver_amd")
 
 
 def add_arguments(parser):
@@ -177,24 +180,45 @@ class Solver(object):
                     dst.copy_(src)
 
     @torch.no_grad()
-    def load_variable_slots(self, store, getter, global_step=0):
+    def load_variable_slots(self, store, getter, global_step=0, plateau_lr=None):
         """Optimiser state from per-variable slots (a TensorFlow checkpoint, core/estimator.restore_variables):
-        getter(variable name, slot name) -> ndarray or None, slot names "Adam" / "Adam_1" (m, v) or "Momentum".  The
-        bias-correction powers are not read: they are functions of global_step here as in TF (beta^t)."""
+        getter(variable name, slot name) -> ndarray (TF shape) or None, slot names "Adam" / "Adam_1" (m, v) or "Momentum";
+        plateau_lr = the `Optimizer/learning_rate/value` variable of plateau_decay (solver.py:246-254) when the file has
+        one.  Channel-padded stores map the TF shapes onto their padded layout (store.write_slot).  The bias-correction
+        powers are not read: they are functions of global_step here as in TF (beta^t).  Returns the number of slots read."""
         self.global_step = int(global_step)
+        if plateau_lr is not None:
+            self.plateau_lr = float(plateau_lr)
         names = ("Adam", "Adam_1") if self.optimizer in ("adam", "adamw") else ("Momentum",)
-        if not hasattr(store, "where") or hasattr(store, "logical_specs"):
-            return 0                               # channel-padded stores keep fresh slots (zeros)
+        if not hasattr(store, "where"):
+            return 0
         state = self._ensure_state(store)
-        loaded = 0
+        loaded, missing = 0, []
         for name in store.trainable_names():
-            grp, off, n, _, _ = store.where[name]
+            grp = store.where[name][0]
             for k, slot in enumerate(names):
                 v = getter(name, slot)
                 if v is not None:
-                    state[grp][k][off:off + n].copy_(torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)).reshape(-1))
+                    store.write_slot(state[grp][k], name, np.ascontiguousarray(v, dtype=np.float32))
                     loaded += 1
+                else:
+                    missing.append(name + "/" + slot)
+        if loaded and missing:
+            log.warning("optimiser slots missing in the checkpoint for %d entries (kept at zero), e.g. %s",
+                        len(missing), missing[:3])
         return loaded
+
+    def variable_slots(self, store):
+        """The way back: {(variable name, slot name): tensor in the TF shape} of the live optimiser state."""
+        out = {}
+        if self._state is None or not hasattr(store, "where"):
+            return out
+        names = ("Adam", "Adam_1") if self.optimizer in ("adam", "adamw") else ("Momentum",)
+        for name in store.trainable_names():
+            grp = store.where[name][0]
+            for k, slot in enumerate(names):
+                out[(name, slot)] = store.read_slot(self._state[grp][k], name)
+        return out
 
     def apply_gradients(self, store, l2, lr):
         """One optimiser step on the flat buffers; gradients are already in store.grad."""

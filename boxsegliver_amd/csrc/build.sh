@@ -8,13 +8,18 @@ mkdir -p "$OUT" "$ROOT/build"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function"
 objs=()
+pids=()
 for src in conv_igemm conv_igemm_lin conv_igemm_bf16 conv_wgrad conv3d deconv norm reduce pool head weights lits fc optim; do
   o="$ROOT/build/$src.o"
   if [[ ! -f "$o" || "$HERE/$src.hip" -nt "$o" || "$HERE/common.h" -nt "$o" || "$ROOT/include/unetk.h" -nt "$o" ]]; then
+    rm -f "$o"                                  # a failed compile must not leave a stale object for the link
     "$HIPCC" $FLAGS -c "$HERE/$src.hip" -o "$o" &
+    pids+=("$!")
   fi
   objs+=("$o")
 done
-wait
+for pid in "${pids[@]:-}"; do                   # a bare `wait` returns 0 even when a job failed
+  [[ -z "$pid" ]] || wait "$pid" || { echo "build.sh: a compile job failed" >&2; exit 1; }
+done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libunetk.so" "${objs[@]}"
 echo "built $OUT/libunetk.so"

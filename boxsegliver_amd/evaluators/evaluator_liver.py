@@ -29,6 +29,7 @@ from .. import loss_metrics as metric_ops
 from .. import ops
 from ..NetworksV2.base import ModeKeys
 from ..utils import array_kits as arr_ops
+from ..utils import tf_checkpoint
 from .evaluator_base import EvaluateBase
 
 
@@ -271,6 +272,10 @@ class EvaluateVolume(EvaluateBase):
         """evaluator_liver.py:704-766: build the model, restore the checkpoint, stream the cases."""
         model = self._model()
         restored = [False]
+        # a requested checkpoint must exist -- a TensorFlow V2 prefix (`model.ckpt-3` = .index + .data-* files) or a file of
+        # this package; the reference raises FileNotFoundError (:705-708).  checkpoint_path=None scores the live variables.
+        if checkpoint_path and not tf_checkpoint.checkpoint_exists(checkpoint_path):
+            raise FileNotFoundError("Missing checkpoint file {} (status_file {})".format(checkpoint_path, latest_filename))
         mode = getattr(self.config, "mode", ModeKeys.EVAL)
         patches = bool(getattr(self.config, "eval_in_patches", False))
 
@@ -284,7 +289,7 @@ class EvaluateVolume(EvaluateBase):
                         restored[0] = True
                         if model.params is None:
                             self._forward(model, features)              # creates the variables
-                        if checkpoint_path and self.estimator is not None and Path(str(checkpoint_path)).exists():
+                        if checkpoint_path and self.estimator is not None:
                             self.estimator._restore(checkpoint_path, model, None)
                     preds_eval = {k: v for k, v in features.items() if not torch.is_tensor(v) or k == "names"}
                     preds_eval["Prob"] = self._slab_probability(model, features)

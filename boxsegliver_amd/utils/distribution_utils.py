@@ -50,6 +50,15 @@ class DistributionStrategy(object):
             return (v / self.num_replicas_in_sync).reshape(())
         return value
 
+    def broadcast_object(self, obj, src=0):
+        """A small picklable host value from `src` to every rank (control decisions: learning-rate / stop flags)."""
+        if self.num_replicas_in_sync > 1:
+            box = [obj]
+            dist.broadcast_object_list(box, src=src, device=torch.device("cuda", torch.cuda.current_device())
+                                       if dist.get_backend() == "nccl" else None)
+            return box[0]
+        return obj
+
     def broadcast_(self, tensors, src=0):
         if self.num_replicas_in_sync > 1:
             for t in tensors:

@@ -308,3 +308,116 @@ def test_rccl_bucketed_allreduce_from_backward_hooks_world1():
         mp.spawn(_rccl_worker, args=(1, _free_port(), d), nprocs=1, join=True)
         r = torch.load(os.path.join(d, "r0.pt"))
     assert r["same"] and r["n"] >= 3 and r["fired"] == r["n"] and r["mean"] == 3.0
+
+
+def _rccl_worker_n(rank, world, port, out_dir):
+    """RCCL with N > 1 ranks, one GPU each: the bucketed all-reduce launched from backward hooks must leave in every
+    rank's gradient buffers the SUM over ranks of the plain per-rank gradients (different shards per rank), and a whole
+    Solver step must keep the replicas bit-identical."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    from boxsegliver_amd.NetworksV2.UNet import UNet
+    from boxsegliver_amd.core.solver import Solver
+    from boxsegliver_amd.utils.distribution_utils import DistributionStrategy, GradBuckets
+    args = _unet_args(2 * world, world)
+    model = UNet(args)
+    inputs = _shard(rank)
+    model(inputs, "eval", **YML)
+    strategy = DistributionStrategy("mirrored", world, rank)
+    if rank != 0:
+        model.params.flat["reg"].mul_(0.5)
+    strategy.broadcast_(list(model.params.flat.values()))
+    model.params.zero_grad()
+    model(inputs, "train", **YML).backward()
+    want = {k: v.clone() for k, v in model.params.grad.items()}
+    for v in want.values():
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)                      # plain all-reduce after backward
+    buckets = GradBuckets(model.params, strategy, bucket_bytes=1 << 20)
+    fired = 0
+    for _ in range(2):
+        model.params.zero_grad()
+        buckets.arm()
+        model(inputs, "train", **YML).backward()
+        fired = sum(buckets._fired)
+        buckets.finish()
+    torch.cuda.synchronize()
+    same = all(torch.equal(want[k], model.params.grad[k]) for k in want)
+    buckets.remove()
+    solver = Solver(args)
+    solver.strategy = strategy
+    for _ in range(2):
+        solver(model(inputs, "train", **YML), model)
+    torch.cuda.synchronize()
+    torch.save({"same": same, "n": len(buckets.buckets), "fired": fired,
+                "flat": {k: v.cpu() for k, v in model.params.flat.items()}},
+               os.path.join(out_dir, "r{}.pt".format(rank)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank; this box has fewer than 2")
+def test_rccl_bucketed_allreduce_two_ranks():
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_rccl_worker_n, args=(world, _free_port(), d), nprocs=world, join=True)
+        r = [torch.load(os.path.join(d, "r{}.pt".format(i))) for i in range(world)]
+    for x in r:
+        assert x["same"] and x["n"] >= 3 and x["fired"] == x["n"]
+    for g in ("reg", "noreg"):
+        assert torch.equal(r[0]["flat"][g], r[1]["flat"][g])
+
+
+# ------------------------------------------------------------ control hooks under data parallelism (ADVICE r1, high)
+def _plateau_worker(rank, world, port, out_dir):
+    import json
+    import types
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from boxsegliver_amd.core import hooks
+    from boxsegliver_amd.core.estimator import _RunContext
+    from boxsegliver_amd.core.solver import Solver
+    from boxsegliver_amd.utils.distribution_utils import DistributionStrategy
+    a = _solver_args()
+    a.learning_policy, a.lr_decay_rate, a.lr_end = "plateau", 0.1, 1e-6
+    solver = Solver(a)
+    save_dir = os.path.join(out_dir, "model")            # ONE directory shared by the ranks, as in a real job
+    est = types.SimpleNamespace(params={"solver": solver}, _train_distribution=DistributionStrategy("mirrored", world, rank),
+                                model_dir=save_dir)
+    hook = hooks.ReduceLROnPlateauHook(save_dir, lr_patience=1, tr_patience=3, min_delta=0.01, every_n_steps=1,
+                                       moving_average=0.0)
+    ctx = _RunContext(types.SimpleNamespace(estimator=est))
+    lrs, stopped_at = [], None
+    gen = torch.Generator().manual_seed(17 + rank)
+    for i in range(40):
+        solver.global_step = i + 3
+        lr = solver._get_model_learning_rate()
+        lrs.append(lr)
+        # rank-local losses that disagree about "improved by min_delta": rank 0 keeps improving, rank 1 stagnates
+        loss = (1.0 / (i + 1) if rank == 0 else 0.5) + 0.01 * float(torch.rand(1, generator=gen))
+        hook.after_run(ctx, types.SimpleNamespace(loss=torch.tensor(loss), train_op=lr,
+                                                  model=types.SimpleNamespace(metrics_dict={})))
+        if ctx.stop_requested:
+            stopped_at = i
+            break
+    with open(os.path.join(out_dir, "r{}.json".format(rank)), "w") as f:
+        json.dump({"lrs": lrs, "stopped_at": stopped_at, "state": hook._state()}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_plateau_hook_is_collective_under_dp_gloo_world2():
+    """Different per-rank losses must yield the SAME learning-rate sequence and the SAME stop step on every rank (decided
+    on rank 0 from the replica-mean loss and broadcast); lr_schedule is written once, by rank 0."""
+    import json
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_plateau_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        r = [json.load(open(os.path.join(d, "r{}.json".format(i)))) for i in range(world)]
+        sched = json.load(open(os.path.join(d, "model", "lr_schedule")))
+    assert r[0]["lrs"] == r[1]["lrs"] and r[0]["stopped_at"] == r[1]["stopped_at"]
+    assert r[0]["state"] == r[1]["state"]
+    assert min(r[0]["lrs"]) < 1e-3                     # the mean loss did plateau: the rate was decayed at least once
+    assert r[0]["stopped_at"] is not None              # ... and training stopped, on both ranks at the same step
+    assert sched["best"] == pytest.approx(r[0]["state"]["best"])

@@ -106,3 +106,74 @@ def test_load_weights_with_scope_from_reference_checkpoint_dir(tmp_path):
         models.init_model(dst, args)
     args.load_weights = None
     assert models.init_model(dst, args) is None
+
+
+def test_offline_eval_and_predict_restore_a_tf_prefix_and_refuse_missing_ones(tmp_path):
+    """`model.ckpt-3` exists only as .index / .data-* files -- evaluator.run and estimator.predict must
+    restore it (not silently score the fresh initialisation) and must raise FileNotFoundError for a path that is not a
+    checkpoint (reference evaluators/evaluator_liver.py:705-708)."""
+    from boxsegliver_amd.core import estimator as est
+    from boxsegliver_amd.core import models
+    from boxsegliver_amd.data import synthetic
+    from boxsegliver_amd.evaluators import evaluator_liver as ev
+    t, UNet, Solver, args, inputs = _setup(tmp_path, eval_mirror=False, random_flip=0, metrics_eval=["Dice"],
+                                           use_global_dice=False, pred_type="pred", mode="eval", eval_num=-1, save_path=None)
+    (tmp_path / "run").mkdir()
+    src, solver = UNet(args), Solver(args)
+    for _ in range(2):
+        solver(src(inputs, "train", **t.YML), src)
+    prefix = _export_tf(tmp_path / "run" / "model.ckpt-2", src, solver)
+    want = src.params.state_dict()
+
+    params = {"args": args, "model": UNet, "model_kwargs": dict(t.YML), "model_args": (), "eval_cases": [(7, 4)]}
+    e = est.CustomEstimator(models.model_fn, str(tmp_path / "run"), est.RunConfig(model_dir=str(tmp_path / "run")), params)
+    evaluator = ev.get_evaluator("Volume", estimator=e, model_dir=str(tmp_path / "run"), params=params)
+    evaluator.run(synthetic.input_fn_eval_volumes, checkpoint_path=prefix)
+    got = evaluator._model().params.state_dict()
+    for k, v in want.items():
+        assert torch.equal(v, got[k]), k
+    with pytest.raises(FileNotFoundError):
+        evaluator.run(synthetic.input_fn_eval_volumes, checkpoint_path=str(tmp_path / "run" / "model.ckpt-9"))
+
+    params2 = {"args": args, "model": UNet, "model_kwargs": dict(t.YML), "model_args": ()}
+    e2 = est.CustomEstimator(models.model_fn, str(tmp_path / "run"), est.RunConfig(model_dir=str(tmp_path / "run")), params2)
+    next(e2.predict(synthetic.input_fn, checkpoint_path=prefix))
+    got2 = params2["model_instances"][0].params.state_dict()
+    for k, v in want.items():
+        assert torch.equal(v, got2[k]), k
+    with pytest.raises(FileNotFoundError):
+        next(e2.predict(synthetic.input_fn, checkpoint_path=str(tmp_path / "run" / "model.ckpt-9")))
+
+
+def test_save_after_resuming_from_a_tf_model_dir_and_plateau_lr_travels(tmp_path):
+    """ADVICE r1 (medium x2): after a resume from a reference model_dir the status file is TensorFlow's text
+    CheckpointState -- the next save must replace it (no JSONDecodeError) and leave the TF bundle on disk; the plateau
+    learning-rate variable `Optimizer/learning_rate/value` (solver.py:246-254) is exported and restored."""
+    import json
+    import os
+    from boxsegliver_amd.core import estimator as est
+    from boxsegliver_amd.utils import tf_checkpoint as tfc
+    t, UNet, Solver, args, inputs = _setup(tmp_path, learning_policy="plateau", lr_decay_rate=0.2)
+    run = tmp_path / "run"
+    run.mkdir()
+    model, solver = UNet(args), Solver(args)
+    solver(model(inputs, "train", **t.YML), model)
+    solver.update_plateau_lr()                                         # 1e-3 -> 2e-4, as the plateau hook would
+    prefix = est.save_tf_checkpoint(run / "model.ckpt-1", model, solver)
+    assert float(tfc.CheckpointReader(prefix).get_tensor("Optimizer/learning_rate/value")) == pytest.approx(2e-4)
+    (run / "checkpoint").write_text('model_checkpoint_path: "model.ckpt-1"\nall_model_checkpoint_paths: "model.ckpt-1"\n')
+
+    params = {"args": args, "solver": Solver(args)}
+    e = est.CustomEstimator(lambda *a, **k: None, str(run), est.RunConfig(model_dir=str(run)), params)
+    model2 = UNet(args)
+    model2(inputs, "eval", **t.YML)
+    params["model_instances"] = [model2]
+    e._maybe_restore(model2, params["solver"])
+    assert params["solver"].global_step == 1 and params["solver"].plateau_lr == pytest.approx(2e-4)
+    assert params["solver"]._get_model_learning_rate() == pytest.approx(2e-4)
+    fname = e.save_checkpoint()                                        # used to raise JSONDecodeError here
+    assert fname == "model.ckpt-1.pt" and json.load(open(str(run / "checkpoint")))["global_step"] == 1
+    assert os.path.exists(prefix + ".index") and os.path.exists(prefix + ".data-00000-of-00001")   # TF bundle kept
+    params["solver"](model2(inputs, "train", **t.YML), model2)
+    assert e.save_checkpoint() == "model.ckpt-2.pt" and not os.path.exists(str(run / "model.ckpt-1.pt"))
+    assert os.path.exists(prefix + ".index")

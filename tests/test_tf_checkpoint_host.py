@@ -133,3 +133,50 @@ def test_checkpoint_state_files(tmp_path):
     assert not tfc.checkpoint_exists(tmp_path / "model.ckpt-5000")
     tfc.write_checkpoint(tmp_path / "model.ckpt-5000", {"a": np.zeros(3, np.float32)})
     assert tfc.checkpoint_exists(tmp_path / "model.ckpt-5000")
+
+
+def test_padded_store_optimiser_slots_round_trip_in_tf_shapes(tmp_path):
+    """channel-padded stores (UNet3D, SmallUNet_V2) used to drop the Adam slots on both TF import and
+    export; they now travel in the logical (TF) shapes and scatter back into the padded layout, padding exactly zero."""
+    import argparse
+    import types
+
+    import torch
+    from boxsegliver_amd.NetworksV2.padded import PaddedParamStore
+    from boxsegliver_amd.core import estimator as est
+    from boxsegliver_amd.core.solver import Solver
+    from boxsegliver_amd.utils import tf_checkpoint as tfc
+    specs = [("N/a/weights", (3, 3, 3, 30), "conv_w"), ("N/a/beta", (30,), "beta"), ("N/b/weights", (3, 3, 60, 30), "conv_w"),
+             ("N/a/moving_mean", (30,), "moving_mean")]
+    pads = {"N/a/weights": ((3, 3, 3, 32), {}), "N/a/beta": ((32,), {}), "N/a/moving_mean": ((32,), {}),
+            "N/b/weights": ((3, 3, 64, 32), {2: [(0, 30, 0), (30, 30, 32)]})}
+
+    def make():
+        store = PaddedParamStore(specs, pads, torch.device("cpu"))
+        store.initialize("xavier", seed=5)
+        a = argparse.Namespace(learning_rate=1e-3, learning_policy="plateau", lr_decay_step=1000, lr_decay_rate=0.5,
+                               num_of_total_steps=10, lr_power=0.9, lr_end=1e-6, lr_decay_boundaries=None,
+                               lr_custom_values=None, optimizer="Adam")
+        return types.SimpleNamespace(params=store, name="N"), Solver(a)
+
+    model, solver = make()
+    state = solver._ensure_state(model.params)
+    g = torch.Generator().manual_seed(1)
+    for grp in ("reg", "noreg"):
+        for k in range(2):
+            for name in model.params.trainable_names():
+                if model.params.where[name][0] == grp:
+                    model.params.write_slot(state[grp][k], name, torch.randn(model.params.logical_shape[name], generator=g))
+    solver.global_step, solver.plateau_lr = 7, 2.5e-4
+    prefix = est.save_tf_checkpoint(tmp_path / "m.ckpt-7", model, solver)
+    shapes = tfc.CheckpointReader(prefix).get_variable_to_shape_map()
+    assert shapes["Optimizer/N/b/weights/Adam_1"] == [3, 3, 60, 30] and shapes["Optimizer/N/a/beta/Adam"] == [30]
+    model2, solver2 = make()
+    est.restore_variables(prefix, model2, solver2)
+    assert solver2.global_step == 7 and solver2.plateau_lr == pytest.approx(2.5e-4)
+    for grp in ("reg", "noreg"):
+        for k in range(2):
+            assert torch.equal(solver2._state[grp][k], state[grp][k])          # incl. the zero padding
+    _, off, n, shp, _ = model2.params.where["N/b/weights"]
+    phys = solver2._state["reg"][0][off:off + n].view(shp)
+    assert float(phys[:, :, 30:32].abs().max()) == 0 and float(phys[:, :, 62:].abs().max()) == 0 and float(phys[..., 30:].abs().max()) == 0

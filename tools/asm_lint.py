@@ -1,12 +1,19 @@
-"""Lint the generated gfx950 ISA of the MFMA kernels for accumulator read-back inside a K loop.
+"""Lint the generated gfx950 ISA of every kernel in csrc/*.hip (cross-compiles with hipcc; no GPU needed).
 
-Background (round 1): with two MFMA loops selected by a run-time flag in one kernel, the compiler kept the accumulator
-in VGPRs across tiles, copied it to AGPRs before each MFMA loop and read it back (`v_accvgpr_read`) right after -- with
-too few wait states after the last 16-pass MFMA, so rows 27 / 31 of every 32-row panel lost the final k-step,
-non-reproducibly.  A healthy kernel reads its accumulators only AFTER the last MFMA in program text (the epilogue).
+Checks, per kernel:
+1. **No accumulator read-back inside a K loop.**  Background (round 1): with two MFMA loops selected by a run-time flag
+   in one kernel, the compiler kept the accumulator in VGPRs across tiles, copied it to AGPRs before each MFMA loop and
+   read it back (`v_accvgpr_read`) right after -- with too few wait states after the last 16-pass MFMA, so rows 27 / 31
+   of every 32-row panel lost the final k-step, non-reproducibly.  A healthy kernel reads its accumulators only AFTER
+   the last MFMA in program text (the epilogue).
+2. **The matrix kernels really are MFMA kernels of the intended shape**: fp32 kernels contain `v_mfma_f32_32x32x2_f32`
+   (exact fp32), bf16 kernels `v_mfma_f32_32x32x16_bf16`; a template change that silently falls back to VALU FMAs (or to
+   another MFMA shape with different rounding) is caught here, not by a slow benchmark.
+3. **No scratch**: `.private_segment_fixed_size` == 0 and no `scratch_` instructions (a register spill in a hot loop).
 
-Usage: python tools/asm_lint.py      (cross-compiles csrc/*.hip to ISA with hipcc; no GPU needed; exits 1 on a hit)
+Usage: python tools/asm_lint.py      (exits 1 on a finding).  `tests/test_asm_lint.py` runs the same checks under pytest.
 """
+import concurrent.futures
 import glob
 import os
 import re
@@ -17,26 +24,84 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "boxsegliver_amd", "csrc")
 
+# kernel-name prefix -> MFMA opcode its body must contain (template instances checked individually)
+EXPECT = [
+    ("conv3x3_igemm_bf16_kernel", "v_mfma_f32_32x32x16_bf16"),
+    ("pw_gemm_bf16_kernel", "v_mfma_f32_32x32x16_bf16"),
+    ("conv3x3_igemm_kernel", "v_mfma_f32_32x32x2_f32"),
+    ("conv3x3_igemm_lin_kernel", "v_mfma_f32_32x32x2_f32"),
+    ("pw_gemm_kernel", "v_mfma_f32_32x32x2_f32"),
+    ("conv3x3_wgrad_c3_kernel", "v_mfma_f32_32x32x2_f32"),
+]
+
+
+def expected_opcode(name):
+    """The MFMA opcode a kernel of this (demangled) name must contain, or None when it is not a matrix kernel."""
+    base = name.split("<")[0].split("(")[0].replace("void ", "").strip()
+    for prefix, op in EXPECT:
+        if base == prefix:
+            return op
+    if base in ("conv3x3_wgrad_kernel", "deconv_wgrad_kernel"):   # <.., BF16, ..> instances use the bf16 pipe
+        args = name[name.find("<") + 1:name.rfind(">")].replace(" ", "").split(",") if "<" in name else []
+        bf16 = (base == "conv3x3_wgrad_kernel" and len(args) > 2 and args[2] == "true") or \
+               (base == "deconv_wgrad_kernel" and len(args) > 0 and args[0] == "true")
+        return "v_mfma_f32_32x32x16_bf16" if bf16 else "v_mfma_f32_32x32x2_f32"
+    return None
+
+
+def _compile(src, tmp):
+    out = os.path.join(tmp, os.path.basename(src) + ".s")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wno-unused-function", "-S",
+                           "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def lint(jobs=4):
+    """[{file, kernel, n_mfma, early_acc_reads, opcodes, scratch_insts, private_segment, expect, findings}] over csrc."""
+    rows = []
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    with tempfile.TemporaryDirectory() as tmp, concurrent.futures.ThreadPoolExecutor(jobs) as pool:
+        texts = list(pool.map(lambda s: _compile(s, tmp), srcs))
+    for src, txt in zip(srcs, texts):
+        private = {m.group(1): int(m.group(2)) for m in re.finditer(
+            r"\.amdhsa_kernel (\w+)\b.*?\.amdhsa_private_segment_fixed_size (\d+)", txt, re.S)}
+        for m in re.finditer(r"^(_Z\w+):[^\n]*\n", txt, re.M):
+            end = txt.find("s_endpgm", m.end())
+            if end < 0:
+                continue
+            body = txt[m.end():end]
+            sym = m.group(1)
+            if sym not in private:
+                continue                                     # a device function, not a kernel
+            name = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.strip()
+            name = name.replace("(anonymous namespace)::", "")
+            mf = [x.start() for x in re.finditer(r"v_mfma", body)]
+            early = [x.start() for x in re.finditer(r"v_accvgpr_read", body) if mf and x.start() < mf[-1]]
+            ops = sorted(set(re.findall(r"v_mfma_\w+", body)))
+            scratch = len(re.findall(r"^\s*scratch_\w+", body, re.M))
+            want = expected_opcode(name)
+            findings = []
+            if early:
+                findings.append("{} accumulator read(s) before the last MFMA".format(len(early)))
+            if want and want not in ops:
+                findings.append("expected {} but the body has {}".format(want, ops or "no MFMA"))
+            if private[sym] > 0 or scratch:
+                findings.append("scratch: private_segment {} B, {} scratch_ instruction(s)".format(private[sym], scratch))
+            rows.append(dict(file=os.path.basename(src), kernel=name, n_mfma=len(mf), early_acc_reads=len(early),
+                             opcodes=ops, scratch_insts=scratch, private_segment=private[sym], expect=want,
+                             findings=findings))
+    return rows
+
 
 def main():
+    rows = lint()
     bad = 0
-    with tempfile.TemporaryDirectory() as tmp:
-        for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
-            out = os.path.join(tmp, os.path.basename(src) + ".s")
-            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-                                   "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wno-unused-function", "-S",
-                                   "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
-            txt = open(out).read()
-            for m in re.finditer(r"^(_Z\w+):[^\n]*\n", txt, re.M):
-                body = txt[m.end():txt.find("s_endpgm", m.end())]
-                mf = [x.start() for x in re.finditer(r"v_mfma", body)]
-                if not mf:
-                    continue
-                early = [x.start() for x in re.finditer(r"v_accvgpr_read", body) if x.start() < mf[-1]]
-                name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
-                name = name.replace("(anonymous namespace)::", "")
-                print("%-84s mfma %4d  accumulator reads before the last mfma: %d" % (name[:84], len(mf), len(early)))
-                bad += bool(early)
+    for r in rows:
+        if r["n_mfma"] or r["findings"]:
+            print("%-84s mfma %4d  %s" % (r["kernel"][:84], r["n_mfma"], "; ".join(r["findings"]) or "ok"))
+        bad += bool(r["findings"])
+    print("{} kernels, {} with findings".format(len(rows), bad))
     print("FAIL" if bad else "ok")
     return 1 if bad else 0
 
