@@ -282,7 +282,7 @@ def main():
             cfg = "configs[1]" if (a.size == 256 and a.batch == 32 and a.dtype == "fp32") else \
                 ("configs[2] shape" if (a.size == 512 and a.batch == 8) else "off-config shape")
             workload_name = "UNet 2D Liver+Tumor {0}x{0}x3 bs={1}/GPU fp32 (BASELINE.json " + cfg + ")"
-        wl = workload_name.format(a.size, a.batch) + ", fwd+bwd+TF-Adam" + ("+RCCL grad all-reduce" if world > 1 else "")
+        wl = workload_name.format(a.size, a.batch) + ", fwd+bwd+TF-Adam" + ("+{} grad all-reduce".format("RCCL" if backend == "nccl" else backend) if world > 1 else "")
         if a.dtype == "bf16":
             wl = wl.replace(" fp32", " bf16-MFMA/fp32-accumulate+storage")
         peak = FP32_PEAK_TFLOPS if a.dtype == "fp32" else BF16_PEAK_TFLOPS
