@@ -251,7 +251,7 @@ class GUNet(base.BaseNet):
                     scope = "{}/Encode/down_conv{}/mod_conv{}".format(nm, i + 1, j)
                     out = None
                     if j == 2 and i < nds:
-                        cat = torch.empty((n, hh, ww, 2 * c), dtype=torch.float32, device=dev)
+                        cat = torch.empty((n, hh, ww, 2 * c), dtype=self.storage_dtype, device=dev)
                         out = ops.alias(cat, 0, (n, hh, ww, c), cat.stride())
                         cats[i] = cat
                     den = None

@@ -142,7 +142,7 @@ class UNet(base.BaseNet):
             for i in range(num_down_samples):
                 s = "{}/Encode{}/Repeat/convolution2d_".format(nm, i + 1)
                 tensor_out = self._conv_unit(tensor_out, s + "1")
-                cat = torch.empty((n, hh, ww, 2 * c), dtype=torch.float32, device=dev)
+                cat = torch.empty((n, hh, ww, 2 * c), dtype=self.storage_dtype, device=dev)
                 skip_view = ops.alias(cat, 0, (n, hh, ww, c), cat.stride())
                 tensor_out = self._conv_unit(tensor_out, s + "2", out=skip_view)
                 self._layers["Encode{:d}".format(i + 1)] = tensor_out

@@ -199,9 +199,25 @@ class BaseNet(object):
 
     @property
     def compute_bf16(self):
-        """--compute_dtype bf16 (not a reference flag; BASELINE.json configs[2]): the 3x3 contractions round their
-        operands to bf16 for the bf16 matrix cores; tensors, statistics, master weights and the optimiser stay fp32."""
-        return str(getattr(self._args, "compute_dtype", "fp32") or "fp32").lower() in ("bf16", "bfloat16")
+        """--compute_dtype (not a reference flag; BASELINE.json configs[2]) as the precision value of include/unetk.h:
+        0 `fp32` (exact fp32 MFMA); 1 `bf16c`: the contractions round their operands to bf16 for the bf16 matrix cores,
+        tensors in HBM stay fp32 (round 1's mode); 2 `bf16`: bf16 matrix cores AND bf16 storage of activations and
+        activation gradients -- configs[2]'s "bf16 activations / weights-compute, fp32 master / accum / stats".
+        Statistics, master weights, weight gradients and the optimiser are fp32 in every mode."""
+        name = str(getattr(self._args, "compute_dtype", "fp32") or "fp32").lower()
+        if name in ("bf16", "bfloat16", "bf16s"):
+            return 2
+        if name in ("bf16c", "bf16_compute"):
+            return 1
+        if name in ("fp32", "float32"):
+            return 0
+        raise ValueError("unknown --compute_dtype {!r} (fp32 | bf16 | bf16c)".format(name))
+
+    @property
+    def storage_dtype(self):
+        """dtype of the activation tensors the network allocates (concat buffers)."""
+        import torch
+        return torch.bfloat16 if self.compute_bf16 == 2 else torch.float32
 
     @property
     def num_classes(self):

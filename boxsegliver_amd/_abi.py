@@ -12,7 +12,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 _LIB = None
 LIB_PATH = os.environ.get("UNETK_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libunetk.so")
 
-ABI_VERSION = 4            # must equal unetk_abi_version() of the loaded library (checked in lib())
+ABI_VERSION = 5            # must equal unetk_abi_version() of the loaded library (checked in lib())
 UNETK_MAX_CLASSES = 8
 W_NONE, W_NUMERICAL, W_PROPORTION, W_PIXELMAP = 0, 1, 2, 3
 
@@ -22,7 +22,7 @@ class ConvDesc(Structure):
                 ("x_stride", c_int32), ("y_stride", c_int32), ("precision", c_int32), ("dilation", c_int32)]
 
 
-FP32, BF16 = 0, 1
+FP32, BF16, BF16S = 0, 1, 2      # BF16S: bf16 arithmetic + bf16 storage of activations (include/unetk.h)
 
 
 class DeconvDesc(Structure):
@@ -43,13 +43,13 @@ class Deconv3dDesc(Structure):
 class NormDesc(Structure):
     _fields_ = [("N", c_int32), ("HW", c_int32), ("C", c_int32), ("per_sample", c_int32), ("z_stride", c_int32),
                 ("guide_ch", c_int32), ("gw_stride", c_int32), ("gw_coff", c_int32), ("affine_only", c_int32),
-                ("guide_leaky", c_int32)]
+                ("guide_leaky", c_int32), ("storage", c_int32)]
 
 
 class HeadDesc(Structure):
     _fields_ = [("N", c_int32), ("HW", c_int32), ("C", c_int32), ("ncls", c_int32),
                 ("weight_mode", c_int32), ("numeric_w", c_float * UNETK_MAX_CLASSES),
-                ("proportion_decay", c_float)]
+                ("proportion_decay", c_float), ("storage", c_int32)]
 
 
 class LitsDesc(Structure):
@@ -64,6 +64,7 @@ _SIGNATURES = {
     "unetk_error_string": (c_char_p, [c_int]),
     "unetk_conv3x3_pack": (c_int, [P, c_int, c_int, P, P, P]),
     "unetk_conv3x3_pack_bf16": (c_int, [P, c_int, c_int, P, P, P]),
+    "unetk_conv3x3_pack_bf16s": (c_int, [P, c_int, c_int, P, P, P]),
     "unetk_conv3x3_stat_rows": (c_int, [POINTER(ConvDesc)]),
     "unetk_conv3x3_fwd": (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
     "unetk_conv3x3_dgrad": (c_int, [POINTER(ConvDesc), P, P, P, P]),
@@ -87,12 +88,15 @@ _SIGNATURES = {
     "unetk_fc_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "unetk_maxpool2_fwd": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, P]),
     "unetk_maxpool2_bwd": (c_int, [P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P]),
+    "unetk_maxpool2_fwd_bf16": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, P]),
+    "unetk_maxpool2_bwd_bf16": (c_int, [P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P]),
     "unetk_avgpool2_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "unetk_image_gradients": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "unetk_sobel_concat": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "unetk_flip_axpy": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     "unetk_deconv2x2_pack": (c_int, [P, c_int, c_int, P, P, P]),
     "unetk_deconv2x2_pack_bf16": (c_int, [P, c_int, c_int, P, P, P]),
+    "unetk_deconv2x2_pack_bf16s": (c_int, [P, c_int, c_int, P, P, P]),
     "unetk_deconv3d_pack_bf16": (c_int, [P, c_int, c_int, c_int, P, P, P]),
     "unetk_deconv2x2_fwd": (c_int, [POINTER(DeconvDesc), P, P, P, P, P]),
     "unetk_deconv2x2_bwd_ws_bytes": (c_size_t, [POINTER(DeconvDesc)]),

@@ -55,8 +55,10 @@ def add_arguments(parser):
     group.add_argument("--dropout", type=float, help="Dropout for backbone networks")
     group.add_argument("--img_grad", action="store_true", help="Use image gradients")
     # not a reference flag: arithmetic of the 3x3 contractions on MI355X (BASELINE.json configs[1] fp32 / configs[2] bf16)
-    group.add_argument("--compute_dtype", type=str, default="fp32", choices=["fp32", "bf16"],
-                       help="fp32: exact fp32 MFMA (default). bf16: bf16 MFMA operands, fp32 accumulate/storage")
+    group.add_argument("--compute_dtype", type=str, default="fp32", choices=["fp32", "bf16", "bf16c"],
+                       help="fp32: exact fp32 MFMA (default). bf16: bf16 MFMA + bf16 storage of activations / activation "
+                            "gradients, fp32 accumulate / statistics / master weights. bf16c: bf16 MFMA operands only, "
+                            "fp32 storage")
     group.add_argument("--mid_cat", action="store_true", help="Concat guide to middle layers")
 
 

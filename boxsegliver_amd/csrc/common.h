@@ -36,6 +36,31 @@ __device__ __forceinline__ int mfma32_row(int r, int h) { return (r & 3) + 8 * (
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void stg4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// ---- bf16 storage (UNETK_BF16S): activations / activation gradients live in HBM as bf16 (uint16_t bit patterns),
+// arithmetic stays fp32.  ld4 / st4 move FOUR consecutive channels: a float4 (16 B) or four bf16 (8 B).
+typedef uint16_t bf16_t;
+__device__ __forceinline__ uint32_t unetk_pk_bf16(float lo, float hi) {   // RNE, lo in bits 0..15
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ float unetk_bf16_lo(uint32_t v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float unetk_bf16_hi(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  return make_float4(unetk_bf16_lo(v.x), unetk_bf16_hi(v.x), unetk_bf16_lo(v.y), unetk_bf16_hi(v.y));
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(unetk_pk_bf16(v.x, v.y), unetk_pk_bf16(v.z, v.w));
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return __uint_as_float((uint32_t)*p << 16); }
+// values a bf16 store would keep (for statistics / column sums that must see what memory holds)
+__device__ __forceinline__ float unetk_round_bf16(float v) { return unetk_bf16_lo(unetk_pk_bf16(v, 0.f)); }
+static inline bool unetk_aligned8(const void* p) { return (((uintptr_t)p) & 7u) == 0; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -73,7 +98,9 @@ struct ConvParams {
   int tiles_h, tiles_w, n_ntiles, stat_rows;
   ImgAddr xa, ya;
   int accumulate;                    // epilogue: y += acc (depth taps of a 3-D conv), statistics on the sum
-  int bf16;                          // operands rounded to bf16 for v_mfma_f32_32x32x16_bf16 (wp = bf16 K8 pack)
+  int bf16;                          // UNETK_BF16: operands rounded to bf16 for v_mfma_f32_32x32x16_bf16 (wp = bf16 K8 pack);
+                                     // UNETK_BF16S: x and y ARE bf16 in memory (wp = the channel-pair-permuted pack)
+  int ybf16;                         // direct kernel only: y is stored as bf16 (UNETK_BF16S first layer, fp32 input)
   int spg;                           // planes per statistics group (a 3-D sample's depth planes); 0/1 = every plane
   int lin_pix;                       // conv_igemm_lin.hip: padded pixels a block may stage (sizes its LDS)
   int stride;                        // 2: TF SAME stride-2 conv; H x W = OUTPUT extent and the four fields below are set
@@ -120,6 +147,9 @@ struct WgParams {
 // conv_wgrad.hip: dw[9][Cin][Cout] = filter gradient of one 2-D tap plane; ws layout as unetk_conv3x3_wgrad
 size_t unetk_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
+// conv_wgrad_bf16s.hip: UNETK_BF16S -- x and dy are bf16 in memory (x fp32 for the first layer, 9 * Cin <= 32)
+size_t unetk_wgrad_bf16s_ws_bytes(int N, int H, int W, int Cin, int Cout);
+int unetk_wgrad_bf16s_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
 // stride-2 variant (p.stride == 2; p.H, p.W = output plane): fp32, Cin % 32 == 0 and Cout % 64 == 0
 bool unetk_wgrad_strided_ok(int Cin, int Cout);
 size_t unetk_wgrad_strided_ws_bytes(int N, int Ho, int Wo, int Cin, int Cout);

@@ -242,7 +242,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
 // taps live in registers and the 10x18xCIN input halo in LDS (read as broadcasts by the Cout/4 threads of a pixel): the
 // first version re-read both through L1 per pixel and ran at 0.9 TB/s of output, VALU / L1-issue bound.
 // CIN = 0: generic fallback (any Cin, filters through L1).
-template <int CIN>
+// TY = bf16_t: UNETK_BF16S -- the output is stored as bf16 (statistics still from the fp32 sums); the input stays fp32.
+template <int CIN, typename TY = float>
 __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [max(180 * cin, 2 * PL * Cout)]
   const int cin = CIN > 0 ? CIN : p.Cin;
@@ -297,12 +298,12 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvParams p) {
           }
         }
       }
-      float* yp = p.y + p.ya.off(n_img) + ((int64_t)gh * p.W + gw) * p.ys + cq * 4;
+      TY* yp = reinterpret_cast<TY*>(p.y) + p.ya.off(n_img) + ((int64_t)gh * p.W + gw) * p.ys + cq * 4;
       if (p.accumulate) {
-        const float4 o = ldg4(yp);
+        const float4 o = ld4(yp);
         a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
       }
-      stg4(yp, a);
+      st4(yp, a);
       s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
       sq.x += a.x * a.x; sq.y += a.y * a.y; sq.z += a.z * a.z; sq.w += a.w * a.w;
     }
@@ -471,6 +472,19 @@ int unetk_conv_run(ConvParams p, hipStream_t st) {
   const size_t halo = (size_t)180 * p.Cin * sizeof(float);
   if (halo > lds) lds = halo;
   if (lds > 64 * 1024) return UNETK_E_UNSUPPORTED;
+  if (p.ybf16) {      // UNETK_BF16S first layer: fp32 image in, bf16 out
+    if (p.accumulate) return UNETK_E_UNSUPPORTED;
+    switch (p.Cin) {
+      case 1: hipLaunchKernelGGL((conv3x3_direct_kernel<1, bf16_t>), dim3(n_mtiles), dim3(256), lds, st, p); break;
+      case 2: hipLaunchKernelGGL((conv3x3_direct_kernel<2, bf16_t>), dim3(n_mtiles), dim3(256), lds, st, p); break;
+      case 3: hipLaunchKernelGGL((conv3x3_direct_kernel<3, bf16_t>), dim3(n_mtiles), dim3(256), lds, st, p); break;
+      case 4: hipLaunchKernelGGL((conv3x3_direct_kernel<4, bf16_t>), dim3(n_mtiles), dim3(256), lds, st, p); break;
+      case 5: hipLaunchKernelGGL((conv3x3_direct_kernel<5, bf16_t>), dim3(n_mtiles), dim3(256), lds, st, p); break;
+      default: hipLaunchKernelGGL((conv3x3_direct_kernel<0, bf16_t>), dim3(n_mtiles), dim3(256), lds, st, p); break;
+    }
+    UNETK_LAUNCH_CHECK();
+    return UNETK_OK;
+  }
   switch (p.Cin) {
     case 1: hipLaunchKernelGGL(conv3x3_direct_kernel<1>, dim3(n_mtiles), dim3(256), lds, st, p); break;
     case 2: hipLaunchKernelGGL(conv3x3_direct_kernel<2>, dim3(n_mtiles), dim3(256), lds, st, p); break;
@@ -509,10 +523,12 @@ extern "C" int unetk_conv3x3_stat_rows(const unetk_conv_desc* d) {
   if (!conv_desc_ok(d)) return UNETK_E_BADARG;
   if (d->dilation == 2) return unetk_conv_stat_rows(d->N, d->H, d->W, d->Cin, d->Cout, 1, 1, 2);
   if (d->precision == UNETK_BF16) return unetk_conv_stat_rows_bf16(d->N, d->H, d->W, d->Cin, d->Cout);
+  if (d->precision == UNETK_BF16S && unetk_conv_bf16_ok(d->Cin, d->Cout))
+    return unetk_conv_stat_rows_bf16(d->N, d->H, d->W, d->Cin, d->Cout);
   return unetk_conv_stat_rows(d->N, d->H, d->W, d->Cin, d->Cout);
 }
 
-extern "C" int unetk_conv3x3_fwd(const unetk_conv_desc* d, const float* x, const float* w, float* y,
+extern "C" int unetk_conv3x3_fwd(const unetk_conv_desc* d, const void* x, const void* w, void* y,
                                  float* stat_partials, void* stream) {
   UNETK_REQUIRE(conv_desc_ok(d) && x && w && y);
   UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(w) && unetk_aligned16(y));
@@ -520,8 +536,14 @@ extern "C" int unetk_conv3x3_fwd(const unetk_conv_desc* d, const float* x, const
   if (pick_cfg(d->Cin, d->Cout).id >= 0) UNETK_REQUIRE(d->x_stride % 4 == 0);
   if (d->precision == UNETK_BF16 && !unetk_conv_bf16_ok(d->Cin, d->Cout)) return UNETK_E_UNSUPPORTED;
   ConvParams p{};
-  p.bf16 = d->precision == UNETK_BF16;
-  p.x = x; p.wp = w; p.y = y; p.stat = stat_partials;
+  p.bf16 = d->precision == UNETK_BF16 ? 1 : 0;
+  if (d->precision == UNETK_BF16S) {
+    if (d->dilation > 1) return UNETK_E_UNSUPPORTED;
+    if (unetk_conv_bf16_ok(d->Cin, d->Cout)) p.bf16 = UNETK_BF16S;         // bf16 in, bf16 out (igemm on the bf16 matrix cores)
+    else if (pick_cfg(d->Cin, d->Cout).id < 0) p.ybf16 = 1;                // first layer: fp32 image in, bf16 out (direct kernel)
+    else return UNETK_E_UNSUPPORTED;
+  }
+  p.x = (const float*)x; p.wp = (const float*)w; p.y = (float*)y; p.stat = stat_partials;
   p.dil = d->dilation;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.xs = d->x_stride; p.ys = d->y_stride;
   p.xa = unetk_dense_addr(p.H, p.W, p.xs);
@@ -529,17 +551,18 @@ extern "C" int unetk_conv3x3_fwd(const unetk_conv_desc* d, const float* x, const
   return unetk_conv_run(p, (hipStream_t)stream);
 }
 
-extern "C" int unetk_conv3x3_dgrad(const unetk_conv_desc* d, const float* dy, const float* w, float* dx,
+extern "C" int unetk_conv3x3_dgrad(const unetk_conv_desc* d, const void* dy, const void* w, void* dx,
                                    void* stream) {
   UNETK_REQUIRE(conv_desc_ok(d) && dy && w && dx);
   UNETK_REQUIRE(unetk_aligned16(dy) && unetk_aligned16(w) && unetk_aligned16(dx));
   // dgrad = conv3x3 with Cin <-> Cout on the packed, tap-flipped filters
   if (pick_cfg(d->Cout, d->Cin).id < 0) return UNETK_E_UNSUPPORTED;
   UNETK_REQUIRE(d->x_stride % 4 == 0 && d->y_stride % 4 == 0);
-  if (d->precision == UNETK_BF16 && !unetk_conv_bf16_ok(d->Cout, d->Cin)) return UNETK_E_UNSUPPORTED;
+  if (d->precision != UNETK_FP32 && !unetk_conv_bf16_ok(d->Cout, d->Cin)) return UNETK_E_UNSUPPORTED;
+  if (d->precision == UNETK_BF16S && d->dilation > 1) return UNETK_E_UNSUPPORTED;
   ConvParams p{};
-  p.bf16 = d->precision == UNETK_BF16;
-  p.x = dy; p.wp = w; p.y = dx; p.stat = nullptr;
+  p.bf16 = d->precision;                    // UNETK_FP32 / UNETK_BF16 / UNETK_BF16S (dy and dx are bf16)
+  p.x = (const float*)dy; p.wp = (const float*)w; p.y = (float*)dx; p.stat = nullptr;
   p.dil = d->dilation;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cout; p.Cout = d->Cin; p.xs = d->y_stride; p.ys = d->x_stride;
   p.xa = unetk_dense_addr(p.H, p.W, p.xs);

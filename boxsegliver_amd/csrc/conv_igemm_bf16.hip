@@ -12,11 +12,20 @@
 //     kernel is the L2 -> LDS stream (halo + the nine filter panels of the chunk), which scales as 1/BM for the
 //     filters and 1/BN for the halo: hence the tall 512 x 128 block tile (8 waves, 4 x 2 MFMA tiles per wave).
 // Statistics for the following norm come from the fp32 accumulators, as in the fp32 kernel.
+//
+// BS = true is UNETK_BF16S ("bf16 storage"): x is already bf16 in HBM (the halo is copied, not converted: half the
+// staging bytes) and y is written as bf16.  So that a lane can store TWO adjacent output channels as one 4-byte word
+// (a half-wave then writes 128 contiguous bytes per pixel instead of two 64-byte pieces), the filter pack of this mode
+// (unetk_conv3x3_pack_bf16s) permutes the output channels inside every 64-channel block: MFMA column l of tile tn holds
+// channel 2 l + tn.
 #include "common.h"
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// 16-byte register staging uses the NATIVE vector type: an array of HIP's uint4 (a struct of unions) is not always
+// promoted to registers by SROA -- two-element arrays ended up in scratch (found by tools/asm_lint.py)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CKB = 32;  // input channels per K-chunk
 constexpr int PSQ = 5;   // LDS pixel stride in 16-B units: 64 B of bf16 + 16 B pad -> conflict-free ds_read_b128
@@ -29,8 +38,9 @@ __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
   return r;
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool BS = false>
 __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvParams p) {
+  static_assert(!BS || TN == 2, "bf16 storage packs channel pairs (tile 0 / tile 1) into one word");
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int TH = BM / TW, HH = TH + 2;
@@ -82,12 +92,21 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
     woff[r] = q * p.Cout + n0 + n;
   }
 
-  float4 hreg[HR][2];
-  uint4 wreg[WR];
+  float4 hreg[BS ? 1 : HR][2];
+  u32x4 hq[BS ? HR : 1];
+  u32x4 wreg[WR];
+  const bf16_t* xb = reinterpret_cast<const bf16_t*>(p.x);
+  if constexpr (BS) {   // out-of-image items read the tensor's first bytes (always mapped) and are zeroed by a select: no
+#pragma unroll          // per-thread branch around the loads for the compiler to unswitch the main loop on
+    for (int r = 0; r < HR; ++r) hoff[r] = hok[r] ? hoff[r] : 0;
+  }
   auto load_halo = [&](int c) {
 #pragma unroll
     for (int r = 0; r < HR; ++r) {
-      if (hok[r]) {
+      if constexpr (BS) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(xb + hoff[r] + c * CKB);
+        hq[r] = hok[r] ? v : u32x4{0u, 0u, 0u, 0u};
+      } else if (hok[r]) {
         hreg[r][0] = ldg4(p.x + hoff[r] + c * CKB);
         hreg[r][1] = ldg4(p.x + hoff[r] + c * CKB + 4);
       } else {
@@ -99,24 +118,28 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
 #pragma unroll
     for (int r = 0; r < HR; ++r)
       if (hlds[r] >= 0) {
-        uint4 v;
-        v.x = pk_bf16(hreg[r][0].x, hreg[r][0].y);
-        v.y = pk_bf16(hreg[r][0].z, hreg[r][0].w);
-        v.z = pk_bf16(hreg[r][1].x, hreg[r][1].y);
-        v.w = pk_bf16(hreg[r][1].z, hreg[r][1].w);
-        halo[buf * HALO_Q + hlds[r]] = v;
+        u32x4 v;
+        if constexpr (BS) {
+          v = hq[r];
+        } else {
+          v.x = pk_bf16(hreg[r][0].x, hreg[r][0].y);
+          v.y = pk_bf16(hreg[r][0].z, hreg[r][0].w);
+          v.z = pk_bf16(hreg[r][1].x, hreg[r][1].y);
+          v.w = pk_bf16(hreg[r][1].z, hreg[r][1].w);
+        }
+        *reinterpret_cast<u32x4*>(&halo[buf * HALO_Q + hlds[r]]) = v;
       }
   };
   auto load_w = [&](int c, int t) {
     const uint4* base = wq + ((int64_t)t * cin8 + c * (CKB / 8)) * p.Cout;
 #pragma unroll
     for (int r = 0; r < WR; ++r)
-      if (tid + r * NT < WB_Q) wreg[r] = base[woff[r]];
+      if (tid + r * NT < WB_Q) wreg[r] = *reinterpret_cast<const u32x4*>(base + woff[r]);
   };
   auto store_w = [&](int buf) {
 #pragma unroll
     for (int r = 0; r < WR; ++r)
-      if (tid + r * NT < WB_Q) wbuf[buf * WB_Q + tid + r * NT] = wreg[r];
+      if (tid + r * NT < WB_Q) *reinterpret_cast<u32x4*>(&wbuf[buf * WB_Q + tid + r * NT]) = wreg[r];
   };
 
   int abase[TM];
@@ -143,15 +166,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
   store_w(0);
   __syncthreads();
 
+  // The prefetches are UNCONDITIONAL (the last chunk re-fetches itself / tap 0 into the free buffers, never read): with
+  // `if (more_chunks)` guards the compiler peeled the last chunk out of the loop and shuttled accumulators between
+  // AGPRs and VGPRs around the peeled copy (tools/asm_lint.py: accumulator reads before the last MFMA).
   int step = 0;
   for (int c = 0; c < nchunks; ++c) {
     const uint4* hb = halo + (c & 1) * HALO_Q;
-    const bool more_chunks = (c + 1 < nchunks);
+    const int cn = min(c + 1, nchunks - 1);
 #pragma unroll
     for (int t = 0; t < 9; ++t, ++step) {
-      const bool has_next = (t < 8) || more_chunks;
-      if (has_next) load_w(t < 8 ? c : c + 1, t < 8 ? t + 1 : 0);
-      if (t == 0 && more_chunks) load_halo(c + 1);   // HBM latency >> one tap step: a whole chunk of slack
+      load_w(t < 8 ? c : cn, t < 8 ? t + 1 : 0);
+      if (t == 0) load_halo(cn);                     // HBM latency >> one tap step: a whole chunk of slack
 
       const uint4* wb = wbuf + (step & 1) * WB_Q;
       const int toff = ((t / 3) * HWD + (t % 3)) * PSQ;
@@ -170,8 +195,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
                                                                   __builtin_bit_cast(bf16x8, b[tn]), acc[tm][tn], 0, 0, 0);
       }
 
-      if (has_next) store_w((step + 1) & 1);
-      if (t == 8 && more_chunks) store_halo((c + 1) & 1);
+      store_w((step + 1) & 1);
+      if (t == 8) store_halo((c + 1) & 1);
       __syncthreads();
     }
   }
@@ -188,6 +213,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
       const int i = mfma32_row(r, h);
       const int gh = h0 + 2 * sub + (i >> 4), gw = w0 + (i & 15);
       if (gh < p.H && gw < p.W) {
+        if constexpr (BS) {   // channels (2 l31, 2 l31 + 1) of this wave's 64-channel block: one 4-byte store
+          bf16_t* yb = reinterpret_cast<bf16_t*>(p.y) + yimg + ((int64_t)gh * p.W + gw) * p.ys + n0 + wn * 64 + 2 * l31;
+          const float v0 = acc[tm][0][r], v1 = acc[tm][TN - 1][r];
+          *reinterpret_cast<uint32_t*>(yb) = pk_bf16(v0, v1);
+          ssum[0] += v0; ssq[0] += v0 * v0;
+          ssum[TN - 1] += v1; ssq[TN - 1] += v1 * v1;
+          continue;
+        }
         float* yp = p.y + yimg + ((int64_t)gh * p.W + gw) * p.ys + n0 + wn * TN * 32 + l31;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
@@ -217,7 +250,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
       float s = 0.f;
 #pragma unroll
       for (int m = 0; m < WM; ++m) s += red[(k * WM + m) * BN + n];
-      p.stat[((int64_t)k * p.stat_rows + mtile) * p.Cout + n0 + n] = s;
+      const int nc = BS ? (n & ~63) + 2 * (n & 31) + ((n >> 5) & 1) : n;    // tile position -> channel
+      p.stat[((int64_t)k * p.stat_rows + mtile) * p.Cout + n0 + nc] = s;
     }
   }
 }
@@ -225,12 +259,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
 // Filter re-layout + rounding.  K8-interleaved panel: wp[t][q][n][j] = bf16(B_t[k = 8q + j][n]).
 //   forward : B_t[k = ci][n = co] = w[t][ci][co]
 //   dgrad   : B_t[k = co][n = ci] = w[8 - t][ci][co]
+// perm (UNETK_BF16S): column position n' of every 64-column block holds output channel 2 (n' & 31) + (n' >> 5 & 1).
 __global__ void pack_conv3x3_bf16_kernel(const float* __restrict__ w, int Cin, int Cout, uint4* __restrict__ wp_fwd,
-                                         uint4* __restrict__ wp_dgrad) {
+                                         uint4* __restrict__ wp_dgrad, int perm) {
   const int64_t total = (int64_t)9 * Cin * Cout / 8;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     if (wp_fwd != nullptr) {
-      const int n = (int)(i % Cout);
+      int n = (int)(i % Cout);
+      if (perm) n = (n & ~63) + 2 * (n & 31) + ((n >> 5) & 1);
       const int64_t r = i / Cout;
       const int q = (int)(r % (Cin / 8));
       const int t = (int)(r / (Cin / 8));
@@ -244,7 +280,8 @@ __global__ void pack_conv3x3_bf16_kernel(const float* __restrict__ w, int Cin, i
       wp_fwd[i] = v;
     }
     if (wp_dgrad != nullptr) {
-      const int n = (int)(i % Cin);
+      int n = (int)(i % Cin);
+      if (perm) n = (n & ~63) + 2 * (n & 31) + ((n >> 5) & 1);
       const int64_t r = i / Cin;
       const int q = (int)(r % (Cout / 8));
       const int t = (int)(r / (Cout / 8));
@@ -277,14 +314,14 @@ inline BfCfg pick_bf16(int H, int Cin, int Cout, int N = 1 << 20, int W = 1 << 1
   return {4, 16};
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool BS = false>
 int launch_bf16(const ConvParams& p, int n_mtiles, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int TH = BM / TW;
   constexpr size_t lds = (size_t)(2 * (TH + 2) * HWD * PSQ + 2 * (CKB / 8) * BN) * 16;
   static_assert(lds >= 2 * WM * BN * sizeof(float), "stat scratch must fit");
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = conv3x3_igemm_bf16_kernel<WM, WN, TM, TN>;
+  auto kern = conv3x3_igemm_bf16_kernel<WM, WN, TM, TN, BS>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -309,6 +346,20 @@ int unetk_conv_stat_rows_bf16(int N, int H, int W, int Cin, int Cout) {
 int unetk_conv_run_bf16(ConvParams p, hipStream_t st) {
   const BfCfg cfg = pick_bf16(p.H, p.Cin, p.Cout, p.N, p.W);
   if (cfg.id < 0) return UNETK_E_UNSUPPORTED;
+  if (p.bf16 == UNETK_BF16S) {   // bf16 storage: 16-B halo pieces of 8 channels, 4-B output words of 2 channels
+    if (cfg.id == 4 || p.accumulate) return UNETK_E_UNSUPPORTED;     // Cout % 64 != 0 / 3-D depth taps: not in this mode
+    if (p.xs % 8 != 0 || p.ys % 2 != 0) return UNETK_E_BADARG;
+    p.tiles_h = (p.H + cfg.th - 1) / cfg.th;
+    p.tiles_w = (p.W + TW - 1) / TW;
+    const int n_mt = p.N * p.tiles_h * p.tiles_w;
+    p.stat_rows = n_mt;
+    switch (cfg.id) {
+      case 0: p.n_ntiles = p.Cout / 128; return launch_bf16<4, 2, 4, 2, true>(p, n_mt, st);
+      case 1: p.n_ntiles = p.Cout / 128; return launch_bf16<2, 2, 2, 2, true>(p, n_mt, st);
+      case 2: p.n_ntiles = p.Cout / 64; return launch_bf16<4, 1, 2, 2, true>(p, n_mt, st);
+      default: p.n_ntiles = p.Cout / 64; return launch_bf16<4, 1, 1, 2, true>(p, n_mt, st);
+    }
+  }
   if (p.xs % 4 != 0) return UNETK_E_BADARG;
   p.tiles_h = (p.H + cfg.th - 1) / cfg.th;
   p.tiles_w = (p.W + TW - 1) / TW;
@@ -331,7 +382,20 @@ extern "C" int unetk_conv3x3_pack_bf16(const float* w_hwio, int Cin, int Cout, v
   const int64_t total = (int64_t)9 * Cin * Cout / 8;
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(pack_conv3x3_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_hwio, Cin, Cout,
-                     (uint4*)wp_fwd, (uint4*)wp_dgrad);
+                     (uint4*)wp_fwd, (uint4*)wp_dgrad, 0);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+extern "C" int unetk_conv3x3_pack_bf16s(const float* w_hwio, int Cin, int Cout, void* wp_fwd, void* wp_dgrad,
+                                        void* stream) {
+  UNETK_REQUIRE(w_hwio && Cin > 0 && Cout > 0 && (wp_fwd || wp_dgrad));
+  if (Cin % 64 != 0 || Cout % 64 != 0) return UNETK_E_UNSUPPORTED;     // the channel-pair permutation works on 64-blocks
+  UNETK_REQUIRE((!wp_fwd || unetk_aligned16(wp_fwd)) && (!wp_dgrad || unetk_aligned16(wp_dgrad)));
+  const int64_t total = (int64_t)9 * Cin * Cout / 8;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_conv3x3_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_hwio, Cin, Cout,
+                     (uint4*)wp_fwd, (uint4*)wp_dgrad, 1);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }

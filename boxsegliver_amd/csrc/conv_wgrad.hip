@@ -640,15 +640,27 @@ int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_
 
 extern "C" size_t unetk_conv3x3_wgrad_ws_bytes(const unetk_conv_desc* d) {
   if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return 0;
+  if (d->precision == UNETK_BF16S) return unetk_wgrad_bf16s_ws_bytes(d->N, d->H, d->W, d->Cin, d->Cout);
   return unetk_wgrad_ws_bytes(d->N, d->H, d->W, d->Cin, d->Cout);
 }
 
-extern "C" int unetk_conv3x3_wgrad(const unetk_conv_desc* d, const float* x, const float* dy, float* dw,
+extern "C" int unetk_conv3x3_wgrad(const unetk_conv_desc* d, const void* xv, const void* dyv, float* dw,
                                    void* ws, size_t ws_bytes, void* stream) {
+  const float* x = (const float*)xv;
+  const float* dy = (const float*)dyv;
   UNETK_REQUIRE(d && x && dy && dw && ws);
   UNETK_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0);
   UNETK_REQUIRE(d->x_stride >= d->Cin && d->y_stride >= d->Cout);
   UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(dy) && unetk_aligned16(dw) && unetk_aligned16(ws));
+  if (d->precision == UNETK_BF16S) {        // x and dy are bf16 (x fp32 for the first layer); stride 1, dense taps only
+    if (d->dilation > 1) return UNETK_E_UNSUPPORTED;
+    WgParams q{};
+    q.x = x; q.dy = dy;
+    q.N = d->N; q.H = d->H; q.W = d->W; q.Cin = d->Cin; q.Cout = d->Cout; q.xs = d->x_stride; q.ys = d->y_stride;
+    q.xa = unetk_dense_addr(q.H, q.W, q.xs);
+    q.ya = unetk_dense_addr(q.H, q.W, q.ys);
+    return unetk_wgrad_bf16s_run(q, dw, ws, ws_bytes, (hipStream_t)stream);
+  }
   WgParams p{};
   p.x = x; p.dy = dy;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.xs = d->x_stride; p.ys = d->y_stride;

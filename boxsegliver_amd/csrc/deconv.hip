@@ -91,6 +91,57 @@ __device__ __forceinline__ void pw_epilogue(const PwParams& p, f32x16 (&acc)[TM]
   }
 }
 
+// UNETK_BF16S epilogue: the output is bf16 and the filter pack of this mode permutes the GEMM columns inside every
+// 64-column block (MFMA column l of tile tn = column 2 l + tn), so a lane owns two ADJACENT columns and stores them as
+// one 4-byte word: a half-wave writes 128 contiguous bytes per row.  Forward: bias + ReLU + scatter; dgrad: plain rows.
+template <int MODE, int TM>
+__device__ __forceinline__ void pw_epilogue_bf16s(const PwParams& p, f32x16 (&acc)[TM][2], int m0, int n0, int wm, int wn,
+                                                  int l31, int h) {
+  bf16_t* outb = reinterpret_cast<bf16_t*>(p.out);
+  const int n = n0 + wn * 64 + 2 * l31;                      // this lane's column pair (n, n + 1)
+  if (MODE == 0) {
+    const int ab = n / p.Cout, co = n - ab * p.Cout;         // Cout % 64 == 0: the pair shares a tap
+    const float b0 = p.bias ? p.bias[co] : 0.f, b1 = p.bias ? p.bias[co + 1] : 0.f;
+    const int64_t tapoff = ((int64_t)(ab >> 1) * 2 * p.W + (ab & 1)) * p.out_stride + p.out_coff + co;
+    const int HW = p.H * p.W;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int mb = m0 + (wm * TM + tm) * 32 + 4 * h;
+      int nn = mb / HW;
+      const int rem = mb - nn * HW;
+      int yy = rem / p.W, xx = rem - yy * p.W;
+      int64_t img = p.oa.off(nn);
+      int prev = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int delta = (r & 3) + 8 * (r >> 2);
+        xx += delta - prev;
+        prev = delta;
+        while (xx >= p.W) {
+          xx -= p.W;
+          if (++yy == p.H) {
+            yy = 0;
+            img = p.oa.off(++nn);
+          }
+        }
+        if (mb + delta >= p.M) break;
+        const int64_t ob = img + ((int64_t)(2 * yy) * 2 * p.W + 2 * xx) * p.out_stride;
+        *reinterpret_cast<uint32_t*>(outb + ob + tapoff) =
+            unetk_pk_bf16(fmaxf(acc[tm][0][r] + b0, 0.f), fmaxf(acc[tm][1][r] + b1, 0.f));
+      }
+    }
+  } else {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + tm) * 32 + mfma32_row(r, h);
+        if (m >= p.M) continue;
+        *reinterpret_cast<uint32_t*>(outb + (int64_t)m * p.Ncols + n) = unetk_pk_bf16(acc[tm][0][r], acc[tm][1][r]);
+      }
+  }
+}
+
 // MODE 0: forward (scatter epilogue), MODE 1: dgrad (gather prologue)
 template <int MODE, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(WM* WN * 64) void pw_gemm_kernel(PwParams p) {
@@ -228,6 +279,7 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_gemm_kernel(PwParams p) {
 // K8-interleaved [K/8][Ncols][8] (B), v_mfma_f32_32x32x16_bf16, fp32 accumulate; K chunk = 32.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int CKB = 32, PSQ = 5;   // LDS row stride in 16-B units: 64 B of bf16 + 16 B pad
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // native 16-B register type (see conv_igemm_bf16.hip)
 
 __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
   uint32_t r;
@@ -235,8 +287,10 @@ __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
   return r;
 }
 
-template <int MODE, int WM, int WN, int TM, int TN>
+// BS = UNETK_BF16S: the A operand is already bf16 in memory (copied, not converted) and the output is bf16.
+template <int MODE, int WM, int WN, int TM, int TN, bool BS = false>
 __global__ __launch_bounds__(WM* WN * 64) void pw_gemm_bf16_kernel(PwParams p) {
+  static_assert(!BS || TN == 2, "bf16 storage stores column pairs");
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int A_Q = BM * PSQ, WB_Q = CKB / 8 * BN;
@@ -283,8 +337,14 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_gemm_bf16_kernel(PwParams p) {
     woff[r] = q * p.Ncols + n0 + n;
   }
 
-  float4 areg[AR][2];
-  uint4 wreg[WR];
+  float4 areg[BS ? 1 : AR][2];
+  u32x4 aq[BS ? AR : 1];
+  u32x4 wreg[WR];
+  if constexpr (BS) {   // rows past M read the tensor's first bytes and are zeroed by a select (no branch around the loads)
+#pragma unroll
+    for (int r = 0; r < AR; ++r) aoff[r] = aok[r] ? aoff[r] : 0;
+  }
+  const bf16_t* ab16 = reinterpret_cast<const bf16_t*>(p.a);
   auto load_a = [&](int s) {
     int64_t koff;
     if (MODE == 0) {
@@ -296,7 +356,10 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_gemm_bf16_kernel(PwParams p) {
     }
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
-      if (aok[r]) {
+      if constexpr (BS) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(ab16 + aoff[r] + koff);
+        aq[r] = aok[r] ? v : u32x4{0u, 0u, 0u, 0u};
+      } else if (aok[r]) {
         areg[r][0] = ldg4(p.a + aoff[r] + koff);
         areg[r][1] = ldg4(p.a + aoff[r] + koff + 4);
       } else {
@@ -308,22 +371,26 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_gemm_bf16_kernel(PwParams p) {
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
       const int idx = tid + r * NT;
-      uint4 v;
-      v.x = pk_bf16(areg[r][0].x, areg[r][0].y);
-      v.y = pk_bf16(areg[r][0].z, areg[r][0].w);
-      v.z = pk_bf16(areg[r][1].x, areg[r][1].y);
-      v.w = pk_bf16(areg[r][1].z, areg[r][1].w);
-      abuf[buf * A_Q + (idx >> 2) * PSQ + (idx & 3)] = v;
+      u32x4 v;
+      if constexpr (BS) {
+        v = aq[r];
+      } else {
+        v.x = pk_bf16(areg[r][0].x, areg[r][0].y);
+        v.y = pk_bf16(areg[r][0].z, areg[r][0].w);
+        v.z = pk_bf16(areg[r][1].x, areg[r][1].y);
+        v.w = pk_bf16(areg[r][1].z, areg[r][1].w);
+      }
+      *reinterpret_cast<u32x4*>(&abuf[buf * A_Q + (idx >> 2) * PSQ + (idx & 3)]) = v;
     }
   };
   auto load_w = [&](int s) {
     const uint4* base = wq + (int64_t)s * (CKB / 8) * p.Ncols;
 #pragma unroll
-    for (int r = 0; r < WR; ++r) wreg[r] = base[woff[r]];
+    for (int r = 0; r < WR; ++r) wreg[r] = *reinterpret_cast<const u32x4*>(base + woff[r]);
   };
   auto store_w = [&](int buf) {
 #pragma unroll
-    for (int r = 0; r < WR; ++r) wbuf[buf * WB_Q + tid + r * NT] = wreg[r];
+    for (int r = 0; r < WR; ++r) *reinterpret_cast<u32x4*>(&wbuf[buf * WB_Q + tid + r * NT]) = wreg[r];
   };
 
   int abase[TM];
@@ -374,12 +441,15 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_gemm_bf16_kernel(PwParams p) {
     __syncthreads();
   }
 
-  pw_epilogue<MODE, TM, TN>(p, acc, m0, n0, wm, wn, l31, h);
+  if constexpr (BS) pw_epilogue_bf16s<MODE, TM>(p, acc, m0, n0, wm, wn, l31, h);
+  else pw_epilogue<MODE, TM, TN>(p, acc, m0, n0, wm, wn, l31, h);
 }
 
 // dpre[pix][co] = dcat[pix][coff+co] * (cat[pix][coff+co] > 0); partial[blk][co] = column sums (bias grad)
-__global__ __launch_bounds__(256) void relu_bwd_bias_kernel(const float* __restrict__ cat, const float* __restrict__ dcat,
-                                                            int stride, int coff, float* __restrict__ dpre,
+// T = bf16_t (UNETK_BF16S): cat, dcat and dpre are bf16; dcat * mask is exact in bf16, the column sums are fp32.
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_bias_kernel(const T* __restrict__ cat, const T* __restrict__ dcat,
+                                                            int stride, int coff, T* __restrict__ dpre,
                                                             float* __restrict__ partial, int64_t npix, int C, int cq_n,
                                                             int rpi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [rpi][C]
@@ -387,14 +457,14 @@ __global__ __launch_bounds__(256) void relu_bwd_bias_kernel(const float* __restr
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (rl < rpi) {
     for (int64_t pix = (int64_t)blockIdx.x * rpi + rl; pix < npix; pix += (int64_t)gridDim.x * rpi) {
-      const float4 v = ldg4(cat + pix * stride + coff + cq * 4);
-      const float4 d = ldg4(dcat + pix * stride + coff + cq * 4);
+      const float4 v = ld4(cat + pix * stride + coff + cq * 4);
+      const float4 d = ld4(dcat + pix * stride + coff + cq * 4);
       float4 o;
       o.x = v.x > 0.f ? d.x : 0.f;
       o.y = v.y > 0.f ? d.y : 0.f;
       o.z = v.z > 0.f ? d.z : 0.f;
       o.w = v.w > 0.f ? d.w : 0.f;
-      stg4(dpre + pix * C + cq * 4, o);
+      st4(dpre + pix * C + cq * 4, o);
       s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
     }
     stg4(&smem[rl * C + cq * 4], s);
@@ -522,6 +592,100 @@ __global__ __launch_bounds__(256) void deconv_wgrad_kernel(DwParams p) {
   }
 }
 
+// UNETK_BF16S filter gradient: dpre and x are bf16 in memory; their 128-pixel x 64-channel tiles stay bf16 in LDS
+// ([pixel][64 channels], 128-byte rows, 16-byte chunks XOR-swizzled by bit 1 of the row as in conv_wgrad_bf16s.hip) and
+// both k-strided MFMA operands come out of the LDS transpose path: 4 ds_read_b64_tr_b16 per 32x32x16 MFMA instead of the
+// 16 ds_read_b32 + 8 conversions of the fp32-storage variant.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+__device__ __forceinline__ uint2 tr_read(const char* base, int byte_off) {
+  return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + byte_off)));
+}
+
+__global__ __launch_bounds__(256) void deconv_wgrad_bf16s_kernel(DwParams p) {
+  constexpr int KT = 128, CT = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  char* at = smem_c;                 // [KT][128 B]  dpre rows (co)
+  char* bt = smem_c + KT * 128;      // [KT][128 B]  x rows (ci)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave >> 1, wci = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  int bid = blockIdx.x;
+  const int ci_t = bid % p.n_ci_tiles; bid /= p.n_ci_tiles;
+  const int co_t = bid % p.n_co_tiles; bid /= p.n_co_tiles;
+  const int ab = bid & 3;
+  const int split = bid >> 2;
+  const int co0 = co_t * CT, ci0 = ci_t * CT;
+  const bf16_t* xb = reinterpret_cast<const bf16_t*>(p.x);
+  const bf16_t* db = reinterpret_cast<const bf16_t*>(p.dpre);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int mb = split * p.m_per_split, me = min(mb + p.m_per_split, p.M);
+  constexpr int LR = KT * 8 / 256;      // 4 sixteen-byte chunks of each operand per thread
+  uint4 va[LR], vb[LR];
+  const int HWp = p.H * p.W;
+  // thread -> rows (tid >> 3) + 32 i of the tile, chunk q = tid & 7
+  auto load_tile = [&](int mt) {
+    const int m_first = mt + (tid >> 3), q = tid & 7;
+    int nn = m_first / HWp;
+    const int rem = m_first - nn * HWp;
+    int yy = rem / p.W, xx = rem - yy * p.W;
+    int64_t img = p.da.off(nn);
+#pragma unroll
+    for (int i = 0; i < LR; ++i) {
+      const int m = m_first + 32 * i;
+      va[i] = vb[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (m < me) {
+        const int64_t o = img + ((int64_t)(2 * yy + (ab >> 1)) * 2 * p.W + 2 * xx + (ab & 1)) * p.Cout;
+        if (co0 + q * 8 < p.Cout) va[i] = *reinterpret_cast<const uint4*>(db + o + co0 + q * 8);
+        vb[i] = *reinterpret_cast<const uint4*>(xb + (int64_t)m * p.Cin + ci0 + q * 8);
+      }
+      xx += 32;
+      while (xx >= p.W) {
+        xx -= p.W;
+        if (++yy == p.H) {
+          yy = 0;
+          img = p.da.off(++nn);
+        }
+      }
+    }
+  };
+  // fragment addressing (see conv_wgrad_bf16s.hip): 16-lane group -> channel 16-block (g & 1), pixel half h
+  const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, g16 = (lane >> 4) & 1;
+  const int sw = (q4 >> 1) << 2;
+  const int a_off = (8 * h + q4) * 128 + (((2 * (wco * 2 + g16) + (p4 >> 1)) ^ sw) << 4) + 8 * (p4 & 1);
+  const int b_off = (8 * h + q4) * 128 + (((2 * (wci * 2 + g16) + (p4 >> 1)) ^ sw) << 4) + 8 * (p4 & 1);
+  if (mb < me) load_tile(mb);
+  for (int mt = mb; mt < me; mt += KT) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < LR; ++i) {
+      const int row = (tid >> 3) + 32 * i, q = tid & 7;
+      const int o = row * 128 + ((q ^ (((row >> 1) & 1) << 2)) << 4);
+      *reinterpret_cast<uint4*>(at + o) = va[i];
+      *reinterpret_cast<uint4*>(bt + o) = vb[i];
+    }
+    __syncthreads();
+    if (mt + KT < me) load_tile(mt + KT);
+#pragma unroll
+    for (int s = 0; s < KT / 16; ++s) {
+      const uint2 a0 = tr_read(at, s * 16 * 128 + a_off), a1 = tr_read(at, s * 16 * 128 + 4 * 128 + a_off);
+      const uint2 b0 = tr_read(bt, s * 16 * 128 + b_off), b1 = tr_read(bt, s * 16 * 128 + 4 * 128 + b_off);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y)),
+                                                    __builtin_bit_cast(bf16x8, make_uint4(b0.x, b0.y, b1.x, b1.y)), acc, 0, 0, 0);
+    }
+  }
+  float* out = p.slab + ((int64_t)split * 4 + ab) * p.Cout * p.Cin;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = co0 + wco * 32 + mfma32_row(r, h);
+    if (co < p.Cout) out[(int64_t)co * p.Cin + ci0 + wci * 32 + l31] = acc[r];
+  }
+}
+
 // wp_fwd[q][n=(bc,co)][j] = w[bc][co][4q+j]   (K = Cin)
 // wp_dgrad[q][n=ci][j]    = w_flat[(4q+j)][ci] with w_flat = [(bc,co)][ci]   (K = 4*Cout)
 __global__ void pack_deconv_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ wp_fwd,
@@ -544,13 +708,15 @@ __global__ void pack_deconv_kernel(const float* __restrict__ w, int Cin, int Cou
 }
 
 // bf16 packs: wp_fwd[q][n=(bc,co)][j] = bf16(w[bc][co][8q+j]) (K = Cin); wp_dgrad[q][n=ci][j] = bf16(w_flat[8q+j][ci])
+// perm (UNETK_BF16S): column position n' of every 64-column block holds GEMM column 2 (n' & 31) + (n' >> 5 & 1).
 __global__ void pack_deconv_bf16_kernel(const float* __restrict__ w, int Cin, int Cout, uint4* __restrict__ wp_fwd,
-                                        uint4* __restrict__ wp_dgrad) {
+                                        uint4* __restrict__ wp_dgrad, int perm) {
   const int64_t total = (int64_t)Cin * Cout / 2;  // 16-B units = 4*Cin*Cout/8
   const int Nf = 4 * Cout;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     if (wp_fwd != nullptr) {
-      const int n = (int)(i % Nf);
+      int n = (int)(i % Nf);
+      if (perm) n = (n & ~63) + 2 * (n & 31) + ((n >> 5) & 1);
       const int q = (int)(i / Nf);
       const float* s = w + (int64_t)n * Cin + 8 * q;
       uint4 v;
@@ -558,7 +724,8 @@ __global__ void pack_deconv_bf16_kernel(const float* __restrict__ w, int Cin, in
       wp_fwd[i] = v;
     }
     if (wp_dgrad != nullptr) {
-      const int n = (int)(i % Cin);
+      int n = (int)(i % Cin);
+      if (perm) n = (n & ~63) + 2 * (n & 31) + ((n >> 5) & 1);
       const int q = (int)(i / Cin);
       const float* s = w + (int64_t)(8 * q) * Cin + n;
       const int64_t cs = Cin;
@@ -570,12 +737,12 @@ __global__ void pack_deconv_bf16_kernel(const float* __restrict__ w, int Cin, in
   }
 }
 
-template <int MODE, int WM, int WN, int TM, int TN>
+template <int MODE, int WM, int WN, int TM, int TN, bool BS = false>
 int launch_pw_bf16(const PwParams& p, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr size_t lds = (size_t)(2 * BM * PSQ + 2 * (CKB / 8) * BN) * 16;
   const int n_mtiles = (p.M + BM - 1) / BM;
-  hipLaunchKernelGGL((pw_gemm_bf16_kernel<MODE, WM, WN, TM, TN>), dim3(n_mtiles * p.n_ntiles), dim3(WM * WN * 64), lds, st,
+  hipLaunchKernelGGL((pw_gemm_bf16_kernel<MODE, WM, WN, TM, TN, BS>), dim3(n_mtiles * p.n_ntiles), dim3(WM * WN * 64), lds, st,
                      p);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
@@ -593,6 +760,15 @@ int launch_pw(const PwParams& p, hipStream_t st) {
 
 template <int MODE>
 int run_pw(PwParams& p, hipStream_t st) {
+  if (p.bf16 == UNETK_BF16S) {
+    if (p.accumulate || p.Ncols % 64 != 0) return UNETK_E_UNSUPPORTED;
+    if (p.Ncols % 128 == 0) {
+      p.n_ntiles = p.Ncols / 128;
+      return launch_pw_bf16<MODE, 2, 2, 2, 2, true>(p, st);
+    }
+    p.n_ntiles = p.Ncols / 64;
+    return launch_pw_bf16<MODE, 4, 1, 1, 2, true>(p, st);
+  }
   if (p.Ncols % 128 == 0) {
     p.n_ntiles = p.Ncols / 128;
     return p.bf16 ? launch_pw_bf16<MODE, 2, 2, 2, 2>(p, st) : launch_pw<MODE, 2, 2, 2, 2>(p, st);
@@ -637,16 +813,17 @@ unetk_deconv3d_desc from2d(const unetk_deconv_desc* d) {
 // filter panel of depth tap a: 4*Cin*Cout elements per tap, 4 bytes (fp32 K4 pack) or 2 bytes (bf16 K8 pack) each
 inline const float* tap_panel(const float* wp, int a, const unetk_deconv3d_desc* d) {
   const int64_t elems = (int64_t)a * 4 * d->Cin * d->Cout;
-  return d->precision == UNETK_BF16 ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(wp) + elems)
+  return d->precision != UNETK_FP32 ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(wp) + elems)
                                     : wp + elems;
 }
 
 }  // namespace
 
-extern "C" int unetk_deconv3d_pack_bf16(const float* w, int kd, int Cin, int Cout, void* wp_fwd, void* wp_dgrad,
-                                        void* stream) {
+static int deconv_pack_bf16_impl(const float* w, int kd, int Cin, int Cout, void* wp_fwd, void* wp_dgrad, void* stream,
+                                 int perm) {
   UNETK_REQUIRE(w && (kd == 1 || kd == 2) && Cin > 0 && Cout > 0 && (wp_fwd || wp_dgrad));
   if (Cin % 8 != 0 || Cout % 8 != 0) return UNETK_E_UNSUPPORTED;
+  if (perm && (Cin % 64 != 0 || Cout % 64 != 0)) return UNETK_E_UNSUPPORTED;
   UNETK_REQUIRE((!wp_fwd || unetk_aligned16(wp_fwd)) && (!wp_dgrad || unetk_aligned16(wp_dgrad)));
   const int64_t total = (int64_t)Cin * Cout / 2;
   int grid = (int)((total + 255) / 256);
@@ -655,10 +832,19 @@ extern "C" int unetk_deconv3d_pack_bf16(const float* w, int kd, int Cin, int Cou
     const int64_t o = (int64_t)a * Cin * Cout / 2;        // 16-B units per tap
     hipLaunchKernelGGL(pack_deconv_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        w + (int64_t)a * 4 * Cin * Cout, Cin, Cout, wp_fwd ? (uint4*)wp_fwd + o : nullptr,
-                       wp_dgrad ? (uint4*)wp_dgrad + o : nullptr);
+                       wp_dgrad ? (uint4*)wp_dgrad + o : nullptr, perm);
     UNETK_LAUNCH_CHECK();
   }
   return UNETK_OK;
+}
+
+extern "C" int unetk_deconv3d_pack_bf16(const float* w, int kd, int Cin, int Cout, void* wp_fwd, void* wp_dgrad,
+                                        void* stream) {
+  return deconv_pack_bf16_impl(w, kd, Cin, Cout, wp_fwd, wp_dgrad, stream, 0);
+}
+
+extern "C" int unetk_deconv2x2_pack_bf16s(const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad, void* stream) {
+  return deconv_pack_bf16_impl(w, 1, Cin, Cout, wp_fwd, wp_dgrad, stream, 1);
 }
 
 extern "C" int unetk_deconv2x2_pack_bf16(const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad, void* stream) {
@@ -682,16 +868,22 @@ extern "C" int unetk_deconv3d_pack(const float* w, int kd, int Cin, int Cout, fl
   return UNETK_OK;
 }
 
-extern "C" int unetk_deconv3d_fwd(const unetk_deconv3d_desc* d, const float* x, const float* wp_fwd,
-                                  const float* bias, float* out, void* stream) {
+extern "C" int unetk_deconv3d_fwd(const unetk_deconv3d_desc* d, const void* xv, const void* wpv,
+                                  const float* bias, void* outv, void* stream) {
+  const float* x = (const float*)xv;
+  const float* wp_fwd = (const float*)wpv;
+  float* out = (float*)outv;
   UNETK_REQUIRE(deconv_desc_ok(d) && x && wp_fwd && out);
   UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(wp_fwd));
   if (d->Cin % CK != 0 || d->Cout % 16 != 0) return UNETK_E_UNSUPPORTED;
   if (d->precision == UNETK_BF16 && (d->Cin % CKB != 0 || d->Cout % 32 != 0)) return UNETK_E_UNSUPPORTED;
+  if (d->precision == UNETK_BF16S && (d->kd != 1 || d->Cin % 64 != 0 || d->Cout % 64 != 0 || d->out_stride % 2 != 0 ||
+                                      d->out_coff % 2 != 0))
+    return UNETK_E_UNSUPPORTED;
   const int64_t plane = (int64_t)4 * d->H * d->W * d->out_stride;      // one output depth plane
   for (int a = 0; a < d->kd; ++a) {
     PwParams p{};
-    p.bf16 = d->precision == UNETK_BF16;
+    p.bf16 = d->precision;
     p.a = x; p.wp = tap_panel(wp_fwd, a, d); p.bias = bias; p.out = out + a * plane;
     p.M = d->N * d->D * d->H * d->W; p.K = d->Cin; p.Ncols = 4 * d->Cout;
     p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.out_stride = d->out_stride; p.out_coff = d->out_coff;
@@ -715,10 +907,17 @@ extern "C" size_t unetk_deconv3d_bwd_ws_bytes(const unetk_deconv3d_desc* d) {
   return f * sizeof(float);
 }
 
-extern "C" int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const float* x, const float* wp_dgrad,
-                                  const float* cat, const float* dcat, float* dx, float* dw, float* dbias, void* ws,
+extern "C" int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const void* xv, const void* wpv,
+                                  const void* catv, const void* dcatv, void* dxv, float* dw, float* dbias, void* ws,
                                   size_t ws_bytes, void* stream) {
+  const float* x = (const float*)xv;
+  const float* wp_dgrad = (const float*)wpv;
+  const float* cat = (const float*)catv;
+  const float* dcat = (const float*)dcatv;
+  float* dx = (float*)dxv;
   UNETK_REQUIRE(deconv_desc_ok(d) && x && wp_dgrad && cat && dcat && dx && dw && ws);
+  const bool bs = d->precision == UNETK_BF16S;
+  if (bs && (d->kd != 1 || d->Cout % 64 != 0 || d->out_stride % 4 != 0)) return UNETK_E_UNSUPPORTED;
   if (d->Cin % 64 != 0 || d->Cout % 32 != 0 || d->out_stride % 4 != 0 || d->out_coff % 4 != 0)
     return UNETK_E_UNSUPPORTED;
   UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(wp_dgrad) && unetk_aligned16(cat) && unetk_aligned16(dcat) &&
@@ -737,9 +936,15 @@ extern "C" int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const float* x, 
 
   // 1. ReLU backward over the whole up half + bias-grad partials
   const ColMap cm = unetk_colmap(d->Cout);
-  hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3(pl.nblk_bias), dim3(256), (size_t)cm.rows_per_iter * d->Cout * sizeof(float),
-                     st, cat, dcat, d->out_stride, d->out_coff, dpre, bpart, (int64_t)4 * d->kd * M, d->Cout, cm.cq_n,
-                     cm.rows_per_iter);
+  if (bs)     // dpre is bf16 in the same workspace region (half of it used)
+    hipLaunchKernelGGL(relu_bwd_bias_kernel<bf16_t>, dim3(pl.nblk_bias), dim3(256),
+                       (size_t)cm.rows_per_iter * d->Cout * sizeof(float), st, (const bf16_t*)catv, (const bf16_t*)dcatv,
+                       d->out_stride, d->out_coff, (bf16_t*)dpre, bpart, (int64_t)4 * d->kd * M, d->Cout, cm.cq_n,
+                       cm.rows_per_iter);
+  else
+    hipLaunchKernelGGL(relu_bwd_bias_kernel<float>, dim3(pl.nblk_bias), dim3(256),
+                       (size_t)cm.rows_per_iter * d->Cout * sizeof(float), st, cat, dcat, d->out_stride, d->out_coff, dpre,
+                       bpart, (int64_t)4 * d->kd * M, d->Cout, cm.cq_n, cm.rows_per_iter);
   UNETK_LAUNCH_CHECK();
   int rc = unetk_rows_reduce(bpart, 1, pl.nblk_bias, d->Cout, dbias ? dbias : bsink, btmp, st);
   if (rc != UNETK_OK) return rc;
@@ -750,7 +955,7 @@ extern "C" int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const float* x, 
   for (int a = 0; a < d->kd; ++a) {
     // 2. input gradient: [M x 4Cout] . [4Cout x Cin], accumulated over depth taps
     PwParams p{};
-    p.bf16 = d->precision == UNETK_BF16;
+    p.bf16 = d->precision;
     p.a = dpre + a * plane; p.wp = tap_panel(wp_dgrad, a, d); p.bias = nullptr; p.out = dx;
     p.M = M; p.K = 4 * d->Cout; p.Ncols = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout;
     p.oa = da; p.accumulate = a > 0 ? 1 : 0;
@@ -773,7 +978,9 @@ extern "C" int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const float* x, 
       if (e != hipSuccess) return (int)e;
       attr_done = true;
     }
-    if (q.bf16)
+    if (bs)
+      hipLaunchKernelGGL(deconv_wgrad_bf16s_kernel, dim3(grid), dim3(256), (size_t)2 * 128 * 128, st, q);
+    else if (q.bf16)
       hipLaunchKernelGGL(deconv_wgrad_kernel<true>, dim3(grid), dim3(256), (size_t)2 * 128 * 64 * sizeof(float), st, q);
     else
       hipLaunchKernelGGL(deconv_wgrad_kernel<false>, dim3(grid), dim3(256), (size_t)2 * 128 * 64 * sizeof(float), st, q);
@@ -789,8 +996,8 @@ extern "C" int unetk_deconv2x2_pack(const float* w, int Cin, int Cout, float* wp
   return unetk_deconv3d_pack(w, 1, Cin, Cout, wp_fwd, wp_dgrad, stream);
 }
 
-extern "C" int unetk_deconv2x2_fwd(const unetk_deconv_desc* d, const float* x, const float* wp_fwd, const float* bias,
-                                   float* out, void* stream) {
+extern "C" int unetk_deconv2x2_fwd(const unetk_deconv_desc* d, const void* x, const void* wp_fwd, const float* bias,
+                                   void* out, void* stream) {
   UNETK_REQUIRE(d);
   const unetk_deconv3d_desc e = from2d(d);
   return unetk_deconv3d_fwd(&e, x, wp_fwd, bias, out, stream);
@@ -802,8 +1009,8 @@ extern "C" size_t unetk_deconv2x2_bwd_ws_bytes(const unetk_deconv_desc* d) {
   return unetk_deconv3d_bwd_ws_bytes(&e);
 }
 
-extern "C" int unetk_deconv2x2_bwd(const unetk_deconv_desc* d, const float* x, const float* wp_dgrad, const float* cat,
-                                   const float* dcat, float* dx, float* dw, float* dbias, void* ws, size_t ws_bytes,
+extern "C" int unetk_deconv2x2_bwd(const unetk_deconv_desc* d, const void* x, const void* wp_dgrad, const void* cat,
+                                   const void* dcat, void* dx, float* dw, float* dbias, void* ws, size_t ws_bytes,
                                    void* stream) {
   UNETK_REQUIRE(d && dbias);
   const unetk_deconv3d_desc e = from2d(d);

@@ -112,8 +112,8 @@ __device__ __forceinline__ void pixel_logits(const float4 zv, const float (&wr)[
   }
 }
 
-template <int NCLS>
-__global__ __launch_bounds__(256) void head_fwd_kernel(unetk_head_desc d, const float* __restrict__ z,
+template <int NCLS, typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(unetk_head_desc d, const T* __restrict__ z,
                                                        const float* __restrict__ w, const float* __restrict__ bvec,
                                                        const int32_t* __restrict__ labels, const float* __restrict__ pixel_w,
                                                        const float* __restrict__ wn, float* __restrict__ logits,
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(unetk_head_desc d, const 
 
   for (int i = blk * gpb + grp; i < d.HW; i += bps * gpb) {
     const int64_t pix = (int64_t)b * d.HW + i;
-    const float4 zv = ldg4(z + pix * d.C + gl * 4);
+    const float4 zv = ld4(z + pix * d.C + gl * 4);
     float lg[NCLS];
     pixel_logits<NCLS>(zv, wr, bias, lpp, lg);
     if (gl == 0) {
@@ -235,13 +235,13 @@ __global__ void head_finalize_kernel(unetk_head_desc d, const float* __restrict_
   }
 }
 
-template <int NCLS>
-__global__ __launch_bounds__(256) void head_bwd_kernel(unetk_head_desc d, const float* __restrict__ z,
+template <int NCLS, typename T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(unetk_head_desc d, const T* __restrict__ z,
                                                        const float* __restrict__ w, const int32_t* __restrict__ labels,
                                                        const float* __restrict__ pixel_w, const float* __restrict__ wn,
                                                        const float* __restrict__ logits, const float* __restrict__ result,
                                                        float xs, float ds, const float* __restrict__ dev_scales,
-                                                       float* __restrict__ dz, float* __restrict__ pw,
+                                                       T* __restrict__ dz, float* __restrict__ pw,
                                                        float* __restrict__ pb) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [gpb][C*NCLS] then [4][NCLS]
   const int lpp = d.C >> 2, gpb = 256 / lpp;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(unetk_head_desc d, const 
   const float* iu = result + 3 + (int64_t)d.N * (NCLS - 1) * 4;
 
   for (int64_t pix = (int64_t)blockIdx.x * gpb + grp; pix < npix; pix += (int64_t)gridDim.x * gpb) {
-    const float4 zv = ldg4(z + pix * d.C + gl * 4);      // issued first: its latency overlaps the softmax arithmetic below
+    const float4 zv = ld4(z + pix * d.C + gl * 4);       // issued first: its latency overlaps the softmax arithmetic below
     const int b = (int)(pix / d.HW);
     const int lab = labels[pix];
     float lg[NCLS], p[NCLS], dl[NCLS];
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(unetk_head_desc d, const 
       aw[3][k] = fmaf(zv.w, dl[k], aw[3][k]);
       if (gl == 0) abias[k] += dl[k];
     }
-    stg4(dz + pix * d.C + gl * 4, o);
+    st4(dz + pix * d.C + gl * 4, o);
   }
   // block reduction over pixel groups (fixed order)
   const int CW = d.C * NCLS;
@@ -391,12 +391,13 @@ extern "C" size_t unetk_head_ws_bytes(const unetk_head_desc* d) {
     default: { constexpr int K_ = 8; CALL; } break; \
   }
 
-extern "C" int unetk_head_fwd(const unetk_head_desc* d, const float* z, const float* w, const float* b,
+extern "C" int unetk_head_fwd(const unetk_head_desc* d, const void* z, const float* w, const float* b,
                               const int32_t* labels, const float* pixel_w, float* logits, float* probs,
                               float* result, void* ws, size_t ws_bytes, void* stream) {
   UNETK_REQUIRE(head_desc_ok(d) && z && w && b && logits);
   if (!head_shape_supported(d)) return UNETK_E_UNSUPPORTED;
-  UNETK_REQUIRE(unetk_aligned16(z));
+  const bool bs = d->storage == UNETK_BF16S;
+  UNETK_REQUIRE((d->storage == UNETK_FP32 && unetk_aligned16(z)) || (bs && unetk_aligned8(z)));
   hipStream_t st = (hipStream_t)stream;
   const HeadWs L = head_ws(d);
   float* wsf = (float*)ws;
@@ -426,8 +427,13 @@ extern "C" int unetk_head_fwd(const unetk_head_desc* d, const float* z, const fl
     UNETK_REQUIRE(ws && ws_bytes >= (size_t)L.total * sizeof(float));
     part_eff = wsf + L.part_off;
   }
-  HEAD_DISPATCH(d->ncls, hipLaunchKernelGGL(head_fwd_kernel<K_>, dim3(d->N * bps), dim3(256), 0, st, *d, z, w, b, labels,
-                                            pixel_w, wn, logits, probs, part_eff, bps));
+  if (bs) {
+    HEAD_DISPATCH(d->ncls, hipLaunchKernelGGL((head_fwd_kernel<K_, bf16_t>), dim3(d->N * bps), dim3(256), 0, st, *d,
+                                              (const bf16_t*)z, w, b, labels, pixel_w, wn, logits, probs, part_eff, bps));
+  } else {
+    HEAD_DISPATCH(d->ncls, hipLaunchKernelGGL((head_fwd_kernel<K_, float>), dim3(d->N * bps), dim3(256), 0, st, *d,
+                                              (const float*)z, w, b, labels, pixel_w, wn, logits, probs, part_eff, bps));
+  }
   UNETK_LAUNCH_CHECK();
   if (labels) {
     hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), (size_t)d->N * (3 + L.nq) * sizeof(double), st, *d, part,
@@ -437,13 +443,15 @@ extern "C" int unetk_head_fwd(const unetk_head_desc* d, const float* z, const fl
   return UNETK_OK;
 }
 
-extern "C" int unetk_head_bwd(const unetk_head_desc* d, const float* z, const float* w, const int32_t* labels,
+extern "C" int unetk_head_bwd(const unetk_head_desc* d, const void* z, const float* w, const int32_t* labels,
                               const float* pixel_w, const float* logits, const float* result, float xent_scale,
-                              float dice_scale, const float* dev_scales, float* dz, float* dw, float* db, void* ws,
+                              float dice_scale, const float* dev_scales, void* dz, float* dw, float* db, void* ws,
                               size_t ws_bytes, void* stream) {
   UNETK_REQUIRE(head_desc_ok(d) && z && w && labels && logits && result && dz && dw && db && ws);
   if (!head_shape_supported(d)) return UNETK_E_UNSUPPORTED;
-  UNETK_REQUIRE(unetk_aligned16(z) && unetk_aligned16(dz));
+  const bool bs = d->storage == UNETK_BF16S;
+  UNETK_REQUIRE((d->storage == UNETK_FP32 && unetk_aligned16(z) && unetk_aligned16(dz)) ||
+                (bs && unetk_aligned8(z) && unetk_aligned8(dz)));
   UNETK_REQUIRE(d->weight_mode != UNETK_W_PIXELMAP || pixel_w);
   hipStream_t st = (hipStream_t)stream;
   const HeadWs L = head_ws(d);
@@ -456,8 +464,15 @@ extern "C" int unetk_head_bwd(const unetk_head_desc* d, const float* z, const fl
   const int gpb = 256 / (d->C / 4);
   const size_t lds = (size_t)gpb * d->C * d->ncls * sizeof(float);
   if (lds > 64 * 1024) return UNETK_E_UNSUPPORTED;
-  HEAD_DISPATCH(d->ncls, hipLaunchKernelGGL(head_bwd_kernel<K_>, dim3(L.bwd_nblk), dim3(256), lds, st, *d, z, w, labels,
-                                            pixel_w, wn, logits, result, xent_scale, dice_scale, dev_scales, dz, pw, pb));
+  if (bs) {
+    HEAD_DISPATCH(d->ncls, hipLaunchKernelGGL((head_bwd_kernel<K_, bf16_t>), dim3(L.bwd_nblk), dim3(256), lds, st, *d,
+                                              (const bf16_t*)z, w, labels, pixel_w, wn, logits, result, xent_scale,
+                                              dice_scale, dev_scales, (bf16_t*)dz, pw, pb));
+  } else {
+    HEAD_DISPATCH(d->ncls, hipLaunchKernelGGL((head_bwd_kernel<K_, float>), dim3(L.bwd_nblk), dim3(256), lds, st, *d,
+                                              (const float*)z, w, labels, pixel_w, wn, logits, result, xent_scale,
+                                              dice_scale, dev_scales, (float*)dz, pw, pb));
+  }
   UNETK_LAUNCH_CHECK();
   int rc = unetk_rows_reduce(pw, 1, L.bwd_nblk, d->C * d->ncls, dw, tmp, st);
   if (rc != UNETK_OK) return rc;

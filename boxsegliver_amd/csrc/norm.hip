@@ -85,14 +85,14 @@ __global__ void norm_finalize_kernel(const float* __restrict__ sums, int Ns, int
 }
 
 struct ApplyArgs {
-  const float* y;
+  const void* y;        // T = float, or bf16_t under d->storage == UNETK_BF16S (then z is bf16 too)
   const float* scale;   // [Ns][C]
   const float* shift;
   const float* den;     // [N][C] or null
   const float* guide;   // [N*HW][G] or null
   const float* gw;      // [G][gw_stride], columns gw_coff ..
   const float* gb;      // [gw_stride]
-  float* z;
+  void* z;
   int64_t P;
   int C, zs, cq_n, rpi, gw_stride, gw_coff, sst;
 };
@@ -106,9 +106,11 @@ __device__ __forceinline__ float lrelu(float s) { return s > 0.f ? s : 0.2f * s;
 __device__ __forceinline__ float lrelu_grad(float s) { return s > 0.f ? 1.f : 0.2f; }
 
 // z = relu((y*scale + shift) [* den] [+ guide . gw + gb])
-template <int G, bool D, bool L = false>
+template <int G, bool D, bool L = false, typename T = float>
 __global__ __launch_bounds__(256) void norm_apply_relu_kernel(ApplyArgs a) {
   static_assert(!(L && (D || G == 0)), "the leaky guide needs a guide and no density gains");
+  const T* ay = static_cast<const T*>(a.y);
+  T* az = static_cast<T*>(a.z);
   const int cq = threadIdx.x % a.cq_n, rl = threadIdx.x / a.cq_n;
   if (rl >= a.rpi) return;
   const int n = blockIdx.y;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void norm_apply_relu_kernel(ApplyArgs a) {
   }
   const int64_t base = (int64_t)n * a.P;
   for (int64_t pix = (int64_t)blockIdx.x * a.rpi + rl; pix < a.P; pix += (int64_t)gridDim.x * a.rpi) {
-    const float4 v = ldg4(a.y + (base + pix) * a.C + cq * 4);
+    const float4 v = ld4(ay + (base + pix) * a.C + cq * 4);
     float4 u;
     u.x = fmaf(v.x, sc.x, sh.x); u.y = fmaf(v.y, sc.y, sh.y); u.z = fmaf(v.z, sc.z, sh.z); u.w = fmaf(v.w, sc.w, sh.w);
     if (L) {
@@ -148,13 +150,13 @@ __global__ __launch_bounds__(256) void norm_apply_relu_kernel(ApplyArgs a) {
       }
     }
     u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
-    stg4(a.z + (base + pix) * a.zs + cq * 4, u);
+    st4(az + (base + pix) * a.zs + cq * 4, u);
   }
 }
 
 struct BwdArgs {
-  const float* y;
-  const float* dz;
+  const void* y;        // T = float or bf16_t (d->storage): y, dz and dy share it
+  const void* dz;
   const float* scale;   // [Ns][C]
   const float* shift;
   const float* mean;
@@ -165,7 +167,7 @@ struct BwdArgs {
   const float* gb;
   const float* ksum;    // apply pass: k = 0 row at ksum + n*kst, k = 1 row at ksum + krow + n*kst
   float* partial;       // [K][L][nblk][C] (reduce pass)
-  float* dy;
+  void* dy;
   int64_t P;
   float inv_ps;         // 1 / pixels per STATISTICS group
   int C, dzs, cq_n, rpi, gw_stride, gw_coff, L, plain, sst, kst, krow;
@@ -175,9 +177,11 @@ struct BwdArgs {
 //   partial[0] = sum dt, partial[1] = sum dt*xhat, partial[2+g] = sum du*guide_g,
 //   D only: partial[2+G] = sum du (guide bias gradient), partial[3+G] = sum du*t (density gradient, per sample)
 //   L only: partial[2+g] = sum du*lrelu'(s)*guide_g, partial[2+G] = sum du*lrelu'(s)  (s = guide . gw + gb)
-template <int G, bool D, bool L = false>
+template <int G, bool D, bool L = false, typename T = float>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
   constexpr int K = 2 + G + (D ? 2 : 0) + (L ? 1 : 0);
+  const T* ay = static_cast<const T*>(a.y);
+  const T* adz = static_cast<const T*>(a.dz);
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [K][rpi][C]
   const int cq = threadIdx.x % a.cq_n, rl = threadIdx.x / a.cq_n;
   const int n = blockIdx.y;
@@ -201,8 +205,8 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
     }
     const int64_t base = (int64_t)n * a.P;
     for (int64_t pix = (int64_t)blockIdx.x * a.rpi + rl; pix < a.P; pix += (int64_t)gridDim.x * a.rpi) {
-      const float4 v = ldg4(a.y + (base + pix) * a.C + cq * 4);
-      const float4 d = ldg4(a.dz + (base + pix) * a.dzs + cq * 4);
+      const float4 v = ld4(ay + (base + pix) * a.C + cq * 4);
+      const float4 d = ld4(adz + (base + pix) * a.dzs + cq * 4);
       float4 u;
       u.x = fmaf(v.x, sc.x, sh.x); u.y = fmaf(v.y, sc.y, sh.y); u.z = fmaf(v.z, sc.z, sh.z); u.w = fmaf(v.w, sc.w, sh.w);
       float gg[G > 0 ? G : 1];
@@ -253,10 +257,13 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
 }
 
 // pass 2: dy = scale * (dt - sum_dt/Ps - xhat * sum_dt_xhat/Ps)   (sums over the STATISTICS group)
-template <int G, bool D, bool L = false>
+template <int G, bool D, bool L = false, typename T = float>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdArgs a) {
   const int cq = threadIdx.x % a.cq_n, rl = threadIdx.x / a.cq_n;
   if (rl >= a.rpi) return;
+  const T* ay = static_cast<const T*>(a.y);
+  const T* adz = static_cast<const T*>(a.dz);
+  T* ady = static_cast<T*>(a.dy);
   const int n = blockIdx.y;
   const int64_t so = (int64_t)n * a.sst + cq * 4;
   const float4 mu = ldg4(a.mean + so), rs = ldg4(a.rstd + so), sc0 = ldg4(a.scale + so), sh0 = ldg4(a.shift + so);
@@ -281,8 +288,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdArgs a) {
   }
   const int64_t base = (int64_t)n * a.P;
   for (int64_t pix = (int64_t)blockIdx.x * a.rpi + rl; pix < a.P; pix += (int64_t)gridDim.x * a.rpi) {
-    const float4 v = ldg4(a.y + (base + pix) * a.C + cq * 4);
-    const float4 d = ldg4(a.dz + (base + pix) * a.dzs + cq * 4);
+    const float4 v = ld4(ay + (base + pix) * a.C + cq * 4);
+    const float4 d = ld4(adz + (base + pix) * a.dzs + cq * 4);
     float4 u, o;
     u.x = fmaf(v.x, sc.x, sh.x); u.y = fmaf(v.y, sc.y, sh.y); u.z = fmaf(v.z, sc.z, sh.z); u.w = fmaf(v.w, sc.w, sh.w);
     if (L) {
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdArgs a) {
   }
     NBA(x) NBA(y) NBA(z) NBA(w)
 #undef NBA
-    stg4(a.dy + (base + pix) * a.C + cq * 4, o);
+    st4(ady + (base + pix) * a.C + cq * 4, o);
   }
 }
 
@@ -352,10 +359,14 @@ int bwd_blocks(const NormGeom& g) {
     case 3: { constexpr int GG = 3; CALL; } break; \
     default: { constexpr int GG = 4; CALL; } break; \
   }
-#define GD_DISPATCH(G_, D_, L_, KERN, ...)                                               \
-  if (L_) { GL_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, false, true>), __VA_ARGS__)); } \
-  else if (D_) { G_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, true>), __VA_ARGS__)); }     \
-  else { G_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, false>), __VA_ARGS__)); }
+#define GD_DISPATCH_T(TT, G_, D_, L_, KERN, ...)                                               \
+  if (L_) { GL_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, false, true, TT>), __VA_ARGS__)); }   \
+  else if (D_) { G_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, true, false, TT>), __VA_ARGS__)); } \
+  else { G_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, false, false, TT>), __VA_ARGS__)); }
+// S_: tensors in HBM are bf16 (UNETK_BF16S) instead of fp32
+#define GD_DISPATCH(S_, G_, D_, L_, KERN, ...)                      \
+  if (S_) { GD_DISPATCH_T(bf16_t, G_, D_, L_, KERN, __VA_ARGS__) } \
+  else { GD_DISPATCH_T(float, G_, D_, L_, KERN, __VA_ARGS__) }
 
 }  // namespace
 
@@ -394,12 +405,15 @@ extern "C" int unetk_norm_finalize(const unetk_norm_desc* d, const float* stat_p
   return UNETK_OK;
 }
 
-extern "C" int unetk_norm_apply_relu(const unetk_norm_desc* d, const float* y, const float* scale, const float* shift,
-                                     const float* den, const float* guide, const float* gw, const float* gb, float* z,
+extern "C" int unetk_norm_apply_relu(const unetk_norm_desc* d, const void* y, const float* scale, const float* shift,
+                                     const float* den, const float* guide, const float* gw, const float* gb, void* z,
                                      void* stream) {
   UNETK_REQUIRE(norm_desc_ok(d) && y && scale && shift && z && d->z_stride >= d->C);
   if (!norm_supported(d) || d->z_stride % 4 != 0) return UNETK_E_UNSUPPORTED;
-  UNETK_REQUIRE(unetk_aligned16(y) && unetk_aligned16(z) && unetk_aligned16(scale) && unetk_aligned16(shift));
+  const bool bs = d->storage == UNETK_BF16S;
+  UNETK_REQUIRE(d->storage == UNETK_FP32 || bs);
+  UNETK_REQUIRE(bs ? (unetk_aligned8(y) && unetk_aligned8(z)) : (unetk_aligned16(y) && unetk_aligned16(z)));
+  UNETK_REQUIRE(unetk_aligned16(scale) && unetk_aligned16(shift));
   UNETK_REQUIRE(!den || unetk_aligned16(den));
   if (d->guide_ch > 0) {
     UNETK_REQUIRE(guide && gw && gb && d->gw_stride >= d->gw_coff + d->C);
@@ -413,7 +427,7 @@ extern "C" int unetk_norm_apply_relu(const unetk_norm_desc* d, const float* y, c
   if (gx > cap) gx = cap;
   const bool leaky = d->guide_leaky != 0;
   if (leaky && (d->guide_ch < 1 || den != nullptr)) return UNETK_E_UNSUPPORTED;
-  GD_DISPATCH(d->guide_ch, den != nullptr, leaky, norm_apply_relu_kernel, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, a);
+  GD_DISPATCH(bs, d->guide_ch, den != nullptr, leaky, norm_apply_relu_kernel, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, a);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
@@ -435,14 +449,18 @@ extern "C" size_t unetk_norm_bwd_ws_bytes(const unetk_norm_desc* d) {
   return f * sizeof(float);
 }
 
-extern "C" int unetk_norm_relu_bwd(const unetk_norm_desc* d, const float* y, const float* dz, int dz_stride,
+extern "C" int unetk_norm_relu_bwd(const unetk_norm_desc* d, const void* y, const void* dz, int dz_stride,
                                    const float* scale, const float* shift, const float* mean, const float* rstd,
-                                   const float* den, const float* guide, const float* gw, const float* gb, float* dy,
+                                   const float* den, const float* guide, const float* gw, const float* gb, void* dy,
                                    float* dgamma, float* dbeta, float* dden, float* dgw, float* dgb, void* ws,
                                    size_t ws_bytes, void* stream) {
   UNETK_REQUIRE(norm_desc_ok(d) && y && dz && scale && shift && mean && rstd && dy && ws && dz_stride >= d->C);
   if (!norm_supported(d) || dz_stride % 4 != 0) return UNETK_E_UNSUPPORTED;
-  UNETK_REQUIRE(unetk_aligned16(y) && unetk_aligned16(dz) && unetk_aligned16(dy) && unetk_aligned16(ws));
+  const bool bs = d->storage == UNETK_BF16S;
+  UNETK_REQUIRE(d->storage == UNETK_FP32 || bs);
+  UNETK_REQUIRE(bs ? (unetk_aligned8(y) && unetk_aligned8(dz) && unetk_aligned8(dy))
+                   : (unetk_aligned16(y) && unetk_aligned16(dz) && unetk_aligned16(dy)));
+  UNETK_REQUIRE(unetk_aligned16(ws));
   const int G = d->guide_ch;
   const bool D = den != nullptr;
   UNETK_REQUIRE(!D || (dden && unetk_aligned16(den)));
@@ -473,7 +491,7 @@ extern "C" int unetk_norm_relu_bwd(const unetk_norm_desc* d, const float* y, con
   else if (g.L == 1) { a.ksum = sums; a.kst = 0; a.krow = d->C; }
   else { a.ksum = psum; a.kst = 0; a.krow = d->C; }
   const size_t lds = (size_t)K * g.rpi * d->C * sizeof(float);
-  GD_DISPATCH(G, D, leaky, norm_bwd_reduce_kernel, dim3(nblk, g.L), dim3(256), lds, st, a);
+  GD_DISPATCH(bs, G, D, leaky, norm_bwd_reduce_kernel, dim3(nblk, g.L), dim3(256), lds, st, a);
   UNETK_LAUNCH_CHECK();
   int rc = unetk_rows_reduce(partial, K * g.L, nblk, d->C, sums, tmp1, st);   // -> sums[K][L][C]
   if (rc != UNETK_OK) return rc;
@@ -490,7 +508,7 @@ extern "C" int unetk_norm_relu_bwd(const unetk_norm_desc* d, const float* y, con
   int64_t gx = (g.P + g.rpi - 1) / g.rpi;
   const int64_t cap = g.L > 1 ? (4096 + g.L - 1) / g.L : 4096;
   if (gx > cap) gx = cap;
-  GD_DISPATCH(G, D, leaky, norm_bwd_apply_kernel, dim3((int)gx, g.L), dim3(256), 0, st, a);
+  GD_DISPATCH(bs, G, D, leaky, norm_bwd_apply_kernel, dim3((int)gx, g.L), dim3(256), 0, st, a);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }

@@ -6,7 +6,8 @@
 namespace {
 
 // ---------------------------------------------------------------- max pool 2x2 s2 VALID
-__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, int xs, float* __restrict__ p,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, int xs, T* __restrict__ p,
                                                            int N, int H, int W, int C) {
   const int Ho = H >> 1, Wo = W >> 1, cq_n = C >> 2;
   const int64_t total = (int64_t)N * Ho * Wo * cq_n;
@@ -16,20 +17,21 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restri
     const int wo = (int)(r % Wo); r /= Wo;
     const int ho = (int)(r % Ho);
     const int n = (int)(r / Ho);
-    const float* b = x + (((int64_t)n * H + 2 * ho) * W + 2 * wo) * xs + cq * 4;
-    const float4 a0 = ldg4(b), a1 = ldg4(b + xs), a2 = ldg4(b + (int64_t)W * xs), a3 = ldg4(b + (int64_t)W * xs + xs);
+    const T* b = x + (((int64_t)n * H + 2 * ho) * W + 2 * wo) * xs + cq * 4;
+    const float4 a0 = ld4(b), a1 = ld4(b + xs), a2 = ld4(b + (int64_t)W * xs), a3 = ld4(b + (int64_t)W * xs + xs);
     float4 o;
     o.x = fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x));
     o.y = fmaxf(fmaxf(a0.y, a1.y), fmaxf(a2.y, a3.y));
     o.z = fmaxf(fmaxf(a0.z, a1.z), fmaxf(a2.z, a3.z));
     o.w = fmaxf(fmaxf(a0.w, a1.w), fmaxf(a2.w, a3.w));
-    stg4(p + i * 4, o);
+    st4(p + i * 4, o);
   }
 }
 
-__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ x, int xs, const float* __restrict__ p,
-                                                           const float* __restrict__ dp, const float* __restrict__ add,
-                                                           int as, float* __restrict__ dx, int N, int H, int W, int C) {
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ x, int xs, const T* __restrict__ p,
+                                                           const T* __restrict__ dp, const T* __restrict__ add,
+                                                           int as, T* __restrict__ dx, int N, int H, int W, int C) {
   const int Ho = H >> 1, Wo = W >> 1, cq_n = C >> 2;
   const int64_t total = (int64_t)N * Ho * Wo * cq_n;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -39,9 +41,9 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
     const int ho = (int)(r % Ho);
     const int n = (int)(r / Ho);
     const int64_t pix = ((int64_t)n * H + 2 * ho) * W + 2 * wo;
-    const float* b = x + pix * xs + cq * 4;
-    const float4 a0 = ldg4(b), a1 = ldg4(b + xs), a2 = ldg4(b + (int64_t)W * xs);  // 4th is implied
-    const float4 m = ldg4(p + i * 4), g = ldg4(dp + i * 4);
+    const T* b = x + pix * xs + cq * 4;
+    const float4 a0 = ld4(b), a1 = ld4(b + xs), a2 = ld4(b + (int64_t)W * xs);  // 4th is implied
+    const float4 m = ld4(p + i * 4), g = ld4(dp + i * 4);
     float4 o0, o1, o2, o3;
     // first maximum in window scan order gets the gradient (TF MaxPoolGrad)
 #define MPB(f)                                              \
@@ -58,18 +60,18 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
     MPB(x) MPB(y) MPB(z) MPB(w)
 #undef MPB
     if (add) {   // the skip connection's gradient (the other consumer of x), summed here instead of in a separate pass
-      const float* s = add + pix * as + cq * 4;
-      const float4 s0 = ldg4(s), s1 = ldg4(s + as), s2 = ldg4(s + (int64_t)W * as), s3 = ldg4(s + (int64_t)W * as + as);
+      const T* s = add + pix * as + cq * 4;
+      const float4 s0 = ld4(s), s1 = ld4(s + as), s2 = ld4(s + (int64_t)W * as), s3 = ld4(s + (int64_t)W * as + as);
       o0.x += s0.x; o0.y += s0.y; o0.z += s0.z; o0.w += s0.w;
       o1.x += s1.x; o1.y += s1.y; o1.z += s1.z; o1.w += s1.w;
       o2.x += s2.x; o2.y += s2.y; o2.z += s2.z; o2.w += s2.w;
       o3.x += s3.x; o3.y += s3.y; o3.z += s3.z; o3.w += s3.w;
     }
-    float* d = dx + pix * C + cq * 4;
-    stg4(d, o0);
-    stg4(d + C, o1);
-    stg4(d + (int64_t)W * C, o2);
-    stg4(d + (int64_t)W * C + C, o3);
+    T* d = dx + pix * C + cq * 4;
+    st4(d, o0);
+    st4(d + C, o1);
+    st4(d + (int64_t)W * C, o2);
+    st4(d + (int64_t)W * C + C, o3);
   }
 }
 
@@ -191,8 +193,19 @@ extern "C" int unetk_maxpool2_fwd(const float* x, int x_stride, float* p, int N,
   if (C % 4 != 0 || x_stride % 4 != 0) return UNETK_E_UNSUPPORTED;
   UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(p));
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_stride, p, N,
+  hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_stride, p, N,
                      H, W, C);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+extern "C" int unetk_maxpool2_fwd_bf16(const void* x, int x_stride, void* p, int N, int H, int W, int C, void* stream) {
+  UNETK_REQUIRE(x && p && N > 0 && H > 1 && W > 1 && C > 0 && x_stride >= C);
+  if (C % 4 != 0 || x_stride % 4 != 0) return UNETK_E_UNSUPPORTED;
+  UNETK_REQUIRE(unetk_aligned8(x) && unetk_aligned8(p));
+  const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, x_stride, (bf16_t*)p, N, H, W, C);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
@@ -204,8 +217,22 @@ extern "C" int unetk_maxpool2_bwd(const float* x, int x_stride, const float* p, 
   UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(p) && unetk_aligned16(dp) && unetk_aligned16(dx));
   UNETK_REQUIRE(!add || (add_stride >= C && add_stride % 4 == 0 && unetk_aligned16(add)));
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_stride, p, dp,
+  hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_stride, p, dp,
                      add, add_stride, dx, N, H, W, C);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+extern "C" int unetk_maxpool2_bwd_bf16(const void* x, int x_stride, const void* p, const void* dp, const void* add,
+                                       int add_stride, void* dx, int N, int H, int W, int C, void* stream) {
+  UNETK_REQUIRE(x && p && dp && dx && N > 0 && H > 1 && W > 1 && C > 0 && x_stride >= C);
+  if (C % 4 != 0 || x_stride % 4 != 0 || (H & 1) || (W & 1)) return UNETK_E_UNSUPPORTED;
+  UNETK_REQUIRE(unetk_aligned8(x) && unetk_aligned8(p) && unetk_aligned8(dp) && unetk_aligned8(dx));
+  UNETK_REQUIRE(!add || (add_stride >= C && add_stride % 4 == 0 && unetk_aligned8(add)));
+  const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, x_stride, (const bf16_t*)p, (const bf16_t*)dp, (const bf16_t*)add, add_stride,
+                     (bf16_t*)dx, N, H, W, C);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }

@@ -68,10 +68,11 @@ def _igemm_tag(cin, cout, bf16=False, h=0, n=1 << 20, w=1 << 10):
     def cdiv(a, b):
         return -(-a // b)
     if bf16 and cin % 32 == 0 and cout % 32 == 0:
+        bs = ",true>" if int(bf16) == _abi.BF16S else ">"          # <..., BS = true>: bf16 storage
         if cout % 128 == 0:
-            return "conv3x3_igemm_bf16_kernel<4,2,4,2>" if h >= 24 else "conv3x3_igemm_bf16_kernel<2,2,2,2>"
+            return ("conv3x3_igemm_bf16_kernel<4,2,4,2" if h >= 24 else "conv3x3_igemm_bf16_kernel<2,2,2,2") + bs
         if cout % 64 == 0:
-            return "conv3x3_igemm_bf16_kernel<4,1,2,2>" if h >= 12 else "conv3x3_igemm_bf16_kernel<4,1,1,2>"
+            return ("conv3x3_igemm_bf16_kernel<4,1,2,2" if h >= 12 else "conv3x3_igemm_bf16_kernel<4,1,1,2") + bs
         return "conv3x3_igemm_bf16_kernel<4,1,2,1>"
     if cin % 16 == 0 and cout % 128 == 0:
         if n * cdiv(h, 8) * cdiv(w, 16) * (cout // 128) < 384:      # under-filled grid: half-height tiles
@@ -116,6 +117,26 @@ def conv_uses_bf16(cin, cout):
     return cin % 32 == 0 and cout % 32 == 0
 
 
+def precision_of(flag):
+    """NormSpec.bf16 / --compute_dtype -> UNETK_FP32 (0) | UNETK_BF16 (1: bf16 MFMA operands, fp32 tensors) |
+    UNETK_BF16S (2: bf16 MFMA + bf16 STORAGE of activations and activation gradients, include/unetk.h)."""
+    if flag is True:
+        return _abi.BF16
+    return int(flag or 0)
+
+
+def storage_dtype(prec):
+    return torch.bfloat16 if int(prec) == _abi.BF16S else torch.float32
+
+
+def _storage_of(t):
+    """Descriptor `storage` value of an activation tensor."""
+    if t.dtype == torch.bfloat16:
+        return _abi.BF16S
+    assert t.dtype == torch.float32, t.dtype
+    return _abi.FP32
+
+
 def conv3x3_pack(w, want_dgrad=True, bf16=False):
     _require_cuda(w)
     kh, kw, cin, cout = w.shape
@@ -123,6 +144,10 @@ def conv3x3_pack(w, want_dgrad=True, bf16=False):
     if bf16:
         wp_f = torch.empty(9 * cin * cout, dtype=torch.bfloat16, device=w.device)
         wp_d = torch.empty_like(wp_f) if want_dgrad else None
+        if int(bf16) == _abi.BF16S:          # output channels pair-permuted inside 64-blocks (conv_igemm_bf16.hip)
+            check(_abi.lib().unetk_conv3x3_pack_bf16s(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()),
+                  "conv3x3_pack_bf16s")
+            return wp_f, wp_d
         check(_abi.lib().unetk_conv3x3_pack_bf16(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()),
               "conv3x3_pack_bf16")
         return wp_f, wp_d
@@ -137,12 +162,19 @@ def conv_uses_mfma(cin, cout):
 
 
 def conv3x3_fwd(x, w, cout, want_stats=True, y=None, bf16=False, dilation=1):
-    """x NHWC (pixel-strided ok); w = packed filter if conv_uses_mfma(cin, cout) else raw HWIO."""
+    """x NHWC (pixel-strided ok); w = packed filter if conv_uses_mfma(cin, cout) else raw HWIO.
+    bf16 = precision (precision_of): under UNETK_BF16S x is bf16 (fp32 for the direct first-layer kernel) and y is bf16."""
     _require_cuda(x, w)
     n, h, wd, cin = x.shape
+    prec = precision_of(bf16)
     if y is None:
-        y = torch.empty((n, h, wd, cout), dtype=torch.float32, device=x.device)
-    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(x), _pix_stride(y), _abi.BF16 if bf16 else _abi.FP32, int(dilation))
+        y = torch.empty((n, h, wd, cout), dtype=storage_dtype(prec), device=x.device)
+    if prec == _abi.BF16S:
+        assert y.dtype == torch.bfloat16 and x.dtype == (torch.bfloat16 if conv_uses_mfma(cin, cout) else torch.float32), \
+            (x.dtype, y.dtype, cin, cout)
+    else:
+        assert x.dtype == torch.float32 and y.dtype == torch.float32
+    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(x), _pix_stride(y), prec, int(dilation))
     stats = None
     rows = 0
     if want_stats:
@@ -160,9 +192,11 @@ def conv3x3_fwd(x, w, cout, want_stats=True, y=None, bf16=False, dilation=1):
 def conv3x3_dgrad(dy, wp_dgrad, cin, x_stride=None, dx=None, bf16=False, dilation=1):
     _require_cuda(dy, wp_dgrad)
     n, h, wd, cout = dy.shape
+    prec = precision_of(bf16)
+    assert dy.dtype == storage_dtype(prec), (dy.dtype, prec)
     if dx is None:
-        dx = torch.empty((n, h, wd, cin), dtype=torch.float32, device=dy.device)
-    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(dx), _pix_stride(dy), _abi.BF16 if bf16 else _abi.FP32, int(dilation))
+        dx = torch.empty((n, h, wd, cin), dtype=dy.dtype, device=dy.device)
+    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(dx), _pix_stride(dy), prec, int(dilation))
     with _Timed(_igemm_tag(cout, cin, bf16, h, n, wd), 18.0 * n * h * wd * cin * cout, "dgrad {}x{}x{} {}->{}".format(n, h, wd, cout, cin)):
         check(_abi.lib().unetk_conv3x3_dgrad(ctypes.byref(d), ptr(dy), ptr(wp_dgrad), ptr(dx), stream_ptr()),
               "conv3x3_dgrad")
@@ -173,7 +207,10 @@ def conv3x3_wgrad(x, dy, bf16=False, dilation=1):
     _require_cuda(x, dy)
     n, h, wd, cin = x.shape
     cout = dy.shape[3]
-    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(x), _pix_stride(dy), _abi.BF16 if bf16 else _abi.FP32, int(dilation))
+    prec = precision_of(bf16)
+    if prec == _abi.BF16S:
+        assert dy.dtype == torch.bfloat16 and x.dtype == (torch.bfloat16 if cin % 64 == 0 else torch.float32), (x.dtype, dy.dtype)
+    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(x), _pix_stride(dy), prec, int(dilation))
     nbytes = _abi.lib().unetk_conv3x3_wgrad_ws_bytes(ctypes.byref(d))
     if nbytes == 0:
         raise _abi.UnetkError("conv3x3_wgrad: unsupported shape Cin={} Cout={}".format(cin, cout))
@@ -182,6 +219,8 @@ def conv3x3_wgrad(x, dy, bf16=False, dilation=1):
     tag = "conv3x3_wgrad_kernel(+slab_reduce)" if cin % 64 == 0 else "conv3x3_wgrad_c3_kernel(+slab_reduce)"
     if bf16 and cin % 32 == 0:
         tag = "conv3x3_wgrad_kernel<bf16>(+slab_reduce)"
+    if prec == _abi.BF16S:
+        tag = "conv3x3_wgrad_bf16s_kernel(+slab_reduce)" if cin % 64 == 0 else "conv3x3_wgrad_c3_bf16s_kernel(+slab_reduce)"
     with _Timed(tag, 18.0 * n * h * wd * cin * cout, "{}x{}x{} {}->{}".format(n, h, wd, cin, cout)):
         check(_abi.lib().unetk_conv3x3_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes,
                                              stream_ptr()), "conv3x3_wgrad")
@@ -281,7 +320,8 @@ def norm_finalize(d, stats, rows, gamma, beta, eps, decay, training, moving_mean
 
 
 def norm_apply_relu(d, y, aff, z, guide=None, gw=None, gb=None, den=None):
-    assert y.is_contiguous()
+    assert y.is_contiguous() and y.dtype == z.dtype
+    d.storage = _storage_of(y)
     if den is not None:
         assert den.is_contiguous() and tuple(den.shape) == (d.N, d.C), (tuple(den.shape), d.N, d.C)
     check(_abi.lib().unetk_norm_apply_relu(ctypes.byref(d), ptr(y), ptr(aff[2]), ptr(aff[3]), ptr(den), ptr(guide),
@@ -291,6 +331,8 @@ def norm_apply_relu(d, y, aff, z, guide=None, gw=None, gb=None, den=None):
 
 def norm_relu_bwd(d, y, dz, aff, has_gamma, has_beta, guide=None, gw=None, gb=None, den=None):
     dev = y.device
+    assert dz.dtype == y.dtype, (dz.dtype, y.dtype)
+    d.storage = _storage_of(y)
     dy = torch.empty_like(y)
     dden = torch.empty_like(den) if den is not None else None
     dgamma = torch.empty((d.C,), dtype=torch.float32, device=dev) if has_gamma else None
@@ -358,20 +400,22 @@ def avgpool2_fwd(x):
 def maxpool2_fwd(x):
     _require_cuda(x)
     n, h, w, c = x.shape
-    p = torch.empty((n, h // 2, w // 2, c), dtype=torch.float32, device=x.device)
-    check(_abi.lib().unetk_maxpool2_fwd(ptr(x), _pix_stride(x), ptr(p), n, h, w, c, stream_ptr()), "maxpool2_fwd")
+    p = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+    fn = _abi.lib().unetk_maxpool2_fwd_bf16 if _storage_of(x) == _abi.BF16S else _abi.lib().unetk_maxpool2_fwd
+    check(fn(ptr(x), _pix_stride(x), ptr(p), n, h, w, c, stream_ptr()), "maxpool2_fwd")
     return p
 
 
 def maxpool2_bwd(x, p, dp, add=None):
     """dx = route(dp) [+ add]; `add` may be a channel slice of a wider NHWC buffer (the concat buffer's gradient)."""
     n, h, w, c = x.shape
-    dx = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+    dx = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
+    assert dp.dtype == x.dtype and p.dtype == x.dtype
     if add is not None:
-        assert tuple(add.shape) == (n, h, w, c) and add.stride(3) == 1
-    check(_abi.lib().unetk_maxpool2_bwd(ptr(x), _pix_stride(x), ptr(p), ptr(dp.contiguous()), ptr(add),
-                                        _pix_stride(add) if add is not None else 0, ptr(dx), n, h, w, c,
-                                        stream_ptr()), "maxpool2_bwd")
+        assert tuple(add.shape) == (n, h, w, c) and add.stride(3) == 1 and add.dtype == x.dtype
+    fn = _abi.lib().unetk_maxpool2_bwd_bf16 if _storage_of(x) == _abi.BF16S else _abi.lib().unetk_maxpool2_bwd
+    check(fn(ptr(x), _pix_stride(x), ptr(p), ptr(dp.contiguous()), ptr(add),
+             _pix_stride(add) if add is not None else 0, ptr(dx), n, h, w, c, stream_ptr()), "maxpool2_bwd")
     return dx
 
 
@@ -382,6 +426,10 @@ def deconv2x2_pack(w, bf16=False):
     if bf16:
         wp_f = torch.empty(4 * cin * cout, dtype=torch.bfloat16, device=w.device)
         wp_d = torch.empty_like(wp_f)
+        if int(bf16) == _abi.BF16S:
+            check(_abi.lib().unetk_deconv2x2_pack_bf16s(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()),
+                  "deconv2x2_pack_bf16s")
+            return wp_f, wp_d
         check(_abi.lib().unetk_deconv2x2_pack_bf16(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()),
               "deconv2x2_pack_bf16")
         return wp_f, wp_d
@@ -394,8 +442,11 @@ def deconv2x2_pack(w, bf16=False):
 def deconv2x2_fwd(x, wp_fwd, bias, cat, coff, cout, bf16=False):
     n, h, w, cin = x.shape
     assert x.is_contiguous()
-    d = DeconvDesc(n, h, w, cin, cout, _pix_stride(cat), coff, _abi.BF16 if bf16 else _abi.FP32)
-    with _Timed("pw_gemm_bf16_kernel<fwd>" if bf16 else "pw_gemm_kernel<fwd>", 8.0 * n * h * w * cin * cout, "{}x{}x{} {}->{}".format(n, h, w, cin, cout)):
+    prec = precision_of(bf16)
+    assert x.dtype == storage_dtype(prec) and cat.dtype == x.dtype, (x.dtype, cat.dtype, prec)
+    d = DeconvDesc(n, h, w, cin, cout, _pix_stride(cat), coff, prec)
+    tag = {0: "pw_gemm_kernel<fwd>", 1: "pw_gemm_bf16_kernel<fwd>", 2: "pw_gemm_bf16_kernel<fwd,bs>"}[prec]
+    with _Timed(tag, 8.0 * n * h * w * cin * cout, "{}x{}x{} {}->{}".format(n, h, w, cin, cout)):
         check(_abi.lib().unetk_deconv2x2_fwd(ctypes.byref(d), ptr(x), ptr(wp_fwd), ptr(bias), ptr(cat), stream_ptr()),
               "deconv2x2_fwd")
     return cat
@@ -403,7 +454,9 @@ def deconv2x2_fwd(x, wp_fwd, bias, cat, coff, cout, bf16=False):
 
 def deconv2x2_bwd(x, wp_dgrad, cat, dcat, coff, cout, bf16=False):
     n, h, w, cin = x.shape
-    d = DeconvDesc(n, h, w, cin, cout, _pix_stride(cat), coff, _abi.BF16 if bf16 else _abi.FP32)
+    prec = precision_of(bf16)
+    assert x.dtype == storage_dtype(prec) and cat.dtype == x.dtype and dcat.dtype == x.dtype
+    d = DeconvDesc(n, h, w, cin, cout, _pix_stride(cat), coff, prec)
     assert _pix_stride(dcat) == _pix_stride(cat)
     nbytes = _abi.lib().unetk_deconv2x2_bwd_ws_bytes(ctypes.byref(d))
     if nbytes == 0:
@@ -412,7 +465,7 @@ def deconv2x2_bwd(x, wp_dgrad, cat, dcat, coff, cout, bf16=False):
     dx = torch.empty_like(x)
     dw = torch.empty((2, 2, cout, cin), dtype=torch.float32, device=x.device)
     db = torch.empty((cout,), dtype=torch.float32, device=x.device)
-    with _Timed("deconv2x2_bwd{}(relu_bwd+pw_gemm<dgrad>+deconv_wgrad)".format("<bf16>" if bf16 else ""),
+    with _Timed("deconv2x2_bwd{}(relu_bwd+pw_gemm<dgrad>+deconv_wgrad)".format({0: "", 1: "<bf16>", 2: "<bf16s>"}[prec]),
                 16.0 * n * h * w * cin * cout,
                 "{}x{}x{} {}->{}".format(n, h, w, cin, cout)):
         check(_abi.lib().unetk_deconv2x2_bwd(ctypes.byref(d), ptr(x), ptr(wp_dgrad), ptr(cat), ptr(dcat), ptr(dx),
@@ -483,6 +536,7 @@ def head_fwd(d, z, w, b, labels, pixel_w=None, want_probs=False):
     npix = d.N * d.HW
     dev = z.device
     assert z.is_contiguous()
+    d.storage = _storage_of(z)
     logits = torch.empty((npix, d.ncls), dtype=torch.float32, device=dev)
     probs = torch.empty_like(logits) if want_probs else None
     nres = _abi.lib().unetk_head_result_floats(ctypes.byref(d))
@@ -497,6 +551,7 @@ def head_fwd(d, z, w, b, labels, pixel_w=None, want_probs=False):
 
 
 def head_bwd(d, z, w, labels, pixel_w, logits, result, ws, xent_scale, dice_scale, dev_scales=None):
+    d.storage = _storage_of(z)
     dz = torch.empty_like(z)
     dw = torch.empty((d.C, d.ncls), dtype=torch.float32, device=z.device)
     db = torch.empty((d.ncls,), dtype=torch.float32, device=z.device)
@@ -573,7 +628,7 @@ class NormSpec(object):
         assert kind in ("batch_norm", "instance_norm", "none")   # "none" = --without_norm: conv + bias + ReLU
         self.kind, self.eps, self.decay, self.training = kind, eps, decay, training
         self.guide_leaky = False   # LGNet: leaky-ReLU on the guide branch before it is added
-        self.bf16 = bf16        # UNETK_BF16 contractions (operands rounded to bf16, fp32 accumulate / storage)
+        self.bf16 = precision_of(bf16)   # 0 fp32 | 1 UNETK_BF16 (bf16 operands, fp32 tensors) | 2 UNETK_BF16S (+ bf16 tensors)
 
     @property
     def per_sample(self):
@@ -595,7 +650,14 @@ class Conv3x3NormRelu(torch.autograd.Function):
         if den is not None:
             den = den.contiguous()
         mfma = conv_uses_mfma(cin, cout)
-        bf16 = bool(getattr(spec, "bf16", False)) and conv_uses_bf16(cin, cout)
+        prec = precision_of(getattr(spec, "bf16", 0))
+        bf16 = prec if conv_uses_bf16(cin, cout) else 0
+        if prec == _abi.BF16S:
+            # bf16 storage: the matrix kernels need 64-channel blocks on both sides; the first layer (small Cin, direct
+            # kernel) reads the fp32 image and writes bf16
+            if mfma and (cin % 64 or cout % 64):
+                raise _abi.UnetkError("bf16 storage needs Cin % 64 == 0 and Cout % 64 == 0 (got {}->{})".format(cin, cout))
+            bf16 = prec
         need_dx = ctx.needs_input_grad[0]
         if mfma:
             wp_f, wp_d = conv3x3_pack(w, want_dgrad=need_dx, bf16=bf16)
@@ -643,6 +705,8 @@ class Conv3x3NormRelu(torch.autograd.Function):
         x, y, aff, guide, gw, gb, den = ctx.saved_tensors
         if dz.stride(3) != 1:
             dz = dz.contiguous()
+        if dz.dtype != y.dtype:
+            raise _abi.UnetkError("gradient dtype {} does not match the stored activations ({})".format(dz.dtype, y.dtype))
         dden = None
         if den is None:
             dy, dgamma, dbeta, dgw, dgb = norm_relu_bwd(ctx.desc, y, dz, aff, ctx.has[0], ctx.has[1], guide, gw, gb)
@@ -822,7 +886,9 @@ class DeconvConcat(torch.autograd.Function):
         cout = w.shape[2]
         coff = cat.shape[3] - cout
         assert skip.data_ptr() == cat.data_ptr() and skip.shape[3] == coff
-        bf16 = bool(bf16) and conv_uses_bf16(w.shape[3], cout)
+        bf16 = precision_of(bf16) if conv_uses_bf16(w.shape[3], cout) else 0
+        if x.dtype == torch.bfloat16 and (bf16 != _abi.BF16S or w.shape[3] % 64 or cout % 64):
+            raise _abi.UnetkError("bf16 storage needs Cin % 64 == 0 and Cout % 64 == 0 in the transposed conv")
         wp_f, wp_d = deconv2x2_pack(w, bf16)
         deconv2x2_fwd(x, wp_f, b, cat, coff, cout, bf16)
         ctx.save_for_backward(x, cat)

@@ -9,7 +9,9 @@
  *
  * Conventions
  *   - all tensors are device pointers, fp32, NHWC, densely packed unless a
- *     "*_stride" (pixel stride, in floats) argument says otherwise; labels int32
+ *     "*_stride" (pixel stride, in ELEMENTS) argument says otherwise; labels int32.
+ *     Activation tensors passed as `void*` are fp32, or bf16 (2 bytes / element) when the
+ *     descriptor selects UNETK_BF16S ("bf16 storage", see below)
  *   - conv filters are TF HWIO [kh,kw,Cin,Cout]; transposed-conv filters are TF
  *     [kh,kw,Cout,Cin]  (slim.conv2d / slim.conv2d_transpose variable layouts)
  *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it
@@ -54,7 +56,7 @@ const char* unetk_error_string(int code);
 typedef struct unetk_conv_desc {
   int32_t N, H, W, Cin, Cout;
   int32_t x_stride, y_stride;
-  int32_t precision; /* UNETK_FP32 (exact fp32 MFMA) or UNETK_BF16 */
+  int32_t precision; /* UNETK_FP32 (exact fp32 MFMA), UNETK_BF16, or UNETK_BF16S (x / y / dy / dx are bf16) */
   int32_t dilation;  /* 0 / 1 = dense 3x3; 2 = slim.conv2d(..., rate=2) (SmallUNet.py:44-49: bridge, conv_d3/conv1):
                         taps at (2 kh, 2 kw), SAME pads 2.  fp32 only, Cin % 16 == 0 and Cout % 64 == 0 (wgrad: both % 64) */
 } unetk_conv_desc;
@@ -66,6 +68,14 @@ typedef struct unetk_conv_desc {
  * that layer) and filters packed by unetk_conv3x3_pack_bf16. */
 #define UNETK_FP32 0
 #define UNETK_BF16 1
+/* UNETK_BF16S = UNETK_BF16 arithmetic + bf16 STORAGE of activations and activation gradients (BASELINE.json
+ * configs[2]: "bf16 activations / weights-compute, fp32 master / accum / stats"): every tensor passed as `void*`
+ * (conv / deconv inputs and outputs, the norm's y / z / dz / dy, pooling, the head's feature map and its gradient)
+ * is bf16 in memory, rounded RNE from the fp32 accumulator by the kernel that produces it; statistics come from the
+ * fp32 accumulators, master weights, weight gradients, norm parameters and the optimiser stay fp32.  Halves the
+ * bytes of every HBM-bound pass and lets the filter gradient read its k-strided operands with ds_read_b64_tr_b16.
+ * The first conv (Cin < 16, direct kernel) reads fp32 images and writes bf16.  2-D, stride 1, dilation 1 only. */
+#define UNETK_BF16S 2
 
 /* Re-layout HWIO filters for the MFMA kernels ("K4-interleaved": [tap][Cin/4][Cout][4]).
  * wp_fwd feeds unetk_conv3x3_fwd; wp_dgrad (taps flipped, Cin<->Cout swapped) feeds
@@ -78,6 +88,13 @@ int unetk_conv3x3_pack(const float* w_hwio, int Cin, int Cout, float* wp_fwd, fl
 int unetk_conv3x3_pack_bf16(const float* w_hwio, int Cin, int Cout, void* wp_fwd, void* wp_dgrad,
                             void* stream);
 
+/* UNETK_BF16S filters: as unetk_conv3x3_pack_bf16, with the OUTPUT channels of each pack (Cout for wp_fwd, Cin for
+ * wp_dgrad) permuted inside every 64-channel block -- column position n' holds channel 2 (n' & 31) + (n' >> 5 & 1) -- so
+ * that a lane of the bf16-storage kernels owns two adjacent channels and stores them as one word.  Cin % 64 == 0 and
+ * Cout % 64 == 0. */
+int unetk_conv3x3_pack_bf16s(const float* w_hwio, int Cin, int Cout, void* wp_fwd, void* wp_dgrad,
+                             void* stream);
+
 /* Number of per-channel statistic partial rows unetk_conv3x3_fwd writes (one per pixel tile). */
 int unetk_conv3x3_stat_rows(const unetk_conv_desc* d);
 
@@ -86,18 +103,18 @@ int unetk_conv3x3_stat_rows(const unetk_conv_desc* d);
  * (2 * stat_rows * Cout floats; deterministic, no atomics).
  * `w` is wp_fwd from unetk_conv3x3_pack when Cin % 16 == 0 && Cout % 32 == 0, else the raw
  * HWIO filter (direct kernel; used by Encode1/conv1 where Cin = 3). */
-int unetk_conv3x3_fwd(const unetk_conv_desc* d, const float* x, const float* w, float* y,
+int unetk_conv3x3_fwd(const unetk_conv_desc* d, const void* x, const void* w, void* y,
                       float* stat_partials, void* stream);
 
 /* dx = conv3x3_input_grad(dy, w): d describes the FORWARD conv (dx has Cin channels,
  * pixel stride x_stride; dy has Cout channels, pixel stride y_stride).  `w` = wp_dgrad. */
-int unetk_conv3x3_dgrad(const unetk_conv_desc* d, const float* dy, const float* w, float* dx,
+int unetk_conv3x3_dgrad(const unetk_conv_desc* d, const void* dy, const void* w, void* dx,
                         void* stream);
 
 /* dw[HWIO] = conv3x3_filter_grad(x, dy).  Split-K over pixel tiles through a workspace of
  * fixed-order partial slabs (bit-reproducible). */
 size_t unetk_conv3x3_wgrad_ws_bytes(const unetk_conv_desc* d);
-int unetk_conv3x3_wgrad(const unetk_conv_desc* d, const float* x, const float* dy, float* dw,
+int unetk_conv3x3_wgrad(const unetk_conv_desc* d, const void* x, const void* dy, float* dw,
                         void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------- slim.conv3d  (NetworksV2/UNet3D.py:153,165)
@@ -144,6 +161,8 @@ typedef struct unetk_norm_desc {
   int32_t guide_leaky;         /* 1 = LGNet's guide branch (LGNet.py:30-55): the 1x1 guide conv is followed by
                                   tf.nn.leaky_relu (alpha 0.2) before the add: u = t + lrelu(guide . gw + gb);
                                   needs guide_ch > 0, no density gains */
+  int32_t storage;             /* UNETK_FP32: y / z / dz / dy are fp32; UNETK_BF16S: they are bf16 in memory (strides in
+                                  elements), arithmetic, statistics and parameter gradients stay fp32 */
 } unetk_norm_desc;
 
 /* Finalise the conv's statistic partials ([2][stat_rows][C], each image's tiles contiguous) into
@@ -161,18 +180,18 @@ int unetk_norm_finalize(const unetk_norm_desc* d, const float* stat_partials, in
  * the per-sample channel gains the context MLP (unetk_fc_*) produced.  gb may be given with guide_ch == 0: a bare
  * per-channel shift after the gain -- with den = gain * gamma' this is `after_affine` (slim_nets.channel_wise_affine,
  * GUNet.py:213-214: (net) * gamma' + beta') in the same pass. */
-int unetk_norm_apply_relu(const unetk_norm_desc* d, const float* y, const float* scale,
+int unetk_norm_apply_relu(const unetk_norm_desc* d, const void* y, const float* scale,
                           const float* shift, const float* den, const float* guide, const float* gw,
-                          const float* gb, float* z, void* stream);
+                          const float* gb, void* z, void* stream);
 
 /* Backward of z = relu(norm(y) [* den] [+ modulation]).  Pass 1: per-group column sums of dt and dt*xhat
  * (du = dz * (z > 0), dt = du * den) [and du*guide_g, du, du*t]; pass 2: dy.  dz has pixel stride dz_stride.
  * Outputs (nullable when the parameter does not exist): dgamma[C], dbeta[C], dden[N][C] (required with den),
  * dgw[guide_ch][C], dgb[C]. */
 size_t unetk_norm_bwd_ws_bytes(const unetk_norm_desc* d);
-int unetk_norm_relu_bwd(const unetk_norm_desc* d, const float* y, const float* dz, int dz_stride,
+int unetk_norm_relu_bwd(const unetk_norm_desc* d, const void* y, const void* dz, int dz_stride,
                         const float* scale, const float* shift, const float* mean, const float* rstd,
-                        const float* den, const float* guide, const float* gw, const float* gb, float* dy,
+                        const float* den, const float* guide, const float* gw, const float* gb, void* dy,
                         float* dgamma, float* dbeta, float* dden, float* dgw, float* dgb, void* ws,
                         size_t ws_bytes, void* stream);
 
@@ -196,6 +215,11 @@ int unetk_maxpool2_fwd(const float* x, int x_stride, float* p, int N, int H, int
                        void* stream);
 int unetk_maxpool2_bwd(const float* x, int x_stride, const float* p, const float* dp, const float* add,
                        int add_stride, float* dx, int N, int H, int W, int C, void* stream);
+/* UNETK_BF16S variants: x, p, dp, add, dx are bf16 (strides in elements); the skip gradient is summed in fp32 and
+ * rounded once. */
+int unetk_maxpool2_fwd_bf16(const void* x, int x_stride, void* p, int N, int H, int W, int C, void* stream);
+int unetk_maxpool2_bwd_bf16(const void* x, int x_stride, const void* p, const void* dp, const void* add,
+                            int add_stride, void* dx, int N, int H, int W, int C, void* stream);
 /* slim.avg_pool2d(gs, 2) of GUNet's spatial-guide pyramid (GUNet.py:157-158); x, p dense, any C. */
 int unetk_avgpool2_fwd(const float* x, float* p, int N, int H, int W, int C, void* stream);
 /* --img_grad (UNet.py:69-71, GUNet.py:335-338): out [N,H,W,3C] = concat(x, dy, dx) with
@@ -216,7 +240,8 @@ int unetk_flip_axpy(const float* x, float* out, int N, int H, int W, int C, int 
 typedef struct unetk_deconv_desc {
   int32_t N, H, W, Cin, Cout; /* input geometry; output is [N,2H,2W,Cout] */
   int32_t out_stride, out_coff;
-  int32_t precision; /* UNETK_FP32 / UNETK_BF16 (Cin % 32 == 0 and Cout % 32 == 0; filters from *_pack_bf16) */
+  int32_t precision; /* UNETK_FP32 / UNETK_BF16 (Cin % 32 == 0 and Cout % 32 == 0; filters from *_pack_bf16) /
+                        UNETK_BF16S (x, out / cat, dcat, dx are bf16; Cin % 64 == 0 and Cout % 32 == 0) */
 } unetk_deconv_desc;
 
 /* wp_fwd: [Cin/4][4*Cout][4]; wp_dgrad: [4*Cout/4][Cin][4]; each 4*Cin*Cout floats. */
@@ -225,13 +250,17 @@ int unetk_deconv2x2_pack(const float* w, int Cin, int Cout, float* wp_fwd, float
 /* UNETK_BF16: wp_fwd [Cin/8][4*Cout][8], wp_dgrad [4*Cout/8][Cin][8], each 4*Cin*Cout bf16. */
 int unetk_deconv2x2_pack_bf16(const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad,
                               void* stream);
-int unetk_deconv2x2_fwd(const unetk_deconv_desc* d, const float* x, const float* wp_fwd,
-                        const float* bias, float* out, void* stream);
+/* UNETK_BF16S: the bf16 packs with the GEMM columns permuted inside every 64-column block (see
+ * unetk_conv3x3_pack_bf16s).  Cin % 64 == 0 and Cout % 64 == 0. */
+int unetk_deconv2x2_pack_bf16s(const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad,
+                               void* stream);
+int unetk_deconv2x2_fwd(const unetk_deconv_desc* d, const void* x, const void* wp_fwd,
+                        const float* bias, void* out, void* stream);
 /* Backward.  dcat/cat: gradient and forward value of the concat buffer (same strides/offset as
  * `out`).  Produces dx [N,H,W,Cin], dw [2,2,Cout,Cin], dbias [Cout]. */
 size_t unetk_deconv2x2_bwd_ws_bytes(const unetk_deconv_desc* d);
-int unetk_deconv2x2_bwd(const unetk_deconv_desc* d, const float* x, const float* wp_dgrad,
-                        const float* cat, const float* dcat, float* dx, float* dw, float* dbias,
+int unetk_deconv2x2_bwd(const unetk_deconv_desc* d, const void* x, const void* wp_dgrad,
+                        const void* cat, const void* dcat, void* dx, float* dw, float* dbias,
                         void* ws, size_t ws_bytes, void* stream);
 
 /* slim.conv3d_transpose(x, c, kernel == stride in {(1,2,2), (2,2,2)}, biases_initializer=None) + tf.concat,
@@ -241,17 +270,17 @@ typedef struct unetk_deconv3d_desc {
   int32_t N, D, H, W, Cin, Cout;
   int32_t kd; /* depth kernel == depth stride: 1 or 2 */
   int32_t out_stride, out_coff;
-  int32_t precision; /* UNETK_FP32 / UNETK_BF16 */
+  int32_t precision; /* UNETK_FP32 / UNETK_BF16 / UNETK_BF16S (as unetk_deconv_desc) */
 } unetk_deconv3d_desc;
 int unetk_deconv3d_pack(const float* w, int kd, int Cin, int Cout, float* wp_fwd, float* wp_dgrad,
                         void* stream);
 int unetk_deconv3d_pack_bf16(const float* w, int kd, int Cin, int Cout, void* wp_fwd, void* wp_dgrad,
                              void* stream);
-int unetk_deconv3d_fwd(const unetk_deconv3d_desc* d, const float* x, const float* wp_fwd,
-                       const float* bias, float* out, void* stream);
+int unetk_deconv3d_fwd(const unetk_deconv3d_desc* d, const void* x, const void* wp_fwd,
+                       const float* bias, void* out, void* stream);
 size_t unetk_deconv3d_bwd_ws_bytes(const unetk_deconv3d_desc* d);
-int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const float* x, const float* wp_dgrad,
-                       const float* cat, const float* dcat, float* dx, float* dw, float* dbias,
+int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const void* x, const void* wp_dgrad,
+                       const void* cat, const void* dcat, void* dx, float* dw, float* dbias,
                        void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------- logits + loss head
@@ -264,6 +293,8 @@ typedef struct unetk_head_desc {
   int32_t weight_mode;                    /* UNETK_W_* */
   float numeric_w[UNETK_MAX_CLASSES];     /* --loss_numeric_w */
   float proportion_decay;                 /* --loss_proportion_decay (<=0: none) */
+  int32_t storage;                        /* UNETK_FP32, or UNETK_BF16S: the feature map z and its gradient dz are bf16
+                                             (logits, probabilities, losses and dw / db stay fp32) */
 } unetk_head_desc;
 
 /* Reduced outputs of the forward pass (device, floats), layout:
@@ -274,17 +305,17 @@ typedef struct unetk_head_desc {
 size_t unetk_head_result_floats(const unetk_head_desc* d);
 size_t unetk_head_ws_bytes(const unetk_head_desc* d);
 /* logits [N*HW, ncls] always written; probs (same shape) optional; pixel_w only for PIXELMAP. */
-int unetk_head_fwd(const unetk_head_desc* d, const float* z, const float* w, const float* b,
+int unetk_head_fwd(const unetk_head_desc* d, const void* z, const float* w, const float* b,
                    const int32_t* labels, const float* pixel_w, float* logits, float* probs,
                    float* result, void* ws, size_t ws_bytes, void* stream);
 /* Backward of (xent_scale * xent + dice_scale * dice) w.r.t. z, w, b.  `result` and `ws` are
  * the buffers the forward filled (ws keeps the per-sample weight tables).  dev_scales (nullable)
  * points at two device floats multiplied into xent_scale / dice_scale (upstream gradients that
  * live on the device -- avoids a host sync). */
-int unetk_head_bwd(const unetk_head_desc* d, const float* z, const float* w,
+int unetk_head_bwd(const unetk_head_desc* d, const void* z, const float* w,
                    const int32_t* labels, const float* pixel_w, const float* logits,
                    const float* result, float xent_scale, float dice_scale,
-                   const float* dev_scales, float* dz, float* dw, float* db, void* ws,
+                   const float* dev_scales, void* dz, float* dw, float* db, void* ws,
                    size_t ws_bytes, void* stream);
 /* Inference helpers: evaluators/evaluator_liver.py:663 np.argmax(prob, -1) (lowest index on ties)
  * and UNet.py:112-118 Pred_c = prob_c > 0.5 (uint8).  preds is [ncls-1][npix] or NULL. */

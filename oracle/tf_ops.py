@@ -89,6 +89,79 @@ def conv_same_bf16_operands(x, w):
     return _ConvSameBf16Operands.apply(x, w)
 
 
+class _StoreBf16(torch.autograd.Function):
+    """UNETK_BF16S ("bf16 storage", include/unetk.h; BASELINE.json configs[2]): a tensor that lives in HBM as bf16.  The
+    forward value is rounded when it is written; so is its gradient (the activation gradient is stored as bf16 too, and
+    when a tensor has two consumers their gradients are summed in fp32 and rounded once -- autograd hands the sum here)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return bf16_round(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return bf16_round(g)
+
+
+def store_bf16(x):
+    return _StoreBf16.apply(x)
+
+
+class _NormReluBf16S(torch.autograd.Function):
+    """Normalisation + ReLU of a conv unit under UNETK_BF16S, restating csrc/norm.hip with bf16 tensors:
+    statistics come from the conv's fp32 accumulators (the UNROUNDED y), the raw output is stored rounded (y_r), the
+    affine + ReLU reads y_r and its result is stored rounded; the backward recomputes u from y_r, uses xhat of y_r in
+    the batch-norm gradient formula (rounding is passed straight through) and stores dy rounded.
+    kind: "batch_norm" (statistics over all but the channel axis), "instance_norm" (per sample) or "none" (y + bias)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, kind, eps, mean_in, var_in):
+        axes = tuple(range(y.dim() - 1)) if kind == "batch_norm" else tuple(range(1, y.dim() - 1))
+        keep = kind == "instance_norm"
+        yr = bf16_round(y)
+        if kind == "none":
+            scale = torch.ones_like(beta)
+            mean = torch.zeros_like(beta)
+            rstd = torch.ones_like(beta)
+        else:
+            if mean_in is None:
+                mean = y.mean(dim=axes, keepdim=keep)
+                var = y.var(dim=axes, unbiased=False, keepdim=keep)
+            else:
+                mean, var = mean_in, var_in
+            rstd = torch.rsqrt(var + eps)
+            scale = rstd * gamma if gamma is not None else rstd
+        shift = (beta if beta is not None else 0.0) - mean * scale
+        u = yr * scale + shift
+        z = bf16_round(torch.relu(u))
+        ctx.save_for_backward(yr, u, mean, rstd, scale)
+        ctx.cfg = (kind, axes, keep, gamma is not None, beta is not None, mean_in is not None)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        yr, u, mean, rstd, scale = ctx.saved_tensors
+        kind, axes, keep, has_g, has_b, frozen = ctx.cfg
+        du = bf16_round(dz) * (u > 0).to(dz.dtype)
+        par_axes = tuple(range(yr.dim() - 1))
+        dbeta = du.sum(dim=par_axes) if has_b else None
+        if kind == "none":
+            return bf16_round(du), None, dbeta, None, None, None, None
+        xhat = (yr - mean) * rstd
+        dgamma = (du * xhat).sum(dim=par_axes) if has_g else None
+        if frozen:                       # eval-mode statistics: no dependence of the statistics on y
+            dy = scale * du
+        else:
+            k1 = du.mean(dim=axes, keepdim=keep)
+            k2 = (du * xhat).mean(dim=axes, keepdim=keep)
+            dy = scale * (du - k1 - xhat * k2)
+        return bf16_round(dy), dgamma, dbeta, None, None, None, None
+
+
+def norm_relu_bf16s(y, gamma, beta, kind, eps=0.0, mean=None, var=None):
+    return _NormReluBf16S.apply(y, gamma, beta, kind, eps, mean, var)
+
+
 def conv_transpose_ks(x, w, stride, bias=None):
     """slim.conv2d_transpose / conv3d_transpose with kernel == stride, SAME (B5).
 

@@ -113,12 +113,15 @@ class UNet2DOracle(object):
     # ------------------------------------------------------------------ layers
     def _conv_norm_relu(self, x, p, scope, is_training, new_stats, taps):
         w = p[scope + "/weights"]
-        if getattr(self, "bf16", False) and w.shape[2] % 32 == 0 and w.shape[3] % 32 == 0:
-            y = tf_ops.conv_same_bf16_operands(x, w)      # UNETK_BF16 emulation (3x3 units with Cin, Cout % 32 == 0)
+        mode = int(getattr(self, "bf16", 0) or 0)     # 0 fp32 | 1 UNETK_BF16 (operands) | 2 UNETK_BF16S (+ bf16 storage)
+        if mode and w.shape[2] % 32 == 0 and w.shape[3] % 32 == 0:
+            y = tf_ops.conv_same_bf16_operands(x, w)      # 3x3 units with Cin, Cout % 32 == 0 on the bf16 matrix cores
         else:
             y = tf_ops.conv_nd_same(x, w)
         if taps is not None:
             taps[scope + "/conv"] = y
+        if mode == 2:
+            return self._norm_relu_bf16s(y, p, scope, is_training, new_stats, taps)
         if self.without_norm:
             y = y + p[scope + "/biases"]
         elif self.normalizer == "batch_norm":
@@ -136,6 +139,31 @@ class UNet2DOracle(object):
             taps[scope] = y
         return y
 
+    def _norm_relu_bf16s(self, y, p, scope, is_training, new_stats, taps):
+        """The unit's norm + ReLU with bf16 tensors (tf_ops.norm_relu_bf16s): y is the fp32 accumulator of the conv; the
+        moving statistics are updated from it exactly as in the fp32 mode."""
+        if self.without_norm:
+            z = tf_ops.norm_relu_bf16s(y, None, p[scope + "/biases"], "none")
+        elif self.normalizer == "batch_norm":
+            bn = scope + "/BatchNorm"
+            mm, mv = p[bn + "/moving_mean"], p[bn + "/moving_variance"]
+            if is_training:
+                axes = tuple(range(y.dim() - 1))
+                mean, var = y.detach().mean(dim=axes), y.detach().var(dim=axes, unbiased=False)
+                m = y.numel() // y.shape[-1]
+                new_stats[bn + "/moving_mean"] = mm * self.bn_decay + mean * (1.0 - self.bn_decay)
+                new_stats[bn + "/moving_variance"] = mv * self.bn_decay + var * (m / max(m - 1, 1)) * (1.0 - self.bn_decay)
+                z = tf_ops.norm_relu_bf16s(y, p[bn + "/gamma"], p[bn + "/beta"], "batch_norm", self.bn_eps)
+            else:
+                new_stats[bn + "/moving_mean"], new_stats[bn + "/moving_variance"] = mm, mv
+                z = tf_ops.norm_relu_bf16s(y, p[bn + "/gamma"], p[bn + "/beta"], "batch_norm", self.bn_eps, mm, mv)
+        else:
+            inn = scope + "/InstanceNorm"
+            z = tf_ops.norm_relu_bf16s(y, p[inn + "/gamma"], p[inn + "/beta"], "instance_norm", self.in_eps)
+        if taps is not None:
+            taps[scope] = z
+        return z
+
     def forward(self, p, images, is_training, taps=None):
         """Returns (logits, new_moving_stats).  images: [bs,H,W,C] float."""
         new_stats = OrderedDict()
@@ -148,6 +176,8 @@ class UNet2DOracle(object):
             x = self._conv_norm_relu(x, p, s + "2", is_training, new_stats, taps)
             skips.append(x)
             x = tf_ops.max_pool2x2(x)
+            if int(getattr(self, "bf16", 0) or 0) == 2:
+                x = tf_ops.store_bf16(x)          # the pooled tensor and its gradient are bf16 in memory
             if taps is not None:
                 taps["{}/Encode{}/pool".format(n, i + 1)] = x
         x = self._conv_norm_relu(x, p, n + "/ED-Bridge/ED-Bridge_1", is_training, new_stats, taps)
@@ -159,9 +189,14 @@ class UNet2DOracle(object):
                                                             and wt.shape[3] % 32 == 0) else tf_ops.conv_transpose_ks
             up = convt(x, wt, (2, 2), bias=p[d + "/Conv2d_transpose/biases"])
             up = torch.relu(up)
+            bf16s = int(getattr(self, "bf16", 0) or 0) == 2
+            if bf16s:
+                up = tf_ops.store_bf16(up)        # written into the bf16 concat buffer
             if taps is not None:
                 taps[d + "/up"] = up
             x = torch.cat((skips[i], up), dim=-1)                   # UNet.py:93 skip first
+            if bf16s:
+                x = tf_ops.store_bf16(x)          # forward no-op; the concat buffer's GRADIENT is stored as bf16
             x = self._conv_norm_relu(x, p, d + "/Repeat/convolution2d_1", is_training, new_stats, taps)
             x = self._conv_norm_relu(x, p, d + "/Repeat/convolution2d_2", is_training, new_stats, taps)
         logits = tf_ops.conv_nd_same(x, p[n + "/AdjustChannels/weights"]) + p[n + "/AdjustChannels/biases"]

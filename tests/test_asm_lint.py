@@ -12,13 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 # kernels allowed to use scratch, with the reason.  Empty = none.
-KNOWN_SCRATCH = {
-    # found by this lint in round 2 (48 B of private arrays, not register-pressure spills: vgpr_spill_count 0); the
-    # small-plane / 2x2-wave instances of the round-1 bf16 kernels -- to be emptied by the bf16-storage rework
-    "conv3x3_igemm_bf16_kernel<2, 2, 2, 2>": "private array (48 B) in the 128x128 small-plane instance",
-    "pw_gemm_bf16_kernel<0, 2, 2, 2, 2>": "private array (48 B)",
-    "pw_gemm_bf16_kernel<1, 2, 2, 2, 2>": "private array (48 B)",
-}
+KNOWN_SCRATCH = {}       # round 2: the lint found 48-byte private arrays in three bf16 kernels (uint4 staging arrays SROA
+#                          did not promote) -- fixed with native vector types, see conv_igemm_bf16.hip
 
 
 @pytest.fixture(scope="module")
@@ -33,7 +28,8 @@ def test_every_kernel_compiles_and_matrix_kernels_are_found(rows):
     names = [r["kernel"] for r in rows]
     assert len(rows) > 100
     for stem in ("conv3x3_igemm_kernel<", "conv3x3_igemm_bf16_kernel<", "conv3x3_wgrad_kernel<", "pw_gemm_kernel<",
-                 "conv3x3_igemm_lin_kernel<", "deconv_wgrad_kernel<", "conv3x3_wgrad_c3_kernel"):
+                 "conv3x3_igemm_lin_kernel<", "deconv_wgrad_kernel<", "conv3x3_wgrad_c3_kernel", "conv3x3_wgrad_bf16s_kernel",
+                 "deconv_wgrad_bf16s_kernel"):
         assert any(stem in n for n in names), stem
 
 

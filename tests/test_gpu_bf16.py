@@ -153,7 +153,7 @@ def test_unet_bf16_step_against_both_oracles():
         tools/debug_bf16.py measures loss 9e-5, logits max 2.3e-2 / mean 3.7e-3, whole-gradient L2 0.18; the bars
         below are 3x those.  The well-conditioned no-norm net below carries the tight bars."""
     from boxsegliver_amd import ops
-    t, args, model, inputs, net, params, images, labels = _unet_pair("bf16")
+    t, args, model, inputs, net, params, images, labels = _unet_pair("bf16c")
     total, data_loss, logits, grads, _ = net.loss_and_grads(
         params, torch.from_numpy(images), torch.from_numpy(labels).long(), **t.loss_kwargs(args))
     ops.DEBUG_CAPTURE = []
@@ -205,7 +205,7 @@ def test_unet_bf16_no_norm_matches_the_bf16_arithmetic_oracle():
     (measured 9e-7 / 1.3e-3 / 2.3e-3) -- and it is closer to it than to the fp32-arithmetic oracle."""
     from oracle import unet2d
     import test_gpu_unet as t
-    args = t.make_args(im_height=64, im_width=64, compute_dtype="bf16", without_norm=True)
+    args = t.make_args(im_height=64, im_width=64, compute_dtype="bf16c", without_norm=True)
     images, labels = t.synth(2, 64, 64, 3)
     model, inputs = t.build(args, images, labels)
     net = unet2d.UNet2DOracle(3, 3, without_norm=True)
@@ -236,7 +236,7 @@ def test_unet_bf16_no_norm_matches_the_bf16_arithmetic_oracle():
 def test_unet_bf16_full_width_step_is_bit_reproducible():
     """bs 8 at 256x256 (every kernel walks many tiles per block / split, as at BASELINE.json's sizes): two runs of the
     same bf16 step give bit-identical loss and gradients (fixed-order reductions, no atomics, no read-before-ready)."""
-    t, args, model, inputs, *_ = _unet_pair("bf16", size=256, batch_size=8)
+    t, args, model, inputs, *_ = _unet_pair("bf16c", size=256, batch_size=8)
     images, labels = t.synth(8, 256, 256, 3)
     inputs = {"images": torch.from_numpy(images).cuda(), "labels": torch.from_numpy(labels).cuda()}
     runs = []
@@ -254,7 +254,7 @@ def test_unet_bf16_trains_like_fp32():
     """Five Adam steps in each mode from the same variables: the bf16 loss curve stays within 3 % of the fp32 one."""
     from boxsegliver_amd.core.solver import Solver
     curves = {}
-    for mode in ("fp32", "bf16"):
+    for mode in ("fp32", "bf16c"):
         t, args, model, inputs, *_ = _unet_pair(mode, size=32)
         solver = Solver(args)
         curve = []
@@ -264,7 +264,7 @@ def test_unet_bf16_trains_like_fp32():
             solver(loss, model)
         curves[mode] = np.array(curve)
     assert curves["fp32"][-1] < curves["fp32"][0]
-    np.testing.assert_allclose(curves["bf16"], curves["fp32"], rtol=3e-2)
+    np.testing.assert_allclose(curves["bf16c"], curves["fp32"], rtol=3e-2)
 
 
 @pytest.mark.parametrize("shape", [(2, 4, 8, 128, 64), (1, 2, 2, 1024, 512), (2, 8, 8, 256, 128), (1, 5, 3, 64, 32)])

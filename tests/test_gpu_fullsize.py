@@ -54,7 +54,7 @@ def test_gunet_config3_shape_against_device_float64_oracle():
 
 def test_unet_config2_shape_bf16_against_device_float64_oracle_of_the_same_arithmetic():
     import test_gpu_unet as t
-    args = t.make_args(batch_size=8, im_height=512, im_width=512, compute_dtype="bf16")
+    args = t.make_args(batch_size=8, im_height=512, im_width=512, compute_dtype="bf16c")
     images, labels = t.synth(8, 512, 512, 3)
     model, inputs = t.build(args, images, labels)
     net, params = t.oracle_for(args)
