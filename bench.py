@@ -151,9 +151,10 @@ def main():
     ap.add_argument("--model", default="UNet", choices=["UNet", "GUNet", "UNet3D", "UNetInter", "LGNet", "SmallUNet", "InterUNet"],
                     help="UNet = the headline workload (BASELINE.json configs[1]); GUNet / UNet3D = configs[3] / [4] "
                          "(use --batch 8 / --size 96 --batch 1..4)")
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
-                    help="fp32 = the headline configuration (exact fp32 MFMA); bf16 = BASELINE.json configs[2]'s mode: "
-                         "3x3 contractions on the bf16 matrix cores, fp32 accumulate/storage (use --size 512 --batch 8)")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "bf16c"],
+                    help="fp32 = the headline configuration (exact fp32 MFMA); bf16 = BASELINE.json configs[2]'s mode: bf16 "
+                         "matrix cores + bf16 storage of activations / activation gradients, fp32 accumulate / statistics / "
+                         "master weights (use --size 512 --batch 8); bf16c = bf16 MFMA operands only, fp32 storage (round 1)")
     ap.add_argument("--launch-check", action="store_true",
                     help="self-test of the multi-rank launch only (no kernels, no GPU needed): every rank joins the process "
                          "group, rank 0 prints the ranks it saw as a `launch-check` line")
@@ -284,7 +285,9 @@ def main():
             workload_name = "UNet 2D Liver+Tumor {0}x{0}x3 bs={1}/GPU fp32 (BASELINE.json " + cfg + ")"
         wl = workload_name.format(a.size, a.batch) + ", fwd+bwd+TF-Adam" + ("+{} grad all-reduce".format("RCCL" if backend == "nccl" else backend) if world > 1 else "")
         if a.dtype == "bf16":
-            wl = wl.replace(" fp32", " bf16-MFMA/fp32-accumulate+storage")
+            wl = wl.replace(" fp32", " bf16-MFMA + bf16 activation storage / fp32 accumulate, statistics, master weights")
+        elif a.dtype == "bf16c":
+            wl = wl.replace(" fp32", " bf16-MFMA operands / fp32 storage")
         peak = FP32_PEAK_TFLOPS if a.dtype == "fp32" else BF16_PEAK_TFLOPS
         if gflop_unit is None:      # conv / deconv algorithmic FLOPs (2 per MAC, fwd + dgrad + wgrad) of one unit, from the events
             gflop_unit = (sum(f for _, f, _, _ in prof) / a.steps / a.batch / 1e9) if prof else 0.0
@@ -296,6 +299,7 @@ def main():
             "rank_ms_per_step_min": round(min(rank_ms), 3), "rank_ms_per_step_max": round(max(rank_ms), 3),
             "dist_backend": (backend if world > 1 else None), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.dtype == "fp32" else "bf16", "data": "synthetic",
+            "compute_dtype_flag": a.dtype,
             "config": {"workload": wl, "global_batch": a.batch * world, "parallelism": "dp{}".format(world),
                        "classes": len(args.classes) + 1, "final_loss": round(loss_val, 5)},
             "whole_step_tflops": round(slices * gflop_unit / 1e3, 2),
@@ -328,7 +332,7 @@ def main():
             try:
                 import glob
                 import re
-                suffix = "" if a.dtype == "fp32" else "_bf16"
+                suffix = {"fp32": "", "bf16": "_bf16", "bf16c": "_bf16c"}[a.dtype]
                 files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic" + suffix + ".json")))
                 pmc = json.load(open(files[-1]))["kernels"] if files else {}
                 norm = {re.sub(r"(,1)+>", ">", k.replace(" ", "")): v for k, v in pmc.items()}   # <..., S=1, DIL=1> == the tag

@@ -197,7 +197,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
 
       store_w((step + 1) & 1);
       if (t == 8) store_halo((c + 1) & 1);
-      __syncthreads();
+      // NOT __syncthreads(): its fence waits for every outstanding global load (vmcnt(0)), i.e. it would force the halo
+      // prefetch of the next chunk -- issued at tap 0 for use at tap 8 -- to land within ONE tap step.  The LDS writes
+      // above must be complete (lgkmcnt(0)) before the barrier; the register-staged loads are tracked by the compiler.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
   }
 
@@ -307,9 +312,15 @@ struct BfCfg {
 // couts = 128 blocks on 256 CUs: 315 vs 277 slices/s at 512^2 bs 8 -- the bf16 kernels are bound by the L2 -> LDS stream,
 // which the tall tile halves per MFMA; so the choice depends on H only.)
 inline BfCfg pick_bf16(int H, int Cin, int Cout, int N = 1 << 20, int W = 1 << 10) {
-  (void)N; (void)W;
   if (Cin % CKB != 0 || Cout % 32 != 0) return {-1, 8};
-  if (Cout % 128 == 0) return H >= 24 ? BfCfg{0, 32} : BfCfg{1, 8};
+  if (Cout % 128 == 0) {
+    if (H < 24) return BfCfg{1, 8};
+    // the 32 x 32 level at batch 8: 512-pixel tiles give 64-128 blocks for 256 CUs; with bf16 storage (half the staging
+    // bytes per MFMA) the 128-pixel tile's 4x larger grid wins there (measured in round 2; with fp32 storage it did not)
+    const int64_t blocks = (int64_t)N * ((H + 31) / 32) * ((W + TW - 1) / TW) * (Cout / 128);
+    if (blocks < 200) return BfCfg{1, 8};
+    return BfCfg{0, 32};
+  }
   if (Cout % 64 == 0) return H >= 12 ? BfCfg{2, 16} : BfCfg{3, 8};
   return {4, 16};
 }

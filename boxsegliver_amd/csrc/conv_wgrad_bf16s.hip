@@ -10,10 +10,14 @@
 //   * per 16-pixel k-step a wave issues 2 transposed reads for its dy fragment and 3 per filter row for x (12 consecutive
 //     halo pixels of its channel); the three kw taps of a filter row are the windows [kw, kw + 8) of those 12 values --
 //     kw = 0 and kw = 2 are register sub-ranges, kw = 1 costs four v_alignbit.  11 reads per 9 MFMAs.
-//   * tiles arrive by async direct-to-LDS loads (global_load_lds_dwordx4, 1 KiB per wave instruction) into a 2-stage
-//     ring, as in the fp32 kernel; the image is lane-linear, so the bank swizzle is applied on the GLOBAL side: lane L of
-//     a piece fetches 16-byte chunk (L & 7) ^ 4 * bit1(row) of its row.  With it any four consecutive rows x 32 channels
-//     (one transposed read of a 32-lane half) cover four distinct 64-byte bank groups: conflict-free for every tap shift.
+//   * tiles arrive by async direct-to-LDS loads (global_load_lds_dwordx4, 1 KiB per wave instruction) into a FOUR-stage
+//     ring (160 KiB): a tile is ~1 us of MFMA work at the bf16 rate, less than one HBM round trip, so three tiles are
+//     kept in flight (the fp32 kernel's two stages left this kernel latency-bound at 3.6 us per tile).  Every wave
+//     issues exactly five pieces per tile (the 40th is a dummy), so "tile t has landed" is the constant s_waitcnt
+//     vmcnt(10); past the end of its range a block re-fetches its last tile to keep that count.  The image is
+//     lane-linear, so the bank swizzle is applied on the GLOBAL side: lane L of a piece fetches 16-byte chunk
+//     (L & 7) ^ 4 * bit1(row) of its row.  With it any four consecutive rows x 32 channels (one transposed read of a
+//     32-lane half) cover four distinct 64-byte bank groups: conflict-free for every tap shift.
 //   * 512 threads = 2 (ci) x 2 (co) x 2 (pixel-row halves) waves own a 64 x 64 x 9-tap panel; split-K over pixel tiles
 //     into slabs + the fixed-order slab reduction of conv_wgrad.hip => bit-reproducible, no atomics.
 #include "common.h"
@@ -25,11 +29,17 @@ constexpr int HALO_PIX = (TH + 2) * HWD;          // 180
 constexpr int CT = 64;                            // channels per panel side = one 128-byte LDS row
 constexpr int NP_X = (HALO_PIX + 7) / 8;          // 23 one-KiB pieces (8 rows each) of the x halo
 constexpr int NP_Y = TH * TW / 8;                 // 16 pieces of the dy tile
-constexpr int NP = NP_X + NP_Y;                   // 39
-constexpr int IPW = (NP + 7) / 8;                 // pieces per wave
-constexpr int XH_B = NP_X * 1024, STAGE_B = NP * 1024;
+constexpr int NP = NP_X + NP_Y;                   // 39 (+ 1 dummy so that every wave issues IPW loads per tile)
+constexpr int IPW = (NP + 7) / 8;                 // 5 pieces per wave
+constexpr int NSTAGE = 4;
+constexpr int XH_B = NP_X * 1024, STAGE_B = IPW * 8 * 1024;      // 40 KiB
 constexpr int RED_B = 4 * 144 * 64 * 4;           // pixel-row-half reduction scratch: [4 waves][9 x 16][64 lanes] floats
-constexpr int LDS_B = 2 * STAGE_B > RED_B ? 2 * STAGE_B : RED_B;
+constexpr int LDS_B = NSTAGE * STAGE_B > RED_B ? NSTAGE * STAGE_B : RED_B;
+static_assert(LDS_B <= 160 * 1024, "LDS budget");
+
+// 128 bytes of zeros in global memory: the source of out-of-image halo pixels for the direct-to-LDS loads (constant data;
+// the fp32 kernel memsets a page of its workspace per call instead -- one more launch)
+__device__ const uint32_t kZeroPage[32] = {};
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -73,6 +83,9 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
       const int pix = 8 * j + lrow;
       rel_h[i] = pix < HALO_PIX ? pix / HWD - 1 : (1 << 20);      // relative to the tile origin; 1 << 20 = dummy row
       rel_w[i] = pix % HWD - 1;
+    } else if (j >= NP) {
+      rel_h[i] = 1 << 20;                                          // the dummy 40th piece: zeros into the stage's spare KiB
+      rel_w[i] = 0;
     } else {
       const int pix = 8 * (j - NP_X) + lrow;
       rel_h[i] = pix / TW;
@@ -88,13 +101,13 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
       const int j = wave + 8 * i;
-      if (j < NP) {   // wave-uniform
+      {
         const bool is_x = j < NP_X;
         const int gh = h0 + rel_h[i], gw = w0 + rel_w[i];
         const bool ok = gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
         const int64_t pixoff = (int64_t)gh * p.W + gw;
         const bf16_t* src = is_x ? xb + ximg + pixoff * p.xs + ci0 + lchunk * 8 : dyb + yimg + pixoff * p.ys + co0 + lchunk * 8;
-        if (!ok) src = reinterpret_cast<const bf16_t*>(p.zeros) + (lane & 7) * 8;
+        if (!ok) src = reinterpret_cast<const bf16_t*>(kZeroPage) + (lane & 7) * 8;
         char* dst = smem + stage * STAGE_B + j * 1024;   // wave-uniform; lanes land at dst + lane * 16 B
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -119,40 +132,98 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
   const int t_begin = split * p.tiles_per_split;
   const int t_end = min(t_begin + p.tiles_per_split, p.total_tiles);
 
-  if (t_begin < t_end) issue_tile(t_begin, 0);
-  int stage = 0;
-  for (int tile = t_begin; tile < t_end; ++tile, stage ^= 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the tile have landed ...
-    __syncthreads();                                   // ... everybody's have, and the other stage is free
-    if (tile + 1 < t_end) issue_tile(tile + 1, stage ^ 1);
-
-    const char* xh = smem + stage * STAGE_B;
-    const char* dyt = xh + XH_B;
-    // this wave's four tile rows; (ks * 4) is even, so the swizzle parity of halo row (r + kh) is that of (rr + kh)
+  // prologue: three tiles in flight (indices clamped to the block's last tile: the ring then always holds IPW loads per
+  // stage and "tile t has landed" is vmcnt(2 * IPW))
+  if (t_begin < t_end) {
 #pragma unroll
-    for (int rr = 0; rr < TH / 2; ++rr) {
-      const int r = ks * (TH / 2) + rr;
-      const int brow = r * TW * 128 + b_off;
-      const uint2 b0 = tr_read(dyt, brow), b1 = tr_read(dyt, brow + 4 * 128);
-      const bf16x8 b = frag(b0.x, b0.y, b1.x, b1.y);
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int arow = (r + kh) * HWD * 128 + (((rr + kh) & 1) ? a_off1 : a_off0);
-        const uint2 a0 = tr_read(xh, arow), a1 = tr_read(xh, arow + 4 * 128), a2 = tr_read(xh, arow + 8 * 128);
-        // 12 consecutive halo pixels of this lane's channel: (a0.x a0.y a1.x a1.y a2.x a2.y), two pixels per word
-        acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(a0.x, a0.y, a1.x, a1.y), b, acc[kh * 3 + 0], 0, 0, 0);
-        acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-            frag(__builtin_amdgcn_alignbit(a0.y, a0.x, 16), __builtin_amdgcn_alignbit(a1.x, a0.y, 16),
-                 __builtin_amdgcn_alignbit(a1.y, a1.x, 16), __builtin_amdgcn_alignbit(a2.x, a1.y, 16)),
-            b, acc[kh * 3 + 1], 0, 0, 0);
-        acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(a0.y, a1.x, a1.y, a2.x), b, acc[kh * 3 + 2], 0, 0, 0);
-      }
-    }
+    for (int k = 0; k < NSTAGE - 1; ++k) issue_tile(min(t_begin + k, t_end - 1), k);
   }
+  // The main loop is hand-synchronised.  __syncthreads() carries a fence that waits for ALL outstanding memory operations
+  // (vmcnt(0): the three tiles in flight!), and the compiler guards every LDS read that follows a direct-to-LDS load with
+  // another vmcnt(0) (it cannot tell the ring's stages apart) -- together they serialised loads and MFMAs (measured:
+  // time = loads + compute).  So: a bare s_barrier after a counted vmcnt, and the transposed reads are inline asm with
+  // counted lgkmcnt waits whose "+v" operands tie the consuming MFMAs behind them.
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+#define TR_READ(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define LGKM_WAIT3(n, r0, r1, r2) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(r0), "+v"(r1), "+v"(r2))
+#define LGKM_WAIT5(n, r0, r1, r2, r3, r4) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4))
+#define LO(v) ((uint32_t)(v))
+#define HI(v) ((uint32_t)((v) >> 32))
+  // MFMAs of one halo row hr (12 pixels of this lane's channel in a0 a1 a2) against the dy row rr_: filter row kh = hr - rr_
+#define ROW_MFMA(kh_, a0, a1, a2, b0, b1)                                                                                  \
+  {                                                                                                                        \
+    const bf16x8 bb = frag(LO(b0), HI(b0), LO(b1), HI(b1));                                                                \
+    acc[(kh_) * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(LO(a0), HI(a0), LO(a1), HI(a1)), bb, acc[(kh_) * 3 + 0], 0, 0, 0); \
+    acc[(kh_) * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                                          \
+        frag(__builtin_amdgcn_alignbit(HI(a0), LO(a0), 16), __builtin_amdgcn_alignbit(LO(a1), HI(a0), 16),                  \
+             __builtin_amdgcn_alignbit(HI(a1), LO(a1), 16), __builtin_amdgcn_alignbit(LO(a2), HI(a1), 16)),                 \
+        bb, acc[(kh_) * 3 + 1], 0, 0, 0);                                                                                  \
+    acc[(kh_) * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(HI(a0), LO(a1), HI(a1), LO(a2)), bb, acc[(kh_) * 3 + 2], 0, 0, 0); \
+  }
+  constexpr int AROW = HWD * 128, BROW = TW * 128;     // bytes between consecutive halo rows / dy tile rows
+  int stage = 0;
+  for (int tile = t_begin; tile < t_end; ++tile, stage = (stage + 1) & (NSTAGE - 1)) {
+    static_assert(IPW == 5 && NSTAGE == 4, "the wait count below is (NSTAGE - 2) * IPW");
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // this wave's pieces of `tile` have landed (two younger tiles may fly) ...
+    __builtin_amdgcn_s_barrier();                      // ... everybody's have, and every wave is done reading the stage of tile - 1
+    issue_tile(min(tile + NSTAGE - 1, t_end - 1), (stage + NSTAGE - 1) & (NSTAGE - 1));
+
+    // this wave's four tile rows r = 4 ks + rr read halo rows 4 ks + 0 .. 5 (parity of the swizzle = parity of the local
+    // index, 4 ks being even) and dy rows 4 ks + 0 .. 3.  Halo row hr serves the pairs (rr, kh = hr - rr).
+    const uint32_t xa0 = lds0 + stage * STAGE_B + ks * (TH / 2) * AROW + a_off0;   // even local halo rows
+    const uint32_t xa1 = lds0 + stage * STAGE_B + ks * (TH / 2) * AROW + a_off1;   // odd
+    const uint32_t yb = lds0 + stage * STAGE_B + XH_B + ks * (TH / 2) * BROW + b_off;
+    uint64_t B00, B01, B10, B11, B20, B21, B30, B31;
+    uint64_t P0, P1, P2, Q0, Q1, Q2;                   // halo rows, double-buffered: even rows in P, odd rows in Q
+    TR_READ(B00, yb, 0 * BROW);            TR_READ(B01, yb, 0 * BROW + 512);
+    TR_READ(B10, yb, 1 * BROW);            TR_READ(B11, yb, 1 * BROW + 512);
+    TR_READ(P0, xa0, 0 * AROW);            TR_READ(P1, xa0, 0 * AROW + 512);   TR_READ(P2, xa0, 0 * AROW + 1024);
+    // hr = 0: prefetch row 1 and dy row 2
+    TR_READ(Q0, xa1, 1 * AROW);            TR_READ(Q1, xa1, 1 * AROW + 512);   TR_READ(Q2, xa1, 1 * AROW + 1024);
+    TR_READ(B20, yb, 2 * BROW);            TR_READ(B21, yb, 2 * BROW + 512);
+    LGKM_WAIT5(5, P0, P1, P2, B00, B01);
+    ROW_MFMA(0, P0, P1, P2, B00, B01);
+    // hr = 1 (in Q): prefetch row 2 -> P is free once the MFMAs above have read it (program order), dy row 3
+    {
+      uint64_t R0, R1, R2;
+      TR_READ(R0, xa0, 2 * AROW);          TR_READ(R1, xa0, 2 * AROW + 512);   TR_READ(R2, xa0, 2 * AROW + 1024);
+      TR_READ(B30, yb, 3 * BROW);          TR_READ(B31, yb, 3 * BROW + 512);
+      LGKM_WAIT5(7, Q0, Q1, Q2, B10, B11);
+      ROW_MFMA(0, Q0, Q1, Q2, B10, B11);
+      ROW_MFMA(1, Q0, Q1, Q2, B00, B01);
+      // hr = 2 (in R): prefetch row 3 into Q
+      TR_READ(Q0, xa1, 3 * AROW);          TR_READ(Q1, xa1, 3 * AROW + 512);   TR_READ(Q2, xa1, 3 * AROW + 1024);
+      LGKM_WAIT5(5, R0, R1, R2, B20, B21);
+      ROW_MFMA(0, R0, R1, R2, B20, B21);
+      ROW_MFMA(1, R0, R1, R2, B10, B11);
+      ROW_MFMA(2, R0, R1, R2, B00, B01);
+    }
+    // hr = 3 (in Q): prefetch row 4 into P
+    TR_READ(P0, xa0, 4 * AROW);            TR_READ(P1, xa0, 4 * AROW + 512);   TR_READ(P2, xa0, 4 * AROW + 1024);
+    LGKM_WAIT5(3, Q0, Q1, Q2, B30, B31);
+    ROW_MFMA(0, Q0, Q1, Q2, B30, B31);
+    ROW_MFMA(1, Q0, Q1, Q2, B20, B21);
+    ROW_MFMA(2, Q0, Q1, Q2, B10, B11);
+    // hr = 4 (in P): prefetch row 5 into Q
+    TR_READ(Q0, xa1, 5 * AROW);            TR_READ(Q1, xa1, 5 * AROW + 512);   TR_READ(Q2, xa1, 5 * AROW + 1024);
+    LGKM_WAIT3(3, P0, P1, P2);
+    ROW_MFMA(1, P0, P1, P2, B30, B31);
+    ROW_MFMA(2, P0, P1, P2, B20, B21);
+    // hr = 5 (in Q)
+    LGKM_WAIT3(0, Q0, Q1, Q2);
+    ROW_MFMA(2, Q0, Q1, Q2, B30, B31);
+  }
+#undef TR_READ
+#undef LGKM_WAIT3
+#undef LGKM_WAIT5
+#undef ROW_MFMA
+#undef LO
+#undef HI
 
   // ---- sum the two pixel-row halves through LDS (fixed order), then the ks == 0 waves write the split's slab
   float* red = reinterpret_cast<float*>(smem);  // [4 waves][144][64 lanes]
   const int pidx = wci * 2 + wco;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-fetches still in flight must land before LDS is reused
   __syncthreads();
   if (ks == 1) {
 #pragma unroll
@@ -266,8 +337,9 @@ bool plan(int N, int H, int W, int Cin, int Cout, Plan* pl) {
     pl->n_ci_tiles = Cin / CT;
     pl->n_co_tiles = Cout / CT;
     const int panels = pl->n_ci_tiles * pl->n_co_tiles;
-    S = (512 + panels - 1) / panels;     // one 512-thread block per CU (144 KB of LDS) x 256 CUs x 2 rounds
-    if (pl->total_tiles / S < 16 && panels <= 256) S = (256 + panels - 1) / panels;
+    // ONE round of blocks: 256 CUs x one 512-thread block (160 KB of LDS) -- all blocks do equal work, and every extra
+    // split costs a 9 x Cin x Cout slab written and read again (with >= 256 panels there is no split and no reduction)
+    S = panels >= 256 ? 1 : (256 + panels - 1) / panels;
   } else if (9 * Cin <= 32 && Cout == CT) {
     pl->small = true;
     pl->n_ci_tiles = pl->n_co_tiles = 1;
@@ -295,12 +367,10 @@ int unetk_wgrad_bf16s_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipS
   if (!plan(p.N, p.H, p.W, p.Cin, p.Cout, &pl)) return UNETK_E_UNSUPPORTED;
   if (ws_bytes < unetk_wgrad_bf16s_ws_bytes(p.N, p.H, p.W, p.Cin, p.Cout)) return UNETK_E_WORKSPACE;
   if (p.ys % 8 != 0 || (!pl.small && p.xs % 8 != 0)) return UNETK_E_BADARG;       // 16-byte chunks of 8 bf16
-  p.zeros = (const float*)ws;
-  p.slab = (float*)ws + 64;
+  p.zeros = nullptr;
+  p.slab = pl.S == 1 ? dw : (float*)ws + 64;           // a single split writes the gradient in place
   p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.total_tiles = pl.total_tiles;
   p.tiles_per_split = pl.tiles_per_split; p.n_ci_tiles = pl.n_ci_tiles; p.n_co_tiles = pl.n_co_tiles;
-  hipError_t ez = hipMemsetAsync(ws, 0, 256, st);
-  if (ez != hipSuccess) return (int)ez;
   if (pl.small) {
     const size_t lds3 = (size_t)(TH * TW * CT + HALO_PIX * 4) * sizeof(float);
     hipLaunchKernelGGL(conv3x3_wgrad_c3_bf16s_kernel, dim3(pl.S), dim3(256), lds3, st, p);
@@ -315,5 +385,6 @@ int unetk_wgrad_bf16s_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipS
     hipLaunchKernelGGL(conv3x3_wgrad_bf16s_kernel, dim3(pl.S * pl.n_ci_tiles * pl.n_co_tiles), dim3(512), LDS_B, st, p);
     UNETK_LAUNCH_CHECK();
   }
+  if (pl.S == 1) return UNETK_OK;
   return unetk_launch_slab_reduce((const float*)ws + 64, pl.S, (int64_t)9 * p.Cin * p.Cout, dw, st);
 }

@@ -30,7 +30,8 @@ HeadWs head_ws(const unetk_head_desc* d) {
   HeadWs w{};
   const int N = d->N, ncls = d->ncls;
   int bps = (d->HW + 1023) / 1024;      // streaming, latency-bound kernels: enough blocks for ~8 waves per SIMD
-  if (bps > 64) bps = 64;
+  const int cap = N >= 32 ? 64 : (2048 + N - 1) / N;      // ~2048 blocks in all (a batch of 8 got only 512 with a flat cap of 64)
+  if (bps > cap) bps = cap;
   if (bps < 1) bps = 1;
   w.bps = bps;
   w.nq = head_nq(ncls);

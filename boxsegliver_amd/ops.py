@@ -70,7 +70,8 @@ def _igemm_tag(cin, cout, bf16=False, h=0, n=1 << 20, w=1 << 10):
     if bf16 and cin % 32 == 0 and cout % 32 == 0:
         bs = ",true>" if int(bf16) == _abi.BF16S else ">"          # <..., BS = true>: bf16 storage
         if cout % 128 == 0:
-            return ("conv3x3_igemm_bf16_kernel<4,2,4,2" if h >= 24 else "conv3x3_igemm_bf16_kernel<2,2,2,2") + bs
+            tall = h >= 24 and n * cdiv(h, 32) * cdiv(w, 16) * (cout // 128) >= 200     # pick_bf16 (conv_igemm_bf16.hip)
+            return ("conv3x3_igemm_bf16_kernel<4,2,4,2" if tall else "conv3x3_igemm_bf16_kernel<2,2,2,2") + bs
         if cout % 64 == 0:
             return ("conv3x3_igemm_bf16_kernel<4,1,2,2" if h >= 12 else "conv3x3_igemm_bf16_kernel<4,1,1,2") + bs
         return "conv3x3_igemm_bf16_kernel<4,1,2,1>"
