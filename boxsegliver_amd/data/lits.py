@@ -130,20 +130,32 @@ def png_encode(arr):
 
 
 # ------------------------------------------------------------------------------------------------- dataset lists
+def random_split_k_fold(items, k, seed=None):
+    """DataLoader/misc.py:24-42: shuffle with NumPy's legacy generator seeded by `seed`, cut into k consecutive blocks of
+    floor(n / k) items and deal the remainder one by one to the first folds (pinned on the reference's own output by
+    tests/golden/ref_k_folds.json)."""
+    items = list(items)
+    np.random.RandomState(seed).shuffle(items)       # == np.random.seed(seed); np.random.shuffle(items), state untouched
+    size = len(items) // k
+    folds = [items[i * size:(i + 1) * size] for i in range(k)]
+    for i, extra in enumerate(items[k * size:]):
+        folds[i].append(extra)
+    return folds
+
+
 def read_or_create_k_folds(path, list_, k_split=None, seed=None):
-    """DataLoader/misc.py:45-74 (the shipped data/LiTS/k_folds.txt came from k_split=5, seed=1357)."""
+    """DataLoader/misc.py:45-74: parse "Fold i:pid pid ..." lines, or create the split and write that file.  (The shipped
+    data/LiTS/k_folds.txt is read as is; it was not produced by seed 1357 under today's NumPy.)"""
     path = Path(path)
     if path.exists():
         with path.open() as f:
             return [line[line.find(":") + 1:].strip().split(" ") for line in f.readlines()]
     if not isinstance(k_split, int) or k_split <= 0:
         raise ValueError("Wrong `k_split` value. Need a positive integer, got {}".format(k_split))
-    items = list(list_)
-    np.random.RandomState(seed).shuffle(items)
-    k_folds = [[str(x) for x in items[i::k_split]] for i in range(k_split)]
+    k_folds = random_split_k_fold(list_, k_split, seed) if k_split > 1 else [list(list_)]
     with path.open("w") as f:
         for i, fold in enumerate(k_folds):
-            f.write("Fold %d:" % i + " ".join(fold) + "\n")
+            f.write("Fold %d:" % i + " ".join(str(x) for x in fold) + "\n")
     return k_folds
 
 
