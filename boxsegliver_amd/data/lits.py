@@ -222,90 +222,124 @@ class SliceStore(object):
 
 
 # ------------------------------------------------------------------------------------------------- sampler
-def gen_train_batch(data_list, batch_size, liver_percent=0., tumor_percent=0., random_scale=(1., 1.),
-                    random_window_level=False, config=None, seed=None):
-    """input_pipeline.py:285-378.  Yields per sample (slice indices [C] with -1 for zero padding, label slice index,
-    [off_y, off_x, crop_h, crop_w], pid, (clip_lo, clip_hi)); indices are slice numbers WITHIN the case."""
-    rnd, nrs = random.Random(seed), np.random.RandomState(seed)
-    d = data_list
-    keys = np.arange(len(d))
-    tumor_keys = [i for i in keys if len(d[i]["slices"]) > 0]
-    target_size = np.asarray((config.im_height, config.im_width), dtype=np.float32)
-    force_liver = math.ceil(batch_size * liver_percent)
-    force_tumor = math.ceil(batch_size * tumor_percent)
-    while True:
-        ci = np.concatenate((nrs.choice(tumor_keys, force_tumor, True) if force_tumor else np.zeros(0, np.int64),
-                             nrs.choice(keys, batch_size - force_tumor, True)), axis=0).astype(np.int64)
-        liver_counter = tumor_counter = 0
-        for i in ci:
-            case = d[int(i)]
-            crop_size = (target_size * nrs.uniform(*random_scale, size=2)).astype(np.int32).tolist()
-            size, pid = case["size"], case["PID"]
-            if tumor_counter < force_tumor:
-                tumor_slices = case["slices"]
-                ind = int(nrs.choice(np.arange(len(tumor_slices))))
-                selected = case["tumor_slices_index"][ind]
-                tumor_counter += 1
-                liver_counter += 1
-                obj_bb = tumor_slices[ind][rnd.randint(0, len(tumor_slices[ind]) - 1)]
-            elif liver_counter < force_liver:
-                selected = rnd.randint(case["bbox"][0], case["bbox"][3] - 1)
-                liver_counter += 1
-                obj_bb = case["bbox"][1:3] + case["bbox"][4:6]
-            else:
-                selected = rnd.randint(0, size[0] - 1)
-                obj_bb = [size[1], size[2], 0, 0]                           # object does not exist
-            rng_yl = max(obj_bb[2] + 5 - crop_size[0], 0)
-            rng_yr = min(obj_bb[0] - 5, size[1] - crop_size[0])
-            if rng_yl + 20 < rng_yr:
-                off_y = rnd.randint(rng_yl, rng_yr)
-            else:
-                off_y = rnd.randint(max(obj_bb[0] - 20, 0), min(int(obj_bb[0] * .75 + obj_bb[2] * .25), size[1] - crop_size[0]))
-            rng_xl = max(obj_bb[3] + 5 - crop_size[1], 0)
-            rng_xr = min(obj_bb[1] - 5, size[2] - crop_size[1])
-            if rng_xl + 20 < rng_xr:
-                off_x = rnd.randint(rng_xl, rng_xr)
-            else:
-                off_x = rnd.randint(max(obj_bb[1] - 20, 0), min((obj_bb[1] + obj_bb[3]) // 2, size[2] - crop_size[1]))
-            chans = [selected]
-            if config.im_channel > 1:
-                left = (config.im_channel - 1) // 2
-                for k in range(1, left + 1):
-                    chans.insert(0, selected - k if selected - k >= 0 else -1)
-                for k in range(1, config.im_channel - left):
-                    chans.append(selected + k if selected + k < size[0] else -1)
-            if random_window_level:
-                clip = (rnd.randint(10, 50) * IM_SCALE * 1., rnd.randint(500, 540) * IM_SCALE * 1.)
-            else:
-                clip = (50 * IM_SCALE * 1., 500 * IM_SCALE * 1.)
-            yield chans, selected, [off_y, off_x] + crop_size, pid, clip
+class TrainSampler(object):
+    """Which slices, crops and windows make up a training batch -- the sampling POLICY of the reference's python generator
+    (input_pipeline.py:285-378) as one vectorised draw per batch.
+
+    The reference yields one sample at a time from nested Python loops and feeds it through tf.data's per-sample map.  Here
+    the cases are flattened ONCE into numpy tables (volume extents, liver boxes, a CSR list of tumor slices and of the tumor
+    boxes on each of them) and `draw()` emits the whole batch at once: the `[bs, C + 7]` int32 table + `[bs, 2]` windows
+    that `unetk_lits_batch` consumes, with no per-sample Python.  The policy (not the random stream) is the reference's:
+      * the first ceil(bs * tumor_percent) samples come from cases WITH tumors: a uniformly chosen tumor slice, the crop
+        placed around a uniformly chosen tumor box of that slice; they also count as liver samples;
+      * then, up to ceil(bs * liver_percent) samples in all, a uniformly chosen slice of the liver's z range, the crop
+        placed around the liver box; the rest are uniformly chosen slices, crop anywhere;
+      * crop extent = target size x U(random_scale) per axis; the crop's origin is uniform in the range that keeps the
+        object box (shrunk by 5 px) inside the crop when that range is more than 20 px wide, else in
+        [box start - 20, a point between the box's start and its centre] clipped to the image (:337-352);
+      * neighbouring slices fill the other channels, -1 (zeros) outside the volume; window level uniform in
+        [10, 50] / [500, 540] HU-units x IM_SCALE when random_window_level else fixed 50 / 500; independent flip coins."""
+
+    def __init__(self, data_list, batch_size, config, liver_percent=0., tumor_percent=0., random_scale=(1., 1.),
+                 random_window_level=False, random_flip=0, seed=None):
+        self.bs, self.c = int(batch_size), int(config.im_channel)
+        self.target = np.array([config.im_height, config.im_width], dtype=np.float64)
+        self.scale = (float(random_scale[0]), float(random_scale[1]))
+        self.window, self.flip = bool(random_window_level), int(random_flip or 0)
+        self.rng = np.random.default_rng(seed)
+        d = list(data_list)
+        self.pid = np.array([int(c["PID"]) for c in d], dtype=np.int64)
+        self.size = np.array([c["size"] for c in d], dtype=np.int64)                       # [n, (depth, H, W)]
+        self.liver = np.array([c["bbox"] for c in d], dtype=np.int64)                      # [n, (z0, y0, x0, z1, y1, x1)]
+        # CSR: case -> its tumor slices -> the tumor boxes (y0, x0, y1, x1) on each
+        n_slices = np.array([len(c["slices"]) for c in d], dtype=np.int64)
+        self.slice_ptr = np.concatenate(([0], np.cumsum(n_slices)))
+        self.slice_z = np.array([z for c in d for z in c["tumor_slices_index"]], dtype=np.int64)
+        n_boxes = np.array([len(bx) for c in d for bx in c["slices"]], dtype=np.int64)
+        self.box_ptr = np.concatenate(([0], np.cumsum(n_boxes)))
+        self.boxes = np.array([b for c in d for bx in c["slices"] for b in bx], dtype=np.int64).reshape(-1, 4)
+        self.tumor_cases = np.flatnonzero(n_slices > 0)
+        self.n_tumor = int(math.ceil(self.bs * tumor_percent))
+        self.n_liver = max(int(math.ceil(self.bs * liver_percent)), self.n_tumor)          # tumor samples count as liver
+        if self.n_tumor and len(self.tumor_cases) == 0:
+            raise ValueError("tumor_percent > 0 needs at least one case with tumors")
+
+    def _randint(self, lo, hi):
+        """Uniform integers in [lo, hi] (inclusive, element-wise)."""
+        if np.any(hi < lo):
+            raise ValueError("empty crop range: the crop is larger than the slice")      # random.randint raises there
+        return lo + np.floor(self.rng.random(lo.shape) * (hi - lo + 1)).astype(np.int64)
+
+    def draw(self):
+        """One batch: dict(case [bs] index into data_list, pid, z, chans [bs, C] (-1 = zeros), box [bs, 4] = (off_y, off_x,
+        crop_h, crop_w), clip [bs, 2], flips [bs, 2], kind [bs] 0 tumor / 1 liver / 2 any)."""
+        bs, rng = self.bs, self.rng
+        j = np.arange(bs)
+        kind = np.where(j < self.n_tumor, 0, np.where(j < self.n_liver, 1, 2))
+        case = rng.integers(0, len(self.pid), bs)
+        if self.n_tumor:
+            case[:self.n_tumor] = self.tumor_cases[rng.integers(0, len(self.tumor_cases), self.n_tumor)]
+        depth, h, w = self.size[case, 0], self.size[case, 1], self.size[case, 2]
+        crop = np.floor(self.target[None, :] * rng.uniform(self.scale[0], self.scale[1], (bs, 2))).astype(np.int64)
+        # the slice and the object box (y0, x0, y1, x1) the crop is placed around; "no object" = an inverted box
+        z = np.floor(rng.random(bs) * depth).astype(np.int64)
+        obj = np.stack([h, w, np.zeros_like(h), np.zeros_like(w)], axis=1)
+        lv = kind == 1
+        if lv.any():
+            lb = self.liver[case[lv]]
+            z[lv] = lb[:, 0] + np.floor(rng.random(int(lv.sum())) * (lb[:, 3] - lb[:, 0])).astype(np.int64)
+            obj[lv] = lb[:, [1, 2, 4, 5]]
+        tm = kind == 0
+        if tm.any():
+            ct = case[tm]
+            s = self.slice_ptr[ct] + np.floor(rng.random(len(ct)) * (self.slice_ptr[ct + 1] - self.slice_ptr[ct])).astype(np.int64)
+            z[tm] = self.slice_z[s]
+            obj[tm] = self.boxes[self.box_ptr[s] + np.floor(rng.random(len(ct)) * (self.box_ptr[s + 1] - self.box_ptr[s])).astype(np.int64)]
+        off = np.empty((bs, 2), dtype=np.int64)
+        for ax, extent in ((0, h), (1, w)):
+            start, stop, cr = obj[:, ax], obj[:, ax + 2], crop[:, ax]
+            lo_in, hi_in = np.maximum(stop + 5 - cr, 0), np.minimum(start - 5, extent - cr)      # box (shrunk by 5) inside the crop
+            wide = lo_in + 20 < hi_in
+            anchor = np.floor(start * .75 + stop * .25).astype(np.int64) if ax == 0 else (start + stop) // 2
+            lo = np.where(wide, lo_in, np.maximum(start - 20, 0))
+            hi = np.where(wide, hi_in, np.minimum(anchor, extent - cr))
+            off[:, ax] = self._randint(lo, hi)
+        left = (self.c - 1) // 2
+        chans = z[:, None] + np.arange(-left, self.c - left)[None, :]
+        chans = np.where((chans >= 0) & (chans < depth[:, None]), chans, -1)
+        if self.window:
+            clip = np.stack([rng.integers(10, 51, bs), rng.integers(500, 541, bs)], axis=1).astype(np.float32) * IM_SCALE
+        else:
+            clip = np.tile(np.array([[50., 500.]], dtype=np.float32) * IM_SCALE, (bs, 1))
+        flips = np.stack([(rng.random(bs) < 0.5) & bool(self.flip & 1), (rng.random(bs) < 0.5) & bool(self.flip & 2)], axis=1)
+        return dict(case=case, pid=self.pid[case], z=z, chans=chans, box=np.concatenate([off, crop], axis=1), clip=clip,
+                    flips=flips.astype(np.int32), kind=kind)
+
+    def table(self, slice_offset):
+        """The batch as `unetk_lits_batch` takes it: int32 [bs, C + 7] = (resident-store indices of the C channel slices, of
+        the label slice, off_y, off_x, crop_h, crop_w, flip_lr, flip_ud), float32 [bs, 2] windows, int64 [bs] case ids.
+        slice_offset: {pid: index of the case's first slice in the resident store}."""
+        b = self.draw()
+        base = np.array([slice_offset[int(p)] for p in b["pid"]], dtype=np.int64)
+        tab = np.empty((self.bs, self.c + 7), dtype=np.int32)
+        tab[:, :self.c] = np.where(b["chans"] >= 0, base[:, None] + b["chans"], -1)
+        tab[:, self.c] = base + b["z"]
+        tab[:, self.c + 1:self.c + 5] = b["box"]
+        tab[:, self.c + 5:] = b["flips"]
+        return tab, b["clip"], b["pid"]
 
 
 def batches(store, data_list, config, training, seed=1234, liver_percent=0., tumor_percent=0., random_scale=(1., 1.)):
     """The tf.data pipelines get_dataset_for_train / get_dataset_for_eval_online (:381-430) as a generator of
-    (features, labels) device batches: the sampler on the host, everything else in `unetk_lits_batch`."""
+    (features, labels) device batches: one vectorised sampler draw on the host, everything else in `unetk_lits_batch`."""
     bs = distribution_utils.per_device_batch_size(config.batch_size, config.num_gpus)
     c = config.im_channel
-    gen = gen_train_batch(data_list, bs, liver_percent, tumor_percent, random_scale if training else (1., 1.),
-                          random_window_level=training, config=config, seed=seed)
-    rnd = random.Random(seed + 1)
-    rf = int(getattr(config, "random_flip", 0) or 0)
+    sampler = TrainSampler(data_list, bs, config, liver_percent, tumor_percent, random_scale if training else (1., 1.),
+                           random_window_level=training, random_flip=(getattr(config, "random_flip", 0) if training else 0),
+                           seed=seed)
     step = 0
     while True:
-        tab = np.zeros((bs, c + 7), dtype=np.int32)
-        clip = np.zeros((bs, 2), dtype=np.float32)
-        names = np.zeros((bs,), dtype=np.int64)
-        for j in range(bs):
-            chans, lab, box, pid, cl = next(gen)
-            off = store.offset[int(pid)]
-            tab[j, :c] = [off + z if z >= 0 else -1 for z in chans]
-            tab[j, c] = off + lab
-            tab[j, c + 1:c + 5] = box
-            if training:                                                     # image_ops.random_flip_*: one coin per sample
-                tab[j, c + 5] = int(rf & 1 > 0 and rnd.random() < 0.5)
-                tab[j, c + 6] = int(rf & 2 > 0 and rnd.random() < 0.5)
-            clip[j] = cl
-            names[j] = pid
+        tab, clip, names = sampler.table(store.offset)
         images, labels = ops.lits_batch(store.im, store.lb, torch.from_numpy(tab).to(store.device),
                                         torch.from_numpy(clip).to(store.device), (config.im_height, config.im_width), c,
                                         LB_SCALE, float(config.noise_scale) if training else 0.0, seed * 7919 + step)
@@ -389,78 +423,100 @@ def cv2_resize_linear(img, dsize):
     return (rows[:, x0] * (1.0 - fxb) + rows[:, x1] * fxb).astype(np.float32)
 
 
+def _grown_span(lo, hi, pad, extent, align, at_least=0):
+    """One axis of the evaluation window: the object's half-open span [lo, hi) grown by `pad`, clipped to [0, extent),
+    widened to `at_least` pixels if shorter, then its length rounded UP to a multiple of `align` about the same centre.
+    Returns (start, stop, wanted length); stop - start < wanted length when the far border clipped it."""
+    a, b = max(lo - pad, 0), min(hi + pad, extent)
+    if at_least:
+        if at_least > extent:
+            raise ValueError("Cannot satisfied conditions!")
+        if b - a < at_least:
+            a = min(max(a - (at_least - (b - a)) // 2, 0), extent - at_least)
+            b = a + at_least
+    want = -(-(b - a) // align) * align
+    start = max(int((a + b - 1) / 2 - (want - 1) / 2), 0)
+    return start, min(start + want, extent), want
+
+
+def aligned_window(case, align, padding, min_shape=None):
+    """The (y, x) window of a case that the evaluators cut from every slice: the liver box + `padding`, at least `min_shape`,
+    sides rounded up to `align` (input_pipeline.py:444-479,556-580).  When the far border clips EITHER axis so that its
+    side is no longer a multiple of `align`, BOTH axes are re-anchored at their far ends (the reference's rule; it warns
+    when that pushes a start below zero).  Returns (y1, y2, x1, x2)."""
+    _, h, w = case["size"]
+    bb = case["bbox"]
+    spans = [_grown_span(bb[1], bb[4], padding, h, align, min_shape[0] if min_shape else 0),
+             _grown_span(bb[2], bb[5], padding, w, align, min_shape[1] if min_shape else 0)]
+    if any((stop - start) % align for start, stop, _ in spans):
+        spans = [(stop - want, stop, want) for _, stop, want in spans]
+        if any(start < 0 for start, _, _ in spans):
+            print("\nWarning: bbox aligns with {} failed! point1 ({}, {}) point2 ({}, {})\n".format(
+                align, spans[1][0], spans[0][0], spans[1][1], spans[0][1]))
+    return spans[0][0], spans[0][1], spans[1][0], spans[1][1]
+
+
+def _load_lits_volume(case, root, test_data=False):
+    from . import nii_kits
+    obj_num = int(case["vol_case"][:-4].split("-")[-1])
+    if test_data:
+        return obj_num, nii_kits.read_nii(root / case["vol_case"])[1]
+    return obj_num, nii_kits.read_lits(obj_num, "vol", root / case["vol_case"])[1]
+
+
+def _window_normalise(volume):
+    """HU window [GRAY_MIN, GRAY_MAX] -> [0, 1], (z, y, x) -> (y, x, z) float32 (input_pipeline.py:595-596)."""
+    volume = (np.clip(volume, GRAY_MIN, GRAY_MAX) - GRAY_MIN) / (GRAY_MAX - GRAY_MIN)
+    return volume.transpose((1, 2, 0)).astype(np.float32)
+
+
 def parse_case_eval(case, align, padding, padding_z, im_channel, parse_label=True, test_data=False, proj_root="."):
     """input_pipeline.py:556-612: the liver box (+ padding, sides rounded up to `align`) of one NIfTI case ->
     normalised float32 volume (y, x, z) with the half-channel context slices, cropped uint8 segmentation (z, y, x)."""
     from . import nii_kits
     d, h, w = case["size"]
-    z1 = max(case["bbox"][0] - padding_z, 0)
-    z2 = min(case["bbox"][3] + padding_z, d)
-    y1 = max(case["bbox"][1] - padding, 0)
-    x1 = max(case["bbox"][2] - padding, 0)
-    y2 = min(case["bbox"][4] + padding, h)
-    x2 = min(case["bbox"][5] + padding, w)
-    cy = (y1 + y2 - 1) / 2
-    cx = (x1 + x2 - 1) / 2
-    sz_y = int(math.ceil((y2 - y1) / align)) * align
-    sz_x = int(math.ceil((x2 - x1) / align)) * align
-    y1 = max(int(cy - (sz_y - 1) / 2), 0)
-    x1 = max(int(cx - (sz_x - 1) / 2), 0)
-    y2 = min(y1 + sz_y, h)
-    x2 = min(x1 + sz_x, w)
-    if (y2 - y1) % align != 0 or (x2 - x1) % align != 0:
-        y1 = y2 - sz_y
-        x1 = x2 - sz_x
-        if y1 < 0 or x1 < 0:
-            print("\nWarning: bbox aligns with {} failed! point1 ({}, {}) point2 ({}, {})\n".format(align, x1, y1, x2, y2))
-
+    z1, z2 = max(case["bbox"][0] - padding_z, 0), min(case["bbox"][3] + padding_z, d)
+    y1, y2, x1, x2 = aligned_window(case, align, padding)
     root = Path(proj_root)
-    obj_num = int(case["vol_case"][:-4].split("-")[-1])
-    if test_data:
-        _, volume = nii_kits.read_nii(root / case["vol_case"])
-    else:
-        _, volume = nii_kits.read_lits(obj_num, "vol", root / case["vol_case"])
-    lhc = (im_channel - 1) // 2
+    obj_num, volume = _load_lits_volume(case, root, test_data)
+    lhc = (im_channel - 1) // 2                       # context slices before / after the centre slice of a sample
     rhc = im_channel - 1 - lhc
-    left_pad = lhc - z1 if z1 < lhc else 0
-    right_pad = z2 + rhc - d if z2 + rhc > d else 0
-    volume = volume[max(0, z1 - lhc):min(d, z2 + rhc), y1:y2, x1:x2]
-    cd, ch, cw = volume.shape
-    if left_pad > 0 or right_pad > 0:
-        volume = np.concatenate((np.zeros((left_pad, ch, cw), dtype=volume.dtype), volume,
-                                 np.zeros((right_pad, ch, cw), dtype=volume.dtype)), axis=0)
-        cd, ch, cw = volume.shape
-    volume = (np.clip(volume, GRAY_MIN, GRAY_MAX) - GRAY_MIN) / (GRAY_MAX - GRAY_MIN)
-    volume = volume.transpose((1, 2, 0)).astype(np.float32)
-
+    lo, hi = z1 - lhc, z2 + rhc                       # zero slices stand in for context beyond the volume
+    volume = np.pad(volume[max(lo, 0):min(hi, d), y1:y2, x1:x2], ((max(-lo, 0), max(hi - d, 0)), (0, 0), (0, 0)))
+    cshape = list(volume.shape)
+    volume = _window_normalise(volume)
     segmentation, lab_case = None, None
     if parse_label:
         _, segmentation = nii_kits.read_lits(obj_num, "lab", root / case["lab_case"])
         segmentation = segmentation.astype(np.uint8)[z1:z2, y1:y2, x1:x2]
         lab_case = case["lab_case"]
     bbox = [x1, y1, z1, x2 - 1, y2 - 1, z2 - 1]
-    return case["PID"], case["vol_case"], lab_case, bbox, [d, h, w], [cd, ch, cw], lhc, rhc, volume, segmentation
+    return case["PID"], case["vol_case"], lab_case, bbox, [d, h, w], cshape, lhc, rhc, volume, segmentation
 
 
 def _mirrored(eval_batch, config):
-    """input_pipeline.py:538-553 (the `random_flip & 3 > 0` test is the reference's, literally)."""
+    """The mirrored copies of a slab under --eval_mirror (input_pipeline.py:538-553): variant 1 = flipped along W when
+    random_flip has bit 0, 2 = along H with bit 1, 3 = both -- the last one whenever `random_flip & 3 > 0`, i.e. also for
+    random_flip 1 and 2 (the reference's test, kept literally; evaluators.mirror_plan averages accordingly)."""
     if not getattr(config, "eval_mirror", False):
         return
-    if config.random_flip & 1 > 0:
-        tmp = copy.copy(eval_batch)
-        tmp["images"] = np.flip(tmp["images"], axis=2)
-        tmp["mirror"] = 1
-        yield tmp, None
-    if config.random_flip & 2 > 0:
-        tmp = copy.copy(eval_batch)
-        tmp["images"] = np.flip(tmp["images"], axis=1)
-        tmp["mirror"] = 2
-        yield tmp, None
-    if config.random_flip & 3 > 0:
-        tmp = copy.copy(eval_batch)
-        tmp["images"] = np.flip(np.flip(tmp["images"], axis=2), axis=1)
-        tmp["mirror"] = 3
-        yield tmp, None
+    rf = int(config.random_flip)
+    for variant, wanted, axes in ((1, rf & 1, (2,)), (2, rf & 2, (1,)), (3, rf & 3, (1, 2))):
+        if wanted > 0:
+            yield dict(eval_batch, images=np.flip(eval_batch["images"], axis=axes), mirror=variant), None
+
+
+def _slabs(volume, batch_size, lhc, rhc, head, config):
+    """Serve a (y, x, z) volume as batch_size-slice slabs with (lhc, rhc) context slices per sample, each followed by its
+    mirrored copies.  `head` = the constant entries of every slab's feature dict."""
+    n = volume.shape[-1] - lhc - rhc
+    assert n % batch_size == 0, "Wrong padding"
+    win = np.lib.stride_tricks.sliding_window_view(volume, lhc + rhc + 1, axis=-1)      # [y, x, n, c] without copying
+    for idx in range(0, n, batch_size):
+        slab = dict(head, images=np.ascontiguousarray(np.moveaxis(win[:, :, idx:idx + batch_size], 2, 0)), mirror=0)
+        yield slab, None
+        for item in _mirrored(slab, config):
+            yield item
 
 
 def get_dataset_for_eval_image_v2(data_list, config, proj_root="."):
@@ -478,20 +534,12 @@ def get_dataset_for_eval_image_v2(data_list, config, proj_root="."):
             case, align, padding, padding_z, c, parse_label=getattr(config, "mode", "eval") != "infer", proj_root=proj_root)
         if not resize:
             pshape = tuple(cshape[1:])
-        eval_batch = {"images": np.empty((batch_size,) + tuple(pshape) + (c,), dtype=np.float32), "names": pid, "mirror": 0}
-        pads = (batch_size - ((bbox[5] - bbox[2] + 1) % batch_size)) % batch_size
-        if pads > 0:
-            volume = np.concatenate((volume, np.zeros(tuple(cshape[1:]) + (pads,), volume.dtype)), axis=-1)
+        pads = -(bbox[5] - bbox[2] + 1) % batch_size          # zero slices that complete the last slab
+        volume = np.pad(volume, ((0, 0), (0, 0), (0, pads)))
         if resize:
             volume = cv2_resize_linear(volume, pshape)      # dsize = (im_height, im_width), as the reference passes it
-        nb = (volume.shape[-1] - lhc - rhc) // batch_size
-        assert volume.shape[-1] - lhc - rhc == batch_size * nb, "Wrong padding"
-        for idx in range(lhc, volume.shape[-1] - rhc, batch_size):
-            for j in range(batch_size):
-                eval_batch["images"][j] = volume[:, :, idx + j - lhc:idx + j + rhc + 1]
-            yield copy.copy(eval_batch), None
-            for item in _mirrored(eval_batch, config):
-                yield item
+        for item in _slabs(volume, batch_size, lhc, rhc, {"names": pid}, config):
+            yield item
         yield None, (segmentation, vol_path, pads, bbox, resize)
 
 
@@ -504,39 +552,22 @@ def get_dataset_for_eval_image(data_list, config, proj_root=".", test_data=False
     resize = not (config.im_height <= 0 or config.im_width <= 0)
     root = Path(proj_root)
     parse_label = getattr(config, "mode", "eval") != "infer"
+    lhc = (c - 1) // 2
+    rhc = c - 1 - lhc
     for case in data_list[getattr(config, "eval_skip_num", 0):]:
-        obj_num = int(case["vol_case"][:-4].split("-")[-1])
-        if test_data:
-            _, volume = nii_kits.read_nii(root / case["vol_case"])
-        else:
-            _, volume = nii_kits.read_lits(obj_num, "vol", root / case["vol_case"])
-        volume = (np.clip(volume, GRAY_MIN, GRAY_MAX) - GRAY_MIN) / (GRAY_MAX - GRAY_MIN)
-        volume = volume.transpose((1, 2, 0)).astype(np.float32)
+        obj_num, volume = _load_lits_volume(case, root, test_data)
+        volume = _window_normalise(volume)
         segmentation, seg_path = None, None
         if parse_label:
             _, segmentation = nii_kits.read_lits(obj_num, "lab", root / case["lab_case"])
             segmentation, seg_path = segmentation.astype(np.uint8), case["lab_case"]
-        lhc = (c - 1) // 2
-        rhc = c - 1 - lhc
         h, w, ori_d = volume.shape
-        if not resize:
-            pshape = (h, w)
-        eval_batch = {"images": np.empty((batch_size,) + tuple(pshape) + (c,), dtype=np.float32), "names": case["PID"],
-                      "mirror": 0}
-        pads = (batch_size - (ori_d % batch_size)) % batch_size
-        volume = np.concatenate((np.zeros((h, w, lhc), volume.dtype), volume, np.zeros((h, w, pads + rhc), volume.dtype)),
-                                axis=-1)
-        d = volume.shape[-1]
+        pads = -ori_d % batch_size
+        volume = np.pad(volume, ((0, 0), (0, 0), (lhc, pads + rhc)))       # context + the zero slices of the last slab
         if resize:
             volume = cv2_resize_linear(volume, pshape)
-        nb = (d - lhc - rhc) // batch_size
-        assert d - lhc - rhc == batch_size * nb, "Wrong padding"
-        for idx in range(lhc, d - rhc, batch_size):
-            for j in range(batch_size):
-                eval_batch["images"][j] = volume[:, :, idx + j - lhc:idx + j + rhc + 1]
-            yield copy.copy(eval_batch), None
-            for item in _mirrored(eval_batch, config):
-                yield item
+        for item in _slabs(volume, batch_size, lhc, rhc, {"names": case["PID"]}, config):
+            yield item
         yield None, (segmentation, seg_path, pads, (0, 0, 0, w - 1, h - 1, ori_d - 1), resize)
 
 
@@ -544,34 +575,8 @@ def parse_case_patches(case, align, padding, padding_z, min_shape=None):
     """input_pipeline.py:444-479: the liver box (+ padding) grown to at least `min_shape` (the patch) inside the slice,
     then its sides rounded up to `align` around the centre."""
     d, h, w = case["size"]
-    z1 = max(case["bbox"][0] - padding_z, 0)
-    z2 = min(case["bbox"][3] + padding_z, d)
-    y1 = max(case["bbox"][1] - padding, 0)
-    x1 = max(case["bbox"][2] - padding, 0)
-    y2 = min(case["bbox"][4] + padding, h)
-    x2 = min(case["bbox"][5] + padding, w)
-    if min_shape:
-        if min_shape[0] > h or min_shape[1] > w:
-            raise ValueError("Cannot satisfied conditions!")
-        if y2 - y1 < min_shape[0]:
-            y1 = min(max(y1 - (min_shape[0] - (y2 - y1)) // 2, 0), h - min_shape[0])
-            y2 = y1 + min_shape[0]
-        if x2 - x1 < min_shape[1]:
-            x1 = min(max(x1 - (min_shape[1] - (x2 - x1)) // 2, 0), w - min_shape[1])
-            x2 = x1 + min_shape[1]
-    cy = (y1 + y2 - 1) / 2
-    cx = (x1 + x2 - 1) / 2
-    sz_y = int(math.ceil((y2 - y1) / align)) * align
-    sz_x = int(math.ceil((x2 - x1) / align)) * align
-    y1 = max(int(cy - (sz_y - 1) / 2), 0)
-    x1 = max(int(cx - (sz_x - 1) / 2), 0)
-    y2 = min(y1 + sz_y, h)
-    x2 = min(x1 + sz_x, w)
-    if (y2 - y1) % align != 0 or (x2 - x1) % align != 0:
-        y1 = y2 - sz_y
-        x1 = x2 - sz_x
-        if y1 < 0 or x1 < 0:
-            print("\nWarning: bbox aligns with {} failed! point1 ({}, {}) point2 ({}, {})\n".format(align, x1, y1, x2, y2))
+    z1, z2 = max(case["bbox"][0] - padding_z, 0), min(case["bbox"][3] + padding_z, d)
+    y1, y2, x1, x2 = aligned_window(case, align, padding, min_shape)
     return case["PID"], d, h, w, z1, y1, x1, z2, y2, x2
 
 

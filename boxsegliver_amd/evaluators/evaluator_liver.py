@@ -359,33 +359,20 @@ class EvaluateVolume(EvaluateBase):
 
 
 def _compare(cur_result, ori_result, primary_metric=None, secondary_metric=None):
-    """evaluator_liver.py:1193-1227: lexicographic "is cur better than ori" with the primary / secondary metric
-    first; larger is better for every key."""
-    if not isinstance(cur_result, dict):
-        raise TypeError("`cur_result` should be dict, but got {}".format(type(cur_result)))
-    if not isinstance(ori_result, dict):
-        raise TypeError("`ori_result` should be dict, but got {}".format(type(ori_result)))
+    """Is `cur_result` better than `ori_result`?  (evaluator_liver.py:1193-1227)  Larger is better for every metric; the
+    results are ranked lexicographically with the primary metric first, the secondary second, then the remaining keys in
+    the dict's own order; a complete tie is "not better".  Same argument errors as the reference."""
+    for name, res in (("cur_result", cur_result), ("ori_result", ori_result)):
+        if not isinstance(res, dict):
+            raise TypeError("`{}` should be dict, but got {}".format(name, type(res)))
     if set(cur_result) != set(ori_result):
         raise ValueError("Dicts with different keys can not be compared. cur_result({}) vs ori_result({})"
                          .format(list(cur_result.keys()), list(ori_result.keys())))
-    if primary_metric and primary_metric not in cur_result:
-        raise KeyError("`primary_metric` not in valid result key: {}".format(primary_metric))
-    if secondary_metric and secondary_metric not in cur_result:
-        raise KeyError("`secondary_metric` not in valid result key: {}".format(secondary_metric))
+    for name, key in (("primary_metric", primary_metric), ("secondary_metric", secondary_metric)):
+        if key and key not in cur_result:
+            raise KeyError("`{}` not in valid result key: {}".format(name, key))
     if primary_metric == secondary_metric:
         raise ValueError("`primary_metric` can not be equal to `secondary_metric`")
-    keys = list(cur_result.keys())
-    if primary_metric:
-        keys.remove(primary_metric)
-        keys.insert(0, primary_metric)
-        if secondary_metric:
-            keys.remove(secondary_metric)
-            keys.insert(1, secondary_metric)
-    for key in keys:
-        if cur_result[key] > ori_result[key]:
-            return True
-        elif cur_result[key] == ori_result[key]:
-            continue
-        else:
-            return False
-    return False
+    lead = [primary_metric] + ([secondary_metric] if secondary_metric else []) if primary_metric else []
+    order = lead + [k for k in cur_result if k not in lead]
+    return tuple(cur_result[k] for k in order) > tuple(ori_result[k] for k in order)

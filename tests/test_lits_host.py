@@ -101,28 +101,72 @@ def test_collect_datasets_splits_by_fold(tmp_path):
         lits.collect_datasets(tmp_path, 3, "train")
 
 
-def test_sampler_invariants():
+def test_sampler_policy_forced_shares_and_crop_invariants():
+    """TrainSampler.draw emits a whole batch at once; the POLICY is the reference's (input_pipeline.py:285-378): forced
+    tumor / liver shares in batch order, crops inside the slice and placed around the object, neighbour channels with -1
+    padding, window ranges.  (The random stream is this package's own.)"""
     cfg = argparse.Namespace(im_height=48, im_width=48, im_channel=3)
     cases = [lits.parse_case(_meta_case(i)) for i in range(4)]
-    gen = lits.gen_train_batch(cases, 8, liver_percent=0.66, tumor_percent=0.5, random_scale=(1.0, 1.4),
-                               random_window_level=True, config=cfg, seed=7)
-    n_tumor = 0
-    for k in range(8 * 20):
-        chans, lab, (off_y, off_x, ch, cw), pid, (lo, hi) = next(gen)
-        case = cases[pid]
-        depth, h, w = case["size"]
-        assert 48 <= ch <= 67 and 48 <= cw <= 67 and 0 <= off_y and off_y + ch <= h and 0 <= off_x and off_x + cw <= w
-        assert len(chans) == 3 and chans[1] == lab and 0 <= lab < depth
-        assert chans[0] == (lab - 1 if lab > 0 else -1) and chans[2] == (lab + 1 if lab + 1 < depth else -1)
-        assert 10 * 64 <= lo <= 50 * 64 and 500 * 64 <= hi <= 540 * 64
-        if k % 8 < 4:                                                       # the first ceil(8 * 0.5) of a batch: tumor slices
-            assert lab in case["tumor_slices_index"]
-            n_tumor += 1
-        elif k % 8 < 6:                                                     # up to ceil(8 * 0.66) = 6: liver slices
-            assert case["bbox"][0] <= lab <= case["bbox"][3] - 1
-    assert n_tumor == 80
-    # fixed window without random_window_level; same seed -> same stream
-    g1 = lits.gen_train_batch(cases, 4, config=cfg, seed=3)
-    g2 = lits.gen_train_batch(cases, 4, config=cfg, seed=3)
-    a, b = [next(g1) for _ in range(8)], [next(g2) for _ in range(8)]
-    assert a == b and a[0][4] == (50 * 64.0, 500 * 64.0)
+    smp = lits.TrainSampler(cases, 8, cfg, liver_percent=0.66, tumor_percent=0.5, random_scale=(1.0, 1.4),
+                            random_window_level=True, random_flip=3, seed=7)
+    seen_flips = np.zeros(2)
+    inside = total_tumor = 0
+    for _ in range(40):
+        b = smp.draw()
+        assert b["kind"].tolist() == [0, 0, 0, 0, 1, 1, 2, 2]             # ceil(8 * .5) tumor, up to ceil(8 * .66) = 6 liver
+        for j in range(8):
+            case = cases[int(b["case"][j])]
+            depth, h, w = case["size"]
+            off_y, off_x, ch, cw = b["box"][j]
+            z = int(b["z"][j])
+            assert case["PID"] == b["pid"][j]
+            assert 48 <= ch <= 67 and 48 <= cw <= 67 and 0 <= off_y and off_y + ch <= h and 0 <= off_x and off_x + cw <= w
+            assert b["chans"][j].tolist() == [z - 1 if z > 0 else -1, z, z + 1 if z + 1 < depth else -1]
+            lo, hi = b["clip"][j]
+            assert 10 * 64 <= lo <= 50 * 64 and 500 * 64 <= hi <= 540 * 64
+            if b["kind"][j] == 0:
+                k = case["tumor_slices_index"].index(z)                   # a tumor slice of a case that has tumors
+                total_tumor += 1
+                # the crop covers at least one tumor box of that slice whenever it is placed by the "inside" rule
+                inside += any(off_y <= bb[0] and bb[2] <= off_y + ch and off_x <= bb[1] and bb[3] <= off_x + cw
+                              for bb in case["slices"][k])
+            elif b["kind"][j] == 1:
+                assert case["bbox"][0] <= z <= case["bbox"][3] - 1
+        seen_flips += b["flips"].sum(0)
+    assert total_tumor == 160 and inside > 0.9 * total_tumor
+    assert 100 < seen_flips[0] < 220 and 100 < seen_flips[1] < 220         # fair coins on 320 samples
+    # the table for the gather kernel: store offsets applied, -1 kept, label slice = centre channel
+    tab, clip, names = smp.table({c["PID"]: 1000 * c["PID"] for c in cases})
+    assert tab.shape == (8, 10) and tab.dtype == np.int32 and clip.shape == (8, 2) and clip.dtype == np.float32
+    assert (tab[:, 3] == tab[:, 1]).all() and (tab[:, 1] // 1000 == names).all()
+    assert ((tab[:, 0] == -1) | (tab[:, 0] == tab[:, 1] - 1)).all() and set(np.unique(tab[:, 8:])) <= {0, 1}
+    # fixed window and no flips when not asked for; same seed -> same stream; eval-style sampler has no forced shares
+    s1 = lits.TrainSampler(cases, 4, cfg, seed=3)
+    s2 = lits.TrainSampler(cases, 4, cfg, seed=3)
+    a, b2 = s1.draw(), s2.draw()
+    assert all(np.array_equal(a[k], b2[k]) for k in a) and (a["clip"] == [50 * 64.0, 500 * 64.0]).all()
+    assert a["kind"].tolist() == [2, 2, 2, 2] and not a["flips"].any()
+    with pytest.raises(ValueError):
+        lits.TrainSampler(cases, 2, argparse.Namespace(im_height=200, im_width=48, im_channel=1), seed=1).draw()   # crop > slice
+
+
+def test_sampler_distribution_matches_the_policy():
+    """Over many draws: tumor samples hit every tumor slice of the chosen case with equal probability, liver samples are
+    uniform over the liver's z range, unconstrained samples over the whole depth."""
+    cfg = argparse.Namespace(im_height=32, im_width=32, im_channel=1)
+    cases = [lits.parse_case(_meta_case(i)) for i in range(2)]
+    smp = lits.TrainSampler(cases, 6, cfg, liver_percent=0.6, tumor_percent=0.3, seed=11)
+    zs = {0: [], 1: [], 2: []}
+    for _ in range(600):
+        b = smp.draw()
+        for k, z in zip(b["kind"], b["z"]):
+            zs[int(k)].append(int(z))
+    t = np.bincount(zs[0], minlength=12)
+    tumor_slices = cases[0]["tumor_slices_index"]
+    assert set(np.flatnonzero(t)) == set(tumor_slices)
+    assert t[tumor_slices].min() > 0.8 * t[tumor_slices].mean()
+    lz = np.bincount(zs[1], minlength=12)
+    z0, z1 = cases[0]["bbox"][0], cases[0]["bbox"][3]
+    assert lz[:z0].sum() == 0 and lz[z1:].sum() == 0 and lz[z0:z1].min() > 0.7 * lz[z0:z1].mean()
+    az = np.bincount(zs[2], minlength=12)
+    assert az.min() > 0.6 * az.mean()
