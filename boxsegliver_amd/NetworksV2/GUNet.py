@@ -15,8 +15,16 @@ the same norm-apply / norm-backward kernels (no extra pass over the activations)
 `after_affine` (GUNetV2.yml and the *_AA.yml configs; GUNet.py:213-214, slim_nets.channel_wise_affine): the per-channel
 gamma' / beta' after the modulation fold into the gains / guide weights / post-shift of the same kernels.
 
-Not built (raise NotImplementedError): --use_se, context_model vgg16*, the conv context subnet (`ct_conv`),
---fix, --dropout (no shipped script uses them); after_affine together with --without_norm.
+`--dropout` (GUNet.py:189-190): slim.dropout on the normalised output of the FIRST conv of every encoder block, before
+the gains / guide term -- a counter-RNG mask regenerated inside the norm kernels (unetk_norm_desc.dropout_keep).
+`--fix` (GUNet.py:299-304): the guide's 1x1 convs get norm(scale, eps 1e-3, BN decay .99) + ReLU instead of a bias.  The
+conv is linear in the guide, so its batch / instance statistics follow EXACTLY from the guide's first and second moments
+(unetk_guide_moments): the norm folds into the guide weights on the host (tiny [g, C] products under autograd) and the
+kernels only switch the guide branch's activation to ReLU (guide_leaky with slope 0); nothing is materialised.
+`--use_se` (GUNet.py:192-201): the gains of a unit are sigmoid(fc(relu(fc(concat(mean_hw(net), context slice))))) --
+ops.Conv3x3NormRelu forms mean_hw(net) from the conv's per-sample statistics and back-propagates through it.
+Not built (raise NotImplementedError): context_model vgg16*, the conv context subnet (`ct_conv`); --fix or --use_se
+combined with each other or with --dropout / after_affine; after_affine together with --without_norm.
 --without_norm (GUNet.py:251-252,314-315): every unit = conv + bias (* density gain + guide term) + ReLU, the norm stage
 of the fused kernels reduced to the per-channel shift (unetk_norm_desc.affine_only).
 """
@@ -35,9 +43,14 @@ def n_modulator_params(init_channels, num_down_samples, mod_layers):
     return init_channels * sum(2 ** i for i in range(num_down_samples + 1) if i in mod_layers) * 2
 
 
+def n_modulator_params_se(context_feature_length, num_down_samples, mod_layers):
+    """GUNet.py:44-46 (--use_se): every modulated conv unit takes a context_fc_channels[-1]-long slice."""
+    return context_feature_length * sum(1 for i in range(num_down_samples + 1) if i in mod_layers) * 2
+
+
 def param_specs(in_channels, num_classes, guide_channel, init_channels, num_down_samples, mod_layers, normalizer,
                 norm_with_center, norm_with_scale, use_spatial, name, context_dims=None, after_affine=False, mid_cat_g=0,
-                without_norm=False):
+                without_norm=False, fix=False, se_length=0):
     """Variables with the reference's TF names: <name>/spatial/conv{i}/{weights,biases},
     <name>/Encode/down_conv{i}/mod_conv{j}/{weights,<Norm>/...}, <name>/Decode/up{i}/{weights,biases},
     <name>/Decode/up_conv{i}/up_conv{i}_{j}/..., <name>/AdjustChannels/{weights,biases}."""
@@ -68,7 +81,15 @@ def param_specs(in_channels, num_classes, guide_channel, init_channels, num_down
             if i in mod_layers:
                 c2 = 2 * init_channels * 2 ** i
                 specs.append(("{}/spatial/conv{}/weights".format(name, i + 1), (1, 1, guide_channel, c2), "conv_w"))
-                specs.append(("{}/spatial/conv{}/biases".format(name, i + 1), (c2,), "bias"))
+                if fix:                     # GUNet.py:299-304: normalizer_fn set -> no bias; centre + scale
+                    gs = "{}/spatial/conv{}/{}".format(name, i + 1, ns)
+                    specs.append((gs + "/beta", (c2,), "beta"))
+                    specs.append((gs + "/gamma", (c2,), "gamma"))
+                    if bn:
+                        specs.append((gs + "/moving_mean", (c2,), "moving_mean"))
+                        specs.append((gs + "/moving_variance", (c2,), "moving_var"))
+                else:
+                    specs.append(("{}/spatial/conv{}/biases".format(name, i + 1), (c2,), "bias"))
     cin = in_channels
     for i in range(num_down_samples + 1):
         c = init_channels * 2 ** i
@@ -83,6 +104,12 @@ def param_specs(in_channels, num_classes, guide_channel, init_channels, num_down
             if after_affine:                          # slim_nets.channel_wise_affine (slim_nets.py:152-212), GUNet.py:213-214
                 specs.append((scope + "/ChannelWiseAffine/beta", (c,), "beta"))
                 specs.append((scope + "/ChannelWiseAffine/gamma", (c,), "gamma"))
+            if se_length and bool(context_dims) and i in mod_layers:      # GUNet.py:196-199: the SE gate's two slim.fully_connected
+                hid = (c + se_length) // 4
+                specs.append((scope + "/fully_connected/weights", (c + se_length, hid), "fc_w"))
+                specs.append((scope + "/fully_connected/biases", (hid,), "fc_b"))
+                specs.append((scope + "/fully_connected_1/weights", (hid, c), "fc_w"))
+                specs.append((scope + "/fully_connected_1/biases", (c,), "fc_b"))
             cin = c
         if i == 0 and mid_cat_g:            # UNetInter --mid_cat: the guide joins the pooled level-0 output (UNetInter.py:124-127)
             cin = c + mid_cat_g
@@ -123,10 +150,11 @@ class GUNet(base.BaseNet):
 
     def _net_arg_scope(self, *args, **kwargs):
         """GUNet.py:240-257: as UNet (decoder norm = _get_normalization defaults), pools with SAME."""
-        if self.use_se or hasattr(self.args, "ct_conv"):
-            raise NotImplementedError("GUNet --use_se / ct_conv context variants are not built yet")
-        if getattr(self.args, "fix", False) or self.dropout:
-            raise NotImplementedError("GUNet --fix / --dropout are not built yet")
+        if hasattr(self.args, "ct_conv"):
+            raise NotImplementedError("GUNet ct_conv context variant is not built")
+        fix = bool(getattr(self.args, "fix", False)) and self.use_spatial_guide and not self._concat_guide
+        if (fix and self.use_context_guide) or (self.use_se and self.use_context_guide and self.dropout):
+            raise NotImplementedError("GUNet --fix with --use_context, and --use_se with --dropout, are not built")
         self._norm = ("none", {}) if getattr(self.args, "without_norm", False) else self._get_normalization()
         return self._norm
 
@@ -152,6 +180,56 @@ class GUNet(base.BaseNet):
         if self._taps is not None:
             self._taps[scope] = z
         return z
+
+    def _se_gate(self, scope, ctx_feat):
+        """GUNet.py:192-201: pooled [N, C] -> sigmoid(fc(relu(fc(concat(pooled, context slice))))); the two
+        slim.fully_connected live under the conv unit's scope."""
+        p = self.params
+
+        def gate(pooled):
+            h = torch.cat((pooled, ctx_feat), dim=1)
+            h = ops.FullyConnected.apply(h, p[scope + "/fully_connected/weights"], p[scope + "/fully_connected/biases"], 1, None, 0)
+            return ops.FullyConnected.apply(h, p[scope + "/fully_connected_1/weights"], p[scope + "/fully_connected_1/biases"],
+                                            2, None, 0)
+        return gate
+
+    def _fixed_guide(self, level, j, c, guide, gw, spec):
+        """--fix (GUNet.py:299-304): sp = relu(norm(conv1x1(guide))) with scale + centre, eps 1e-3 (BN decay .99) on the
+        2C-channel conv of the level.  The conv has no bias and is linear in the guide, so per statistics group
+            mean_c = E[g] . gw[:, c],   var_c = gw[:, c]^T Cov(g) gw[:, c]
+        exactly; the norm folds into the weights: gw' = gw * A, gb' = beta - mean * A with A = gamma / sqrt(var + eps), and
+        the kernels apply the ReLU (guide_leaky, slope 0).  Returns (gw', gb') -- [g, C] / [C], or [N, g, C] / [N, C] under
+        instance norm.  Batch norm keeps moving statistics of the conv output as slim.batch_norm would."""
+        p, nm = self.params, self.name
+        kind, _ = self._norm
+        bn = kind == "batch_norm"
+        ns = "{}/spatial/conv{}/{}".format(nm, level + 1, "BatchNorm" if bn else "InstanceNorm")
+        sl = slice((j - 1) * c, j * c)
+        gamma, beta = p[ns + "/gamma"][sl], p[ns + "/beta"][sl]
+        g_ch = guide.shape[-1]
+        eps = 1e-3
+        training = self.mode == ModeKeys.TRAIN
+        if bn and not training:
+            mean_c, var_c = p[ns + "/moving_mean"][sl], p[ns + "/moving_variance"][sl]
+        else:
+            mom = ops.guide_moments(guide, not bn)                                   # [groups, g + g*g]
+            mg = mom[:, :g_ch]
+            cov = mom[:, g_ch:].reshape(-1, g_ch, g_ch) - mg[:, :, None] * mg[:, None, :]
+            mean_c = mg @ gw                                                          # [groups, C]
+            var_c = torch.einsum("gc,kgh,hc->kc", gw, cov, gw).clamp_min(0.0)
+            if bn:
+                with torch.no_grad():
+                    cnt = float(guide.numel() // g_ch)
+                    mm, mv = p[ns + "/moving_mean"][sl], p[ns + "/moving_variance"][sl]
+                    mm.mul_(0.99).add_(mean_c[0].detach(), alpha=0.01)
+                    mv.mul_(0.99).add_(var_c[0].detach() * (cnt / max(cnt - 1.0, 1.0)), alpha=0.01)
+                mean_c, var_c = mean_c[0], var_c[0]
+        a = gamma * torch.rsqrt(var_c + eps)
+        spec.guide_leaky, spec.guide_alpha = True, 0.0
+        if bn:
+            return (gw * a).contiguous(), (beta - mean_c * a).contiguous()
+        spec.guide_per_sample = True
+        return (gw[None, :, :] * a[:, None, :]).contiguous(), (beta - mean_c * a).contiguous()
 
     def _build_network(self, *args, **kwargs):
         base_channels = kwargs.get("init_channels", 64)
@@ -179,8 +257,10 @@ class GUNet(base.BaseNet):
             context = self._inputs["context"]
             if context.dim() != 2 or context.shape[0] != n or not context.is_cuda:
                 raise ValueError("context must be a [bs, L] device tensor, got {}".format(tuple(context.shape)))
-            context_dims = [int(context.shape[1])] + list(kwargs.get("context_fc_channels", [256])) + \
-                [n_modulator_params(base_channels, nds, mod_layers)]
+            fc_ch = list(kwargs.get("context_fc_channels", [256]))
+            context_dims = [int(context.shape[1])] + fc_ch + \
+                [n_modulator_params_se(fc_ch[-1], nds, mod_layers) if self.use_se else
+                 n_modulator_params(base_channels, nds, mod_layers)]
         if self.params is None:
             in_ch = self.channel * (3 if getattr(self.args, "img_grad", False) else 1)      # GUNet.py:335-338
             gc = int(getattr(self.args, "guide_channel", 1))
@@ -189,7 +269,10 @@ class GUNet(base.BaseNet):
             mid_g = gc if (self._concat_guide and self._mid_cat) else 0
             specs = param_specs(in_ch, self.num_classes, g_ch, base_channels, nds, mod_layers,
                                 self.args.normalizer, norm_with_center, norm_with_scale, g_ch > 0, nm,
-                                context_dims, after_affine, mid_g, bool(getattr(self.args, "without_norm", False)))
+                                context_dims, after_affine, mid_g, bool(getattr(self.args, "without_norm", False)),
+                                fix=bool(getattr(self.args, "fix", False)) and g_ch > 0,
+                                se_length=(list(kwargs.get("context_fc_channels", [256]))[-1]
+                                           if (self.use_se and self.use_context_guide) else 0))
             if mid_g:
                 # Encode2's first conv sees 64 + g channels: padded with zero filter rows to the filter-gradient tile (32)
                 wname = "{}/Encode/down_conv2/mod_conv1/weights".format(nm)
@@ -229,6 +312,7 @@ class GUNet(base.BaseNet):
                         den_all, p["{}/context/fc{}/weights".format(nm, li)], p["{}/context/fc{}/biases".format(nm, li)],
                         not last, None if last else keep, seed)
                 self._layers["context_params"] = den_all
+            se_len = int(context_dims[-2]) if (context_dims and self.use_se) else 0
 
             if self._concat_guide:
                 gs = self._inputs["sp_guide"].to(torch.float32)
@@ -246,24 +330,39 @@ class GUNet(base.BaseNet):
                 c = base_channels * 2 ** i
                 mod = i in guides
                 dens = den_all is not None and i in mod_layers
-                spec = self._spec(0.99) if (mod or dens) else self._spec(self._encoder_decay)  # GUNet.py:313-330 decay .99
+                fix = bool(getattr(self.args, "fix", False)) and mod
+                training = self.mode == ModeKeys.TRAIN
                 for j in (1, 2):
+                    spec = self._spec(0.99) if (mod or dens) else self._spec(self._encoder_decay)  # GUNet.py:313-330 decay .99
                     scope = "{}/Encode/down_conv{}/mod_conv{}".format(nm, i + 1, j)
                     out = None
                     if j == 2 and i < nds:
                         cat = torch.empty((n, hh, ww, 2 * c), dtype=self.storage_dtype, device=dev)
                         out = ops.alias(cat, 0, (n, hh, ww, c), cat.stride())
                         cats[i] = cat
+                    if j == 1 and self.dropout and training:          # GUNet.py:189-190: between the two convs of a block
+                        self._dropout_calls = getattr(self, "_dropout_calls", 0) + 1
+                        spec.dropout = (1.0 - float(self.dropout),
+                                        int(getattr(self.args, "seed", None) or 1234) * 7919 + self._dropout_calls * 131 + i)
                     den = None
-                    if dens:                                                 # GUNet.py:203-206
+                    if dens and self.use_se:                                 # GUNet.py:192-201
+                        ctx_feat = den_all[:, den_off:den_off + se_len]
+                        den_off += se_len
+                        spec.se = self._se_gate(scope, ctx_feat)
+                    elif dens:                                               # GUNet.py:203-206
                         den = den_all[:, den_off:den_off + c]
                         den_off += c
                     guide = gw = gb = None
                     if mod:
                         guide = guides[i]
                         gw = p["{}/spatial/conv{}/weights".format(nm, i + 1)].view(g_ch, 2 * c)[:, (j - 1) * c:j * c]
-                        gb = p["{}/spatial/conv{}/biases".format(nm, i + 1)][(j - 1) * c:j * c]
+                        if fix:
+                            gw, gb = self._fixed_guide(i, j, c, guide, gw, spec)
+                        else:
+                            gb = p["{}/spatial/conv{}/biases".format(nm, i + 1)][(j - 1) * c:j * c]
                     if after_affine:
+                        if fix or spec.se is not None:
+                            raise NotImplementedError("GUNet after_affine with --fix / --use_se is not built")
                         # (t * den + sp) * ga + ba == t * (den ga) + guide . (gw ga) + (gb ga + ba): the channel-wise affine
                         # folds into the gains / guide weights the kernel already takes (tiny [bs, C] / [g, C] products)
                         ga, ba = p[scope + "/ChannelWiseAffine/gamma"], p[scope + "/ChannelWiseAffine/beta"]

@@ -12,7 +12,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 _LIB = None
 LIB_PATH = os.environ.get("UNETK_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libunetk.so")
 
-ABI_VERSION = 5            # must equal unetk_abi_version() of the loaded library (checked in lib())
+ABI_VERSION = 6            # must equal unetk_abi_version() of the loaded library (checked in lib())
 UNETK_MAX_CLASSES = 8
 W_NONE, W_NUMERICAL, W_PROPORTION, W_PIXELMAP = 0, 1, 2, 3
 
@@ -43,7 +43,8 @@ class Deconv3dDesc(Structure):
 class NormDesc(Structure):
     _fields_ = [("N", c_int32), ("HW", c_int32), ("C", c_int32), ("per_sample", c_int32), ("z_stride", c_int32),
                 ("guide_ch", c_int32), ("gw_stride", c_int32), ("gw_coff", c_int32), ("affine_only", c_int32),
-                ("guide_leaky", c_int32), ("storage", c_int32)]
+                ("guide_leaky", c_int32), ("storage", c_int32), ("guide_alpha", c_float), ("dropout_keep", c_float),
+                ("dropout_seed", ctypes.c_uint32), ("guide_per_sample", c_int32)]
 
 
 class HeadDesc(Structure):
@@ -84,12 +85,14 @@ _SIGNATURES = {
     "unetk_norm_bwd_ws_bytes": (c_size_t, [POINTER(NormDesc)]),
     "unetk_norm_relu_bwd": (c_int, [POINTER(NormDesc), P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                                     c_size_t, P]),
+    "unetk_norm_se_bwd_add": (c_int, [POINTER(NormDesc), P, P, P, P, P, P, P, P]),
     "unetk_fc_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, P]),
     "unetk_fc_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "unetk_maxpool2_fwd": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, P]),
     "unetk_maxpool2_bwd": (c_int, [P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P]),
     "unetk_maxpool2_fwd_bf16": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, P]),
     "unetk_maxpool2_bwd_bf16": (c_int, [P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P]),
+    "unetk_guide_moments": (c_int, [P, c_int, c_int64, c_int, c_int, P, P]),
     "unetk_avgpool2_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "unetk_image_gradients": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "unetk_sobel_concat": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),

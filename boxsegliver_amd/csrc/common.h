@@ -61,6 +61,16 @@ __device__ __forceinline__ float ld1(const bf16_t* p) { return __uint_as_float((
 __device__ __forceinline__ float unetk_round_bf16(float v) { return unetk_bf16_lo(unetk_pk_bf16(v, 0.f)); }
 static inline bool unetk_aligned8(const void* p) { return (((uintptr_t)p) & 7u) == 0; }
 
+// counter RNG of slim.dropout masks: murmur3 finaliser of (seed, element index) -> uniform [0, 1); the forward and the
+// backward of an op regenerate the same mask from it (nothing is stored for the big activations)
+__device__ __forceinline__ float unetk_uniform(uint32_t seed, uint32_t idx) {
+  uint32_t h = idx * 0x9E3779B1u + seed;
+  h ^= h >> 16; h *= 0x85EBCA6Bu;
+  h ^= h >> 13; h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -8,14 +8,7 @@
 
 namespace {
 
-// counter RNG of slim.dropout's mask: murmur3 finaliser of (seed, element) -> uniform [0, 1)
-__device__ __forceinline__ float fc_uniform(uint32_t seed, uint32_t idx) {
-  uint32_t h = idx * 0x9E3779B1u + seed;
-  h ^= h >> 16; h *= 0x85EBCA6Bu;
-  h ^= h >> 13; h *= 0xC2B2AE35u;
-  h ^= h >> 16;
-  return (float)(h >> 8) * (1.0f / 16777216.0f);
-}
+__device__ __forceinline__ float fc_uniform(uint32_t seed, uint32_t idx) { return unetk_uniform(seed, idx); }
 
 __global__ __launch_bounds__(256) void fc_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ b, float* __restrict__ y,
@@ -26,7 +19,8 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(const float* __restrict__ x
   const float* xr = x + (int64_t)r * k;
   float acc = b ? b[o] : 0.f;
   for (int i = 0; i < k; ++i) acc = fmaf(xr[i], w[(int64_t)i * n + o], acc);
-  if (relu) acc = fmaxf(acc, 0.f);
+  if (relu == 1) acc = fmaxf(acc, 0.f);
+  else if (relu == 2) acc = 1.0f / (1.0f + expf(-acc));        // tf.nn.sigmoid (GUNet's SE gate, GUNet.py:199)
   if (mask) {
     const float m = fc_uniform(seed, (uint32_t)(r * n + o)) < keep_prob ? 1.0f / keep_prob : 0.f;
     mask[(int64_t)r * n + o] = m;
@@ -46,7 +40,8 @@ __global__ __launch_bounds__(256) void fc_bwd_pre_kernel(const float* __restrict
     const int64_t i = (int64_t)r * n + o;
     float d = dy[i];
     if (mask) d *= mask[i];
-    if (relu && !(y[i] > 0.f)) d = 0.f;
+    if (relu == 1 && !(y[i] > 0.f)) d = 0.f;
+    else if (relu == 2) d *= y[i] * (1.0f - y[i]);
     dpre[i] = d;
     s += d;
   }

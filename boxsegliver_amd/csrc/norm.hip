@@ -95,6 +95,10 @@ struct ApplyArgs {
   void* z;
   int64_t P;
   int C, zs, cq_n, rpi, gw_stride, gw_coff, sst;
+  int gw_ns, gb_ns;     // per-sample strides of gw / gb (0 = shared by the batch)
+  float alpha;          // leaky slope of the guide branch (L)
+  float keep;           // dropout keep probability, 0 = no dropout
+  uint32_t seed;
 };
 
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
@@ -102,8 +106,16 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(
 
 // LGNet's guide branch (LGNet.py:30-55): the 1x1 guide conv has a leaky-ReLU activation (tf.nn.leaky_relu, alpha 0.2)
 // before it is added: u = t + lrelu(guide . gw + gb) -- template flag L (without density modulation).
-__device__ __forceinline__ float lrelu(float s) { return s > 0.f ? s : 0.2f * s; }
-__device__ __forceinline__ float lrelu_grad(float s) { return s > 0.f ? 1.f : 0.2f; }
+// alpha = d->guide_alpha: 0.2 for LGNet, 0 (plain ReLU) for GUNet --fix
+__device__ __forceinline__ float lrelu(float s, float al) { return s > 0.f ? s : al * s; }
+__device__ __forceinline__ float lrelu_grad(float s, float al) { return s > 0.f ? 1.f : al; }
+
+// slim.dropout between the two convs of a modulated block (GUNet.py:189-190): the mask multiplies the NORMALISED value
+// before the density gain / guide term; kept entries are scaled by 1 / keep.  Regenerated from (seed, element) in every pass.
+__device__ __forceinline__ float4 drop4(uint32_t seed, uint32_t idx, float keep, float inv_keep) {
+  return make_float4(unetk_uniform(seed, idx) < keep ? inv_keep : 0.f, unetk_uniform(seed, idx + 1) < keep ? inv_keep : 0.f,
+                     unetk_uniform(seed, idx + 2) < keep ? inv_keep : 0.f, unetk_uniform(seed, idx + 3) < keep ? inv_keep : 0.f);
+}
 
 // z = relu((y*scale + shift) [* den] [+ guide . gw + gb])
 template <int G, bool D, bool L = false, typename T = float>
@@ -123,17 +135,24 @@ __global__ __launch_bounds__(256) void norm_apply_relu_kernel(ApplyArgs a) {
   }
   float4 gwv[G > 0 ? G : 1];
   float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (a.gb) gbv = ldg4(a.gb + a.gw_coff + cq * 4);   // guide bias, or a bare post-shift when G == 0
-  if (!L) sh = add4(sh, gbv);
+  if (a.gb) gbv = ldg4(a.gb + (int64_t)n * a.gb_ns + a.gw_coff + cq * 4);   // guide bias, or a bare post-shift when G == 0
+  const bool drop = a.keep > 0.f;
+  const float inv_keep = drop ? 1.0f / a.keep : 1.f;
+  if (!L && !drop) sh = add4(sh, gbv);                 // with dropout the post-shift is added after the mask
   if (G > 0) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) gwv[g] = ldg4(a.gw + (int64_t)g * a.gw_stride + a.gw_coff + cq * 4);
+    for (int g = 0; g < G; ++g) gwv[g] = ldg4(a.gw + (int64_t)n * a.gw_ns + (int64_t)g * a.gw_stride + a.gw_coff + cq * 4);
   }
   const int64_t base = (int64_t)n * a.P;
   for (int64_t pix = (int64_t)blockIdx.x * a.rpi + rl; pix < a.P; pix += (int64_t)gridDim.x * a.rpi) {
     const float4 v = ld4(ay + (base + pix) * a.C + cq * 4);
     float4 u;
     u.x = fmaf(v.x, sc.x, sh.x); u.y = fmaf(v.y, sc.y, sh.y); u.z = fmaf(v.z, sc.z, sh.z); u.w = fmaf(v.w, sc.w, sh.w);
+    if (drop) {
+      const float4 m = drop4(a.seed, (uint32_t)((base + pix) * a.C + cq * 4), a.keep, inv_keep);
+      u.x *= m.x; u.y *= m.y; u.z *= m.z; u.w *= m.w;
+      if (!L) u = add4(u, gbv);
+    }
     if (L) {
       float4 s = gbv;
 #pragma unroll
@@ -141,7 +160,7 @@ __global__ __launch_bounds__(256) void norm_apply_relu_kernel(ApplyArgs a) {
         const float gg = a.guide[(base + pix) * G + g];
         s.x = fmaf(gg, gwv[g].x, s.x); s.y = fmaf(gg, gwv[g].y, s.y); s.z = fmaf(gg, gwv[g].z, s.z); s.w = fmaf(gg, gwv[g].w, s.w);
       }
-      u.x += lrelu(s.x); u.y += lrelu(s.y); u.z += lrelu(s.z); u.w += lrelu(s.w);
+      u.x += lrelu(s.x, a.alpha); u.y += lrelu(s.y, a.alpha); u.z += lrelu(s.z, a.alpha); u.w += lrelu(s.w, a.alpha);
     } else {
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -171,6 +190,9 @@ struct BwdArgs {
   int64_t P;
   float inv_ps;         // 1 / pixels per STATISTICS group
   int C, dzs, cq_n, rpi, gw_stride, gw_coff, L, plain, sst, kst, krow;
+  int gw_ns, gb_ns;     // per-sample strides of gw / gb (0 = shared)
+  float alpha, keep;
+  uint32_t seed;
 };
 
 // pass 1.  With dt = du * den (dt = du without density), du = dz * (u > 0), xhat = (y - mean) rstd, t = y*scale + shift:
@@ -197,11 +219,13 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
     float4 sh = D ? mul4(sh0, dn) : sh0;
     float4 gwv[G > 0 ? G : 1];
     float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.gb) gbv = ldg4(a.gb + a.gw_coff + cq * 4);
-    if (!L) sh = add4(sh, gbv);
+    if (a.gb) gbv = ldg4(a.gb + (int64_t)n * a.gb_ns + a.gw_coff + cq * 4);
+    const bool drop = a.keep > 0.f;
+    const float inv_keep = drop ? 1.0f / a.keep : 1.f;
+    if (!L && !drop) sh = add4(sh, gbv);
     if (G > 0) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) gwv[g] = ldg4(a.gw + (int64_t)g * a.gw_stride + a.gw_coff + cq * 4);
+      for (int g = 0; g < G; ++g) gwv[g] = ldg4(a.gw + (int64_t)n * a.gw_ns + (int64_t)g * a.gw_stride + a.gw_coff + cq * 4);
     }
     const int64_t base = (int64_t)n * a.P;
     for (int64_t pix = (int64_t)blockIdx.x * a.rpi + rl; pix < a.P; pix += (int64_t)gridDim.x * a.rpi) {
@@ -209,6 +233,12 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
       const float4 d = ld4(adz + (base + pix) * a.dzs + cq * 4);
       float4 u;
       u.x = fmaf(v.x, sc.x, sh.x); u.y = fmaf(v.y, sc.y, sh.y); u.z = fmaf(v.z, sc.z, sh.z); u.w = fmaf(v.w, sc.w, sh.w);
+      float4 m = make_float4(1.f, 1.f, 1.f, 1.f);    // dropout mask (0 or 1 / keep) on the normalised value
+      if (drop) {
+        m = drop4(a.seed, (uint32_t)((base + pix) * a.C + cq * 4), a.keep, inv_keep);
+        u.x *= m.x; u.y *= m.y; u.z *= m.z; u.w *= m.w;
+        if (!L) u = add4(u, gbv);
+      }
       float gg[G > 0 ? G : 1];
       float4 ls = make_float4(1.f, 1.f, 1.f, 1.f);   // lrelu'(s) of the leaky guide branch
       if (L) {
@@ -218,8 +248,8 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
           gg[g] = a.guide[(base + pix) * G + g];
           sg.x = fmaf(gg[g], gwv[g].x, sg.x); sg.y = fmaf(gg[g], gwv[g].y, sg.y); sg.z = fmaf(gg[g], gwv[g].z, sg.z); sg.w = fmaf(gg[g], gwv[g].w, sg.w);
         }
-        u.x += lrelu(sg.x); u.y += lrelu(sg.y); u.z += lrelu(sg.z); u.w += lrelu(sg.w);
-        ls = make_float4(lrelu_grad(sg.x), lrelu_grad(sg.y), lrelu_grad(sg.z), lrelu_grad(sg.w));
+        u.x += lrelu(sg.x, a.alpha); u.y += lrelu(sg.y, a.alpha); u.z += lrelu(sg.z, a.alpha); u.w += lrelu(sg.w, a.alpha);
+        ls = make_float4(lrelu_grad(sg.x, a.alpha), lrelu_grad(sg.y, a.alpha), lrelu_grad(sg.z, a.alpha), lrelu_grad(sg.w, a.alpha));
       } else {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -230,14 +260,14 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
 #define NBR(f)                                                                \
   {                                                                           \
     const float du = u.f > 0.f ? d.f : 0.f;                                   \
-    const float dt = D ? du * dn.f : du;                                      \
+    const float dt = (D ? du * dn.f : du) * m.f;                              \
     const float dg = L ? du * ls.f : du;                                      \
     s[0].f += dt;                                                             \
     s[1].f += dt * ((v.f - mu.f) * rs.f);                                     \
     _Pragma("unroll") for (int g = 0; g < G; ++g) s[2 + g].f += dg * gg[g];  \
     if (D) {                                                                  \
       s[2 + G].f += du;                                                       \
-      s[3 + G].f += du * fmaf(v.f, sc0.f, sh0.f);                             \
+      s[3 + G].f += du * m.f * fmaf(v.f, sc0.f, sh0.f);                       \
     }                                                                         \
     if (L) s[2 + G].f += dg;                                                  \
   }
@@ -273,11 +303,13 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdArgs a) {
   float4 sh = D ? mul4(sh0, dn) : sh0;
   float4 gwv[G > 0 ? G : 1];
   float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (a.gb) gbv = ldg4(a.gb + a.gw_coff + cq * 4);   // guide bias, or a bare post-shift when G == 0
-  if (!L) sh = add4(sh, gbv);
+  if (a.gb) gbv = ldg4(a.gb + (int64_t)n * a.gb_ns + a.gw_coff + cq * 4);   // guide bias, or a bare post-shift when G == 0
+  const bool drop = a.keep > 0.f;
+  const float inv_keep = drop ? 1.0f / a.keep : 1.f;
+  if (!L && !drop) sh = add4(sh, gbv);
   if (G > 0) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) gwv[g] = ldg4(a.gw + (int64_t)g * a.gw_stride + a.gw_coff + cq * 4);
+    for (int g = 0; g < G; ++g) gwv[g] = ldg4(a.gw + (int64_t)n * a.gw_ns + (int64_t)g * a.gw_stride + a.gw_coff + cq * 4);
   }
   float4 k1 = ldg4(a.ksum + (int64_t)n * a.kst + cq * 4), k2 = ldg4(a.ksum + a.krow + (int64_t)n * a.kst + cq * 4);
   k1.x *= a.inv_ps; k1.y *= a.inv_ps; k1.z *= a.inv_ps; k1.w *= a.inv_ps;
@@ -292,6 +324,12 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdArgs a) {
     const float4 d = ld4(adz + (base + pix) * a.dzs + cq * 4);
     float4 u, o;
     u.x = fmaf(v.x, sc.x, sh.x); u.y = fmaf(v.y, sc.y, sh.y); u.z = fmaf(v.z, sc.z, sh.z); u.w = fmaf(v.w, sc.w, sh.w);
+    float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (drop) {
+      m = drop4(a.seed, (uint32_t)((base + pix) * a.C + cq * 4), a.keep, inv_keep);
+      u.x *= m.x; u.y *= m.y; u.z *= m.z; u.w *= m.w;
+      if (!L) u = add4(u, gbv);
+    }
     if (L) {
       float4 sg = gbv;
 #pragma unroll
@@ -299,7 +337,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdArgs a) {
         const float gg = a.guide[(base + pix) * G + g];
         sg.x = fmaf(gg, gwv[g].x, sg.x); sg.y = fmaf(gg, gwv[g].y, sg.y); sg.z = fmaf(gg, gwv[g].z, sg.z); sg.w = fmaf(gg, gwv[g].w, sg.w);
       }
-      u.x += lrelu(sg.x); u.y += lrelu(sg.y); u.z += lrelu(sg.z); u.w += lrelu(sg.w);
+      u.x += lrelu(sg.x, a.alpha); u.y += lrelu(sg.y, a.alpha); u.z += lrelu(sg.z, a.alpha); u.w += lrelu(sg.w, a.alpha);
     } else {
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -310,7 +348,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdArgs a) {
 #define NBA(f)                                          \
   {                                                     \
     const float du = u.f > 0.f ? d.f : 0.f;             \
-    const float dt = D ? du * dn.f : du;                \
+    const float dt = (D ? du * dn.f : du) * m.f;        \
     const float xh = (v.f - mu.f) * rs.f;               \
     o.f = sc0.f * (dt - k1.f - xh * k2.f);              \
   }
@@ -329,6 +367,44 @@ __global__ void norm_bwd_params_kernel(const float* __restrict__ psum, int C, in
   if (dgamma) dgamma[c] = psum[C + c];
   if (dgb) dgb[c] = density ? psum[(int64_t)(2 + G) * C + c] : psum[c];   // density | leaky: the separate sum du [* lrelu']
   for (int g = 0; g < G; ++g) dgw[(int64_t)g * C + c] = psum[(int64_t)(2 + g) * C + c];
+}
+
+// per-sample guide weights (GUNet --fix under instance norm): dgw[n][g][c] / dgb[n][c] from sums[k][l = n][c]
+__global__ void norm_bwd_guide_ps_kernel(const float* __restrict__ sums, int N, int C, int G, int kb, float* __restrict__ dgw,
+                                         float* __restrict__ dgb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i - n * C;
+  if (dgb) dgb[i] = sums[((int64_t)kb * N + n) * C + c];
+  for (int g = 0; g < G; ++g) dgw[((int64_t)n * G + g) * C + c] = sums[((int64_t)(2 + g) * N + n) * C + c];
+}
+
+// GUNet --use_se: the SE gate reads pooled[b][c] = mean over the sample's pixels of the normalised conv output, so the
+// loss reaches y a second time through it: dt gets the per-(sample, channel) constant g[b][c] / HW.  The norm backward is
+// linear in dt, so that part is added in place afterwards:  dy += scale * (A[b][c] - xhat * k2[c]) with
+// A = g / HW - mean over the statistics group, k2 = mean of (g / HW) * xhat over the group (both tiny, from the host).
+template <typename T>
+__global__ __launch_bounds__(256) void norm_se_bwd_add_kernel(const T* __restrict__ y, T* __restrict__ dy,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ scale, const float* __restrict__ A,
+                                                              const float* __restrict__ k2, int64_t P, int C, int cq_n, int rpi,
+                                                              int sst) {
+  const int cq = threadIdx.x % cq_n, rl = threadIdx.x / cq_n;
+  if (rl >= rpi) return;
+  const int n = blockIdx.y;
+  const int64_t so = (int64_t)n * sst + cq * 4;
+  const float4 mu = ldg4(mean + so), rs = ldg4(rstd + so), sc = ldg4(scale + so);
+  const float4 av = ldg4(A + (int64_t)n * C + cq * 4), kv = ldg4(k2 + so);
+  const int64_t base = (int64_t)n * P;
+  for (int64_t pix = (int64_t)blockIdx.x * rpi + rl; pix < P; pix += (int64_t)gridDim.x * rpi) {
+    const float4 v = ld4(y + (base + pix) * C + cq * 4);
+    float4 o = ld4(dy + (base + pix) * C + cq * 4);
+    o.x += sc.x * (av.x - (v.x - mu.x) * rs.x * kv.x);
+    o.y += sc.y * (av.y - (v.y - mu.y) * rs.y * kv.y);
+    o.z += sc.z * (av.z - (v.z - mu.z) * rs.z * kv.z);
+    o.w += sc.w * (av.w - (v.w - mu.w) * rs.w * kv.w);
+    st4(dy + (base + pix) * C + cq * 4, o);
+  }
 }
 
 bool norm_desc_ok(const unetk_norm_desc* d) {
@@ -421,7 +497,11 @@ extern "C" int unetk_norm_apply_relu(const unetk_norm_desc* d, const void* y, co
   }
   UNETK_REQUIRE(!gb || (d->gw_coff % 4 == 0 && d->gw_coff >= 0 && unetk_aligned16(gb)));
   const NormGeom g = geom(d, den != nullptr);
-  ApplyArgs a{y, scale, shift, den, guide, gw, gb, z, g.P, d->C, d->z_stride, g.cq_n, g.rpi, d->gw_stride, d->gw_coff, g.sst};
+  if (d->dropout_keep < 0.f || d->dropout_keep > 1.f) return UNETK_E_BADARG;
+  if (d->guide_per_sample && g.L != d->N) return UNETK_E_UNSUPPORTED;      // needs one launch group per sample
+  ApplyArgs a{y, scale, shift, den, guide, gw, gb, z, g.P, d->C, d->z_stride, g.cq_n, g.rpi, d->gw_stride, d->gw_coff, g.sst,
+              d->guide_per_sample ? d->guide_ch * d->gw_stride : 0, d->guide_per_sample ? d->gw_stride : 0, d->guide_alpha,
+              d->dropout_keep, d->dropout_seed};
   int64_t gx = (g.P + g.rpi - 1) / g.rpi;
   const int64_t cap = g.L > 1 ? (4096 + g.L - 1) / g.L : 4096;
   if (gx > cap) gx = cap;
@@ -486,6 +566,11 @@ extern "C" int unetk_norm_relu_bwd(const unetk_norm_desc* d, const void* y, cons
   a.guide = guide; a.gw = gw; a.gb = gb; a.partial = partial; a.dy = dy;
   a.P = g.P; a.inv_ps = 1.0f / (float)g.Ps; a.C = d->C; a.dzs = dz_stride; a.cq_n = g.cq_n; a.rpi = g.rpi;
   a.gw_stride = d->gw_stride; a.gw_coff = d->gw_coff; a.L = g.L; a.plain = d->affine_only; a.sst = g.sst;
+  if (d->dropout_keep < 0.f || d->dropout_keep > 1.f) return UNETK_E_BADARG;
+  if (d->dropout_keep > 0.f && (gb || G > 0) && !D && !leaky) return UNETK_E_UNSUPPORTED;   // the guide-bias sum needs the density variant (pass den = 1)
+  if (d->guide_per_sample && g.L != d->N) return UNETK_E_UNSUPPORTED;
+  a.gw_ns = d->guide_per_sample ? G * d->gw_stride : 0; a.gb_ns = d->guide_per_sample ? d->gw_stride : 0;
+  a.alpha = d->guide_alpha; a.keep = d->dropout_keep; a.seed = d->dropout_seed;
   // the statistics sums of the dy formula: per launch group when the statistics are per sample, else the batch totals
   if (d->per_sample) { a.ksum = sums; a.kst = d->C; a.krow = g.L * d->C; }
   else if (g.L == 1) { a.ksum = sums; a.kst = 0; a.krow = d->C; }
@@ -497,9 +582,16 @@ extern "C" int unetk_norm_relu_bwd(const unetk_norm_desc* d, const void* y, cons
   if (rc != UNETK_OK) return rc;
   rc = unetk_rows_reduce(sums, K, g.L, d->C, psum, tmp2, st);                 // -> psum[K][C]
   if (rc != UNETK_OK) return rc;
-  hipLaunchKernelGGL(norm_bwd_params_kernel, dim3((d->C + 255) / 256), dim3(256), 0, st, psum, d->C, G, (D || leaky) ? 1 : 0, dgamma,
-                     dbeta, dgw, dgb);
+  const bool gps = d->guide_per_sample != 0;
+  hipLaunchKernelGGL(norm_bwd_params_kernel, dim3((d->C + 255) / 256), dim3(256), 0, st, psum, d->C, gps ? 0 : G,
+                     (D || leaky) ? 1 : 0, dgamma, dbeta, gps ? nullptr : dgw, gps ? nullptr : dgb);
   UNETK_LAUNCH_CHECK();
+  if (gps) {   // dgw [N][G][C], dgb [N][C]: the per-launch-group sums, not their total
+    const int kb = (D || leaky) ? 2 + G : 0;
+    hipLaunchKernelGGL(norm_bwd_guide_ps_kernel, dim3((d->N * d->C + 255) / 256), dim3(256), 0, st, sums, d->N, d->C, G, kb, dgw,
+                       dgb);
+    UNETK_LAUNCH_CHECK();
+  }
   if (D) {   // density gradient: the per-sample row sum du * t
     hipError_t e = hipMemcpyAsync(dden, sums + (size_t)(3 + G) * g.L * d->C, (size_t)d->N * d->C * sizeof(float),
                                   hipMemcpyDeviceToDevice, st);
@@ -509,6 +601,28 @@ extern "C" int unetk_norm_relu_bwd(const unetk_norm_desc* d, const void* y, cons
   const int64_t cap = g.L > 1 ? (4096 + g.L - 1) / g.L : 4096;
   if (gx > cap) gx = cap;
   GD_DISPATCH(bs, G, D, leaky, norm_bwd_apply_kernel, dim3((int)gx, g.L), dim3(256), 0, st, a);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+extern "C" int unetk_norm_se_bwd_add(const unetk_norm_desc* d, const void* y, void* dy, const float* mean, const float* rstd,
+                                     const float* scale, const float* A, const float* k2, void* stream) {
+  UNETK_REQUIRE(norm_desc_ok(d) && y && dy && mean && rstd && scale && A && k2);
+  if (!norm_supported(d)) return UNETK_E_UNSUPPORTED;
+  const bool bs = d->storage == UNETK_BF16S;
+  UNETK_REQUIRE(d->storage == UNETK_FP32 || bs);
+  UNETK_REQUIRE(bs ? (unetk_aligned8(y) && unetk_aligned8(dy)) : (unetk_aligned16(y) && unetk_aligned16(dy)));
+  UNETK_REQUIRE(unetk_aligned16(A) && unetk_aligned16(k2) && unetk_aligned16(mean) && unetk_aligned16(rstd) && unetk_aligned16(scale));
+  NormGeom g = geom(d, true);            // one launch group per sample: A is per (sample, channel)
+  int64_t gx = (g.P + g.rpi - 1) / g.rpi;
+  const int64_t cap = (4096 + g.L - 1) / g.L;
+  if (gx > cap) gx = cap;
+  if (bs)
+    hipLaunchKernelGGL(norm_se_bwd_add_kernel<bf16_t>, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y,
+                       (bf16_t*)dy, mean, rstd, scale, A, k2, g.P, d->C, g.cq_n, g.rpi, g.sst);
+  else
+    hipLaunchKernelGGL(norm_se_bwd_add_kernel<float>, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, (const float*)y,
+                       (float*)dy, mean, rstd, scale, A, k2, g.P, d->C, g.cq_n, g.rpi, g.sst);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }

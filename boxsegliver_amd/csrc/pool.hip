@@ -98,6 +98,34 @@ __global__ void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restri
   }
 }
 
+// First and second moments of the (pooled) spatial guide, per statistics group: out[grp][0..G) = mean of channel g,
+// out[grp][G + i*G + j] = mean of g_i * g_j.  GUNet --fix (GUNet.py:299-304) normalises the guide's 1x1 conv; because that
+// conv is linear in the guide, its batch / instance statistics follow exactly from these G + G^2 numbers and the conv
+// never has to be materialised.  One block per group, fp64 accumulation, fixed order.
+__global__ __launch_bounds__(256) void guide_moments_kernel(const float* __restrict__ guide, int64_t P, int G,
+                                                            float* __restrict__ out) {
+  __shared__ double red[256];
+  const int grp = blockIdx.x;
+  const float* gp = guide + (int64_t)grp * P * G;
+  const int nq = G + G * G;
+  for (int q = 0; q < nq; ++q) {
+    const int i = q < G ? q : (q - G) / G, j = q < G ? -1 : (q - G) % G;
+    double s = 0.0;
+    for (int64_t p = threadIdx.x; p < P; p += 256) {
+      const double a = gp[p * G + i];
+      s += j < 0 ? a : a * (double)gp[p * G + j];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(int64_t)grp * nq + q] = (float)(red[0] / (double)P);
+    __syncthreads();
+  }
+}
+
 // tf.image.image_gradients + concat (UNet.py:69-71): out[..., 0:C] = x, [C:2C] = x[h+1] - x[h] (last row 0),
 // [2C:3C] = x[w+1] - x[w] (last column 0).  Few channels (C = 1..3) -> scalar, HBM-bound on the 3C write.
 __global__ void image_gradients_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int H, int W, int C) {
@@ -242,6 +270,15 @@ extern "C" int unetk_avgpool2_fwd(const float* x, float* p, int N, int H, int W,
   if ((H & 1) || (W & 1)) return UNETK_E_UNSUPPORTED;
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
   hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, p, N, H, W, C);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+extern "C" int unetk_guide_moments(const float* guide, int N, int64_t HW, int G, int per_sample, float* out, void* stream) {
+  UNETK_REQUIRE(guide && out && N > 0 && HW > 0 && G > 0 && G <= 4);
+  const int groups = per_sample ? N : 1;
+  const int64_t P = per_sample ? HW : (int64_t)N * HW;
+  hipLaunchKernelGGL(guide_moments_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, guide, P, G, out);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }

@@ -338,8 +338,12 @@ def norm_relu_bwd(d, y, dz, aff, has_gamma, has_beta, guide=None, gw=None, gb=No
     dden = torch.empty_like(den) if den is not None else None
     dgamma = torch.empty((d.C,), dtype=torch.float32, device=dev) if has_gamma else None
     dbeta = torch.empty((d.C,), dtype=torch.float32, device=dev) if has_beta else None
-    dgw = torch.empty((d.guide_ch, d.C), dtype=torch.float32, device=dev) if d.guide_ch else None
-    dgb = torch.empty((d.C,), dtype=torch.float32, device=dev) if (d.guide_ch or gb is not None) else None
+    if d.guide_per_sample:
+        dgw = torch.empty((d.N, d.guide_ch, d.C), dtype=torch.float32, device=dev) if d.guide_ch else None
+        dgb = torch.empty((d.N, d.C), dtype=torch.float32, device=dev) if (d.guide_ch or gb is not None) else None
+    else:
+        dgw = torch.empty((d.guide_ch, d.C), dtype=torch.float32, device=dev) if d.guide_ch else None
+        dgb = torch.empty((d.C,), dtype=torch.float32, device=dev) if (d.guide_ch or gb is not None) else None
     nbytes = _abi.lib().unetk_norm_bwd_ws_bytes(ctypes.byref(d))
     if nbytes == 0:
         raise _abi.UnetkError("norm_relu_bwd: unsupported channel count {}".format(d.C))
@@ -621,6 +625,23 @@ def sumsq(p):
     return out
 
 
+def guide_moments(guide, per_sample):
+    """[groups, G + G*G]: E[g_i] and E[g_i g_j] of a (pooled) guide [N, H, W, G] per statistics group (GUNet --fix)."""
+    _require_cuda(guide)
+    guide = guide.to(torch.float32).contiguous()
+    n, g = guide.shape[0], guide.shape[-1]
+    hw = guide.numel() // (n * g)
+    out = torch.empty((n if per_sample else 1, g + g * g), dtype=torch.float32, device=guide.device)
+    check(_abi.lib().unetk_guide_moments(ptr(guide), n, hw, g, 1 if per_sample else 0, ptr(out), stream_ptr()), "guide_moments")
+    return out
+
+
+def norm_se_bwd_add(d, y, dy, aff, a_mat, k2):
+    check(_abi.lib().unetk_norm_se_bwd_add(ctypes.byref(d), ptr(y), ptr(dy), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]),
+                                           ptr(a_mat.contiguous()), ptr(k2.contiguous()), stream_ptr()), "norm_se_bwd_add")
+    return dy
+
+
 # ----------------------------------------------------------------------------- autograd nodes
 class NormSpec(object):
     """How a conv unit is normalised (the slim arg_scope state around slim.conv2d)."""
@@ -629,6 +650,10 @@ class NormSpec(object):
         assert kind in ("batch_norm", "instance_norm", "none")   # "none" = --without_norm: conv + bias + ReLU
         self.kind, self.eps, self.decay, self.training = kind, eps, decay, training
         self.guide_leaky = False   # LGNet: leaky-ReLU on the guide branch before it is added
+        self.guide_alpha = 0.2     # its slope (tf.nn.leaky_relu default); 0 = the ReLU of GUNet --fix
+        self.guide_per_sample = False   # gw [N, g, C] / gb [N, C]: per-sample folded guide weights (--fix under instance norm)
+        self.dropout = None        # (keep_prob, seed): slim.dropout on the normalised value (GUNet --dropout), training only
+        self.se = None             # GUNet --use_se: callable pooled [N, C] -> gains [N, C] (differentiable torch graph)
         self.bf16 = precision_of(bf16)   # 0 fp32 | 1 UNETK_BF16 (bf16 operands, fp32 tensors) | 2 UNETK_BF16S (+ bf16 tensors)
 
     @property
@@ -668,8 +693,11 @@ class Conv3x3NormRelu(torch.autograd.Function):
                 raise _abi.UnetkError("conv3x3 input gradient needs Cin%64==0 and Cout%16==0 "
                                       "(got {}->{})".format(cin, cout))
         plain = spec.kind == "none"
+        se = getattr(spec, "se", None)
         use_batch_stats = (spec.training or spec.per_sample) and not plain
-        y, stats, rows = conv3x3_fwd(x, wp_f, cout, want_stats=use_batch_stats, bf16=bf16, dilation=dilation)
+        if se is not None and (plain or den is not None or getattr(spec, "dropout", None)):
+            raise _abi.UnetkError("--use_se needs a normalised unit, no other density gain and no --dropout")
+        y, stats, rows = conv3x3_fwd(x, wp_f, cout, want_stats=use_batch_stats or se is not None, bf16=bf16, dilation=dilation)
         z = out if out is not None else torch.empty_like(y)
         g_ch = 0 if guide is None else guide.shape[-1]
         if g_ch:
@@ -677,8 +705,17 @@ class Conv3x3NormRelu(torch.autograd.Function):
         if gb is not None:                  # without a guide: a bare per-channel shift after the gain (after_affine)
             gb = gb.contiguous()
         d = norm_desc(y.shape, spec.per_sample, _pix_stride(z), g_ch, cout if g_ch else 0, 0)
-        if g_ch and getattr(spec, "guide_leaky", False):      # LGNet: u = t + leaky_relu(guide . gw + gb)
+        if g_ch and getattr(spec, "guide_leaky", False):      # LGNet: u = t + leaky_relu(guide . gw + gb); --fix: ReLU
             d.guide_leaky = 1
+            d.guide_alpha = float(getattr(spec, "guide_alpha", 0.2))
+        if getattr(spec, "guide_per_sample", False):
+            d.guide_per_sample = 1
+            d.gw_stride = cout
+        drop = getattr(spec, "dropout", None)
+        if drop is not None and spec.training:
+            d.dropout_keep, d.dropout_seed = float(drop[0]), int(drop[1]) & 0xFFFFFFFF
+            if den is None and (g_ch or gb is not None) and not d.guide_leaky:
+                den = torch.ones((x.shape[0], cout), dtype=torch.float32, device=x.device)   # the backward's separate sum du
         if plain:
             # --without_norm (UNet.py:47-48): z = relu(y + bias); `beta` carries the conv bias
             d.affine_only = 1
@@ -687,9 +724,29 @@ class Conv3x3NormRelu(torch.autograd.Function):
         else:
             aff = norm_finalize(d, stats, rows, gamma, beta, spec.eps, spec.decay, spec.training, moving_mean,
                                 moving_var, y.device)
+        se_graph = None
+        if se is not None:
+            # GUNet.py:192-201: gains = sigmoid(fc(relu(fc(concat(mean_hw(net), context))))).  mean_hw(net)[b, c] =
+            # gamma * xhat_mean[b, c] + beta with xhat_mean from the per-sample means of the raw conv output (the same
+            # statistic partials, reduced per sample); the tiny [N, C] graph below is ordinary torch autograd, run
+            # backwards from inside this node's backward (the gains' gradient is only known there)
+            ps = norm_desc(y.shape, True)
+            mean_b = norm_finalize(ps, stats, rows, None, None, spec.eps, 0.0, True, None, None, y.device)[0]    # [N, C]
+            xhat_mean = ((mean_b - aff[0]) * aff[1]).detach()
+            with torch.enable_grad():
+                g_leaf = gamma.detach().requires_grad_(True) if gamma is not None else None
+                b_leaf = beta.detach().requires_grad_(True) if beta is not None else None
+                pooled = xhat_mean if g_leaf is None else xhat_mean * g_leaf
+                pooled = pooled if b_leaf is None else pooled + b_leaf
+                pooled = pooled + torch.zeros_like(xhat_mean).requires_grad_(True) if not pooled.requires_grad else pooled
+                pooled.retain_grad()
+                gains = se(pooled)
+            den = gains.detach().contiguous()
+            se_graph = (g_leaf, b_leaf, pooled, gains, xhat_mean)
         norm_apply_relu(d, y, aff, z, guide, gw, gb, den)
         if spec.training:
             ctx.save_for_backward(x, y, aff, guide, gw, gb, den)
+            ctx.se_graph = se_graph
             ctx.wp_d = wp_d
             ctx.need_dx = need_dx
             ctx.bf16 = bf16
@@ -714,6 +771,24 @@ class Conv3x3NormRelu(torch.autograd.Function):
         else:
             dy, dgamma, dbeta, dgw, dgb, dden = norm_relu_bwd(ctx.desc, y, dz, aff, ctx.has[0], ctx.has[1], guide, gw, gb,
                                                               den)
+        if getattr(ctx, "se_graph", None) is not None:
+            g_leaf, b_leaf, pooled, gains, xhat_mean = ctx.se_graph
+            torch.autograd.backward(gains, dden)              # FC parameters accumulate here; pooled.grad = d loss / d pooled
+            gp = pooled.grad
+            if g_leaf is not None and g_leaf.grad is not None:
+                dgamma = dgamma + g_leaf.grad if dgamma is not None else g_leaf.grad
+            if b_leaf is not None and b_leaf.grad is not None:
+                dbeta = dbeta + b_leaf.grad if dbeta is not None else b_leaf.grad
+            if not ctx.desc.per_sample:                       # under instance norm the pooled value does not depend on y
+                hw = float(ctx.desc.HW)
+                a_mat = gp / hw
+                k2 = (a_mat * xhat_mean).mean(dim=0, keepdim=True)
+                a_mat = a_mat - a_mat.mean(dim=0, keepdim=True)
+                norm_se_bwd_add(ctx.desc, y, dy, aff, a_mat, k2)
+            dden = None                                       # the gains are internal to this node
+            ctx.se_graph = None
+        if ctx.desc.dropout_keep > 0 and den is not None and not ctx.needs_input_grad[11]:
+            dden = None
         dw = conv3x3_wgrad(x, dy, bf16=ctx.bf16, dilation=ctx.dilation)
         dx = conv3x3_dgrad(dy, ctx.wp_d, x.shape[3], bf16=ctx.bf16, dilation=ctx.dilation) if ctx.need_dx else None
         if DEBUG_CAPTURE is not None:

@@ -163,6 +163,16 @@ typedef struct unetk_norm_desc {
                                   needs guide_ch > 0, no density gains */
   int32_t storage;             /* UNETK_FP32: y / z / dz / dy are fp32; UNETK_BF16S: they are bf16 in memory (strides in
                                   elements), arithmetic, statistics and parameter gradients stay fp32 */
+  float guide_alpha;           /* slope of the guide branch's activation when guide_leaky: 0.2 = LGNet's tf.nn.leaky_relu,
+                                  0 = the ReLU of GUNet --fix (GUNet.py:299-304: the guide convs get norm + ReLU; the host
+                                  folds that norm into gw / gb, exactly, from the guide's first and second moments) */
+  float dropout_keep;          /* > 0: slim.dropout(keep_prob) on the NORMALISED value before the gains / guide term
+                                  (GUNet --dropout, GUNet.py:189-190; training only); the 0 | 1/keep mask is regenerated
+                                  from (dropout_seed, element index) in the forward and both backward passes.  With a guide
+                                  or post-shift the backward needs the density variant (pass den = ones) */
+  uint32_t dropout_seed;
+  int32_t guide_per_sample;    /* 1: gw is [N][guide_ch][gw_stride], gb [N][gw_stride] (per-sample folded weights: --fix under
+                                  instance norm) and dgw / dgb come back per sample; needs per_sample or den */
 } unetk_norm_desc;
 
 /* Finalise the conv's statistic partials ([2][stat_rows][C], each image's tiles contiguous) into
@@ -195,9 +205,18 @@ int unetk_norm_relu_bwd(const unetk_norm_desc* d, const void* y, const void* dz,
                         float* dgamma, float* dbeta, float* dden, float* dgw, float* dgb, void* ws,
                         size_t ws_bytes, void* stream);
 
+/* GUNet --use_se (GUNet.py:192-201): the SE gate's input is pooled[b][c] = mean over the sample's pixels of the normalised
+ * conv output, so the loss reaches y once more through it.  The norm backward is linear in dt, and this part of dt is the
+ * per-(sample, channel) constant g[b][c] / HW: after unetk_norm_relu_bwd,  dy += scale * (A[b][c] - xhat * k2[group][c])
+ * with A = g / HW - its mean over the statistics group and k2 = the group mean of (g / HW) * xhat (both [.][C], formed by
+ * the caller from the per-sample means; zero under instance norm). */
+int unetk_norm_se_bwd_add(const unetk_norm_desc* d, const void* y, void* dy, const float* mean,
+                          const float* rstd, const float* scale, const float* A, const float* k2,
+                          void* stream);
+
 /* ---------------------------------------------------------------- GUNet's context MLP (GUNet.py:136-150 `_context_subnets`)
  * slim.fully_connected(x, n): y[B][n] = act(x[B][k] . w[k][n] + b[n]), TF weight layout [in, out]; relu = 1 for the
- * hidden layers, 0 for the last (activation_fn=None).  slim.dropout(keep_prob) in training: mask from a counter
+ * hidden layers, 0 for the last (activation_fn=None), 2 = tf.nn.sigmoid (the SE gate of GUNet --use_se, GUNet.py:199).  slim.dropout(keep_prob) in training: mask from a counter
  * RNG keyed by (seed, element), kept entries scaled by 1/keep_prob; `mask` ([B][n] floats, 0 or 1/keep_prob,
  * nullable = no dropout) is written by the forward and read by the backward.
  * Backward: dx[B][k] (nullable), dw[k][n], db[n] from dy[B][n] (gated by y > 0 when relu, times the mask). */
@@ -222,6 +241,10 @@ int unetk_maxpool2_bwd_bf16(const void* x, int x_stride, const void* p, const vo
                             int add_stride, void* dx, int N, int H, int W, int C, void* stream);
 /* slim.avg_pool2d(gs, 2) of GUNet's spatial-guide pyramid (GUNet.py:157-158); x, p dense, any C. */
 int unetk_avgpool2_fwd(const float* x, float* p, int N, int H, int W, int C, void* stream);
+/* Moments of the (pooled) spatial guide [N, HW, G] per statistics group (1 group, or N with per_sample):
+ * out[grp][0..G) = E[g_i], out[grp][G + i G + j] = E[g_i g_j].  GUNet --fix normalises the guide's 1x1 conv
+ * (GUNet.py:299-304); that conv being linear in the guide, its statistics follow exactly from these numbers. */
+int unetk_guide_moments(const float* guide, int N, int64_t HW, int G, int per_sample, float* out, void* stream);
 /* --img_grad (UNet.py:69-71, GUNet.py:335-338): out [N,H,W,3C] = concat(x, dy, dx) with
  * tf.image.image_gradients' forward differences (dy[h] = x[h+1] - x[h], last row 0; dx likewise). */
 /* InterUNet's --img_grad input (InterUNet.py:105-109): out [N,H,W,C+2] = concat(x, sobel_dy(x[..., ch]), sobel_dx(x[..., ch]))

@@ -16,7 +16,13 @@ Follows /root/reference/NetworksV2/GUNet.py:
   conditional_normalization :119-133,203-206  net * den[:, None, None, slice] after the norm, before the spatial add
 The dropout masks are an INPUT here (`drop_masks`: one [bs, width] tensor of 0 / 1/keep_prob per hidden layer):
 TF's own mask stream is not reproducible, so parity is on the arithmetic given the mask.
-SE, vgg context models, ct_conv and after_affine variants are not restated.
+--dropout (:189-190): slim.dropout on the normalised output of the first conv of every encoder block; the unit masks are an
+INPUT as well (`unit_masks`: {scope: [bs, H, W, C] of 0 / 1/keep_prob}).
+--fix (:299-304): the guide's 1x1 convs are conv (no bias) -> norm(scale, centre, eps 1e-3, BN decay .99) -> ReLU, here
+computed literally on the materialised 2C-channel tensor.
+--use_se (:192-201): gains = sigmoid(fc(relu(fc(concat(mean_hw(net), context slice))))), the context MLP then emits
+context_fc_channels[-1] values per modulated conv unit (:44-46).
+vgg context models and ct_conv are not restated.
 """
 from collections import OrderedDict
 
@@ -28,7 +34,8 @@ from .unet2d import TRAINABLE_KINDS  # noqa: F401
 
 def param_specs(in_channels, num_classes, guide_channel=1, init_channels=64, num_down_samples=4,
                 mod_layers=(1, 2, 3, 4), normalizer="instance_norm", norm_with_center=True, norm_with_scale=False,
-                name="GUNet", use_spatial=True, context_dims=None, after_affine=False, mid_cat_g=0, without_norm=False):
+                name="GUNet", use_spatial=True, context_dims=None, after_affine=False, mid_cat_g=0, without_norm=False,
+                fix=False, se_length=0):
     """context_dims = [context length, fc widths ..., n_modulator_param] enables the context branch.
     without_norm (GUNet.py:251-252,314-315): every conv unit has a bias and no normaliser."""
     specs = []
@@ -62,7 +69,15 @@ def param_specs(in_channels, num_classes, guide_channel=1, init_channels=64, num
         if use_spatial and i in mod_layers:
             c2 = 2 * init_channels * 2 ** i
             specs.append(("{}/spatial/conv{}/weights".format(name, i + 1), (1, 1, guide_channel, c2), "conv_w"))
-            specs.append(("{}/spatial/conv{}/biases".format(name, i + 1), (c2,), "bias"))
+            if fix:                                                    # normalizer_fn set: no bias (GUNet.py:302-304)
+                gsc = "{}/spatial/conv{}/{}".format(name, i + 1, norm_scope)
+                specs.append((gsc + "/beta", (c2,), "beta"))
+                specs.append((gsc + "/gamma", (c2,), "gamma"))
+                if bn:
+                    specs.append((gsc + "/moving_mean", (c2,), "moving_mean"))
+                    specs.append((gsc + "/moving_variance", (c2,), "moving_var"))
+            else:
+                specs.append(("{}/spatial/conv{}/biases".format(name, i + 1), (c2,), "bias"))
     cin = in_channels
     for i in range(num_down_samples + 1):
         c = init_channels * 2 ** i
@@ -78,6 +93,12 @@ def param_specs(in_channels, num_classes, guide_channel=1, init_channels=64, num
                 specs.append((scope + "/ChannelWiseAffine/beta", None, "beta"))
                 specs.append((scope + "/ChannelWiseAffine/gamma", None, "gamma"))
             fix_shapes(c, start)
+            if se_length and context_dims and i in mod_layers:         # the SE gate's two slim.fully_connected (:196-199)
+                hid = (c + se_length) // 4
+                specs.append((scope + "/fully_connected/weights", (c + se_length, hid), "fc_w"))
+                specs.append((scope + "/fully_connected/biases", (hid,), "fc_b"))
+                specs.append((scope + "/fully_connected_1/weights", (hid, c), "fc_w"))
+                specs.append((scope + "/fully_connected_1/biases", (c,), "fc_b"))
             cin = c
         if i == 0 and mid_cat_g:                                        # UNetInter --mid_cat (UNetInter.py:124-127)
             cin = c + mid_cat_g
@@ -102,7 +123,8 @@ class GUNet2DOracle(object):
     def __init__(self, in_channels, num_classes, guide_channel=1, init_channels=64, num_down_samples=4,
                  mod_layers=(1, 2, 3, 4), normalizer="instance_norm", norm_with_center=True, norm_with_scale=False,
                  name="GUNet", img_grad=False, use_spatial=True, context_length=None, context_fc_channels=(256, 256),
-                 after_affine=False, concat_guide=False, encoder_decay=0.999, mid_cat=False, without_norm=False):
+                 after_affine=False, concat_guide=False, encoder_decay=0.999, mid_cat=False, without_norm=False,
+                 fix=False, use_se=False):
         """concat_guide + mod_layers=() + encoder_decay=.99 + name="UNetInter" is the reference's UNetInter
         (NetworksV2/UNetInter.py:76-141): the guide joins the input channels, encoder BN decay .99 (:98-113)."""
         self.name, self.num_classes = name, num_classes
@@ -112,8 +134,14 @@ class GUNet2DOracle(object):
             use_spatial, mod_layers = False, ()
         self.use_spatial = use_spatial
         self.context_dims = None
-        if context_length:                                             # GUNet.py:47-48
-            n_mod = init_channels * sum(2 ** i for i in range(num_down_samples + 1) if i in mod_layers) * 2
+        self.fix = bool(fix and use_spatial)
+        self.use_se = bool(use_se and context_length)
+        self.se_length = int(list(context_fc_channels)[-1]) if self.use_se else 0
+        if context_length:                                             # GUNet.py:44-48
+            if self.use_se:
+                n_mod = self.se_length * sum(1 for i in range(num_down_samples + 1) if i in mod_layers) * 2
+            else:
+                n_mod = init_channels * sum(2 ** i for i in range(num_down_samples + 1) if i in mod_layers) * 2
             self.context_dims = [context_length] + list(context_fc_channels) + [n_mod]
         self.img_grad = img_grad                                       # GUNet.py:335-338
         self.init_channels, self.nds = init_channels, num_down_samples
@@ -122,10 +150,10 @@ class GUNet2DOracle(object):
         self.without_norm = without_norm
         self.specs = param_specs(in_channels, num_classes, guide_channel, init_channels, num_down_samples, mod_layers,
                                  normalizer, norm_with_center, norm_with_scale, name, use_spatial, self.context_dims,
-                                 after_affine, guide_channel if self.mid_cat else 0, without_norm)
+                                 after_affine, guide_channel if self.mid_cat else 0, without_norm, self.fix, self.se_length)
         self.kinds = {n: k for n, _, k in self.specs}
 
-    def _unit(self, x, p, scope, is_training, new_stats, decay, sp=None, den=None):
+    def _unit(self, x, p, scope, is_training, new_stats, decay, sp=None, den=None, mask=None, se_feat=None):
         y = tf_ops.conv_nd_same(x, p[scope + "/weights"])
         if self.without_norm:
             y = y + p[scope + "/biases"]
@@ -137,6 +165,12 @@ class GUNet2DOracle(object):
         else:
             ns = scope + "/InstanceNorm"
             y = tf_ops.instance_norm(y, p.get(ns + "/gamma"), p.get(ns + "/beta"), eps=1e-6)
+        if mask is not None:                                           # slim.dropout, GUNet.py:189-190 (mask given)
+            y = y * mask
+        if se_feat is not None:                                        # GUNet.py:192-201
+            out = torch.cat((y.mean(dim=(1, 2)), se_feat), dim=-1)
+            out = torch.relu(out @ p[scope + "/fully_connected/weights"] + p[scope + "/fully_connected/biases"])
+            den = torch.sigmoid(out @ p[scope + "/fully_connected_1/weights"] + p[scope + "/fully_connected_1/biases"])
         if den is not None:                                            # conditional_normalization, GUNet.py:129-133
             y = y * den[:, None, None, :]
         if sp is not None:
@@ -157,7 +191,7 @@ class GUNet2DOracle(object):
                     net = net * drop_masks[li - 1]
         return net
 
-    def forward(self, p, images, sp_guide, is_training, context=None, drop_masks=None):
+    def forward(self, p, images, sp_guide, is_training, context=None, drop_masks=None, unit_masks=None):
         n = self.name
         new_stats = OrderedDict()
         den_all, den_off = None, 0
@@ -169,7 +203,20 @@ class GUNet2DOracle(object):
         for i in range(self.nds + 1):
             if self.use_spatial and i in self.mod_layers:
                 w = p["{}/spatial/conv{}/weights".format(n, i + 1)]
-                sp_params[i] = gs @ w.reshape(w.shape[2], w.shape[3]) + p["{}/spatial/conv{}/biases".format(n, i + 1)]
+                sp_i = gs @ w.reshape(w.shape[2], w.shape[3])
+                if self.fix:                                           # conv -> norm (eps 1e-3, BN decay .99) -> ReLU
+                    sc = "{}/spatial/conv{}".format(n, i + 1)
+                    if self.normalizer == "batch_norm":
+                        ns = sc + "/BatchNorm"
+                        sp_i, mm, mv = tf_ops.batch_norm(sp_i, p[ns + "/gamma"], p[ns + "/beta"], p[ns + "/moving_mean"],
+                                                         p[ns + "/moving_variance"], is_training, eps=1e-3, decay=0.99)
+                        new_stats[ns + "/moving_mean"], new_stats[ns + "/moving_variance"] = mm, mv
+                    else:
+                        ns = sc + "/InstanceNorm"
+                        sp_i = tf_ops.instance_norm(sp_i, p[ns + "/gamma"], p[ns + "/beta"], eps=1e-3)
+                    sp_params[i] = torch.relu(sp_i)
+                else:
+                    sp_params[i] = sp_i + p["{}/spatial/conv{}/biases".format(n, i + 1)]
             if i < self.nds:
                 gs = tf_ops.avg_pool2x2_same(gs)
         x = torch.cat((images,) + tf_ops.image_gradients(images), dim=-1) if self.img_grad else images
@@ -182,11 +229,16 @@ class GUNet2DOracle(object):
             for j in (1, 2):
                 scope = "{}/Encode/down_conv{}/mod_conv{}".format(n, i + 1, j)
                 sp = sp_params[i][..., (j - 1) * c:j * c] if (mod and self.use_spatial) else None
-                den = None
-                if mod and den_all is not None:
+                den = se_feat = None
+                if mod and den_all is not None and self.use_se:
+                    se_feat = den_all[:, den_off:den_off + self.se_length]
+                    den_off += self.se_length
+                elif mod and den_all is not None:
                     den = den_all[:, den_off:den_off + c]
                     den_off += c
-                x = self._unit(x, p, scope, is_training, new_stats, 0.99 if mod else self.encoder_decay, sp, den)
+                mask = unit_masks.get(scope) if (unit_masks and j == 1) else None
+                x = self._unit(x, p, scope, is_training, new_stats, 0.99 if mod else self.encoder_decay, sp, den, mask,
+                               se_feat)
             if i < self.nds:
                 skips.append(x)
                 if i == 0 and self.mid_cat:                             # UNetInter.py:124-127
@@ -213,8 +265,8 @@ class GUNet2DOracle(object):
 
     def loss(self, p, images, sp_guide, labels, loss_type="xentropy", loss_weight_type="none", numeric_w=None,
              proportion_decay=None, weight_decay_rate=0.0, bias_decay=False, is_training=True, context=None,
-             drop_masks=None):
-        logits, new_stats = self.forward(p, images, sp_guide, is_training, context, drop_masks)
+             drop_masks=None, unit_masks=None):
+        logits, new_stats = self.forward(p, images, sp_guide, is_training, context, drop_masks, unit_masks)
         kw = {}
         if loss_weight_type == "numerical":
             kw["numeric_w"] = numeric_w

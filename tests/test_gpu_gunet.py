@@ -575,3 +575,236 @@ def test_unetinter_matches_oracle_and_trains(normalizer, mid_cat):
     m2d = zoo["UNetInter"](make_args(use_spatial=True, guide_channel=1, mid_cat=False, use_2d=True))
     m2d(inputs, "eval", **yml)
     assert m2d.probability.shape == (2, 32, 32, 3)
+
+
+# ----------------------------------------------------------------------------- --dropout / --fix / --use_se (GUNet.py:189-201,299-304)
+def unit_mask_host(seed, shape, keep):
+    """The 0 | 1/keep mask the norm kernels regenerate: unetk_uniform(seed, flat NHWC element index) < keep."""
+    idx = np.arange(int(np.prod(shape)), dtype=np.uint64)
+    u = fc_uniform_host(seed & 0xFFFFFFFF, idx).reshape(shape)
+    return np.where(u < np.float32(keep), np.float32(1.0 / keep), np.float32(0.0)).astype(np.float32)
+
+
+@pytest.mark.parametrize("per_sample,g_ch,with_den,leaky", [(True, 0, False, False), (False, 1, False, False), (True, 2, True, False),
+                                                            (False, 0, True, False), (True, 1, False, True)])
+def test_norm_dropout_forward_backward(per_sample, g_ch, with_den, leaky):
+    """u = norm(y) * mask [* den] [+ guide . gw + gb | + lrelu(guide . gw + gb)], z = relu(u): slim.dropout on the normalised
+    value (GUNet.py:189-190) inside the norm kernels, against float64 autograd with the SAME mask (regenerated on the host)."""
+    from boxsegliver_amd import ops
+    from oracle import tf_ops
+    n, h, c, keep, seed = 3, 12, 64, 0.7, 987654321
+    gen = torch.Generator().manual_seed(g_ch + 10 * per_sample)
+    y = torch.randn(n, h, h, c, generator=gen) * 2 + 0.5
+    gamma, beta = 0.5 + torch.rand(c, generator=gen), 0.3 * torch.randn(c, generator=gen)
+    den = 1.0 + 0.5 * torch.randn(n, c, generator=gen) if with_den else None
+    dz = torch.randn(n, h, h, c, generator=gen)
+    guide = torch.rand(n, h, h, g_ch, generator=gen) if g_ch else None
+    gw = torch.randn(g_ch, c, generator=gen) if g_ch else None
+    gb = 0.1 * torch.randn(c, generator=gen) if g_ch else None
+    yd = y.cuda()
+    d = ops.norm_desc(y.shape, per_sample, c, g_ch, c if g_ch else 0, 0)
+    d.dropout_keep, d.dropout_seed = keep, seed
+    if leaky:
+        d.guide_leaky, d.guide_alpha = 1, 0.0
+    flat = yd.reshape(n, h * h, c)
+    stats = torch.stack([flat.sum(1), (flat * flat).sum(1)]).contiguous()
+    aff = ops.norm_finalize(d, stats, n, gamma.cuda(), beta.cuda(), 1e-6 if per_sample else 1e-3, 0.99, True,
+                            torch.zeros(c).cuda(), torch.ones(c).cuda(), yd.device)
+    cu = lambda t: None if t is None else t.cuda().contiguous()
+    den_k = den if (with_den or not g_ch or leaky) else torch.ones(n, c)      # guide bias sum needs the density variant
+    z = torch.empty_like(yd)
+    ops.norm_apply_relu(d, yd, aff, z, cu(guide), cu(gw), cu(gb), cu(den_k))
+    out = ops.norm_relu_bwd(d, yd, cu(dz), aff, True, True, cu(guide), cu(gw), cu(gb), cu(den_k))
+    dy, dgamma, dbeta, dgw, dgb = out[:5]
+    mask = torch.from_numpy(unit_mask_host(seed, (n, h, h, c), keep)).double()
+    assert 0.6 < (mask > 0).double().mean().item() < 0.8
+    d64 = lambda t: None if t is None else t.double().requires_grad_(True)
+    y64, g64, b64, den64, gw64, gb64 = d64(y), d64(gamma), d64(beta), d64(den), d64(gw), d64(gb)
+    t = tf_ops.instance_norm(y64, g64, b64, eps=1e-6) if per_sample else \
+        tf_ops.batch_norm(y64, g64, b64, torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64), True)[0]
+    u = t * mask
+    if den64 is not None:
+        u = u * den64[:, None, None, :]
+    if g_ch:
+        s = guide.double() @ gw64 + gb64
+        u = u + (torch.relu(s) if leaky else s)
+    ref = torch.relu(u)
+    ref.backward(dz.double())
+    tol = 2e-5
+    assert rel(z.cpu().numpy(), ref.detach().numpy()) < tol
+    assert rel(dy.cpu().numpy(), y64.grad.numpy()) < tol
+    assert rel(dgamma.cpu().numpy(), g64.grad.numpy()) < tol and rel(dbeta.cpu().numpy(), b64.grad.numpy()) < tol
+    if with_den:
+        assert rel(out[5].cpu().numpy(), den64.grad.numpy()) < tol
+    if g_ch:
+        assert rel(dgw.cpu().numpy(), gw64.grad.numpy()) < tol and rel(dgb.cpu().numpy(), gb64.grad.numpy()) < tol
+
+
+@pytest.mark.parametrize("g_ch", [1, 2])
+def test_norm_per_sample_guide_weights_with_relu_branch(g_ch):
+    """--fix under instance norm: per-sample folded guide weights gw [N, g, C] / gb [N, C], ReLU on the guide branch;
+    dgw / dgb come back per sample."""
+    from boxsegliver_amd import ops
+    from oracle import tf_ops
+    n, h, c = 3, 10, 128
+    gen = torch.Generator().manual_seed(g_ch)
+    y = torch.randn(n, h, h, c, generator=gen) * 2 + 0.5
+    beta = 0.3 * torch.randn(c, generator=gen)
+    dz = torch.randn(n, h, h, c, generator=gen)
+    guide = torch.rand(n, h, h, g_ch, generator=gen)
+    gw = torch.randn(n, g_ch, c, generator=gen)
+    gb = 0.3 * torch.randn(n, c, generator=gen)
+    yd = y.cuda()
+    d = ops.norm_desc(y.shape, True, c, g_ch, c, 0)
+    d.guide_leaky, d.guide_alpha, d.guide_per_sample = 1, 0.0, 1
+    flat = yd.reshape(n, h * h, c)
+    stats = torch.stack([flat.sum(1), (flat * flat).sum(1)]).contiguous()
+    aff = ops.norm_finalize(d, stats, n, None, beta.cuda(), 1e-6, 0.0, True, None, None, yd.device)
+    z = torch.empty_like(yd)
+    ops.norm_apply_relu(d, yd, aff, z, guide.cuda(), gw.cuda(), gb.cuda())
+    dy, dgamma, dbeta, dgw, dgb = ops.norm_relu_bwd(d, yd, dz.cuda(), aff, False, True, guide.cuda(), gw.cuda(), gb.cuda())
+    assert dgw.shape == (n, g_ch, c) and dgb.shape == (n, c)
+    y64, b64, gw64, gb64 = y.double().requires_grad_(True), beta.double().requires_grad_(True), \
+        gw.double().requires_grad_(True), gb.double().requires_grad_(True)
+    t = tf_ops.instance_norm(y64, None, b64, eps=1e-6)
+    s = torch.einsum("nhwg,ngc->nhwc", guide.double(), gw64) + gb64[:, None, None, :]
+    ref = torch.relu(t + torch.relu(s))
+    ref.backward(dz.double())
+    tol = 2e-5
+    assert rel(z.cpu().numpy(), ref.detach().numpy()) < tol and rel(dy.cpu().numpy(), y64.grad.numpy()) < tol
+    assert rel(dbeta.cpu().numpy(), b64.grad.numpy()) < tol
+    assert rel(dgw.cpu().numpy(), gw64.grad.numpy()) < tol and rel(dgb.cpu().numpy(), gb64.grad.numpy()) < tol
+
+
+def test_guide_moments_exact():
+    from boxsegliver_amd import ops
+    gen = torch.Generator().manual_seed(2)
+    g = torch.rand(3, 16, 20, 2, generator=gen)
+    for per_sample in (False, True):
+        m = ops.guide_moments(g.cuda(), per_sample).cpu().double()
+        gd = g.double().reshape(3, -1, 2) if per_sample else g.double().reshape(1, -1, 2)
+        np.testing.assert_allclose(m[:, :2].numpy(), gd.mean(1).numpy(), rtol=1e-6)
+        np.testing.assert_allclose(m[:, 2:].reshape(-1, 2, 2).numpy(), torch.einsum("kpi,kpj->kij", gd, gd).numpy() / gd.shape[1],
+                                   rtol=1e-6)
+
+
+def _whole_net_check(model, inputs, net, params, tensors, args, yml, oracle_kw, loss_tol=1e-4, grad_tol=2e-2):
+    images, guide, labels = tensors[:3]
+    p64 = {k: v.double() for k, v in params.items()}
+    kw = dict(kwargs_of(args))
+    kw.update({k: (v.double() if torch.is_tensor(v) else v) for k, v in oracle_kw.items()})
+    total, _, logits, grads, new_stats = net.loss_and_grads(p64, images.double(), guide.double(), labels, **kw)
+    model.params.zero_grad()
+    loss = model(inputs, "train", **yml)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - total.item()) < loss_tol * max(1.0, abs(total.item()))
+    got = model.layers["logits"].cpu().numpy()
+    assert np.abs(got - logits.numpy()).max() < 1e-3
+    num = den = 0.0
+    for name in model.params.trainable_names():
+        g = model.params[name].grad.cpu().numpy().astype(np.float64)
+        if model.params.where[name][0] == "reg":
+            g = g + args.weight_decay_rate * model.params[name].detach().cpu().numpy().astype(np.float64)
+        ref = grads[name].numpy()
+        assert np.linalg.norm(g - ref) / max(np.linalg.norm(ref), 1e-30) < 0.15, name
+        num += np.sum((g - ref) ** 2)
+        den += np.sum(ref ** 2)
+    assert (num / den) ** 0.5 < grad_tol
+    for name, ref in new_stats.items():
+        np.testing.assert_allclose(model.params[name].cpu().numpy(), ref.numpy(), rtol=2e-4, atol=1e-6)
+    return loss
+
+
+def _setup_variant(args, yml, oracle_ctor_kw, ctx_len=0, size=32):
+    from boxsegliver_amd.NetworksV2.GUNet import GUNet
+    from boxsegliver_amd.data.synthetic import make_batch, make_guide
+    images, labels, _ = make_batch(2, size, size, 3, 3, 1234)
+    guide = make_guide(labels, args.guide_channel, 1234)
+    gen = torch.Generator().manual_seed(5)
+    model = GUNet(args)
+    inputs = {"images": torch.from_numpy(images).cuda(), "labels": torch.from_numpy(labels).cuda(),
+              "sp_guide": torch.from_numpy(guide).cuda()}
+    context = None
+    if ctx_len:
+        context = torch.rand(2, ctx_len, generator=gen)
+        inputs["context"] = context.cuda()
+    model(inputs, "eval", **yml)
+    net = gunet2d.GUNet2DOracle(3, 3, guide_channel=args.guide_channel, normalizer=args.normalizer,
+                                context_length=ctx_len or None, context_fc_channels=yml["context_fc_channels"], **oracle_ctor_kw)
+    assert [(n, tuple(s), k) for n, s, k in net.specs] == [(n, tuple(s), k) for n, s, k in model.params.specs]
+    params = {}
+    for name, t in model.params.state_dict().items():
+        kind = net.kinds[name]
+        if kind == "gamma":
+            params[name] = 0.5 + torch.rand(t.shape, generator=gen)
+        elif kind in ("beta", "bias", "fc_b"):
+            params[name] = 0.2 * torch.randn(t.shape, generator=gen)
+        elif "spatial" in name and kind == "conv_w":
+            params[name] = 0.5 * torch.randn(t.shape, generator=gen)
+        elif kind in ("moving_mean",):
+            params[name] = 0.1 * torch.randn(t.shape, generator=gen)
+        elif kind in ("moving_var",):
+            params[name] = 0.5 + torch.rand(t.shape, generator=gen)
+        else:
+            params[name] = t.clone()
+    model.params.load_state(params)
+    return model, inputs, net, params, (torch.from_numpy(images), torch.from_numpy(guide), torch.from_numpy(labels).long(),
+                                        context)
+
+
+@pytest.mark.parametrize("normalizer,g_ch", [("instance_norm", 1), ("batch_norm", 2)])
+def test_gunet_fix_matches_oracle(normalizer, g_ch):
+    """--fix: the oracle materialises conv1x1 -> norm -> ReLU on the guide; the product folds the norm into the guide weights
+    from the guide's moments.  Same loss / logits / gradients (incl. the guide convs' gamma / beta) and moving statistics."""
+    args = make_args(normalizer=normalizer, guide_channel=g_ch, fix=True)
+    model, inputs, net, params, tensors = _setup_variant(args, YML, dict(fix=True))
+    names = list(model.params.state_dict())
+    ns = "BatchNorm" if normalizer == "batch_norm" else "InstanceNorm"
+    assert "GUNet/spatial/conv2/{}/gamma".format(ns) in names and "GUNet/spatial/conv2/biases" not in names
+    _whole_net_check(model, inputs, net, params, tensors, args, YML, {})
+    # eval mode: batch norm uses the moving statistics of the guide convs
+    logits_eval, _ = net.forward({k: v.double() for k, v in model.params.state_dict().items()}, tensors[0].double(),
+                                 tensors[1].double(), False)
+    model(inputs, "eval", **YML)
+    assert np.abs(model.layers["logits"].cpu().numpy() - logits_eval.numpy()).max() < 1e-3
+
+
+@pytest.mark.parametrize("normalizer,use_context", [("instance_norm", False), ("batch_norm", True)])
+def test_gunet_dropout_matches_oracle(normalizer, use_context):
+    """--dropout 0.3: the first conv unit of every encoder block is masked after its norm; the oracle gets the masks the
+    kernels regenerate (restated RNG), so the comparison is on the arithmetic."""
+    yml = dict(YML, context_fc_channels=[32, 16])
+    args = make_args(normalizer=normalizer, dropout=0.3, use_context=use_context, side_dropout=0.0)
+    model, inputs, net, params, tensors = _setup_variant(args, yml, {}, ctx_len=10 if use_context else 0)
+    calls = getattr(model, "_dropout_calls", 0)
+    masks = {}
+    for i in range(5):                                   # the seeds GUNet._build_network will use in the next training call
+        c = 64 * 2 ** i
+        seed = int(args.seed) * 7919 + (calls + 1 + i) * 131 + i
+        masks["GUNet/Encode/down_conv{}/mod_conv1".format(i + 1)] = torch.from_numpy(
+            unit_mask_host(seed, (2, 32 >> i, 32 >> i, c), 0.7))
+    okw = {"unit_masks": masks}
+    if use_context:
+        okw["context"] = tensors[3]
+    _whole_net_check(model, inputs, net, params, tensors, args, yml, okw)
+    model(inputs, "eval", **yml)                          # no dropout outside training
+    okw_eval = {k: v for k, v in okw.items() if k != "unit_masks"}
+    p64 = {k: v.double() for k, v in model.params.state_dict().items()}
+    ref, _ = net.forward(p64, tensors[0].double(), tensors[1].double(), False,
+                         context=okw_eval.get("context").double() if use_context else None)
+    assert np.abs(model.layers["logits"].cpu().numpy() - ref.numpy()).max() < 1e-3
+
+
+@pytest.mark.parametrize("normalizer", ["instance_norm", "batch_norm"])
+def test_gunet_use_se_matches_oracle(normalizer):
+    """--use_se: gains = sigmoid(fc(relu(fc(concat(mean_hw(norm(conv)), context slice))))) per modulated conv unit; under batch
+    norm the pooled value depends on the unit's own conv output (the extra term of unetk_norm_se_bwd_add)."""
+    yml = dict(YML, context_fc_channels=[32, 16])
+    args = make_args(normalizer=normalizer, use_context=True, use_se=True, side_dropout=0.0)
+    model, inputs, net, params, tensors = _setup_variant(args, yml, dict(use_se=True), ctx_len=10)
+    names = list(model.params.state_dict())
+    assert "GUNet/Encode/down_conv2/mod_conv1/fully_connected/weights" in names
+    assert model.params["GUNet/Encode/down_conv2/mod_conv1/fully_connected/weights"].shape == (128 + 16, (128 + 16) // 4)
+    assert model.params["GUNet/context/fc3/weights"].shape == (16, 16 * 4 * 2)
+    _whole_net_check(model, inputs, net, params, tensors, args, yml, {"context": tensors[3]})
