@@ -167,26 +167,26 @@ class GUNet(base.BaseNet):
                                 bool(np_["is_training"]), self.compute_bf16)
         return ops.NormSpec("instance_norm", np_["eps"], 0.0, self.is_training, self.compute_bf16)
 
-    def _unit(self, x, scope, spec, out=None, guide=None, gw=None, gb=None, den=None):
+    def _unit(self, x, scope, spec, out=None, guide=None, gw=None, gb=None, den=None, se_feat=None):
         p = self.params
         if spec.kind == "none":
             z = ops.Conv3x3NormRelu.apply(x, p[scope + "/weights"], None, p[scope + "/biases"], None, None, spec, out,
-                                          guide, gw, gb, den)
+                                          guide, gw, gb, den, 1, se_feat)
         else:
             ns = scope + ("/BatchNorm" if spec.kind == "batch_norm" else "/InstanceNorm")
             z = ops.Conv3x3NormRelu.apply(x, p[scope + "/weights"], p.get(ns + "/gamma"), p.get(ns + "/beta"),
                                           p.get(ns + "/moving_mean"), p.get(ns + "/moving_variance"), spec, out, guide,
-                                          gw, gb, den)
+                                          gw, gb, den, 1, se_feat)
         if self._taps is not None:
             self._taps[scope] = z
         return z
 
-    def _se_gate(self, scope, ctx_feat):
-        """GUNet.py:192-201: pooled [N, C] -> sigmoid(fc(relu(fc(concat(pooled, context slice))))); the two
+    def _se_gate(self, scope):
+        """GUNet.py:192-201: (pooled [N, C], context slice [N, L]) -> sigmoid(fc(relu(fc(concat(...))))); the two
         slim.fully_connected live under the conv unit's scope."""
         p = self.params
 
-        def gate(pooled):
+        def gate(pooled, ctx_feat):
             h = torch.cat((pooled, ctx_feat), dim=1)
             h = ops.FullyConnected.apply(h, p[scope + "/fully_connected/weights"], p[scope + "/fully_connected/biases"], 1, None, 0)
             return ops.FullyConnected.apply(h, p[scope + "/fully_connected_1/weights"], p[scope + "/fully_connected_1/biases"],
@@ -344,11 +344,11 @@ class GUNet(base.BaseNet):
                         self._dropout_calls = getattr(self, "_dropout_calls", 0) + 1
                         spec.dropout = (1.0 - float(self.dropout),
                                         int(getattr(self.args, "seed", None) or 1234) * 7919 + self._dropout_calls * 131 + i)
-                    den = None
+                    den = se_feat = None
                     if dens and self.use_se:                                 # GUNet.py:192-201
-                        ctx_feat = den_all[:, den_off:den_off + se_len]
+                        se_feat = den_all[:, den_off:den_off + se_len].contiguous()
                         den_off += se_len
-                        spec.se = self._se_gate(scope, ctx_feat)
+                        spec.se = self._se_gate(scope)
                     elif dens:                                               # GUNet.py:203-206
                         den = den_all[:, den_off:den_off + c]
                         den_off += c
@@ -371,7 +371,7 @@ class GUNet(base.BaseNet):
                             gw, gb = gw * ga, gb * ga + ba
                         else:
                             gb = ba
-                    x = self._unit(x, scope, spec, out, guide, gw, gb, den)
+                    x = self._unit(x, scope, spec, out, guide, gw, gb, den, se_feat)
                 if i < nds:
                     if i == 0 and self._concat_guide and self._mid_cat:
                         # UNetInter.py:124-129: pool(concat(level-0 output, guide)); zero channels up to the padded width

@@ -500,7 +500,8 @@ extern "C" int unetk_norm_apply_relu(const unetk_norm_desc* d, const void* y, co
   if (d->dropout_keep < 0.f || d->dropout_keep > 1.f) return UNETK_E_BADARG;
   if (d->guide_per_sample && g.L != d->N) return UNETK_E_UNSUPPORTED;      // needs one launch group per sample
   ApplyArgs a{y, scale, shift, den, guide, gw, gb, z, g.P, d->C, d->z_stride, g.cq_n, g.rpi, d->gw_stride, d->gw_coff, g.sst,
-              d->guide_per_sample ? d->guide_ch * d->gw_stride : 0, d->guide_per_sample ? d->gw_stride : 0, d->guide_alpha,
+              d->guide_per_sample ? d->guide_ch * d->gw_stride : 0, d->guide_per_sample ? d->gw_stride : 0,
+              d->guide_leaky == 2 ? d->guide_alpha : 0.2f,
               d->dropout_keep, d->dropout_seed};
   int64_t gx = (g.P + g.rpi - 1) / g.rpi;
   const int64_t cap = g.L > 1 ? (4096 + g.L - 1) / g.L : 4096;
@@ -570,7 +571,7 @@ extern "C" int unetk_norm_relu_bwd(const unetk_norm_desc* d, const void* y, cons
   if (d->dropout_keep > 0.f && (gb || G > 0) && !D && !leaky) return UNETK_E_UNSUPPORTED;   // the guide-bias sum needs the density variant (pass den = 1)
   if (d->guide_per_sample && g.L != d->N) return UNETK_E_UNSUPPORTED;
   a.gw_ns = d->guide_per_sample ? G * d->gw_stride : 0; a.gb_ns = d->guide_per_sample ? d->gw_stride : 0;
-  a.alpha = d->guide_alpha; a.keep = d->dropout_keep; a.seed = d->dropout_seed;
+  a.alpha = d->guide_leaky == 2 ? d->guide_alpha : 0.2f; a.keep = d->dropout_keep; a.seed = d->dropout_seed;
   // the statistics sums of the dy formula: per launch group when the statistics are per sample, else the batch totals
   if (d->per_sample) { a.ksum = sums; a.kst = d->C; a.krow = g.L * d->C; }
   else if (g.L == 1) { a.ksum = sums; a.kst = 0; a.krow = d->C; }

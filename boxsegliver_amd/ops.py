@@ -653,7 +653,7 @@ class NormSpec(object):
         self.guide_alpha = 0.2     # its slope (tf.nn.leaky_relu default); 0 = the ReLU of GUNet --fix
         self.guide_per_sample = False   # gw [N, g, C] / gb [N, C]: per-sample folded guide weights (--fix under instance norm)
         self.dropout = None        # (keep_prob, seed): slim.dropout on the normalised value (GUNet --dropout), training only
-        self.se = None             # GUNet --use_se: callable pooled [N, C] -> gains [N, C] (differentiable torch graph)
+        self.se = None             # GUNet --use_se: callable (pooled [N, C], context slice) -> gains [N, C] (torch graph)
         self.bf16 = precision_of(bf16)   # 0 fp32 | 1 UNETK_BF16 (bf16 operands, fp32 tensors) | 2 UNETK_BF16S (+ bf16 tensors)
 
     @property
@@ -667,7 +667,7 @@ class Conv3x3NormRelu(torch.autograd.Function):
     ReLU (NetworksV2/UNet.py:41-56,79; GUNet.py:162-217 `modulated_conv_block`)."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, moving_mean, moving_var, spec, out, guide, gw, gb, den=None, dilation=1):
+    def forward(ctx, x, w, gamma, beta, moving_mean, moving_var, spec, out, guide, gw, gb, den=None, dilation=1, se_feat=None):
         _require_cuda(x, w)
         cin, cout = w.shape[2], w.shape[3]
         dilation = int(dilation or 1)
@@ -706,8 +706,9 @@ class Conv3x3NormRelu(torch.autograd.Function):
             gb = gb.contiguous()
         d = norm_desc(y.shape, spec.per_sample, _pix_stride(z), g_ch, cout if g_ch else 0, 0)
         if g_ch and getattr(spec, "guide_leaky", False):      # LGNet: u = t + leaky_relu(guide . gw + gb); --fix: ReLU
-            d.guide_leaky = 1
-            d.guide_alpha = float(getattr(spec, "guide_alpha", 0.2))
+            alpha = float(getattr(spec, "guide_alpha", 0.2))
+            d.guide_leaky = 1 if alpha == 0.2 else 2           # 1 = tf.nn.leaky_relu's default slope, 2 = guide_alpha
+            d.guide_alpha = alpha
         if getattr(spec, "guide_per_sample", False):
             d.guide_per_sample = 1
             d.gw_stride = cout
@@ -740,9 +741,12 @@ class Conv3x3NormRelu(torch.autograd.Function):
                 pooled = pooled if b_leaf is None else pooled + b_leaf
                 pooled = pooled + torch.zeros_like(xhat_mean).requires_grad_(True) if not pooled.requires_grad else pooled
                 pooled.retain_grad()
-                gains = se(pooled)
+                # the context slice comes from the OUTER graph (the context MLP): inside, a detached leaf stands in for it
+                # and its gradient is handed back as this node's gradient for `se_feat`
+                f_leaf = se_feat.detach().requires_grad_(True) if se_feat is not None else None
+                gains = se(pooled, f_leaf)
             den = gains.detach().contiguous()
-            se_graph = (g_leaf, b_leaf, pooled, gains, xhat_mean)
+            se_graph = (g_leaf, b_leaf, pooled, gains, xhat_mean, f_leaf)
         norm_apply_relu(d, y, aff, z, guide, gw, gb, den)
         if spec.training:
             ctx.save_for_backward(x, y, aff, guide, gw, gb, den)
@@ -765,16 +769,17 @@ class Conv3x3NormRelu(torch.autograd.Function):
             dz = dz.contiguous()
         if dz.dtype != y.dtype:
             raise _abi.UnetkError("gradient dtype {} does not match the stored activations ({})".format(dz.dtype, y.dtype))
-        dden = None
+        dden = dfeat = None
         if den is None:
             dy, dgamma, dbeta, dgw, dgb = norm_relu_bwd(ctx.desc, y, dz, aff, ctx.has[0], ctx.has[1], guide, gw, gb)
         else:
             dy, dgamma, dbeta, dgw, dgb, dden = norm_relu_bwd(ctx.desc, y, dz, aff, ctx.has[0], ctx.has[1], guide, gw, gb,
                                                               den)
         if getattr(ctx, "se_graph", None) is not None:
-            g_leaf, b_leaf, pooled, gains, xhat_mean = ctx.se_graph
+            g_leaf, b_leaf, pooled, gains, xhat_mean, f_leaf = ctx.se_graph
             torch.autograd.backward(gains, dden)              # FC parameters accumulate here; pooled.grad = d loss / d pooled
             gp = pooled.grad
+            dfeat = f_leaf.grad if f_leaf is not None else None
             if g_leaf is not None and g_leaf.grad is not None:
                 dgamma = dgamma + g_leaf.grad if dgamma is not None else g_leaf.grad
             if b_leaf is not None and b_leaf.grad is not None:
@@ -796,11 +801,12 @@ class Conv3x3NormRelu(torch.autograd.Function):
                                       dx=dx, dgamma=dgamma, dbeta=dbeta, w=ctx.w_dbg, guide=guide, gw=gw, gb=gb,
                                       dgw=dgw, dgb=dgb, per_sample=bool(ctx.desc.per_sample), bf16=ctx.bf16, den=den,
                                       dden=dden, guide_leaky=bool(ctx.desc.guide_leaky), plain=bool(ctx.desc.affine_only)))
-        return dx, dw, dgamma, dbeta, None, None, None, None, None, dgw, dgb, dden, None
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, dgw, dgb, dden, None, dfeat
 
 
 class FullyConnected(torch.autograd.Function):
-    """y = dropout(act(x . w + b)) -- one slim.fully_connected (+ slim.dropout) of GUNet's context MLP
+    """y = dropout(act(x . w + b)), act = identity (relu 0 / False), ReLU (1 / True) or sigmoid (2: the SE gate,
+    GUNet.py:199) -- one slim.fully_connected (+ slim.dropout) of GUNet's context MLP
     (NetworksV2/Backbone/slim_nets.py:43-56; GUNet.py:50-60).  w is TF's [in, out].  keep_prob None = no dropout;
     the mask (0 or 1/keep_prob per element, counter RNG keyed by `seed`) is kept for the backward."""
 
@@ -813,7 +819,7 @@ class FullyConnected(torch.autograd.Function):
         assert w.shape[0] == k and w.is_contiguous()
         y = torch.empty((bsz, n), dtype=torch.float32, device=x.device)
         mask = torch.empty_like(y) if keep_prob is not None else None
-        check(_abi.lib().unetk_fc_fwd(ptr(x), ptr(w), ptr(b), ptr(y), ptr(mask), bsz, k, n, 1 if relu else 0,
+        check(_abi.lib().unetk_fc_fwd(ptr(x), ptr(w), ptr(b), ptr(y), ptr(mask), bsz, k, n, int(relu or 0),
                                       float(keep_prob) if keep_prob is not None else 1.0, int(seed) & 0xFFFFFFFF,
                                       stream_ptr()), "fc_fwd")
         ctx.save_for_backward(x, w, y, mask)
@@ -832,7 +838,7 @@ class FullyConnected(torch.autograd.Function):
         db = torch.empty((n,), dtype=torch.float32, device=x.device) if ctx.has_b else None
         ws = torch.empty_like(y)
         check(_abi.lib().unetk_fc_bwd(ptr(x), ptr(w), ptr(y), ptr(mask), ptr(dy), ptr(dx), ptr(dw), ptr(db), ptr(ws), bsz, k,
-                                      n, 1 if ctx.relu else 0, stream_ptr()), "fc_bwd")
+                                      n, int(ctx.relu or 0), stream_ptr()), "fc_bwd")
         return dx, dw, db, None, None, None
 
 

@@ -163,8 +163,8 @@ typedef struct unetk_norm_desc {
                                   needs guide_ch > 0, no density gains */
   int32_t storage;             /* UNETK_FP32: y / z / dz / dy are fp32; UNETK_BF16S: they are bf16 in memory (strides in
                                   elements), arithmetic, statistics and parameter gradients stay fp32 */
-  float guide_alpha;           /* slope of the guide branch's activation when guide_leaky: 0.2 = LGNet's tf.nn.leaky_relu,
-                                  0 = the ReLU of GUNet --fix (GUNet.py:299-304: the guide convs get norm + ReLU; the host
+  float guide_alpha;           /* slope of the guide branch's activation when guide_leaky == 2 (guide_leaky == 1 is
+                                  tf.nn.leaky_relu's default 0.2, LGNet): 0 = the ReLU of GUNet --fix (GUNet.py:299-304: the guide convs get norm + ReLU; the host
                                   folds that norm into gw / gb, exactly, from the guide's first and second moments) */
   float dropout_keep;          /* > 0: slim.dropout(keep_prob) on the NORMALISED value before the gains / guide term
                                   (GUNet --dropout, GUNet.py:189-190; training only); the 0 | 1/keep mask is regenerated

@@ -605,7 +605,7 @@ def test_norm_dropout_forward_backward(per_sample, g_ch, with_den, leaky):
     d = ops.norm_desc(y.shape, per_sample, c, g_ch, c if g_ch else 0, 0)
     d.dropout_keep, d.dropout_seed = keep, seed
     if leaky:
-        d.guide_leaky, d.guide_alpha = 1, 0.0
+        d.guide_leaky, d.guide_alpha = 2, 0.0
     flat = yd.reshape(n, h * h, c)
     stats = torch.stack([flat.sum(1), (flat * flat).sum(1)]).contiguous()
     aff = ops.norm_finalize(d, stats, n, gamma.cuda(), beta.cuda(), 1e-6 if per_sample else 1e-3, 0.99, True,
@@ -656,7 +656,7 @@ def test_norm_per_sample_guide_weights_with_relu_branch(g_ch):
     gb = 0.3 * torch.randn(n, c, generator=gen)
     yd = y.cuda()
     d = ops.norm_desc(y.shape, True, c, g_ch, c, 0)
-    d.guide_leaky, d.guide_alpha, d.guide_per_sample = 1, 0.0, 1
+    d.guide_leaky, d.guide_alpha, d.guide_per_sample = 2, 0.0, 1
     flat = yd.reshape(n, h * h, c)
     stats = torch.stack([flat.sum(1), (flat * flat).sum(1)]).contiguous()
     aff = ops.norm_finalize(d, stats, n, None, beta.cuda(), 1e-6, 0.0, True, None, None, yd.device)
@@ -781,7 +781,8 @@ def test_gunet_dropout_matches_oracle(normalizer, use_context):
     masks = {}
     for i in range(5):                                   # the seeds GUNet._build_network will use in the next training call
         c = 64 * 2 ** i
-        seed = int(args.seed) * 7919 + (calls + 1 + i) * 131 + i
+        # (the context MLP draws one call number per forward before the encoder does)
+        seed = int(args.seed) * 7919 + (calls + 1 + i + (1 if use_context else 0)) * 131 + i
         masks["GUNet/Encode/down_conv{}/mod_conv1".format(i + 1)] = torch.from_numpy(
             unit_mask_host(seed, (2, 32 >> i, 32 >> i, c), 0.7))
     okw = {"unit_masks": masks}
