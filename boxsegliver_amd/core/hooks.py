@@ -285,3 +285,80 @@ class EvaluatorHook(SessionRunHook):
         with self._best_file(best).open("w") as f:
             json.dump({k: (int(v) if isinstance(v, (np.integer,)) else float(v)) for k, v in self._better_result.items()}, f)
         return False
+
+
+class EvaluatorHookV2(SessionRunHook):
+    """core/hooks.py:288-468: evaluate every N steps; keep a MOVING AVERAGE of every metric and save the variables (status
+    file `checkpoint_best`, `best_result` json = {"ma_results", "ma_best_result"}) whenever the mean of the averaged metrics
+    beats the best so far under `compare_fn` (default: larger is better).  As in the reference the first trigger only
+    evaluates (the averages start with the second: "update moving average for 1 trigger delay", :386-388), and the
+    evaluation at the end of training does not count as a trigger."""
+
+    def __init__(self, evaluator, checkpoint_dir=None, compare_fn=lambda x, y: x > y, prefix=None, eval_n_secs=None,
+                 eval_n_steps=None, saver=None, checkpoint_basename="best_model.ckpt", save_best=False, ma_alpha=0.9):
+        if not isinstance(evaluator, evaluator_base.EvaluateBase):
+            raise TypeError("`evaluator` must be an EvaluateBase instance")
+        self._summary_tag = prefix + "/Eval/{}" if prefix else "Eval/{}"
+        self._evaluator = evaluator
+        self._compare_fn = compare_fn
+        self._checkpoint_dir = checkpoint_dir
+        self._timer = SecondOrStepTimer(every_secs=eval_n_secs, every_steps=eval_n_steps)
+        self._save_best = save_best
+        self._basename = checkpoint_basename
+        self._ma_results = None
+        self._ma_best_result = None
+        self.ma_alpha = ma_alpha
+        self._trigger_counter = 0
+        self._need_save = False
+        self.summaries = []                    # (step, {tag: value}): stands in for the TF summary writer
+        if self._save_best:
+            best_file = self._best_file()
+            if best_file.exists():
+                with best_file.open() as f:
+                    data = json.load(f)
+                self._ma_results, self._ma_best_result = data["ma_results"], data["ma_best_result"]
+                log.info("Load previous best result records: %s", data)
+
+    def _best_file(self, name="best_result"):
+        return Path(self._checkpoint_dir) / name
+
+    def after_run(self, run_context, run_values):
+        step = _global_step(run_context)
+        if self._timer.should_trigger_for_step(step):
+            self._timer.update_last_triggered_step(step)
+            self._trigger_counter += 1
+            if self._evaluate(run_context.session, step):
+                run_context.request_stop()
+
+    def end(self, session):
+        last_step = session.estimator.params["solver"].global_step
+        if last_step != self._timer.last_triggered_step():
+            self._evaluate(session, last_step)
+
+    def _evaluate(self, session, step):
+        results = self._evaluator.run_with_session(session)
+        if self._trigger_counter <= 1:
+            return False
+        if self._ma_results is None:
+            self._ma_results = {k: float(v) for k, v in results.items()}
+            self._ma_best_result = float(np.mean(list(results.values())))
+            self._need_save = True
+        else:
+            self._ma_results = {k: float(self.ma_alpha * v + (1 - self.ma_alpha) * results[k])
+                                for k, v in self._ma_results.items()}
+            new_avg = float(np.mean(list(self._ma_results.values())))
+            if self._compare_fn(new_avg, self._ma_best_result):
+                self._ma_best_result = new_avg
+                self._need_save = True
+        self.summaries.append((step, {self._summary_tag.format(k): v for k, v in self._ma_results.items()}))
+        if not (self._save_best and self._need_save):
+            return False
+        self._need_save = False
+        strategy = _strategy(session)
+        if strategy is not None and strategy.rank != 0:
+            return False                      # every rank evaluates (lock-step), rank 0 alone writes
+        log.info("Saving (best) checkpoints for %d into %s (checkpoint_best).", step - 1, self._checkpoint_dir)
+        session.estimator.save_checkpoint(status_file="checkpoint_best", tag=self._basename)
+        with self._best_file().open("w") as f:
+            json.dump({"ma_results": self._ma_results, "ma_best_result": float(self._ma_best_result)}, f)
+        return False

@@ -347,6 +347,35 @@ def batches(store, data_list, config, training, seed=1234, liver_percent=0., tum
         yield {"images": images, "names": torch.from_numpy(names)}, labels
 
 
+def batches_eval_3d(store, data_list, config):
+    """--eval_3d online evaluation (input_pipeline_g.py:602-700 `gen_eval_3d_online_batch` + :796-833): every validation
+    case is served ONCE, as consecutive batch_size-slice batches over the liver's z range [z1, z2) -- the last batch padded
+    with empty slices (index -1: zero image, zero label) -- each slice cropped to the liver box (y1, x1, y2 - y1, x2 - x1) and
+    resized to the network size, fixed window, no noise, no flips; `names` carries the case id of the batch.
+    The whole table of a case is laid out in one vectorised step; the gather kernel does the rest."""
+    bs = distribution_utils.per_device_batch_size(config.batch_size, config.num_gpus)
+    c = config.im_channel
+    left = (c - 1) // 2
+    ctx = np.arange(-left, c - left)[None, :]
+    clip_row = np.array([[50., 500.]], dtype=np.float32) * IM_SCALE
+    for case in data_list:
+        z1, y1, x1, z2, y2, x2 = case["bbox"]
+        depth, pid = case["size"][0], int(case["PID"])
+        z = np.concatenate((np.arange(z1, z2), np.full((-(z2 - z1)) % bs, -100)))          # -100: padding (as the reference)
+        chans = z[:, None] + ctx
+        ok = (z[:, None] >= 0) & (chans >= 0) & (chans < depth)
+        off = store.offset[pid]
+        tab = np.zeros((len(z), c + 7), dtype=np.int32)
+        tab[:, :c] = np.where(ok, off + chans, -1)
+        tab[:, c] = np.where(z >= 0, off + z, -1)
+        tab[:, c + 1:c + 5] = [y1, x1, y2 - y1, x2 - x1]
+        for b0 in range(0, len(z), bs):
+            t = torch.from_numpy(np.ascontiguousarray(tab[b0:b0 + bs])).to(store.device)
+            clip = torch.from_numpy(np.repeat(clip_row, bs, axis=0)).to(store.device)
+            images, labels = ops.lits_batch(store.im, store.lb, t, clip, (config.im_height, config.im_width), c, LB_SCALE, 0.0, 0)
+            yield {"images": images, "names": torch.full((bs,), pid, dtype=torch.int64)}, labels
+
+
 def input_fn(mode, params):
     """input_pipeline.py:199-241 for the modes train / eval_online; params["lits_root"] holds png/, meta.json,
     k_folds.txt.  Offline volume evaluation: `input_fn_eval` below."""
@@ -365,6 +394,8 @@ def input_fn(mode, params):
     seed = int(getattr(args, "seed", 1234) or 1234) + 1000 * int(params.get("rank", 0))
     if mode == "train":
         return batches(store, cases, args, True, seed, getattr(args, "liver_percent", 0.), getattr(args, "tumor_percent", 0.), rs)
+    if mode == "eval_online" and getattr(args, "eval_3d", False):
+        return batches_eval_3d(store, cases, args)
     if mode == "eval_online":
         gen = batches(store, cases, args, False, seed + 500, getattr(args, "liver_percent", 0.),
                       getattr(args, "tumor_percent", 0.))

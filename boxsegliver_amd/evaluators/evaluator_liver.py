@@ -245,7 +245,7 @@ class EvaluateVolume(EvaluateBase):
         the live variables and moving statistics -- the mean of the in-graph "<Class>/<Metric>" values per batch, or
         with --use_global_dice the Dice of the summed confusion counts of the thresholded predictions."""
         if getattr(self.config, "eval_3d", False):
-            raise NotImplementedError("online 3-D evaluation needs the LiTS volume pipeline (SURVEY.md 8f2)")
+            return self._run_with_session_3d(session)
         model = self._model()
         if not getattr(self.config, "use_global_dice", False):
             keys = list(model.metrics_dict)
@@ -267,6 +267,62 @@ class EvaluateVolume(EvaluateBase):
                 acc[cls + "_tp"] += conf.tp
         return {cls + "/Dice": 2 * acc[cls + "_tp"] / max(2 * acc[cls + "_tp"] + acc[cls + "_fn"] + acc[cls + "_fp"], 1)
                 for cls in self.classes}
+
+    def _run_with_session_3d(self, session=None):
+        """evaluator_liver.py:171-282 (--eval_3d): the `eval_online` pipeline serves every validation case as consecutive
+        slice batches over the liver's z range (data/lits.batches_eval_3d); the thresholded predictions of a case are
+        stacked, the padding slices of its last batch dropped, and each class volume is scored against (labels == class)
+        -- per-case `metric_3d` averaged over the cases, or with --use_global_dice the Dice of the confusion counts summed
+        over all cases.  No post-processing (the reference omits it here to save training time, :208-210).
+        The volumes stay on the device until a case is complete: one device->host copy per case.
+        (The reference's per-case branch indexes the label ARRAY with the class name, :212,:234 -- it cannot run as written;
+        this restates the evident intent, the same comparison its global-Dice branch makes at :262.)"""
+        model = self._model()
+        keys = ["labels", "names"] + list(model.predictions)
+        use_global = bool(getattr(self.config, "use_global_dice", False))
+        self.clear_metrics()
+        acc = defaultdict(int)
+        depths = {}
+        for fold_case in self.params.get(("lits_store", False), (None, []))[1]:
+            depths[str(int(fold_case["PID"]))] = int(fold_case["bbox"][3] - fold_case["bbox"][0])
+
+        def finish(case, preds, labels):
+            vol = {cls: torch.cat(preds[cls], dim=0) for cls in self.classes}
+            lab = torch.cat(labels, dim=0)
+            n_real = depths.get(case, lab.shape[0])                    # drop the padding slices of the last batch
+            lab = lab[:n_real].cpu().numpy()
+            results = {}
+            for i, cls in enumerate(self.classes):
+                pred = vol[cls][:n_real].cpu().numpy().astype(np.uint8)
+                ref = (lab == i + 1).astype(np.uint8)
+                if use_global:
+                    conf = metric_ops.ConfusionMatrix(pred.astype(int), ref.astype(int))
+                    conf.compute()
+                    acc[cls + "_fn"] += conf.fn
+                    acc[cls + "_fp"] += conf.fp
+                    acc[cls + "_tp"] += conf.tp
+                else:
+                    for met, value in metric_ops.metric_3d(pred, ref, required=self.metrics_str).items():
+                        results["{}/{}".format(cls, met)] = value
+            if not use_global:
+                self.append_metrics(results)
+
+        cur, preds, labels = None, defaultdict(list), []
+        for x in self.estimator.evaluate_online(session, keys, yield_single_examples=False):
+            case = str(int(x["names"][0]))
+            if cur is not None and case != cur:
+                finish(cur, preds, labels)
+                preds, labels = defaultdict(list), []
+            cur = case
+            for cls in self.classes:
+                preds[cls].append(x[cls + "Pred"].reshape(x[cls + "Pred"].shape[:3]))
+            labels.append(x["labels"])
+        if cur is not None:
+            finish(cur, preds, labels)
+        if use_global:
+            return {cls + "/Dice": 2 * acc[cls + "_tp"] / max(2 * acc[cls + "_tp"] + acc[cls + "_fn"] + acc[cls + "_fp"], 1)
+                    for cls in self.classes}
+        return {k: float(np.mean(v)) for k, v in self.metric_values.items()}
 
     def run(self, input_fn, checkpoint_path=None, latest_filename=None, save=False, hooks=None, cases=None):
         """evaluator_liver.py:704-766: build the model, restore the checkpoint, stream the cases."""

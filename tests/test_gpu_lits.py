@@ -114,3 +114,61 @@ def test_device_resident_pipeline_feeds_training(tmp_path):
     e.train(lits.input_fn, steps=3)
     evals = list(e.evaluate_online(None, ["Liver/Dice"], yield_single_examples=False))
     assert len(evals) == 2 and 0.0 <= float(evals[0]["Liver/Dice"]) <= 1.0
+
+
+@pytest.mark.parametrize("use_global_dice", [False, True])
+def test_online_3d_evaluation_from_the_training_session(tmp_path, use_global_dice):
+    """--eval_3d (evaluators/evaluator_liver.py:171-282): every validation case served once as slice batches over its
+    liver z range (the last batch padded), predictions stacked per case and scored in 3-D -- against the same loop written
+    out here (own forward passes, numpy metrics)."""
+    import test_gpu_unet as t
+    from boxsegliver_amd import loss_metrics
+    from boxsegliver_amd.NetworksV2.UNet import UNet
+    from boxsegliver_amd.core import estimator as est
+    from boxsegliver_amd.core import models
+    from boxsegliver_amd.core.solver import Solver
+    from boxsegliver_amd.data import lits
+    from boxsegliver_amd.evaluators import evaluator_liver as ev
+    _write_dataset(tmp_path, n_cases=4, depth=7)
+    (tmp_path / "k_folds.txt").write_text("Fold 0:0 1\nFold 1:2 3\n")
+    args = t.make_args(batch_size=4, im_height=32, im_width=32, im_channel=3, test_fold=1, filter_size=0, noise_scale=0.05,
+                       zoom_scale=(1.0, 1.2), random_flip=3, liver_percent=0.66, tumor_percent=0.5, eval_per_epoch=True,
+                       eval_num_batches_per_epoch=2, model="UNet", log_step=1, eval_3d=True, use_global_dice=use_global_dice,
+                       metrics_eval=["Dice", "VOE"])
+    params = {"args": args, "model": UNet, "model_kwargs": dict(t.YML), "model_args": (), "solver": Solver(args),
+              "solver_kwargs": {}, "lits_root": str(tmp_path)}
+    e = est.CustomEstimator(models.model_fn, str(tmp_path / "run"), est.RunConfig(model_dir=str(tmp_path / "run"),
+                                                                                 save_checkpoints_steps=0), params)
+    e.train(lits.input_fn, steps=2)
+    evaluator = ev.get_evaluator("Volume", estimator=e, model_dir=str(tmp_path / "run"), params=params)
+    results = evaluator.run_with_session(None)
+    # the batches: 2 validation cases, liver z range [1, 6) = 5 slices -> 2 batches of 4 each, 3 padding slices at the end
+    store, cases = params[("lits_store", False)]
+    batches = list(lits.batches_eval_3d(store, cases, args))
+    assert len(batches) == 4 and [int(f["names"][0]) for f, _ in batches] == [2, 2, 3, 3]
+    assert int(batches[1][1][1:].abs().sum()) == 0 and float(batches[1][0]["images"][1:].abs().sum()) == 0   # padding: zeros
+    # the same evaluation written out
+    model = params["model_instances"][0]
+    per_case, tp_fp_fn = [], np.zeros((2, 3))
+    for k in range(2):
+        preds, labs = [], []
+        for feats, labels in batches[2 * k:2 * k + 2]:
+            model({"images": feats["images"], "labels": labels}, "eval", **t.YML)
+            preds.append(torch.stack([model.predictions[c + "Pred"][..., 0] for c in ("Liver", "Tumor")]).cpu().numpy())
+            labs.append(labels.cpu().numpy())
+        pred, lab = np.concatenate(preds, axis=1)[:, :5], np.concatenate(labs, axis=0)[:5]
+        row = {}
+        for i, cls in enumerate(("Liver", "Tumor")):
+            ref = (lab == i + 1)
+            for met, v in loss_metrics.metric_3d(pred[i], ref, required=["Dice", "VOE"]).items():
+                row["{}/{}".format(cls, met)] = v
+            tp_fp_fn[i] += [np.sum((pred[i] > 0) & ref), np.sum((pred[i] > 0) & ~ref), np.sum(~(pred[i] > 0) & ref)]
+        per_case.append(row)
+    if use_global_dice:
+        want = {cls + "/Dice": 2 * tp_fp_fn[i, 0] / max(2 * tp_fp_fn[i, 0] + tp_fp_fn[i, 1] + tp_fp_fn[i, 2], 1)
+                for i, cls in enumerate(("Liver", "Tumor"))}
+    else:
+        want = {k: float(np.mean([r[k] for r in per_case])) for k in per_case[0]}
+    assert set(results) == set(want)
+    for k in want:
+        assert results[k] == pytest.approx(want[k], abs=1e-12), k

@@ -127,3 +127,49 @@ def test_log_learning_rate_hook_records():
         solver.global_step = step
         hook.after_run(ctx, _spec(0.0, 1e-3 * step))
     assert [s for s, _ in hook.records] == [1, 3, 5] and hook.records[1][1] == pytest.approx(3e-3)
+
+
+def test_evaluator_hook_v2_moving_average_best_checkpoint(tmp_path):
+    """core/hooks.py:288-468: the first trigger only evaluates; from the second on every metric is averaged
+    (ma <- alpha ma + (1 - alpha) new) and the variables are saved whenever mean(ma) improves; `best_result` keeps both."""
+    class _Ev(EvaluateBase):
+        def __init__(self, seq):
+            super(_Ev, self).__init__()
+            self.seq, self.calls = list(seq), 0
+
+        def run_with_session(self, session):
+            r = self.seq[min(self.calls, len(self.seq) - 1)]
+            self.calls += 1
+            return dict(r)
+
+    seq = [{"Liver/Dice": 0.1, "Tumor/Dice": 0.1}, {"Liver/Dice": 0.8, "Tumor/Dice": 0.4}, {"Liver/Dice": 0.9, "Tumor/Dice": 0.6},
+           {"Liver/Dice": 0.2, "Tumor/Dice": 0.2}, {"Liver/Dice": 0.2, "Tumor/Dice": 0.2}]
+    solver = _solver("period_step")
+    est = _FakeEstimator(solver, tmp_path)
+    ev = _Ev(seq)
+    hook = hooks.EvaluatorHookV2(ev, checkpoint_dir=str(tmp_path), eval_n_steps=2, save_best=True, ma_alpha=0.5)
+    ctx = _ctx(est)
+    for step in range(1, 10):
+        solver.global_step = step
+        hook.after_run(ctx, _spec(0.5, 1e-3))
+    # triggers at steps 1, 3, 5, 7, 9 -> 5 evaluations; the first is discarded
+    assert ev.calls == 5
+    ma1 = {"Liver/Dice": 0.8, "Tumor/Dice": 0.4}                                  # second trigger initialises
+    ma2 = {k: 0.5 * ma1[k] + 0.5 * seq[2][k] for k in ma1}                        # 0.85, 0.5  -> mean 0.675 > 0.6: save
+    ma3 = {k: 0.5 * ma2[k] + 0.5 * seq[3][k] for k in ma1}                        # mean 0.4375: no save
+    ma4 = {k: 0.5 * ma3[k] + 0.5 * seq[4][k] for k in ma1}
+    assert [s for s, _, _ in [(x[2], 0, 0) for x in est.saved]] == [3, 5]        # saved at the 2nd and 3rd trigger only
+    assert all(x[0] == "checkpoint_best" and x[1] == "best_model.ckpt" for x in est.saved)
+    best = json.load(open(str(tmp_path / "best_result")))
+    assert best["ma_best_result"] == pytest.approx(0.675) and best["ma_results"] == pytest.approx(ma2)
+    assert hook._ma_results == pytest.approx(ma4)
+    assert [s for s, _ in hook.summaries] == [3, 5, 7, 9]
+    # a fresh hook resumes from best_result; end() evaluates once more when the last step was not a trigger
+    hook2 = hooks.EvaluatorHookV2(_Ev([{"Liver/Dice": 1.0, "Tumor/Dice": 1.0}]), checkpoint_dir=str(tmp_path), eval_n_steps=100,
+                                  save_best=True, ma_alpha=0.5)
+    assert hook2._ma_best_result == pytest.approx(0.675) and hook2._ma_results == pytest.approx(ma2)
+    solver.global_step = 11
+    hook2.end(ctx.session)
+    assert hook2._evaluator.calls == 1 and len(est.saved) == 2                     # trigger counter 0: evaluated, not averaged
+    with pytest.raises(TypeError):
+        hooks.EvaluatorHookV2(object())
