@@ -296,7 +296,7 @@ class CustomEstimator(object):
                     self._params["model_instances"] = [self._params["model"](args)]
                 model = self._params["model_instances"][0]
                 if model.params is None:
-                    model({"images": features["images"], "labels": labels}, ModeKeys.EVAL,
+                    model(dict({k: v for k, v in features.items() if k != "names"}, labels=labels), ModeKeys.EVAL,
                           **{k: v for k, v in self._params.get("model_kwargs", {}).items()
                              if k not in ("build_metrics", "build_summaries")})
                 self._maybe_restore(model, solver)

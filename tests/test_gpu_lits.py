@@ -172,3 +172,43 @@ def test_online_3d_evaluation_from_the_training_session(tmp_path, use_global_dic
     assert set(results) == set(want)
     for k in want:
         assert results[k] == pytest.approx(want[k], abs=1e-12), k
+
+
+def test_entry_main_trains_from_the_command_line(tmp_path):
+    """`python -m boxsegliver_amd.entry.main liver --mode train ...` on a synthetic dataset in the reference's on-disk format:
+    plateau policy + online evaluation + best checkpoint, the hook set entry/main.py:163-186 installs; and the GUNet entry
+    (main_g, `nf_inter` on synthetic NF-shaped tensors) with EvaluatorHookV2."""
+    import json
+    import os
+    from boxsegliver_amd.entry import main as entry
+    from boxsegliver_amd.entry import main_g
+    _write_dataset(tmp_path)
+    run = tmp_path / "run"
+    argv = ("liver --mode train --tag cli --model UNet --classes Liver Tumor --test_fold 2 --im_height 32 --im_width 32 "
+            "--im_channel 3 --noise_scale 0.05 --random_flip 3 --eval_num_batches_per_epoch 2 --num_of_steps 5 "
+            "--primary_metric Tumor/Dice --secondary_metric Liver/Dice --loss_weight_type numerical --loss_numeric_w 0.2 0.4 4.4 "
+            "--batches_per_epoch 2 --batch_size 4 --weight_decay_rate 0.000001 --learning_policy plateau --learning_rate 0.001 "
+            "--lr_end 0 --lr_decay_rate 0.2 --eval_per_epoch --evaluator Volume --save_best --log_step 1").split()
+    argv += ["--lits_root", str(tmp_path), "--model_dir", str(run)]
+    assert entry.main(argv) == 0
+    status = json.load(open(str(run / "checkpoint")))
+    assert status["global_step"] == 5 and os.path.exists(str(run / status["model_checkpoint_path"]))
+    best = json.load(open(str(run / "best_result")))
+    assert set(best) == {"Liver/Dice", "Tumor/Dice"} and os.path.exists(str(run / "checkpoint_best"))
+    assert os.path.exists(str(run / "lr_schedule")) and os.path.exists(str(run / "logs" / "train_cli"))
+    # resuming: max_steps already reached -> nothing to do; a larger budget continues from step 5
+    argv2 = [a for a in argv]
+    i = argv2.index("--num_of_steps")
+    argv2[i:i + 2] = ["--num_of_total_steps", "7"]
+    assert entry.main(argv2) == 0
+    assert json.load(open(str(run / "checkpoint")))["global_step"] == 7
+    # GUNet through main_g: synthetic NF-shaped tensors (the NF data is private), moving-average best checkpoint
+    run_g = tmp_path / "run_g"
+    argv_g = ("nf_inter --mode train --tag g --model GUNet --classes NF --im_height 32 --im_width 32 --im_channel 3 --noise_scale 0 "
+              "--num_of_steps 5 --primary_metric NF/Dice --loss_weight_type numerical --loss_numeric_w 1 6 --batches_per_epoch 2 "
+              "--batch_size 2 --normalizer instance_norm --eval_num_batches_per_epoch 2 --eval_per_epoch --evaluator Volume "
+              "--save_best --summary_prefix nf --use_spatial --guide_channel 1 --log_step 1").split() + ["--model_dir", str(run_g)]
+    assert main_g.main(argv_g) == 0
+    best = json.load(open(str(run_g / "best_result")))
+    assert set(best) == {"ma_results", "ma_best_result"} and "NF/Dice" in best["ma_results"]
+    assert os.path.exists(str(run_g / "checkpoint_best"))
