@@ -16,8 +16,11 @@ namespace {
 
 constexpr int TW = 16, TH = 8, HWD = TW + 2, HH = TH + 2;
 constexpr int HALO_PIX = HH * HWD;   // 180
-constexpr int CT = 64;
 constexpr size_t WG_LDS_BYTES = 157696;   // 2 stages of the 64x64 panel; also holds the 147 KB reduction scratch
+
+// 256 bytes of zeros in global memory: the source of out-of-image halo pixels for the direct-to-LDS loads (constant data in
+// the code object -- no per-call memset of a workspace page)
+__device__ const float kZeroPage[64] = {};
 
 // Pixel tile TH_ x TW_: 8 x 16 in general; 10 x 12 (STK) for small planes whose width is a multiple of 12 but not of 16
 // (UNet3D's 12^2 / 24^2 levels), where 8 x 16 tiles would be 56 % / 75 % full.
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
         }
         const int64_t pixoff = (int64_t)gh * pw + gw;
         const float* src = is_x ? p.x + ximg + pixoff * p.xs + ci0 + qx * 4 : p.dy + yimg + pixoff * p.ys + co0 + qy * 4;
-        if (!ok) src = p.zeros + (lane & 15) * 4;
+        if (!ok) src = kZeroPage + (lane & 15) * 4;
         float* dst = smem + stage * G::STAGE_F + j * 256;   // wave-uniform; lanes land at dst + lane*16 B
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -236,14 +239,17 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
 // through the matrix cores (M = (tap, ci) padded to 32, N = co, K = pixels) because the scalar version is
 // VALU-issue bound (27 FMAs + 27 loads per pixel per lane), ~15x off the HBM roofline.
 // 4 waves = (pixel-row half) x (co half); dy tile by direct-to-LDS loads, x halo (Cin floats / pixel).
+template <int COT>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_kernel(WgParams p) {
+  // COT = 64: waves = (pixel-row half) x (co half); COT = 32 (UNet3D conv_e0/conv1, 30 channels padded): four row quarters
+  constexpr int NCO = COT / 32, KS = 4 / NCO, RPW = TH / KS, PP = 256 / COT, NPIECE = TH * TW / PP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* dyt = smem;                       // [128 pixels][64]   (32 pieces of 1 KiB)
-  float* xh = smem + TH * TW * CT;         // [180 pixels][4]
+  float* dyt = smem;                       // [128 pixels][COT]   (NPIECE pieces of 1 KiB)
+  float* xh = smem + TH * TW * COT;        // [180 pixels][4]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int khalf = wave >> 1, wco = wave & 1;
+  const int kq = wave / NCO, wco = wave % NCO;
   const int l31 = lane & 31, h = lane >> 5;
   const int cin = p.Cin, m_rows = 9 * cin;
   const int split = blockIdx.x;
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_kernel(WgParams p) {
   const bool a_on = l31 < m_rows;
   const int a_tap = a_on ? l31 / cin : 0, a_ci = a_on ? l31 % cin : 0;
   const int a_off = ((a_tap / 3) * HWD + (a_tap % 3)) * 4 + a_ci;
-  const int lp = lane >> 4, q = lane & 15;
+  const int lp = lane / (COT / 4), q = lane % (COT / 4);
 
   f32x16 acc;
 #pragma unroll
@@ -267,12 +273,12 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_kernel(WgParams p) {
     const int64_t ximg = p.xa.off(n_img), yimg = p.ya.off(n_img);
     __syncthreads();   // previous tile's fragment reads are done
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {          // dy: piece j = wave + 4 i covers pixels 4j .. 4j+3
+    for (int i = 0; i < NPIECE / 4; ++i) {          // dy: piece j = wave + 4 i covers pixels PP j .. PP j + PP - 1
       const int j = wave + 4 * i;
-      const int pix = 4 * j + lp;
+      const int pix = PP * j + lp;
       const int gh = h0 + (pix >> 4), gw = w0 + (pix & 15);
       const float* src = (gh < p.H && gw < p.W) ? p.dy + yimg + ((int64_t)gh * p.W + gw) * p.ys + q * 4
-                                                : p.zeros + q * 4;
+                                                : kZeroPage + (q & 15) * 4;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(dyt + j * 256), 16, 0, 0);
     }
@@ -286,12 +292,12 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_kernel(WgParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
-    for (int rr = 0; rr < TH / 2; ++rr) {
-      const int r = khalf * (TH / 2) + rr;
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int r = kq * RPW + rr;
 #pragma unroll
       for (int c2 = 0; c2 < TW / 2; ++c2) {
         const int col = 2 * c2 + h;
-        const float b = dyt[(r * TW + col) * CT + wco * 32 + l31];
+        const float b = dyt[(r * TW + col) * COT + wco * 32 + l31];
         float a = xh[(r * HWD + col) * 4 + a_off];
         a = a_on ? a : 0.f;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
@@ -299,18 +305,21 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_kernel(WgParams p) {
     }
   }
   __syncthreads();
-  float* red = smem;   // [2][16][64]
-  if (khalf == 1) {
+  float* red = smem;   // [KS - 1][NCO][16][64]
+  if (kq > 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wco * 16 + r) * 64 + lane] = acc[r];
+    for (int r = 0; r < 16; ++r) red[(((kq - 1) * NCO + wco) * 16 + r) * 64 + lane] = acc[r];
   }
   __syncthreads();
-  if (khalf == 0) {
+  if (kq == 0) {
     float* out = p.slab + (int64_t)split * m_rows * p.Cout;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = mfma32_row(r, h);
-      if (i < m_rows) out[(int64_t)i * p.Cout + wco * 32 + l31] = acc[r] + red[(wco * 16 + r) * 64 + lane];
+      float v = acc[r];
+#pragma unroll
+      for (int k = 0; k < KS - 1; ++k) v += red[((k * NCO + wco) * 16 + r) * 64 + lane];   // fixed order
+      if (i < m_rows) out[(int64_t)i * p.Cout + wco * 32 + l31] = v;
     }
   }
 }
@@ -370,50 +379,46 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_smallc_kernel(WgParams p) {
 
 }  // namespace
 
-// dst[i] = sum_s slab[s * rs][i], fixed order.  n % 4 == 0.
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, int S, int rs, int64_t n, float* __restrict__ dst) {
+// dst[i] = sum_s slab[s][i] in a fixed order, ONE launch for any S (n % 4 == 0): a block is (256 / RL) float4 columns x
+// RL row lanes; row lane r sums slabs r, r + RL, ... and the RL partial sums are added in lane order through LDS.
+template <int RL>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int S, int64_t n,
+                                                          float* __restrict__ dst) {
+  constexpr int CL = 256 / RL;
+  __shared__ float4 red[RL > 1 ? RL : 1][CL];
+  const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
   const int64_t n4 = n >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < S; ++s) {
-      const float4 v = ldg4(slab + (int64_t)s * rs * n + i * 4);
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-    }
-    stg4(dst + i * 4, a);
-  }
-}
-
-// Level 1 for many slabs: row group g = blockIdx.y sums rows [g*chunk, (g+1)*chunk) IN PLACE into row
-// g*chunk (each element is read and then overwritten by the same thread only).
-__global__ void slab_reduce_l1_kernel(float* __restrict__ slab, int S, int chunk, int64_t n) {
-  const int64_t n4 = n >> 2;
-  const int s0 = blockIdx.y * chunk, s1 = min(s0 + chunk, S);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = s0; s < s1; ++s) {
+  const int64_t i = (int64_t)blockIdx.x * CL + cl;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4)
+    for (int s = rl; s < S; s += RL) {
       const float4 v = ldg4(slab + (int64_t)s * n + i * 4);
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
-    stg4(slab + (int64_t)s0 * n + i * 4, a);
+  if (RL > 1) {
+    red[rl][cl] = a;
+    __syncthreads();
+    if (rl != 0 || i >= n4) return;
+#pragma unroll
+    for (int r = 1; r < RL; ++r) {
+      const float4 v = red[r][cl];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  } else if (i >= n4) {
+    return;
   }
+  stg4(dst + i * 4, a);
 }
 
-// NOTE: reduces in place when S > 16 (the slabs are scratch).
 int unetk_launch_slab_reduce(const float* slab, int S, int64_t n, float* dst, hipStream_t st) {
   const int64_t n4 = n >> 2;
-  int grid = (int)((n4 + 255) / 256);
-  if (grid > 8192) grid = 8192;
-  if (grid < 1) grid = 1;
-  int rs = 1;
-  if (S > 16) {
-    const int chunk = (S + 15) / 16;
-    const int groups = (S + chunk - 1) / chunk;
-    hipLaunchKernelGGL(slab_reduce_l1_kernel, dim3(grid, groups), dim3(256), 0, st, const_cast<float*>(slab), S, chunk, n);
-    UNETK_LAUNCH_CHECK();
-    S = groups;
-    rs = chunk;
+  if (S >= 64) {
+    hipLaunchKernelGGL(slab_reduce_kernel<16>, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, slab, S, n, dst);
+  } else if (S >= 8) {
+    hipLaunchKernelGGL(slab_reduce_kernel<4>, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, slab, S, n, dst);
+  } else {
+    hipLaunchKernelGGL(slab_reduce_kernel<1>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, slab, S, n, dst);
   }
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, st, slab, S, rs, n, dst);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
@@ -538,16 +543,14 @@ int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_
     if (p.Hin < 2 * p.H - 1 || p.Hin > 2 * p.H || p.Win < 2 * p.W - 1 || p.Win > 2 * p.W) return UNETK_E_BADARG;
     const WgPlan pl = wg_plan_strided(p.N, p.H, p.W, p.Cin, p.Cout);
     if (ws_bytes < unetk_wgrad_strided_ws_bytes(p.N, p.H, p.W, p.Cin, p.Cout)) return UNETK_E_WORKSPACE;
-    p.zeros = (const float*)ws;
-    p.slab = (float*)ws + 64;
+    p.slab = pl.S == 1 ? dw : (float*)ws + 64;           // a single split writes the gradient in place
     p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.total_tiles = pl.total_tiles;
     p.tiles_per_split = pl.tiles_per_split; p.n_ci_tiles = pl.n_ci_tiles; p.n_co_tiles = pl.n_co_tiles;
-    hipError_t ez = hipMemsetAsync(ws, 0, 256, st);
-    if (ez != hipSuccess) return (int)ez;
     const int grid = pl.S * pl.n_ci_tiles * pl.n_co_tiles;
     const int rc = pl.mode == 4 ? launch_wgrad<32, 64, false, S2TH, STW, false, 2>(p, grid, st)
                                 : launch_wgrad<32, 64, false, S2TH, TW, false, 2>(p, grid, st);
     if (rc != UNETK_OK) return rc;
+    if (pl.S == 1) return UNETK_OK;
     return unetk_launch_slab_reduce((const float*)ws + 64, pl.S, (int64_t)9 * p.Cin * p.Cout, dw, st);
   }
   if (p.dil == 2) {      // atrous: 6 x 16 tiles (the 10 x 20 halo of two stages fits LDS), 64 x 64 panels, fp32
@@ -566,26 +569,21 @@ int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_
     pl.tiles_per_split = (pl.total_tiles + S - 1) / S;
     pl.S = (pl.total_tiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
     if (ws_bytes < 256 + (size_t)pl.S * 9 * p.Cin * p.Cout * sizeof(float)) return UNETK_E_WORKSPACE;
-    p.zeros = (const float*)ws;
-    p.slab = (float*)ws + 64;
+    p.slab = pl.S == 1 ? dw : (float*)ws + 64;           // a single split writes the gradient in place
     p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.total_tiles = pl.total_tiles;
     p.tiles_per_split = pl.tiles_per_split; p.n_ci_tiles = pl.n_ci_tiles; p.n_co_tiles = pl.n_co_tiles;
-    hipError_t ez = hipMemsetAsync(ws, 0, 256, st);
-    if (ez != hipSuccess) return (int)ez;
     const int rc = launch_wgrad<64, 64, false, 6, TW, false, 1, 2>(p, pl.S * panels, st);
     if (rc != UNETK_OK) return rc;
+    if (pl.S == 1) return UNETK_OK;
     return unetk_launch_slab_reduce((const float*)ws + 64, pl.S, (int64_t)9 * p.Cin * p.Cout, dw, st);
   }
   p.stride = 1; p.Hin = p.H; p.Win = p.W; p.pbh = p.pbw = 1;
   const WgPlan pl = wg_plan(p.N, p.H, p.W, p.Cin, p.Cout, p.bf16 != 0);
   if (pl.mode < 0) return UNETK_E_UNSUPPORTED;
   if (ws_bytes < unetk_wgrad_ws_bytes(p.N, p.H, p.W, p.Cin, p.Cout)) return UNETK_E_WORKSPACE;
-  p.zeros = (const float*)ws;
-  p.slab = (float*)ws + 64;
+  p.slab = pl.S == 1 ? dw : (float*)ws + 64;           // a single split writes the gradient in place
   p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.total_tiles = pl.total_tiles;
   p.tiles_per_split = pl.tiles_per_split; p.n_ci_tiles = pl.n_ci_tiles; p.n_co_tiles = pl.n_co_tiles;
-  hipError_t ez = hipMemsetAsync(ws, 0, 256, st);
-  if (ez != hipSuccess) return (int)ez;
   int rc = UNETK_OK;
   if (pl.mode == 2 || pl.mode == 5) {
     if (p.xs % 4 != 0 || p.ys % 4 != 0) return UNETK_E_BADARG;
@@ -606,9 +604,10 @@ int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_
     else if (pl.cot == 64) rc = launch_wgrad<32, 64, false>(p, grid, st);
     else rc = launch_wgrad<32, 32, false>(p, grid, st);
     if (rc != UNETK_OK) return rc;
-  } else if (9 * p.Cin <= 32 && p.Cout == CT && p.ys % 4 == 0) {
-    const size_t lds3 = (size_t)(TH * TW * CT + HALO_PIX * 4) * sizeof(float);
-    hipLaunchKernelGGL(conv3x3_wgrad_c3_kernel, dim3(pl.S), dim3(256), lds3, st, p);
+  } else if (9 * p.Cin <= 32 && (p.Cout == 64 || p.Cout == 32) && p.ys % 4 == 0) {
+    const size_t lds3 = (size_t)(TH * TW * p.Cout + HALO_PIX * 4) * sizeof(float);
+    if (p.Cout == 64) hipLaunchKernelGGL(conv3x3_wgrad_c3_kernel<64>, dim3(pl.S), dim3(256), lds3, st, p);
+    else hipLaunchKernelGGL(conv3x3_wgrad_c3_kernel<32>, dim3(pl.S), dim3(256), lds3, st, p);
     UNETK_LAUNCH_CHECK();
   } else {
     const int PL = 256 / p.Cout;
@@ -635,6 +634,7 @@ int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_
     }
     UNETK_LAUNCH_CHECK();
   }
+  if (pl.S == 1) return UNETK_OK;
   return unetk_launch_slab_reduce((const float*)ws + 64, pl.S, (int64_t)9 * p.Cin * p.Cout, dw, st);
 }
 

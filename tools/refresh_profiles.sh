@@ -23,6 +23,7 @@ echo "fp32 benches done"
 $T python bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_bf16_256_bs32.json"
 $T python bench.py --dtype bf16 --size 512 --batch 8 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_bf16_512_bs8.json"
 $T python bench.py --dtype bf16 --model GUNet --batch 8 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_bf16_gunet_bs8.json"
+$T python bench.py --dtype bf16c --size 512 --batch 8 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_bf16c_512_bs8.json"
 echo "bf16 benches done"
 
 # rocprofv3: kernel trace + stats (own run), then the two PMC passes (own runs, kernel-trace only)
@@ -31,8 +32,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_fp32" -o fp32
   python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/prof_fp32.log" 2>&1
 echo "kernel trace fp32 done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bf16" -o bf16 -- \
-  python3 "$ROOT/bench.py" --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/prof_bf16.log" 2>&1
-echo "kernel trace bf16 done"
+  python3 "$ROOT/bench.py" --dtype bf16 --size 512 --batch 8 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/prof_bf16.log" 2>&1
+echo "kernel trace bf16 (512x512 bs 8) done"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_u3d" -o u3d -- \
+  python3 "$ROOT/bench.py" --model UNet3D --size 96 --batch 1 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/prof_u3d.log" 2>&1
+echo "kernel trace UNet3D done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- \
   python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_fetch.log" 2>&1
 echo "pmc fetch done"
@@ -43,8 +47,19 @@ cd "$ROOT"
 F=$(find "$OUT/pmc_fetch" -name '*counter_collection.csv' | head -1)
 W=$(find "$OUT/pmc_write" -name '*counter_collection.csv' | head -1)
 python tools/pmc_summary.py "$F" "$W" "$OUT/pmc_traffic.json" | tee "$OUT/pmc_summary.txt"
+cd /tmp
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_bf16" -o fetch -- \
+  python3 "$ROOT/bench.py" --dtype bf16 --size 512 --batch 8 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_fetch_bf16.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_bf16" -o write -- \
+  python3 "$ROOT/bench.py" --dtype bf16 --size 512 --batch 8 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_write_bf16.log" 2>&1
+echo "pmc bf16 done"
+cd "$ROOT"
+F=$(find "$OUT/pmc_fetch_bf16" -name '*counter_collection.csv' | head -1)
+W=$(find "$OUT/pmc_write_bf16" -name '*counter_collection.csv' | head -1)
+python tools/pmc_summary.py "$F" "$W" "$OUT/pmc_traffic_bf16.json" | tee "$OUT/pmc_summary_bf16.txt"
 cp "$(find "$OUT/prof_fp32" -name '*kernel_stats.csv' | head -1)" "$OUT/bench_kernel_stats.csv"
 cp "$(find "$OUT/prof_bf16" -name '*kernel_stats.csv' | head -1)" "$OUT/bench_bf16_kernel_stats.csv"
+cp "$(find "$OUT/prof_u3d" -name '*kernel_stats.csv' | head -1)" "$OUT/bench_unet3d_kernel_stats.csv"
 # keep the merge-back small: drop the raw traces
-rm -rf "$OUT/prof_fp32" "$OUT/prof_bf16" "$OUT/pmc_fetch" "$OUT/pmc_write"
+rm -rf "$OUT/prof_fp32" "$OUT/prof_bf16" "$OUT/prof_u3d" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_fetch_bf16" "$OUT/pmc_write_bf16"
 head -8 "$OUT/bench_kernel_stats.csv"
