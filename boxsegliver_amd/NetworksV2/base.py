@@ -10,6 +10,8 @@ from collections import OrderedDict
 
 import torch
 
+from .. import ops
+
 
 class ModeKeys(object):
     """tensorflow_estimator ModeKeys values (reference base.py:25)."""
@@ -80,6 +82,7 @@ class ParamStore(object):
         return sum(self.where[n][2] for n in self.trainable_names())
 
     def zero_grad(self):
+        ops.new_step()                        # the backward kernels may write each gradient slot in place once per step
         for g in self.grad.values():
             g.zero_()
         for name in self.trainable_names():

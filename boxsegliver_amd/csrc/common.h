@@ -125,6 +125,11 @@ struct ConvParams {
   // the plane (depth index + dshift0 + dt * dstep) of the same sample (zero outside [0, spg)) with the filter panel
   // wp + dt * 9 * Cin * Cout; no per-tap read-modify-write of the output.  0 / 1 = a plain 2-D conv per plane.
   int kd, dshift0, dstep;
+  // stream-K scheduling of the linear-pixel kernel (conv_igemm_lin.hip): slab for the pieces of split tiles
+  // ([sk_tiles][sk_maxp][BM][BN] floats, caller's workspace; nullptr = one block per tile), chunks per tile, tiles
+  float* sk_slab;
+  size_t sk_slab_bytes;
+  int sk_tiles, sk_nc, sk_maxp, sk_whole;
 };
 bool unetk_conv_lin_gen_ok(int H, int W, int Cin, int Cout);
 int unetk_conv_run_lin_gen(ConvParams p, hipStream_t st);
@@ -135,6 +140,7 @@ bool unetk_conv_stride2_ok(int Cin, int Cout);
 bool unetk_conv_lin_ok(int N, int H, int W, int Cin, int Cout, int spg);
 int unetk_conv_stat_rows_lin(int N, int H, int W, int spg, int Cout = 0);   // Cout picks the block height (64 / 128 pixels)
 int unetk_conv_run_lin(ConvParams p, hipStream_t st);
+size_t unetk_conv_lin_sk_bytes(int N, int H, int W, int Cin, int Cout, int spg, int kd);   // 0 = stream-K not used for this shape
 // conv_igemm_bf16.hip
 bool unetk_conv_bf16_ok(int Cin, int Cout);
 int unetk_conv_run_bf16(ConvParams p, hipStream_t st);
@@ -168,6 +174,7 @@ int unetk_launch_slab_reduce(const float* slab, int S, int64_t n, float* dst, hi
 // dst[k][c] = sum_rows src[k][row][c] (fp64 accumulate).  tmp: K*64*C floats when rows > 256.
 int unetk_rows_reduce(const float* src, int K, int rows, int C, float* dst, float* tmp, hipStream_t st);
 size_t unetk_rows_reduce_tmp_floats(int K, int rows, int C);
+int unetk_rows_reduce_l1(const float* src, int K, int rows, int C, float* tmp, hipStream_t st);   // -> tmp[K][64][C]
 
 // Thread mapping for [npix, C] column-wise kernels: thread = (channel quad, row lane).
 struct ColMap {

@@ -164,6 +164,12 @@ extern "C" size_t unetk_conv3d_ws_bytes(const unetk_conv3d_desc* d) {
     const size_t sb = unetk_wgrad_strided_ws_bytes(d->N * g.Do, g.Ho, g.Wo, d->Cin, d->Cout);
     if (sb > bytes) bytes = sb;
   }
+  if (d->shw == 1 && d->sd == 1) {   // stream-K slabs of the small-plane kernel, forward and input gradient
+    const size_t kf = unetk_conv_lin_sk_bytes(d->N * d->D, d->H, d->W, d->Cin, d->Cout, d->D, d->kd);
+    const size_t kb = unetk_conv_lin_sk_bytes(d->N * d->D, d->H, d->W, d->Cout, d->Cin, d->D, d->kd);
+    if (kf > bytes) bytes = kf;
+    if (kb > bytes) bytes = kb;
+  }
   return bytes;
 }
 
@@ -196,6 +202,7 @@ extern "C" int unetk_conv3d_fwd(const unetk_conv3d_desc* d, const float* x, cons
     p.ya = planes(d->H * d->W * d->y_stride, d->D, 1, d->D);
     p.spg = d->D;
     p.kd = 3; p.dshift0 = -g.pb_d; p.dstep = 1;
+    if (ws && unetk_aligned16(ws)) { p.sk_slab = (float*)ws; p.sk_slab_bytes = ws_bytes; }
     return unetk_conv_run(p, st);
   }
   // order: partial-coverage taps first, a full-coverage tap last (it emits the statistics)
@@ -338,6 +345,7 @@ extern "C" int unetk_conv3d_dgrad(const unetk_conv3d_desc* d, const float* dy, c
     p.ya = planes(d->H * d->W * d->x_stride, d->D, 1, d->D);
     p.spg = d->D;
     p.kd = 3; p.dshift0 = g.pb_d; p.dstep = -1;
+    if (ws && unetk_aligned16(ws)) { p.sk_slab = (float*)ws; p.sk_slab_bytes = ws_bytes; }
     return unetk_conv_run(p, st);
   }
   const float* Z;

@@ -28,9 +28,25 @@ constexpr int LIN_MAXPIX = 416;   // staged padded pixels per block (host guaran
 // of a 16-channel chunk staged once and contracted with all 9 taps (class of tap (kh, kw) = (kh & 1, kw & 1), i.e.
 // 4 + 2 + 2 + 1 taps in a fixed order) -- instead of four blocks that each re-stage the halo for 1..4 taps (the 1- and
 // 2-tap classes were staging-bound).
-template <int WM, int WN, int TM, int TN, bool GEN = false, bool FUSED = false>
+//
+// SK ("stream-K", plain variant only): the launch is a FIXED number of blocks (2 per CU) and the work is the linear
+// sequence of (tile, K-chunk) pairs, tile-major; block b owns the contiguous range [b TOT / G, (b + 1) TOT / G) whatever
+// tiles it crosses.  UNet3D at one or two patches per GPU has layers of 70 .. 900 tiles -- on 256 CUs a whole number of
+// tiles per CU wastes up to a third of the machine (432 tiles: 176 CUs get two, 80 get one), and the 6 x 6 bridge
+// (70 tiles, K = 8640) leaves most CUs idle.  A block that owns a whole tile runs the normal epilogue; the pieces of a
+// split tile go to a slab (p.sk_slab, [tile][piece][BM][BN]) and lin_sk_fixup_kernel adds them in block order, writes y
+// and the tile's statistic partials: fixed order, bit-reproducible, no atomics.
+__device__ __forceinline__ int sk_block_of(int64_t pos, int64_t tot, int G) {   // the block b with s_b <= pos < s_{b+1}
+  int b = (int)((pos * G) / tot);
+  while (b + 1 < G && ((int64_t)(b + 1) * tot) / G <= pos) ++b;
+  while (b > 0 && ((int64_t)b * tot) / G > pos) --b;
+  return b;
+}
+
+template <int WM, int WN, int TM, int TN, bool GEN = false, bool FUSED = false, bool SK = false>
 __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvParams p) {
   static_assert(GEN || !FUSED, "FUSED is a GEN variant");
+  static_assert(!(SK && GEN), "stream-K is for the plain variant");
   constexpr int NQ = FUSED ? 4 : 1;
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -50,7 +66,28 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
 
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bid0 = SK ? 0 : xcd_remap(blockIdx.x, gridDim.x);
+  // stream-K: the first p.sk_whole blocks take one whole tile each (as many full rounds of 256 as the layer has); the other
+  // blocks share the REMAINING tiles' (tile, chunk) sequence evenly -- one pass of the loop below per tile a block touches
+  const int sk_G = SK ? (int)gridDim.x - p.sk_whole : 1;
+  const int64_t sk_tot = SK ? (int64_t)(p.sk_tiles - p.sk_whole) * p.sk_nc : 0;
+  const int64_t sk_base = SK ? (int64_t)p.sk_whole * p.sk_nc : 0;
+  int64_t sk_s = 0, sk_s1 = 0;
+  int sk_b = 0;
+  if (SK) {
+    if ((int)blockIdx.x < p.sk_whole) {
+      sk_s = (int64_t)xcd_remap(blockIdx.x, p.sk_whole) * p.sk_nc;
+      sk_s1 = sk_s + p.sk_nc;
+    } else {
+      sk_b = xcd_remap(blockIdx.x - p.sk_whole, sk_G);
+      sk_s = sk_base + ((int64_t)sk_b * sk_tot) / sk_G;
+      sk_s1 = sk_base + ((int64_t)(sk_b + 1) * sk_tot) / sk_G;
+    }
+    if (sk_s >= sk_s1) return;
+  }
+  do {
+  const int bid = SK ? (int)(sk_s / p.sk_nc) : bid0;
+  const int c_lo = SK ? (int)(sk_s - (int64_t)bid * p.sk_nc) : 0;
   const int ntile = bid % p.n_ntiles;
   const int mtile_all = bid / p.n_ntiles;
   const int q = (GEN && !FUSED) ? (mtile_all & 3) : 0;          // parity class; its 4 blocks of a tile are neighbours (L2)
@@ -148,8 +185,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
 #pragma unroll
         for (int r = 0; r < 16; ++r) accq[qq][tm][tn][r] = 0.f;
 
-  load_halo(0);
-  load_w(0, GEN ? p.tap_panel[q][0] : 0);
+  const int nchunks_all = KD * nchunks;
+  const int c_hi = SK ? min(nchunks_all, c_lo + (int)(sk_s1 - sk_s)) : nchunks_all;
+  load_halo(c_lo);
+  load_w(c_lo, GEN ? p.tap_panel[q][0] : 0);
   store_halo(0);
   store_w(0);
   __syncthreads();
@@ -314,10 +353,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
   }
 
   int step = 0;
-  const int nchunks_all = KD * nchunks;
-  for (int c = 0; c < nchunks_all; ++c) {
-    const float* hb = halo + (c & 1) * HALO_F;
-    const bool more_chunks = (c + 1 < nchunks_all);
+  for (int c = c_lo; c < c_hi; ++c) {
+    const float* hb = halo + ((c - c_lo) & 1) * HALO_F;
+    const bool more_chunks = (c + 1 < c_hi);
 #pragma unroll
     for (int t = 0; t < 9; ++t, ++step) {
       const bool has_next = (t < 8) || more_chunks;
@@ -347,9 +385,25 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
       }
 
       if (has_next) store_w((step + 1) & 1);
-      if (t == 5 && more_chunks) store_halo((c + 1) & 1);
+      if (t == 5 && more_chunks) store_halo((c + 1 - c_lo) & 1);
       __syncthreads();
     }
+  }
+
+  if (SK && (c_lo != 0 || c_hi != nchunks_all)) {
+    // a piece of a split tile: raw accumulators to the slab, [tile][piece = block - first block of the tile][BM][BN]
+    const int piece = sk_b - sk_block_of((int64_t)bid * p.sk_nc - sk_base, sk_tot, sk_G);
+    float* sl = p.sk_slab + ((int64_t)(bid - p.sk_whole) * p.sk_maxp + piece) * (BM * BN);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float* rp = sl + ((wm * TM + tm) * 32 + mfma32_row(r, h)) * BN + wn * TN * 32 + l31;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) rp[tn * 32] = acc[tm][tn][r];
+      }
+    sk_s += c_hi - c_lo;
+    continue;
   }
 
   float ssum[TN], ssq[TN];
@@ -411,6 +465,61 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
       for (int m = 0; m < WM; ++m) s += red[(k * WM + m) * BN + n];
       p.stat[((int64_t)k * p.stat_rows + mtile) * p.Cout + n0 + n] = s;
     }
+  }
+  if (SK) {
+    sk_s += c_hi - c_lo;
+    __syncthreads();   // the statistic scratch aliases the next tile's staging buffers
+  }
+  } while (SK && sk_s < sk_s1);
+}
+
+// Stream-K fix-up: one block per remainder tile; a tile that one block computed whole is already written.  Otherwise y = the sum of
+// the tile's pieces in block order (+ the statistic partials of the sums).  Thread = (channel quad, row lane).
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void lin_sk_fixup_kernel(ConvParams p, int G) {
+  constexpr int CQ = BN / 4, RL = 256 / CQ;
+  __shared__ float4 red[2][RL][CQ];
+  const int tr = blockIdx.x, tt = p.sk_whole + tr;          // the tr-th remainder tile
+  const int64_t tot = (int64_t)(p.sk_tiles - p.sk_whole) * p.sk_nc;
+  const int bf = sk_block_of((int64_t)tr * p.sk_nc, tot, G), bl = sk_block_of((int64_t)(tr + 1) * p.sk_nc - 1, tot, G);
+  const int np = bl - bf + 1;
+  if (np == 1) return;
+  const int ntile = tt % p.n_ntiles, mtile = tt / p.n_ntiles;
+  const int n0 = ntile * BN;
+  const int HW = p.H * p.W;
+  const int gpix = p.spg * HW;
+  const int bpg = (gpix + BM - 1) / BM;
+  const int grp = mtile / bpg, lb = mtile - grp * bpg;
+  const int P0 = grp * gpix + lb * BM;
+  const int P1 = min(P0 + BM, (grp + 1) * gpix);
+  const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ;
+  const float* sl = p.sk_slab + (int64_t)tr * p.sk_maxp * (BM * BN);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), sq = s;
+  for (int row = rl; row < BM && P0 + row < P1; row += RL) {
+    float4 v = ldg4(sl + row * BN + cq * 4);
+    for (int pc = 1; pc < np; ++pc) {
+      const float4 u = ldg4(sl + (int64_t)pc * (BM * BN) + row * BN + cq * 4);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    const int pix = P0 + row;
+    const int plane = pix / HW, rem = pix - plane * HW;
+    stg4(p.y + p.ya.off(plane) + (int64_t)rem * p.ys + n0 + cq * 4, v);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
+  }
+  if (p.stat == nullptr) return;
+  red[0][rl][cq] = s;
+  red[1][rl][cq] = sq;
+  __syncthreads();
+  if (threadIdx.x < 2 * CQ) {
+    const int k = threadIdx.x / CQ, c = threadIdx.x % CQ;
+    float4 a = red[k][0][c];
+#pragma unroll
+    for (int j = 1; j < RL; ++j) {
+      const float4 u = red[k][j][c];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+    }
+    stg4(p.stat + ((int64_t)k * p.stat_rows + mtile) * p.Cout + n0 + c * 4, a);
   }
 }
 
@@ -510,6 +619,71 @@ int unetk_conv_run_lin_gen(ConvParams p, hipStream_t st) {
   return launch_lin<4, 1, 1, 2, true>(p, 4 * n_mtiles, st);
 }
 
+namespace {
+
+// Stream-K plan: used when whole tiles quantise badly over the CUs (or do not fill them) and the K loop is long enough to
+// cut.  G = 2 blocks per CU (fewer when the layer has fewer than 4 chunks per block).
+struct SkPlan {
+  bool on;
+  int G, whole, tiles, nc, maxp, bm, bn;     // G = blocks sharing the remainder tiles
+  size_t bytes;
+};
+
+SkPlan sk_plan(int N, int H, int W, int Cin, int Cout, int spg, int kd) {
+  SkPlan s{};
+  const int bm = lin_bm(N, H, W, Cout, spg);
+  const int bn = (bm == 64 || Cout % 128 == 0) ? 128 : 64;
+  const int n_mt = (N / spg) * (int)(((int64_t)spg * H * W + bm - 1) / bm);
+  s.bm = bm; s.bn = bn;
+  s.tiles = n_mt * (Cout / bn);
+  s.nc = (kd > 1 ? kd : 1) * (Cin / CK);
+  const double eff = (double)s.tiles / (double)(((s.tiles + 255) / 256) * 256);
+  if (s.tiles >= 2048 || eff >= 0.92) return s;
+  s.whole = s.tiles / 256 * 256;                         // full rounds run one whole tile per block
+  const int rem = s.tiles - s.whole;
+  // measured (UNet3D, one patch): a remainder of 176 tiles with K >= 48 chunks gains 10-12 %, 96 tiles or K = 24 chunks
+  // do not pay for the slab round trip and the fix-up launch
+  if (s.whole > 0 && (rem < 128 || s.nc < 48)) return s;
+  const int64_t tot = (int64_t)rem * s.nc;
+  int G = 256;
+  if (s.whole == 0 && tot >= 512 * 4) G = 512;           // nothing else resident: two blocks per CU
+  while (G > 32 && tot < (int64_t)G * 4) G >>= 1;
+  if (tot < (int64_t)G * 4) return s;
+  s.G = G;
+  const int64_t minlen = tot / G;
+  s.maxp = (int)((s.nc + minlen - 1) / minlen) + 1;
+  s.bytes = (size_t)rem * s.maxp * bm * bn * sizeof(float);
+  s.on = s.bytes <= ((size_t)1 << 30);
+  return s;
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_lin_sk(const ConvParams& p, const SkPlan& sk, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr size_t lds_max = (size_t)(2 * LIN_MAXPIX * PS + 2 * CK * BN) * sizeof(float);
+  const size_t lds = (size_t)(2 * p.lin_pix * PS + 2 * CK * BN) * sizeof(float);
+  auto kern = conv3x3_igemm_lin_kernel<WM, WN, TM, TN, false, false, true>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(sk.whole + sk.G), dim3(WM * WN * 64), lds, st, p);
+  UNETK_LAUNCH_CHECK();
+  hipLaunchKernelGGL((lin_sk_fixup_kernel<BM, BN>), dim3(sk.tiles - sk.whole), dim3(256), 0, st, p, sk.G);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+}  // namespace
+
+size_t unetk_conv_lin_sk_bytes(int N, int H, int W, int Cin, int Cout, int spg, int kd) {
+  if (!unetk_conv_lin_ok(N, H, W, Cin, Cout, spg)) return 0;
+  const SkPlan sk = sk_plan(N, H, W, Cin, Cout, spg, kd);
+  return sk.on ? sk.bytes : 0;
+}
+
 int unetk_conv_run_lin(ConvParams p, hipStream_t st) {
   const int n_mtiles = unetk_conv_stat_rows_lin(p.N, p.H, p.W, p.spg, p.Cout);
   const int bm = lin_bm(p.N, p.H, p.W, p.Cout, p.spg);
@@ -517,6 +691,17 @@ int unetk_conv_run_lin(ConvParams p, hipStream_t st) {
   p.tiles_h = p.tiles_w = 0;
   p.lin_pix = lin_rows_bound(p.H, p.W, bm) * (p.W + 2);
   if (p.xs % 4 != 0) return UNETK_E_BADARG;
+  if (p.sk_slab != nullptr && !p.accumulate && p.ys % 4 == 0) {
+    const SkPlan sk = sk_plan(p.N, p.H, p.W, p.Cin, p.Cout, p.spg, p.kd);
+    if (sk.on && p.sk_slab_bytes >= sk.bytes && unetk_aligned16(p.sk_slab)) {
+      p.sk_tiles = sk.tiles; p.sk_nc = sk.nc; p.sk_maxp = sk.maxp; p.sk_whole = sk.whole;
+      p.n_ntiles = p.Cout / sk.bn;
+      if (bm == 64) return launch_lin_sk<2, 2, 1, 2>(p, sk, st);
+      if (p.Cout % 128 == 0) return launch_lin_sk<2, 2, 2, 2>(p, sk, st);
+      return launch_lin_sk<4, 1, 1, 2>(p, sk, st);
+    }
+  }
+  p.sk_slab = nullptr;
   if (bm == 64) {
     p.n_ntiles = p.Cout / 128;
     return launch_lin<2, 2, 1, 2>(p, n_mtiles, st);

@@ -48,6 +48,55 @@ NormGeom geom(const unetk_norm_desc* d, bool density) {
   return g;
 }
 
+// Last level of the statistics reduction fused with the finalisation: src[2][Ns][rows][C] (rows <= 256: the conv
+// epilogue's partials, or their first-level sums) -> mean / rstd / scale / shift.  Block = 16 channels x 16 row lanes of
+// one group; fp64 row sums in a fixed order, rounded to fp32 exactly as unetk_rows_reduce + norm_finalize_kernel did.
+__global__ __launch_bounds__(256) void norm_reduce_finalize_kernel(
+    const float* __restrict__ src, int rows, int Ns, int C, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float decay, int update_moving, float* __restrict__ moving_mean,
+    float* __restrict__ moving_var, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+    float* __restrict__ scale_out, float* __restrict__ shift_out) {
+  __shared__ double red[2][16][17];
+  const int cblocks = (C + 15) / 16;
+  const int cb = blockIdx.x % cblocks, gi = blockIdx.x / cblocks;
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = cb * 16 + cl;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C)
+    for (int r = rl; r < rows; r += 16) {
+      s0 += (double)src[((int64_t)gi * rows + r) * C + c];
+      s1 += (double)src[((int64_t)(Ns + gi) * rows + r) * C + c];
+    }
+  red[0][rl][cl] = s0;
+  red[1][rl][cl] = s1;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+  double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    t0 += red[0][j][cl];
+    t1 += red[1][j][cl];
+  }
+  const double m = (double)(float)t0 / count;
+  double v = (double)(float)t1 / count - m * m;
+  if (v < 0.0) v = 0.0;
+  const float mean = (float)m, var = (float)v;
+  if (update_moving) {   // batch norm only (Ns == 1)
+    const double unbiased = count > 1.0 ? v * (count / (count - 1.0)) : v;
+    moving_mean[c] = moving_mean[c] * decay + mean * (1.f - decay);
+    moving_var[c] = moving_var[c] * decay + (float)unbiased * (1.f - decay);
+  }
+  const float rstd = 1.0f / sqrtf(var + eps);
+  const float g = gamma ? gamma[c] : 1.f;
+  const float b = beta ? beta[c] : 0.f;
+  const float scale = g * rstd;
+  const int i = gi * C + c;
+  mean_out[i] = mean;
+  rstd_out[i] = rstd;
+  scale_out[i] = scale;
+  shift_out[i] = b - mean * scale;
+}
+
 // sums[0][g][c] = sum y, sums[1][g][c] = sum y^2 over `count` elements of group g
 __global__ void norm_finalize_kernel(const float* __restrict__ sums, int Ns, int C, double count,
                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -467,8 +516,20 @@ extern "C" int unetk_norm_finalize(const unetk_norm_desc* d, const float* stat_p
     if (ws_bytes < unetk_norm_finalize_ws_bytes(d, stat_rows)) return UNETK_E_WORKSPACE;
     sums = (float*)ws;
     // partials are [2][stat_rows][C] with each image's tiles contiguous -> [2*Ns][rows_per_group][C]
-    int rc = unetk_rows_reduce(stat_partials, 2 * g.Ns, stat_rows / g.Ns, d->C, sums, sums + 2 * g.Ns * d->C, st);
-    if (rc != UNETK_OK) return rc;
+    const float* src = stat_partials;
+    int rows = stat_rows / g.Ns;
+    if (rows > 256) {   // first level: 64 row blocks per (statistic, group)
+      int rc = unetk_rows_reduce_l1(stat_partials, 2 * g.Ns, rows, d->C, sums + 2 * g.Ns * d->C, st);
+      if (rc != UNETK_OK) return rc;
+      src = sums + 2 * g.Ns * d->C;
+      rows = 64;
+    }
+    const int update_moving = (!d->per_sample && training && moving_mean && moving_var) ? 1 : 0;
+    hipLaunchKernelGGL(norm_reduce_finalize_kernel, dim3(((d->C + 15) / 16) * g.Ns), dim3(256), 0, st, src, rows, g.Ns, d->C,
+                       (double)g.Ps, gamma, beta, eps, decay, update_moving, moving_mean, moving_var, mean_out, rstd_out,
+                       scale_out, shift_out);
+    UNETK_LAUNCH_CHECK();
+    return UNETK_OK;
   } else {
     UNETK_REQUIRE(moving_mean && moving_var);
   }
@@ -581,8 +642,12 @@ extern "C" int unetk_norm_relu_bwd(const unetk_norm_desc* d, const void* y, cons
   UNETK_LAUNCH_CHECK();
   int rc = unetk_rows_reduce(partial, K * g.L, nblk, d->C, sums, tmp1, st);   // -> sums[K][L][C]
   if (rc != UNETK_OK) return rc;
-  rc = unetk_rows_reduce(sums, K, g.L, d->C, psum, tmp2, st);                 // -> psum[K][C]
-  if (rc != UNETK_OK) return rc;
+  if (g.L == 1) {
+    psum = sums;                                                               // one launch group: nothing to add up
+  } else {
+    rc = unetk_rows_reduce(sums, K, g.L, d->C, psum, tmp2, st);               // -> psum[K][C]
+    if (rc != UNETK_OK) return rc;
+  }
   const bool gps = d->guide_per_sample != 0;
   hipLaunchKernelGGL(norm_bwd_params_kernel, dim3((d->C + 255) / 256), dim3(256), 0, st, psum, d->C, gps ? 0 : G,
                      (D || leaky) ? 1 : 0, dgamma, dbeta, gps ? nullptr : dgw, gps ? nullptr : dgb);

@@ -50,14 +50,21 @@ __global__ __launch_bounds__(256) void rows_reduce_final_kernel(const float* __r
 
 size_t unetk_rows_reduce_tmp_floats(int K, int rows, int C) { return rows > 256 ? (size_t)K * 64 * C : 0; }
 
+// first level only: src[K][rows][C] -> tmp[K][64][C]
+int unetk_rows_reduce_l1(const float* src, int K, int rows, int C, float* tmp, hipStream_t st) {
+  const int RB = 64;
+  const int cblocks = (C + 63) / 64;
+  hipLaunchKernelGGL(rows_reduce_l1_kernel, dim3(cblocks * RB * K), dim3(256), 0, st, src, rows, C, RB, tmp);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
 int unetk_rows_reduce(const float* src, int K, int rows, int C, float* dst, float* tmp, hipStream_t st) {
   if (rows > 256) {
-    const int RB = 64;
-    const int cblocks = (C + 63) / 64;
-    hipLaunchKernelGGL(rows_reduce_l1_kernel, dim3(cblocks * RB * K), dim3(256), 0, st, src, rows, C, RB, tmp);
-    UNETK_LAUNCH_CHECK();
+    const int rc = unetk_rows_reduce_l1(src, K, rows, C, tmp, st);
+    if (rc != UNETK_OK) return rc;
     src = tmp;
-    rows = RB;
+    rows = 64;
   }
   const int cblocks = (C + 15) / 16;
   hipLaunchKernelGGL(rows_reduce_final_kernel, dim3(cblocks * K), dim3(256), 0, st, src, rows, C, dst);

@@ -96,6 +96,51 @@ def alias(t, offset_elems=0, size=None, stride=None):
     return out
 
 
+# ----------------------------------------------------------------------------- in-place parameter gradients
+class _GradSink(object):
+    """Parameter gradients written by the backward kernels straight into the variable's slice of the flat gradient
+    buffer (ParamStore.grad) instead of a fresh tensor that autograd then adds to it: 65 tiny add launches per step
+    gone.  A slot is written in place at most once between two new_step() calls (ParamStore.zero_grad); a second
+    gradient for the same variable falls back to the returned-tensor path, i.e. autograd accumulates it.  `hooks`
+    maps a slot to the callback the data-parallel buckets would have got from a post-accumulate hook."""
+    written = set()
+    hooks = {}
+    enabled = True
+
+
+def new_step():
+    _GradSink.written.clear()
+
+
+def grad_sink(p):
+    """The flat-gradient slot of leaf parameter `p` when a backward kernel may write it in place, else None."""
+    if not _GradSink.enabled or p is None or not p.is_leaf or not p.requires_grad:
+        return None
+    g = p.grad
+    if g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.shape != p.shape:
+        return None
+    return g
+
+
+def _take(slot):
+    """Claim `slot` for an in-place write in this step (None if absent or already written)."""
+    if slot is None or slot.data_ptr() in _GradSink.written:
+        return None
+    _GradSink.written.add(slot.data_ptr())
+    return slot
+
+
+def _ret(value, slot):
+    """What a backward returns for a parameter: None when its gradient already sits in `slot` (the bucket hook fires
+    here, after the kernel was queued), else the tensor for autograd to accumulate."""
+    if slot is None:
+        return value
+    hook = _GradSink.hooks.get(slot.data_ptr())
+    if hook is not None:
+        hook()
+    return None
+
+
 def _require_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -204,7 +249,7 @@ def conv3x3_dgrad(dy, wp_dgrad, cin, x_stride=None, dx=None, bf16=False, dilatio
     return dx
 
 
-def conv3x3_wgrad(x, dy, bf16=False, dilation=1):
+def conv3x3_wgrad(x, dy, bf16=False, dilation=1, out=None):
     _require_cuda(x, dy)
     n, h, wd, cin = x.shape
     cout = dy.shape[3]
@@ -216,7 +261,8 @@ def conv3x3_wgrad(x, dy, bf16=False, dilation=1):
     if nbytes == 0:
         raise _abi.UnetkError("conv3x3_wgrad: unsupported shape Cin={} Cout={}".format(cin, cout))
     ws = WORKSPACE.get(nbytes, x.device)
-    dw = torch.empty((3, 3, cin, cout), dtype=torch.float32, device=x.device)
+    dw = out if out is not None else torch.empty((3, 3, cin, cout), dtype=torch.float32, device=x.device)
+    assert tuple(dw.shape) == (3, 3, cin, cout) and dw.is_contiguous()
     tag = "conv3x3_wgrad_kernel(+slab_reduce)" if cin % 64 == 0 else "conv3x3_wgrad_c3_kernel(+slab_reduce)"
     if bf16 and cin % 32 == 0:
         tag = "conv3x3_wgrad_kernel<bf16>(+slab_reduce)"
@@ -288,9 +334,10 @@ def conv3d_dgrad(dy, wp_dgrad, d):
     return dx
 
 
-def conv3d_wgrad(x, dy, d):
+def conv3d_wgrad(x, dy, d, out=None):
     assert x.stride(-2) == d.x_stride and dy.is_contiguous()
-    dw = torch.empty((d.kd, 3, 3, d.Cin, d.Cout), dtype=torch.float32, device=x.device)
+    dw = out if out is not None else torch.empty((d.kd, 3, 3, d.Cin, d.Cout), dtype=torch.float32, device=x.device)
+    assert tuple(dw.shape) == (d.kd, 3, 3, d.Cin, d.Cout) and dw.is_contiguous()
     ws, nbytes = _ws3d(d, x.device)
     flops = 2.0 * dy.numel() / d.Cout * d.kd * 9 * d.Cin * d.Cout
     with _Timed("conv3d_wgrad", flops, "k{}s{}{} {}".format(d.kd, d.sd, d.shw, tuple(x.shape))):
@@ -330,14 +377,15 @@ def norm_apply_relu(d, y, aff, z, guide=None, gw=None, gb=None, den=None):
     return z
 
 
-def norm_relu_bwd(d, y, dz, aff, has_gamma, has_beta, guide=None, gw=None, gb=None, den=None):
+def norm_relu_bwd(d, y, dz, aff, has_gamma, has_beta, guide=None, gw=None, gb=None, den=None, out_gamma=None,
+                  out_beta=None):
     dev = y.device
     assert dz.dtype == y.dtype, (dz.dtype, y.dtype)
     d.storage = _storage_of(y)
     dy = torch.empty_like(y)
     dden = torch.empty_like(den) if den is not None else None
-    dgamma = torch.empty((d.C,), dtype=torch.float32, device=dev) if has_gamma else None
-    dbeta = torch.empty((d.C,), dtype=torch.float32, device=dev) if has_beta else None
+    dgamma = (out_gamma if out_gamma is not None else torch.empty((d.C,), dtype=torch.float32, device=dev)) if has_gamma else None
+    dbeta = (out_beta if out_beta is not None else torch.empty((d.C,), dtype=torch.float32, device=dev)) if has_beta else None
     if d.guide_per_sample:
         dgw = torch.empty((d.N, d.guide_ch, d.C), dtype=torch.float32, device=dev) if d.guide_ch else None
         dgb = torch.empty((d.N, d.C), dtype=torch.float32, device=dev) if (d.guide_ch or gb is not None) else None
@@ -457,7 +505,7 @@ def deconv2x2_fwd(x, wp_fwd, bias, cat, coff, cout, bf16=False):
     return cat
 
 
-def deconv2x2_bwd(x, wp_dgrad, cat, dcat, coff, cout, bf16=False):
+def deconv2x2_bwd(x, wp_dgrad, cat, dcat, coff, cout, bf16=False, out_w=None, out_b=None):
     n, h, w, cin = x.shape
     prec = precision_of(bf16)
     assert x.dtype == storage_dtype(prec) and cat.dtype == x.dtype and dcat.dtype == x.dtype
@@ -468,8 +516,9 @@ def deconv2x2_bwd(x, wp_dgrad, cat, dcat, coff, cout, bf16=False):
         raise _abi.UnetkError("deconv2x2_bwd: unsupported shape Cin={} Cout={}".format(cin, cout))
     ws = WORKSPACE.get(nbytes, x.device)
     dx = torch.empty_like(x)
-    dw = torch.empty((2, 2, cout, cin), dtype=torch.float32, device=x.device)
-    db = torch.empty((cout,), dtype=torch.float32, device=x.device)
+    dw = out_w if out_w is not None else torch.empty((2, 2, cout, cin), dtype=torch.float32, device=x.device)
+    db = out_b if out_b is not None else torch.empty((cout,), dtype=torch.float32, device=x.device)
+    assert tuple(dw.shape) == (2, 2, cout, cin) and dw.is_contiguous()
     with _Timed("deconv2x2_bwd{}(relu_bwd+pw_gemm<dgrad>+deconv_wgrad)".format({0: "", 1: "<bf16>", 2: "<bf16s>"}[prec]),
                 16.0 * n * h * w * cin * cout,
                 "{}x{}x{} {}->{}".format(n, h, w, cin, cout)):
@@ -505,7 +554,7 @@ def deconv3d_fwd(x, wp_fwd, bias, cat, coff, cout, kd):
     return cat
 
 
-def deconv3d_bwd(x, wp_dgrad, cat, dcat, coff, cout, kd, want_dbias):
+def deconv3d_bwd(x, wp_dgrad, cat, dcat, coff, cout, kd, want_dbias, out_w=None):
     n, dd, h, w, cin = x.shape
     d = Deconv3dDesc(n, dd, h, w, cin, cout, kd, _pix_stride_nd(cat), coff)
     assert _pix_stride_nd(dcat) == _pix_stride_nd(cat)
@@ -514,7 +563,8 @@ def deconv3d_bwd(x, wp_dgrad, cat, dcat, coff, cout, kd, want_dbias):
         raise _abi.UnetkError("deconv3d_bwd: unsupported shape Cin={} Cout={}".format(cin, cout))
     ws = WORKSPACE.get(nbytes, x.device)
     dx = torch.empty_like(x)
-    dw = torch.empty((kd, 2, 2, cout, cin), dtype=torch.float32, device=x.device)
+    dw = out_w if out_w is not None else torch.empty((kd, 2, 2, cout, cin), dtype=torch.float32, device=x.device)
+    assert tuple(dw.shape) == (kd, 2, 2, cout, cin) and dw.is_contiguous()
     db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_dbias else None
     with _Timed("deconv3d_bwd", 16.0 * kd * n * dd * h * w * cin * cout, "kd{} {}".format(kd, tuple(x.shape))):
         check(_abi.lib().unetk_deconv3d_bwd(ctypes.byref(d), ptr(x), ptr(wp_dgrad), ptr(cat), ptr(dcat), ptr(dx),
@@ -555,11 +605,12 @@ def head_fwd(d, z, w, b, labels, pixel_w=None, want_probs=False):
     return logits, probs, result, ws
 
 
-def head_bwd(d, z, w, labels, pixel_w, logits, result, ws, xent_scale, dice_scale, dev_scales=None):
+def head_bwd(d, z, w, labels, pixel_w, logits, result, ws, xent_scale, dice_scale, dev_scales=None, out_w=None, out_b=None):
     d.storage = _storage_of(z)
     dz = torch.empty_like(z)
-    dw = torch.empty((d.C, d.ncls), dtype=torch.float32, device=z.device)
-    db = torch.empty((d.ncls,), dtype=torch.float32, device=z.device)
+    dw = out_w if out_w is not None else torch.empty((d.C, d.ncls), dtype=torch.float32, device=z.device)
+    db = out_b if out_b is not None else torch.empty((d.ncls,), dtype=torch.float32, device=z.device)
+    assert tuple(dw.shape) == (d.C, d.ncls) and dw.is_contiguous()
     check(_abi.lib().unetk_head_bwd(ctypes.byref(d), ptr(z), ptr(w), ptr(labels), ptr(pixel_w), ptr(logits), ptr(result),
                                     float(xent_scale), float(dice_scale), ptr(dev_scales), ptr(dz), ptr(dw), ptr(db),
                                     ptr(ws), ws.numel(), stream_ptr()), "head_bwd")
@@ -757,6 +808,8 @@ class Conv3x3NormRelu(torch.autograd.Function):
             ctx.dilation = dilation
             ctx.desc = d
             ctx.has = (gamma is not None, beta is not None)
+            # gamma / beta of a unit with an SE gate also get gradient from the gate's graph: those stay with autograd
+            ctx.sinks = (grad_sink(w), grad_sink(gamma) if se is None else None, grad_sink(beta) if se is None and not plain else None)
             ctx.w_dbg = w.detach() if DEBUG_CAPTURE is not None else None
             ctx.gb_dbg = (gamma, beta) if DEBUG_CAPTURE is not None else None
             ctx.z_dbg = z.detach() if DEBUG_CAPTURE is not None else None      # the forward's own ReLU mask, for the checkers
@@ -770,11 +823,14 @@ class Conv3x3NormRelu(torch.autograd.Function):
         if dz.dtype != y.dtype:
             raise _abi.UnetkError("gradient dtype {} does not match the stored activations ({})".format(dz.dtype, y.dtype))
         dden = dfeat = None
+        debug = DEBUG_CAPTURE is not None            # the checkers read the returned tensors
+        sw, sg, sb = (None, None, None) if debug else (_take(ctx.sinks[0]), _take(ctx.sinks[1]), _take(ctx.sinks[2]))
         if den is None:
-            dy, dgamma, dbeta, dgw, dgb = norm_relu_bwd(ctx.desc, y, dz, aff, ctx.has[0], ctx.has[1], guide, gw, gb)
+            dy, dgamma, dbeta, dgw, dgb = norm_relu_bwd(ctx.desc, y, dz, aff, ctx.has[0], ctx.has[1], guide, gw, gb,
+                                                        out_gamma=sg, out_beta=sb)
         else:
             dy, dgamma, dbeta, dgw, dgb, dden = norm_relu_bwd(ctx.desc, y, dz, aff, ctx.has[0], ctx.has[1], guide, gw, gb,
-                                                              den)
+                                                              den, out_gamma=sg, out_beta=sb)
         if getattr(ctx, "se_graph", None) is not None:
             g_leaf, b_leaf, pooled, gains, xhat_mean, f_leaf = ctx.se_graph
             torch.autograd.backward(gains, dden)              # FC parameters accumulate here; pooled.grad = d loss / d pooled
@@ -794,14 +850,14 @@ class Conv3x3NormRelu(torch.autograd.Function):
             ctx.se_graph = None
         if ctx.desc.dropout_keep > 0 and den is not None and not ctx.needs_input_grad[11]:
             dden = None
-        dw = conv3x3_wgrad(x, dy, bf16=ctx.bf16, dilation=ctx.dilation)
+        dw = conv3x3_wgrad(x, dy, bf16=ctx.bf16, dilation=ctx.dilation, out=sw)
         dx = conv3x3_dgrad(dy, ctx.wp_d, x.shape[3], bf16=ctx.bf16, dilation=ctx.dilation) if ctx.need_dx else None
         if DEBUG_CAPTURE is not None:
             DEBUG_CAPTURE.append(dict(x=x, y=y, dilation=ctx.dilation, z=ctx.z_dbg, gamma=ctx.gb_dbg[0], beta=ctx.gb_dbg[1], aff=aff, dz=dz, dy=dy, dw=dw,
                                       dx=dx, dgamma=dgamma, dbeta=dbeta, w=ctx.w_dbg, guide=guide, gw=gw, gb=gb,
                                       dgw=dgw, dgb=dgb, per_sample=bool(ctx.desc.per_sample), bf16=ctx.bf16, den=den,
                                       dden=dden, guide_leaky=bool(ctx.desc.guide_leaky), plain=bool(ctx.desc.affine_only)))
-        return dx, dw, dgamma, dbeta, None, None, None, None, None, dgw, dgb, dden, None, dfeat
+        return dx, _ret(dw, sw), _ret(dgamma, sg), _ret(dbeta, sb), None, None, None, None, None, dgw, dgb, dden, None, dfeat
 
 
 class FullyConnected(torch.autograd.Function):
@@ -876,6 +932,7 @@ class Conv3dNormRelu(torch.autograd.Function):
             ctx.save_for_backward(x, y, aff)
             ctx.wp_d, ctx.need_dx, ctx.d, ctx.nd = wp_d, need_dx, d, nd
             ctx.has = (gamma is not None, beta is not None)
+            ctx.sinks = (grad_sink(w), grad_sink(gamma), grad_sink(beta) if not plain else None)
             ctx.dbg = (w.detach(), gamma, beta, stride, z.detach()) if DEBUG_CAPTURE is not None else None
         return alias(z) if out is not None else z
 
@@ -884,15 +941,17 @@ class Conv3dNormRelu(torch.autograd.Function):
         x, y, aff = ctx.saved_tensors
         if dz.stride(-1) != 1:
             dz = dz.contiguous()
-        dy, dgamma, dbeta, _, _ = norm_relu_bwd_nd(ctx.nd, y, dz, aff, ctx.has[0], ctx.has[1])
-        dw = conv3d_wgrad(x, dy, ctx.d)
+        debug = DEBUG_CAPTURE is not None
+        sw, sg, sb = (None, None, None) if debug else (_take(ctx.sinks[0]), _take(ctx.sinks[1]), _take(ctx.sinks[2]))
+        dy, dgamma, dbeta, _, _ = norm_relu_bwd_nd(ctx.nd, y, dz, aff, ctx.has[0], ctx.has[1], out_gamma=sg, out_beta=sb)
+        dw = conv3d_wgrad(x, dy, ctx.d, out=sw)
         dense = conv3d_desc(x.shape, ctx.d.Cout, ctx.d.kd, (ctx.d.sd, ctx.d.shw, ctx.d.shw))   # dx is dense
         dx = conv3d_dgrad(dy, ctx.wp_d, dense) if ctx.need_dx else None
         if DEBUG_CAPTURE is not None:
             DEBUG_CAPTURE.append(dict(kind="conv3d", x=x, y=y, w=ctx.dbg[0], gamma=ctx.dbg[1], beta=ctx.dbg[2],
                                       stride=ctx.dbg[3], z=ctx.dbg[4], dz=dz, dy=dy, dw=dw, dx=dx, dgamma=dgamma, dbeta=dbeta,
                                       per_sample=bool(ctx.nd.per_sample), plain=bool(ctx.nd.affine_only)))
-        return dx, dw, dgamma, dbeta, None, None, None, None, None
+        return dx, _ret(dw, sw), _ret(dgamma, sg), _ret(dbeta, sb), None, None, None, None, None
 
 
 class Deconv3dConcat(torch.autograd.Function):
@@ -909,6 +968,7 @@ class Deconv3dConcat(torch.autograd.Function):
         deconv3d_fwd(x, wp_f, None, cat, coff, cout, kd)
         ctx.save_for_backward(x, cat)
         ctx.wp_d, ctx.cout, ctx.coff, ctx.kd = wp_d, cout, coff, kd
+        ctx.sink = grad_sink(w)
         ctx.w_dbg = w.detach() if DEBUG_CAPTURE is not None else None
         return alias(cat)
 
@@ -916,11 +976,12 @@ class Deconv3dConcat(torch.autograd.Function):
     def backward(ctx, dcat):
         x, cat = ctx.saved_tensors
         dcat = dcat.contiguous()
-        dx, dw, _ = deconv3d_bwd(x, ctx.wp_d, cat, dcat, ctx.coff, ctx.cout, ctx.kd, want_dbias=False)
+        sw = None if DEBUG_CAPTURE is not None else _take(ctx.sink)
+        dx, dw, _ = deconv3d_bwd(x, ctx.wp_d, cat, dcat, ctx.coff, ctx.cout, ctx.kd, want_dbias=False, out_w=sw)
         if DEBUG_CAPTURE is not None:
             DEBUG_CAPTURE.append(dict(kind="deconv3d", x=x, w=ctx.w_dbg, cat=cat.clone(), dcat=dcat, dx=dx, dw=dw,
                                       coff=ctx.coff, kd=ctx.kd))
-        return dx, dw, dcat[..., :ctx.coff], None
+        return dx, _ret(dw, sw), dcat[..., :ctx.coff], None
 
 
 class MaxPool2x2(torch.autograd.Function):
@@ -978,6 +1039,7 @@ class DeconvConcat(torch.autograd.Function):
         ctx.bf16 = bf16
         ctx.cout, ctx.coff = cout, coff
         ctx.has_b = b is not None            # SmallUNet's conv2d_transpose has biases_initializer=None
+        ctx.sinks = (grad_sink(w), grad_sink(b))
         ctx.wb_dbg = (w.detach(), b.detach() if b is not None else None) if DEBUG_CAPTURE is not None else None
         return alias(cat)
 
@@ -985,12 +1047,13 @@ class DeconvConcat(torch.autograd.Function):
     def backward(ctx, dcat):
         x, cat = ctx.saved_tensors
         dcat = dcat.contiguous()
-        dx, dw, db = deconv2x2_bwd(x, ctx.wp_d, cat, dcat, ctx.coff, ctx.cout, ctx.bf16)
+        sw, sb = (None, None) if DEBUG_CAPTURE is not None else (_take(ctx.sinks[0]), _take(ctx.sinks[1]))
+        dx, dw, db = deconv2x2_bwd(x, ctx.wp_d, cat, dcat, ctx.coff, ctx.cout, ctx.bf16, out_w=sw, out_b=sb)
         dskip = dcat[..., :ctx.coff]
         if DEBUG_CAPTURE is not None:
             DEBUG_CAPTURE.append(dict(kind="deconv", x=x, w=ctx.wb_dbg[0], b=ctx.wb_dbg[1], cat=cat.clone(),
                                       dcat=dcat, dx=dx, dw=dw, db=db, coff=ctx.coff, bf16=ctx.bf16))
-        return dx, dw, (db if ctx.has_b else None), dskip, None, None
+        return dx, _ret(dw, sw), (_ret(db, sb) if ctx.has_b else None), dskip, None, None
 
 
 class DeconvConcatFront(torch.autograd.Function):
@@ -1035,6 +1098,7 @@ class HeadLoss(torch.autograd.Function):
         ctx.save_for_backward(z, w2, labels, pixel_w, logits, result, ws)
         ctx.desc = desc
         ctx.w_shape = w.shape
+        ctx.sinks = (grad_sink(w), grad_sink(b))
         xent = result[0:1].reshape(())
         dice = result[1:2].reshape(())
         outs = (xent.clone(), dice.clone(), logits, probs if probs is not None else logits.new_empty(0), result)
@@ -1046,6 +1110,8 @@ class HeadLoss(torch.autograd.Function):
         z, w2, labels, pixel_w, logits, result, ws = ctx.saved_tensors
         zero = torch.zeros((), dtype=torch.float32, device=z.device)
         scales = torch.stack([gx if gx is not None else zero, gd if gd is not None else zero]).to(torch.float32)
+        sw, sb = _take(ctx.sinks[0]), _take(ctx.sinks[1])
         dz, dw, db = head_bwd(ctx.desc, z, w2, labels, pixel_w, logits, result, ws,
-                              1.0 if gx is not None else 0.0, 1.0 if gd is not None else 0.0, scales)
-        return dz, dw.reshape(ctx.w_shape), db, None, None, None, None
+                              1.0 if gx is not None else 0.0, 1.0 if gd is not None else 0.0, scales,
+                              out_w=sw.reshape(ctx.desc.C, ctx.desc.ncls) if sw is not None else None, out_b=sb)
+        return dz, _ret(dw.reshape(ctx.w_shape), sw), _ret(db, sb), None, None, None, None

@@ -12,6 +12,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from .. import ops
+
 
 def per_device_batch_size(batch_size, num_gpus):
     """distribution_utils.py:107-134 (same error text)."""
@@ -94,14 +96,25 @@ class GradBuckets(object):
                         self._bucket_of[m] = len(self.buckets)
                     self.buckets.append((grp, lo, hi, len(members)))
                     hi, members = lo, []
+        self._sink_keys = []
         for name in store.trainable_names():
             t = store.tensors[name]
-            self._hooks.append(t.register_post_accumulate_grad_hook(self._make_hook(self._bucket_of[name])))
+            hook = self._make_hook(name, self._bucket_of[name])
+            self._hooks.append(t.register_post_accumulate_grad_hook(hook))
+            # gradients the backward kernels write straight into the flat buffer (ops._GradSink) never pass through
+            # autograd's accumulation: the op calls the same arrival hook itself
+            grp, off, n, shp, _ = store.where[name]
+            key = store.grad[grp].data_ptr() + off * 4
+            ops._GradSink.hooks[key] = (lambda h=hook: h(None))
+            self._sink_keys.append(key)
         self.arm()
 
-    def _make_hook(self, b):
+    def _make_hook(self, name, b):
         def hook(_param):
-            if self._armed:
+            # a variable arrives ONCE per step: autograd also runs the post-accumulate hook of a variable whose
+            # gradient the kernels wrote in place (it sees an undefined gradient), after the op's own call
+            if self._armed and name not in self._arrived:
+                self._arrived.add(name)
                 self._pending[b] -= 1
                 if self._pending[b] == 0:
                     self._launch(b)
@@ -117,6 +130,7 @@ class GradBuckets(object):
         self._pending = [b[3] for b in self.buckets]
         self._fired = [False] * len(self.buckets)
         self._works = []
+        self._arrived = set()
         self._armed = True
 
     def finish(self):
@@ -133,6 +147,9 @@ class GradBuckets(object):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for k in self._sink_keys:
+            ops._GradSink.hooks.pop(k, None)
+        self._sink_keys = []
 
 
 def init_process_group_from_env(backend=None):

@@ -1,10 +1,9 @@
 #!/usr/bin/env bash
 set -o pipefail
 mkdir -p gpurun_out
-python bench.py --model UNet3D --size 96 --batch 1 --steps 5 --warmup 2 --no-cpu-baseline --detail > gpurun_out/r2_u3d_bs1.json 2> gpurun_out/r2_u3d.err || tail -5 gpurun_out/r2_u3d.err
-cut -c1-300 gpurun_out/r2_u3d_bs1.json
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_u3d
-rm -rf $OUT; mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o u3d -- python3 $GRAFT_REPO_ROOT/bench.py --model UNet3D --size 96 --batch 1 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > $OUT/bench.json 2> $OUT/err.log
-rm -f $OUT/*kernel_trace.csv $OUT/*.db
+for w8 in 0 1; do for sk in 0 1; do
+UNETK_LIN_W8=$w8 UNETK_LIN_SK=$sk python bench.py --model UNet3D --size 96 --batch 1 --steps 5 --warmup 2 --no-cpu-baseline --detail > gpurun_out/r2s2_u3d_w${w8}_sk${sk}.json 2> gpurun_out/r2s2_u3d.err || tail -5 gpurun_out/r2s2_u3d.err
+echo "w8=$w8 sk=$sk"; cut -c60-130 gpurun_out/r2s2_u3d_w${w8}_sk${sk}.json
+done; done
+timeout -k 10 900 python -m pytest tests/test_gpu_unet.py tests/test_dp.py tests/test_gpu_unet3d.py tests/test_gpu_golden.py tests/test_gpu_tf_checkpoint.py -x -q > gpurun_out/r2s2_t4.log 2>&1
+tail -6 gpurun_out/r2s2_t4.log
