@@ -12,7 +12,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 _LIB = None
 LIB_PATH = os.environ.get("UNETK_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libunetk.so")
 
-ABI_VERSION = 6            # must equal unetk_abi_version() of the loaded library (checked in lib())
+ABI_VERSION = 7            # must equal unetk_abi_version() of the loaded library (checked in lib())
 UNETK_MAX_CLASSES = 8
 W_NONE, W_NUMERICAL, W_PROPORTION, W_PIXELMAP = 0, 1, 2, 3
 
@@ -69,6 +69,8 @@ _SIGNATURES = {
     "unetk_conv3x3_stat_rows": (c_int, [POINTER(ConvDesc)]),
     "unetk_conv3x3_fwd": (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
     "unetk_conv3x3_dgrad": (c_int, [POINTER(ConvDesc), P, P, P, P]),
+    "unetk_conv3x3_dgrad_nbr_rows": (c_int, [POINTER(ConvDesc)]),
+    "unetk_conv3x3_dgrad_nbr": (c_int, [POINTER(ConvDesc), P, P, P, P, c_int, P, P, P, P, c_int, P, P]),
     "unetk_conv3x3_wgrad_ws_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "unetk_conv3x3_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, c_size_t, P]),
     "unetk_conv3d_pack": (c_int, [P, c_int, c_int, c_int, P, P, P]),
@@ -85,6 +87,8 @@ _SIGNATURES = {
     "unetk_norm_bwd_ws_bytes": (c_size_t, [POINTER(NormDesc)]),
     "unetk_norm_relu_bwd": (c_int, [POINTER(NormDesc), P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                                     c_size_t, P]),
+    "unetk_norm_relu_bwd_pre": (c_int, [POINTER(NormDesc), P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int,
+                                        P, c_size_t, P]),
     "unetk_norm_se_bwd_add": (c_int, [POINTER(NormDesc), P, P, P, P, P, P, P, P]),
     "unetk_fc_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, P]),
     "unetk_fc_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),

@@ -125,6 +125,13 @@ struct ConvParams {
   // the plane (depth index + dshift0 + dt * dstep) of the same sample (zero outside [0, spg)) with the filter panel
   // wp + dt * 9 * Cin * Cout; no per-tap read-modify-write of the output.  0 / 1 = a plain 2-D conv per plane.
   int kd, dshift0, dstep;
+  // input gradient fused with the PRODUCER's norm-backward reduction (tiled fp32 / bf16-storage kernels): the output dx
+  // is the dz of the unit whose raw conv output is ny (same pixels, p.Cout channels, pixel stride nys); the epilogue
+  // emits, instead of (sum y, sum y^2), the partials  sum du  and  sum du * xhat  with du = dz * (ny*nsc + nsh > 0),
+  // xhat = (ny - nmu) * nrs, into p.stat.  nsst = statistics stride per image (C under instance norm, 0 under batch norm).
+  const void* ny;
+  const float *nsc, *nsh, *nmu, *nrs;
+  int nys, nsst;
   // stream-K scheduling of the linear-pixel kernel (conv_igemm_lin.hip): slab for the pieces of split tiles
   // ([sk_tiles][sk_maxp][BM][BN] floats, caller's workspace; nullptr = one block per tile), chunks per tile, tiles
   float* sk_slab;

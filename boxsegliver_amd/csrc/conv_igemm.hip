@@ -175,6 +175,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
   float ssum[TN], ssq[TN];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) ssum[tn] = ssq[tn] = 0.f;
+  float nsc[TN], nsh[TN], nmu[TN], nrs[TN];
+  if (p.ny != nullptr) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int64_t o = (int64_t)n_img * p.nsst + n0 + (wn * TN + tn) * 32 + l31;
+      nsc[tn] = p.nsc[o]; nsh[tn] = p.nsh[o]; nmu[tn] = p.nmu[o]; nrs[tn] = p.nrs[o];
+    }
+  }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int sub = wm * TM + tm;
@@ -196,6 +204,38 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
           for (int tn = 0; tn < TN; ++tn) prior[r][tn] = yp[tn * 32];
         }
       }
+    }
+    if (p.ny != nullptr) {
+      // fused norm-backward reduction of the producing unit (see ConvParams::ny): its raw output at this fragment's
+      // pixels, all loads issued together
+      const float* nyb = static_cast<const float*>(p.ny) + (int64_t)n_img * p.H * p.W * p.nys + n0 + wn * TN * 32 + l31;
+      float qv[16][TN];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = mfma32_row(r, h);
+        const int gh = h0 + 2 * sub + (i >> 4), gw = w0 + (i & 15);
+        const bool ok = gh < p.H && gw < p.W;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) qv[r][tn] = ok ? nyb[((int64_t)gh * p.W + gw) * p.nys + tn * 32] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = mfma32_row(r, h);
+        const int gh = h0 + 2 * sub + (i >> 4), gw = w0 + (i & 15);
+        if (gh < p.H && gw < p.W) {
+          float* yp = p.y + yimg + ((int64_t)gh * p.W + gw) * p.ys + n0 + wn * TN * 32 + l31;
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const float v = acc[tm][tn][r] + prior[r][tn];
+            yp[tn * 32] = v;
+            const float q = qv[r][tn];
+            const float du = fmaf(q, nsc[tn], nsh[tn]) > 0.f ? v : 0.f;
+            ssum[tn] += du;
+            ssq[tn] += du * ((q - nmu[tn]) * nrs[tn]);
+          }
+        }
+      }
+      continue;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -567,5 +607,42 @@ extern "C" int unetk_conv3x3_dgrad(const unetk_conv_desc* d, const void* dy, con
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cout; p.Cout = d->Cin; p.xs = d->y_stride; p.ys = d->x_stride;
   p.xa = unetk_dense_addr(p.H, p.W, p.xs);
   p.ya = unetk_dense_addr(p.H, p.W, p.ys);
+  return unetk_conv_run(p, (hipStream_t)stream);
+}
+
+// ---- input gradient fused with the producing unit's norm-backward reduction (ConvParams::ny)
+extern "C" int unetk_conv3x3_dgrad_nbr_rows(const unetk_conv_desc* d) {
+  if (!conv_desc_ok(d) || d->dilation > 1) return 0;
+  const int K = d->Cout, Nc = d->Cin;                       // the dgrad conv contracts Cout, produces Cin channels
+  // measured: the extra epilogue work (16 x TN strided loads of prod_y per fragment) costs ~0.03 ms on the deep layers and
+  // 0.38 ms on the 64-channel 256^2 level, whose K loop is only 36 steps -- more than the separate reduction pass there
+  if (K < 128 || Nc < 128) return 0;
+  if (d->precision == UNETK_BF16S) {
+    if (!unetk_conv_bf16_ok(K, Nc) || K % 64 != 0 || Nc % 64 != 0) return 0;
+    return unetk_conv_stat_rows_bf16(d->N, d->H, d->W, K, Nc);
+  }
+  if (d->precision != UNETK_FP32) return 0;
+  if (pick_cfg(K, Nc).id < 0 || unetk_conv_lin_ok(d->N, d->H, d->W, K, Nc, 1)) return 0;   // tiled fp32 kernel only
+  return unetk_conv_stat_rows(d->N, d->H, d->W, K, Nc);
+}
+
+extern "C" int unetk_conv3x3_dgrad_nbr(const unetk_conv_desc* d, const void* dy, const void* w, void* dx,
+                                       const void* prod_y, int prod_y_stride, const float* scale, const float* shift,
+                                       const float* mean, const float* rstd, int per_sample, float* partials,
+                                       void* stream) {
+  UNETK_REQUIRE(conv_desc_ok(d) && dy && w && dx && prod_y && scale && shift && mean && rstd && partials);
+  UNETK_REQUIRE(unetk_aligned16(dy) && unetk_aligned16(w) && unetk_aligned16(dx));
+  UNETK_REQUIRE(d->x_stride % 4 == 0 && d->y_stride % 4 == 0 && prod_y_stride >= d->Cin);
+  if (unetk_conv3x3_dgrad_nbr_rows(d) <= 0) return UNETK_E_UNSUPPORTED;
+  ConvParams p{};
+  p.bf16 = d->precision;
+  p.x = (const float*)dy; p.wp = (const float*)w; p.y = (float*)dx; p.stat = partials;
+  p.dil = d->dilation;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cout; p.Cout = d->Cin; p.xs = d->y_stride; p.ys = d->x_stride;
+  p.xa = unetk_dense_addr(p.H, p.W, p.xs);
+  p.ya = unetk_dense_addr(p.H, p.W, p.ys);
+  p.ny = prod_y; p.nys = prod_y_stride;
+  p.nsc = scale; p.nsh = shift; p.nmu = mean; p.nrs = rstd;
+  p.nsst = per_sample ? d->Cin : 0;
   return unetk_conv_run(p, (hipStream_t)stream);
 }

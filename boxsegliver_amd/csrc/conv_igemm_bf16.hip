@@ -210,9 +210,30 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
   float ssum[TN], ssq[TN];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) ssum[tn] = ssq[tn] = 0.f;
+  // input gradient fused with the producing unit's norm-backward reduction (ConvParams::ny; bf16 storage only): the two
+  // channels of a lane are (2 l31, 2 l31 + 1) of the wave's 64-channel block
+  float nsc[2], nsh[2], nmu[2], nrs[2];
+  const bool fuse = BS && p.ny != nullptr;
+  if (fuse) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t o = (int64_t)n_img * p.nsst + n0 + wn * 64 + 2 * l31 + j;
+      nsc[j] = p.nsc[o]; nsh[j] = p.nsh[o]; nmu[j] = p.nmu[o]; nrs[j] = p.nrs[o];
+    }
+  }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int sub = wm * TM + tm;
+    uint32_t qv[16];
+    if (fuse) {   // the producer's raw output at this fragment's pixels, loads issued together
+      const bf16_t* nyb = static_cast<const bf16_t*>(p.ny) + (int64_t)n_img * p.H * p.W * p.nys + n0 + wn * 64 + 2 * l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = mfma32_row(r, h);
+        const int gh = h0 + 2 * sub + (i >> 4), gw = w0 + (i & 15);
+        qv[r] = (gh < p.H && gw < p.W) ? *reinterpret_cast<const uint32_t*>(nyb + ((int64_t)gh * p.W + gw) * p.nys) : 0u;
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = mfma32_row(r, h);
@@ -221,7 +242,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
         if constexpr (BS) {   // channels (2 l31, 2 l31 + 1) of this wave's 64-channel block: one 4-byte store
           bf16_t* yb = reinterpret_cast<bf16_t*>(p.y) + yimg + ((int64_t)gh * p.W + gw) * p.ys + n0 + wn * 64 + 2 * l31;
           const float v0 = acc[tm][0][r], v1 = acc[tm][TN - 1][r];
-          *reinterpret_cast<uint32_t*>(yb) = pk_bf16(v0, v1);
+          const uint32_t pk = pk_bf16(v0, v1);
+          *reinterpret_cast<uint32_t*>(yb) = pk;
+          if (fuse) {   // on the values memory holds (what a separate reduction pass would read back)
+            const float d0 = unetk_bf16_lo(pk), d1 = unetk_bf16_hi(pk);
+            const float q0 = unetk_bf16_lo(qv[r]), q1 = unetk_bf16_hi(qv[r]);
+            const float du0 = fmaf(q0, nsc[0], nsh[0]) > 0.f ? d0 : 0.f, du1 = fmaf(q1, nsc[1], nsh[1]) > 0.f ? d1 : 0.f;
+            ssum[0] += du0; ssq[0] += du0 * ((q0 - nmu[0]) * nrs[0]);
+            ssum[TN - 1] += du1; ssq[TN - 1] += du1 * ((q1 - nmu[1]) * nrs[1]);
+            continue;
+          }
           ssum[0] += v0; ssq[0] += v0 * v0;
           ssum[TN - 1] += v1; ssq[TN - 1] += v1 * v1;
           continue;

@@ -586,7 +586,7 @@ extern "C" size_t unetk_norm_bwd_ws_bytes(const unetk_norm_desc* d) {
   f += (size_t)K * g.L * d->C;                                       // sums per launch group
   f += (size_t)K * d->C;                                             // sums over groups
   if (nblk1 > nblk) nblk = nblk1;
-  f += unetk_rows_reduce_tmp_floats(K * g.L, nblk, d->C);
+  f += unetk_rows_reduce_tmp_floats(K * g.L, 257, d->C);              // always: pre-computed partials may have any row count
   f += unetk_rows_reduce_tmp_floats(K, g.L, d->C);
   return f * sizeof(float);
 }
@@ -596,6 +596,18 @@ extern "C" int unetk_norm_relu_bwd(const unetk_norm_desc* d, const void* y, cons
                                    const float* den, const float* guide, const float* gw, const float* gb, void* dy,
                                    float* dgamma, float* dbeta, float* dden, float* dgw, float* dgb, void* ws,
                                    size_t ws_bytes, void* stream) {
+  return unetk_norm_relu_bwd_pre(d, y, dz, dz_stride, scale, shift, mean, rstd, den, guide, gw, gb, dy, dgamma, dbeta, dden,
+                                 dgw, dgb, nullptr, 0, ws, ws_bytes, stream);
+}
+
+// pre_partials [2][pre_rows][C] (nullable): the reduction pass's sums (sum du, sum du * xhat), per tile of the kernel that
+// PRODUCED dz (unetk_conv3x3_dgrad_nbr) -- then only the apply pass runs here.  Plain units only (no guide, density,
+// dropout, bias-only).
+extern "C" int unetk_norm_relu_bwd_pre(const unetk_norm_desc* d, const void* y, const void* dz, int dz_stride,
+                                       const float* scale, const float* shift, const float* mean, const float* rstd,
+                                       const float* den, const float* guide, const float* gw, const float* gb, void* dy,
+                                       float* dgamma, float* dbeta, float* dden, float* dgw, float* dgb,
+                                       const float* pre_partials, int pre_rows, void* ws, size_t ws_bytes, void* stream) {
   UNETK_REQUIRE(norm_desc_ok(d) && y && dz && scale && shift && mean && rstd && dy && ws && dz_stride >= d->C);
   if (!norm_supported(d) || dz_stride % 4 != 0) return UNETK_E_UNSUPPORTED;
   const bool bs = d->storage == UNETK_BF16S;
@@ -622,7 +634,7 @@ extern "C" int unetk_norm_relu_bwd(const unetk_norm_desc* d, const void* y, cons
   float* sums = partial + (size_t)K * g.L * nblk * d->C;
   float* psum = sums + (size_t)K * g.L * d->C;
   float* tmp1 = psum + (size_t)K * d->C;
-  float* tmp2 = tmp1 + unetk_rows_reduce_tmp_floats(K * g.L, nblk, d->C);
+  float* tmp2 = tmp1 + unetk_rows_reduce_tmp_floats(K * g.L, 257, d->C);
   BwdArgs a{};
   a.y = y; a.dz = dz; a.scale = scale; a.shift = shift; a.mean = mean; a.rstd = rstd; a.den = den;
   a.guide = guide; a.gw = gw; a.gb = gb; a.partial = partial; a.dy = dy;
@@ -638,9 +650,16 @@ extern "C" int unetk_norm_relu_bwd(const unetk_norm_desc* d, const void* y, cons
   else if (g.L == 1) { a.ksum = sums; a.kst = 0; a.krow = d->C; }
   else { a.ksum = psum; a.kst = 0; a.krow = d->C; }
   const size_t lds = (size_t)K * g.rpi * d->C * sizeof(float);
-  GD_DISPATCH(bs, G, D, leaky, norm_bwd_reduce_kernel, dim3(nblk, g.L), dim3(256), lds, st, a);
-  UNETK_LAUNCH_CHECK();
-  int rc = unetk_rows_reduce(partial, K * g.L, nblk, d->C, sums, tmp1, st);   // -> sums[K][L][C]
+  int rc;
+  if (pre_partials != nullptr) {
+    if (G > 0 || D || leaky || gb || d->dropout_keep > 0.f || d->affine_only) return UNETK_E_UNSUPPORTED;
+    UNETK_REQUIRE(pre_rows > 0 && pre_rows % g.L == 0);
+    rc = unetk_rows_reduce(pre_partials, K * g.L, pre_rows / g.L, d->C, sums, tmp1, st);   // -> sums[K][L][C]
+  } else {
+    GD_DISPATCH(bs, G, D, leaky, norm_bwd_reduce_kernel, dim3(nblk, g.L), dim3(256), lds, st, a);
+    UNETK_LAUNCH_CHECK();
+    rc = unetk_rows_reduce(partial, K * g.L, nblk, d->C, sums, tmp1, st);   // -> sums[K][L][C]
+  }
   if (rc != UNETK_OK) return rc;
   if (g.L == 1) {
     psum = sums;                                                               // one launch group: nothing to add up

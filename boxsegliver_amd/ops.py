@@ -37,6 +37,8 @@ class _Workspace(object):
 
 
 WORKSPACE = _Workspace()
+FUSE_NBR = True         # conv2's input gradient also emits conv1's norm-backward reduction (unetk_conv3x3_dgrad_nbr)
+FUSED_NBR = {}          # dx.data_ptr() -> (producer y.data_ptr(), shape, partials, rows); consumed by the producer's backward
 DEBUG_CAPTURE = None    # tools/: set to a list to record each conv unit's backward operands
 PROFILE_SHAPES = False  # bench.py --detail: one row per (kernel, layer shape)
 PROFILE = None          # bench.py: set to a list -> (kernel tag, algorithmic FLOPs, start event, end event)
@@ -110,6 +112,7 @@ class _GradSink(object):
 
 def new_step():
     _GradSink.written.clear()
+    FUSED_NBR.clear()
 
 
 def grad_sink(p):
@@ -235,7 +238,9 @@ def conv3x3_fwd(x, w, cout, want_stats=True, y=None, bf16=False, dilation=1):
     return y, stats, rows
 
 
-def conv3x3_dgrad(dy, wp_dgrad, cin, x_stride=None, dx=None, bf16=False, dilation=1):
+def conv3x3_dgrad(dy, wp_dgrad, cin, x_stride=None, dx=None, bf16=False, dilation=1, producer=None):
+    """producer = (y, aff, per_sample) of the unit whose activation is this conv's input: the kernel then also emits that
+    unit's norm-backward reduction (unetk_conv3x3_dgrad_nbr) and the partials are left in FUSED_NBR for its backward."""
     _require_cuda(dy, wp_dgrad)
     n, h, wd, cout = dy.shape
     prec = precision_of(bf16)
@@ -243,6 +248,19 @@ def conv3x3_dgrad(dy, wp_dgrad, cin, x_stride=None, dx=None, bf16=False, dilatio
     if dx is None:
         dx = torch.empty((n, h, wd, cin), dtype=dy.dtype, device=dy.device)
     d = ConvDesc(n, h, wd, cin, cout, _pix_stride(dx), _pix_stride(dy), prec, int(dilation))
+    if producer is not None and FUSE_NBR:
+        py, paff, per_sample = producer
+        rows = _abi.lib().unetk_conv3x3_dgrad_nbr_rows(ctypes.byref(d))
+        if rows > 0 and py.dtype == dx.dtype and tuple(py.shape) == tuple(dx.shape) and py.is_contiguous():
+            part = torch.empty((2, rows, cin), dtype=torch.float32, device=dy.device)
+            with _Timed(_igemm_tag(cout, cin, bf16, h, n, wd), 18.0 * n * h * wd * cin * cout,
+                        "dgrad+nbr {}x{}x{} {}->{}".format(n, h, wd, cout, cin)):
+                check(_abi.lib().unetk_conv3x3_dgrad_nbr(ctypes.byref(d), ptr(dy), ptr(wp_dgrad), ptr(dx), ptr(py), cin,
+                                                         ptr(paff[2]), ptr(paff[3]), ptr(paff[0]), ptr(paff[1]),
+                                                         1 if per_sample else 0, ptr(part), stream_ptr()),
+                      "conv3x3_dgrad_nbr")
+            FUSED_NBR[dx.data_ptr()] = (py.data_ptr(), tuple(dx.shape), part, rows)
+            return dx
     with _Timed(_igemm_tag(cout, cin, bf16, h, n, wd), 18.0 * n * h * wd * cin * cout, "dgrad {}x{}x{} {}->{}".format(n, h, wd, cout, cin)):
         check(_abi.lib().unetk_conv3x3_dgrad(ctypes.byref(d), ptr(dy), ptr(wp_dgrad), ptr(dx), stream_ptr()),
               "conv3x3_dgrad")
@@ -378,7 +396,7 @@ def norm_apply_relu(d, y, aff, z, guide=None, gw=None, gb=None, den=None):
 
 
 def norm_relu_bwd(d, y, dz, aff, has_gamma, has_beta, guide=None, gw=None, gb=None, den=None, out_gamma=None,
-                  out_beta=None):
+                  out_beta=None, pre=None):
     dev = y.device
     assert dz.dtype == y.dtype, (dz.dtype, y.dtype)
     d.storage = _storage_of(y)
@@ -396,10 +414,11 @@ def norm_relu_bwd(d, y, dz, aff, has_gamma, has_beta, guide=None, gw=None, gb=No
     if nbytes == 0:
         raise _abi.UnetkError("norm_relu_bwd: unsupported channel count {}".format(d.C))
     ws = WORKSPACE.get(nbytes, dev)
-    check(_abi.lib().unetk_norm_relu_bwd(ctypes.byref(d), ptr(y), ptr(dz), _pix_stride_nd(dz), ptr(aff[2]), ptr(aff[3]),
-                                         ptr(aff[0]), ptr(aff[1]), ptr(den), ptr(guide), ptr(gw), ptr(gb), ptr(dy),
-                                         ptr(dgamma), ptr(dbeta), ptr(dden), ptr(dgw), ptr(dgb), ptr(ws), nbytes,
-                                         stream_ptr()),
+    pre_part, pre_rows = pre if pre is not None else (None, 0)
+    check(_abi.lib().unetk_norm_relu_bwd_pre(ctypes.byref(d), ptr(y), ptr(dz), _pix_stride_nd(dz), ptr(aff[2]), ptr(aff[3]),
+                                             ptr(aff[0]), ptr(aff[1]), ptr(den), ptr(guide), ptr(gw), ptr(gb), ptr(dy),
+                                             ptr(dgamma), ptr(dbeta), ptr(dden), ptr(dgw), ptr(dgb), ptr(pre_part),
+                                             int(pre_rows), ptr(ws), nbytes, stream_ptr()),
           "norm_relu_bwd")
     if den is not None:
         return dy, dgamma, dbeta, dgw, dgb, dden
@@ -799,7 +818,12 @@ class Conv3x3NormRelu(torch.autograd.Function):
             den = gains.detach().contiguous()
             se_graph = (g_leaf, b_leaf, pooled, gains, xhat_mean, f_leaf)
         norm_apply_relu(d, y, aff, z, guide, gw, gb, den)
+        # a unit another conv unit may fuse its input gradient with (see conv3x3_dgrad): plain normalised units only
+        simple = (not plain and se is None and den is None and g_ch == 0 and gb is None and d.dropout_keep == 0)
         if spec.training:
+            src = getattr(x, "_unetk_unit", None)
+            ctx.producer = src if (need_dx and src is not None and dilation == 1) else None
+            ctx.simple = simple
             ctx.save_for_backward(x, y, aff, guide, gw, gb, den)
             ctx.se_graph = se_graph
             ctx.wp_d = wp_d
@@ -813,11 +837,17 @@ class Conv3x3NormRelu(torch.autograd.Function):
             ctx.w_dbg = w.detach() if DEBUG_CAPTURE is not None else None
             ctx.gb_dbg = (gamma, beta) if DEBUG_CAPTURE is not None else None
             ctx.z_dbg = z.detach() if DEBUG_CAPTURE is not None else None      # the forward's own ReLU mask, for the checkers
-        return alias(z) if out is not None else z
+        zr = alias(z) if out is not None else z
+        if spec.training and simple and out is None:
+            zr._unetk_unit = (y, aff, spec.per_sample)
+        return zr
 
     @staticmethod
     def backward(ctx, dz):
         x, y, aff, guide, gw, gb, den = ctx.saved_tensors
+        pre = FUSED_NBR.pop(dz.data_ptr(), None) if DEBUG_CAPTURE is None else None
+        if pre is not None and not (ctx.simple and pre[0] == y.data_ptr() and pre[1] == tuple(dz.shape) and dz.is_contiguous()):
+            pre = None
         if dz.stride(3) != 1:
             dz = dz.contiguous()
         if dz.dtype != y.dtype:
@@ -827,7 +857,7 @@ class Conv3x3NormRelu(torch.autograd.Function):
         sw, sg, sb = (None, None, None) if debug else (_take(ctx.sinks[0]), _take(ctx.sinks[1]), _take(ctx.sinks[2]))
         if den is None:
             dy, dgamma, dbeta, dgw, dgb = norm_relu_bwd(ctx.desc, y, dz, aff, ctx.has[0], ctx.has[1], guide, gw, gb,
-                                                        out_gamma=sg, out_beta=sb)
+                                                        out_gamma=sg, out_beta=sb, pre=(pre[2], pre[3]) if pre else None)
         else:
             dy, dgamma, dbeta, dgw, dgb, dden = norm_relu_bwd(ctx.desc, y, dz, aff, ctx.has[0], ctx.has[1], guide, gw, gb,
                                                               den, out_gamma=sg, out_beta=sb)
@@ -851,7 +881,8 @@ class Conv3x3NormRelu(torch.autograd.Function):
         if ctx.desc.dropout_keep > 0 and den is not None and not ctx.needs_input_grad[11]:
             dden = None
         dw = conv3x3_wgrad(x, dy, bf16=ctx.bf16, dilation=ctx.dilation, out=sw)
-        dx = conv3x3_dgrad(dy, ctx.wp_d, x.shape[3], bf16=ctx.bf16, dilation=ctx.dilation) if ctx.need_dx else None
+        dx = conv3x3_dgrad(dy, ctx.wp_d, x.shape[3], bf16=ctx.bf16, dilation=ctx.dilation,
+                           producer=ctx.producer if DEBUG_CAPTURE is None else None) if ctx.need_dx else None
         if DEBUG_CAPTURE is not None:
             DEBUG_CAPTURE.append(dict(x=x, y=y, dilation=ctx.dilation, z=ctx.z_dbg, gamma=ctx.gb_dbg[0], beta=ctx.gb_dbg[1], aff=aff, dz=dz, dy=dy, dw=dw,
                                       dx=dx, dgamma=dgamma, dbeta=dbeta, w=ctx.w_dbg, guide=guide, gw=gw, gb=gb,

@@ -111,6 +111,19 @@ int unetk_conv3x3_fwd(const unetk_conv_desc* d, const void* x, const void* w, vo
 int unetk_conv3x3_dgrad(const unetk_conv_desc* d, const void* dy, const void* w, void* dx,
                         void* stream);
 
+/* The same input gradient, fused with the norm-backward REDUCTION of the unit that produced the conv's input (the
+ * slim.repeat(x, 2, slim.conv2d, ...) pairs of UNet.py:79,85,94: conv2's dx is the dz of conv1's norm + ReLU): while the
+ * dx tile is in registers the epilogue reads prod_y (conv1's raw output, same [N,H,W,Cin], pixel stride prod_y_stride;
+ * bf16 under UNETK_BF16S) and writes, per tile, the partial sums  sum du  and  sum du * xhat  (du = dx * (prod_y * scale +
+ * shift > 0), xhat = (prod_y - mean) * rstd; scale / shift / mean / rstd are conv1's unetk_norm_finalize outputs,
+ * [N][Cin] when per_sample else [Cin]) into partials [2][rows][Cin] -- the input unetk_norm_relu_bwd_pre takes instead of
+ * running its own pass over (dz, y).  unetk_conv3x3_dgrad_nbr_rows = rows, or 0 when the shape has no fused variant
+ * (tiled fp32 kernel and bf16-storage kernel only; the caller then uses the two separate calls). */
+int unetk_conv3x3_dgrad_nbr_rows(const unetk_conv_desc* d);
+int unetk_conv3x3_dgrad_nbr(const unetk_conv_desc* d, const void* dy, const void* w, void* dx, const void* prod_y,
+                            int prod_y_stride, const float* scale, const float* shift, const float* mean,
+                            const float* rstd, int per_sample, float* partials, void* stream);
+
 /* dw[HWIO] = conv3x3_filter_grad(x, dy).  Split-K over pixel tiles through a workspace of
  * fixed-order partial slabs (bit-reproducible). */
 size_t unetk_conv3x3_wgrad_ws_bytes(const unetk_conv_desc* d);
@@ -204,6 +217,15 @@ int unetk_norm_relu_bwd(const unetk_norm_desc* d, const void* y, const void* dz,
                         const float* den, const float* guide, const float* gw, const float* gb, void* dy,
                         float* dgamma, float* dbeta, float* dden, float* dgw, float* dgb, void* ws,
                         size_t ws_bytes, void* stream);
+
+/* unetk_norm_relu_bwd with the reduction pass already done by the kernel that produced dz (unetk_conv3x3_dgrad_nbr):
+ * pre_partials [2][pre_rows][C], each statistics group's rows contiguous; NULL = unetk_norm_relu_bwd.  Plain units only
+ * (no guide, density, dropout or bias-only mode: UNETK_E_UNSUPPORTED). */
+int unetk_norm_relu_bwd_pre(const unetk_norm_desc* d, const void* y, const void* dz, int dz_stride,
+                            const float* scale, const float* shift, const float* mean, const float* rstd,
+                            const float* den, const float* guide, const float* gw, const float* gb, void* dy,
+                            float* dgamma, float* dbeta, float* dden, float* dgw, float* dgb,
+                            const float* pre_partials, int pre_rows, void* ws, size_t ws_bytes, void* stream);
 
 /* GUNet --use_se (GUNet.py:192-201): the SE gate's input is pooled[b][c] = mean over the sample's pixels of the normalised
  * conv output, so the loss reaches y once more through it.  The norm backward is linear in dt, and this part of dt is the
