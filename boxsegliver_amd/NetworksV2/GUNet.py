@@ -23,7 +23,10 @@ conv is linear in the guide, so its batch / instance statistics follow EXACTLY f
 kernels only switch the guide branch's activation to ReLU (guide_leaky with slope 0); nothing is materialised.
 `--use_se` (GUNet.py:192-201): the gains of a unit are sigmoid(fc(relu(fc(concat(mean_hw(net), context slice))))) --
 ops.Conv3x3NormRelu forms mean_hw(net) from the conv's per-sample statistics and back-propagates through it.
-Not built (raise NotImplementedError): context_model vgg16*, the conv context subnet (`ct_conv`); --fix or --use_se
+context_model "vgg16B" / "vgg16C" / "vgg16D" (GUNet.py:62-75, slim_nets.py:60-144; ext_config/GUNet_DE_VGG16{B,D}.yml): the
+context vector as [bs, L, 1] through 1-D conv + ReLU stacks and "same" max-pools (ops.Conv1d / ops.MaxPool1d, csrc/conv1d.hip),
+flattened into mlp(num_base=5) = fc6 ..; the last layer starts at weights 0 / biases 1.
+Not built (raise NotImplementedError): the conv context subnet (`ct_conv`); --fix or --use_se
 combined with each other or with --dropout / after_affine; after_affine together with --without_norm.
 --without_norm (GUNet.py:251-252,314-315): every unit = conv + bias (* density gain + guide term) + ReLU, the norm stage
 of the fused kernels reduced to the per-channel shift (unetk_norm_desc.affine_only).
@@ -48,9 +51,29 @@ def n_modulator_params_se(context_feature_length, num_down_samples, mod_layers):
     return context_feature_length * sum(1 for i in range(num_down_samples + 1) if i in mod_layers) * 2
 
 
+def vgg_context_layout(model, length, c0):
+    """Layers of slim_nets.vgg16B / C / D (slim_nets.py:60-144) on a [bs, length, 1] context, in graph order:
+    ("conv", scope under <name>/context, kernel, cin, cout) | ("pool",); and the flattened feature length."""
+    reps = {"vgg16B": (2, 2, 2, 2, 2), "vgg16C": (2, 2, 2, 2, 2), "vgg16D": (2, 2, 3, 3, 3)}[model]
+    layers, cin, l = [], 1, int(length)
+    for g, (rep, mult) in enumerate(zip(reps, (1, 2, 4, 8, 8)), start=1):
+        cout = int(c0) * mult
+        for j in range(1, rep + 1):                                   # slim.repeat(net, rep, conv_op, cout, 3, scope="conv{g}")
+            layers.append(("conv", "conv{0}/conv{0}_{1}".format(g, j), 3, cin, cout))
+            cin = cout
+        if model == "vgg16C" and g >= 3:                              # conv_op(net, cout, 1, scope="conv{g}_3")
+            layers.append(("conv", "conv{}_3".format(g), 1, cin, cout))
+        layers.append(("pool",))
+        l = (l + 1) // 2                                              # max_pooling1d(2, 2, padding="same")
+    return layers, l * cin
+
+
+VGG_CONTEXT_MODELS = ("vgg16B", "vgg16C", "vgg16D")
+
+
 def param_specs(in_channels, num_classes, guide_channel, init_channels, num_down_samples, mod_layers, normalizer,
                 norm_with_center, norm_with_scale, use_spatial, name, context_dims=None, after_affine=False, mid_cat_g=0,
-                without_norm=False, fix=False, se_length=0):
+                without_norm=False, fix=False, se_length=0, context_model="fc", context_conv_init_channels=16):
     """Variables with the reference's TF names: <name>/spatial/conv{i}/{weights,biases},
     <name>/Encode/down_conv{i}/mod_conv{j}/{weights,<Norm>/...}, <name>/Decode/up{i}/{weights,biases},
     <name>/Decode/up_conv{i}/up_conv{i}_{j}/..., <name>/AdjustChannels/{weights,biases}."""
@@ -70,7 +93,21 @@ def param_specs(in_channels, num_classes, guide_channel, init_channels, num_down
             specs.append(("{}/{}/moving_mean".format(scope, ns), (c,), "moving_mean"))
             specs.append(("{}/{}/moving_variance".format(scope, ns), (c,), "moving_var"))
 
-    if context_dims:      # [context length, fc channels ..., n_modulator_param]: <name>/context/fc{i}/{weights,biases}
+    if context_dims and context_model in VGG_CONTEXT_MODELS:
+        # GUNet.py:62-75: 1-D VGG trunk (slim.conv1d: bias, no regulariser) + mlp(num_base=5): fc6.. ; the last layer starts at
+        # weights 0 / biases 1 (every gain = 1)
+        layers, feat = vgg_context_layout(context_model, context_dims[0], context_conv_init_channels)
+        for lay in layers:
+            if lay[0] == "conv":
+                _, scope, k, ci, co = lay
+                specs.append(("{}/context/{}/weights".format(name, scope), (k, ci, co), "conv1d_w"))
+                specs.append(("{}/context/{}/biases".format(name, scope), (co,), "fc_b"))
+        dims = [feat] + list(context_dims[1:])
+        for i in range(1, len(dims)):
+            last = i == len(dims) - 1
+            specs.append(("{}/context/fc{}/weights".format(name, 5 + i), (dims[i - 1], dims[i]), "fc_w_zero" if last else "fc_w"))
+            specs.append(("{}/context/fc{}/biases".format(name, 5 + i), (dims[i],), "fc_b_one" if last else "fc_b"))
+    elif context_dims:    # [context length, fc channels ..., n_modulator_param]: <name>/context/fc{i}/{weights,biases}
         for i in range(1, len(context_dims)):
             last = i == len(context_dims) - 1
             specs.append(("{}/context/fc{}/weights".format(name, i), (context_dims[i - 1], context_dims[i]),
@@ -251,9 +288,11 @@ class GUNet(base.BaseNet):
         g_ch = int(getattr(self.args, "guide_channel", 1)) if (self.use_spatial_guide and not self._concat_guide) else 0
         context_dims = None
         if self.use_context_guide:
-            if kwargs.get("context_model", "fc") != "fc":
-                raise NotImplementedError("GUNet context_model {} is not built (only \"fc\")".format(
-                    kwargs.get("context_model")))
+            context_model = kwargs.get("context_model", "fc")
+            if context_model == "resnet":
+                raise NotImplementedError                                                   # GUNet.py:76-77, literally
+            if context_model != "fc" and context_model not in VGG_CONTEXT_MODELS:
+                raise ValueError("Not supported context model")                             # GUNet.py:78-79
             context = self._inputs["context"]
             if context.dim() != 2 or context.shape[0] != n or not context.is_cuda:
                 raise ValueError("context must be a [bs, L] device tensor, got {}".format(tuple(context.shape)))
@@ -272,7 +311,9 @@ class GUNet(base.BaseNet):
                                 context_dims, after_affine, mid_g, bool(getattr(self.args, "without_norm", False)),
                                 fix=bool(getattr(self.args, "fix", False)) and g_ch > 0,
                                 se_length=(list(kwargs.get("context_fc_channels", [256]))[-1]
-                                           if (self.use_se and self.use_context_guide) else 0))
+                                           if (self.use_se and self.use_context_guide) else 0),
+                                context_model=kwargs.get("context_model", "fc"),
+                                context_conv_init_channels=int(kwargs.get("context_conv_init_channels", 16)))
             if mid_g:
                 # Encode2's first conv sees 64 + g channels: padded with zero filter rows to the filter-gradient tile (32)
                 wname = "{}/Encode/down_conv2/mod_conv1/weights".format(nm)
@@ -305,12 +346,27 @@ class GUNet(base.BaseNet):
                 training = self.mode == ModeKeys.TRAIN
                 keep = 1.0 - self.side_dropout if (self.side_dropout and training) else None
                 self._dropout_calls = getattr(self, "_dropout_calls", 0) + 1
-                for li in range(1, len(context_dims)):
-                    last = li == len(context_dims) - 1
+                fc_base, n_fc = 0, len(context_dims) - 1
+                cmodel = kwargs.get("context_model", "fc")
+                if cmodel in VGG_CONTEXT_MODELS:
+                    # slim_nets.vgg (slim_nets.py:60-144) on tf.expand_dims(context, -1): conv1d + ReLU stacks, "same" pools,
+                    # flatten; then mlp(num_base=5) = fc6 .. (GUNet.py:62-75)
+                    layers, _ = vgg_context_layout(cmodel, context_dims[0], int(kwargs.get("context_conv_init_channels", 16)))
+                    t = den_all.unsqueeze(-1)
+                    for lay in layers:
+                        if lay[0] == "conv":
+                            cs = "{}/context/{}".format(nm, lay[1])
+                            t = ops.Conv1d.apply(t, p[cs + "/weights"], p[cs + "/biases"], True)
+                        else:
+                            t = ops.MaxPool1d.apply(t)
+                    den_all = t.reshape(t.shape[0], -1)                                       # slim.flatten
+                    fc_base = 5
+                for li in range(1, n_fc + 1):
+                    last = li == n_fc
                     seed = (int(getattr(self.args, "seed", None) or 1234) * 1000003 + self._dropout_calls * 101 + li)
                     den_all = ops.FullyConnected.apply(
-                        den_all, p["{}/context/fc{}/weights".format(nm, li)], p["{}/context/fc{}/biases".format(nm, li)],
-                        not last, None if last else keep, seed)
+                        den_all, p["{}/context/fc{}/weights".format(nm, fc_base + li)],
+                        p["{}/context/fc{}/biases".format(nm, fc_base + li)], not last, None if last else keep, seed)
                 self._layers["context_params"] = den_all
             se_len = int(context_dims[-2]) if (context_dims and self.use_se) else 0
 

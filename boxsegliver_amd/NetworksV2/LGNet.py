@@ -70,8 +70,9 @@ class LGNet(GUNet):
     def _net_arg_scope(self, *args, **kwargs):
         """LGNet.py:108-130: every slim.conv2d = 3x3, normaliser from _get_normalization(), no activation (the ReLUs are
         explicit); pools SAME."""
-        if getattr(self.args, "without_norm", False):
-            raise NotImplementedError("LGNet --without_norm is not built")
+        # --without_norm is INERT for LGNet, as in the reference: its _net_arg_scope (LGNet.py:108-130) never reads the flag
+        # (only the module-level modulated_conv_block at :60-92 does, and _build_network does not call it), so every
+        # slim.conv2d keeps its normaliser.  The flag is accepted and changes nothing.
         self._norm = self._get_normalization()
         return self._norm
 

@@ -112,6 +112,11 @@ class ParamStore(object):
             elif kind == "fc_w":        # slim.fully_connected default: Glorot uniform, [in, out], no regulariser
                 limit = (6.0 / (shape[0] + shape[1])) ** 0.5
                 t.copy_(((torch.rand(shape, generator=gen, dtype=torch.float64) * 2 - 1) * limit).to(torch.float32))
+            elif kind == "conv1d_w":    # slim.conv1d default: Glorot uniform on [k, in, out], no regulariser (slim_nets.py:69 ...)
+                limit = (6.0 / (shape[0] * shape[1] + shape[0] * shape[2])) ** 0.5
+                t.copy_(((torch.rand(shape, generator=gen, dtype=torch.float64) * 2 - 1) * limit).to(torch.float32))
+            elif kind == "fc_b_one":    # final_biases_initializer=tf.ones_initializer() of the vgg context models (GUNet.py:74)
+                t.fill_(1.0)
             elif kind == "fc_w_he":     # tf.keras.initializers.he_normal: truncated normal, var 2/fan_in (GUNet.py:59)
                 std = (2.0 / shape[0]) ** 0.5 / 0.87962566103423978
                 v = torch.empty(shape, dtype=torch.float64)

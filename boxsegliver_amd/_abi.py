@@ -92,6 +92,10 @@ _SIGNATURES = {
     "unetk_norm_se_bwd_add": (c_int, [POINTER(NormDesc), P, P, P, P, P, P, P, P]),
     "unetk_fc_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, P]),
     "unetk_fc_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "unetk_conv1d_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "unetk_conv1d_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "unetk_maxpool1d_fwd": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "unetk_maxpool1d_bwd": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "unetk_maxpool2_fwd": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, P]),
     "unetk_maxpool2_bwd": (c_int, [P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P]),
     "unetk_maxpool2_fwd_bf16": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, P]),

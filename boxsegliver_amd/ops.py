@@ -929,6 +929,64 @@ class FullyConnected(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+class Conv1d(torch.autograd.Function):
+    """y = relu(conv1d(x, w) + b): slim.conv1d(x, C, k) with slim's defaults (stride 1, SAME, bias, ReLU) -- the layers of
+    GUNet's 1-D VGG context models (NetworksV2/Backbone/slim_nets.py:60-144).  x [B, L, Cin], w TF [k, Cin, Cout]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu=True):
+        _require_cuda(x, w)
+        x = x.contiguous()
+        bsz, length, cin = x.shape
+        k, cin_w, cout = w.shape
+        assert cin_w == cin and w.is_contiguous() and k in (1, 3)
+        y = torch.empty((bsz, length, cout), dtype=torch.float32, device=x.device)
+        check(_abi.lib().unetk_conv1d_fwd(ptr(x), ptr(w), ptr(b), ptr(y), bsz, length, cin, cout, k, 1 if relu else 0,
+                                          stream_ptr()), "conv1d_fwd")
+        ctx.save_for_backward(x, w, y)
+        ctx.relu, ctx.has_b = bool(relu), b is not None
+        ctx.sinks = (grad_sink(w), grad_sink(b))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        bsz, length, cin = x.shape
+        k, _, cout = w.shape
+        sw, sb = _take(ctx.sinks[0]), _take(ctx.sinks[1])
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = sw if sw is not None else torch.empty_like(w)
+        db = (sb if sb is not None else torch.empty((cout,), dtype=torch.float32, device=x.device)) if ctx.has_b else None
+        ws = torch.empty_like(y)
+        check(_abi.lib().unetk_conv1d_bwd(ptr(x), ptr(w), ptr(y), ptr(dy), ptr(dx), ptr(dw), ptr(db), ptr(ws), bsz, length,
+                                          cin, cout, k, 1 if ctx.relu else 0, stream_ptr()), "conv1d_bwd")
+        return dx, _ret(dw, sw), (_ret(db, sb) if ctx.has_b else None), None
+
+
+class MaxPool1d(torch.autograd.Function):
+    """tf.layers.max_pooling1d(x, 2, 2, padding="same") on [B, L, C] (slim_nets.py:73 ...): Lo = ceil(L / 2)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_cuda(x)
+        x = x.contiguous()
+        bsz, length, c = x.shape
+        y = torch.empty((bsz, (length + 1) // 2, c), dtype=torch.float32, device=x.device)
+        check(_abi.lib().unetk_maxpool1d_fwd(ptr(x), ptr(y), bsz, length, c, stream_ptr()), "maxpool1d_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        bsz, length, c = x.shape
+        dx = torch.empty_like(x)
+        check(_abi.lib().unetk_maxpool1d_bwd(ptr(x), ptr(dy.contiguous()), ptr(dx), bsz, length, c, stream_ptr()),
+              "maxpool1d_bwd")
+        return dx
+
+
 class Conv3dNormRelu(torch.autograd.Function):
     """z = relu(norm(conv3d(x, w))) -- one slim.conv3d unit of UNet3D (UNet3D.py:108-121,153,165): kernel
     (1,3,3) or (3,3,3), stride 1 / (1,2,2) / (2,2,2), SAME, no bias, instance or batch norm, ReLU."""

@@ -247,6 +247,19 @@ int unetk_fc_fwd(const float* x, const float* w, const float* b, float* y, float
 int unetk_fc_bwd(const float* x, const float* w, const float* y, const float* mask, const float* dy, float* dx,
                  float* dw, float* db, float* dpre_ws, int B, int k, int n, int relu, void* stream);
 
+/* ---------------------------------------------------------------- GUNet's 1-D VGG context models (slim_nets.py:60-144)
+ * context_model "vgg16B" / "vgg16C" / "vgg16D" (GUNet.py:62-75; ext_config/GUNet_DE_VGG16{B,D}.yml): the context vector as
+ * [B][L][1] through slim.conv1d (kernel k = 3 or 1, stride 1, SAME, bias, ReLU; w = TF [k][Cin][Cout]) and
+ * tf.layers.max_pooling1d(2, 2, "same") (Lo = ceil(L / 2)); flattened [B][Lo * C] it feeds unetk_fc_*.
+ * Backward: dx (nullable) / dw / db from dy gated by y > 0 when relu; dpre_ws = B * L * Cout floats of scratch.  The pool
+ * backward routes to the first maximum of the window. */
+int unetk_conv1d_fwd(const float* x, const float* w, const float* b, float* y, int B, int L, int Cin, int Cout, int k,
+                     int relu, void* stream);
+int unetk_conv1d_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw, float* db,
+                     float* dpre_ws, int B, int L, int Cin, int Cout, int k, int relu, void* stream);
+int unetk_maxpool1d_fwd(const float* x, float* y, int B, int L, int C, void* stream);
+int unetk_maxpool1d_bwd(const float* x, const float* dy, float* dx, int B, int L, int C, void* stream);
+
 /* ---------------------------------------------------------------- slim.max_pool2d(x, [2,2])  UNet.py:81
  * VALID, stride 2.  x [N,H,W,C] with pixel stride x_stride; p dense [N,H/2,W/2,C].
  * Backward routes dp to the first maximum in window scan order (TF MaxPoolGrad); `add` (nullable, [N,H,W,C] with

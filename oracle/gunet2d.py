@@ -22,7 +22,7 @@ INPUT as well (`unit_masks`: {scope: [bs, H, W, C] of 0 / 1/keep_prob}).
 computed literally on the materialised 2C-channel tensor.
 --use_se (:192-201): gains = sigmoid(fc(relu(fc(concat(mean_hw(net), context slice))))), the context MLP then emits
 context_fc_channels[-1] values per modulated conv unit (:44-46).
-vgg context models and ct_conv are not restated.
+context_model vgg16B / C / D (:62-75; Backbone/slim_nets.py:60-144) restated in `context_params`; ct_conv is not.
 """
 from collections import OrderedDict
 
@@ -32,10 +32,34 @@ from . import losses, tf_ops
 from .unet2d import TRAINABLE_KINDS  # noqa: F401
 
 
+# Backbone/slim_nets.py:60-144 -- vgg16B / vgg16C / vgg16D on the 1-D context: per group (conv repeats with kernel 3, an
+# optional extra kernel-1 conv named conv{g}_3, then max_pooling1d(2, 2, "same")); channels first_layer_channel x
+# (1, 2, 4, 8, 8).  slim.repeat(net, r, conv_op, C, 3, scope="conv{g}") names the layers conv{g}/conv{g}_{1..r}.
+_VGG1D = {
+    "vgg16B": [(2, False), (2, False), (2, False), (2, False), (2, False)],      # slim_nets.py:60-86
+    "vgg16C": [(2, False), (2, False), (2, True), (2, True), (2, True)],         # :89-118
+    "vgg16D": [(2, False), (2, False), (3, False), (3, False), (3, False)],      # :121-146
+}
+
+
+def vgg1d_scopes(model, first_layer_channel):
+    """[(scope, kernel, cin, cout) ... | None for a pool] in graph order."""
+    out, cin = [], 1
+    for g, ((rep, extra), mult) in enumerate(zip(_VGG1D[model], (1, 2, 4, 8, 8)), start=1):
+        cout = first_layer_channel * mult
+        for j in range(rep):
+            out.append(("conv%d/conv%d_%d" % (g, g, j + 1), 3, cin, cout))
+            cin = cout
+        if extra:
+            out.append(("conv%d_3" % g, 1, cin, cout))
+        out.append(None)
+    return out
+
+
 def param_specs(in_channels, num_classes, guide_channel=1, init_channels=64, num_down_samples=4,
                 mod_layers=(1, 2, 3, 4), normalizer="instance_norm", norm_with_center=True, norm_with_scale=False,
                 name="GUNet", use_spatial=True, context_dims=None, after_affine=False, mid_cat_g=0, without_norm=False,
-                fix=False, se_length=0):
+                fix=False, se_length=0, context_model="fc", context_conv_init_channels=16):
     """context_dims = [context length, fc widths ..., n_modulator_param] enables the context branch.
     without_norm (GUNet.py:251-252,314-315): every conv unit has a bias and no normaliser."""
     specs = []
@@ -59,7 +83,23 @@ def param_specs(in_channels, num_classes, guide_channel=1, init_channels=64, num
             if specs[k][1] is None:
                 specs[k] = (specs[k][0], (c,), specs[k][2])
 
-    if context_dims:
+    if context_dims and context_model != "fc":
+        # GUNet.py:62-75: slim_nets.vgg(...) then mlp(..., num_base=5) -> fc6, fc7, ..; final layer zeros / ones initialised
+        length, feat_c = context_dims[0], 1
+        for lay in vgg1d_scopes(context_model, context_conv_init_channels):
+            if lay is None:
+                length = -(-length // 2)                           # "same" pooling: ceil
+                continue
+            scope, k, ci, co = lay
+            specs.append(("{}/context/{}/weights".format(name, scope), (k, ci, co), "conv1d_w"))
+            specs.append(("{}/context/{}/biases".format(name, scope), (co,), "fc_b"))
+            feat_c = co
+        dims = [length * feat_c] + list(context_dims[1:])
+        for i in range(1, len(dims)):
+            last = i == len(dims) - 1
+            specs.append(("{}/context/fc{}/weights".format(name, 5 + i), (dims[i - 1], dims[i]), "fc_w_zero" if last else "fc_w"))
+            specs.append(("{}/context/fc{}/biases".format(name, 5 + i), (dims[i],), "fc_b_one" if last else "fc_b"))
+    elif context_dims:
         for i in range(1, len(context_dims)):
             last = i == len(context_dims) - 1
             specs.append(("{}/context/fc{}/weights".format(name, i), (context_dims[i - 1], context_dims[i]),
@@ -124,7 +164,7 @@ class GUNet2DOracle(object):
                  mod_layers=(1, 2, 3, 4), normalizer="instance_norm", norm_with_center=True, norm_with_scale=False,
                  name="GUNet", img_grad=False, use_spatial=True, context_length=None, context_fc_channels=(256, 256),
                  after_affine=False, concat_guide=False, encoder_decay=0.999, mid_cat=False, without_norm=False,
-                 fix=False, use_se=False):
+                 fix=False, use_se=False, context_model="fc", context_conv_init_channels=16):
         """concat_guide + mod_layers=() + encoder_decay=.99 + name="UNetInter" is the reference's UNetInter
         (NetworksV2/UNetInter.py:76-141): the guide joins the input channels, encoder BN decay .99 (:98-113)."""
         self.name, self.num_classes = name, num_classes
@@ -150,7 +190,9 @@ class GUNet2DOracle(object):
         self.without_norm = without_norm
         self.specs = param_specs(in_channels, num_classes, guide_channel, init_channels, num_down_samples, mod_layers,
                                  normalizer, norm_with_center, norm_with_scale, name, use_spatial, self.context_dims,
-                                 after_affine, guide_channel if self.mid_cat else 0, without_norm, self.fix, self.se_length)
+                                 after_affine, guide_channel if self.mid_cat else 0, without_norm, self.fix, self.se_length,
+                                 context_model, context_conv_init_channels)
+        self.context_model, self.context_c0 = context_model, context_conv_init_channels
         self.kinds = {n: k for n, _, k in self.specs}
 
     def _unit(self, x, p, scope, is_training, new_stats, decay, sp=None, den=None, mask=None, se_feat=None):
@@ -183,8 +225,24 @@ class GUNet2DOracle(object):
         """slim_nets.mlp (slim_nets.py:43-56) as called from GUNet.py:51-60."""
         net = context
         dims = self.context_dims
+        base = 0
+        if self.context_model != "fc":
+            # slim_nets.vgg16{B,C,D} on tf.expand_dims(context, -1) (GUNet.py:62-75): conv1d SAME + bias + ReLU, "same" pools
+            t = context[:, None, :]                                                          # [B, C = 1, L] for torch
+            for lay in vgg1d_scopes(self.context_model, self.context_c0):
+                if lay is None:
+                    t = torch.nn.functional.max_pool1d(t, 2, 2, ceil_mode=True)
+                    continue
+                scope, k, _, _ = lay
+                w = p["{}/context/{}/weights".format(self.name, scope)]                      # TF [k, Cin, Cout]
+                t = torch.nn.functional.conv1d(t, w.permute(2, 1, 0), p["{}/context/{}/biases".format(self.name, scope)],
+                                               padding=(k - 1) // 2)
+                t = torch.relu(t)
+            net = t.permute(0, 2, 1).reshape(t.shape[0], -1)                                 # slim.flatten of [B, L, C]
+            base = 5
         for li in range(1, len(dims)):
-            net = net @ p["{}/context/fc{}/weights".format(self.name, li)] + p["{}/context/fc{}/biases".format(self.name, li)]
+            net = net @ p["{}/context/fc{}/weights".format(self.name, base + li)] + \
+                p["{}/context/fc{}/biases".format(self.name, base + li)]
             if li < len(dims) - 1:
                 net = torch.relu(net)
                 if drop_masks is not None:

@@ -77,6 +77,10 @@ def init_params(specs, seed=1234, dtype=torch.float32):
             params[name] = tf_ops.xavier_uniform_(shape, rf * shape[2], rf * shape[3], gen, dtype)
         elif kind == "fc_w":          # slim.fully_connected default (slim_nets.py:45): Glorot uniform on [in, out]
             params[name] = tf_ops.xavier_uniform_(shape, shape[0], shape[1], gen, dtype)
+        elif kind == "conv1d_w":      # slim.conv1d default initialiser: Glorot uniform, fans k*Cin / k*Cout
+            params[name] = tf_ops.xavier_uniform_(shape, shape[0] * shape[1], shape[0] * shape[2], gen, dtype)
+        elif kind == "fc_b_one":      # final_biases_initializer=tf.ones_initializer() (GUNet.py:74)
+            params[name] = torch.ones(shape, dtype=dtype)
         elif kind == "fc_w_he":       # tf.keras.initializers.he_normal (GUNet.py:59): truncated normal, var 2/fan_in
             std = (2.0 / shape[0]) ** 0.5 / 0.87962566103423978
             v = torch.empty(shape, dtype=torch.float64)
@@ -89,7 +93,7 @@ def init_params(specs, seed=1234, dtype=torch.float32):
     return params
 
 
-TRAINABLE_KINDS = ("conv_w", "deconv_w", "bias", "gamma", "beta", "fc_w", "fc_w_he", "fc_b")
+TRAINABLE_KINDS = ("conv_w", "deconv_w", "bias", "gamma", "beta", "fc_w", "fc_w_he", "fc_b", "conv1d_w", "fc_w_zero", "fc_b_one")
 
 
 class UNet2DOracle(object):

@@ -809,3 +809,106 @@ def test_gunet_use_se_matches_oracle(normalizer):
     assert model.params["GUNet/Encode/down_conv2/mod_conv1/fully_connected/weights"].shape == (128 + 16, (128 + 16) // 4)
     assert model.params["GUNet/context/fc3/weights"].shape == (16, 16 * 4 * 2)
     _whole_net_check(model, inputs, net, params, tensors, args, yml, {"context": tensors[3]})
+
+
+# ----------------------------------------------------------------------------- 1-D VGG context models (GUNet_DE_VGG16{B,D}.yml)
+@pytest.mark.parametrize("k,length,cin,cout,relu", [(3, 37, 1, 2, True), (3, 16, 8, 16, True), (1, 9, 16, 16, True),
+                                                    (3, 5, 4, 6, False)])
+def test_conv1d_and_same_maxpool1d_against_float64_autograd(k, length, cin, cout, relu):
+    """slim.conv1d (SAME, bias, ReLU) and tf.layers.max_pooling1d(2, 2, "same") of slim_nets.vgg16* (slim_nets.py:60-144)."""
+    from boxsegliver_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    b = 3
+    x = torch.randn(b, length, cin, generator=gen)
+    w = torch.randn(k, cin, cout, generator=gen) / (k * cin) ** 0.5
+    bias = 0.3 * torch.randn(cout, generator=gen)
+    xd, wd, bd = (t.cuda().requires_grad_(True) for t in (x, w, bias))
+    y = ops.Conv1d.apply(xd, wd, bd, relu)
+    z = ops.MaxPool1d.apply(y)
+    assert z.shape == (b, (length + 1) // 2, cout)
+    dz = torch.randn(z.shape, generator=gen)
+    z.backward(dz.cuda())
+    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, bias))
+    t = torch.nn.functional.conv1d(x64.permute(0, 2, 1), w64.permute(2, 1, 0), b64, padding=(k - 1) // 2)
+    t = torch.relu(t) if relu else t
+    ref = torch.nn.functional.max_pool1d(t, 2, 2, ceil_mode=True).permute(0, 2, 1)
+    ref.backward(dz.double())
+    assert rel(z.detach().cpu().numpy(), ref.detach().numpy()) < 1e-6
+    for got, want in ((xd.grad, x64.grad), (wd.grad, w64.grad), (bd.grad, b64.grad)):
+        assert rel(got.cpu().numpy(), want.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("cmodel,normalizer", [("vgg16B", "instance_norm"), ("vgg16D", "batch_norm"), ("vgg16C", "instance_norm")])
+def test_gunet_vgg_context_models_match_oracle(cmodel, normalizer):
+    """context_model vgg16B / vgg16D (the shipped ext_config/GUNet_DE_VGG16{B,D}.yml) and vgg16C (GUNet.py:62-75): variable
+    names and shapes, the zeros / ones initialisation of the last layer (every gain = 1), and -- with random variables --
+    loss, logits, the gains and all context-branch gradients against the float64 oracle."""
+    import yaml
+    from pathlib import Path
+    from boxsegliver_amd import ops
+    from boxsegliver_amd.NetworksV2.GUNet import GUNet
+    from boxsegliver_amd.data.synthetic import make_batch, make_guide
+    cfg_name = "GUNet_DE_VGG16B.yml" if cmodel != "vgg16D" else "GUNet_DE_VGG16D.yml"
+    cfg = yaml.safe_load((Path(ops.__file__).parent / "NetworksV2" / "ext_config" / cfg_name).read_text())
+    assert cfg["context_conv_init_channels"] == 2 and cfg["context_fc_channels"] == [200, 200]
+    cfg["context_model"] = cmodel
+    yml = dict(cfg, build_metrics=True, build_summaries=False)
+    ctx_len = 45                                                           # odd lengths exercise the "same" pools
+    args = make_args(normalizer=normalizer, use_context=True, use_spatial=True, side_dropout=0.0)
+    images, labels, _ = make_batch(2, 32, 32, 3, 3, 1234)
+    guide = make_guide(labels, args.guide_channel, 1234)
+    gen = torch.Generator().manual_seed(21)
+    context = torch.rand(2, ctx_len, generator=gen)
+    model = GUNet(args)
+    inputs = {"images": torch.from_numpy(images).cuda(), "labels": torch.from_numpy(labels).cuda(),
+              "sp_guide": torch.from_numpy(guide).cuda(), "context": context.cuda()}
+    model(inputs, "eval", **yml)
+    net = gunet2d.GUNet2DOracle(3, 3, guide_channel=1, normalizer=normalizer, context_length=ctx_len,
+                                context_fc_channels=(200, 200), context_model=cmodel, context_conv_init_channels=2)
+    assert [(n, tuple(s), k) for n, s, k in net.specs] == [(n, tuple(s), k) for n, s, k in model.params.specs]
+    names = list(model.params.state_dict())
+    assert "GUNet/context/conv1/conv1_1/weights" in names and "GUNet/context/fc8/biases" in names and "GUNet/context/fc1/weights" not in names
+    assert ("GUNet/context/conv3_3/weights" in names) == (cmodel == "vgg16C")
+    assert ("GUNet/context/conv5/conv5_3/weights" in names) == (cmodel == "vgg16D")
+    assert model.params["GUNet/context/conv1/conv1_1/weights"].shape == (3, 1, 2)
+    assert model.params["GUNet/context/fc6/weights"].shape == (2 * 16, 200)             # ceil(45 / 32) = 2 positions x 16 channels
+    assert float(model.params["GUNet/context/fc8/weights"].abs().sum()) == 0.0 and \
+        float((model.params["GUNet/context/fc8/biases"] - 1).abs().sum()) == 0.0          # GUNet.py:73-74
+    assert torch.equal(model.layers["context_params"], torch.ones_like(model.layers["context_params"]))
+    assert model.params.where["GUNet/context/conv2/conv2_1/weights"][0] == "noreg"       # slim.conv1d: no regulariser in scope
+    params = {}
+    for name, t in model.params.state_dict().items():
+        kind = net.kinds[name]
+        if kind == "gamma":
+            params[name] = 0.5 + torch.rand(t.shape, generator=gen)
+        elif kind in ("beta", "bias", "fc_b"):
+            params[name] = 0.2 * torch.randn(t.shape, generator=gen)
+        elif "spatial" in name:
+            params[name] = 0.5 * torch.randn(t.shape, generator=gen)
+        elif kind == "fc_w_zero":
+            params[name] = torch.randn(t.shape, generator=gen) * (2.0 / t.shape[0]) ** 0.5
+        elif kind == "conv1d_w":
+            params[name] = torch.randn(t.shape, generator=gen) * (2.0 / (t.shape[0] * t.shape[1])) ** 0.5
+        else:
+            params[name] = t.clone()
+    model.params.load_state(params)
+    model.params.zero_grad()
+    loss = model(inputs, "train", **yml)
+    loss.backward()
+    torch.cuda.synchronize()
+    kw = dict(kwargs_of(args), context=context.double(), drop_masks=None)
+    p64 = {k: v.double() for k, v in params.items()}
+    total, _, logits, grads64, _ = net.loss_and_grads(p64, torch.from_numpy(images).double(), torch.from_numpy(guide).double(),
+                                                      torch.from_numpy(labels).long(), **kw)
+    assert abs(loss.item() - total.item()) < 1e-4 * max(1.0, abs(total.item()))
+    assert np.abs(model.layers["logits"].cpu().numpy() - logits.numpy()).max() < 1e-3
+    den_ref = net.context_params(p64, context.double()).numpy()
+    assert rel(model.layers["context_params"].detach().cpu().numpy(), den_ref) < 1e-5
+    for name in model.params.trainable_names():
+        if "/context/" not in name:
+            continue
+        g = model.params[name].grad.cpu().numpy()
+        ref = grads64[name].numpy()
+        assert np.abs(ref).max() > 0, name
+        # the density gradient the trunk receives carries the encoder's ReLU flips: compare like the other context tests
+        assert rel(g, ref) < 3e-2, (name, rel(g, ref))

@@ -138,3 +138,27 @@ def test_lgnet_matches_oracle_and_trains(cfg, normalizer, loss_type):
     assert model(inputs, "train", **yml).item() < first
     with pytest.raises(ValueError):
         zoo["LGNet"](args)(inputs, "eval", **dict(yml, mod_layers=[[0, 1], [1, 0]]))
+
+
+def test_lgnet_without_norm_flag_is_inert_as_in_the_reference():
+    """The reference's LGNet._net_arg_scope (LGNet.py:108-130) never reads --without_norm (only the unused module-level
+    modulated_conv_block at :60-92 does): the flag must change neither the variables nor the result."""
+    from boxsegliver_amd import ops
+    from boxsegliver_amd.core import models
+    from boxsegliver_amd.data.synthetic import make_batch, make_guide
+    yml = yaml.safe_load((Path(ops.__file__).parent / "NetworksV2" / "LGNet.yml").read_text())
+    yml.update(build_metrics=True, build_summaries=False)
+    zoo = {cls.__name__: cls for cls in models.MODEL_ZOO}
+    images, labels, _ = make_batch(2, 32, 32, 3, 3, 1234)
+    guide = make_guide(labels, 1, 1234)
+    inputs = {"images": torch.from_numpy(images).cuda(), "labels": torch.from_numpy(labels).cuda(),
+              "sp_guide": torch.from_numpy(guide).cuda()}
+    out = []
+    for flag in (False, True):
+        args = make_args(normalizer="instance_norm", loss_type="xentropy", use_spatial=True, guide_channel=1)
+        args.without_norm = flag
+        model = zoo["LGNet"](args)
+        model(inputs, "eval", **yml)
+        out.append((list(model.params.state_dict()), model.layers["logits"].clone()))
+    assert out[0][0] == out[1][0] and any("InstanceNorm" in n for n in out[1][0])
+    assert torch.equal(out[0][1], out[1][1])
