@@ -1,6 +1,6 @@
 """Every model configuration the package ships resolves through the reference's lookup rule (core/models.py:92-118:
 <model>.yml, then NetworksV2/, then NetworksV2/ext_config/) and names a model of the registry; the GUNet variants only
-use options the host mirror implements (context_model "fc")."""
+use options the host mirror implements (context_model "fc" or the 1-D VGG trunks of GUNet_DE_VGG16{B,D}.yml)."""
 import argparse
 from pathlib import Path
 
@@ -33,7 +33,9 @@ def test_shipped_config_resolves(cfg):
     if model == "LGNet":
         assert len(kw["mod_layers"]) == 2 and all(br == sorted(br) for br in kw["mod_layers"])
     if model in ("GUNet",):
-        assert kw["context_model"] == "fc" and kw["mod_layers"] == [1, 2, 3, 4] and len(kw["context_fc_channels"]) == 2
+        want = {"GUNet_DE_VGG16B.yml": "vgg16B", "GUNet_DE_VGG16D.yml": "vgg16D"}.get(cfg, "fc")
+        assert kw["context_model"] == want and kw["mod_layers"] == [1, 2, 3, 4] and len(kw["context_fc_channels"]) == 2
+        assert (kw.get("context_conv_init_channels") == 2) == (want != "fc")
     if model == "UNet3D":
         assert kw["num_pool_layers"] in (4, 5) and kw["init_channels"] == 30 and kw["max_channels"] == 320
 
