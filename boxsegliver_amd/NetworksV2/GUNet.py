@@ -26,7 +26,9 @@ ops.Conv3x3NormRelu forms mean_hw(net) from the conv's per-sample statistics and
 context_model "vgg16B" / "vgg16C" / "vgg16D" (GUNet.py:62-75, slim_nets.py:60-144; ext_config/GUNet_DE_VGG16{B,D}.yml): the
 context vector as [bs, L, 1] through 1-D conv + ReLU stacks and "same" max-pools (ops.Conv1d / ops.MaxPool1d, csrc/conv1d.hip),
 flattened into mlp(num_base=5) = fc6 ..; the last layer starts at weights 0 / biases 1.
-Not built (raise NotImplementedError): the conv context subnet (`ct_conv`); --fix or --use_se
+`ct_conv` (`_context_subnets_conv`, GUNet.py:83-116; the nf2 pipeline's [bs, 32, 32, 3] context): three conv units of the model's
+own arg_scope, spatial mean (ops.SpatialMean), fully_connected(200) and fully_connected(n_mod), he_normal.
+Not built (raise NotImplementedError): ct_conv with --use_se; --fix or --use_se
 combined with each other or with --dropout / after_affine; after_affine together with --without_norm.
 --without_norm (GUNet.py:251-252,314-315): every unit = conv + bias (* density gain + guide term) + ReLU, the norm stage
 of the fused kernels reduced to the per-channel shift (unetk_norm_desc.affine_only).
@@ -93,7 +95,19 @@ def param_specs(in_channels, num_classes, guide_channel, init_channels, num_down
             specs.append(("{}/{}/moving_mean".format(scope, ns), (c,), "moving_mean"))
             specs.append(("{}/{}/moving_variance".format(scope, ns), (c,), "moving_var"))
 
-    if context_dims and context_model in VGG_CONTEXT_MODELS:
+    if context_dims and context_model == "ct_conv":
+        # `_context_subnets_conv` (GUNet.py:83-116): three slim.conv2d(3x3) of the model's arg_scope (regulariser, normaliser,
+        # ReLU) on the [bs, 32, 32, 3] context, mean over H x W, fully_connected(200) + fully_connected(n_mod), he_normal
+        cin = context_dims[0]
+        for scope, cout in (("Conv", 64), ("Conv_1", 64), ("Conv_2", 128)):
+            specs.append(("{}/context/{}/weights".format(name, scope), (3, 3, cin, cout), "conv_w"))
+            norm_vars("{}/context/{}".format(name, scope), cout, True, True)
+            cin = cout
+        specs.append((name + "/context/fully_connected/weights", (128, 200), "fc_w_he"))
+        specs.append((name + "/context/fully_connected/biases", (200,), "fc_b"))
+        specs.append((name + "/context/fully_connected_1/weights", (200, context_dims[-1]), "fc_w_he"))
+        specs.append((name + "/context/fully_connected_1/biases", (context_dims[-1],), "fc_b"))
+    elif context_dims and context_model in VGG_CONTEXT_MODELS:
         # GUNet.py:62-75: 1-D VGG trunk (slim.conv1d: bias, no regulariser) + mlp(num_base=5): fc6.. ; the last layer starts at
         # weights 0 / biases 1 (every gain = 1)
         layers, feat = vgg_context_layout(context_model, context_dims[0], context_conv_init_channels)
@@ -187,8 +201,7 @@ class GUNet(base.BaseNet):
 
     def _net_arg_scope(self, *args, **kwargs):
         """GUNet.py:240-257: as UNet (decoder norm = _get_normalization defaults), pools with SAME."""
-        if hasattr(self.args, "ct_conv"):
-            raise NotImplementedError("GUNet ct_conv context variant is not built")
+        self.ct_conv = hasattr(self.args, "ct_conv")                 # GUNet.py:236: the flag's presence, not its value
         fix = bool(getattr(self.args, "fix", False)) and self.use_spatial_guide and not self._concat_guide
         if (fix and self.use_context_guide) or (self.use_se and self.use_context_guide and self.dropout):
             raise NotImplementedError("GUNet --fix with --use_context, and --use_se with --dropout, are not built")
@@ -289,15 +302,22 @@ class GUNet(base.BaseNet):
         context_dims = None
         if self.use_context_guide:
             context_model = kwargs.get("context_model", "fc")
+            if self.ct_conv:
+                context_model = "ct_conv"
             if context_model == "resnet":
                 raise NotImplementedError                                                   # GUNet.py:76-77, literally
-            if context_model != "fc" and context_model not in VGG_CONTEXT_MODELS:
+            if context_model not in ("fc", "ct_conv") and context_model not in VGG_CONTEXT_MODELS:
                 raise ValueError("Not supported context model")                             # GUNet.py:78-79
             context = self._inputs["context"]
-            if context.dim() != 2 or context.shape[0] != n or not context.is_cuda:
+            if self.ct_conv:
+                if context.dim() != 4 or context.shape[0] != n or not context.is_cuda:      # GUNet.py:279: [bs, 32, 32, 3]
+                    raise ValueError("ct_conv: context must be a [bs, h, w, c] device tensor, got {}".format(tuple(context.shape)))
+                if self.use_se:
+                    raise NotImplementedError("GUNet ct_conv with --use_se is not built")
+            elif context.dim() != 2 or context.shape[0] != n or not context.is_cuda:
                 raise ValueError("context must be a [bs, L] device tensor, got {}".format(tuple(context.shape)))
-            fc_ch = list(kwargs.get("context_fc_channels", [256]))
-            context_dims = [int(context.shape[1])] + fc_ch + \
+            fc_ch = [] if self.ct_conv else list(kwargs.get("context_fc_channels", [256]))
+            context_dims = [int(context.shape[-1])] + fc_ch + \
                 [n_modulator_params_se(fc_ch[-1], nds, mod_layers) if self.use_se else
                  n_modulator_params(base_channels, nds, mod_layers)]
         if self.params is None:
@@ -312,7 +332,7 @@ class GUNet(base.BaseNet):
                                 fix=bool(getattr(self.args, "fix", False)) and g_ch > 0,
                                 se_length=(list(kwargs.get("context_fc_channels", [256]))[-1]
                                            if (self.use_se and self.use_context_guide) else 0),
-                                context_model=kwargs.get("context_model", "fc"),
+                                context_model="ct_conv" if self.ct_conv else kwargs.get("context_model", "fc"),
                                 context_conv_init_channels=int(kwargs.get("context_conv_init_channels", 16)))
             if mid_g:
                 # Encode2's first conv sees 64 + g channels: padded with zero filter rows to the filter-gradient tile (32)
@@ -347,8 +367,19 @@ class GUNet(base.BaseNet):
                 keep = 1.0 - self.side_dropout if (self.side_dropout and training) else None
                 self._dropout_calls = getattr(self, "_dropout_calls", 0) + 1
                 fc_base, n_fc = 0, len(context_dims) - 1
-                cmodel = kwargs.get("context_model", "fc")
-                if cmodel in VGG_CONTEXT_MODELS:
+                cmodel = "ct_conv" if self.ct_conv else kwargs.get("context_model", "fc")
+                if cmodel == "ct_conv":
+                    # `_context_subnets_conv` (GUNet.py:83-116): conv units of the model's own arg_scope, spatial mean, two FCs
+                    t = den_all
+                    for cs in ("Conv", "Conv_1", "Conv_2"):
+                        t = self._unit(t, "{}/context/{}".format(nm, cs), self._spec())
+                    t = ops.SpatialMean.apply(t)
+                    t = ops.FullyConnected.apply(t, p[nm + "/context/fully_connected/weights"],
+                                                 p[nm + "/context/fully_connected/biases"], 1, None, 0)
+                    den_all = ops.FullyConnected.apply(t, p[nm + "/context/fully_connected_1/weights"],
+                                                       p[nm + "/context/fully_connected_1/biases"], 0, None, 0)
+                    n_fc = 0
+                elif cmodel in VGG_CONTEXT_MODELS:
                     # slim_nets.vgg (slim_nets.py:60-144) on tf.expand_dims(context, -1): conv1d + ReLU stacks, "same" pools,
                     # flatten; then mlp(num_base=5) = fc6 .. (GUNet.py:62-75)
                     layers, _ = vgg_context_layout(cmodel, context_dims[0], int(kwargs.get("context_conv_init_channels", 16)))

@@ -100,6 +100,8 @@ _SIGNATURES = {
     "unetk_maxpool2_bwd": (c_int, [P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P]),
     "unetk_maxpool2_fwd_bf16": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, P]),
     "unetk_maxpool2_bwd_bf16": (c_int, [P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P]),
+    "unetk_spatial_mean_fwd": (c_int, [P, P, c_int, c_int64, c_int, P]),
+    "unetk_spatial_mean_bwd": (c_int, [P, P, c_int, c_int64, c_int, P]),
     "unetk_guide_moments": (c_int, [P, c_int, c_int64, c_int, c_int, P, P]),
     "unetk_avgpool2_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "unetk_image_gradients": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

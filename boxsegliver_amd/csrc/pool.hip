@@ -274,6 +274,46 @@ extern "C" int unetk_avgpool2_fwd(const float* x, float* p, int N, int H, int W,
   return UNETK_OK;
 }
 
+// tf.reduce_mean(x, axis=(1, 2)) of the conv context subnet (GUNet.py:108): y[n][c] = mean over the sample's HW pixels.
+// Latency-sized (32 x 32 x 128 per sample): block = (sample, 64 channels) x 4 pixel lanes, fixed-order sums.
+__global__ __launch_bounds__(256) void spatial_mean_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t HW,
+                                                               int C) {
+  __shared__ float red[4][64];
+  const int cb = blockIdx.x, n = blockIdx.y;
+  const int c = cb * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C)
+    for (int64_t p = pl; p < HW; p += 4) s += x[((int64_t)n * HW + p) * C + c];
+  red[pl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (pl == 0 && c < C)
+    y[(int64_t)n * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)HW;
+}
+
+__global__ void spatial_mean_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int64_t HW, int C, int64_t total) {
+  const float inv = 1.0f / (float)HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t n = i / C / HW;
+    dx[i] = dy[n * C + c] * inv;
+  }
+}
+
+extern "C" int unetk_spatial_mean_fwd(const float* x, float* y, int N, int64_t HW, int C, void* stream) {
+  UNETK_REQUIRE(x && y && N > 0 && N <= 65535 && HW > 0 && C > 0);
+  hipLaunchKernelGGL(spatial_mean_fwd_kernel, dim3((C + 63) / 64, N), dim3(256), 0, (hipStream_t)stream, x, y, HW, C);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+extern "C" int unetk_spatial_mean_bwd(const float* dy, float* dx, int N, int64_t HW, int C, void* stream) {
+  UNETK_REQUIRE(dy && dx && N > 0 && HW > 0 && C > 0);
+  const int64_t total = (int64_t)N * HW * C;
+  hipLaunchKernelGGL(spatial_mean_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, HW, C, total);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
 extern "C" int unetk_guide_moments(const float* guide, int N, int64_t HW, int G, int per_sample, float* out, void* stream) {
   UNETK_REQUIRE(guide && out && N > 0 && HW > 0 && G > 0 && G <= 4);
   const int groups = per_sample ? N : 1;

@@ -987,6 +987,29 @@ class MaxPool1d(torch.autograd.Function):
         return dx
 
 
+class SpatialMean(torch.autograd.Function):
+    """tf.reduce_mean(x, axis=(1, 2)) on NHWC (GUNet.py:108, the conv context subnet)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_cuda(x)
+        x = x.contiguous()
+        n, c = x.shape[0], x.shape[-1]
+        hw = x.numel() // (n * c)
+        y = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        check(_abi.lib().unetk_spatial_mean_fwd(ptr(x), ptr(y), n, hw, c, stream_ptr()), "spatial_mean_fwd")
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c = ctx.shape[0], ctx.shape[-1]
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=dy.device)
+        check(_abi.lib().unetk_spatial_mean_bwd(ptr(dy.contiguous()), ptr(dx), n, dx.numel() // (n * c), c, stream_ptr()),
+              "spatial_mean_bwd")
+        return dx
+
+
 class Conv3dNormRelu(torch.autograd.Function):
     """z = relu(norm(conv3d(x, w))) -- one slim.conv3d unit of UNet3D (UNet3D.py:108-121,153,165): kernel
     (1,3,3) or (3,3,3), stride 1 / (1,2,2) / (2,2,2), SAME, no bias, instance or batch norm, ReLU."""

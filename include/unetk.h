@@ -260,6 +260,11 @@ int unetk_conv1d_bwd(const float* x, const float* w, const float* y, const float
 int unetk_maxpool1d_fwd(const float* x, float* y, int B, int L, int C, void* stream);
 int unetk_maxpool1d_bwd(const float* x, const float* dy, float* dx, int B, int L, int C, void* stream);
 
+/* tf.reduce_mean(x, axis=(1, 2)) of GUNet's conv context subnet (`_context_subnets_conv`, GUNet.py:83-116): x [N][HW][C] ->
+ * y [N][C]; backward dx = dy / HW broadcast over the pixels. */
+int unetk_spatial_mean_fwd(const float* x, float* y, int N, int64_t HW, int C, void* stream);
+int unetk_spatial_mean_bwd(const float* dy, float* dx, int N, int64_t HW, int C, void* stream);
+
 /* ---------------------------------------------------------------- slim.max_pool2d(x, [2,2])  UNet.py:81
  * VALID, stride 2.  x [N,H,W,C] with pixel stride x_stride; p dense [N,H/2,W/2,C].
  * Backward routes dp to the first maximum in window scan order (TF MaxPoolGrad); `add` (nullable, [N,H,W,C] with

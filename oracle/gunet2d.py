@@ -83,7 +83,21 @@ def param_specs(in_channels, num_classes, guide_channel=1, init_channels=64, num
             if specs[k][1] is None:
                 specs[k] = (specs[k][0], (c,), specs[k][2])
 
-    if context_dims and context_model != "fc":
+    if context_dims and context_model == "ct_conv":
+        # _context_subnets_conv (GUNet.py:83-116): slim.conv2d x 3 under the model's arg_scope (default scopes Conv, Conv_1,
+        # Conv_2), reduce_mean over (1, 2), fully_connected(200), fully_connected(n_mod) -- both he_normal
+        cin = context_dims[0]
+        for scope, cout in (("Conv", 64), ("Conv_1", 64), ("Conv_2", 128)):
+            start = len(specs)
+            specs.append(("{}/context/{}/weights".format(name, scope), (3, 3, cin, cout), "conv_w"))
+            norm_vars("{}/context/{}".format(name, scope), True, True)
+            fix_shapes(cout, start)
+            cin = cout
+        specs.append((name + "/context/fully_connected/weights", (128, 200), "fc_w_he"))
+        specs.append((name + "/context/fully_connected/biases", (200,), "fc_b"))
+        specs.append((name + "/context/fully_connected_1/weights", (200, context_dims[-1]), "fc_w_he"))
+        specs.append((name + "/context/fully_connected_1/biases", (context_dims[-1],), "fc_b"))
+    elif context_dims and context_model != "fc":
         # GUNet.py:62-75: slim_nets.vgg(...) then mlp(..., num_base=5) -> fc6, fc7, ..; final layer zeros / ones initialised
         length, feat_c = context_dims[0], 1
         for lay in vgg1d_scopes(context_model, context_conv_init_channels):
@@ -183,6 +197,8 @@ class GUNet2DOracle(object):
             else:
                 n_mod = init_channels * sum(2 ** i for i in range(num_down_samples + 1) if i in mod_layers) * 2
             self.context_dims = [context_length] + list(context_fc_channels) + [n_mod]
+            if context_model == "ct_conv":                             # context_length = the context image's channels
+                self.context_dims = [context_length, n_mod]
         self.img_grad = img_grad                                       # GUNet.py:335-338
         self.init_channels, self.nds = init_channels, num_down_samples
         self.mod_layers = tuple(mod_layers)
@@ -226,6 +242,8 @@ class GUNet2DOracle(object):
         net = context
         dims = self.context_dims
         base = 0
+        if self.context_model == "ct_conv":
+            raise RuntimeError("ct_conv runs inside forward() (its convs carry norm statistics)")
         if self.context_model != "fc":
             # slim_nets.vgg16{B,C,D} on tf.expand_dims(context, -1) (GUNet.py:62-75): conv1d SAME + bias + ReLU, "same" pools
             t = context[:, None, :]                                                          # [B, C = 1, L] for torch
@@ -253,7 +271,15 @@ class GUNet2DOracle(object):
         n = self.name
         new_stats = OrderedDict()
         den_all, den_off = None, 0
-        if self.context_dims:
+        if self.context_dims and self.context_model == "ct_conv":
+            t = context                                                # GUNet.py:95-111
+            for cs in ("Conv", "Conv_1", "Conv_2"):
+                t = self._unit(t, p, "{}/context/{}".format(n, cs), is_training, new_stats, 0.999)
+            t = t.mean(dim=(1, 2))
+            t = torch.relu(t @ p[n + "/context/fully_connected/weights"] + p[n + "/context/fully_connected/biases"])
+            den_all = t @ p[n + "/context/fully_connected_1/weights"] + p[n + "/context/fully_connected_1/biases"]
+            self.last_context_params = den_all
+        elif self.context_dims:
             den_all = self.context_params(p, context, drop_masks)
         # spatial subnets (GUNet.py:136-159)
         sp_params = {}

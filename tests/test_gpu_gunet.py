@@ -912,3 +912,75 @@ def test_gunet_vgg_context_models_match_oracle(cmodel, normalizer):
         assert np.abs(ref).max() > 0, name
         # the density gradient the trunk receives carries the encoder's ReLU flips: compare like the other context tests
         assert rel(g, ref) < 3e-2, (name, rel(g, ref))
+
+
+# ----------------------------------------------------------------------------- ct_conv (`_context_subnets_conv`, GUNet.py:83-116)
+@pytest.mark.parametrize("normalizer", ["instance_norm", "batch_norm"])
+def test_gunet_conv_context_subnet_matches_oracle(normalizer):
+    """args.ct_conv present (the nf2 pipeline, input_pipeline_iin.py:95): the context is a [bs, 32, 32, 3] image that goes
+    through three conv units of the model's arg_scope, a spatial mean and two he_normal fully-connected layers."""
+    from boxsegliver_amd import ops
+    from boxsegliver_amd.NetworksV2.GUNet import GUNet
+    from boxsegliver_amd.data.synthetic import make_batch, make_guide
+    args = make_args(normalizer=normalizer, use_context=True, use_spatial=True, side_dropout=0.0)
+    args.ct_conv = 1
+    images, labels, _ = make_batch(2, 32, 32, 3, 3, 1234)
+    guide = make_guide(labels, args.guide_channel, 1234)
+    gen = torch.Generator().manual_seed(33)
+    context = torch.rand(2, 32, 32, 3, generator=gen)
+    # spatial mean at op level first
+    xm = torch.randn(3, 5, 7, 130, generator=gen)
+    xd = xm.cuda().requires_grad_(True)
+    ym = ops.SpatialMean.apply(xd)
+    gm = torch.randn(3, 130, generator=gen)
+    ym.backward(gm.cuda())
+    assert rel(ym.detach().cpu().numpy(), xm.double().mean(dim=(1, 2)).numpy()) < 1e-6
+    assert rel(xd.grad.cpu().numpy(), (gm.double()[:, None, None, :] / 35).expand(3, 5, 7, 130).numpy()) < 1e-6
+    model = GUNet(args)
+    inputs = {"images": torch.from_numpy(images).cuda(), "labels": torch.from_numpy(labels).cuda(),
+              "sp_guide": torch.from_numpy(guide).cuda(), "context": context.cuda()}
+    model(inputs, "eval", **YML)
+    net = gunet2d.GUNet2DOracle(3, 3, guide_channel=1, normalizer=normalizer, context_length=3, context_model="ct_conv")
+    assert [(n, tuple(s), k) for n, s, k in net.specs] == [(n, tuple(s), k) for n, s, k in model.params.specs]
+    names = list(model.params.state_dict())
+    assert "GUNet/context/Conv_2/weights" in names and "GUNet/context/fully_connected_1/biases" in names
+    assert model.params["GUNet/context/fully_connected_1/weights"].shape == (200, 64 * (2 + 4 + 8 + 16) * 2)
+    assert model.params.where["GUNet/context/Conv_1/weights"][0] == "reg"            # slim.conv2d of the model's arg_scope
+    params = {}
+    for name, t in model.params.state_dict().items():
+        kind = net.kinds[name]
+        if kind == "gamma":
+            params[name] = 0.5 + torch.rand(t.shape, generator=gen)
+        elif kind in ("beta", "bias", "fc_b"):
+            params[name] = 0.2 * torch.randn(t.shape, generator=gen)
+        elif "spatial" in name:
+            params[name] = 0.5 * torch.randn(t.shape, generator=gen)
+        else:
+            params[name] = t.clone()
+    params["GUNet/context/fully_connected_1/biases"] = params["GUNet/context/fully_connected_1/biases"] + 1.0
+    model.params.load_state(params)
+    model.params.zero_grad()
+    loss = model(inputs, "train", **YML)
+    loss.backward()
+    torch.cuda.synchronize()
+    kw = dict(kwargs_of(args), context=context.double(), drop_masks=None)
+    p64 = {k: v.double() for k, v in params.items()}
+    total, _, logits, grads64, new_stats = net.loss_and_grads(p64, torch.from_numpy(images).double(),
+                                                              torch.from_numpy(guide).double(),
+                                                              torch.from_numpy(labels).long(), **kw)
+    assert abs(loss.item() - total.item()) < 1e-4 * max(1.0, abs(total.item()))
+    assert np.abs(model.layers["logits"].cpu().numpy() - logits.numpy()).max() < 1e-3
+    assert rel(model.layers["context_params"].detach().cpu().numpy(), net.last_context_params.detach().numpy()) < 1e-5
+    for name in model.params.trainable_names():
+        if "/context/" not in name:
+            continue
+        g = model.params[name].grad.cpu().numpy().astype(np.float64)
+        ref = grads64[name].numpy()
+        # (backward() leaves the DATA-loss gradient; the regulariser's wd * w is added inside the optimiser kernel and is
+        #  1e-5 * w here, far under the bar)
+        assert np.abs(ref).max() > 0, name
+        l2 = np.linalg.norm(g - ref) / np.linalg.norm(ref)
+        assert l2 < 5e-2, (name, l2)
+    for name, ref in new_stats.items():
+        if "/context/" in name:
+            np.testing.assert_allclose(model.params[name].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-6)

@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_gunet.py tests/test_gpu_lgnet.py tests/test_gpu_fused_nbr.py -x -q > gpurun_out/r2s2_t6.log 2>&1
+timeout -k 10 900 python -m pytest tests/test_gpu_gunet.py -x -q -k "conv_context or vgg or context" > gpurun_out/r2s2_t6.log 2>&1
 tail -25 gpurun_out/r2s2_t6.log
