@@ -27,9 +27,17 @@ constexpr int TW = 16;   // spatial tile width
 // reads tap (kh, kw) at halo (2 r + kh, 2 c + kw): same inner loop, A reads 2-way bank-conflicted (LDS has the slack).
 // DIL = 2 (with S = 1): rate-2 atrous conv (slim.conv2d(x, C, 3, rate=2): SmallUNet.py:44-49 bridge / conv_d3): the staged
 // halo grows to (TH + 4) x (TW + 4) and tap (kh, kw) reads it at (2 kh, 2 kw); everything else is unchanged.
-template <int WM, int WN, int TM, int TN, int S = 1, int DIL = 1>
+// MODE 2 (NBR): the epilogue also emits the norm-backward reduction of the unit that produced the input (ConvParams::ny).  A
+// separate instantiation, not a run-time branch: the branch kept 70 more VGPRs live in EVERY launch (114 -> 187 for the
+// 128 x 128 tile, 81 -> 152 for the 256 x 64 one, whose occupancy halved: +9 % on the 64-channel layers).
+// MODE 1 = the epilogue accumulates (y += acc: depth taps of a 3-D conv) -- also its own instantiation: the sixteen old
+// values per fragment it keeps in flight are 32 registers the plain kernel does not need (114 -> 71 VGPRs, i.e. three
+// waves per SIMD instead of two next to the 64 accumulator registers).
+template <int WM, int WN, int TM, int TN, int S = 1, int DIL = 1, int MODE = 0>
 __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p) {
+  constexpr bool NBR = MODE == 2, ACC = MODE == 1;
   static_assert(S == 1 || DIL == 1, "strided atrous convs are not needed");
+  static_assert(!NBR || (S == 1 && DIL == 1), "the fused reduction is for plain 3x3 convs");
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int TH = BM / TW, HH = S * TH + 2 * DIL;
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) ssum[tn] = ssq[tn] = 0.f;
   float nsc[TN], nsh[TN], nmu[TN], nrs[TN];
-  if (p.ny != nullptr) {
+  if constexpr (NBR) {
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const int64_t o = (int64_t)n_img * p.nsst + n0 + (wn * TN + tn) * 32 + l31;
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
     for (int r = 0; r < 16; ++r)
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) prior[r][tn] = 0.f;
-    if (p.accumulate) {
+    if constexpr (ACC) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = mfma32_row(r, h);
@@ -205,33 +213,37 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
         }
       }
     }
-    if (p.ny != nullptr) {
+    if constexpr (NBR) {
       // fused norm-backward reduction of the producing unit (see ConvParams::ny): its raw output at this fragment's
-      // pixels, all loads issued together
+      // pixels, eight rows' loads issued together (all sixteen cost 32 more live registers; the 2-D input gradient never
+      // accumulates, so `prior` is dead here)
       const float* nyb = static_cast<const float*>(p.ny) + (int64_t)n_img * p.H * p.W * p.nys + n0 + wn * TN * 32 + l31;
-      float qv[16][TN];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = mfma32_row(r, h);
-        const int gh = h0 + 2 * sub + (i >> 4), gw = w0 + (i & 15);
-        const bool ok = gh < p.H && gw < p.W;
+      for (int rb = 0; rb < 16; rb += 8) {
+        float qv[8][TN];
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) qv[r][tn] = ok ? nyb[((int64_t)gh * p.W + gw) * p.nys + tn * 32] : 0.f;
-      }
+        for (int r = 0; r < 8; ++r) {
+          const int i = mfma32_row(rb + r, h);
+          const int gh = h0 + 2 * sub + (i >> 4), gw = w0 + (i & 15);
+          const bool ok = gh < p.H && gw < p.W;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = mfma32_row(r, h);
-        const int gh = h0 + 2 * sub + (i >> 4), gw = w0 + (i & 15);
-        if (gh < p.H && gw < p.W) {
-          float* yp = p.y + yimg + ((int64_t)gh * p.W + gw) * p.ys + n0 + wn * TN * 32 + l31;
+          for (int tn = 0; tn < TN; ++tn) qv[r][tn] = ok ? nyb[((int64_t)gh * p.W + gw) * p.nys + tn * 32] : 0.f;
+        }
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn) {
-            const float v = acc[tm][tn][r] + prior[r][tn];
-            yp[tn * 32] = v;
-            const float q = qv[r][tn];
-            const float du = fmaf(q, nsc[tn], nsh[tn]) > 0.f ? v : 0.f;
-            ssum[tn] += du;
-            ssq[tn] += du * ((q - nmu[tn]) * nrs[tn]);
+        for (int r = 0; r < 8; ++r) {
+          const int i = mfma32_row(rb + r, h);
+          const int gh = h0 + 2 * sub + (i >> 4), gw = w0 + (i & 15);
+          if (gh < p.H && gw < p.W) {
+            float* yp = p.y + yimg + ((int64_t)gh * p.W + gw) * p.ys + n0 + wn * TN * 32 + l31;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+              const float v = acc[tm][tn][rb + r];
+              yp[tn * 32] = v;
+              const float q = qv[r][tn];
+              const float du = fmaf(q, nsc[tn], nsh[tn]) > 0.f ? v : 0.f;
+              ssum[tn] += du;
+              ssq[tn] += du * ((q - nmu[tn]) * nrs[tn]);
+            }
           }
         }
       }
@@ -415,14 +427,14 @@ inline ConvCfg pick_cfg(int Cin, int Cout) {
   return {-1, 8};
 }
 
-template <int WM, int WN, int TM, int TN, int S = 1, int DIL = 1>
-int launch_igemm(const ConvParams& p, int n_mtiles, hipStream_t st) {
+template <int WM, int WN, int TM, int TN, int S = 1, int DIL = 1, int MODE = 0>
+int launch_igemm_mode(const ConvParams& p, int n_mtiles, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int TH = BM / TW;
   constexpr size_t lds = (2 * (S * TH + 2 * DIL) * (S * TW + 2 * DIL) * PS + 2 * CK * BN) * sizeof(float);
   static_assert(lds >= 2 * WM * BN * sizeof(float), "stat scratch must fit");
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = conv3x3_igemm_kernel<WM, WN, TM, TN, S, DIL>;
+  auto kern = conv3x3_igemm_kernel<WM, WN, TM, TN, S, DIL, MODE>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -433,6 +445,13 @@ int launch_igemm(const ConvParams& p, int n_mtiles, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, st, p);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
+}
+
+template <int WM, int WN, int TM, int TN, int S = 1, int DIL = 1, bool NBR = false>
+int launch_igemm(const ConvParams& p, int n_mtiles, hipStream_t st) {
+  if constexpr (NBR) return launch_igemm_mode<WM, WN, TM, TN, S, DIL, 2>(p, n_mtiles, st);
+  if (p.accumulate) return launch_igemm_mode<WM, WN, TM, TN, S, DIL, 1>(p, n_mtiles, st);
+  return launch_igemm_mode<WM, WN, TM, TN, S, DIL, 0>(p, n_mtiles, st);
 }
 
 }  // namespace
@@ -453,6 +472,7 @@ int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout, int spg, int st
 bool unetk_conv_stride2_ok(int Cin, int Cout) { return Cin % CK == 0 && Cout % 64 == 0; }
 
 int unetk_conv_run(ConvParams p, hipStream_t st) {
+  if (p.ny != nullptr && (p.stride == 2 || p.dil == 2)) return UNETK_E_UNSUPPORTED;
   if (p.stride == 2) {   // p.H x p.W = output extent, p.Hin x p.Win = input extent
     if (p.bf16 || !unetk_conv_stride2_ok(p.Cin, p.Cout) || p.xs % 4 != 0) return UNETK_E_UNSUPPORTED;
     p.tiles_h = (p.H + s2_th(p.Cout) - 1) / s2_th(p.Cout);
@@ -490,12 +510,15 @@ int unetk_conv_run(ConvParams p, hipStream_t st) {
   p.tiles_w = (p.W + TW - 1) / TW;
   const int n_mtiles = p.N * p.tiles_h * p.tiles_w;
   p.stat_rows = n_mtiles;
+  if (p.ny != nullptr && cfg.id != 0) return UNETK_E_UNSUPPORTED;   // the fused reduction exists for the 128-wide tiles
   if (small) {
     p.n_ntiles = p.Cout / 128;
+    if (p.ny != nullptr) return launch_igemm<2, 2, 1, 2, 1, 1, true>(p, n_mtiles, st);
     return launch_igemm<2, 2, 1, 2>(p, n_mtiles, st);
   }
   if (cfg.id == 0) {
     p.n_ntiles = p.Cout / 128;
+    if (p.ny != nullptr) return launch_igemm<2, 2, 2, 2, 1, 1, true>(p, n_mtiles, st);
     return launch_igemm<2, 2, 2, 2>(p, n_mtiles, st);
   }
   if (cfg.id == 1) {
@@ -616,7 +639,7 @@ extern "C" int unetk_conv3x3_dgrad_nbr_rows(const unetk_conv_desc* d) {
   const int K = d->Cout, Nc = d->Cin;                       // the dgrad conv contracts Cout, produces Cin channels
   // measured: the extra epilogue work (16 x TN strided loads of prod_y per fragment) costs ~0.03 ms on the deep layers and
   // 0.38 ms on the 64-channel 256^2 level, whose K loop is only 36 steps -- more than the separate reduction pass there
-  if (K < 128 || Nc < 128) return 0;
+  if (K < 128 || Nc < 128 || Nc % 128 != 0) return 0;
   if (d->precision == UNETK_BF16S) {
     if (!unetk_conv_bf16_ok(K, Nc) || K % 64 != 0 || Nc % 64 != 0) return 0;
     return unetk_conv_stat_rows_bf16(d->N, d->H, d->W, K, Nc);

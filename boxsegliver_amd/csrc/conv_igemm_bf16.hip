@@ -18,6 +18,8 @@
 // (a half-wave then writes 128 contiguous bytes per pixel instead of two 64-byte pieces), the filter pack of this mode
 // (unetk_conv3x3_pack_bf16s) permutes the output channels inside every 64-channel block: MFMA column l of tile tn holds
 // channel 2 l + tn.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -38,9 +40,12 @@ __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
   return r;
 }
 
-template <int WM, int WN, int TM, int TN, bool BS = false>
+// NBR: input gradient fused with the producing unit's norm-backward reduction (ConvParams::ny) -- its own instantiation so
+// the plain kernels keep their register budget (see conv_igemm.hip).
+template <int WM, int WN, int TM, int TN, bool BS = false, bool NBR = false>
 __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvParams p) {
   static_assert(!BS || TN == 2, "bf16 storage packs channel pairs (tile 0 / tile 1) into one word");
+  static_assert(!NBR || BS, "the fused reduction is built for bf16 storage");
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int TH = BM / TW, HH = TH + 2;
@@ -213,8 +218,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
   // input gradient fused with the producing unit's norm-backward reduction (ConvParams::ny; bf16 storage only): the two
   // channels of a lane are (2 l31, 2 l31 + 1) of the wave's 64-channel block
   float nsc[2], nsh[2], nmu[2], nrs[2];
-  const bool fuse = BS && p.ny != nullptr;
-  if (fuse) {
+  constexpr bool fuse = NBR;
+  if constexpr (fuse) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int64_t o = (int64_t)n_img * p.nsst + n0 + wn * 64 + 2 * l31 + j;
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
   for (int tm = 0; tm < TM; ++tm) {
     const int sub = wm * TM + tm;
     uint32_t qv[16];
-    if (fuse) {   // the producer's raw output at this fragment's pixels, loads issued together
+    if constexpr (fuse) {   // the producer's raw output at this fragment's pixels, loads issued together
       const bf16_t* nyb = static_cast<const bf16_t*>(p.ny) + (int64_t)n_img * p.H * p.W * p.nys + n0 + wn * 64 + 2 * l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
           const float v0 = acc[tm][0][r], v1 = acc[tm][TN - 1][r];
           const uint32_t pk = pk_bf16(v0, v1);
           *reinterpret_cast<uint32_t*>(yb) = pk;
-          if (fuse) {   // on the values memory holds (what a separate reduction pass would read back)
+          if constexpr (fuse) {   // on the values memory holds (what a separate reduction pass would read back)
             const float d0 = unetk_bf16_lo(pk), d1 = unetk_bf16_hi(pk);
             const float q0 = unetk_bf16_lo(qv[r]), q1 = unetk_bf16_hi(qv[r]);
             const float du0 = fmaf(q0, nsc[0], nsh[0]) > 0.f ? d0 : 0.f, du1 = fmaf(q1, nsc[1], nsh[1]) > 0.f ? d1 : 0.f;
@@ -349,20 +354,22 @@ inline BfCfg pick_bf16(int H, int Cin, int Cout, int N = 1 << 20, int W = 1 << 1
     // bytes per MFMA) the 128-pixel tile's 4x larger grid wins there (measured in round 2; with fp32 storage it did not)
     const int64_t blocks = (int64_t)N * ((H + 31) / 32) * ((W + TW - 1) / TW) * (Cout / 128);
     if (blocks < 200) return BfCfg{1, 8};
+    static const int mid_env = getenv("UNETK_BF16_MID") ? atoi(getenv("UNETK_BF16_MID")) : 0;   // experiment: 256 x 128 tiles
+    if (mid_env) return BfCfg{5, 16};
     return BfCfg{0, 32};
   }
   if (Cout % 64 == 0) return H >= 12 ? BfCfg{2, 16} : BfCfg{3, 8};
   return {4, 16};
 }
 
-template <int WM, int WN, int TM, int TN, bool BS = false>
+template <int WM, int WN, int TM, int TN, bool BS = false, bool NBR = false>
 int launch_bf16(const ConvParams& p, int n_mtiles, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int TH = BM / TW;
   constexpr size_t lds = (size_t)(2 * (TH + 2) * HWD * PSQ + 2 * (CKB / 8) * BN) * 16;
   static_assert(lds >= 2 * WM * BN * sizeof(float), "stat scratch must fit");
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = conv3x3_igemm_bf16_kernel<WM, WN, TM, TN, BS>;
+  auto kern = conv3x3_igemm_bf16_kernel<WM, WN, TM, TN, BS, NBR>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -395,12 +402,29 @@ int unetk_conv_run_bf16(ConvParams p, hipStream_t st) {
     const int n_mt = p.N * p.tiles_h * p.tiles_w;
     p.stat_rows = n_mt;
     switch (cfg.id) {
-      case 0: p.n_ntiles = p.Cout / 128; return launch_bf16<4, 2, 4, 2, true>(p, n_mt, st);
-      case 1: p.n_ntiles = p.Cout / 128; return launch_bf16<2, 2, 2, 2, true>(p, n_mt, st);
-      case 2: p.n_ntiles = p.Cout / 64; return launch_bf16<4, 1, 2, 2, true>(p, n_mt, st);
-      default: p.n_ntiles = p.Cout / 64; return launch_bf16<4, 1, 1, 2, true>(p, n_mt, st);
+      case 0:
+        p.n_ntiles = p.Cout / 128;
+        if (p.ny != nullptr) return launch_bf16<4, 2, 4, 2, true, true>(p, n_mt, st);
+        return launch_bf16<4, 2, 4, 2, true>(p, n_mt, st);
+      case 1:
+        p.n_ntiles = p.Cout / 128;
+        if (p.ny != nullptr) return launch_bf16<2, 2, 2, 2, true, true>(p, n_mt, st);
+        return launch_bf16<2, 2, 2, 2, true>(p, n_mt, st);
+      case 5:
+        p.n_ntiles = p.Cout / 128;
+        if (p.ny != nullptr) return launch_bf16<4, 2, 2, 2, true, true>(p, n_mt, st);
+        return launch_bf16<4, 2, 2, 2, true>(p, n_mt, st);
+      case 2:
+        if (p.ny != nullptr) return UNETK_E_UNSUPPORTED;
+        p.n_ntiles = p.Cout / 64;
+        return launch_bf16<4, 1, 2, 2, true>(p, n_mt, st);
+      default:
+        if (p.ny != nullptr) return UNETK_E_UNSUPPORTED;
+        p.n_ntiles = p.Cout / 64;
+        return launch_bf16<4, 1, 1, 2, true>(p, n_mt, st);
     }
   }
+  if (p.ny != nullptr) return UNETK_E_UNSUPPORTED;
   if (p.xs % 4 != 0) return UNETK_E_BADARG;
   p.tiles_h = (p.H + cfg.th - 1) / cfg.th;
   p.tiles_w = (p.W + TW - 1) / TW;

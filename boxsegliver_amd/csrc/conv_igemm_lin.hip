@@ -43,8 +43,12 @@ __device__ __forceinline__ int sk_block_of(int64_t pos, int64_t tot, int G) {   
   return b;
 }
 
-template <int WM, int WN, int TM, int TN, bool GEN = false, bool FUSED = false, bool SK = false>
-__global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvParams p) {
+// ACC: the plain variant's epilogue accumulates (y += acc, one depth tap of an unfused 3-D conv).  Its own instantiation:
+// the row pointers and old values it keeps in flight cost 60+ registers (the 128 x 128 stream-K variant ran at ONE wave
+// per SIMD with them: 210 + 64 registers).
+template <int WM, int WN, int TM, int TN, bool GEN = false, bool FUSED = false, bool SK = false, bool ACC = false>
+__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))) void conv3x3_igemm_lin_kernel(ConvParams p) {
+  static_assert(!(ACC && (GEN || SK)), "ACC is a flag of the plain variant (the GEN variants test p.accumulate)");
   static_assert(GEN || !FUSED, "FUSED is a GEN variant");
   static_assert(!(SK && GEN), "stream-K is for the plain variant");
   constexpr int NQ = FUSED ? 4 : 1;
@@ -244,34 +248,40 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
         const int rem0 = pb - plane * HW;
         int aa = rem0 / p.W, bb = rem0 - aa * p.W, prev = 0;
         int64_t img = p.ya.off(plane);
-        float* rowp[16];
+        // four rows at a time: their old values (y += acc) are loaded together, then added and stored.  All sixteen at once
+        // (pointers + values = 64 more registers next to the 4 x 32 accumulators) held this kernel at ONE wave per SIMD.
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int delta = (r & 3) + 8 * (r >> 2);
-          bb += delta - prev;
-          prev = delta;
-          while (bb >= p.W) {
-            bb -= p.W;
-            if (++aa == p.H) {
-              aa = 0;
-              img = p.ya.off(++plane);
+        for (int rb = 0; rb < 16; rb += 4) {
+          float* rowp[4];
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int r = rb + r4;
+            const int delta = (r & 3) + 8 * (r >> 2);
+            bb += delta - prev;
+            prev = delta;
+            while (bb >= p.W) {
+              bb -= p.W;
+              if (++aa == p.H) {
+                aa = 0;
+                img = p.ya.off(++plane);
+              }
             }
+            const int hi = p.os * aa + p.ooh[qq], wi = p.os * bb + p.oow[qq];
+            const bool ok = pb + delta < P1 && hi >= 0 && hi < p.Hd && wi >= 0 && wi < p.Wd;
+            rowp[r4] = ok ? p.y + img + ((int64_t)hi * p.Wd + wi) * p.ys + n0 + wn * TN * 32 + l31 : nullptr;
           }
-          const int hi = p.os * aa + p.ooh[qq], wi = p.os * bb + p.oow[qq];
-          const bool ok = pb + delta < P1 && hi >= 0 && hi < p.Hd && wi >= 0 && wi < p.Wd;
-          rowp[r] = ok ? p.y + img + ((int64_t)hi * p.Wd + wi) * p.ys + n0 + wn * TN * 32 + l31 : nullptr;
+          float prior[4][TN];
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) prior[r4][tn] = (p.accumulate && rowp[r4]) ? rowp[r4][tn * 32] : 0.f;
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4)
+            if (rowp[r4]) {
+#pragma unroll
+              for (int tn = 0; tn < TN; ++tn) rowp[r4][tn * 32] = accq[qq][tm][tn][rb + r4] + prior[r4][tn];
+            }
         }
-        float prior[16][TN];
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) prior[r][tn] = (p.accumulate && rowp[r]) ? rowp[r][tn * 32] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (rowp[r]) {
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) rowp[r][tn * 32] = accq[qq][tm][tn][r] + prior[r][tn];
-          }
       }
     }
     return;
@@ -415,33 +425,57 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_lin_kernel(ConvPara
     int plane = pb / HW;
     int rem = pb - plane * HW, prev = 0;
     int64_t img = p.ya.off(plane);
-    float* rowp[16];
+    if constexpr (!ACC) {
+      // plain store: nothing to keep in flight -- each row's address is formed and used at once
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int delta = (r & 3) + 8 * (r >> 2);
-      rem += delta - prev;
-      prev = delta;
-      while (rem >= HW) {
-        rem -= HW;
-        img = p.ya.off(++plane);
+      for (int r = 0; r < 16; ++r) {
+        const int delta = (r & 3) + 8 * (r >> 2);
+        rem += delta - prev;
+        prev = delta;
+        while (rem >= HW) {
+          rem -= HW;
+          img = p.ya.off(++plane);
+        }
+        if (pb + delta < P1) {
+          float* rp = p.y + img + (int64_t)rem * p.ys + n0 + wn * TN * 32 + l31;
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const float v = acc[tm][tn][r];
+            rp[tn * 32] = v;
+            ssum[tn] += v;
+            ssq[tn] += v * v;
+          }
+        }
       }
-      rowp[r] = pb + delta < P1 ? p.y + img + (int64_t)rem * p.ys + n0 + wn * TN * 32 + l31 : nullptr;
-    }
-    // y += acc: all old values first, so the load latencies overlap (see conv_igemm.hip)
-    float prior[16][TN];
+    } else {
+      float* rowp[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
+      for (int r = 0; r < 16; ++r) {
+        const int delta = (r & 3) + 8 * (r >> 2);
+        rem += delta - prev;
+        prev = delta;
+        while (rem >= HW) {
+          rem -= HW;
+          img = p.ya.off(++plane);
+        }
+        rowp[r] = pb + delta < P1 ? p.y + img + (int64_t)rem * p.ys + n0 + wn * TN * 32 + l31 : nullptr;
+      }
+      // y += acc: all old values first, so the load latencies overlap (see conv_igemm.hip)
+      float prior[16][TN];
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) prior[r][tn] = (p.accumulate && rowp[r]) ? rowp[r][tn * 32] : 0.f;
+      for (int r = 0; r < 16; ++r)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (rowp[r]) {
+        for (int tn = 0; tn < TN; ++tn) prior[r][tn] = rowp[r] ? rowp[r][tn * 32] : 0.f;
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          const float v = acc[tm][tn][r] + prior[r][tn];
-          rowp[r][tn * 32] = v;
-          ssum[tn] += v;
-          ssq[tn] += v * v;
+      for (int r = 0; r < 16; ++r) {
+        if (rowp[r]) {
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const float v = acc[tm][tn][r] + prior[r][tn];
+            rowp[r][tn * 32] = v;
+            ssum[tn] += v;
+            ssq[tn] += v * v;
+          }
         }
       }
     }
@@ -523,12 +557,15 @@ __global__ __launch_bounds__(256) void lin_sk_fixup_kernel(ConvParams p, int G) 
   }
 }
 
-template <int WM, int WN, int TM, int TN, bool GEN = false, bool FUSED = false>
+template <int WM, int WN, int TM, int TN, bool GEN = false, bool FUSED = false, bool ACC = false>
 int launch_lin(const ConvParams& p, int n_mtiles, hipStream_t st) {
+  if constexpr (!GEN && !ACC) {
+    if (p.accumulate) return launch_lin<WM, WN, TM, TN, false, false, true>(p, n_mtiles, st);
+  }
   constexpr int BN = WN * TN * 32;
   constexpr size_t lds_max = (size_t)(2 * LIN_MAXPIX * PS + 2 * CK * BN) * sizeof(float);
   const size_t lds = (size_t)(2 * p.lin_pix * PS + 2 * CK * BN) * sizeof(float);
-  auto kern = conv3x3_igemm_lin_kernel<WM, WN, TM, TN, GEN, FUSED>;
+  auto kern = conv3x3_igemm_lin_kernel<WM, WN, TM, TN, GEN, FUSED, false, ACC>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);

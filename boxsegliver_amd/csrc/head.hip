@@ -138,12 +138,36 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(unetk_head_desc d, const 
 #pragma unroll
   for (int i = 0; i < NQ; ++i) q[i] = 0.f;
 
-  for (int i = blk * gpb + grp; i < d.HW; i += bps * gpb) {
-    const int64_t pix = (int64_t)b * d.HW + i;
-    const float4 zv = ld4(z + pix * d.C + gl * 4);
+  // A group of lpp lanes shares a pixel's channel dot products (xor-shuffle sums leave the logits in every lane).  The
+  // softmax / loss / metric arithmetic that follows is ~100 instructions per pixel: done by ONE lane of the group it made
+  // the kernel VALU-bound at 1.3-2.7 TB/s.  So a group takes lpp consecutive pixels per pass and lane j keeps pixel j's
+  // logits: the per-pixel tail then runs in all lanes at once.
+  for (int i0 = (blk * gpb + grp) * lpp; i0 < d.HW; i0 += bps * gpb * lpp) {
     float lg[NCLS];
-    pixel_logits<NCLS>(zv, wr, bias, lpp, lg);
-    if (gl == 0) {
+#pragma unroll
+    for (int k = 0; k < NCLS; ++k) lg[k] = 0.f;
+    const int step = (lpp & 3) == 0 ? 4 : 1;                 // four loads in flight per shuffle chain
+    for (int pp = 0; pp < lpp; pp += step) {
+      float4 zv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ip = i0 + pp + u;
+        zv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (u < step && ip < d.HW) zv[u] = ld4(z + ((int64_t)b * d.HW + ip) * d.C + gl * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u < step) {
+          float t[NCLS];
+          pixel_logits<NCLS>(zv[u], wr, bias, lpp, t);
+#pragma unroll
+          for (int k = 0; k < NCLS; ++k) lg[k] = (gl == pp + u) ? t[k] : lg[k];
+        }
+      }
+    }
+    const int i = i0 + gl;
+    const int64_t pix = (int64_t)b * d.HW + i;
+    if (i < d.HW) {
       float mx = lg[0];
 #pragma unroll
       for (int k = 1; k < NCLS; ++k) mx = fmaxf(mx, lg[k]);

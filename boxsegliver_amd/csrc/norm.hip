@@ -518,7 +518,7 @@ extern "C" int unetk_norm_finalize(const unetk_norm_desc* d, const float* stat_p
     // partials are [2][stat_rows][C] with each image's tiles contiguous -> [2*Ns][rows_per_group][C]
     const float* src = stat_partials;
     int rows = stat_rows / g.Ns;
-    if (rows > 256) {   // first level: 64 row blocks per (statistic, group)
+    if (rows > UNETK_RR_DIRECT_ROWS) {   // first level: 64 row blocks per (statistic, group)
       int rc = unetk_rows_reduce_l1(stat_partials, 2 * g.Ns, rows, d->C, sums + 2 * g.Ns * d->C, st);
       if (rc != UNETK_OK) return rc;
       src = sums + 2 * g.Ns * d->C;
@@ -586,7 +586,7 @@ extern "C" size_t unetk_norm_bwd_ws_bytes(const unetk_norm_desc* d) {
   f += (size_t)K * g.L * d->C;                                       // sums per launch group
   f += (size_t)K * d->C;                                             // sums over groups
   if (nblk1 > nblk) nblk = nblk1;
-  f += unetk_rows_reduce_tmp_floats(K * g.L, 257, d->C);              // always: pre-computed partials may have any row count
+  f += unetk_rows_reduce_tmp_floats(K * g.L, UNETK_RR_DIRECT_ROWS + 1, d->C);              // always: pre-computed partials may have any row count
   f += unetk_rows_reduce_tmp_floats(K, g.L, d->C);
   return f * sizeof(float);
 }
@@ -634,7 +634,7 @@ extern "C" int unetk_norm_relu_bwd_pre(const unetk_norm_desc* d, const void* y, 
   float* sums = partial + (size_t)K * g.L * nblk * d->C;
   float* psum = sums + (size_t)K * g.L * d->C;
   float* tmp1 = psum + (size_t)K * d->C;
-  float* tmp2 = tmp1 + unetk_rows_reduce_tmp_floats(K * g.L, 257, d->C);
+  float* tmp2 = tmp1 + unetk_rows_reduce_tmp_floats(K * g.L, UNETK_RR_DIRECT_ROWS + 1, d->C);
   BwdArgs a{};
   a.y = y; a.dz = dz; a.scale = scale; a.shift = shift; a.mean = mean; a.rstd = rstd; a.den = den;
   a.guide = guide; a.gw = gw; a.gb = gb; a.partial = partial; a.dy = dy;

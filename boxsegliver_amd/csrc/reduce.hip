@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void rows_reduce_final_kernel(const float* __r
 
 }  // namespace
 
-size_t unetk_rows_reduce_tmp_floats(int K, int rows, int C) { return rows > 256 ? (size_t)K * 64 * C : 0; }
+size_t unetk_rows_reduce_tmp_floats(int K, int rows, int C) { return rows > UNETK_RR_DIRECT_ROWS ? (size_t)K * 64 * C : 0; }
 
 // first level only: src[K][rows][C] -> tmp[K][64][C]
 int unetk_rows_reduce_l1(const float* src, int K, int rows, int C, float* tmp, hipStream_t st) {
@@ -60,7 +60,7 @@ int unetk_rows_reduce_l1(const float* src, int K, int rows, int C, float* tmp, h
 }
 
 int unetk_rows_reduce(const float* src, int K, int rows, int C, float* dst, float* tmp, hipStream_t st) {
-  if (rows > 256) {
+  if (rows > UNETK_RR_DIRECT_ROWS) {
     const int rc = unetk_rows_reduce_l1(src, K, rows, C, tmp, st);
     if (rc != UNETK_OK) return rc;
     src = tmp;
