@@ -18,8 +18,6 @@
 // (a half-wave then writes 128 contiguous bytes per pixel instead of two 64-byte pieces), the filter pack of this mode
 // (unetk_conv3x3_pack_bf16s) permutes the output channels inside every 64-channel block: MFMA column l of tile tn holds
 // channel 2 l + tn.
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace {
@@ -354,8 +352,7 @@ inline BfCfg pick_bf16(int H, int Cin, int Cout, int N = 1 << 20, int W = 1 << 1
     // bytes per MFMA) the 128-pixel tile's 4x larger grid wins there (measured in round 2; with fp32 storage it did not)
     const int64_t blocks = (int64_t)N * ((H + 31) / 32) * ((W + TW - 1) / TW) * (Cout / 128);
     if (blocks < 200) return BfCfg{1, 8};
-    static const int mid_env = getenv("UNETK_BF16_MID") ? atoi(getenv("UNETK_BF16_MID")) : 0;   // experiment: 256 x 128 tiles
-    if (mid_env) return BfCfg{5, 16};
+    // (a 256 x 128 tile -- two blocks per CU instead of one -- was measured in round 2: 15.80 vs 15.65 ms per step, no gain)
     return BfCfg{0, 32};
   }
   if (Cout % 64 == 0) return H >= 12 ? BfCfg{2, 16} : BfCfg{3, 8};
@@ -410,10 +407,6 @@ int unetk_conv_run_bf16(ConvParams p, hipStream_t st) {
         p.n_ntiles = p.Cout / 128;
         if (p.ny != nullptr) return launch_bf16<2, 2, 2, 2, true, true>(p, n_mt, st);
         return launch_bf16<2, 2, 2, 2, true>(p, n_mt, st);
-      case 5:
-        p.n_ntiles = p.Cout / 128;
-        if (p.ny != nullptr) return launch_bf16<4, 2, 2, 2, true, true>(p, n_mt, st);
-        return launch_bf16<4, 2, 2, 2, true>(p, n_mt, st);
       case 2:
         if (p.ny != nullptr) return UNETK_E_UNSUPPORTED;
         p.n_ntiles = p.Cout / 64;

@@ -777,6 +777,103 @@ int run_pw(PwParams& p, hipStream_t st) {
   return p.bf16 ? launch_pw_bf16<MODE, 4, 1, 1, 2>(p, st) : launch_pw<MODE, 4, 1, 1, 2>(p, st);
 }
 
+// fp32 filter gradient of ALL FOUR output sub-pixels (a, b) of an input pixel in one block: the x tile is staged once and
+// contracted with the four dpre tiles (four accumulators per wave, the x fragment shared by their MFMAs).  The one-
+// sub-pixel kernel above re-read x four times (1.3 GB per launch against 0.8 GB algorithmic at the 128^2 level) and fed a
+// single dependent MFMA chain per wave from two scalar LDS reads each: 88 TFLOP/s.
+//   dw[a][b][co][ci] = sum_m dpre[2y + a][2x + b][co] * x[m][ci]
+// Block = 64 co x 64 ci x 4 sub-pixels over a range of input pixels (split-K slabs as before); 32-pixel stages with a
+// register prefetch of the next stage.
+__global__ __launch_bounds__(256) void deconv_wgrad4_kernel(DwParams p) {
+  constexpr int KT = 32, CT = 64;
+  __shared__ __attribute__((aligned(16))) float bt[KT * CT];        // x rows (ci)
+  __shared__ __attribute__((aligned(16))) float at[4][KT * CT];     // dpre rows (co) of the four sub-pixels
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave >> 1, wci = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  int bid = blockIdx.x;
+  const int ci_t = bid % p.n_ci_tiles; bid /= p.n_ci_tiles;
+  const int co_t = bid % p.n_co_tiles; bid /= p.n_co_tiles;
+  const int split = bid;
+  const int co0 = co_t * CT, ci0 = ci_t * CT;
+  f32x16 acc[4];
+#pragma unroll
+  for (int ab = 0; ab < 4; ++ab)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ab][r] = 0.f;
+  const int mb = split * p.m_per_split, me = min(mb + p.m_per_split, p.M);
+  constexpr int LR = KT * (CT / 4) / 256;   // 2 float4 of x, 4 x 2 of dpre per thread and stage
+  float4 va[4][LR], vb[LR];
+  const int HWp = p.H * p.W;
+  const bool co_ok = co0 + (tid & 15) * 4 < p.Cout;                  // Cout may be 32: half a co tile
+  auto load_tile = [&](int mt) {
+    const int m_first = mt + (tid >> 4), q = tid & 15;
+    int nn = m_first / HWp;
+    const int rem = m_first - nn * HWp;
+    int yy = rem / p.W, xx = rem - yy * p.W;
+    int64_t img = p.da.off(nn);
+#pragma unroll
+    for (int i = 0; i < LR; ++i) {
+      const int m = m_first + 16 * i;
+      vb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int ab = 0; ab < 4; ++ab) va[ab][i] = vb[i];
+      if (m < me) {
+        vb[i] = ldg4(p.x + (int64_t)m * p.Cin + ci0 + q * 4);
+        if (co_ok) {
+          const float* d0 = p.dpre + img + ((int64_t)(2 * yy) * 2 * p.W + 2 * xx) * p.Cout + co0 + q * 4;
+          va[0][i] = ldg4(d0);
+          va[1][i] = ldg4(d0 + p.Cout);
+          va[2][i] = ldg4(d0 + (int64_t)2 * p.W * p.Cout);
+          va[3][i] = ldg4(d0 + (int64_t)2 * p.W * p.Cout + p.Cout);
+        }
+      }
+      xx += 16;
+      while (xx >= p.W) {
+        xx -= p.W;
+        if (++yy == p.H) {
+          yy = 0;
+          img = p.da.off(++nn);
+        }
+      }
+    }
+  };
+  if (mb < me) load_tile(mb);
+  for (int mt = mb; mt < me; mt += KT) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < LR; ++i) {
+      const int idx = tid + i * 256;
+      const int o = (idx >> 4) * CT + (idx & 15) * 4;
+      *reinterpret_cast<float4*>(&bt[o]) = vb[i];
+#pragma unroll
+      for (int ab = 0; ab < 4; ++ab) *reinterpret_cast<float4*>(&at[ab][o]) = va[ab][i];
+    }
+    __syncthreads();
+    if (mt + KT < me) load_tile(mt + KT);
+#pragma unroll 4
+    for (int s = 0; s < KT / 2; ++s) {
+      const float b = bt[(2 * s + h) * CT + wci * 32 + l31];
+#pragma unroll
+      for (int ab = 0; ab < 4; ++ab) {
+        const float a = at[ab][(2 * s + h) * CT + wco * 32 + l31];
+        acc[ab] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ab], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int ab = 0; ab < 4; ++ab) {
+    float* out = p.slab + ((int64_t)split * 4 + ab) * p.Cout * p.Cin;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wco * 32 + mfma32_row(r, h);
+      if (co < p.Cout) out[(int64_t)co * p.Cin + ci0 + wci * 32 + l31] = acc[ab][r];
+    }
+  }
+}
+
 bool deconv_desc_ok(const unetk_deconv3d_desc* d) {
   return d && d->N > 0 && d->D > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && (d->kd == 1 || d->kd == 2) &&
          d->out_coff >= 0 && d->out_stride >= d->out_coff + d->Cout;
@@ -788,8 +885,11 @@ struct DwPlan {
 DwPlan dw_plan(const unetk_deconv3d_desc* d) {
   DwPlan pl{};
   const int M = d->N * d->D * d->H * d->W;
-  const int panels = 4 * (d->Cin / 64) * ((d->Cout + 63) / 64);
-  int S = (1024 + panels - 1) / panels;
+  // fp32: one block takes all four sub-pixels of its (co, ci) panel (deconv_wgrad4_kernel) -- ~768 blocks of 40 KB LDS;
+  // the bf16 kernels take one sub-pixel per block -- ~1024 blocks
+  const bool four = d->precision == UNETK_FP32;
+  const int panels = (four ? 1 : 4) * (d->Cin / 64) * ((d->Cout + 63) / 64);
+  int S = ((four ? 768 : 1024) + panels - 1) / panels;
   const int mtiles = (M + 127) / 128;
   if (S > mtiles) S = mtiles;
   if (S < 1) S = 1;
@@ -968,6 +1068,13 @@ extern "C" int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const void* xv, 
     q.x = x; q.dpre = dpre + a * plane; q.slab = slab; q.M = M; q.H = d->H; q.W = d->W; q.Cin = d->Cin; q.Cout = d->Cout;
     q.m_per_split = pl.m_per_split; q.n_co_tiles = (d->Cout + 63) / 64; q.n_ci_tiles = d->Cin / 64; q.da = da;
     const int grid = pl.S * 4 * q.n_co_tiles * q.n_ci_tiles;
+    if (d->precision == UNETK_FP32) {
+      hipLaunchKernelGGL(deconv_wgrad4_kernel, dim3(pl.S * q.n_co_tiles * q.n_ci_tiles), dim3(256), 0, st, q);
+      UNETK_LAUNCH_CHECK();
+      rc = unetk_launch_slab_reduce(slab, pl.S, (int64_t)4 * d->Cin * d->Cout, dw + (int64_t)a * 4 * d->Cin * d->Cout, st);
+      if (rc != UNETK_OK) return rc;
+      continue;
+    }
     static bool attr_done = false;
     if (!attr_done) {
       hipError_t e = hipFuncSetAttribute((const void*)deconv_wgrad_kernel<false>,

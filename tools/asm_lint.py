@@ -35,6 +35,7 @@ EXPECT = [
     ("conv3x3_wgrad_c3_bf16s_kernel", "v_mfma_f32_32x32x2_f32"),     # fp32 image x bf16 dy: exact fp32 contraction
     ("conv3x3_wgrad_bf16s_kernel", "v_mfma_f32_32x32x16_bf16"),
     ("deconv_wgrad_bf16s_kernel", "v_mfma_f32_32x32x16_bf16"),
+    ("deconv_wgrad4_kernel", "v_mfma_f32_32x32x2_f32"),
 ]
 
 

@@ -1,13 +1,9 @@
 #!/usr/bin/env bash
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_ops3d.py tests/test_gpu_unet.py tests/test_gpu_bf16s.py tests/test_gpu_unet3d.py tests/test_gpu_fused_nbr.py tests/test_gpu_smallunet.py -x -q > gpurun_out/r2s2_t8.log 2>&1
-tail -5 gpurun_out/r2s2_t8.log
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r2s2_fp32c.json 2> gpurun_out/r2s2.err || tail -5 gpurun_out/r2s2.err
-cut -c60-200 gpurun_out/r2s2_fp32c.json
-python bench.py --dtype bf16 --size 512 --batch 8 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r2s2_bf16c.json 2> gpurun_out/r2s2.err || tail -5 gpurun_out/r2s2.err
-cut -c60-200 gpurun_out/r2s2_bf16c.json
-python bench.py --model UNet3D --size 96 --batch 1 --steps 5 --warmup 2 --no-cpu-baseline --detail > gpurun_out/r2s2_u3d1c.json 2> gpurun_out/r2s2.err || tail -5 gpurun_out/r2s2.err
-cut -c60-200 gpurun_out/r2s2_u3d1c.json
-python bench.py --model GUNet --batch 8 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r2s2_gunet.json 2> gpurun_out/r2s2.err || tail -5 gpurun_out/r2s2.err
-cut -c60-200 gpurun_out/r2s2_gunet.json
+timeout -k 10 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_ops3d.py tests/test_gpu_unet.py tests/test_gpu_unet3d.py tests/test_gpu_interunet.py tests/test_gpu_smallunet.py tests/test_gpu_fullsize.py -x -q > gpurun_out/r2s2_t9.log 2>&1
+tail -5 gpurun_out/r2s2_t9.log
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r2s2_fp32d.json 2> gpurun_out/r2s2.err || tail -5 gpurun_out/r2s2.err
+cut -c60-200 gpurun_out/r2s2_fp32d.json
+python bench.py --model UNet3D --size 96 --batch 1 --steps 5 --warmup 2 --no-cpu-baseline --detail > gpurun_out/r2s2_u3d1d.json 2> gpurun_out/r2s2.err || tail -5 gpurun_out/r2s2.err
+cut -c60-200 gpurun_out/r2s2_u3d1d.json
