@@ -194,6 +194,7 @@ class GUNet(base.BaseNet):
         self.side_dropout = getattr(args, "side_dropout", 0.5)
         self.dropout = getattr(args, "dropout", None)
         self.use_se = getattr(args, "use_se", False)
+        self.ct_conv = hasattr(args, "ct_conv")                      # GUNet.py:236: the flag's presence, not its value
         self._taps = None
         self._concat_guide = False          # UNetInter: the guide joins the input channels instead of modulating
         self._mid_cat = False               # UNetInter --mid_cat: ... or the pooled level-0 output
@@ -201,7 +202,6 @@ class GUNet(base.BaseNet):
 
     def _net_arg_scope(self, *args, **kwargs):
         """GUNet.py:240-257: as UNet (decoder norm = _get_normalization defaults), pools with SAME."""
-        self.ct_conv = hasattr(self.args, "ct_conv")                 # GUNet.py:236: the flag's presence, not its value
         fix = bool(getattr(self.args, "fix", False)) and self.use_spatial_guide and not self._concat_guide
         if (fix and self.use_context_guide) or (self.use_se and self.use_context_guide and self.dropout):
             raise NotImplementedError("GUNet --fix with --use_context, and --use_se with --dropout, are not built")
