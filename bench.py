@@ -335,10 +335,19 @@ def main():
                 suffix = {"fp32": "", "bf16": "_bf16", "bf16c": "_bf16c"}[a.dtype]
                 files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic" + suffix + ".json")))
                 pmc = json.load(open(files[-1]))["kernels"] if files else {}
-                norm = {re.sub(r"(,1)+>", ">", k.replace(" ", "")): v for k, v in pmc.items()}   # <..., S=1, DIL=1> == the tag
-                key = norm.get(top["kernel"].split("(")[0].replace(" ", ""))
-                if key and a.size == 256 and a.batch == 32 and a.model == "UNet":
-                    out["roofline"]["traffic"] = round(key["hbm_bytes_per_launch_corrected"])
+                # the tag names the tile configuration; the PMC table lists its instantiations separately (<..., S = 1, DIL = 1,
+                # MODE>: plain / accumulating / fused-reduction epilogue; <..., BS, NBR> for bf16): launch-weighted mean
+                groups = {}
+                for k, v in pmc.items():
+                    t = re.sub(r"(,1,1,[012]|,true,(true|false)|(,1)+)>$", lambda m: ",true>" if "true" in m.group(0)[:6] else ">",
+                               k.replace(" ", ""))
+                    g = groups.setdefault(t, [0, 0.0])
+                    g[0] += v["launches"]
+                    g[1] += v["launches"] * v["hbm_bytes_per_launch_corrected"]
+                key = groups.get(top["kernel"].split("(")[0].replace(" ", ""))
+                shape_ok = (a.size, a.batch) == ((256, 32) if a.dtype == "fp32" else (512, 8))     # the shapes the PMC passes ran
+                if key and key[0] and shape_ok and a.model == "UNet":
+                    out["roofline"]["traffic"] = round(key[1] / key[0])
                     out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(files[-1]) + \
                         " (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE)"
             except (OSError, KeyError, ValueError, IndexError):

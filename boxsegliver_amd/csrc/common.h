@@ -125,6 +125,11 @@ struct ConvParams {
   // the plane (depth index + dshift0 + dt * dstep) of the same sample (zero outside [0, spg)) with the filter panel
   // wp + dt * 9 * Cin * Cout; no per-tap read-modify-write of the output.  0 / 1 = a plain 2-D conv per plane.
   int kd, dshift0, dstep;
+  // fused depth taps in the TILED kernel (conv_igemm.hip; the natively strided (3,3,3) layers): image i is output plane
+  // dep = i % spg of its sample, tap dt reads input depth dep * dsd + dshift0 + dt (skipped outside [0, din)), i.e. the plane
+  // at xa.off(i) + (dshift0 + dt) * dplane floats; filter panel wp + dt * 9 * Cin * Cout
+  int dsd, din;
+  int64_t dplane;
   // input gradient fused with the PRODUCER's norm-backward reduction (tiled fp32 / bf16-storage kernels): the output dx
   // is the dz of the unit whose raw conv output is ny (same pixels, p.Cout channels, pixel stride nys); the epilogue
   // emits, instead of (sum y, sum y^2), the partials  sum du  and  sum du * xhat  with du = dz * (ny*nsc + nsh > 0),

@@ -205,6 +205,21 @@ extern "C" int unetk_conv3d_fwd(const unetk_conv3d_desc* d, const float* x, cons
     if (ws && unetk_aligned16(ws)) { p.sk_slab = (float*)ws; p.sk_slab_bytes = ws_bytes; }
     return unetk_conv_run(p, st);
   }
+  if (native && d->kd == 3) {
+    // natively strided (3,3,3) conv (UNet3D's (1,2,2) and (2,2,2) down-sampling layers): the three depth taps are contracted
+    // inside ONE launch of the tiled stride-2 kernel (K = 27 Cin; a tap whose input plane falls outside the sample is
+    // skipped per block) -- no memset, no read-modify-write of y per tap, one prologue / epilogue instead of three
+    ConvParams p{};
+    p.x = x; p.wp = wp; p.y = y; p.stat = stat_partials;
+    p.N = d->N * g.Do; p.H = g.Ho; p.W = g.Wo; p.Cin = d->Cin; p.Cout = d->Cout;
+    p.xs = d->x_stride; p.ys = d->y_stride;
+    p.xa = planes(HWx, g.Do, d->sd, d->D);
+    p.ya = planes(g.Ho * g.Wo * d->y_stride, g.Do, 1, g.Do);
+    p.spg = g.Do;
+    p.stride = 2; p.Hin = d->H; p.Win = d->W; p.pbh = 1 - g.off_h; p.pbw = 1 - g.off_w;
+    p.kd = 3; p.dshift0 = -g.pb_d; p.dstep = 1; p.dsd = d->sd; p.din = d->D; p.dplane = HWx;
+    return unetk_conv_run(p, st);
+  }
   // order: partial-coverage taps first, a full-coverage tap last (it emits the statistics)
   int order[3], n_taps = 0, full = -1;
   for (int dt = 0; dt < d->kd; ++dt) {
@@ -294,25 +309,30 @@ extern "C" int unetk_conv3d_dgrad(const unetk_conv3d_desc* d, const float* dy, c
     //   dx[hi] = sum_{kh = ph, ph+2} dy[a - (kh - ph)/2] w[kh],  ph = (hi + pbh) & 1,  a = (hi + pbh - ph) / 2
     const int pbh = 1 - g.off_h, pbw = 1 - g.off_w;
     const int HWx = d->H * d->W * d->x_stride, HWy = g.Ho * g.Wo * d->y_stride;
-    const bool multi = d->kd > 1 || d->sd > 1;
+    // depth stride 1 with three depth taps (UNet3D's (1,2,2) layers): every dx plane receives all three taps, so they are
+    // contracted in ONE launch (K = 3 x taps x Cout) -- no memset, no accumulation passes
+    const bool fuse_d = d->kd == 3 && d->sd == 1 && d->Cin % 32 == 0;
+    const bool multi = !fuse_d && (d->kd > 1 || d->sd > 1);
     if (multi) {
       hipError_t e = hipMemsetAsync(dx, 0, (size_t)d->N * d->D * HWx * sizeof(float), st);
       if (e != hipSuccess) return (int)e;
     }
-    for (int dt = 0; dt < d->kd; ++dt) {
+    for (int dt = 0; dt < (fuse_d ? 1 : d->kd); ++dt) {
       int lo, hi;
       tap_range(d, g, dt, &lo, &hi);
+      if (fuse_d) { lo = 0; hi = g.Do - 1; }
       if (hi < lo) continue;
       ConvParams p{};
       p.x = dy + (int64_t)lo * HWy;
       p.wp = wp_dgrad + (int64_t)dt * 9 * d->Cin * d->Cout;
-      p.y = dx + (int64_t)(lo * d->sd - g.pb_d + dt) * HWx;
+      p.y = dx + (int64_t)(fuse_d ? 0 : lo * d->sd - g.pb_d + dt) * HWx;
       p.N = d->N * (hi - lo + 1); p.H = g.Ho; p.W = g.Wo; p.Cin = d->Cout; p.Cout = d->Cin;
       p.xs = d->y_stride; p.ys = d->x_stride;
       p.xa = planes(HWy, hi - lo + 1, 1, g.Do);
       p.ya = planes(HWx, hi - lo + 1, d->sd, d->D);
       p.accumulate = multi ? 1 : 0;
       p.spg = hi - lo + 1;
+      if (fuse_d) { p.kd = 3; p.dshift0 = g.pb_d; p.dstep = -1; }   // dx[di] = sum_dt dy[di + pb - dt] * w[dt]
       p.os = 2; p.Hd = d->H; p.Wd = d->W;
       for (int ph = 0; ph < 2; ++ph)
         for (int pw = 0; pw < 2; ++pw) {

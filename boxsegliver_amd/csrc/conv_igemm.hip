@@ -93,19 +93,34 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
     woff[r] = ((int64_t)q * p.Cout + n0 + n) * 4;
   }
 
+  // fused depth taps (p.kd > 1): the chunk index runs over (valid depth tap, 16-channel chunk); a tap whose input plane
+  // lies outside the sample is skipped outright (block-uniform: one block = one output plane)
+  const int nchunks = p.Cin / CK;
+  int c_begin = 0, c_end = nchunks;
+  if (p.kd > 1) {
+    const int dep = n_img % p.spg;
+    int dt_lo = 0, dt_hi = p.kd;
+    while (dt_lo < dt_hi && dep * p.dsd + p.dshift0 + dt_lo < 0) ++dt_lo;
+    while (dt_hi > dt_lo && dep * p.dsd + p.dshift0 + dt_hi - 1 >= p.din) --dt_hi;
+    c_begin = dt_lo * nchunks;
+    c_end = dt_hi * nchunks;
+  }
   float4 hreg[HR], wreg[WR];
-  auto load_halo = [&](int c) {
+  auto load_halo = [&](int cc) {
+    const int dt = p.kd > 1 ? cc / nchunks : 0, c = cc - dt * nchunks;
+    const int64_t soff = (p.kd > 1 ? (int64_t)(p.dshift0 + dt) * p.dplane : 0) + c * CK;
 #pragma unroll
     for (int r = 0; r < HR; ++r)
-      hreg[r] = hok[r] ? ldg4(p.x + hoff[r] + c * CK) : make_float4(0.f, 0.f, 0.f, 0.f);
+      hreg[r] = hok[r] ? ldg4(p.x + hoff[r] + soff) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   auto store_halo = [&](int buf) {
 #pragma unroll
     for (int r = 0; r < HR; ++r)
       if (hlds[r] >= 0) *reinterpret_cast<float4*>(&halo[buf * HALO_F + hlds[r]]) = hreg[r];
   };
-  auto load_w = [&](int c, int t) {
-    const float* base = p.wp + ((int64_t)t * cin4 + c * (CK / 4)) * p.Cout * 4;
+  auto load_w = [&](int cc, int t) {
+    const int dt = p.kd > 1 ? cc / nchunks : 0, c = cc - dt * nchunks;
+    const float* base = p.wp + ((int64_t)(dt * 9 + t) * cin4 + c * (CK / 4)) * p.Cout * 4;
 #pragma unroll
     for (int r = 0; r < WR; ++r)
       if (tid + r * NT < WF4) wreg[r] = ldg4(base + woff[r]);
@@ -133,18 +148,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-  const int nchunks = p.Cin / CK;
-
-  load_halo(0);
-  load_w(0, 0);
+  load_halo(c_begin);
+  load_w(c_begin, 0);
   store_halo(0);
   store_w(0);
   __syncthreads();
 
   int step = 0;
-  for (int c = 0; c < nchunks; ++c) {
-    const float* hb = halo + (c & 1) * HALO_F;
-    const bool more_chunks = (c + 1 < nchunks);
+  for (int c = c_begin; c < c_end; ++c) {
+    const float* hb = halo + ((c - c_begin) & 1) * HALO_F;
+    const bool more_chunks = (c + 1 < c_end);
 #pragma unroll
     for (int t = 0; t < 9; ++t, ++step) {
       const bool has_next = (t < 8) || more_chunks;
@@ -174,7 +187,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p
       }
 
       if (has_next) store_w((step + 1) & 1);
-      if (t == 5 && more_chunks) store_halo((c + 1) & 1);
+      if (t == 5 && more_chunks) store_halo((c + 1 - c_begin) & 1);
       __syncthreads();
     }
   }

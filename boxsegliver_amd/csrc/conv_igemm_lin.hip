@@ -126,7 +126,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
     hlds[r] = slot < npix ? slot * PS + q * 4 : -1;
     hdep[r] = plane % p.spg;
   }
-  const int KD = (!GEN && p.kd > 1) ? p.kd : 1;
+  const int KD = ((!GEN || FUSED) && p.kd > 1) ? p.kd : 1;   // fused depth taps: plain variant and the four-class GEN variant
   const int cin4 = p.Cin >> 2;
   int64_t woff[WR];
 #pragma unroll
@@ -200,9 +200,9 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
   if constexpr (GEN && FUSED) {
     constexpr int NTAPS[4] = {4, 2, 2, 1}, KBASE[4] = {0, 4, 6, 8};
     int step = 0;
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = 0; c < KD * nchunks; ++c) {                  // (depth tap, 16-channel chunk) pairs
       const float* hb = halo + (c & 1) * HALO_F;
-      const bool more_chunks = c + 1 < nchunks;
+      const bool more_chunks = c + 1 < KD * nchunks;
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
 #pragma unroll
@@ -644,7 +644,7 @@ int unetk_conv_run_lin_gen(ConvParams p, hipStream_t st) {
     p.n_ntiles = p.Cout / 32;                                     // UNet3D conv_e1/conv1: dx has 32 channels
     return launch_lin<4, 1, 1, 1, true, true>(p, n_mt, st);
   }
-  if (p.Cout % 64 != 0) return UNETK_E_UNSUPPORTED;
+  if (p.Cout % 64 != 0 || p.kd > 1) return UNETK_E_UNSUPPORTED;   // fused depth taps exist in the four-class variant only
   const int n_mtiles = unetk_conv_stat_rows_lin(p.N, p.H, p.W, p.spg, 0);
   p.stat_rows = n_mtiles;
   p.lin_pix = lin_rows_bound(p.H, p.W) * (p.W + 2);
