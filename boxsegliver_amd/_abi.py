@@ -69,6 +69,9 @@ _SIGNATURES = {
     "unetk_conv3x3_stat_rows": (c_int, [POINTER(ConvDesc)]),
     "unetk_conv3x3_fwd": (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
     "unetk_conv3x3_dgrad": (c_int, [POINTER(ConvDesc), P, P, P, P]),
+    "unetk_conv3x3_ws_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "unetk_conv3x3_fwd_ws": (c_int, [POINTER(ConvDesc), P, P, P, P, P, c_size_t, P]),
+    "unetk_conv3x3_dgrad_ws": (c_int, [POINTER(ConvDesc), P, P, P, P, c_size_t, P]),
     "unetk_conv3x3_dgrad_nbr_rows": (c_int, [POINTER(ConvDesc)]),
     "unetk_conv3x3_dgrad_nbr": (c_int, [POINTER(ConvDesc), P, P, P, P, c_int, P, P, P, P, c_int, P, P]),
     "unetk_conv3x3_wgrad_ws_bytes": (c_size_t, [POINTER(ConvDesc)]),

@@ -604,8 +604,20 @@ extern "C" int unetk_conv3x3_stat_rows(const unetk_conv_desc* d) {
   return unetk_conv_stat_rows(d->N, d->H, d->W, d->Cin, d->Cout);
 }
 
+extern "C" size_t unetk_conv3x3_ws_bytes(const unetk_conv_desc* d) {
+  if (!conv_desc_ok(d) || d->precision != UNETK_FP32 || d->dilation > 1) return 0;
+  const size_t f = unetk_conv_lin_sk_bytes(d->N, d->H, d->W, d->Cin, d->Cout, 1, 1);
+  const size_t b = unetk_conv_lin_sk_bytes(d->N, d->H, d->W, d->Cout, d->Cin, 1, 1);
+  return f > b ? f : b;
+}
+
 extern "C" int unetk_conv3x3_fwd(const unetk_conv_desc* d, const void* x, const void* w, void* y,
                                  float* stat_partials, void* stream) {
+  return unetk_conv3x3_fwd_ws(d, x, w, y, stat_partials, nullptr, 0, stream);
+}
+
+extern "C" int unetk_conv3x3_fwd_ws(const unetk_conv_desc* d, const void* x, const void* w, void* y,
+                                    float* stat_partials, void* ws, size_t ws_bytes, void* stream) {
   UNETK_REQUIRE(conv_desc_ok(d) && x && w && y);
   UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(w) && unetk_aligned16(y));
   UNETK_REQUIRE(d->y_stride % 4 == 0);
@@ -624,11 +636,17 @@ extern "C" int unetk_conv3x3_fwd(const unetk_conv_desc* d, const void* x, const 
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.xs = d->x_stride; p.ys = d->y_stride;
   p.xa = unetk_dense_addr(p.H, p.W, p.xs);
   p.ya = unetk_dense_addr(p.H, p.W, p.ys);
+  if (ws && unetk_aligned16(ws) && ws_bytes > 0) { p.sk_slab = (float*)ws; p.sk_slab_bytes = ws_bytes; }
   return unetk_conv_run(p, (hipStream_t)stream);
 }
 
 extern "C" int unetk_conv3x3_dgrad(const unetk_conv_desc* d, const void* dy, const void* w, void* dx,
                                    void* stream) {
+  return unetk_conv3x3_dgrad_ws(d, dy, w, dx, nullptr, 0, stream);
+}
+
+extern "C" int unetk_conv3x3_dgrad_ws(const unetk_conv_desc* d, const void* dy, const void* w, void* dx, void* ws,
+                                      size_t ws_bytes, void* stream) {
   UNETK_REQUIRE(conv_desc_ok(d) && dy && w && dx);
   UNETK_REQUIRE(unetk_aligned16(dy) && unetk_aligned16(w) && unetk_aligned16(dx));
   // dgrad = conv3x3 with Cin <-> Cout on the packed, tap-flipped filters
@@ -643,6 +661,7 @@ extern "C" int unetk_conv3x3_dgrad(const unetk_conv_desc* d, const void* dy, con
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cout; p.Cout = d->Cin; p.xs = d->y_stride; p.ys = d->x_stride;
   p.xa = unetk_dense_addr(p.H, p.W, p.xs);
   p.ya = unetk_dense_addr(p.H, p.W, p.ys);
+  if (ws && unetk_aligned16(ws) && ws_bytes > 0) { p.sk_slab = (float*)ws; p.sk_slab_bytes = ws_bytes; }
   return unetk_conv_run(p, (hipStream_t)stream);
 }
 

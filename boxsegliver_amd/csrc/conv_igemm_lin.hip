@@ -589,7 +589,11 @@ bool unetk_conv_lin_ok(int N, int H, int W, int Cin, int Cout, int spg) {
   const int64_t gpix = (int64_t)spg * H * W;
   const int64_t lin = (gpix + LIN_BM - 1) / LIN_BM * LIN_BM;                                   // MFMA rows issued per group
   const int64_t tiled = (int64_t)spg * ((H + 7) / 8) * 8 * ((W + 15) / 16) * 16;
-  if (lin * 10 > tiled * 9) return false;
+  // ... or when the tiled kernel's grid cannot fill the chip (the 16 x 16 bridge of a 2-D net at 8 slices per GPU: 128 or
+  // 256 blocks of 64 pixels x 128 couts for 256 CUs, 47-100 TFLOP/s): this kernel has the stream-K schedule
+  const int64_t tiled_blocks = (int64_t)(N / spg) * tiled / 64 * (Cout / (Cout % 128 == 0 ? 128 : 64));
+  const bool starved = Cout % 128 == 0 && tiled_blocks <= 256 && gpix % 64 == 0;
+  if (lin * 10 > tiled * 9 && !starved) return false;
   const int rows = (LIN_BM + W - 1) / W + 1 + 2 + 2 * ((LIN_BM + H * W - 1) / (H * W));
   return rows * (W + 2) <= LIN_MAXPIX;
 }
@@ -675,8 +679,10 @@ SkPlan sk_plan(int N, int H, int W, int Cin, int Cout, int spg, int kd) {
   s.tiles = n_mt * (Cout / bn);
   s.nc = (kd > 1 ? kd : 1) * (Cin / CK);
   const double eff = (double)s.tiles / (double)(((s.tiles + 255) / 256) * 256);
-  if (s.tiles >= 2048 || eff >= 0.92) return s;
-  s.whole = s.tiles / 256 * 256;                         // full rounds run one whole tile per block
+  // (up to one tile per CU the K range is always split: a lone 4-wave block per CU runs at ~100 TFLOP/s, two half-K blocks
+  // at more)
+  if (s.tiles >= 2048 || (s.tiles > 256 && eff >= 0.92)) return s;
+  s.whole = s.tiles <= 256 ? 0 : s.tiles / 256 * 256;    // full rounds run one whole tile per block
   const int rem = s.tiles - s.whole;
   // measured (UNet3D, one patch): a remainder of 176 tiles with K >= 48 chunks gains 10-12 %, 96 tiles or K = 24 chunks
   // do not pay for the slab round trip and the fix-up launch

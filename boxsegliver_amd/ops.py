@@ -231,10 +231,12 @@ def conv3x3_fwd(x, w, cout, want_stats=True, y=None, bf16=False, dilation=1):
         if rows <= 0:
             check(rows, "conv3x3_stat_rows")
         stats = torch.empty((2, rows, cout), dtype=torch.float32, device=x.device)
+    nws = _abi.lib().unetk_conv3x3_ws_bytes(ctypes.byref(d)) if prec == _abi.FP32 else 0     # stream-K scratch (small planes)
+    ws = WORKSPACE.get(nws, x.device) if nws else None
     with _Timed(_igemm_tag(cin, cout, bf16, h, n, wd), 18.0 * n * h * wd * cin * cout,
                 "fwd {}x{}x{} {}->{}".format(n, h, wd, cin, cout)):
-        check(_abi.lib().unetk_conv3x3_fwd(ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(stats), stream_ptr()),
-              "conv3x3_fwd")
+        check(_abi.lib().unetk_conv3x3_fwd_ws(ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(stats), ptr(ws), nws,
+                                              stream_ptr()), "conv3x3_fwd")
     return y, stats, rows
 
 
@@ -261,8 +263,10 @@ def conv3x3_dgrad(dy, wp_dgrad, cin, x_stride=None, dx=None, bf16=False, dilatio
                       "conv3x3_dgrad_nbr")
             FUSED_NBR[dx.data_ptr()] = (py.data_ptr(), tuple(dx.shape), part, rows)
             return dx
+    nws = _abi.lib().unetk_conv3x3_ws_bytes(ctypes.byref(d)) if prec == _abi.FP32 else 0
+    ws = WORKSPACE.get(nws, dy.device) if nws else None
     with _Timed(_igemm_tag(cout, cin, bf16, h, n, wd), 18.0 * n * h * wd * cin * cout, "dgrad {}x{}x{} {}->{}".format(n, h, wd, cout, cin)):
-        check(_abi.lib().unetk_conv3x3_dgrad(ctypes.byref(d), ptr(dy), ptr(wp_dgrad), ptr(dx), stream_ptr()),
+        check(_abi.lib().unetk_conv3x3_dgrad_ws(ctypes.byref(d), ptr(dy), ptr(wp_dgrad), ptr(dx), ptr(ws), nws, stream_ptr()),
               "conv3x3_dgrad")
     return dx
 

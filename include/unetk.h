@@ -111,6 +111,16 @@ int unetk_conv3x3_fwd(const unetk_conv_desc* d, const void* x, const void* w, vo
 int unetk_conv3x3_dgrad(const unetk_conv_desc* d, const void* dy, const void* w, void* dx,
                         void* stream);
 
+/* unetk_conv3x3_fwd / _dgrad with a scratch buffer: small planes whose tile grid cannot fill the 256 CUs (the 16 x 16 bridge
+ * of a 2-D net at 8 slices per GPU) are scheduled stream-K -- the (tile, K-chunk) sequence split evenly over the blocks,
+ * pieces of split tiles summed in a fixed order from ws (deterministic).  unetk_conv3x3_ws_bytes = bytes the two calls may
+ * use for this shape (0 = never); ws = NULL behaves as the plain entry points. */
+size_t unetk_conv3x3_ws_bytes(const unetk_conv_desc* d);
+int unetk_conv3x3_fwd_ws(const unetk_conv_desc* d, const void* x, const void* w, void* y, float* stat_partials,
+                         void* ws, size_t ws_bytes, void* stream);
+int unetk_conv3x3_dgrad_ws(const unetk_conv_desc* d, const void* dy, const void* w, void* dx, void* ws,
+                           size_t ws_bytes, void* stream);
+
 /* The same input gradient, fused with the norm-backward REDUCTION of the unit that produced the conv's input (the
  * slim.repeat(x, 2, slim.conv2d, ...) pairs of UNet.py:79,85,94: conv2's dx is the dz of conv1's norm + ReLU): while the
  * dx tile is in registers the epilogue reads prod_y (conv1's raw output, same [N,H,W,Cin], pixel stride prod_y_stride;
