@@ -59,6 +59,8 @@ class ParamStore(object):
             layout[grp].append(name)
             sizes[grp] += _align4(n)
         self.flat = {g: torch.zeros(max(sizes[g], 4), dtype=torch.float32, device=device) for g in sizes}
+        for g in ("reg", "noreg"):                        # filters that are views of these keep their packed forms (ops._PackCache)
+            ops.register_param_buffer(self.flat[g])
         self.grad = {g: torch.zeros_like(self.flat[g]) for g in ("reg", "noreg")}
         self.tensors = OrderedDict()
         for name, shape, kind in self.specs:

@@ -64,6 +64,8 @@ _SIGNATURES = {
     "unetk_abi_version": (c_int, []),
     "unetk_error_string": (c_char_p, [c_int]),
     "unetk_conv3x3_pack": (c_int, [P, c_int, c_int, P, P, P]),
+    "unetk_pack_item_blocks": (c_int, [c_int, c_int, c_int]),
+    "unetk_pack_many": (c_int, [P, c_int, c_int, P]),
     "unetk_conv3x3_pack_bf16": (c_int, [P, c_int, c_int, P, P, P]),
     "unetk_conv3x3_pack_bf16s": (c_int, [P, c_int, c_int, P, P, P]),
     "unetk_conv3x3_stat_rows": (c_int, [POINTER(ConvDesc)]),

@@ -14,6 +14,7 @@
 // Algorithmic bytes per block-step are tiny next to the 64-cycle fp32 MFMA, so the kernel is
 // MFMA-issue bound by construction; the roofline that bounds it is the fp32 matrix peak.
 #include "common.h"
+#include "pack.h"
 
 namespace {
 
@@ -397,26 +398,8 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, int Cin, int Co
                                     float* __restrict__ wp_fwd, float* __restrict__ wp_dgrad) {
   const int64_t total = (int64_t)9 * Cin * Cout / 4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    if (wp_fwd != nullptr) {
-      // i -> (t, q, n): K = Cin, N = Cout
-      const int n = (int)(i % Cout);
-      const int64_t r = i / Cout;
-      const int q = (int)(r % (Cin / 4));
-      const int t = (int)(r / (Cin / 4));
-      const float* s = w + ((int64_t)t * Cin + 4 * q) * Cout + n;
-      stg4(wp_fwd + i * 4, make_float4(s[0], s[Cout], s[2 * (int64_t)Cout], s[3 * (int64_t)Cout]));
-    }
-    if (wp_dgrad != nullptr) {
-      // i -> (t, q, n): K = Cout, N = Cin
-      const int n = (int)(i % Cin);
-      const int64_t r = i / Cin;
-      const int q = (int)(r % (Cout / 4));
-      const int t = (int)(r / (Cout / 4));
-      const float* s = w + ((int64_t)(8 - t) * Cin + n) * Cout + 4 * q;
-      stg4(wp_dgrad + i * 4, make_float4(s[0], s[1], s[2], s[3]));
-    }
-  }
+       i += (int64_t)gridDim.x * blockDim.x)
+    unetk_pack::conv3x3_f32(w, Cin, Cout, wp_fwd, wp_dgrad, i);      // csrc/pack.h
 }
 
 struct ConvCfg {

@@ -19,6 +19,7 @@
 // (unetk_conv3x3_pack_bf16s) permutes the output channels inside every 64-channel block: MFMA column l of tile tn holds
 // channel 2 l + tn.
 #include "common.h"
+#include "pack.h"
 
 namespace {
 
@@ -301,37 +302,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
 __global__ void pack_conv3x3_bf16_kernel(const float* __restrict__ w, int Cin, int Cout, uint4* __restrict__ wp_fwd,
                                          uint4* __restrict__ wp_dgrad, int perm) {
   const int64_t total = (int64_t)9 * Cin * Cout / 8;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    if (wp_fwd != nullptr) {
-      int n = (int)(i % Cout);
-      if (perm) n = (n & ~63) + 2 * (n & 31) + ((n >> 5) & 1);
-      const int64_t r = i / Cout;
-      const int q = (int)(r % (Cin / 8));
-      const int t = (int)(r / (Cin / 8));
-      const float* s = w + ((int64_t)t * Cin + 8 * q) * Cout + n;
-      const int64_t cs = Cout;
-      uint4 v;
-      v.x = pk_bf16(s[0], s[cs]);
-      v.y = pk_bf16(s[2 * cs], s[3 * cs]);
-      v.z = pk_bf16(s[4 * cs], s[5 * cs]);
-      v.w = pk_bf16(s[6 * cs], s[7 * cs]);
-      wp_fwd[i] = v;
-    }
-    if (wp_dgrad != nullptr) {
-      int n = (int)(i % Cin);
-      if (perm) n = (n & ~63) + 2 * (n & 31) + ((n >> 5) & 1);
-      const int64_t r = i / Cin;
-      const int q = (int)(r % (Cout / 8));
-      const int t = (int)(r / (Cout / 8));
-      const float* s = w + ((int64_t)(8 - t) * Cin + n) * Cout + 8 * q;
-      uint4 v;
-      v.x = pk_bf16(s[0], s[1]);
-      v.y = pk_bf16(s[2], s[3]);
-      v.z = pk_bf16(s[4], s[5]);
-      v.w = pk_bf16(s[6], s[7]);
-      wp_dgrad[i] = v;
-    }
-  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    unetk_pack::conv3x3_bf16(w, Cin, Cout, wp_fwd, wp_dgrad, perm, i);   // csrc/pack.h
 }
 
 struct BfCfg {

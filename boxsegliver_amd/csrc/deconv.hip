@@ -11,6 +11,7 @@
 //   dgrad   : M = input pixels, N = ci,       K = (b,c,co) A rows gathered from the 4 output pixels
 //   wgrad   : per (a,b,c): [co x ci] = sum_pixels dpre[pix(a,b,c)][co] * x[pix][ci]  (split-K slabs, fixed order)
 #include "common.h"
+#include "pack.h"
 
 namespace {
 
@@ -691,50 +692,15 @@ __global__ __launch_bounds__(256) void deconv_wgrad_bf16s_kernel(DwParams p) {
 __global__ void pack_deconv_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ wp_fwd,
                                    float* __restrict__ wp_dgrad) {
   const int64_t total = (int64_t)Cin * Cout;  // float4 count = 4*Cin*Cout/4
-  const int Nf = 4 * Cout;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    if (wp_fwd != nullptr) {
-      const int n = (int)(i % Nf);
-      const int q = (int)(i / Nf);
-      stg4(wp_fwd + i * 4, ldg4(w + (int64_t)n * Cin + 4 * q));
-    }
-    if (wp_dgrad != nullptr) {
-      const int n = (int)(i % Cin);
-      const int q = (int)(i / Cin);
-      const float* s = w + (int64_t)(4 * q) * Cin + n;
-      stg4(wp_dgrad + i * 4, make_float4(s[0], s[Cin], s[2 * (int64_t)Cin], s[3 * (int64_t)Cin]));
-    }
-  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    unetk_pack::deconv_f32(w, Cin, Cout, wp_fwd, wp_dgrad, i);        // csrc/pack.h
 }
 
-// bf16 packs: wp_fwd[q][n=(bc,co)][j] = bf16(w[bc][co][8q+j]) (K = Cin); wp_dgrad[q][n=ci][j] = bf16(w_flat[8q+j][ci])
-// perm (UNETK_BF16S): column position n' of every 64-column block holds GEMM column 2 (n' & 31) + (n' >> 5 & 1).
 __global__ void pack_deconv_bf16_kernel(const float* __restrict__ w, int Cin, int Cout, uint4* __restrict__ wp_fwd,
                                         uint4* __restrict__ wp_dgrad, int perm) {
   const int64_t total = (int64_t)Cin * Cout / 2;  // 16-B units = 4*Cin*Cout/8
-  const int Nf = 4 * Cout;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    if (wp_fwd != nullptr) {
-      int n = (int)(i % Nf);
-      if (perm) n = (n & ~63) + 2 * (n & 31) + ((n >> 5) & 1);
-      const int q = (int)(i / Nf);
-      const float* s = w + (int64_t)n * Cin + 8 * q;
-      uint4 v;
-      v.x = pk_bf16(s[0], s[1]); v.y = pk_bf16(s[2], s[3]); v.z = pk_bf16(s[4], s[5]); v.w = pk_bf16(s[6], s[7]);
-      wp_fwd[i] = v;
-    }
-    if (wp_dgrad != nullptr) {
-      int n = (int)(i % Cin);
-      if (perm) n = (n & ~63) + 2 * (n & 31) + ((n >> 5) & 1);
-      const int q = (int)(i / Cin);
-      const float* s = w + (int64_t)(8 * q) * Cin + n;
-      const int64_t cs = Cin;
-      uint4 v;
-      v.x = pk_bf16(s[0], s[cs]); v.y = pk_bf16(s[2 * cs], s[3 * cs]);
-      v.z = pk_bf16(s[4 * cs], s[5 * cs]); v.w = pk_bf16(s[6 * cs], s[7 * cs]);
-      wp_dgrad[i] = v;
-    }
-  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    unetk_pack::deconv_bf16(w, Cin, Cout, wp_fwd, wp_dgrad, perm, i);  // csrc/pack.h
 }
 
 template <int MODE, int WM, int WN, int TM, int TN, bool BS = false>

@@ -111,7 +111,7 @@ extern "C" int unetk_sumsq(const float* p, int64_t n, float* out, void* ws, size
   return UNETK_OK;
 }
 
-extern "C" int unetk_abi_version(void) { return 7; }   // 2: unetk_conv_desc.precision, UNETK_BF16; 3: density modulation, unetk_fc_*; 4: unetk_conv_desc.dilation; 5: UNETK_BF16S (bf16 storage), unetk_norm_desc.storage, unetk_head_desc.storage; 6: norm dropout / guide_alpha / guide_per_sample, unetk_norm_se_bwd_add, fc sigmoid; 7: unetk_conv3x3_dgrad_nbr, unetk_norm_relu_bwd_pre, unetk_conv1d_*, unetk_maxpool1d_*, unetk_spatial_mean_*
+extern "C" int unetk_abi_version(void) { return 7; }   // 2: unetk_conv_desc.precision, UNETK_BF16; 3: density modulation, unetk_fc_*; 4: unetk_conv_desc.dilation; 5: UNETK_BF16S (bf16 storage), unetk_norm_desc.storage, unetk_head_desc.storage; 6: norm dropout / guide_alpha / guide_per_sample, unetk_norm_se_bwd_add, fc sigmoid; 7: unetk_conv3x3_dgrad_nbr, unetk_norm_relu_bwd_pre, unetk_conv1d_*, unetk_maxpool1d_*, unetk_spatial_mean_*, unetk_conv3x3_*_ws, unetk_pack_many
 
 extern "C" const char* unetk_error_string(int code) {
   switch (code) {

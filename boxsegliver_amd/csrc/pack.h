@@ -1,0 +1,115 @@
+// Filter re-layouts ("packs") of the matrix kernels as per-item device functions, shared by the single-filter pack
+// kernels (conv_igemm.hip, conv_igemm_bf16.hip, deconv.hip) and the batched unetk_pack_many (pack.hip).
+// Item i of a filter = one 16-byte unit of the packed result.
+#pragma once
+#include "common.h"
+
+namespace unetk_pack {
+
+__device__ __forceinline__ uint32_t pk2(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// UNETK_BF16S: column position n' of every 64-column block holds output channel 2 (n' & 31) + (n' >> 5 & 1)
+__device__ __forceinline__ int perm64(int n) { return (n & ~63) + 2 * (n & 31) + ((n >> 5) & 1); }
+
+// conv3x3 fp32, K4-interleaved: wp[t][q][n][j] = B_t[k = 4q + j][n]; forward B_t[ci][co] = w[t][ci][co],
+// dgrad B_t[co][ci] = w[8 - t][ci][co].  Items: 9 * Cin * Cout / 4.
+__device__ __forceinline__ void conv3x3_f32(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ wp_fwd,
+                                            float* __restrict__ wp_dgrad, int64_t i) {
+  if (wp_fwd != nullptr) {
+    const int n = (int)(i % Cout);
+    const int64_t r = i / Cout;
+    const int q = (int)(r % (Cin / 4));
+    const int t = (int)(r / (Cin / 4));
+    const float* s = w + ((int64_t)t * Cin + 4 * q) * Cout + n;
+    stg4(wp_fwd + i * 4, make_float4(s[0], s[Cout], s[2 * (int64_t)Cout], s[3 * (int64_t)Cout]));
+  }
+  if (wp_dgrad != nullptr) {
+    const int n = (int)(i % Cin);
+    const int64_t r = i / Cin;
+    const int q = (int)(r % (Cout / 4));
+    const int t = (int)(r / (Cout / 4));
+    const float* s = w + ((int64_t)(8 - t) * Cin + n) * Cout + 4 * q;
+    stg4(wp_dgrad + i * 4, make_float4(s[0], s[1], s[2], s[3]));
+  }
+}
+
+// conv3x3 bf16, K8-interleaved: wp[t][q][n][j] = bf16(B_t[k = 8q + j][n]).  Items: 9 * Cin * Cout / 8.
+__device__ __forceinline__ void conv3x3_bf16(const float* __restrict__ w, int Cin, int Cout, uint4* __restrict__ wp_fwd,
+                                             uint4* __restrict__ wp_dgrad, int perm, int64_t i) {
+  if (wp_fwd != nullptr) {
+    int n = (int)(i % Cout);
+    if (perm) n = perm64(n);
+    const int64_t r = i / Cout;
+    const int q = (int)(r % (Cin / 8));
+    const int t = (int)(r / (Cin / 8));
+    const float* s = w + ((int64_t)t * Cin + 8 * q) * Cout + n;
+    const int64_t cs = Cout;
+    uint4 v;
+    v.x = pk2(s[0], s[cs]);
+    v.y = pk2(s[2 * cs], s[3 * cs]);
+    v.z = pk2(s[4 * cs], s[5 * cs]);
+    v.w = pk2(s[6 * cs], s[7 * cs]);
+    wp_fwd[i] = v;
+  }
+  if (wp_dgrad != nullptr) {
+    int n = (int)(i % Cin);
+    if (perm) n = perm64(n);
+    const int64_t r = i / Cin;
+    const int q = (int)(r % (Cout / 8));
+    const int t = (int)(r / (Cout / 8));
+    const float* s = w + ((int64_t)(8 - t) * Cin + n) * Cout + 8 * q;
+    uint4 v;
+    v.x = pk2(s[0], s[1]);
+    v.y = pk2(s[2], s[3]);
+    v.z = pk2(s[4], s[5]);
+    v.w = pk2(s[6], s[7]);
+    wp_dgrad[i] = v;
+  }
+}
+
+// k = s transposed conv (one depth tap), w = TF [2][2][Cout][Cin].  fp32 items: Cin * Cout; bf16 items: Cin * Cout / 2.
+__device__ __forceinline__ void deconv_f32(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ wp_fwd,
+                                           float* __restrict__ wp_dgrad, int64_t i) {
+  const int Nf = 4 * Cout;
+  if (wp_fwd != nullptr) {
+    const int n = (int)(i % Nf);
+    const int q = (int)(i / Nf);
+    stg4(wp_fwd + i * 4, ldg4(w + (int64_t)n * Cin + 4 * q));
+  }
+  if (wp_dgrad != nullptr) {
+    const int n = (int)(i % Cin);
+    const int q = (int)(i / Cin);
+    const float* s = w + (int64_t)(4 * q) * Cin + n;
+    stg4(wp_dgrad + i * 4, make_float4(s[0], s[Cin], s[2 * (int64_t)Cin], s[3 * (int64_t)Cin]));
+  }
+}
+
+__device__ __forceinline__ void deconv_bf16(const float* __restrict__ w, int Cin, int Cout, uint4* __restrict__ wp_fwd,
+                                            uint4* __restrict__ wp_dgrad, int perm, int64_t i) {
+  const int Nf = 4 * Cout;
+  if (wp_fwd != nullptr) {
+    int n = (int)(i % Nf);
+    if (perm) n = perm64(n);
+    const int q = (int)(i / Nf);
+    const float* s = w + (int64_t)n * Cin + 8 * q;
+    uint4 v;
+    v.x = pk2(s[0], s[1]); v.y = pk2(s[2], s[3]); v.z = pk2(s[4], s[5]); v.w = pk2(s[6], s[7]);
+    wp_fwd[i] = v;
+  }
+  if (wp_dgrad != nullptr) {
+    int n = (int)(i % Cin);
+    if (perm) n = perm64(n);
+    const int q = (int)(i / Cin);
+    const float* s = w + (int64_t)(8 * q) * Cin + n;
+    const int64_t cs = Cin;
+    uint4 v;
+    v.x = pk2(s[0], s[cs]); v.y = pk2(s[2 * cs], s[3 * cs]);
+    v.z = pk2(s[4 * cs], s[5 * cs]); v.w = pk2(s[6 * cs], s[7 * cs]);
+    wp_dgrad[i] = v;
+  }
+}
+
+}  // namespace unetk_pack

@@ -44,6 +44,99 @@ PROFILE_SHAPES = False  # bench.py --detail: one row per (kernel, layer shape)
 PROFILE = None          # bench.py: set to a list -> (kernel tag, algorithmic FLOPs, start event, end event)
 
 
+# ----------------------------------------------------------------------------- packed-filter cache
+PACK_BATCH = True       # re-pack every known filter in ONE launch (unetk_pack_many) after the variables changed
+PARAM_GEN = 0           # bumped by the kernels that write variables behind torch's back (optimiser steps, broadcasts)
+_PARAM_FLATS = {}       # storage data_ptr of a ParamStore's flat buffer -> weakref to that tensor
+
+
+def register_param_buffer(flat):
+    """ParamStore: filters that are views of `flat` may keep their packed forms between steps."""
+    import weakref
+    _PARAM_FLATS[flat.untyped_storage().data_ptr()] = weakref.ref(flat)
+
+
+def bump_param_gen():
+    global PARAM_GEN
+    PARAM_GEN += 1
+
+
+class _PackItem(ctypes.Structure):            # unetk_pack_item
+    _fields_ = [("kind", ctypes.c_int32), ("perm", ctypes.c_int32), ("Cin", ctypes.c_int32), ("Cout", ctypes.c_int32),
+                ("block0", ctypes.c_int32), ("nblocks", ctypes.c_int32), ("r0", ctypes.c_int32), ("r1", ctypes.c_int32),
+                ("w", ctypes.c_void_p), ("wp_fwd", ctypes.c_void_p), ("wp_dgrad", ctypes.c_void_p), ("r2", ctypes.c_void_p)]
+
+
+class _PackCache(object):
+    """Packed filters of the variables, kept between calls and rebuilt together.  An entry is valid while neither torch
+    (the flat buffer's version counter) nor the optimiser kernels (PARAM_GEN) have written the variables since it was
+    packed.  Only views of a registered ParamStore buffer are cached; anything else is packed on the spot."""
+
+    def __init__(self):
+        self.entries = {}          # key -> dict(flat=weakref, gen, wp_f, wp_d, items=[(kind, perm, cin, cout, w_ptr, f_ptr, d_ptr)])
+        self.table = None          # (device tensor, n_items, total_blocks) of ALL live entries
+        self.hits = self.batched = self.singles = 0
+
+    @staticmethod
+    def _flat_of(w):
+        ref = _PARAM_FLATS.get(w.untyped_storage().data_ptr())
+        return ref() if ref is not None else None
+
+    def get(self, w, key, build):
+        """build() -> (wp_f, wp_d, items): packs this filter alone.  Returns (wp_f, wp_d)."""
+        flat = self._flat_of(w) if PACK_BATCH else None
+        if flat is None:
+            wp_f, wp_d, _ = build()
+            return wp_f, wp_d
+        key = (w.data_ptr(), tuple(w.shape)) + tuple(key)
+        gen = (PARAM_GEN, flat._version)
+        ent = self.entries.get(key)
+        if ent is not None and ent["flat"]() is flat:
+            if ent["gen"] == gen:
+                self.hits += 1
+                return ent["wp_f"], ent["wp_d"]
+            self._repack_all()
+            if ent["gen"] == gen:
+                return ent["wp_f"], ent["wp_d"]
+        import weakref
+        wp_f, wp_d, items = build()
+        self.singles += 1
+        self.entries[key] = dict(flat=weakref.ref(flat), gen=gen, wp_f=wp_f, wp_d=wp_d, items=items)
+        self.table = None
+        return wp_f, wp_d
+
+    def _repack_all(self):
+        dead = [k for k, e in self.entries.items() if e["flat"]() is None]
+        for k in dead:
+            del self.entries[k]
+            self.table = None
+        live = list(self.entries.values())
+        if not live:
+            return
+        dev = live[0]["wp_f"].device
+        if self.table is None:
+            rows, block0 = [], 0
+            for e in live:
+                for kind, perm, cin, cout, w_ptr, f_ptr, d_ptr in e["items"]:
+                    nb = _abi.lib().unetk_pack_item_blocks(kind, cin, cout)
+                    if nb <= 0:
+                        check(nb, "pack_item_blocks")
+                    rows.append(_PackItem(kind, perm, cin, cout, block0, nb, 0, 0, w_ptr, f_ptr, d_ptr, None))
+                    block0 += nb
+            arr = (_PackItem * len(rows))(*rows)
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self.table = (host.to(dev), len(rows), block0)
+        tab, n_items, total = self.table
+        check(_abi.lib().unetk_pack_many(ptr(tab), n_items, total, stream_ptr()), "pack_many")
+        self.batched += 1
+        for e in live:
+            e["gen"] = (PARAM_GEN, e["flat"]()._version)
+
+
+PACKS = _PackCache()
+PK_CONV_F32, PK_CONV_BF16, PK_DECONV_F32, PK_DECONV_BF16 = 0, 1, 2, 3
+
+
 class _Timed(object):
     """HIP events on the CURRENT stream (the one the kernel is launched on) around one C-ABI call."""
 
@@ -190,20 +283,26 @@ def conv3x3_pack(w, want_dgrad=True, bf16=False):
     _require_cuda(w)
     kh, kw, cin, cout = w.shape
     assert kh == 3 and kw == 3
-    if bf16:
-        wp_f = torch.empty(9 * cin * cout, dtype=torch.bfloat16, device=w.device)
-        wp_d = torch.empty_like(wp_f) if want_dgrad else None
-        if int(bf16) == _abi.BF16S:          # output channels pair-permuted inside 64-blocks (conv_igemm_bf16.hip)
-            check(_abi.lib().unetk_conv3x3_pack_bf16s(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()),
-                  "conv3x3_pack_bf16s")
-            return wp_f, wp_d
-        check(_abi.lib().unetk_conv3x3_pack_bf16(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()),
-              "conv3x3_pack_bf16")
-        return wp_f, wp_d
-    wp_f = torch.empty(9 * cin * cout, dtype=torch.float32, device=w.device)
-    wp_d = torch.empty_like(wp_f) if want_dgrad else None
-    check(_abi.lib().unetk_conv3x3_pack(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()), "conv3x3_pack")
-    return wp_f, wp_d
+    prec = precision_of(bf16)
+
+    def build():
+        if prec:
+            wp_f = torch.empty(9 * cin * cout, dtype=torch.bfloat16, device=w.device)
+            wp_d = torch.empty_like(wp_f) if want_dgrad else None
+            if prec == _abi.BF16S:          # output channels pair-permuted inside 64-blocks (conv_igemm_bf16.hip)
+                check(_abi.lib().unetk_conv3x3_pack_bf16s(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()),
+                      "conv3x3_pack_bf16s")
+            else:
+                check(_abi.lib().unetk_conv3x3_pack_bf16(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()),
+                      "conv3x3_pack_bf16")
+            kind, perm = PK_CONV_BF16, 1 if prec == _abi.BF16S else 0
+        else:
+            wp_f = torch.empty(9 * cin * cout, dtype=torch.float32, device=w.device)
+            wp_d = torch.empty_like(wp_f) if want_dgrad else None
+            check(_abi.lib().unetk_conv3x3_pack(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()), "conv3x3_pack")
+            kind, perm = PK_CONV_F32, 0
+        return wp_f, wp_d, [(kind, perm, cin, cout, w.data_ptr(), wp_f.data_ptr(), wp_d.data_ptr() if want_dgrad else None)]
+    return PACKS.get(w, ("c3", prec, bool(want_dgrad)), build)
 
 
 def conv_uses_mfma(cin, cout):
@@ -315,10 +414,16 @@ def conv3d_pack(w, want_dgrad=True):
     _require_cuda(w)
     kd, kh, kw, cin, cout = w.shape
     assert kh == 3 and kw == 3
-    wp_f = torch.empty(kd * 9 * cin * cout, dtype=torch.float32, device=w.device)
-    wp_d = torch.empty_like(wp_f) if want_dgrad else None
-    check(_abi.lib().unetk_conv3d_pack(ptr(w), kd, cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()), "conv3d_pack")
-    return wp_f, wp_d
+
+    def build():
+        wp_f = torch.empty(kd * 9 * cin * cout, dtype=torch.float32, device=w.device)
+        wp_d = torch.empty_like(wp_f) if want_dgrad else None
+        check(_abi.lib().unetk_conv3d_pack(ptr(w), kd, cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()), "conv3d_pack")
+        tap = 9 * cin * cout * 4            # bytes per depth tap, source and packs alike
+        items = [(PK_CONV_F32, 0, cin, cout, w.data_ptr() + a * tap, wp_f.data_ptr() + a * tap,
+                  (wp_d.data_ptr() + a * tap) if want_dgrad else None) for a in range(kd)]
+        return wp_f, wp_d, items
+    return PACKS.get(w, ("c3d", 0, bool(want_dgrad)), build)
 
 
 def _ws3d(d, device):
@@ -499,20 +604,26 @@ def deconv2x2_pack(w, bf16=False):
     _require_cuda(w)
     kh, kw, cout, cin = w.shape
     assert kh == 2 and kw == 2
-    if bf16:
-        wp_f = torch.empty(4 * cin * cout, dtype=torch.bfloat16, device=w.device)
-        wp_d = torch.empty_like(wp_f)
-        if int(bf16) == _abi.BF16S:
-            check(_abi.lib().unetk_deconv2x2_pack_bf16s(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()),
-                  "deconv2x2_pack_bf16s")
-            return wp_f, wp_d
-        check(_abi.lib().unetk_deconv2x2_pack_bf16(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()),
-              "deconv2x2_pack_bf16")
-        return wp_f, wp_d
-    wp_f = torch.empty(4 * cin * cout, dtype=torch.float32, device=w.device)
-    wp_d = torch.empty_like(wp_f)
-    check(_abi.lib().unetk_deconv2x2_pack(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()), "deconv2x2_pack")
-    return wp_f, wp_d
+    prec = precision_of(bf16)
+
+    def build():
+        if prec:
+            wp_f = torch.empty(4 * cin * cout, dtype=torch.bfloat16, device=w.device)
+            wp_d = torch.empty_like(wp_f)
+            if prec == _abi.BF16S:
+                check(_abi.lib().unetk_deconv2x2_pack_bf16s(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()),
+                      "deconv2x2_pack_bf16s")
+            else:
+                check(_abi.lib().unetk_deconv2x2_pack_bf16(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()),
+                      "deconv2x2_pack_bf16")
+            kind, perm = PK_DECONV_BF16, 1 if prec == _abi.BF16S else 0
+        else:
+            wp_f = torch.empty(4 * cin * cout, dtype=torch.float32, device=w.device)
+            wp_d = torch.empty_like(wp_f)
+            check(_abi.lib().unetk_deconv2x2_pack(ptr(w), cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()), "deconv2x2_pack")
+            kind, perm = PK_DECONV_F32, 0
+        return wp_f, wp_d, [(kind, perm, cin, cout, w.data_ptr(), wp_f.data_ptr(), wp_d.data_ptr())]
+    return PACKS.get(w, ("d2", prec, True), build)
 
 
 def deconv2x2_fwd(x, wp_fwd, bias, cat, coff, cout, bf16=False):
@@ -555,10 +666,16 @@ def deconv3d_pack(w):
     _require_cuda(w)
     kd, kh, kw, cout, cin = w.shape
     assert kh == 2 and kw == 2 and kd in (1, 2)
-    wp_f = torch.empty(kd * 4 * cin * cout, dtype=torch.float32, device=w.device)
-    wp_d = torch.empty_like(wp_f)
-    check(_abi.lib().unetk_deconv3d_pack(ptr(w), kd, cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()), "deconv3d_pack")
-    return wp_f, wp_d
+
+    def build():
+        wp_f = torch.empty(kd * 4 * cin * cout, dtype=torch.float32, device=w.device)
+        wp_d = torch.empty_like(wp_f)
+        check(_abi.lib().unetk_deconv3d_pack(ptr(w), kd, cin, cout, ptr(wp_f), ptr(wp_d), stream_ptr()), "deconv3d_pack")
+        tap = 4 * cin * cout * 4
+        items = [(PK_DECONV_F32, 0, cin, cout, w.data_ptr() + a * tap, wp_f.data_ptr() + a * tap, wp_d.data_ptr() + a * tap)
+                 for a in range(kd)]
+        return wp_f, wp_d, items
+    return PACKS.get(w, ("d3d", 0, True), build)
 
 
 def _pix_stride_nd(t):
@@ -685,11 +802,13 @@ def lits_batch(slices, seg_slices, sample_tab, clip, out_hw, channels, lab_scale
 def adam_step(p, g, m, v, lr_t, beta1, beta2, eps, gscale=1.0, l2=0.0, decoupled_wd=0.0):
     check(_abi.lib().unetk_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr_t, beta1, beta2, eps, gscale, l2,
                                      decoupled_wd, stream_ptr()), "adam_step")
+    bump_param_gen()
 
 
 def momentum_step(p, g, acc, lr, mom, nesterov, gscale=1.0, l2=0.0):
     check(_abi.lib().unetk_momentum_step(ptr(p), ptr(g), ptr(acc), p.numel(), lr, mom, 1 if nesterov else 0, gscale,
                                          l2, stream_ptr()), "momentum_step")
+    bump_param_gen()
 
 
 def sumsq(p):

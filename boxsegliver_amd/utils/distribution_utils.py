@@ -65,6 +65,7 @@ class DistributionStrategy(object):
         if self.num_replicas_in_sync > 1:
             for t in tensors:
                 dist.broadcast(t, src=src)
+            ops.bump_param_gen()              # the variables changed behind torch's version counters' back
 
 
 class GradBuckets(object):

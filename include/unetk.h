@@ -83,6 +83,25 @@ typedef struct unetk_conv_desc {
 int unetk_conv3x3_pack(const float* w_hwio, int Cin, int Cout, float* wp_fwd, float* wp_dgrad,
                        void* stream);
 
+/* Every filter re-layout of a step in ONE launch.  An item = one filter tap-set: kind (which of the four packs above /
+ * below), perm (1 = the UNETK_BF16S channel-pair permutation), Cin, Cout, the TF-layout source w and the two outputs
+ * (either may be NULL), and the item's block range [block0, block0 + nblocks) inside the launch (nblocks from
+ * unetk_pack_item_blocks, block0 = running sum; items ascending).  `items_dev` is the table in DEVICE memory (16-byte
+ * aligned), total_blocks the sum of nblocks.  A 3-D filter is kd items (one per depth tap). */
+#define UNETK_PACK_CONV3X3_F32 0   /* unetk_conv3x3_pack */
+#define UNETK_PACK_CONV3X3_BF16 1  /* unetk_conv3x3_pack_bf16 (perm 0) / _bf16s (perm 1) */
+#define UNETK_PACK_DECONV_F32 2    /* one depth tap of unetk_deconv3d_pack / unetk_deconv2x2_pack */
+#define UNETK_PACK_DECONV_BF16 3   /* ... of the bf16 transposed-conv packs */
+typedef struct {
+  int32_t kind, perm, Cin, Cout, block0, nblocks, reserved0, reserved1;
+  const void* w;
+  void* wp_fwd;
+  void* wp_dgrad;
+  void* reserved2;
+} unetk_pack_item;
+int unetk_pack_item_blocks(int kind, int Cin, int Cout);
+int unetk_pack_many(const unetk_pack_item* items_dev, int n_items, int total_blocks, void* stream);
+
 /* UNETK_BF16 filters: bf16 "K8-interleaved" [tap][Cin/8][Cout][8]; each output holds 9*Cin*Cout bf16
  * (2 bytes each), 16-byte aligned.  Cin % 8 == 0 and Cout % 8 == 0. */
 int unetk_conv3x3_pack_bf16(const float* w_hwio, int Cin, int Cout, void* wp_fwd, void* wp_dgrad,
