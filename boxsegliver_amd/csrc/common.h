@@ -171,16 +171,23 @@ struct WgParams {
   // pixel (oh, ow) reads input rows stride*oh - pbh + kh.  stride 0 / 1 = plain conv (Hin = H, Win = W, pb = 1).
   int stride, Hin, Win, pbh, pbw;
   int dil;             // 2 = rate-2 atrous conv (slim.conv2d(..., rate=2), SmallUNet's bridge): taps at (2 kh, 2 kw), pad 2
+  // fused depth taps (kd > 1; the filter gradient of a (3,3,3) conv in ONE launch): block (.., dt, split) contracts dy plane i
+  // (output plane dep = i % spg of its sample) with the x plane at xa.off(i) + (dshift0 + dt) * dplane floats, i.e. input
+  // depth dep * dsd + dshift0 + dt (zeros outside [0, din)); its panel goes to slab [split][dt][9 Cin Cout], so one slab
+  // reduction over kd * 9 * Cin * Cout elements yields dw[kd][3][3][Cin][Cout].  With kd x the blocks per split, a third of
+  // the splits fills the chip: three times the tiles per block, a third of the slab traffic.
+  int kd, dshift0, dsd, din, spg;
+  int64_t dplane;
 };
 // conv_wgrad.hip: dw[9][Cin][Cout] = filter gradient of one 2-D tap plane; ws layout as unetk_conv3x3_wgrad
-size_t unetk_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout);
+size_t unetk_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int kd = 1);
 int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
 // conv_wgrad_bf16s.hip: UNETK_BF16S -- x and dy are bf16 in memory (x fp32 for the first layer, 9 * Cin <= 32)
 size_t unetk_wgrad_bf16s_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int unetk_wgrad_bf16s_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
 // stride-2 variant (p.stride == 2; p.H, p.W = output plane): fp32, Cin % 32 == 0 and Cout % 64 == 0
 bool unetk_wgrad_strided_ok(int Cin, int Cout);
-size_t unetk_wgrad_strided_ws_bytes(int N, int Ho, int Wo, int Cin, int Cout);
+size_t unetk_wgrad_strided_ws_bytes(int N, int Ho, int Wo, int Cin, int Cout, int kd = 1);
 // dst[i] = sum_s slab[s*n + i] in fixed order (n % 4 == 0).
 int unetk_launch_slab_reduce(const float* slab, int S, int64_t n, float* dst, hipStream_t st);
 // dst[k][c] = sum_rows src[k][row][c] (fp64 accumulate).  tmp: K*64*C floats when rows > 256.

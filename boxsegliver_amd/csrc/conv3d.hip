@@ -160,8 +160,14 @@ extern "C" size_t unetk_conv3d_ws_bytes(const unetk_conv3d_desc* d) {
   if (d->shw == 2) f += (size_t)d->N * g.Do * d->H * d->W * d->Cout;          // stride-1 result / dilated dy
   f = (f + 63) & ~(size_t)63;
   size_t bytes = f * sizeof(float) + unetk_wgrad_ws_bytes(d->N * g.Do, d->H, d->W, d->Cin, d->Cout);
+  if (d->shw == 1 && d->kd > 1) {   // fused depth taps (one launch for the whole (kd,3,3) filter gradient)
+    const size_t fb = unetk_wgrad_ws_bytes(d->N * g.Do, d->H, d->W, d->Cin, d->Cout, d->kd);
+    if (fb > bytes) bytes = fb;
+  }
   if (d->shw == 2) {
-    const size_t sb = unetk_wgrad_strided_ws_bytes(d->N * g.Do, g.Ho, g.Wo, d->Cin, d->Cout);
+    size_t sb = unetk_wgrad_strided_ws_bytes(d->N * g.Do, g.Ho, g.Wo, d->Cin, d->Cout);
+    if (sb > bytes) bytes = sb;
+    sb = unetk_wgrad_strided_ws_bytes(d->N * g.Do, g.Ho, g.Wo, d->Cin, d->Cout, d->kd);
     if (sb > bytes) bytes = sb;
   }
   if (d->shw == 1 && d->sd == 1) {   // stream-K slabs of the small-plane kernel, forward and input gradient
@@ -410,6 +416,18 @@ extern "C" int unetk_conv3d_wgrad(const unetk_conv3d_desc* d, const float* x, co
     // natively strided filter gradient: tiles of OUTPUT pixels, tap (kh, kw) of output (oh, ow) reads input
     // (2 oh - pb + kh, 2 ow - pb + kw); no zero-dilated copy of dy, a quarter of the MFMA work
     const int HWx = d->H * d->W * d->x_stride, HWy = g.Ho * g.Wo * d->y_stride;
+    if (d->kd == 3) {
+      // the three depth taps in ONE launch (WgParams::kd): every dy plane against the x plane each tap reads
+      WgParams p{};
+      p.x = x; p.dy = dy;
+      p.N = d->N * g.Do; p.H = g.Ho; p.W = g.Wo; p.Cin = d->Cin; p.Cout = d->Cout;
+      p.xs = d->x_stride; p.ys = d->y_stride;
+      p.stride = 2; p.Hin = d->H; p.Win = d->W; p.pbh = same_pb(d->H, 3, 2); p.pbw = same_pb(d->W, 3, 2);
+      p.xa = planes(HWx, g.Do, d->sd, d->D);
+      p.ya = planes(HWy, g.Do, 1, g.Do);
+      p.kd = 3; p.dshift0 = -g.pb_d; p.dsd = d->sd; p.din = d->D; p.spg = g.Do; p.dplane = HWx;
+      return unetk_wgrad_run(p, dw, ws, ws_bytes, st);
+    }
     for (int dt = 0; dt < d->kd; ++dt) {
       int lo, hi;
       tap_range(d, g, dt, &lo, &hi);
@@ -441,6 +459,18 @@ extern "C" int unetk_conv3d_wgrad(const unetk_conv3d_desc* d, const float* x, co
   float* wws = (float*)ws + zf;
   const size_t wws_bytes = ws_bytes - zf * sizeof(float);
   const int HWx = d->H * d->W * d->x_stride, HWz = d->H * d->W * zs;
+  if (d->kd == 3 && d->shw == 1 && unetk_wgrad_ws_bytes(d->N * g.Do, d->H, d->W, d->Cin, d->Cout, 3) > 0) {
+    // the three depth taps in ONE launch (WgParams::kd): a third of the splits fills the chip, so every block walks three
+    // times the tiles and the slab round trip shrinks accordingly
+    WgParams p{};
+    p.x = x; p.dy = Z;
+    p.N = d->N * g.Do; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
+    p.xs = d->x_stride; p.ys = zs;
+    p.xa = planes(HWx, g.Do, d->sd, d->D);
+    p.ya = planes(HWz, g.Do, 1, g.Do);
+    p.kd = 3; p.dshift0 = -g.pb_d; p.dsd = d->sd; p.din = d->D; p.spg = g.Do; p.dplane = HWx;
+    return unetk_wgrad_run(p, dw, wws, wws_bytes, st);
+  }
   for (int dt = 0; dt < d->kd; ++dt) {
     int lo, hi;
     tap_range(d, g, dt, &lo, &hi);

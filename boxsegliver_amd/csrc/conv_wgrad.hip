@@ -86,8 +86,11 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
   int bid = blockIdx.x;
   const int co_t = bid % p.n_co_tiles; bid /= p.n_co_tiles;
   const int ci_t = bid % p.n_ci_tiles; bid /= p.n_ci_tiles;
-  const int split = bid;
+  const int KD = p.kd > 1 ? p.kd : 1;                       // fused depth taps (WgParams::kd)
+  const int dt = bid % KD;
+  const int split = bid / KD;
   const int ci0 = ci_t * CIT, co0 = co_t * COT;
+  const int64_t x_dt = KD > 1 ? (int64_t)(p.dshift0 + dt) * p.dplane : 0;
 
   // ---- staging geometry: wave w issues pieces j = w + 8 i; lane = (pixel of the piece, float4 of the pixel)
   const int lpx = lane / (CIT / 4), qx = lane % (CIT / 4);
@@ -113,7 +116,15 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
     const int n_tile = STK ? 0 : tile / (p.tiles_w * p.tiles_h);
     const int h0 = th_i * TH_, w0 = tw_i * TW_;
     int64_t ximg = 0, yimg = 0;
-    if (!STK) { ximg = p.xa.off(n_tile); yimg = p.ya.off(n_tile); }
+    bool xplane_ok = true;                                  // fused depth taps: the tap's input plane exists
+    if (!STK) {
+      ximg = p.xa.off(n_tile) + x_dt;
+      yimg = p.ya.off(n_tile);
+      if (KD > 1) {
+        const int din_i = (n_tile % p.spg) * p.dsd + p.dshift0 + dt;
+        xplane_ok = din_i >= 0 && din_i < p.din;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < G::IPW; ++i) {
       const int j = wave + 8 * i;
@@ -129,9 +140,16 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
           const int r = v - n_img * (p.H + 1);
           ok = gh >= 0 && gh < (1 << 20) && n_img < p.N && r < p.H && gw >= 0 && gw < p.W;
           gh = r;
-          if (ok) { ximg = p.xa.off(n_img); yimg = p.ya.off(n_img); }
+          if (ok) {
+            ximg = p.xa.off(n_img) + x_dt;
+            yimg = p.ya.off(n_img);
+            if (KD > 1 && is_x) {
+              const int din_i = (n_img % p.spg) * p.dsd + p.dshift0 + dt;
+              ok = din_i >= 0 && din_i < p.din;
+            }
+          }
         } else {
-          ok = gh >= 0 && gh < ph && gw >= 0 && gw < pw;
+          ok = gh >= 0 && gh < ph && gw >= 0 && gw < pw && (!is_x || xplane_ok);
         }
         const int64_t pixoff = (int64_t)gh * pw + gw;
         const float* src = is_x ? p.x + ximg + pixoff * p.xs + ci0 + qx * 4 : p.dy + yimg + pixoff * p.ys + co0 + qy * 4;
@@ -223,7 +241,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
     }
   }
   if (ks == 0) {
-    float* out = p.slab + (int64_t)split * 9 * p.Cin * p.Cout;
+    float* out = p.slab + ((int64_t)split * KD + dt) * 9 * p.Cin * p.Cout;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -437,7 +455,7 @@ constexpr int S2TH = 4;             // stride-2 tile: 4 x 16 (or 4 x 12) output 
 
 bool wg_strided_ok(int Cin, int Cout) { return Cin % 32 == 0 && Cout % 64 == 0; }
 
-WgPlan wg_plan_strided(int N, int H, int W, int Cin, int Cout) {   // H, W = output plane
+WgPlan wg_plan_strided(int N, int H, int W, int Cin, int Cout, int kd = 1) {   // H, W = output plane
   WgPlan pl{};
   const int tw = (W % TW != 0 && W % STW == 0) ? STW : TW;
   pl.mode = tw == STW ? 4 : 3;
@@ -447,8 +465,8 @@ WgPlan wg_plan_strided(int N, int H, int W, int Cin, int Cout) {   // H, W = out
   pl.cit = 32; pl.cot = 64;
   pl.n_ci_tiles = Cin / 32;
   pl.n_co_tiles = Cout / 64;
-  const int panels = pl.n_ci_tiles * pl.n_co_tiles;
-  int S = (512 + panels - 1) / panels;
+  const int panels = pl.n_ci_tiles * pl.n_co_tiles * (kd > 1 ? kd : 1);      // fused depth taps: kd x the blocks per split
+  int S = panels >= 512 ? 1 : 512 / panels;   // floor: 513 blocks would be three rounds of the one-block-per-CU kernel
   if (S > pl.total_tiles) S = pl.total_tiles;
   if (S < 1) S = 1;
   pl.tiles_per_split = (pl.total_tiles + S - 1) / S;
@@ -456,7 +474,7 @@ WgPlan wg_plan_strided(int N, int H, int W, int Cin, int Cout) {   // H, W = out
   return pl;
 }
 
-WgPlan wg_plan(int N, int H, int W, int Cin, int Cout, bool bf16 = false) {
+WgPlan wg_plan(int N, int H, int W, int Cin, int Cout, bool bf16 = false, int kd = 1) {
   WgPlan pl{};
   pl.tiles_h = (H + TH - 1) / TH;
   pl.tiles_w = (W + TW - 1) / TW;
@@ -478,10 +496,11 @@ WgPlan wg_plan(int N, int H, int W, int Cin, int Cout, bool bf16 = false) {
     pl.cot = Cout % 64 == 0 ? 64 : 32;
     pl.n_ci_tiles = Cin / pl.cit;
     pl.n_co_tiles = Cout / pl.cot;
-    const int panels = pl.n_ci_tiles * pl.n_co_tiles;
-    int S = (512 + panels - 1) / panels;  // one 512-thread block per CU (154 KB of LDS) x 256 CUs x 2 rounds
+    const int panels = pl.n_ci_tiles * pl.n_co_tiles * (kd > 1 ? kd : 1);
+    int S = panels >= 512 ? 1 : 512 / panels;   // one 512-thread block per CU (154 KB of LDS) x 256 CUs x 2 rounds; floor: 513 blocks would be three
     // few tiles per block (small layers): one round of 256 blocks halves the per-block epilogue (LDS tree + slab) per tile
-    if (pl.total_tiles / S < 16 && panels <= 256) S = (256 + panels - 1) / panels;
+    // (floor, not ceil: 154 KB of LDS = one block per CU, so 257 blocks take two rounds)
+    if (pl.total_tiles / S < 16 && panels <= 256) S = 256 / panels;
     if (S > pl.total_tiles) S = pl.total_tiles;
     if (S < 1) S = 1;
     pl.tiles_per_split = (pl.total_tiles + S - 1) / S;
@@ -514,7 +533,14 @@ int launch_wgrad(const WgParams& p, int grid, hipStream_t st) {
 
 }  // namespace
 
-size_t unetk_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout) {
+size_t unetk_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int kd) {
+  if (kd > 1) {
+    const WgPlan pk = wg_plan(N, H, W, Cin, Cout, false, kd);
+    if (pk.mode != 0 && pk.mode != 2 && pk.mode != 5) return 0;
+    const size_t fused = 256 + (size_t)pk.S * kd * 9 * Cin * Cout * sizeof(float);
+    const size_t plain = unetk_wgrad_ws_bytes(N, H, W, Cin, Cout, 1);
+    return fused > plain ? fused : plain;
+  }
   const WgPlan pl = wg_plan(N, H, W, Cin, Cout, false), pb = wg_plan(N, H, W, Cin, Cout, true);
   if (pl.mode < 0) return 0;
   int S = pl.S > pb.S ? pl.S : pb.S;                           // either precision
@@ -530,10 +556,10 @@ size_t unetk_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout) {
 
 bool unetk_wgrad_strided_ok(int Cin, int Cout) { return wg_strided_ok(Cin, Cout); }
 
-size_t unetk_wgrad_strided_ws_bytes(int N, int Ho, int Wo, int Cin, int Cout) {
+size_t unetk_wgrad_strided_ws_bytes(int N, int Ho, int Wo, int Cin, int Cout, int kd) {
   if (!wg_strided_ok(Cin, Cout)) return 0;
-  const WgPlan pl = wg_plan_strided(N, Ho, Wo, Cin, Cout);
-  return 256 + (size_t)pl.S * 9 * Cin * Cout * sizeof(float);
+  const WgPlan pl = wg_plan_strided(N, Ho, Wo, Cin, Cout, kd);
+  return 256 + (size_t)pl.S * (kd > 1 ? kd : 1) * 9 * Cin * Cout * sizeof(float);
 }
 
 int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -541,20 +567,21 @@ int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_
     if (!wg_strided_ok(p.Cin, p.Cout) || p.bf16) return UNETK_E_UNSUPPORTED;
     if (p.xs % 4 != 0 || p.ys % 4 != 0 || p.pbh < 0 || p.pbh > 1 || p.pbw < 0 || p.pbw > 1) return UNETK_E_BADARG;
     if (p.Hin < 2 * p.H - 1 || p.Hin > 2 * p.H || p.Win < 2 * p.W - 1 || p.Win > 2 * p.W) return UNETK_E_BADARG;
-    const WgPlan pl = wg_plan_strided(p.N, p.H, p.W, p.Cin, p.Cout);
-    if (ws_bytes < unetk_wgrad_strided_ws_bytes(p.N, p.H, p.W, p.Cin, p.Cout)) return UNETK_E_WORKSPACE;
+    const int KD = p.kd > 1 ? p.kd : 1;
+    const WgPlan pl = wg_plan_strided(p.N, p.H, p.W, p.Cin, p.Cout, KD);
+    if (ws_bytes < unetk_wgrad_strided_ws_bytes(p.N, p.H, p.W, p.Cin, p.Cout, KD)) return UNETK_E_WORKSPACE;
     p.slab = pl.S == 1 ? dw : (float*)ws + 64;           // a single split writes the gradient in place
     p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.total_tiles = pl.total_tiles;
     p.tiles_per_split = pl.tiles_per_split; p.n_ci_tiles = pl.n_ci_tiles; p.n_co_tiles = pl.n_co_tiles;
-    const int grid = pl.S * pl.n_ci_tiles * pl.n_co_tiles;
+    const int grid = pl.S * KD * pl.n_ci_tiles * pl.n_co_tiles;
     const int rc = pl.mode == 4 ? launch_wgrad<32, 64, false, S2TH, STW, false, 2>(p, grid, st)
                                 : launch_wgrad<32, 64, false, S2TH, TW, false, 2>(p, grid, st);
     if (rc != UNETK_OK) return rc;
     if (pl.S == 1) return UNETK_OK;
-    return unetk_launch_slab_reduce((const float*)ws + 64, pl.S, (int64_t)9 * p.Cin * p.Cout, dw, st);
+    return unetk_launch_slab_reduce((const float*)ws + 64, pl.S, (int64_t)KD * 9 * p.Cin * p.Cout, dw, st);
   }
   if (p.dil == 2) {      // atrous: 6 x 16 tiles (the 10 x 20 halo of two stages fits LDS), 64 x 64 panels, fp32
-    if (p.bf16 || p.Cin % 64 != 0 || p.Cout % 64 != 0) return UNETK_E_UNSUPPORTED;
+    if (p.bf16 || p.Cin % 64 != 0 || p.Cout % 64 != 0 || p.kd > 1) return UNETK_E_UNSUPPORTED;
     if (p.xs % 4 != 0 || p.ys % 4 != 0) return UNETK_E_BADARG;
     p.stride = 1; p.Hin = p.H; p.Win = p.W; p.pbh = p.pbw = 2;
     WgPlan pl{};
@@ -563,7 +590,7 @@ int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_
     pl.total_tiles = p.N * pl.tiles_h * pl.tiles_w;
     pl.n_ci_tiles = p.Cin / 64; pl.n_co_tiles = p.Cout / 64;
     const int panels = pl.n_ci_tiles * pl.n_co_tiles;
-    int S = (512 + panels - 1) / panels;
+    int S = panels >= 512 ? 1 : 512 / panels;   // floor: 513 blocks would be three rounds of the one-block-per-CU kernel
     if (S > pl.total_tiles) S = pl.total_tiles;
     if (S < 1) S = 1;
     pl.tiles_per_split = (pl.total_tiles + S - 1) / S;
@@ -578,22 +605,24 @@ int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_
     return unetk_launch_slab_reduce((const float*)ws + 64, pl.S, (int64_t)9 * p.Cin * p.Cout, dw, st);
   }
   p.stride = 1; p.Hin = p.H; p.Win = p.W; p.pbh = p.pbw = 1;
-  const WgPlan pl = wg_plan(p.N, p.H, p.W, p.Cin, p.Cout, p.bf16 != 0);
+  const int KD = p.kd > 1 ? p.kd : 1;
+  const WgPlan pl = wg_plan(p.N, p.H, p.W, p.Cin, p.Cout, p.bf16 != 0, KD);
   if (pl.mode < 0) return UNETK_E_UNSUPPORTED;
-  if (ws_bytes < unetk_wgrad_ws_bytes(p.N, p.H, p.W, p.Cin, p.Cout)) return UNETK_E_WORKSPACE;
+  if (KD > 1 && (p.bf16 || (pl.mode != 0 && pl.mode != 2 && pl.mode != 5))) return UNETK_E_UNSUPPORTED;   // MFMA fp32 kernels only
+  if (ws_bytes < unetk_wgrad_ws_bytes(p.N, p.H, p.W, p.Cin, p.Cout, KD)) return UNETK_E_WORKSPACE;
   p.slab = pl.S == 1 ? dw : (float*)ws + 64;           // a single split writes the gradient in place
   p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.total_tiles = pl.total_tiles;
   p.tiles_per_split = pl.tiles_per_split; p.n_ci_tiles = pl.n_ci_tiles; p.n_co_tiles = pl.n_co_tiles;
   int rc = UNETK_OK;
   if (pl.mode == 2 || pl.mode == 5) {
     if (p.xs % 4 != 0 || p.ys % 4 != 0) return UNETK_E_BADARG;
-    const int grid = pl.S * pl.n_ci_tiles * pl.n_co_tiles;
+    const int grid = pl.S * KD * pl.n_ci_tiles * pl.n_co_tiles;
     rc = pl.mode == 2 ? launch_wgrad<64, 64, false, STH, STW, true>(p, grid, st)
                       : launch_wgrad<64, 64, false, 20, 6, true>(p, grid, st);
     if (rc != UNETK_OK) return rc;
   } else if (pl.mode == 0) {
     if (p.xs % 4 != 0 || p.ys % 4 != 0) return UNETK_E_BADARG;
-    const int grid = pl.S * pl.n_ci_tiles * pl.n_co_tiles;
+    const int grid = pl.S * KD * pl.n_ci_tiles * pl.n_co_tiles;
     if (p.bf16) {
       if (pl.cit == 64 && pl.cot == 64) rc = launch_wgrad<64, 64, true>(p, grid, st);
       else if (pl.cit == 64) rc = launch_wgrad<64, 32, true>(p, grid, st);
@@ -635,7 +664,7 @@ int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_
     UNETK_LAUNCH_CHECK();
   }
   if (pl.S == 1) return UNETK_OK;
-  return unetk_launch_slab_reduce((const float*)ws + 64, pl.S, (int64_t)9 * p.Cin * p.Cout, dw, st);
+  return unetk_launch_slab_reduce((const float*)ws + 64, pl.S, (int64_t)KD * 9 * p.Cin * p.Cout, dw, st);
 }
 
 extern "C" size_t unetk_conv3x3_wgrad_ws_bytes(const unetk_conv_desc* d) {
