@@ -43,6 +43,8 @@ __device__ __forceinline__ int sk_block_of(int64_t pos, int64_t tot, int G) {   
   return b;
 }
 
+// (Measured and dropped in round 2: fetching the filter panels two steps ahead instead of one -- no gain, the small tiles are
+// not waiting for their weights -- and 8-wave variants of the same tiles.)
 // ACC: the plain variant's epilogue accumulates (y += acc, one depth tap of an unfused 3-D conv).  Its own instantiation:
 // the row pointers and old values it keeps in flight cost 60+ registers (the 128 x 128 stream-K variant ran at ONE wave
 // per SIMD with them: 210 + 64 registers).
@@ -638,6 +640,10 @@ int unetk_conv_run_lin_gen(ConvParams p, hipStream_t st) {
     p.stat_rows = n_mt;
     p.lin_pix = lin_rows_bound(p.H, p.W, bm) * (p.W + 2);
     if (p.Cout % 128 == 0) {
+      if ((int64_t)n_mt * (p.Cout / 128) < 128) {   // UNet3D's (2,2,2) layer: 6 x 6 dy planes = 27 pixel tiles -- 64 x 64 tiles
+        p.n_ntiles = p.Cout / 64;                   // double the blocks (54 -> 108 per depth tap: 0.49 -> 0.42 ms; the short
+        return launch_lin<2, 2, 1, 1, true, true>(p, n_mt, st);   // steps of such tiles are latency-bound, not MFMA-bound)
+      }
       p.n_ntiles = p.Cout / 128;
       return launch_lin<2, 2, 1, 2, true, true>(p, n_mt, st);
     }
