@@ -23,8 +23,10 @@ from .unet2d import UNet2DOracle
 ENC = [("e0", 32, 1), ("e1", 64, 2), ("e2", 128, 2)]
 
 
-def param_specs(x_channels, y_channels, num_classes, normalizer="batch_norm", name="SmallUNet", without_norm=False):
+def param_specs(x_channels, y_channels, num_classes, normalizer="batch_norm", name="SmallUNet", without_norm=False, factor=1):
+    """factor = init_channel_factor: every layer has round(out * factor) channels (InterUNet.py:121,129,137,148,157)."""
     specs = []
+    r = lambda v: int(round(v * factor))
 
     def unit(scope, cin, cout):
         specs.append((scope + "/weights", (3, 3, cin, cout), "conv_w"))
@@ -40,33 +42,34 @@ def param_specs(x_channels, y_channels, num_classes, normalizer="batch_norm", na
     for stream, cin0 in (("image", x_channels), ("inter", y_channels)):
         cin = cin0
         for tag, c, _ in ENC:
-            unit("{}/{}_{}/conv1".format(name, stream, tag), cin, c)
-            unit("{}/{}_{}/conv2".format(name, stream, tag), c, c)
-            cin = c
-    unit(name + "/merge_e3/conv1", 256, 512)
-    unit(name + "/merge_e3/conv2", 512, 512)
-    unit(name + "/merge_e3/conv3", 512, 1024)
-    unit(name + "/merge_e3/conv4", 1024, 1024)
-    unit(name + "/conv_d3/conv1", 1024, 512)
-    unit(name + "/conv_d3/conv2", 512, 512)
-    unit(name + "/conv_d3/conv3", 512, 512)
-    cin = 512
+            unit("{}/{}_{}/conv1".format(name, stream, tag), cin, r(c))
+            unit("{}/{}_{}/conv2".format(name, stream, tag), r(c), r(c))
+            cin = r(c)
+    unit(name + "/merge_e3/conv1", 2 * r(128), r(512))
+    unit(name + "/merge_e3/conv2", r(512), r(512))
+    unit(name + "/merge_e3/conv3", r(512), r(1024))
+    unit(name + "/merge_e3/conv4", r(1024), r(1024))
+    unit(name + "/conv_d3/conv1", r(1024), r(512))
+    unit(name + "/conv_d3/conv2", r(512), r(512))
+    unit(name + "/conv_d3/conv3", r(512), r(512))
+    cin = r(512)
     for i, c, skip in ((2, 256, 128), (1, 128, 64), (0, 64, 32)):
-        specs.append(("{}/conv_d{}/up/weights".format(name, i), (2, 2, c, cin), "deconv_w"))
-        unit("{}/conv_d{}/conv1".format(name, i), c + 2 * skip, c)
-        unit("{}/conv_d{}/conv2".format(name, i), c, c)
-        cin = c
-    specs.append((name + "/logits/weights", (1, 1, 64, num_classes), "conv_w"))
+        specs.append(("{}/conv_d{}/up/weights".format(name, i), (2, 2, r(c), cin), "deconv_w"))
+        unit("{}/conv_d{}/conv1".format(name, i), r(c) + 2 * r(skip), r(c))
+        unit("{}/conv_d{}/conv2".format(name, i), r(c), r(c))
+        cin = r(c)
+    specs.append((name + "/logits/weights", (1, 1, cin, num_classes), "conv_w"))
     specs.append((name + "/logits/biases", (num_classes,), "bias"))
     return specs
 
 
 class InterUNetOracle(UNet2DOracle):
-    def __init__(self, x_channels, y_channels, num_classes, normalizer="batch_norm", name="SmallUNet", without_norm=False):
+    def __init__(self, x_channels, y_channels, num_classes, normalizer="batch_norm", name="SmallUNet", without_norm=False,
+                 factor=1):
         self.name, self.img_grad, self.num_classes = name, False, num_classes
         self.normalizer, self.without_norm = normalizer, without_norm
         self.bn_decay, self.bn_eps, self.in_eps = 0.999, 1e-3, 1e-6
-        self.specs = param_specs(x_channels, y_channels, num_classes, normalizer, name, without_norm)
+        self.specs = param_specs(x_channels, y_channels, num_classes, normalizer, name, without_norm, factor)
         self.kinds = {n: k for n, _, k in self.specs}
 
     def _unit(self, x, p, scope, stride, dilation, is_training, new_stats):

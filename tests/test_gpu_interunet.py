@@ -111,3 +111,78 @@ def test_interunet_matches_oracle_and_trains(normalizer, loss_type, img_grad, wi
         first = loss.item() if first is None else first
         solver(loss, model)
     assert model(inputs, "train", **YML).item() < first
+
+
+@pytest.mark.parametrize("factor,normalizer", [(0.75, "instance_norm"), (0.5, "batch_norm")])
+def test_interunet_channel_factor_on_padded_variables(factor, normalizer):
+    """init_channel_factor != 1 (`round(layer["out"] * c)`, InterUNet.py:121; e.g. --model_config SmallUNet_V2.yml): the
+    variables keep the reference's logical shapes (24 / 48 / 96 / 384 ... at 0.75) in checkpoints and are channel-padded
+    to multiples of 64 on the device; the padding is exactly zero and stays zero through training."""
+    from boxsegliver_amd.core import models
+    from boxsegliver_amd.core.solver import Solver
+    from boxsegliver_amd.data.synthetic import make_batch, make_guide
+    yml = dict(YML, init_channel_factor=factor)
+    zoo = {cls.__name__: cls for cls in models.MODEL_ZOO}
+    args = make_args(normalizer=normalizer, loss_type="xentropy", use_spatial=True, guide_channel=1, im_height=64, im_width=64,
+                     img_grad=False, without_norm=False)
+    images, labels, _ = make_batch(2, 64, 64, 3, 3, 1234)
+    guide = make_guide(labels, 1, 1234)
+    model = zoo["InterUNet"](args)
+    inputs = {"images": torch.from_numpy(images).cuda(), "labels": torch.from_numpy(labels).cuda(),
+              "sp_guide": torch.from_numpy(guide).cuda()}
+    model(inputs, "eval", **yml)
+    net = interunet2d.InterUNetOracle(4, 3, 3, normalizer=normalizer, factor=factor)
+    r = lambda v: int(round(v * factor))
+    logical = {n: tuple(s) for n, s, _ in net.specs}
+    assert [(n, tuple(s), k) for n, s, k in net.specs] == [(n, tuple(s), k) for n, s, k in model.params.logical_specs]
+    assert logical["SmallUNet/inter_e0/conv1/weights"] == (3, 3, 3, r(32))
+    assert logical["SmallUNet/conv_d1/conv1/weights"] == (3, 3, r(128) + 2 * r(64), r(128))
+    p64_ = lambda c: (c + 63) // 64 * 64
+    assert model.params["SmallUNet/conv_d1/conv1/weights"].shape == (3, 3, p64_(r(128)) + 2 * p64_(r(64)), p64_(r(128)))   # device
+    sd = model.params.state_dict()
+    assert {n: tuple(t.shape) for n, t in sd.items()} == logical and model.params.num_trainable() == \
+        sum(int(np.prod(s)) for n, s, k in net.specs if k not in ("moving_mean", "moving_var"))
+    gen = torch.Generator().manual_seed(26)
+    params = {}
+    for name, t in sd.items():
+        kind = net.kinds[name]
+        if kind == "gamma":
+            params[name] = 0.5 + torch.rand(t.shape, generator=gen)
+        elif kind in ("beta", "bias"):
+            params[name] = 0.2 * torch.randn(t.shape, generator=gen)
+        else:
+            params[name] = t.clone()
+    model.params.load_state(params)
+    img, gd, lab = torch.from_numpy(images), torch.from_numpy(guide), torch.from_numpy(labels).long()
+    p64 = {k: v.double() for k, v in params.items()}
+    total, _, logits, grads64, new_stats = net.loss_and_grads(p64, (torch.cat((img, gd), -1).double(), img.double()), lab,
+                                                              **kwargs_of(args))
+    model.params.zero_grad()
+    loss = model(inputs, "train", **yml)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - total.item()) < 1e-4 * max(1.0, abs(total.item()))
+    assert np.abs(model.layers["logits"].cpu().numpy() - logits.numpy()).max() < 1e-3
+    num = den = 0.0
+    for name in model.params.trainable_names():
+        g = model.params.logical_grad(name).numpy().astype(np.float64)
+        ref = grads64[name].numpy()
+        num += np.sum((g - ref) ** 2)
+        den += np.sum(ref ** 2)
+    assert (num / den) ** 0.5 < 1e-2
+
+    def padding_is_zero():
+        for name, t in model.params.tensors.items():
+            if name in model.params.pads and model.params.where[name][0] != "stats":
+                full = float(t.detach().abs().sum())
+                inner = sum(float(t.detach()[pidx].abs().sum()) for _, pidx in model.params._blocks(name))
+                assert abs(full - inner) <= 1e-6 * max(full, 1.0), name
+    padding_is_zero()
+    solver = Solver(args)
+    first = None
+    for _ in range(4):
+        loss = model(inputs, "train", **yml)
+        first = loss.item() if first is None else first
+        solver(loss, model)
+    assert model(inputs, "train", **yml).item() < first
+    padding_is_zero()
