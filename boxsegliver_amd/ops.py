@@ -99,6 +99,9 @@ class _PackCache(object):
             if ent["gen"] == gen:
                 return ent["wp_f"], ent["wp_d"]
         import weakref
+        for k in [k for k, e in self.entries.items() if e["flat"]() is None]:      # variables of models that are gone
+            del self.entries[k]
+            self.table = None
         wp_f, wp_d, items = build()
         self.singles += 1
         self.entries[key] = dict(flat=weakref.ref(flat), gen=gen, wp_f=wp_f, wp_d=wp_d, items=items)

@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 1000 python -m pytest tests/test_gpu_interunet.py tests/test_gpu_smallunet.py -x -q > gpurun_out/r2s2_t19.log 2>&1
-tail -25 gpurun_out/r2s2_t19.log
+UNETK_DIST_BACKEND=gloo timeout -k 10 500 python bench.py --gpus 2 --batch 8 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r2s2_2rank.json 2> gpurun_out/r2s2_2rank.err || tail -20 gpurun_out/r2s2_2rank.err
+cut -c1-700 gpurun_out/r2s2_2rank.json
