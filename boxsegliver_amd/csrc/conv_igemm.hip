@@ -13,6 +13,13 @@
 //
 // Algorithmic bytes per block-step are tiny next to the 64-cycle fp32 MFMA, so the kernel is
 // MFMA-issue bound by construction; the roofline that bounds it is the fp32 matrix peak.
+//
+// Where the last 10 % go (round 2, PMC SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE, profiles/r02_pmc_mfma_busy.txt): the
+// clock holds ~2.38 GHz under this kernel, the MFMA pipe is 87-89 % busy.  With the in-loop global loads and LDS writes
+// compiled out (results wrong, timing only) the same launches run at 148-151 TF = 95-96 %, which is also what the
+// stand-alone loop of tools/mfma_mix.hip reaches with a barrier per 32 MFMAs: the staging instructions themselves, not
+// their latency, take MFMA issue time (s_setprio around the MFMA block, either way: no change).  Hence the 16 x 16 pixel
+// tiles below -- fewer staged bytes per MFMA -- wherever the grid still gives two blocks per CU.
 #include "common.h"
 #include "pack.h"
 
@@ -35,7 +42,7 @@ constexpr int TW = 16;   // spatial tile width
 // values per fragment it keeps in flight are 32 registers the plain kernel does not need (114 -> 71 VGPRs, i.e. three
 // waves per SIMD instead of two next to the 64 accumulator registers).
 template <int WM, int WN, int TM, int TN, int S = 1, int DIL = 1, int MODE = 0>
-__global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_kernel(ConvParams p) {
+__global__ __launch_bounds__(WM* WN * 64, (TM * TN == 8 ? 2 : 1)) void conv3x3_igemm_kernel(ConvParams p) {
   constexpr bool NBR = MODE == 2, ACC = MODE == 1;
   static_assert(S == 1 || DIL == 1, "strided atrous convs are not needed");
   static_assert(!NBR || (S == 1 && DIL == 1), "the fused reduction is for plain 3x3 convs");
@@ -416,11 +423,33 @@ inline bool small_grid(int N, int H, int W, int Cout) {
   return blocks < 384;
 }
 
+// Large grids: a 16 x 16 pixel tile (256 x 128, <2,2,4,2>, 128 accumulator registers per wave, two blocks per CU).  The
+// staging traffic per MFMA is what holds the 128 x 128 tile at 87-89 % MFMA-busy (tools/mfma_mix.hip: the same loop
+// without its global loads and LDS writes runs at 95-96 %): per 16-channel chunk a block stages the halo once and NINE
+// filter panels, so doubling the pixels per block nearly halves the loads, LDS writes and barriers per MFMA.
+// The 64-wide configuration has its 16 x 16 pixel tile too (256 x 64, <4,1,2,2>).  `nbr`: the launch also emits the producing
+// unit's norm-backward reduction; with K < 256 channels the loop is too short to carry the four-fragment epilogue (measured
+// on 128 -> 128 at 128^2: 1.19 -> 1.20 ms) and the 8-row tile stays.
+inline bool big_grid(int N, int H, int W, int Cin, int Cout, int spg, bool nbr) {
+  if (Cout % 64 != 0 || spg != 1 || H % 16 != 0 || (nbr && Cin < 256)) return false;
+  const int bn = Cout % 128 == 0 ? 128 : 64;
+  const int64_t blocks = (int64_t)N * (H / 16) * ((W + TW - 1) / TW) * (Cout / bn);
+  return blocks >= 512;
+}
+
 inline ConvCfg pick_cfg(int Cin, int Cout) {
   if (Cin % CK == 0 && Cout % 128 == 0) return {0, 8};
   if (Cin % CK == 0 && Cout % 64 == 0) return {1, 8};
   if (Cin % CK == 0 && Cout % 32 == 0) return {2, 16};
   return {-1, 8};
+}
+
+// rows of the pixel tile the stride-1 tiled kernel takes for this shape (one statistic row per tile)
+inline int tile_rows(int N, int H, int W, int Cin, int Cout, int spg, bool nbr) {
+  const ConvCfg cfg = pick_cfg(Cin, Cout);
+  if (cfg.id == 0 && small_grid(N, H, W, Cout)) return 4;
+  if ((cfg.id == 0 || cfg.id == 1) && big_grid(N, H, W, Cin, Cout, spg, nbr)) return 16;
+  return cfg.th;
 }
 
 template <int WM, int WN, int TM, int TN, int S = 1, int DIL = 1, int MODE = 0>
@@ -460,8 +489,7 @@ int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout, int spg, int st
   if (dil == 2) return N * ((H + 7) / 8) * ((W + TW - 1) / TW);
   if (stride == 2) return N * ((H + s2_th(Cout) - 1) / s2_th(Cout)) * ((W + TW - 1) / TW);
   if (unetk_conv_lin_ok(N, H, W, Cin, Cout, spg)) return unetk_conv_stat_rows_lin(N, H, W, spg, Cout);
-  const ConvCfg cfg = pick_cfg(Cin, Cout);
-  const int th = (cfg.id == 0 && small_grid(N, H, W, Cout)) ? 4 : cfg.th;
+  const int th = tile_rows(N, H, W, Cin, Cout, spg, false);
   return N * ((H + th - 1) / th) * ((W + TW - 1) / TW);
 }
 
@@ -500,8 +528,8 @@ int unetk_conv_run(ConvParams p, hipStream_t st) {
   if (p.spg < 1) p.spg = 1;
   if (unetk_conv_lin_ok(p.N, p.H, p.W, p.Cin, p.Cout, p.spg)) return unetk_conv_run_lin(p, st);   // small planes: linear M
   const ConvCfg cfg = pick_cfg(p.Cin, p.Cout);
-  const bool small = cfg.id == 0 && small_grid(p.N, p.H, p.W, p.Cout);
-  const int th = small ? 4 : cfg.th;
+  const int th = tile_rows(p.N, p.H, p.W, p.Cin, p.Cout, p.spg, p.ny != nullptr);
+  const bool small = cfg.id == 0 && th == 4, big = cfg.id <= 1 && th == 16;
   p.tiles_h = (p.H + th - 1) / th;
   p.tiles_w = (p.W + TW - 1) / TW;
   const int n_mtiles = p.N * p.tiles_h * p.tiles_w;
@@ -511,6 +539,15 @@ int unetk_conv_run(ConvParams p, hipStream_t st) {
     p.n_ntiles = p.Cout / 128;
     if (p.ny != nullptr) return launch_igemm<2, 2, 1, 2, 1, 1, true>(p, n_mtiles, st);
     return launch_igemm<2, 2, 1, 2>(p, n_mtiles, st);
+  }
+  if (big && cfg.id == 1) {
+    p.n_ntiles = p.Cout / 64;
+    return launch_igemm<4, 1, 2, 2>(p, n_mtiles, st);
+  }
+  if (big) {
+    p.n_ntiles = p.Cout / 128;
+    if (p.ny != nullptr) return launch_igemm<2, 2, 4, 2, 1, 1, true>(p, n_mtiles, st);
+    return launch_igemm<2, 2, 4, 2>(p, n_mtiles, st);
   }
   if (cfg.id == 0) {
     p.n_ntiles = p.Cout / 128;
@@ -661,7 +698,8 @@ extern "C" int unetk_conv3x3_dgrad_nbr_rows(const unetk_conv_desc* d) {
   }
   if (d->precision != UNETK_FP32) return 0;
   if (pick_cfg(K, Nc).id < 0 || unetk_conv_lin_ok(d->N, d->H, d->W, K, Nc, 1)) return 0;   // tiled fp32 kernel only
-  return unetk_conv_stat_rows(d->N, d->H, d->W, K, Nc);
+  const int th = tile_rows(d->N, d->H, d->W, K, Nc, 1, true);
+  return d->N * ((d->H + th - 1) / th) * ((d->W + TW - 1) / TW);
 }
 
 extern "C" int unetk_conv3x3_dgrad_nbr(const unetk_conv_desc* d, const void* dy, const void* w, void* dx,

@@ -161,10 +161,13 @@ class _Timed(object):
         return False
 
 
-def _igemm_tag(cin, cout, bf16=False, h=0, n=1 << 20, w=1 << 10):
+def _igemm_tag(cin, cout, bf16=False, h=0, n=1 << 20, w=1 << 10, nbr=False):
     """Kernel name of a conv3x3 forward / input-gradient launch (mirrors the dispatch of conv_igemm*.hip; bench labels)."""
     def cdiv(a, b):
         return -(-a // b)
+
+    def big(bn):        # big_grid (conv_igemm.hip): 16 x 16 pixel tiles when they still give two blocks per CU
+        return h % 16 == 0 and not (nbr and cin < 256) and n * (h // 16) * cdiv(w, 16) * (cout // bn) >= 512
     if bf16 and cin % 32 == 0 and cout % 32 == 0:
         bs = ",true>" if int(bf16) == _abi.BF16S else ">"          # <..., BS = true>: bf16 storage
         if cout % 128 == 0:
@@ -176,9 +179,9 @@ def _igemm_tag(cin, cout, bf16=False, h=0, n=1 << 20, w=1 << 10):
     if cin % 16 == 0 and cout % 128 == 0:
         if n * cdiv(h, 8) * cdiv(w, 16) * (cout // 128) < 384:      # under-filled grid: half-height tiles
             return "conv3x3_igemm_kernel<2,2,1,2>"
-        return "conv3x3_igemm_kernel<2,2,2,2>"
+        return "conv3x3_igemm_kernel<2,2,4,2>" if big(128) else "conv3x3_igemm_kernel<2,2,2,2>"
     if cin % 16 == 0 and cout % 64 == 0:
-        return "conv3x3_igemm_kernel<4,1,1,2>"
+        return "conv3x3_igemm_kernel<4,1,2,2>" if big(64) else "conv3x3_igemm_kernel<4,1,1,2>"
     if cin % 16 == 0 and cout % 32 == 0:
         return "conv3x3_igemm_kernel<4,1,2,1>"
     return "conv3x3_direct_kernel"
@@ -357,7 +360,7 @@ def conv3x3_dgrad(dy, wp_dgrad, cin, x_stride=None, dx=None, bf16=False, dilatio
         rows = _abi.lib().unetk_conv3x3_dgrad_nbr_rows(ctypes.byref(d))
         if rows > 0 and py.dtype == dx.dtype and tuple(py.shape) == tuple(dx.shape) and py.is_contiguous():
             part = torch.empty((2, rows, cin), dtype=torch.float32, device=dy.device)
-            with _Timed(_igemm_tag(cout, cin, bf16, h, n, wd), 18.0 * n * h * wd * cin * cout,
+            with _Timed(_igemm_tag(cout, cin, bf16, h, n, wd, nbr=True), 18.0 * n * h * wd * cin * cout,
                         "dgrad+nbr {}x{}x{} {}->{}".format(n, h, wd, cout, cin)):
                 check(_abi.lib().unetk_conv3x3_dgrad_nbr(ctypes.byref(d), ptr(dy), ptr(wp_dgrad), ptr(dx), ptr(py), cin,
                                                          ptr(paff[2]), ptr(paff[3]), ptr(paff[0]), ptr(paff[1]),
