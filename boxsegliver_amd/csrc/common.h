@@ -192,9 +192,12 @@ size_t unetk_wgrad_strided_ws_bytes(int N, int Ho, int Wo, int Cin, int Cout, in
 int unetk_launch_slab_reduce(const float* slab, int S, int64_t n, float* dst, hipStream_t st);
 // dst[k][c] = sum_rows src[k][row][c] (fp64 accumulate).  tmp: K*64*C floats when rows > 256.
 int unetk_rows_reduce(const float* src, int K, int rows, int C, float* dst, float* tmp, hipStream_t st);
+int unetk_rows_reduce_alias(const float* src, int K, int rows, int C, float* dst, float* tmp, float* alias0, float* alias1,
+                            hipStream_t st);
 // row counts up to UNETK_RR_DIRECT_ROWS go straight to the final kernel; more rows take a first level of 64 row blocks
 // (1024 was measured: the final kernel has only C / 16 x K blocks and took 15 us on 1024 rows, more than the two levels)
 constexpr int UNETK_RR_DIRECT_ROWS = 256;
+constexpr int UNETK_RR_WIDE_ROWS = 1024;    // float4-capable inputs: the wide final kernel takes this many rows directly
 size_t unetk_rows_reduce_tmp_floats(int K, int rows, int C);
 int unetk_rows_reduce_l1(const float* src, int K, int rows, int C, float* tmp, hipStream_t st);   // -> tmp[K][64][C]
 

@@ -738,26 +738,35 @@ extern "C" int unetk_norm_relu_bwd_pre(const unetk_norm_desc* d, const void* y, 
   else { a.ksum = psum; a.kst = 0; a.krow = d->C; }
   const size_t lds = (size_t)K * g.rpi * d->C * sizeof(float);
   int rc;
+  // plain unit (K = 2: sum du, sum du * xhat): d beta / d gamma ARE the two totals, written by the last reduction launch
+  const bool simple = G == 0 && !D && !leaky && dgb == nullptr;
+  float* const al0 = simple ? dbeta : nullptr;
+  float* const al1 = simple ? dgamma : nullptr;
+  const bool last1 = g.L == 1;
   if (pre_partials != nullptr) {
     if (G > 0 || D || leaky || gb || d->dropout_keep > 0.f || d->affine_only) return UNETK_E_UNSUPPORTED;
     UNETK_REQUIRE(pre_rows > 0 && pre_rows % g.L == 0);
-    rc = unetk_rows_reduce(pre_partials, K * g.L, pre_rows / g.L, d->C, sums, tmp1, st);   // -> sums[K][L][C]
+    rc = unetk_rows_reduce_alias(pre_partials, K * g.L, pre_rows / g.L, d->C, sums, tmp1, last1 ? al0 : nullptr,
+                                 last1 ? al1 : nullptr, st);   // -> sums[K][L][C]
   } else {
     GD_DISPATCH(bs, G, D, leaky, norm_bwd_reduce_kernel, dim3(nblk, g.L), dim3(256), lds, st, a);
     UNETK_LAUNCH_CHECK();
-    rc = unetk_rows_reduce(partial, K * g.L, nblk, d->C, sums, tmp1, st);   // -> sums[K][L][C]
+    rc = unetk_rows_reduce_alias(partial, K * g.L, nblk, d->C, sums, tmp1, last1 ? al0 : nullptr, last1 ? al1 : nullptr,
+                                 st);                          // -> sums[K][L][C]
   }
   if (rc != UNETK_OK) return rc;
   if (g.L == 1) {
     psum = sums;                                                               // one launch group: nothing to add up
   } else {
-    rc = unetk_rows_reduce(sums, K, g.L, d->C, psum, tmp2, st);               // -> psum[K][C]
+    rc = unetk_rows_reduce_alias(sums, K, g.L, d->C, psum, tmp2, al0, al1, st);   // -> psum[K][C]
     if (rc != UNETK_OK) return rc;
   }
   const bool gps = d->guide_per_sample != 0;
-  hipLaunchKernelGGL(norm_bwd_params_kernel, dim3((d->C + 255) / 256), dim3(256), 0, st, psum, d->C, gps ? 0 : G,
-                     (D || leaky) ? 1 : 0, dgamma, dbeta, gps ? nullptr : dgw, gps ? nullptr : dgb);
-  UNETK_LAUNCH_CHECK();
+  if (!simple) {
+    hipLaunchKernelGGL(norm_bwd_params_kernel, dim3((d->C + 255) / 256), dim3(256), 0, st, psum, d->C, gps ? 0 : G,
+                       (D || leaky) ? 1 : 0, dgamma, dbeta, gps ? nullptr : dgw, gps ? nullptr : dgb);
+    UNETK_LAUNCH_CHECK();
+  }
   if (gps) {   // dgw [N][G][C], dgb [N][C]: the per-launch-group sums, not their total
     const int kb = (D || leaky) ? 2 + G : 0;
     hipLaunchKernelGGL(norm_bwd_guide_ps_kernel, dim3((d->N * d->C + 255) / 256), dim3(256), 0, st, sums, d->N, d->C, G, kb, dgw,
