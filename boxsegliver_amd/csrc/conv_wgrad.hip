@@ -178,6 +178,8 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
     // other stage (previous tile) are done, so it may be refilled
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // (measured and dropped: the upper four waves issuing their pieces half-way through their rows, so that the two waves
+    // of a SIMD do not both spend the start of the tile on address arithmetic: 132 -> 127 TF)
     if (tile + 1 < t_end) issue_tile(tile + 1, stage ^ 1);
 
     const float* xh = smem + stage * G::STAGE_F;

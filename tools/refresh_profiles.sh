@@ -53,7 +53,15 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_bf16" -o write -- \
   python3 "$ROOT/bench.py" --dtype bf16 --size 512 --batch 8 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_write_bf16.log" 2>&1
 echo "pmc bf16 done"
+# matrix-pipe busy share and held clock per kernel (own pass: SQ + GRBM counters only), fp32 headline and bf16 512x512
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -o mfma -- \
+  python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_mfma.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma_bf16" -o mfma -- \
+  python3 "$ROOT/bench.py" --dtype bf16 --size 512 --batch 8 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_mfma_bf16.log" 2>&1
+echo "pmc mfma done"
 cd "$ROOT"
+python tools/pmc_mfma.py "$(find "$OUT/pmc_mfma" -name '*counter_collection.csv' | head -1)" "$OUT/pmc_mfma_busy.txt"
+python tools/pmc_mfma.py "$(find "$OUT/pmc_mfma_bf16" -name '*counter_collection.csv' | head -1)" "$OUT/pmc_mfma_busy_bf16.txt"
 F=$(find "$OUT/pmc_fetch_bf16" -name '*counter_collection.csv' | head -1)
 W=$(find "$OUT/pmc_write_bf16" -name '*counter_collection.csv' | head -1)
 python tools/pmc_summary.py "$F" "$W" "$OUT/pmc_traffic_bf16.json" | tee "$OUT/pmc_summary_bf16.txt"
@@ -61,5 +69,5 @@ cp "$(find "$OUT/prof_fp32" -name '*kernel_stats.csv' | head -1)" "$OUT/bench_ke
 cp "$(find "$OUT/prof_bf16" -name '*kernel_stats.csv' | head -1)" "$OUT/bench_bf16_kernel_stats.csv"
 cp "$(find "$OUT/prof_u3d" -name '*kernel_stats.csv' | head -1)" "$OUT/bench_unet3d_kernel_stats.csv"
 # keep the merge-back small: drop the raw traces
-rm -rf "$OUT/prof_fp32" "$OUT/prof_bf16" "$OUT/prof_u3d" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_fetch_bf16" "$OUT/pmc_write_bf16"
+rm -rf "$OUT/prof_fp32" "$OUT/prof_bf16" "$OUT/prof_u3d" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_fetch_bf16" "$OUT/pmc_write_bf16" "$OUT/pmc_mfma" "$OUT/pmc_mfma_bf16"
 head -8 "$OUT/bench_kernel_stats.csv"
