@@ -98,7 +98,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
 
   float4 hreg[BS ? 1 : HR][2];
   u32x4 hq[BS ? HR : 1];
-  u32x4 wreg[WR];
+  // Filter panels travel global -> registers -> LDS through a NINE-deep register ring (slot = tap): the panel of step s + 9
+  // is requested when the panel of step s + 1 has been handed to LDS.  One step is only 0.1-0.2 us of MFMA work and VMEM
+  // loads return in order, so a panel requested one step ahead (round 1-2) was waited for at every step for an L2 round
+  // trip -- and for a whole HBM round trip at the step after the next chunk's halo was requested.
+  u32x4 wring[9][WR];
   const bf16_t* xb = reinterpret_cast<const bf16_t*>(p.x);
   if constexpr (BS) {   // out-of-image items read the tensor's first bytes (always mapped) and are zeroed by a select: no
 #pragma unroll          // per-thread branch around the loads for the compiler to unswitch the main loop on
@@ -134,16 +138,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
         *reinterpret_cast<u32x4*>(&halo[buf * HALO_Q + hlds[r]]) = v;
       }
   };
-  auto load_w = [&](int c, int t) {
+  auto load_w = [&](int c, int t) {        // t: compile-time under the unrolled tap loop (register-array index)
     const uint4* base = wq + ((int64_t)t * cin8 + c * (CKB / 8)) * p.Cout;
 #pragma unroll
     for (int r = 0; r < WR; ++r)
-      if (tid + r * NT < WB_Q) wreg[r] = *reinterpret_cast<const u32x4*>(base + woff[r]);
+      if (tid + r * NT < WB_Q) wring[t][r] = *reinterpret_cast<const u32x4*>(base + woff[r]);
   };
-  auto store_w = [&](int buf) {
+  auto store_w = [&](int t, int buf) {
 #pragma unroll
     for (int r = 0; r < WR; ++r)
-      if (tid + r * NT < WB_Q) *reinterpret_cast<u32x4*>(&wbuf[buf * WB_Q + tid + r * NT]) = wreg[r];
+      if (tid + r * NT < WB_Q) *reinterpret_cast<u32x4*>(&wbuf[buf * WB_Q + tid + r * NT]) = wring[t][r];
   };
 
   int abase[TM];
@@ -165,9 +169,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
   const int nchunks = p.Cin / CKB;
 
   load_halo(0);
-  load_w(0, 0);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) load_w(0, t);
   store_halo(0);
-  store_w(0);
+  store_w(0, 0);
+  load_w(min(1, nchunks - 1), 0);
   __syncthreads();
 
   // The prefetches are UNCONDITIONAL (the last chunk re-fetches itself / tap 0 into the free buffers, never read): with
@@ -179,7 +185,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
     const int cn = min(c + 1, nchunks - 1);
 #pragma unroll
     for (int t = 0; t < 9; ++t, ++step) {
-      load_w(t < 8 ? c : cn, t < 8 ? t + 1 : 0);
       if (t == 0) load_halo(cn);                     // HBM latency >> one tap step: a whole chunk of slack
 
       const uint4* wb = wbuf + (step & 1) * WB_Q;
@@ -199,7 +204,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
                                                                   __builtin_bit_cast(bf16x8, b[tn]), acc[tm][tn], 0, 0, 0);
       }
 
-      store_w((step + 1) & 1);
+      store_w((t + 1) % 9, (step + 1) & 1);                            // the next step's panel (requested 8 steps ago)
+      load_w(min(c + (t < 8 ? 1 : 2), nchunks - 1), (t + 1) % 9);      // that slot's next use, 9 steps from now
       if (t == 8) store_halo((c + 1) & 1);
       // NOT __syncthreads(): its fence waits for every outstanding global load (vmcnt(0)), i.e. it would force the halo
       // prefetch of the next chunk -- issued at tap 0 for use at tap 8 -- to land within ONE tap step.  The LDS writes
