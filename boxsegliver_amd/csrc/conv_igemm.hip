@@ -26,6 +26,13 @@
 namespace {
 
 constexpr int CK = 16;   // input channels per K-chunk
+// tap steps at which the next chunk's halo is requested from HBM / written to LDS (registers in between)
+#ifndef HALO_LD_T
+#define HALO_LD_T 2
+#endif
+#ifndef HALO_ST_T
+#define HALO_ST_T 7
+#endif
 constexpr int PS = 20;   // LDS pixel stride (floats): 16 + 4 pad -> conflict-free ds_read_b128
 constexpr int TW = 16;   // spatial tile width
 
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(WM* WN * 64, (TM * TN == 8 ? 2 : 1)) void conv3x3_i
     for (int t = 0; t < 9; ++t, ++step) {
       const bool has_next = (t < 8) || more_chunks;
       if (has_next) load_w(t < 8 ? c : c + 1, t < 8 ? t + 1 : 0);
-      if (t == 5 && more_chunks) load_halo(c + 1);
+      if (t == HALO_LD_T && more_chunks) load_halo(c + 1);
 
       const float* wb = wbuf + (step & 1) * WB_F;
       const int toff = ((t / 3) * DIL * HWD + (t % 3) * DIL) * PS;
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(WM* WN * 64, (TM * TN == 8 ? 2 : 1)) void conv3x3_i
       }
 
       if (has_next) store_w((step + 1) & 1);
-      if (t == 5 && more_chunks) store_halo((c + 1 - c_begin) & 1);
+      if (t == HALO_ST_T && more_chunks) store_halo((c + 1 - c_begin) & 1);
       __syncthreads();
     }
   }

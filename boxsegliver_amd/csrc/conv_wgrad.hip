@@ -11,6 +11,7 @@
 // and the pixel-row slices are summed through LDS in a fixed-order tree at the end.  Partial panels go to a
 // workspace slab per split; a fixed-order reduction sums the slabs -> bit-reproducible, no atomics.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -178,15 +179,17 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
     // other stage (previous tile) are done, so it may be refilled
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // (measured and dropped: the upper four waves issuing their pieces half-way through their rows, so that the two waves
-    // of a SIMD do not both spend the start of the tile on address arithmetic: 132 -> 127 TF)
-    if (tile + 1 < t_end) issue_tile(tile + 1, stage ^ 1);
+    // The next tile's loads (a few hundred address instructions per wave) are issued by the even waves now and by the odd
+    // waves half-way through their rows, from ONE call site inside the row loop: 131.3 -> 133.8 TF.  (A second, inlined
+    // call site ahead of the loop cost 7 % by itself -- measured with the stagger switched off.)
+    const int issue_rr = ((wave & 1) != 0 && G::RPW > 1) ? G::RPW / 2 : 0;
 
     const float* xh = smem + stage * G::STAGE_F;
     const float* dyt = xh + G::XH_F;
     // this wave's k-steps (rows RPW*ks .. +RPW); lane half h takes the odd/even column of a pixel pair
 #pragma unroll 1
     for (int rr = 0; rr < G::RPW; ++rr) {
+      if (rr == issue_rr && tile + 1 < t_end) issue_tile(tile + 1, stage ^ 1);
       const int r = ks * G::RPW + rr;
       if constexpr (BF) {
         float bv[8];
@@ -201,6 +204,27 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw)
             acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(av + kw), b, acc[kh * 3 + kw], 0, 0, 0);
+        }
+        continue;
+      }
+      if constexpr (S == 1 && DIL == 1) {
+        // lane half h takes the columns h TW/2 .. h TW/2 + TW/2 - 1 of the row: the three kw taps of consecutive columns
+        // share their x values, so a filter row needs TW/2 + 2 LDS reads per lane for 3 TW/2 MFMAs (the even / odd column
+        // split below reads one value per MFMA: 1.1 LDS instructions per MFMA against 0.3 here)
+        constexpr int TWH = TW_ / 2;
+        float bv[TWH];
+#pragma unroll
+        for (int j = 0; j < TWH; ++j) bv[j] = dyt[(r * TW_ + h * TWH + j) * COT + b_lane];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          float av[TWH + 2];
+#pragma unroll
+          for (int j = 0; j < TWH + 2; ++j) av[j] = xh[((r + kh) * HWD_ + h * TWH + j) * CIT + a_lane];
+#pragma unroll
+          for (int c2 = 0; c2 < TWH; ++c2)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+              acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c2 + kw], bv[c2], acc[kh * 3 + kw], 0, 0, 0);
         }
         continue;
       }
