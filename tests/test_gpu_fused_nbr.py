@@ -41,7 +41,8 @@ def _pair(kind, prec, n, h, w, c0, c1, c2, fuse, seed=3):
 
 @pytest.mark.parametrize("kind", ["batch_norm", "instance_norm"])
 @pytest.mark.parametrize("prec,shape", [(0, (2, 24, 40, 64, 128, 128)), (0, (3, 16, 32, 64, 256, 128)),
-                                        (2, (2, 32, 48, 64, 128, 128)), (2, (2, 24, 16, 128, 128, 256))])
+                                        (2, (2, 32, 48, 64, 128, 128)), (2, (2, 24, 16, 128, 128, 256)),
+                                        (0, (16, 64, 64, 64, 256, 256))])    # 16 x 16 pixel tiles (>= 512 blocks, K = 256)
 def test_fused_reduction_equals_separate_passes(kind, prec, shape):
     from boxsegliver_amd import ops
     n, h, w, c0, c1, c2 = shape
@@ -57,7 +58,7 @@ def test_fused_reduction_equals_separate_passes(kind, prec, shape):
         # same per-element arithmetic; the sums are grouped per conv tile instead of per reduction block.  bf16 storage
         # rounds dy once more downstream, so a last-bit change of a sum can move isolated dy values by one bf16 ulp
         assert err < (2e-6 if prec == 0 else 3e-3), (name, err)
-    if prec == 0:
+    if prec == 0 and n * h * w <= 8192:                       # the float64 CPU oracle of the small shapes only
         x, w1, g1, b1, w2, g2, b2, dz = ops_in
         v = [t.double().requires_grad_(True) for t in (x, w1, g1, b1, w2, g2, b2)]
 

@@ -115,7 +115,8 @@ def test_conv3x3_dgrad_wgrad(ops, shape):
     assert torch.equal(dw, dw2)
 
 
-@pytest.mark.parametrize("shape", [(8, 128, 128, 64, 128), (4, 64, 64, 256, 256), (16, 256, 256, 64, 64)])
+@pytest.mark.parametrize("shape", [(8, 128, 128, 64, 128), (4, 64, 64, 256, 256), (16, 256, 256, 64, 64),
+                                   (8, 128, 120, 64, 128)])      # 16 x 16 pixel tiles with a ragged last tile column
 def test_conv3x3_large_shapes_against_on_device_float64(ops, shape):
     """BASELINE-sized layers (thousands of tiles, many tiles per split-K block): forward, input gradient and filter
     gradient against PyTorch's float64 convolution evaluated ON THE DEVICE (a checker the CPU oracle is too slow for;
