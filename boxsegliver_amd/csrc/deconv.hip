@@ -145,7 +145,7 @@ __device__ __forceinline__ void pw_epilogue_bf16s(const PwParams& p, f32x16 (&ac
 
 // MODE 0: forward (scatter epilogue), MODE 1: dgrad (gather prologue)
 template <int MODE, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(WM* WN * 64) void pw_gemm_kernel(PwParams p) {
+__global__ __launch_bounds__(WM* WN * 64, (TM * TN == 8 ? 2 : 1)) void pw_gemm_kernel(PwParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int A_F = BM * PS, WB_F = CK * BN;
@@ -737,6 +737,10 @@ int run_pw(PwParams& p, hipStream_t st) {
   }
   if (p.Ncols % 128 == 0) {
     p.n_ntiles = p.Ncols / 128;
+    // fp32, long K: 256-row tiles while they still give two blocks per CU -- half the filter-panel staging per MFMA
+    // (conv_igemm.hip).  Measured at bs 32: K = 1024 forward 0.335 -> 0.277 ms, K = 1024 input gradient -0.045 ms; K <= 512
+    // is 5-10 % SLOWER (eight to thirty-two steps do not amortise the four-fragment prologue / epilogue).
+    if (!p.bf16 && p.K >= 1024 && (int64_t)((p.M + 255) / 256) * p.n_ntiles >= 512) return launch_pw<MODE, 2, 2, 4, 2>(p, st);
     return p.bf16 ? launch_pw_bf16<MODE, 2, 2, 2, 2>(p, st) : launch_pw<MODE, 2, 2, 2, 2>(p, st);
   }
   p.n_ntiles = p.Ncols / 64;
