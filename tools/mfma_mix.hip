@@ -1,7 +1,10 @@
 // Micro-benchmark: what the fp32 MFMA loop of the conv kernels loses to its surroundings.  The same 2 x 2 fragment loop as
 // conv_igemm.hip (32 MFMAs per step, operands from four ds_read_b128 per 16 MFMAs), with the features of the real kernel
 // switched on one at a time:  V0 register-only operands, V1 + LDS operand reads, V2 + one barrier and two ds_write_b128 per
-// step, V3 + the global prefetch loads feeding those writes.  1-3 blocks (4 waves) per CU.
+// step, V3 + five global prefetch loads per step written to LDS at its end, V4 filter fragments straight from global memory
+// to registers (barrier + LDS writes every ninth step), V5 = V3 + s_setprio, V6 = V3 with a barrier every second step,
+// V7 = V3 through direct-to-LDS loads.  1-3 blocks (4 waves) per CU.  Output of one run: profiles/r02_mfma_mix.txt.
+// V3..V7 overwrite their own operands (timing probes, not a correct GEMM); every global index is masked into the source.
 // Build: hipcc --offload-arch=gfx950 -O3 tools/mfma_mix.hip -o /tmp/mfma_mix
 #include <hip/hip_runtime.h>
 #include <cstdio>
