@@ -29,6 +29,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CKB = 32;  // input channels per K-chunk
+// depth of the filter-panel register ring (see the kernel): 9 = a whole chunk of taps ahead.  A depth of 3 keeps the 4-wave
+// configurations at three waves per SIMD instead of two, and is slower all the same (128 x 128: 834 vs 948 TF, 256 x 64:
+// 723 vs 741 TF at 512 x 512 bs 8).
+#ifndef UNETK_BF16_RING
+#define UNETK_BF16_RING(WM, WN, TM, TN) 9
+#endif
 constexpr int PSQ = 5;   // LDS pixel stride in 16-B units: 64 B of bf16 + 16 B pad -> conflict-free ds_read_b128
 constexpr int TW = 16;
 constexpr int HWD = TW + 2;
@@ -43,6 +49,7 @@ __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
 // the plain kernels keep their register budget (see conv_igemm.hip).
 template <int WM, int WN, int TM, int TN, bool BS = false, bool NBR = false>
 __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvParams p) {
+  constexpr int RING = UNETK_BF16_RING(WM, WN, TM, TN);   // depth of the filter-panel register ring (divides 9)
   static_assert(!BS || TN == 2, "bf16 storage packs channel pairs (tile 0 / tile 1) into one word");
   static_assert(!NBR || BS, "the fused reduction is built for bf16 storage");
   constexpr int NT = WM * WN * 64;
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
   // is requested when the panel of step s + 1 has been handed to LDS.  One step is only 0.1-0.2 us of MFMA work and VMEM
   // loads return in order, so a panel requested one step ahead (round 1-2) was waited for at every step for an L2 round
   // trip -- and for a whole HBM round trip at the step after the next chunk's halo was requested.
-  u32x4 wring[9][WR];
+  u32x4 wring[RING][WR];
   const bf16_t* xb = reinterpret_cast<const bf16_t*>(p.x);
   if constexpr (BS) {   // out-of-image items read the tensor's first bytes (always mapped) and are zeroed by a select: no
 #pragma unroll          // per-thread branch around the loads for the compiler to unswitch the main loop on
@@ -138,16 +145,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
         *reinterpret_cast<u32x4*>(&halo[buf * HALO_Q + hlds[r]]) = v;
       }
   };
-  auto load_w = [&](int c, int t) {        // t: compile-time under the unrolled tap loop (register-array index)
+  auto load_w = [&](int c, int t) {        // t: compile-time under the unrolled tap loop (register-array index t % RING)
     const uint4* base = wq + ((int64_t)t * cin8 + c * (CKB / 8)) * p.Cout;
 #pragma unroll
     for (int r = 0; r < WR; ++r)
-      if (tid + r * NT < WB_Q) wring[t][r] = *reinterpret_cast<const u32x4*>(base + woff[r]);
+      if (tid + r * NT < WB_Q) wring[t % RING][r] = *reinterpret_cast<const u32x4*>(base + woff[r]);
   };
   auto store_w = [&](int t, int buf) {
 #pragma unroll
     for (int r = 0; r < WR; ++r)
-      if (tid + r * NT < WB_Q) *reinterpret_cast<u32x4*>(&wbuf[buf * WB_Q + tid + r * NT]) = wring[t][r];
+      if (tid + r * NT < WB_Q) *reinterpret_cast<u32x4*>(&wbuf[buf * WB_Q + tid + r * NT]) = wring[t % RING][r];
   };
 
   int abase[TM];
@@ -170,10 +177,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
 
   load_halo(0);
 #pragma unroll
-  for (int t = 0; t < 9; ++t) load_w(0, t);
+  for (int t = 0; t < RING; ++t) load_w(0, t);
   store_halo(0);
   store_w(0, 0);
-  load_w(min(1, nchunks - 1), 0);
+  load_w(min(RING / 9, nchunks - 1), RING % 9);            // step RING's panel into the slot just emptied
   __syncthreads();
 
   // The prefetches are UNCONDITIONAL (the last chunk re-fetches itself / tap 0 into the free buffers, never read): with
@@ -204,8 +211,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
                                                                   __builtin_bit_cast(bf16x8, b[tn]), acc[tm][tn], 0, 0, 0);
       }
 
-      store_w((t + 1) % 9, (step + 1) & 1);                            // the next step's panel (requested 8 steps ago)
-      load_w(min(c + (t < 8 ? 1 : 2), nchunks - 1), (t + 1) % 9);      // that slot's next use, 9 steps from now
+      store_w((t + 1) % 9, (step + 1) & 1);                            // the next step's panel (requested RING - 1 steps ago)
+      load_w(min(c + (t + 1 + RING) / 9, nchunks - 1), (t + 1 + RING) % 9);   // that slot's next use, RING steps from now
       if (t == 8) store_halo((c + 1) & 1);
       // NOT __syncthreads(): its fence waits for every outstanding global load (vmcnt(0)), i.e. it would force the halo
       // prefetch of the next chunk -- issued at tap 0 for use at tap 8 -- to land within ONE tap step.  The LDS writes
