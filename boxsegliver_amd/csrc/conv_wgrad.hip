@@ -186,7 +186,9 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
 
     const float* xh = smem + stage * G::STAGE_F;
     const float* dyt = xh + G::XH_F;
-    // this wave's k-steps (rows RPW*ks .. +RPW); lane half h takes the odd/even column of a pixel pair
+    // this wave's k-steps (rows RPW*ks .. +RPW); lane half h takes the odd/even column of a pixel pair.  (Measured and
+    // dropped: two rows per iteration with the shared x rows carried in registers and every LDS read requested a filter row
+    // ahead -- 250 VGPRs, 131 instead of 133 TF: the LDS latency at the top of a row is not what this kernel waits for.)
 #pragma unroll 1
     for (int rr = 0; rr < G::RPW; ++rr) {
       if (rr == issue_rr && tile + 1 < t_end) issue_tile(tile + 1, stage ^ 1);
