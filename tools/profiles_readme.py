@@ -47,9 +47,9 @@ differ): other calls of this session read 414.4-419.4 slices/s (fp32 headline) a
 * `{R}_bench_n1.json` -- `python bench.py --steps 10 --warmup 3` (headline, cfg1: UNet 256x256x3 bs 32 fp32, fwd+bwd+TF-Adam):
   **{hv} slices/s, {hms} ms/step = {htf} TFLOP/s = {hp:.1f} % of the fp32 peak**
   (round 1: 402.0, 79.60 ms, 73.8 %); dominant kernel `{rk}` {ra} TFLOP/s = {rfp:.1f} %,
-  {rg} GFLOP and {rms} ms per launch (HIP events on the launch stream inside the timed region); `traffic` = launch-weighted
-  mean over the tile configuration's instantiations in `{R}_pmc_traffic.json` (null in THIS file: it was written before the
-  PMC pass of the same refresh existed for the new tile -- a bench run against the committed profiles fills it);
+  {rg} GFLOP and {rms} ms per launch (HIP events on the launch stream inside the timed region); `traffic` {tr} bytes = launch-weighted
+  mean over the tile configuration's instantiations in `{R}_pmc_traffic.json` (this file is a run of its own, made after the
+  refresh: the other benches of the refresh ran on another box, see the spread above);
   `cpu_baseline` (oracle port) at cfg1-shaped bs 2 and cfg0 (2 classes), median of 5 steps.
 * `{R}_bench_kernel_stats.csv` -- `rocprofv3 --kernel-trace --stats` of `bench.py --steps 5 --warmup 2 --no-cpu-baseline`
   (1 variable-creating eval forward + 2 warm-up + 5 timed steps).  `<2,2,4,2,...>` / `<4,1,2,2,...>` = the 16 x 16 pixel tiles
@@ -99,7 +99,7 @@ bf16 512x512 bs 8:
 ## UNet3D 96^3, one patch
 
 {t3}""".format(R=R, hv=h["value"], hms=h["ms_per_step"], htf=h["whole_step_tflops"], hp=pct(h), rk=rf["kernel"], ra=rf["achieved"],
-               rfp=100 * rf["frac"], rg=rf["avg_launch_gflop"], rms=rf["avg_launch_ms"], bv=hb["value"], bms=hb["ms_per_step"],
+               rfp=100 * rf["frac"], rg=rf["avg_launch_gflop"], tr=rf.get("traffic"), rms=rf["avg_launch_ms"], bv=hb["value"], bms=hb["ms_per_step"],
                btf=hb["whole_step_tflops"], bp=pct(hb), cv=hc["value"], bk=rfb["kernel"], ba=rfb["achieved"], bfp=100 * rfb["frac"],
                h256v=h256["value"], h256ms=h256["ms_per_step"], gbv=gb["value"], gv=g["value"], gp=pct(g),
                ov=" / ".join(str(o["value"]) for o in others), u1v=u1["value"], u1ms=u1["ms_per_step"], u1p=pct(u1),
