@@ -12,7 +12,7 @@ transposed conv writes channels [C,2C) -- tf.concat (UNet.py:93) costs zero byte
 import torch
 
 from .. import ops
-from ..loss_metrics import build_head_desc, metric_from_sums, pixel_weights
+from ..loss_metrics import build_head_desc, metrics_from_sums, pixel_weights
 from ..utils import distribution_utils
 from . import base
 from .base import ModeKeys, ParamStore
@@ -218,10 +218,11 @@ class UNet(base.BaseNet):
             return
         _, _, result = self._head
         n = self._inputs["images"].shape[0]
+        # every foreground class of a metric in one pass; keys in the reference's order (class-major)
+        per_class = {met: metrics_from_sums(result, n, self.num_classes, met) for met in self.args.metrics_train}
         for i in range(1, self.num_classes):
-            obj = self.classes[i]
             for met in self.args.metrics_train:
-                self.metrics_dict["{}/{}".format(obj, met)] = metric_from_sums(result, n, self.num_classes, i, met)
+                self.metrics_dict["{}/{}".format(self.classes[i], met)] = per_class[met][i - 1]
 
     def _build_summaries(self):
         """UNet.py:157-176 writes TensorBoard image summaries; out of scope (SURVEY.md 2 #23)."""

@@ -13,7 +13,7 @@ zero-copy concat as in the 2-D nets.
 import torch
 
 from .. import ops
-from ..loss_metrics import build_head_desc, metric_from_sums
+from ..loss_metrics import build_head_desc, metrics_from_sums
 from ..utils import distribution_utils
 from . import base
 from .base import ModeKeys
@@ -241,10 +241,11 @@ class UNet3D(base.BaseNet):
             return
         _, _, result = self._head
         n = self._inputs["images"].shape[0]
+        # every foreground class of a metric in one pass; keys in the reference's order (class-major)
+        per_class = {met: metrics_from_sums(result, n, self.num_classes, met) for met in self.args.metrics_train}
         for i in range(1, self.num_classes):
-            obj = self.classes[i]
             for met in self.args.metrics_train:
-                self.metrics_dict["{}/{}".format(obj, met)] = metric_from_sums(result, n, self.num_classes, i, met)
+                self.metrics_dict["{}/{}".format(self.classes[i], met)] = per_class[met][i - 1]
 
     def _build_summaries(self):
         return
