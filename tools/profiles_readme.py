@@ -42,14 +42,14 @@ print("""# Round 2 profiles (one MI355X, gfx950, ROCm 7.2)
 All produced on the GPU box by `tools/refresh_profiles.sh` (ONE `gpurun` call, i.e. one device; the script holds the exact
 command lines) with the kernels of the commit that adds this file; this text is written from those files by
 `tools/profiles_readme.py`.  Boxes of the pool differ by 3-5 % on the same binary (`MI355X_MICROARCH.md`, DVFS notes: devices
-differ): other calls of this session read 414.4-419.4 slices/s (fp32 headline) and 534-549 slices/s (bf16 512x512).
+differ): other calls of this session read 414.4-419.4 slices/s (fp32 headline) and 534-551 slices/s (bf16 512x512).
 
 * `{R}_bench_n1.json` -- `python bench.py --steps 10 --warmup 3` (headline, cfg1: UNet 256x256x3 bs 32 fp32, fwd+bwd+TF-Adam):
   **{hv} slices/s, {hms} ms/step = {htf} TFLOP/s = {hp:.1f} % of the fp32 peak**
   (round 1: 402.0, 79.60 ms, 73.8 %); dominant kernel `{rk}` {ra} TFLOP/s = {rfp:.1f} %,
   {rg} GFLOP and {rms} ms per launch (HIP events on the launch stream inside the timed region); `traffic` {tr} bytes = launch-weighted
-  mean over the tile configuration's instantiations in `{R}_pmc_traffic.json` (this file is a run of its own, made after the
-  refresh: the other benches of the refresh ran on another box, see the spread above);
+  mean over the tile configuration's instantiations in `{R}_pmc_traffic.json` (the PMC file of the PREVIOUS refresh of the same kernels: the bench reads the
+  committed one, the passes of this refresh came after it in the script);
   `cpu_baseline` (oracle port) at cfg1-shaped bs 2 and cfg0 (2 classes), median of 5 steps.
 * `{R}_bench_kernel_stats.csv` -- `rocprofv3 --kernel-trace --stats` of `bench.py --steps 5 --warmup 2 --no-cpu-baseline`
   (1 variable-creating eval forward + 2 warm-up + 5 timed steps).  `<2,2,4,2,...>` / `<4,1,2,2,...>` = the 16 x 16 pixel tiles
@@ -63,8 +63,8 @@ differ): other calls of this session read 414.4-419.4 slices/s (fp32 headline) a
   same two commands, summarised by `tools/pmc_mfma.py`: the clock each kernel held and the share of cycles its matrix pipes
   were busy (DESIGN.md 5.0 "Where the last 10 % go").
 * **bf16 storage mode** (`--dtype bf16`): `{R}_bench_bf16_512_bs8.json` (configs[2] per-GPU shape):
-  **{bv} slices/s, {bms} ms/step = {btf} TFLOP/s = {bp:.1f} % of the dense bf16 peak** on this box (548.7 slices/s, 14.58 ms =
-  25.2 % on another box of the session; round 1, fp32 storage: 324.1 slices/s, 24.7 ms, 14.9 % -- kept as `--dtype bf16c`:
+  **{bv} slices/s, {bms} ms/step = {btf} TFLOP/s = {bp:.1f} % of the dense bf16 peak** on this box (537.6-548.7 slices/s = 24.7-25.2 %
+  on other boxes of the session; round 1, fp32 storage: 324.1 slices/s, 24.7 ms, 14.9 % -- kept as `--dtype bf16c`:
   `{R}_bench_bf16c_512_bs8.json`, {cv} slices/s); dominant kernel `{bk}` {ba} TFLOP/s = {bfp:.1f} %;
   `{R}_bench_bf16_256_bs32.json` headline shape in bf16: {h256v} slices/s ({h256ms} ms/step);
   `{R}_bench_bf16_gunet_bs8.json` {gbv} slices/s; `{R}_bench_bf16_kernel_stats.csv` -- rocprofv3 stats of the 512x512 bs 8 run.
