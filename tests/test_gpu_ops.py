@@ -144,6 +144,18 @@ def test_conv3x3_large_shapes_against_on_device_float64(ops, shape):
     assert torch.equal(dw, ops.conv3x3_wgrad(x, dy))
 
 
+@pytest.mark.parametrize("n,off", [(1, 0), (3, 0), (4099, 0), (1 << 20, 0), (1000003, 1), (777, 3)])
+def test_sumsq_sizes_and_alignment(ops, n, off):
+    # float4 body + scalar tail; a view that starts off a 16-byte boundary takes the scalar path
+    g = torch.Generator(device="cuda").manual_seed(n)
+    buf = torch.randn(n + 8, device="cuda", generator=g)
+    v = buf[off:off + n]
+    ref = float((v.double() ** 2).sum())
+    got = float(ops.sumsq(v).item())
+    assert abs(got - ref) <= 1e-6 * max(ref, 1.0), (got, ref)
+    assert got == float(ops.sumsq(v).item())                 # fixed summation order
+
+
 def test_conv3x3_wgrad_first_layer(ops):
     rng = np.random.default_rng(13)
     x = torch.tensor(rng.random((2, 16, 32, 3)), dtype=torch.float64)
@@ -175,6 +187,12 @@ NORM_CASES = [
     ("instance_norm", 128, (2, 16, 8), False, True, 1),     # GUNet.yml: centre only + 1-channel spatial guide
     ("batch_norm", 128, (2, 16, 8), False, True, 2),        # BN encoder with a 2-channel guide
     ("instance_norm", 64, (2, 8, 8), False, False, 0),
+    # many pixels: the backward's partial rows reach the wide final reduction directly (576 and 1024 rows) and, per
+    # sample, through a second level over the launch groups
+    ("batch_norm", 64, (1, 96, 96), True, True, 0),
+    ("batch_norm", 64, (4, 128, 128), True, True, 0),
+    ("instance_norm", 32, (3, 64, 96), True, True, 0),
+    ("batch_norm", 128, (2, 64, 64), False, True, 1),
 ]
 
 
