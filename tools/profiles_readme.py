@@ -61,7 +61,8 @@ differ): other calls of this session read 414.4-419.4 slices/s (fp32 headline) a
   summarised by `tools/pmc_summary.py` (read side x2: the gfx950 FETCH_SIZE correction).
 * `{R}_pmc_mfma_busy.txt` / `{R}_pmc_mfma_busy_bf16.txt` -- `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` (own pass) of the
   same two commands, summarised by `tools/pmc_mfma.py`: the clock each kernel held and the share of cycles its matrix pipes
-  were busy (DESIGN.md 5.0 "Where the last 10 % go").
+  were busy (DESIGN.md 5.0 "Where the last 10 % go"); `{R}_pmc_mfma_busy_unet3d.txt`: the same pass for UNet3D 96^3 at one
+  patch; `{R}_mfma_mix.txt`: output of the stand-alone MFMA-loop probe `tools/mfma_mix.hip`.
 * **bf16 storage mode** (`--dtype bf16`): `{R}_bench_bf16_512_bs8.json` (configs[2] per-GPU shape):
   **{bv} slices/s, {bms} ms/step = {btf} TFLOP/s = {bp:.1f} % of the dense bf16 peak** on this box (537.6-548.7 slices/s = 24.7-25.2 %
   on other boxes of the session; round 1, fp32 storage: 324.1 slices/s, 24.7 ms, 14.9 % -- kept as `--dtype bf16c`:
