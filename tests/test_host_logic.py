@@ -166,3 +166,16 @@ def test_synthetic_input_contract():
     i2, l2, _ = synthetic.make_batch(4, 64, 64, 3, 3, seed=1234)
     assert np.array_equal(images, i2) and np.array_equal(labels, l2)
     assert set(np.unique(synthetic.make_batch(2, 32, 32, 3, 2)[1])) <= {0, 1}
+
+
+def test_profiles_readme_is_generated_from_the_committed_profiles():
+    """profiles/r02_README.md is written by tools/profiles_readme.py from the bench lines, rocprofv3 tables and PMC
+    summaries next to it: regenerating it must give the committed text (numbers in the prose cannot drift from the files)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "profiles_readme.py"), "r02"], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    with open(os.path.join(root, "profiles", "r02_README.md")) as f:
+        assert out.stdout == f.read()
