@@ -19,7 +19,9 @@
 // compiled out (results wrong, timing only) the same launches run at 148-151 TF = 95-96 %, which is also what the
 // stand-alone loop of tools/mfma_mix.hip reaches with a barrier per 32 MFMAs: the staging instructions themselves, not
 // their latency, take MFMA issue time (s_setprio around the MFMA block, either way: no change).  Hence the 16 x 16 pixel
-// tiles below -- fewer staged bytes per MFMA -- wherever the grid still gives two blocks per CU.
+// tiles below -- fewer staged bytes per MFMA -- wherever the grid still gives two blocks per CU.  (Also measured, no gain: an
+// epilogue fast path for interior tiles -- wave-uniform base, scalar row offsets, no per-row bounds branch, a quarter of
+// the ~600 instructions per wave and tile -- 415.5 vs 416.7 slices/s: the other waves of the SIMD already cover it.)
 #include "common.h"
 #include "pack.h"
 
