@@ -84,7 +84,7 @@ class ParamStore(object):
         return sum(self.where[n][2] for n in self.trainable_names())
 
     def zero_grad(self):
-        ops.new_step()                        # the backward kernels may write each gradient slot in place once per step
+        ops.new_step(self.grad.values())      # the backward kernels may write each of THIS store's gradient slots in place once per step
         for g in self.grad.values():
             g.zero_()
         for name in self.trainable_names():

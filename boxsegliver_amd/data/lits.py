@@ -391,13 +391,16 @@ def input_fn(mode, params):
     if len(cases) == 0:
         raise ValueError("No valid dataset found!")
     rs = tuple(getattr(args, "zoom_scale", (1., 1.)))                        # --zoom_scale (input_pipeline.py:62)
-    seed = int(getattr(args, "seed", 1234) or 1234) + 1000 * int(params.get("rank", 0))
+    base_seed = int(getattr(args, "seed", 1234) or 1234)
+    seed = base_seed + 1000 * int(params.get("rank", 0))                     # training: every replica its own shard of the stream
     if mode == "train":
         return batches(store, cases, args, True, seed, getattr(args, "liver_percent", 0.), getattr(args, "tumor_percent", 0.), rs)
     if mode == "eval_online" and getattr(args, "eval_3d", False):
         return batches_eval_3d(store, cases, args)
     if mode == "eval_online":
-        gen = batches(store, cases, args, False, seed + 500, getattr(args, "liver_percent", 0.),
+        # rank-INDEPENDENT stream: the reference (one process) evaluates one sample, and the evaluator hooks let rank 0 alone
+        # decide / save -- every replica must see the same validation data so their best-result state stays identical
+        gen = batches(store, cases, args, False, base_seed + 500, getattr(args, "liver_percent", 0.),
                       getattr(args, "tumor_percent", 0.))
         n = int(getattr(args, "eval_num_batches_per_epoch", 100))
         return (next(gen) for _ in range(n))

@@ -38,7 +38,7 @@ class _Workspace(object):
 
 WORKSPACE = _Workspace()
 FUSE_NBR = True         # conv2's input gradient also emits conv1's norm-backward reduction (unetk_conv3x3_dgrad_nbr)
-FUSED_NBR = {}          # dx.data_ptr() -> (producer y.data_ptr(), shape, partials, rows); consumed by the producer's backward
+FUSED_NBR = {}          # dx.data_ptr() -> (producer y.data_ptr(), shape, partials, rows, dx._version); consumed by the producer's backward
 DEBUG_CAPTURE = None    # tools/: set to a list to record each conv unit's backward operands
 PROFILE_SHAPES = False  # bench.py --detail: one row per (kernel, layer shape)
 PROFILE = None          # bench.py: set to a list -> (kernel tag, algorithmic FLOPs, start event, end event)
@@ -201,34 +201,71 @@ def alias(t, offset_elems=0, size=None, stride=None):
 class _GradSink(object):
     """Parameter gradients written by the backward kernels straight into the variable's slice of the flat gradient
     buffer (ParamStore.grad) instead of a fresh tensor that autograd then adds to it: 65 tiny add launches per step
-    gone.  A slot is written in place at most once between two new_step() calls (ParamStore.zero_grad); a second
-    gradient for the same variable falls back to the returned-tensor path, i.e. autograd accumulates it.  `hooks`
-    maps a slot to the callback the data-parallel buckets would have got from a post-accumulate hook."""
+    gone.  A slot is written in place at most once between two new_step() calls (ParamStore.zero_grad), and only when
+    the variable has exactly ONE recorded use (`uses`, counted by the forwards that end up on an autograd tape; the count
+    restarts with the first recorded forward after a backward -- Solver.__call__ runs zero_grad BETWEEN the forward and
+    its backward, so zero_grad cannot be the reset point): a variable shared by two ops takes the returned-tensor path
+    for every use, i.e. autograd sums the contributions and the post-accumulate hook fires once, after the sum -- the
+    data-parallel buckets must never see an arrival that precedes the variable's last contribution.  A denied slot is
+    always safe (autograd accumulates).  `hooks` maps a slot to the callback the buckets would have got from a
+    post-accumulate hook."""
     written = set()
+    uses = {}
+    tape = True         # is the forward being run recorded on an autograd tape (set by _Op.apply)
+    stale = False       # a backward has run since `uses` was last cleared: the next recorded forward starts a fresh count
     hooks = {}
     enabled = True
 
 
-def new_step():
-    _GradSink.written.clear()
+class _Op(torch.autograd.Function):
+    """Base of the libunetk autograd nodes: notes, before the forward runs (inside it grad mode is always off and
+    needs_input_grad is set regardless), whether a tape is recording -- an evaluation forward under torch.no_grad() must
+    not count as a use of its parameters (grad_sink)."""
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        _GradSink.tape = torch.is_grad_enabled()
+        return super(_Op, cls).apply(*args, **kwargs)
+
+
+def new_step(bufs=None):
+    """Start of a step for the gradient buffers `bufs` (a ParamStore's flat gradient tensors; None = every slot): their
+    slots may be written in place again.  Another model's slots keep their state (its own zero_grad resets them)."""
+    if bufs is None:
+        _GradSink.written.clear()
+    else:
+        spans = [(b.data_ptr(), b.data_ptr() + b.numel() * b.element_size()) for b in bufs]
+        _GradSink.written.difference_update([k for k in _GradSink.written if any(lo <= k < hi for lo, hi in spans)])
     FUSED_NBR.clear()
 
 
-def grad_sink(p):
-    """The flat-gradient slot of leaf parameter `p` when a backward kernel may write it in place, else None."""
+def grad_sink(p, ctx=None):
+    """The flat-gradient slot of leaf parameter `p` when a backward kernel may write it in place, else None.  Called from
+    an op's forward with its autograd context: a forward no tape records (torch.no_grad(): evaluation) is not a use."""
     if not _GradSink.enabled or p is None or not p.is_leaf or not p.requires_grad:
+        return None
+    if ctx is not None and not _GradSink.tape:
         return None
     g = p.grad
     if g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.shape != p.shape:
         return None
+    if _GradSink.stale:
+        _GradSink.uses.clear()
+        _GradSink.stale = False
+    k = g.data_ptr()
+    _GradSink.uses[k] = _GradSink.uses.get(k, 0) + 1
     return g
 
 
 def _take(slot):
-    """Claim `slot` for an in-place write in this step (None if absent or already written)."""
-    if slot is None or slot.data_ptr() in _GradSink.written:
+    """Claim `slot` for an in-place write in this step (None if absent, already written, or used more than once)."""
+    _GradSink.stale = True
+    if slot is None:
         return None
-    _GradSink.written.add(slot.data_ptr())
+    k = slot.data_ptr()
+    if k in _GradSink.written or _GradSink.uses.get(k, 0) != 1:
+        return None
+    _GradSink.written.add(k)
     return slot
 
 
@@ -366,7 +403,10 @@ def conv3x3_dgrad(dy, wp_dgrad, cin, x_stride=None, dx=None, bf16=False, dilatio
                                                          ptr(paff[2]), ptr(paff[3]), ptr(paff[0]), ptr(paff[1]),
                                                          1 if per_sample else 0, ptr(part), stream_ptr()),
                       "conv3x3_dgrad_nbr")
-            FUSED_NBR[dx.data_ptr()] = (py.data_ptr(), tuple(dx.shape), part, rows)
+            # dx._version: when the producer's activation has a SECOND consumer, autograd sums the gradients IN PLACE into
+            # this tensor (same data_ptr, same shape) -- the partials computed from this dx alone would be stale; any in-place
+            # accumulation bumps the version counter, and the producer's backward then ignores the entry
+            FUSED_NBR[dx.data_ptr()] = (py.data_ptr(), tuple(dx.shape), part, rows, dx._version)
             return dx
     nws = _abi.lib().unetk_conv3x3_ws_bytes(ctypes.byref(d)) if prec == _abi.FP32 else 0
     ws = WORKSPACE.get(nws, dy.device) if nws else None
@@ -860,7 +900,7 @@ class NormSpec(object):
         return self.kind == "instance_norm"
 
 
-class Conv3x3NormRelu(torch.autograd.Function):
+class Conv3x3NormRelu(_Op):
     """z = relu(norm(conv3x3(x, w)) [+ spatial guide modulation]) -- one slim.conv2d(x, C, 3) unit:
     conv without bias, slim.batch_norm / slim.instance_norm with optional centre (beta) and scale (gamma),
     ReLU (NetworksV2/UNet.py:41-56,79; GUNet.py:162-217 `modulated_conv_block`)."""
@@ -962,7 +1002,7 @@ class Conv3x3NormRelu(torch.autograd.Function):
             ctx.desc = d
             ctx.has = (gamma is not None, beta is not None)
             # gamma / beta of a unit with an SE gate also get gradient from the gate's graph: those stay with autograd
-            ctx.sinks = (grad_sink(w), grad_sink(gamma) if se is None else None, grad_sink(beta) if se is None and not plain else None)
+            ctx.sinks = (grad_sink(w, ctx), grad_sink(gamma, ctx) if se is None else None, grad_sink(beta, ctx) if se is None and not plain else None)
             ctx.w_dbg = w.detach() if DEBUG_CAPTURE is not None else None
             ctx.gb_dbg = (gamma, beta) if DEBUG_CAPTURE is not None else None
             ctx.z_dbg = z.detach() if DEBUG_CAPTURE is not None else None      # the forward's own ReLU mask, for the checkers
@@ -975,7 +1015,8 @@ class Conv3x3NormRelu(torch.autograd.Function):
     def backward(ctx, dz):
         x, y, aff, guide, gw, gb, den = ctx.saved_tensors
         pre = FUSED_NBR.pop(dz.data_ptr(), None) if DEBUG_CAPTURE is None else None
-        if pre is not None and not (ctx.simple and pre[0] == y.data_ptr() and pre[1] == tuple(dz.shape) and dz.is_contiguous()):
+        if pre is not None and not (ctx.simple and pre[0] == y.data_ptr() and pre[1] == tuple(dz.shape) and dz.is_contiguous()
+                                    and pre[4] == dz._version):
             pre = None
         if dz.stride(3) != 1:
             dz = dz.contiguous()
@@ -1020,7 +1061,7 @@ class Conv3x3NormRelu(torch.autograd.Function):
         return dx, _ret(dw, sw), _ret(dgamma, sg), _ret(dbeta, sb), None, None, None, None, None, dgw, dgb, dden, None, dfeat
 
 
-class FullyConnected(torch.autograd.Function):
+class FullyConnected(_Op):
     """y = dropout(act(x . w + b)), act = identity (relu 0 / False), ReLU (1 / True) or sigmoid (2: the SE gate,
     GUNet.py:199) -- one slim.fully_connected (+ slim.dropout) of GUNet's context MLP
     (NetworksV2/Backbone/slim_nets.py:43-56; GUNet.py:50-60).  w is TF's [in, out].  keep_prob None = no dropout;
@@ -1058,7 +1099,7 @@ class FullyConnected(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
-class Conv1d(torch.autograd.Function):
+class Conv1d(_Op):
     """y = relu(conv1d(x, w) + b): slim.conv1d(x, C, k) with slim's defaults (stride 1, SAME, bias, ReLU) -- the layers of
     GUNet's 1-D VGG context models (NetworksV2/Backbone/slim_nets.py:60-144).  x [B, L, Cin], w TF [k, Cin, Cout]."""
 
@@ -1074,7 +1115,7 @@ class Conv1d(torch.autograd.Function):
                                           stream_ptr()), "conv1d_fwd")
         ctx.save_for_backward(x, w, y)
         ctx.relu, ctx.has_b = bool(relu), b is not None
-        ctx.sinks = (grad_sink(w), grad_sink(b))
+        ctx.sinks = (grad_sink(w, ctx), grad_sink(b, ctx))
         return y
 
     @staticmethod
@@ -1093,7 +1134,7 @@ class Conv1d(torch.autograd.Function):
         return dx, _ret(dw, sw), (_ret(db, sb) if ctx.has_b else None), None
 
 
-class MaxPool1d(torch.autograd.Function):
+class MaxPool1d(_Op):
     """tf.layers.max_pooling1d(x, 2, 2, padding="same") on [B, L, C] (slim_nets.py:73 ...): Lo = ceil(L / 2)."""
 
     @staticmethod
@@ -1116,7 +1157,7 @@ class MaxPool1d(torch.autograd.Function):
         return dx
 
 
-class SpatialMean(torch.autograd.Function):
+class SpatialMean(_Op):
     """tf.reduce_mean(x, axis=(1, 2)) on NHWC (GUNet.py:108, the conv context subnet)."""
 
     @staticmethod
@@ -1139,7 +1180,7 @@ class SpatialMean(torch.autograd.Function):
         return dx
 
 
-class Conv3dNormRelu(torch.autograd.Function):
+class Conv3dNormRelu(_Op):
     """z = relu(norm(conv3d(x, w))) -- one slim.conv3d unit of UNet3D (UNet3D.py:108-121,153,165): kernel
     (1,3,3) or (3,3,3), stride 1 / (1,2,2) / (2,2,2), SAME, no bias, instance or batch norm, ReLU."""
 
@@ -1173,7 +1214,7 @@ class Conv3dNormRelu(torch.autograd.Function):
             ctx.save_for_backward(x, y, aff)
             ctx.wp_d, ctx.need_dx, ctx.d, ctx.nd = wp_d, need_dx, d, nd
             ctx.has = (gamma is not None, beta is not None)
-            ctx.sinks = (grad_sink(w), grad_sink(gamma), grad_sink(beta) if not plain else None)
+            ctx.sinks = (grad_sink(w, ctx), grad_sink(gamma, ctx), grad_sink(beta, ctx) if not plain else None)
             ctx.dbg = (w.detach(), gamma, beta, stride, z.detach()) if DEBUG_CAPTURE is not None else None
         return alias(z) if out is not None else z
 
@@ -1195,7 +1236,7 @@ class Conv3dNormRelu(torch.autograd.Function):
         return dx, _ret(dw, sw), _ret(dgamma, sg), _ret(dbeta, sb), None, None, None, None, None
 
 
-class Deconv3dConcat(torch.autograd.Function):
+class Deconv3dConcat(_Op):
     """cat = concat(skip, relu(conv3d_transpose(x, w, kernel == stride))) -- UNet3D.py:161-163 (no bias);
     `skip` already lives in cat[..., :C], the kernel fills cat[..., C:]."""
 
@@ -1209,7 +1250,7 @@ class Deconv3dConcat(torch.autograd.Function):
         deconv3d_fwd(x, wp_f, None, cat, coff, cout, kd)
         ctx.save_for_backward(x, cat)
         ctx.wp_d, ctx.cout, ctx.coff, ctx.kd = wp_d, cout, coff, kd
-        ctx.sink = grad_sink(w)
+        ctx.sink = grad_sink(w, ctx)
         ctx.w_dbg = w.detach() if DEBUG_CAPTURE is not None else None
         return alias(cat)
 
@@ -1225,7 +1266,7 @@ class Deconv3dConcat(torch.autograd.Function):
         return dx, _ret(dw, sw), dcat[..., :ctx.coff], None
 
 
-class MaxPool2x2(torch.autograd.Function):
+class MaxPool2x2(_Op):
     @staticmethod
     def forward(ctx, x):
         p = maxpool2_fwd(x)
@@ -1238,7 +1279,7 @@ class MaxPool2x2(torch.autograd.Function):
         return maxpool2_bwd(x, p, dp)
 
 
-class MaxPoolSkip(torch.autograd.Function):
+class MaxPoolSkip(_Op):
     """(p, skip) = (max_pool2d(x), x): the encoder activation feeds both the pool and the skip connection
     (UNet.py:80-81,93).  Returning the skip from the same node lets the backward sum the two gradients inside the pool
     backward kernel (dx = route(dp) + dskip, dskip read in place from the concat buffer's gradient) instead of a
@@ -1260,7 +1301,7 @@ class MaxPoolSkip(torch.autograd.Function):
         return maxpool2_bwd(x, p, dp, dskip)
 
 
-class DeconvConcat(torch.autograd.Function):
+class DeconvConcat(_Op):
     """cat = concat(skip, relu(conv2d_transpose(x, w, k=2, s=2) + b)); `skip` already lives in
     cat[..., :C] (the encoder wrote it there), the kernel fills cat[..., C:] -- zero-copy concat."""
 
@@ -1280,7 +1321,7 @@ class DeconvConcat(torch.autograd.Function):
         ctx.bf16 = bf16
         ctx.cout, ctx.coff = cout, coff
         ctx.has_b = b is not None            # SmallUNet's conv2d_transpose has biases_initializer=None
-        ctx.sinks = (grad_sink(w), grad_sink(b))
+        ctx.sinks = (grad_sink(w, ctx), grad_sink(b, ctx))
         ctx.wb_dbg = (w.detach(), b.detach() if b is not None else None) if DEBUG_CAPTURE is not None else None
         return alias(cat)
 
@@ -1297,7 +1338,7 @@ class DeconvConcat(torch.autograd.Function):
         return dx, _ret(dw, sw), (_ret(db, sb) if ctx.has_b else None), dskip, None, None
 
 
-class DeconvConcatFront(torch.autograd.Function):
+class DeconvConcatFront(_Op):
     """cat = concat(relu(conv2d_transpose(x, w, k=2, s=2) [+ b]), skip_a, skip_b) -- InterUNet's decoder (InterUNet.py:150-155:
     the up-sampled tensor FIRST, then the skips of the two encoders).  The skips already live in cat[..., C:] (their
     encoders wrote them there); the kernel fills cat[..., :C]."""
@@ -1328,7 +1369,7 @@ class DeconvConcatFront(torch.autograd.Function):
         return dx, dw, (db if ctx.has_b else None), dcat[..., c0:c1], dcat[..., c1:], None
 
 
-class HeadLoss(torch.autograd.Function):
+class HeadLoss(_Op):
     """(xent, dice) = loss head over logits = z @ w + b; also returns logits / probs / metric sums
     as non-differentiable outputs."""
 
@@ -1339,7 +1380,7 @@ class HeadLoss(torch.autograd.Function):
         ctx.save_for_backward(z, w2, labels, pixel_w, logits, result, ws)
         ctx.desc = desc
         ctx.w_shape = w.shape
-        ctx.sinks = (grad_sink(w), grad_sink(b))
+        ctx.sinks = (grad_sink(w, ctx), grad_sink(b, ctx))
         xent = result[0:1].reshape(())
         dice = result[1:2].reshape(())
         outs = (xent.clone(), dice.clone(), logits, probs if probs is not None else logits.new_empty(0), result)

@@ -98,6 +98,7 @@ class GradBuckets(object):
                     self.buckets.append((grp, lo, hi, len(members)))
                     hi, members = lo, []
         self._sink_keys = []
+        self.history, self.last = [], None
         for name in store.trainable_names():
             t = store.tensors[name]
             hook = self._make_hook(name, self._bucket_of[name])
@@ -118,8 +119,17 @@ class GradBuckets(object):
                 self._arrived.add(name)
                 self._pending[b] -= 1
                 if self._pending[b] == 0:
-                    self._launch(b)
+                    self._ready[b] = True
+                    self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        # Collectives of one process group must be issued in the SAME order on every rank.  Arrival order is a property
+        # of each rank's autograd walk (and a variable may receive no gradient on one rank only), so buckets are launched
+        # strictly by index: a complete bucket waits for the lower-numbered ones.
+        while self._next < len(self.buckets) and self._ready[self._next]:
+            self._launch(self._next)
+            self._next += 1
 
     def _launch(self, b):
         grp, lo, hi, _ = self.buckets[b]
@@ -130,19 +140,44 @@ class GradBuckets(object):
         """Call before backward of every step."""
         self._pending = [b[3] for b in self.buckets]
         self._fired = [False] * len(self.buckets)
+        self._ready = [False] * len(self.buckets)
+        self._next = 0
         self._works = []
         self._arrived = set()
         self._armed = True
 
     def finish(self):
-        """Call after backward: every bucket reduced and visible to the compute stream."""
+        """Call after backward: every bucket reduced and visible to the compute stream.  Leaves the step's diagnostics in
+        `last` (buckets, how many were launched from inside backward, and -- on a GPU -- HIP events bracketing the wait on
+        the compute stream: the all-reduce time backward did not hide; read with exposed_ms() after a synchronize)."""
         self._armed = False
+        in_backward = sum(self._fired)
         for b in range(len(self.buckets)):
-            if not self._fired[b]:
-                self._launch(b)
+            self._ready[b] = True
+        self._launch_ready()
+        ev = None
+        if torch.cuda.is_available() and self.store.grad["reg"].is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in self._works:
             w.wait()
+        if ev is not None:
+            ev[1].record()
         self._works = []
+        self.last = {"buckets": len(self.buckets), "fired_in_backward": in_backward, "events": ev}
+        self.history.append(self.last)
+        if len(self.history) > 64:
+            del self.history[0]
+
+    def exposed_ms(self):
+        """Mean time (ms) the compute stream spent waiting in finish() over the recorded steps (None without events).
+        Synchronises the events' stream."""
+        ts = []
+        for h in self.history:
+            if h["events"] is not None:
+                h["events"][1].synchronize()
+                ts.append(h["events"][0].elapsed_time(h["events"][1]))
+        return sum(ts) / len(ts) if ts else None
 
     def remove(self):
         for h in self._hooks:

@@ -176,6 +176,150 @@ def test_bucketed_overlapped_allreduce_equals_plain_allreduce_gloo_world2():
         np.testing.assert_allclose(res[True][0]["flat"][g].numpy(), model.params.flat[g].detach().numpy(), rtol=1e-5, atol=1e-7)
 
 
+# --------------------------------------------------------- in-place gradient sink x buckets
+def _sink_base():
+    from boxsegliver_amd import ops
+    return ops._Op
+
+
+class _SinkDot(_sink_base()):
+    """CPU stand-in for a libunetk op: y = <x, w>; its backward writes dL/dw straight into the variable's slot of the flat
+    gradient buffer when ops._take grants it (the ops._GradSink protocol of the HIP ops), else returns it to autograd."""
+
+    @staticmethod
+    def forward(ctx, w, x):
+        from boxsegliver_amd import ops
+        ctx.save_for_backward(x)
+        ctx.sink = ops.grad_sink(w, ctx)
+        return (w * x).sum()
+
+    @staticmethod
+    def backward(ctx, dy):
+        from boxsegliver_amd import ops
+        (x,) = ctx.saved_tensors
+        slot = ops._take(ctx.sink)
+        dw = dy * x
+        if slot is not None:
+            slot.copy_(dw)
+        return ops._ret(dw, slot), None
+
+
+class _SinkModel(_ToyModel):
+    """T/a/weights is SHARED by two ops of one step; the order of the terms (= the order in which backward reaches the
+    variables, = the order in which buckets complete) depends on the rank."""
+
+    def loss(self, seed, rank=0):
+        gen = torch.Generator().manual_seed(seed)
+        p = self.params
+        uses = [("T/a/weights", 0.7), ("T/a/beta", 1.0), ("T/b/weights", 1.0), ("T/a/weights", -1.3), ("T/b/gamma", 1.0),
+                ("T/c/weights", 1.0), ("T/c/biases", 1.0)]
+        xs = [torch.randn(p[name].shape, generator=gen) for name, _ in uses]
+        terms = [(_SinkDot.apply(p[name], x) * c + 0.3) ** 2 for (name, c), x in zip(uses, xs)]
+        order = list(range(len(terms)))
+        order = order[rank % len(order):] + order[:rank % len(order)]          # rank-dependent graph order
+        total = 0.0
+        for i in order:
+            total = total + terms[i]
+        return total
+
+
+def _sink_worker(rank, world, port, out_dir, overlap):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from boxsegliver_amd import ops
+    from boxsegliver_amd.core.solver import Solver
+    from boxsegliver_amd.utils.distribution_utils import DistributionStrategy
+    ops.adam_step = _cpu_adam
+    model = _SinkModel()
+    solver = Solver(_solver_args())
+    solver.strategy = DistributionStrategy("mirrored", world, rank)
+    solver.overlap_allreduce = overlap
+    solver.bucket_bytes = 64                       # nearly one bucket per variable: every arrival order matters
+    written, granted, real_take = [], [], ops._take
+
+    def counting_take(slot):
+        out = real_take(slot)
+        granted.append(out is not None)
+        return out
+    ops._take = counting_take
+    for step in range(3):
+        del granted[:]
+        solver(model.loss(10 * step + rank, rank), model)
+        written.append(sum(granted))
+    torch.save({"flat": model.params.flat, "written": written,
+                "diag": {k: v for k, v in solver._buckets.last.items() if k != "events"} if overlap else None},
+               os.path.join(out_dir, "r{}.pt".format(rank)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_shared_variable_and_uneven_arrival_order_under_buckets_gloo(world):
+    """(1) A variable used by two ops must not 'arrive' at its bucket on the first in-place write: its slot is not taken,
+    autograd sums both contributions and the post-accumulate hook fires after the sum.  (2) Ranks reach their variables in
+    different orders: buckets are still all-reduced in index order on every rank (no mismatched collectives).  Overlapped
+    == plain all-reduce after backward == Adam on the mean gradient of a single process."""
+    res = {}
+    for overlap in (True, False):
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(_sink_worker, args=(world, _free_port(), d, overlap), nprocs=world, join=True)
+            res[overlap] = [torch.load(os.path.join(d, "r{}.pt".format(i))) for i in range(world)]
+    for g in ("reg", "noreg"):
+        for r in range(1, world):
+            assert torch.equal(res[True][0]["flat"][g], res[True][r]["flat"][g])
+        if world == 2:
+            assert torch.equal(res[True][0]["flat"][g], res[False][0]["flat"][g])
+        else:       # four addends: a ring all-reduce sums a bucket's elements in another rank order than the whole buffer's
+            np.testing.assert_allclose(res[True][0]["flat"][g].numpy(), res[False][0]["flat"][g].numpy(), rtol=1e-5, atol=1e-8)
+    # single-use variables were written in place (5 of them), the shared one was not
+    assert res[True][0]["written"] == [5, 5, 5]
+    assert res[True][0]["diag"]["buckets"] >= 5
+    model = _SinkModel()
+    st = {g: (torch.zeros_like(model.params.flat[g]), torch.zeros_like(model.params.flat[g])) for g in ("reg", "noreg")}
+    from boxsegliver_amd import ops
+    for step in range(3):
+        grads = {g: torch.zeros_like(model.params.flat[g]) for g in ("reg", "noreg")}
+        for rank in range(world):
+            model.params.zero_grad()
+            ops._GradSink.enabled = False                       # reference: plain autograd accumulation
+            try:
+                model.loss(10 * step + rank, rank).backward()
+            finally:
+                ops._GradSink.enabled = True
+            for g in grads:
+                grads[g] += model.params.grad[g] / world
+        t = step + 1
+        lr_t = 1e-3 * math.sqrt(1 - 0.99 ** t) / (1 - 0.9 ** t)
+        with torch.no_grad():
+            _cpu_adam(model.params.flat["reg"], grads["reg"], *st["reg"], lr_t, 0.9, 0.99, 1e-8, 1.0, 1e-2)
+            _cpu_adam(model.params.flat["noreg"], grads["noreg"], *st["noreg"], lr_t, 0.9, 0.99, 1e-8, 1.0, 0.0)
+    for g in ("reg", "noreg"):
+        np.testing.assert_allclose(res[True][0]["flat"][g].numpy(), model.params.flat[g].detach().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_grad_sink_scopes_and_use_counts():
+    """ops._GradSink bookkeeping: a slot is granted only for a single recorded use; a no_grad forward is not a use; one
+    store's zero_grad does not re-open another store's slots."""
+    from boxsegliver_amd import ops
+    a, b = _ToyModel(), _ToyModel()
+    a.params.zero_grad(); b.params.zero_grad()
+    w = a.params["T/a/weights"]
+    x = torch.ones_like(w)
+    ops._GradSink.uses.clear()
+    with torch.no_grad():
+        _SinkDot.apply(w, x)                                    # evaluation forward: not a use
+    assert ops._GradSink.uses.get(w.grad.data_ptr(), 0) == 0
+    _SinkDot.apply(w, x).backward()
+    assert w.grad.data_ptr() in ops._GradSink.written and torch.equal(w.grad, x)
+    _SinkDot.apply(w, 2 * x).backward()                         # a second step without zero_grad must ACCUMULATE
+    assert torch.equal(w.grad, 3 * x)
+    wb = b.params["T/b/weights"]
+    _SinkDot.apply(wb, torch.ones_like(wb)).backward()
+    a.params.zero_grad()                                        # re-opens a's slots only
+    assert w.grad.data_ptr() not in ops._GradSink.written and wb.grad.data_ptr() in ops._GradSink.written
+    (_SinkDot.apply(w, x) + _SinkDot.apply(w, 4 * x)).backward()   # shared inside one step: autograd sums
+    assert torch.equal(w.grad, 5 * x) and w.grad.data_ptr() not in ops._GradSink.written
+
+
 # ----------------------------------------------------------------------------------------- GPU
 YML = dict(init_channels=64, num_down_samples=2, ret_prob=False, ret_pred=True, build_metrics=True)
 

@@ -92,3 +92,45 @@ def test_fusion_is_taken_inside_the_unet():
     finally:
         ops.conv3x3_dgrad = real
     assert seen == [True, False]                             # conv2 -> conv1 fused; conv1's own dx (x needs a gradient here) has no producer
+
+
+@pytest.mark.parametrize("prec", [0, 2])
+def test_second_consumer_invalidates_the_fused_partials(prec):
+    """z1 feeds conv2 AND a second branch: autograd adds the branch's gradient into conv2's dx in place (same data_ptr and
+    shape), so the partials conv2's input gradient emitted are stale -- the producer must fall back to its own reduction
+    pass (the entry's recorded version counter no longer matches).  Parity with FUSE_NBR = False."""
+    from boxsegliver_amd import ops
+
+    def run(fuse):
+        gen = torch.Generator().manual_seed(11)
+        n, h, w, c0, c1, c2 = 2, 24, 32, 64, 128, 128
+        x = torch.randn(n, h, w, c0, generator=gen)
+        w1 = torch.randn(3, 3, c0, c1, generator=gen) / (3 * c0 ** 0.5)
+        w2 = torch.randn(3, 3, c1, c2, generator=gen) / (3 * c1 ** 0.5)
+        g1, g2 = 0.5 + torch.rand(c1, generator=gen), 0.5 + torch.rand(c2, generator=gen)
+        b1, b2 = 0.2 * torch.randn(c1, generator=gen), 0.2 * torch.randn(c2, generator=gen)
+        dz = torch.randn(n, h, w, c2, generator=gen)
+        side = torch.randn(n, h, w, c1, generator=gen)
+        st = ops.storage_dtype(prec)
+        xd = x.cuda().to(st).requires_grad_(True)
+        ps = [t.cuda().requires_grad_(True) for t in (w1, g1, b1, w2, g2, b2)]
+        spec = ops.NormSpec("batch_norm", 1e-3, 0.99, True, bf16=prec)
+        mm = [torch.zeros(c).cuda() for c in (c1, c2)]
+        mv = [torch.ones(c).cuda() for c in (c1, c2)]
+        ops.FUSE_NBR = fuse
+        ops.new_step()
+        try:
+            z1 = ops.Conv3x3NormRelu.apply(xd, ps[0], ps[1], ps[2], mm[0], mv[0], spec, None, None, None, None)
+            z2 = ops.Conv3x3NormRelu.apply(z1, ps[3], ps[4], ps[5], mm[1], mv[1], spec, None, None, None, None)
+            # the second consumer of z1: a plain torch branch with a large gradient of its own
+            loss = (z2.float() * dz.cuda()).sum() + (z1.float() * side.cuda()).sum() * 3.0
+            loss.backward()
+        finally:
+            ops.FUSE_NBR = True
+            ops.FUSED_NBR.clear()
+        return [xd.grad.float().cpu()] + [p.grad.cpu() for p in ps]
+
+    g_f, g_s = run(True), run(False)
+    for name, a, b in zip(("dx", "dw1", "dgamma1", "dbeta1", "dw2", "dgamma2", "dbeta2"), g_f, g_s):
+        err = float((a.double() - b.double()).norm() / b.double().norm())
+        assert err < (2e-6 if prec == 0 else 3e-3), (name, err)

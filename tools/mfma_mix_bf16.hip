@@ -1,0 +1,323 @@
+// Micro-benchmark: where the bf16 conv kernels (conv_igemm_bf16.hip) lose their matrix-pipe time.  The bf16 twin of
+// tools/mfma_mix.hip: one 512-thread block per CU (or two 256-thread blocks) runs the conv kernel's K loop -- per "step" one
+// filter tap of a 32-channel chunk = 512 x 128 x 32 MACs per block -- with the features of the real kernel switched on one at a
+// time.  Template parameters:
+//   MF   0: v_mfma_f32_32x32x16_bf16, wave tile 128 px x 64 couts (4 x 2 fragments, the round-2 kernel's)
+//        1: v_mfma_f32_32x32x16_bf16, wave tile 64 px x 128 couts (2 x 4 fragments)
+//        2: v_mfma_f32_16x16x32_bf16, wave tile 64 px x 128 couts (4 x 8 fragments)
+//   HP   0: operands in registers (no LDS reads)        1: LDS operand reads as the compiler schedules them (round-2 kernel)
+//        2: hand-pipelined: inline-asm ds_read_b128 into a double-buffered fragment set, counted lgkmcnt waits
+//   BAR  s_barrier every BAR steps (0 = never)
+//   STG  0: nothing staged    1: global_load_dwordx4 -> nine-deep register ring -> ds_write_b128 (round-2 kernel: one filter-panel
+//        piece per step per thread + five halo pieces per nine steps)    2: direct-to-LDS loads (global_load_lds_dwordx4: one
+//        filter-panel piece + one halo piece per wave and step), counted vmcnt before the barrier
+//   NWV  waves per block: 8 (one block per CU) or 4 (two blocks per CU, each a 256 x 128 tile)
+// LDS image = the layout planned for the round-3 kernel: halo [34 rows][20-pixel pitch][64 B] with the 16-byte channel
+// units XOR-swizzled by the pixel column (conflict-free ds_read_b128 for every tap shift), filter-panel ring of six 8 KiB slots.
+// Timing probes, NOT a correct convolution: staged bytes overwrite operands at random; every global index is masked into the source.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/mfma_mix_bf16.hip -o /tmp/mfma_mix_bf16
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <type_traits>
+#include <utility>
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %d at line %d\n", (int)e_, __LINE__); exit(1); } } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int ROWB = 20 * 64;          // bytes per halo row (20-pixel pitch x 64 B)
+constexpr int SLOT_B = 8192;           // filter panel of one (chunk, tap): 32 channels x 128 couts bf16
+// per block size: halo buffer (34 rows = 43 520 B, or 18 rows for the 256-pixel tile, rounded to 1-KiB DMA pieces), ring depth
+constexpr int halo_b(int nwv) { return (nwv == 8 ? 43 : 23) * 1024; }
+constexpr int ring_n(int nwv) { return nwv == 8 ? 6 : 4; }
+constexpr int lds_b(int nwv) { return 2 * halo_b(nwv) + ring_n(nwv) * SLOT_B + 1024; }   // + a spare KiB
+
+#define DS_READ128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+// wait until at most N LDS operations are outstanding; the "+v" operands tie the consuming MFMAs behind the wait
+template <int N>
+__device__ __forceinline__ void wait_lgkm(u32x4* S, int n) {
+  static_assert(N == 6 || N == 8, "fragment set size");
+  if constexpr (N == 6)
+    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(S[0]), "+v"(S[1]), "+v"(S[2]), "+v"(S[3]), "+v"(S[4]), "+v"(S[5]));
+  else
+    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(S[0]), "+v"(S[1]), "+v"(S[2]), "+v"(S[3]), "+v"(S[4]), "+v"(S[5]), "+v"(S[6]), "+v"(S[7]));
+}
+
+// N ds_read_b128 at byte offsets OFF, OFF + STRIDE, ... into S[0..N)
+template <int OFF, int STRIDE, int N>
+__device__ __forceinline__ void read_n(u32x4* S, uint32_t addr) {
+  DS_READ128(S[0], addr, OFF);
+  if constexpr (N > 1) read_n<OFF + STRIDE, STRIDE, N - 1>(S + 1, addr);
+}
+
+template <int N, class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int MF, int HP, int BAR, int STG, int NWV>
+__global__ __launch_bounds__(NWV * 64, 2) void mix(const uint4* __restrict__ src, float* out, int nsteps9) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = NWV * 64;
+  constexpr bool M16 = MF == 2;
+  constexpr int TM = MF == 0 ? 4 : (MF == 1 ? 2 : 4);       // A fragments per k-step
+  constexpr int TN = MF == 0 ? 2 : (MF == 1 ? 4 : 8);       // B fragments
+  constexpr int RD = M16 ? 8 : 6;                           // ds_read_b128 per fragment set
+  constexpr int HALO_B = halo_b(NWV), RING = ring_n(NWV), LDS_B = lds_b(NWV);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5, l15 = lane & 15, kq = lane >> 4;
+
+  // fill LDS with random bf16 bits (finite: exponent field masked to a small range)
+  for (int i = tid; i < LDS_B / 16; i += NT) {
+    uint4 v = src[(blockIdx.x * 8192 + i) & 0xfffff];
+    reinterpret_cast<uint4*>(smem)[i] = v;
+  }
+  __syncthreads();
+
+  // ---- fragment addressing (bytes).  32x32x16: lane (l31, h): pixel (row l31 >> 4, col l31 & 15), k-half h; per kw a base
+  // register, g = 1 is base ^ 32.  16x16x32: lane (l15, kq): pixel col l15, 8-channel unit kq.
+  uint32_t abase[3];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    if (M16) {
+      const int col = l15 + kw;
+      const int s = ((col >> 2) & 1) ? 0 : 3;
+      abase[kw] = lds0 + wave * 4 * ROWB + col * 64 + ((kq ^ s) << 4);
+    } else {
+      const int col = (l31 & 15) + kw;
+      const int s = (col >> 2) & 3;
+      const int wrow = MF == 0 ? (wave >> 1) * 8 : wave * 4;
+      abase[kw] = lds0 + (wrow + (l31 >> 4)) * ROWB + col * 64 + ((h ^ s) << 4);
+    }
+  }
+  uint32_t bbase0;
+  if (M16) bbase0 = lds0 + 2 * HALO_B + kq * 2048 + l15 * 16;
+  else bbase0 = lds0 + 2 * HALO_B + h * 2048 + ((MF == 0 ? (wave & 1) * 64 : 0) + l31) * 16;
+
+  f32x16 acc[M16 ? 1 : TM][M16 ? 1 : TN];
+  f32x4 acc4[M16 ? TM : 1][M16 ? TN : 1];
+  for (auto& r : acc) for (auto& c : r) for (int i = 0; i < 16; ++i) c[i] = 0.f;
+  for (auto& r : acc4) for (auto& c : r) for (int i = 0; i < 4; ++i) c[i] = 0.f;
+
+  // register-only operands (HP == 0)
+  u32x4 ra = *reinterpret_cast<const u32x4*>(smem + lane * 16), rb = *reinterpret_cast<const u32x4*>(smem + 4096 + lane * 16);
+
+  // ---- staging state
+  const unsigned gi = blockIdx.x * 4096u + tid;                 // 16-B units, masked into the 16 MiB source
+  u32x4 wring[STG == 1 ? 9 : 1];
+  u32x4 hq[STG == 1 ? 5 : 1];
+  if (STG == 1)
+    for (int t = 0; t < 9; ++t) wring[t] = *reinterpret_cast<const u32x4*>(&src[(gi + t * 512u) & 0xfffff]);
+
+  u32x4 X[RD], Y[RD];     // hand-pipelined fragment sets: A fragments first, then B
+
+  // issue the reads of (tap T, k-half G) of panel slot `bslot` into set S.  32x32x16: TM + TN reads cover 16 channels;
+  // 16x16x32: one read covers all 32 channels of a fragment, so a "k-half" is half of the TN couts tiles.
+  auto issue = [&](auto tc, auto gc, u32x4* S, uint32_t hoff, uint32_t bslot) {
+    constexpr int T = decltype(tc)::value, G = decltype(gc)::value;
+    constexpr int KH = T / 3, KW = T % 3;
+    const uint32_t a = (M16 ? abase[KW] : (abase[KW] ^ (G ? 32u : 0u))) + hoff;
+    const uint32_t b = bbase0 + bslot;
+    if constexpr (M16) {
+      // A: four pixel rows of this wave (all 32 channels each); B: couts tiles G*4 .. G*4+3.  Both halves read all A rows
+      // again (4 + 4 reads per 16 MFMAs) -- or keep A: here the A fragments are re-read, the conservative count.
+      read_n<KH * ROWB, ROWB, 4>(S, a);
+      read_n<G * 4 * 256, 256, 4>(S + 4, b);
+    } else {
+      read_n<KH * ROWB, 2 * ROWB, TM>(S, a);
+      read_n<G * 4096, 512, TN>(S + TM, b);
+    }
+  };
+  auto mfmas = [&](auto gc, const u32x4* S) {
+    constexpr int G = decltype(gc)::value;
+    if constexpr (M16) {
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+          acc4[tm][G * 4 + tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, S[tm]),
+                                                                       __builtin_bit_cast(bf16x8, S[4 + tn]), acc4[tm][G * 4 + tn], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, S[tm]),
+                                                                __builtin_bit_cast(bf16x8, S[TM + tn]), acc[tm][tn], 0, 0, 0);
+    }
+  };
+
+  uint32_t hoff = 0, slot = 0;
+  if (HP == 2) issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, X, 0u, 0u);
+  unsigned step = 0;
+  for (int c = 0; c < nsteps9; ++c) {
+    static_for<9>([&](auto tc) {
+      constexpr int T = decltype(tc)::value;
+      // ---- top of the step: staged data of the NEXT step has landed (own pieces), then everybody's
+      if constexpr (STG == 2) {
+        // own panel piece(s) of step + 1 (requested RING - 2 steps ago): younger = that step's halo piece + (RING - 3) whole steps
+        if constexpr (NWV == 8) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      }
+      if constexpr (BAR > 0) {
+        if (BAR == 1 || (BAR == 3 && T % 3 == 0) || (BAR == 2 && ((T ^ c) & 1) == 0)) {
+          if constexpr (STG == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+      }
+      if constexpr (STG == 2) {
+        // filter-panel piece of step + RING - 1 (L2-resident: all blocks walk the same 1.2 MB) and a halo piece (streamed)
+        const uint32_t pslot = (slot + RING - 1 >= RING ? slot - 1 : slot + RING - 1) * SLOT_B;
+        constexpr int PPW = 8 / NWV;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+          const uint4* g = src + (((step * 512u) & 0xffff) + (wave * PPW + j) * 64 + lane);
+          char* dst = smem + 2 * HALO_B + pslot + (wave * PPW + j) * 1024;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                           (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+        {
+          const uint4* g = src + ((gi * 16u + step * 65536u + (lane >> 2) * 16u + (lane & 3)) & 0xfffff);
+          char* dst = smem + (hoff ? 0 : HALO_B) + ((T * NWV + wave) % (HALO_B / 1024)) * 1024;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                           (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+      }
+      if constexpr (STG == 1) {
+        if (T == 0)
+#pragma unroll
+          for (int r = 0; r < 5; ++r) hq[r] = *reinterpret_cast<const u32x4*>(&src[(gi * 16u + step * 65536u + r * 8192u) & 0xfffff]);
+      }
+      const uint32_t bslot = slot * SLOT_B;
+      const uint32_t nslot = (slot + 1 == RING ? 0 : slot + 1);
+      if constexpr (HP == 2) {
+        issue(tc, std::integral_constant<int, 1>{}, Y, hoff, bslot);
+        wait_lgkm<RD>(X, 0);
+        mfmas(std::integral_constant<int, 0>{}, X);
+        // next step's first k-half (its panel slot became visible at this step's barrier)
+        issue(std::integral_constant<int, (T + 1) % 9>{}, std::integral_constant<int, 0>{}, X, T == 8 ? (hoff ? 0u : (uint32_t)HALO_B) : hoff,
+              nslot * SLOT_B);
+        wait_lgkm<RD>(Y, 0);
+        mfmas(std::integral_constant<int, 1>{}, Y);
+      } else if constexpr (HP == 1) {
+        constexpr int KH = T / 3, KW = T % 3;
+        const char* l0 = (const char*)nullptr;
+        (void)l0;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          u32x4 S[TM + TN];
+          const uint32_t a = (M16 ? abase[KW] : (abase[KW] ^ (g ? 32u : 0u))) + hoff - lds0;
+          const uint32_t b = bbase0 + bslot - lds0;
+          if constexpr (M16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) S[i] = *reinterpret_cast<const u32x4*>(smem + a + (i + KH) * ROWB);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) S[4 + i] = *reinterpret_cast<const u32x4*>(smem + b + (g * 4 + i) * 256);
+          } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) S[i] = *reinterpret_cast<const u32x4*>(smem + a + (2 * i + KH) * ROWB);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) S[TM + i] = *reinterpret_cast<const u32x4*>(smem + b + g * 4096 + i * 512);
+          }
+          if (g == 0) mfmas(std::integral_constant<int, 0>{}, S);
+          else mfmas(std::integral_constant<int, 1>{}, S);
+        }
+      } else {
+        u32x4 S[TM + TN];
+#pragma unroll
+        for (int i = 0; i < TM + TN; ++i) S[i] = (i & 1) ? ra : rb;
+        mfmas(std::integral_constant<int, 0>{}, S);
+        mfmas(std::integral_constant<int, 1>{}, S);
+      }
+      if constexpr (STG == 1) {
+        // the round-2 kernel's staging: next step's panel piece register -> LDS, its slot re-requested nine steps ahead;
+        // the chunk's five halo pieces written at tap 8
+#pragma unroll
+        for (int r = 0; r < 512 / NT; ++r)
+          *reinterpret_cast<u32x4*>(smem + 2 * HALO_B + nslot * SLOT_B + (tid + r * NT) * 16) = wring[(T + 1) % 9];
+        wring[(T + 1) % 9] = *reinterpret_cast<const u32x4*>(&src[(gi + ((step + 10) & 127) * 512u) & 0xfffff]);
+        if (T == 8)
+#pragma unroll
+          for (int r = 0; r < 5; ++r)
+            *reinterpret_cast<u32x4*>(smem + (hoff ? 0 : HALO_B) + ((tid + r * NT) * 16) % (HALO_B - 1024)) = hq[r];
+      }
+      slot = nslot;
+      ++step;
+    });
+    hoff = hoff ? 0u : (uint32_t)HALO_B;
+  }
+  if (STG == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float sum = 0.f;
+  for (auto& r : acc) for (auto& cc : r) for (int i = 0; i < 16; ++i) sum += cc[i];
+  for (auto& r : acc4) for (auto& cc : r) for (int i = 0; i < 4; ++i) sum += cc[i];
+  if (HP == 2) sum += __uint_as_float(X[0].x & 0xff) + __uint_as_float(Y[0].x & 0xff);
+  out[blockIdx.x * NT + tid] = sum;
+}
+
+template <int MF, int HP, int BAR, int STG, int NWV>
+void run(const uint4* src, float* out, const char* what) {
+  auto k = mix<MF, HP, BAR, STG, NWV>;
+  const int bpc = NWV == 8 ? 1 : 2;
+  const int lds = lds_b(NWV);     // 137 KB: one 512-thread block per CU; 79 KB: two 256-thread blocks
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  const int grid = 256 * bpc, n9 = 240;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(NWV * 64), lds, 0, src, out, 20);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(NWV * 64), lds, 0, src, out, n9);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  // per wave and step: 16 MFMAs of 32x32x16 (or 32 of 16x16x32) = 524 288 FLOP
+  const double flop = (double)grid * NWV * n9 * 9 * 524288.0;
+  printf("MF%d HP%d BAR%d STG%d NWV%d  %-58s %7.3f ms  %7.1f TFLOP/s  (%4.1f %% of 2516.6)\n", MF, HP, BAR, STG, NWV, what, ms,
+         flop / ms / 1e9, flop / ms / 1e9 / 25.166);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) printf("  HIP error %d\n", (int)e);
+}
+
+int main(int argc, char** argv) {
+  const bool zeros = argc > 1 && argv[1][0] == 'z';
+  uint4* src; float* out;
+  const size_t n = 1 << 20;                   // 16 MiB of bf16 bit patterns
+  uint32_t* hs = (uint32_t*)malloc(n * 16);
+  srand(1);
+  for (size_t i = 0; i < n * 4; ++i) {
+    // two bf16 values in [0.5, 2) with random sign and mantissa (finite, well-scaled: the DVFS-relevant "random data" case)
+    const uint32_t lo = 0x3f00u | (rand() & 0x80ffu), hi = 0x3f00u | (rand() & 0x80ffu);
+    hs[i] = zeros ? 0u : (lo | (hi << 16));
+  }
+  hipMalloc(&src, n * 16 + 65536); hipMalloc(&out, 1 << 22);
+  hipMemcpy(src, hs, n * 16, hipMemcpyHostToDevice);
+  printf("data: %s\n", zeros ? "zeros" : "random bf16");
+  run<0, 0, 0, 0, 8>(src, out, "32x32x16 4x2, operands in registers");
+  run<0, 1, 0, 0, 8>(src, out, "+ LDS operand reads (compiler-scheduled)");
+  run<0, 1, 1, 0, 8>(src, out, "+ barrier per step (16 MFMAs per wave)");
+  run<0, 1, 1, 1, 8>(src, out, "+ register-ring staging (= round-2 kernel's loop)");
+  run<0, 1, 1, 2, 8>(src, out, "compiler-scheduled reads, barrier, LDS-DMA staging");
+  run<0, 2, 0, 0, 8>(src, out, "hand-pipelined reads (double-buffered fragments)");
+  run<0, 2, 1, 0, 8>(src, out, "+ barrier per step");
+  run<0, 2, 1, 2, 8>(src, out, "+ LDS-DMA staging (round-3 design)");
+  run<0, 2, 2, 2, 8>(src, out, "same, barrier every 2 steps (= 64-channel chunks)");
+  run<0, 2, 3, 2, 8>(src, out, "same, barrier every 3 steps");
+  run<1, 2, 1, 2, 8>(src, out, "32x32x16 2x4 (64 px x 128 co), pipelined+barrier+DMA");
+  run<2, 0, 0, 0, 8>(src, out, "16x16x32 4x8, operands in registers");
+  run<2, 2, 0, 0, 8>(src, out, "16x16x32 hand-pipelined reads");
+  run<2, 2, 1, 2, 8>(src, out, "16x16x32 pipelined + barrier + LDS-DMA");
+  run<2, 2, 3, 2, 8>(src, out, "same, barrier every 3 steps");
+  run<0, 2, 1, 2, 4>(src, out, "32x32x16 4x2, 2 x 256-thread blocks per CU, pipelined+bar+DMA");
+  run<2, 2, 1, 2, 4>(src, out, "16x16x32, 2 x 256-thread blocks per CU, pipelined+bar+DMA");
+  run<0, 1, 1, 1, 4>(src, out, "round-2 loop, 2 x 256-thread blocks per CU");
+  return 0;
+}
