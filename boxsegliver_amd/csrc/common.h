@@ -106,6 +106,8 @@ struct ConvParams {
   float* stat;
   int N, H, W, Cin, Cout, xs, ys;   // N = number of images (planes)
   int tiles_h, tiles_w, n_ntiles, stat_rows;
+  int ptiles;                        // conv_igemm_bf16s.hip (persistent blocks): pixel tiles x output-channel tiles
+  int dbg;                           // conv_igemm_bf16s.hip: UNETK_V3_FLAGS (measurement switches)
   ImgAddr xa, ya;
   int accumulate;                    // epilogue: y += acc (depth taps of a 3-D conv), statistics on the sum
   int bf16;                          // UNETK_BF16: operands rounded to bf16 for v_mfma_f32_32x32x16_bf16 (wp = bf16 K8 pack);
@@ -157,6 +159,11 @@ size_t unetk_conv_lin_sk_bytes(int N, int H, int W, int Cin, int Cout, int spg, 
 bool unetk_conv_bf16_ok(int Cin, int Cout);
 int unetk_conv_run_bf16(ConvParams p, hipStream_t st);
 int unetk_conv_stat_rows_bf16(int N, int H, int W, int Cin, int Cout);
+int unetk_conv_stat_rows_bf16s(int N, int H, int W, int Cin, int Cout, int xs, int ys);   // UNETK_BF16S: round-3 kernel where it applies
+// conv_igemm_bf16s.hip: UNETK_BF16S round-3 kernel (persistent 512 x 128 / 512 x 64 tiles, LDS-DMA staging, 16x16x32 MFMA)
+bool unetk_conv_bf16s_v3_ok(int N, int H, int W, int Cin, int Cout, int xs, int ys);
+int unetk_conv_bf16s_v3_stat_rows(int N, int H, int W);
+int unetk_conv_bf16s_v3_run(ConvParams p, hipStream_t st);
 
 struct WgParams {
   const float* x;

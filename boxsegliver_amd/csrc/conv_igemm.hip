@@ -629,7 +629,7 @@ extern "C" int unetk_conv3x3_stat_rows(const unetk_conv_desc* d) {
   if (d->dilation == 2) return unetk_conv_stat_rows(d->N, d->H, d->W, d->Cin, d->Cout, 1, 1, 2);
   if (d->precision == UNETK_BF16) return unetk_conv_stat_rows_bf16(d->N, d->H, d->W, d->Cin, d->Cout);
   if (d->precision == UNETK_BF16S && unetk_conv_bf16_ok(d->Cin, d->Cout))
-    return unetk_conv_stat_rows_bf16(d->N, d->H, d->W, d->Cin, d->Cout);
+    return unetk_conv_stat_rows_bf16s(d->N, d->H, d->W, d->Cin, d->Cout, d->x_stride, d->y_stride);
   return unetk_conv_stat_rows(d->N, d->H, d->W, d->Cin, d->Cout);
 }
 
@@ -703,7 +703,7 @@ extern "C" int unetk_conv3x3_dgrad_nbr_rows(const unetk_conv_desc* d) {
   if (K < 128 || Nc < 128 || Nc % 128 != 0) return 0;
   if (d->precision == UNETK_BF16S) {
     if (!unetk_conv_bf16_ok(K, Nc) || K % 64 != 0 || Nc % 64 != 0) return 0;
-    return unetk_conv_stat_rows_bf16(d->N, d->H, d->W, K, Nc);
+    return unetk_conv_stat_rows_bf16s(d->N, d->H, d->W, K, Nc, d->y_stride, d->x_stride);
   }
   if (d->precision != UNETK_FP32) return 0;
   if (pick_cfg(K, Nc).id < 0 || unetk_conv_lin_ok(d->N, d->H, d->W, K, Nc, 1)) return 0;   // tiled fp32 kernel only

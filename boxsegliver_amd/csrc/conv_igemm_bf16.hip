@@ -50,7 +50,7 @@ __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
 template <int WM, int WN, int TM, int TN, bool BS = false, bool NBR = false>
 __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvParams p) {
   constexpr int RING = UNETK_BF16_RING(WM, WN, TM, TN);   // depth of the filter-panel register ring (divides 9)
-  static_assert(!BS || TN == 2, "bf16 storage packs channel pairs (tile 0 / tile 1) into one word");
+  static_assert(!BS || (TN == 2 && (WN * TN * 32 == 128 || WN * TN * 32 == 64)), "bf16 storage packs channel pairs (tile 0 / tile 1) into one word");
   static_assert(!NBR || BS, "the fused reduction is built for bf16 storage");
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -163,7 +163,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
     const int sub = wm * TM + tm;
     abase[tm] = ((2 * sub + (l31 >> 4)) * HWD + (l31 & 15)) * PSQ + h;
   }
-  const int bbase = h * BN + wn * TN * 32 + l31;
+  // B fragment of tile tn: 16-byte unit of the panel.  fp32 storage: panel column = output channel.  bf16 storage: the lane
+  // wants channels (2 l31, 2 l31 + 1) of the wave's 64-block for tiles 0 / 1 (one 4-byte store); the pack shared with the
+  // round-3 kernel keeps channel c at column conv_bf16s_pos(c) (pack.h), conflict-free for these reads too.
+  int bpos[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+    bpos[tn] = h * BN + (BS ? unetk_pack::conv_bf16s_pos(wn * 64 + 2 * l31 + tn, BN == 128 ? 128 : 64) : wn * TN * 32 + tn * 32 + l31);
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_igemm_bf16_kernel(ConvPar
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) a[tm] = hb[abase[tm] + toff + 2 * g];
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) b[tn] = wb[bbase + 2 * g * BN + tn * 32];
+        for (int tn = 0; tn < TN; ++tn) b[tn] = wb[bpos[tn] + 2 * g * BN];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -373,11 +379,19 @@ int unetk_conv_stat_rows_bf16(int N, int H, int W, int Cin, int Cout) {
   return N * ((H + cfg.th - 1) / cfg.th) * ((W + TW - 1) / TW);
 }
 
+// UNETK_BF16S: the round-3 kernel (conv_igemm_bf16s.hip) where its tile grid fills the chip, else the kernels of this file
+int unetk_conv_stat_rows_bf16s(int N, int H, int W, int Cin, int Cout, int xs, int ys) {
+  if (unetk_conv_bf16s_v3_ok(N, H, W, Cin, Cout, xs, ys)) return unetk_conv_bf16s_v3_stat_rows(N, H, W);
+  return unetk_conv_stat_rows_bf16(N, H, W, Cin, Cout);
+}
+
 int unetk_conv_run_bf16(ConvParams p, hipStream_t st) {
   const BfCfg cfg = pick_bf16(p.H, p.Cin, p.Cout, p.N, p.W);
   if (cfg.id < 0) return UNETK_E_UNSUPPORTED;
   if (p.bf16 == UNETK_BF16S) {   // bf16 storage: 16-B halo pieces of 8 channels, 4-B output words of 2 channels
     if (cfg.id == 4 || p.accumulate) return UNETK_E_UNSUPPORTED;     // Cout % 64 != 0 / 3-D depth taps: not in this mode
+    if (unetk_conv_bf16s_v3_ok(p.N, p.H, p.W, p.Cin, p.Cout, p.xs, p.ys) && (p.ny == nullptr || (p.Cout % 128 == 0 && p.nys % 8 == 0)))
+      return unetk_conv_bf16s_v3_run(p, st);
     if (p.xs % 8 != 0 || p.ys % 2 != 0) return UNETK_E_BADARG;
     p.tiles_h = (p.H + cfg.th - 1) / cfg.th;
     p.tiles_w = (p.W + TW - 1) / TW;

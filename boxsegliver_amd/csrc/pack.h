@@ -11,8 +11,36 @@ __device__ __forceinline__ uint32_t pk2(float lo, float hi) {
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
-// UNETK_BF16S: column position n' of every 64-column block holds output channel 2 (n' & 31) + (n' >> 5 & 1)
+// UNETK_BF16S transposed-conv panels: column position n' of every 64-column block holds output channel 2 (n' & 31) + (n' >> 5 & 1)
 __device__ __forceinline__ int perm64(int n) { return (n & ~63) + 2 * (n & 31) + ((n >> 5) & 1); }
+
+// UNETK_BF16S conv3x3 panels: column position n' of the filter panel -> output channel.  Blocks of 128 columns when the
+// output dimension is a multiple of 128, else blocks of 64.  Position n' = 16 m + r of a block holds channel
+//   (r ^ rep[m >> 1]) * NT + m      (NT = 8 tiles per 128-block, rep = {0, 1, 8, 9};  NT = 4 per 64-block, rep = {0, 2})
+// so that (a) the 16x16x32 kernel (conv_igemm_bf16s.hip), whose accumulator-tile column j of tile m reads position
+// 16 m + (j ^ rep), owns channels NT j .. NT j + NT - 1 per lane (one 16- / 8-byte store), and (b) the 32x32x16 kernels
+// (conv_igemm_bf16.hip), whose lane l of tile tn wants channel 2 l + tn (one 4-byte store), find those channels at positions
+// that differ in the low four bits across every 16-lane ds_read_b128 group: {0,3,5,6} and {0,1,6,7,10,..13} -- the values of
+// l >> 2 resp. l >> 1 inside a group -- are subgroups under XOR and the rep values are representatives of distinct cosets.
+__device__ __host__ __forceinline__ int conv_bf16s_chan(int n, int Nout) {
+  if (Nout % 128 == 0) {
+    const int m = (n >> 4) & 7, r = n & 15;
+    const int rep = ((m >> 1) & 1) | (((m >> 1) & 2) << 2);
+    return (n & ~127) + (((r ^ rep) << 3) | m);
+  }
+  const int m = (n >> 4) & 3, r = n & 15;
+  return (n & ~63) + (((r ^ ((m >> 1) << 1)) << 2) | m);
+}
+// inverse: the position (inside its 128- / 64-block) of block-relative channel c
+__device__ __host__ __forceinline__ int conv_bf16s_pos(int c, int Nout) {
+  if (Nout % 128 == 0) {
+    const int m = c & 7;
+    const int rep = ((m >> 1) & 1) | (((m >> 1) & 2) << 2);
+    return m * 16 + ((c >> 3) ^ rep);
+  }
+  const int m = c & 3;
+  return m * 16 + ((c >> 2) ^ ((m >> 1) << 1));
+}
 
 // conv3x3 fp32, K4-interleaved: wp[t][q][n][j] = B_t[k = 4q + j][n]; forward B_t[ci][co] = w[t][ci][co],
 // dgrad B_t[co][ci] = w[8 - t][ci][co].  Items: 9 * Cin * Cout / 4.
@@ -41,7 +69,7 @@ __device__ __forceinline__ void conv3x3_bf16(const float* __restrict__ w, int Ci
                                              uint4* __restrict__ wp_dgrad, int perm, int64_t i) {
   if (wp_fwd != nullptr) {
     int n = (int)(i % Cout);
-    if (perm) n = perm64(n);
+    if (perm) n = conv_bf16s_chan(n, Cout);
     const int64_t r = i / Cout;
     const int q = (int)(r % (Cin / 8));
     const int t = (int)(r / (Cin / 8));
@@ -56,7 +84,7 @@ __device__ __forceinline__ void conv3x3_bf16(const float* __restrict__ w, int Ci
   }
   if (wp_dgrad != nullptr) {
     int n = (int)(i % Cin);
-    if (perm) n = perm64(n);
+    if (perm) n = conv_bf16s_chan(n, Cin);
     const int64_t r = i / Cin;
     const int q = (int)(r % (Cout / 8));
     const int t = (int)(r / (Cout / 8));

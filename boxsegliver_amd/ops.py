@@ -170,6 +170,10 @@ def _igemm_tag(cin, cout, bf16=False, h=0, n=1 << 20, w=1 << 10, nbr=False):
         return h % 16 == 0 and not (nbr and cin < 256) and n * (h // 16) * cdiv(w, 16) * (cout // bn) >= 512
     if bf16 and cin % 32 == 0 and cout % 32 == 0:
         bs = ",true>" if int(bf16) == _abi.BF16S else ">"          # <..., BS = true>: bf16 storage
+        if int(bf16) == _abi.BF16S and h >= 24 and (cout % 128 == 0 or cout == 64):      # unetk_conv_bf16s_v3_ok (conv_igemm_bf16s.hip)
+            bn = 128 if cout % 128 == 0 else 64
+            if n * cdiv(h, 32) * cdiv(w, 16) * (cout // bn) >= 200:
+                return "conv3x3_bf16s_kernel<{}{}>".format(bn // 16, ",nbr" if nbr else "")
         if cout % 128 == 0:
             tall = h >= 24 and n * cdiv(h, 32) * cdiv(w, 16) * (cout // 128) >= 200     # pick_bf16 (conv_igemm_bf16.hip)
             return ("conv3x3_igemm_bf16_kernel<4,2,4,2" if tall else "conv3x3_igemm_bf16_kernel<2,2,2,2") + bs
