@@ -76,6 +76,7 @@ import torch.distributed as dist  # noqa: E402
 # SURVEY.md 8d / BASELINE.md 3: conv / deconv / 1x1 FLOPs only, 2 per MAC, bwd = dgrad + wgrad
 GFLOP_PER_SLICE_FWD_BWD = 288.828
 FP32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 matrix (= vector) peak
+HBM_PEAK_BPS = 8.0e12             # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable by a float4 copy)
 BF16_PEAK_TFLOPS = 2516.6         # dense bf16 MFMA: 256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz (16x the fp32 rate)
 METRIC = "CT slices/sec/node (fwd+bwd) UNet 256×256 bs=32; Dice vs ref"
 
@@ -120,16 +121,20 @@ def _cpu_oracle_steps(size, n_classes, bs, warm, timed):
     return statistics.median(times)
 
 
-def cpu_baseline(size, timed=5):
+def cpu_baseline(size, timed=3):
     """SURVEY.md 8d "CPU baseline beside it": the reference's own TF-1.13 CPU path cannot run (TensorFlow is not
     installable), so the labelled substitute is the oracle on this host's cores: BASELINE.json configs[0]
     (Liver only = 2 classes, bs 2) and the configs[1]-shaped workload at bs 2 (3 classes), fwd+bwd+TF-Adam, median of
-    `timed` steps after one warm-up each.  `value` is the configs[1]-shaped one (the metric's workload)."""
+    `timed` steps after one warm-up each, plus the configs[1] shape at bs 8 (two timed steps: ~1 minute of CPU work in
+    all).  `value` is the configs[1]-shaped bs-2 one (the metric's workload)."""
     threads = torch.get_num_threads()
     bs = 2
     dt1 = _cpu_oracle_steps(size, 3, bs, 1, timed)
     dt0 = _cpu_oracle_steps(size, 2, bs, 1, timed)
+    dt8 = _cpu_oracle_steps(size, 3, 8, 1, 2)          # SURVEY.md 8d: "bs 2 and bs 8"
     return {"value": round(bs / dt1, 4), "unit": "slices/s", "cores": threads, "kind": "port",
+            "bs8": {"value": round(8 / dt8, 4), "unit": "slices/s",
+                    "sample": "same workload at bs 8, median of 2 timed steps after 1 warm-up, {:.2f} s/step".format(dt8)},
             "sample": "oracle (PyTorch-CPU restatement, not TF): UNet {0}x{0}x3 3-class bs {1} (configs[1] shape at bs 2), "
                       "fwd+bwd+Adam, median of {2} timed steps after 1 warm-up, {3:.2f} s/step, {4} torch threads, "
                       "host os.cpu_count()={5}".format(size, bs, timed, dt1, threads, os.cpu_count()),
@@ -276,6 +281,28 @@ def main():
         dist.all_gather(every, mine)
         rank_ms = [float(v.item()) for v in every]
 
+    # ---- data-parallel diagnostics (N > 1): what the buckets did, how long the compute stream waited for them, and this
+    # rank's step WITHOUT the all-reduce (3 extra untimed-by-the-metric steps, replicas may drift afterwards: the run is over)
+    dp_diag = None
+    if world > 1:
+        bk = getattr(solver, "_buckets", None)
+        dp_diag = {"buckets": len(bk.buckets) if bk is not None else 0,
+                   "buckets_fired_in_backward": bk.last["fired_in_backward"] if bk is not None and bk.last else None,
+                   "allreduce_exposed_ms": round(bk.exposed_ms(), 4) if bk is not None and bk.exposed_ms() is not None else None,
+                   "allreduce_bytes": int(sum(g.numel() for g in model.params.grad.values()) * 4)}
+        solver.strategy = None
+        if bk is not None:
+            bk.remove()
+            solver._buckets = None
+        one_step()
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(3):
+            one_step()
+        torch.cuda.synchronize()
+        dp_diag["compute_only_ms_per_step"] = round((time.perf_counter() - tc) / 3 * 1e3, 3)
+        dist.barrier()
+
     if rank == 0:
         ms = elapsed / a.steps * 1e3
         slices = a.batch * world * a.steps / elapsed
@@ -290,7 +317,7 @@ def main():
             wl = wl.replace(" fp32", " bf16-MFMA operands / fp32 storage")
         peak = FP32_PEAK_TFLOPS if a.dtype == "fp32" else BF16_PEAK_TFLOPS
         if gflop_unit is None:      # conv / deconv algorithmic FLOPs (2 per MAC, fwd + dgrad + wgrad) of one unit, from the events
-            gflop_unit = (sum(f for _, f, _, _ in prof) / a.steps / a.batch / 1e9) if prof else 0.0
+            gflop_unit = (sum(e[1] for e in prof) / a.steps / a.batch / 1e9) if prof else 0.0
         out = {
             "metric": METRIC if a.model == "UNet" else "{} units/sec/node (fwd+bwd)".format(a.model),
             "value": round(slices, 2), "unit": "slices/s" if a.model != "UNet3D" else "patches/s", "n_gpus": world,
@@ -306,13 +333,29 @@ def main():
             "whole_step_frac_of_fp32_peak": round(slices * gflop_unit / 1e3 / (FP32_PEAK_TFLOPS * world), 4),
             "whole_step_frac_of_dtype_peak": round(slices * gflop_unit / 1e3 / (peak * world), 4),
         }
+        if dp_diag is not None:
+            dp_diag["dp_efficiency_vs_compute_only"] = round(dp_diag["compute_only_ms_per_step"] / ms, 4)
+            out["data_parallel"] = dp_diag
         if prof:
-            agg = {}
-            for tag, flops, e0, e1 in prof:
+            agg, hbm = {}, {}
+            for tag, flops, e0, e1, nbytes in prof:
+                secs = e0.elapsed_time(e1) * 1e-3
+                if nbytes:                      # HBM-bound passes: algorithmic bytes (each operand once) / time
+                    h = hbm.setdefault(tag, [0, 0.0, 0.0])
+                    h[0] += 1
+                    h[1] += nbytes
+                    h[2] += secs
+                if not flops:
+                    continue
                 d = agg.setdefault(tag, [0, 0.0, 0.0])
                 d[0] += 1
                 d[1] += flops
-                d[2] += e0.elapsed_time(e1) * 1e-3
+                d[2] += secs
+            out["hbm_kernels"] = sorted(
+                [{"kernel": tag, "launches": cnt, "avg_launch_ms": round(secs / cnt * 1e3, 4), "avg_launch_mbytes": round(nb / cnt / 1e6, 2),
+                  "achieved_gbps": round(nb / secs / 1e9, 1), "frac_of_hbm_peak": round(nb / secs / HBM_PEAK_BPS, 4),
+                  "total_ms_per_step": round(secs / a.steps * 1e3, 3)} for tag, (cnt, nb, secs) in hbm.items()],
+                key=lambda k: -k["total_ms_per_step"])
             kern = []
             for tag, (cnt, flops, secs) in agg.items():
                 kern.append({"kernel": tag, "launches": cnt, "avg_launch_ms": round(secs / cnt * 1e3, 4),

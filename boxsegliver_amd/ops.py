@@ -143,9 +143,10 @@ PK_CONV_F32, PK_CONV_BF16, PK_DECONV_F32, PK_DECONV_BF16 = 0, 1, 2, 3
 class _Timed(object):
     """HIP events on the CURRENT stream (the one the kernel is launched on) around one C-ABI call."""
 
-    def __init__(self, tag, flops, shape=None):
+    def __init__(self, tag, flops, shape=None, nbytes=0):
+        """flops: algorithmic FLOPs of a matrix kernel; nbytes: algorithmic HBM bytes (each operand once) of an HBM-bound pass."""
         self.on = PROFILE is not None
-        self.tag, self.flops = (tag if not (PROFILE_SHAPES and shape) else "{} [{}]".format(tag, shape)), flops
+        self.tag, self.flops, self.nbytes = (tag if not (PROFILE_SHAPES and shape) else "{} [{}]".format(tag, shape)), flops, nbytes
 
     def __enter__(self):
         if self.on:
@@ -157,7 +158,7 @@ class _Timed(object):
     def __exit__(self, *exc):
         if self.on and exc[0] is None:
             self.e1.record()
-            PROFILE.append((self.tag, self.flops, self.e0, self.e1))
+            PROFILE.append((self.tag, self.flops, self.e0, self.e1, self.nbytes))
         return False
 
 
@@ -379,8 +380,10 @@ def conv3x3_fwd(x, w, cout, want_stats=True, y=None, bf16=False, dilation=1):
         stats = torch.empty((2, rows, cout), dtype=torch.float32, device=x.device)
     nws = _abi.lib().unetk_conv3x3_ws_bytes(ctypes.byref(d)) if prec == _abi.FP32 else 0     # stream-K scratch (small planes)
     ws = WORKSPACE.get(nws, x.device) if nws else None
-    with _Timed(_igemm_tag(cin, cout, bf16, h, n, wd), 18.0 * n * h * wd * cin * cout,
-                "fwd {}x{}x{} {}->{}".format(n, h, wd, cin, cout)):
+    tag = _igemm_tag(cin, cout, bf16, h, n, wd)
+    # the first layer's direct kernel is HBM-bound (writes 64 channels per pixel from 3): report it by bytes as well
+    nb = (x.numel() * x.element_size() + y.numel() * y.element_size()) if tag == "conv3x3_direct_kernel" else 0
+    with _Timed(tag, 18.0 * n * h * wd * cin * cout, "fwd {}x{}x{} {}->{}".format(n, h, wd, cin, cout), nb):
         check(_abi.lib().unetk_conv3x3_fwd_ws(ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(stats), ptr(ws), nws,
                                               stream_ptr()), "conv3x3_fwd")
     return y, stats, rows
@@ -549,8 +552,9 @@ def norm_apply_relu(d, y, aff, z, guide=None, gw=None, gb=None, den=None):
     d.storage = _storage_of(y)
     if den is not None:
         assert den.is_contiguous() and tuple(den.shape) == (d.N, d.C), (tuple(den.shape), d.N, d.C)
-    check(_abi.lib().unetk_norm_apply_relu(ctypes.byref(d), ptr(y), ptr(aff[2]), ptr(aff[3]), ptr(den), ptr(guide),
-                                           ptr(gw), ptr(gb), ptr(z), stream_ptr()), "norm_apply_relu")
+    with _Timed("norm_apply_relu", 0.0, None, y.numel() * y.element_size() * 2):          # read y, write z
+        check(_abi.lib().unetk_norm_apply_relu(ctypes.byref(d), ptr(y), ptr(aff[2]), ptr(aff[3]), ptr(den), ptr(guide),
+                                               ptr(gw), ptr(gb), ptr(z), stream_ptr()), "norm_apply_relu")
     return z
 
 
@@ -574,11 +578,14 @@ def norm_relu_bwd(d, y, dz, aff, has_gamma, has_beta, guide=None, gw=None, gb=No
         raise _abi.UnetkError("norm_relu_bwd: unsupported channel count {}".format(d.C))
     ws = WORKSPACE.get(nbytes, dev)
     pre_part, pre_rows = pre if pre is not None else (None, 0)
-    check(_abi.lib().unetk_norm_relu_bwd_pre(ctypes.byref(d), ptr(y), ptr(dz), _pix_stride_nd(dz), ptr(aff[2]), ptr(aff[3]),
-                                             ptr(aff[0]), ptr(aff[1]), ptr(den), ptr(guide), ptr(gw), ptr(gb), ptr(dy),
-                                             ptr(dgamma), ptr(dbeta), ptr(dden), ptr(dgw), ptr(dgb), ptr(pre_part),
-                                             int(pre_rows), ptr(ws), nbytes, stream_ptr()),
-          "norm_relu_bwd")
+    # reduction pass reads (dz, y) unless its partials came from the producing kernel; the apply pass reads (dz, y), writes dy
+    with _Timed("norm_relu_bwd" + ("(apply only)" if pre is not None else "(reduce+apply)"), 0.0, None,
+                y.numel() * y.element_size() * (3 if pre is not None else 5)):
+        check(_abi.lib().unetk_norm_relu_bwd_pre(ctypes.byref(d), ptr(y), ptr(dz), _pix_stride_nd(dz), ptr(aff[2]), ptr(aff[3]),
+                                                 ptr(aff[0]), ptr(aff[1]), ptr(den), ptr(guide), ptr(gw), ptr(gb), ptr(dy),
+                                                 ptr(dgamma), ptr(dbeta), ptr(dden), ptr(dgw), ptr(dgb), ptr(pre_part),
+                                                 int(pre_rows), ptr(ws), nbytes, stream_ptr()),
+              "norm_relu_bwd")
     if den is not None:
         return dy, dgamma, dbeta, dgw, dgb, dden
     return dy, dgamma, dbeta, dgw, dgb
@@ -633,7 +640,8 @@ def maxpool2_fwd(x):
     n, h, w, c = x.shape
     p = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
     fn = _abi.lib().unetk_maxpool2_fwd_bf16 if _storage_of(x) == _abi.BF16S else _abi.lib().unetk_maxpool2_fwd
-    check(fn(ptr(x), _pix_stride(x), ptr(p), n, h, w, c, stream_ptr()), "maxpool2_fwd")
+    with _Timed("maxpool2_fwd", 0.0, None, (x.numel() + p.numel()) * x.element_size()):
+        check(fn(ptr(x), _pix_stride(x), ptr(p), n, h, w, c, stream_ptr()), "maxpool2_fwd")
     return p
 
 
@@ -645,8 +653,10 @@ def maxpool2_bwd(x, p, dp, add=None):
     if add is not None:
         assert tuple(add.shape) == (n, h, w, c) and add.stride(3) == 1 and add.dtype == x.dtype
     fn = _abi.lib().unetk_maxpool2_bwd_bf16 if _storage_of(x) == _abi.BF16S else _abi.lib().unetk_maxpool2_bwd
-    check(fn(ptr(x), _pix_stride(x), ptr(p), ptr(dp.contiguous()), ptr(add),
-             _pix_stride(add) if add is not None else 0, ptr(dx), n, h, w, c, stream_ptr()), "maxpool2_bwd")
+    # reads x, p, dp (+ the skip gradient), writes dx
+    with _Timed("maxpool2_bwd", 0.0, None, (x.numel() * (3 if add is not None else 2) + 2 * p.numel()) * x.element_size()):
+        check(fn(ptr(x), _pix_stride(x), ptr(p), ptr(dp.contiguous()), ptr(add),
+                 _pix_stride(add) if add is not None else 0, ptr(dx), n, h, w, c, stream_ptr()), "maxpool2_bwd")
     return dx
 
 
@@ -790,8 +800,9 @@ def head_fwd(d, z, w, b, labels, pixel_w=None, want_probs=False):
         raise _abi.UnetkError("head: bad descriptor")
     result = torch.zeros((nres,), dtype=torch.float32, device=dev)
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)    # kept for backward (weight tables)
-    check(_abi.lib().unetk_head_fwd(ctypes.byref(d), ptr(z), ptr(w), ptr(b), ptr(labels), ptr(pixel_w), ptr(logits),
-                                    ptr(probs), ptr(result), ptr(ws), nbytes, stream_ptr()), "head_fwd")
+    with _Timed("head_fwd", 0.0, None, z.numel() * z.element_size() + npix * (4 + 4 * d.ncls * (2 if want_probs else 1))):
+        check(_abi.lib().unetk_head_fwd(ctypes.byref(d), ptr(z), ptr(w), ptr(b), ptr(labels), ptr(pixel_w), ptr(logits),
+                                        ptr(probs), ptr(result), ptr(ws), nbytes, stream_ptr()), "head_fwd")
     return logits, probs, result, ws
 
 
@@ -801,9 +812,10 @@ def head_bwd(d, z, w, labels, pixel_w, logits, result, ws, xent_scale, dice_scal
     dw = out_w if out_w is not None else torch.empty((d.C, d.ncls), dtype=torch.float32, device=z.device)
     db = out_b if out_b is not None else torch.empty((d.ncls,), dtype=torch.float32, device=z.device)
     assert tuple(dw.shape) == (d.C, d.ncls) and dw.is_contiguous()
-    check(_abi.lib().unetk_head_bwd(ctypes.byref(d), ptr(z), ptr(w), ptr(labels), ptr(pixel_w), ptr(logits), ptr(result),
-                                    float(xent_scale), float(dice_scale), ptr(dev_scales), ptr(dz), ptr(dw), ptr(db),
-                                    ptr(ws), ws.numel(), stream_ptr()), "head_bwd")
+    with _Timed("head_bwd", 0.0, None, 2 * z.numel() * z.element_size() + d.N * d.HW * (4 + 4 * d.ncls)):
+        check(_abi.lib().unetk_head_bwd(ctypes.byref(d), ptr(z), ptr(w), ptr(labels), ptr(pixel_w), ptr(logits), ptr(result),
+                                        float(xent_scale), float(dice_scale), ptr(dev_scales), ptr(dz), ptr(dw), ptr(db),
+                                        ptr(ws), ws.numel(), stream_ptr()), "head_bwd")
     return dz, dw, db
 
 
@@ -850,8 +862,9 @@ def lits_batch(slices, seg_slices, sample_tab, clip, out_hw, channels, lab_scale
 
 
 def adam_step(p, g, m, v, lr_t, beta1, beta2, eps, gscale=1.0, l2=0.0, decoupled_wd=0.0):
-    check(_abi.lib().unetk_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr_t, beta1, beta2, eps, gscale, l2,
-                                     decoupled_wd, stream_ptr()), "adam_step")
+    with _Timed("adam_step", 0.0, None, p.numel() * 4 * 7):            # reads p, g, m, v; writes p, m, v
+        check(_abi.lib().unetk_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr_t, beta1, beta2, eps, gscale, l2,
+                                         decoupled_wd, stream_ptr()), "adam_step")
     bump_param_gen()
 
 

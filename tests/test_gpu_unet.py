@@ -440,3 +440,38 @@ def test_unet_256x256_against_the_oracle_evaluated_on_the_device_in_float64(bs):
     assert (num / den) ** 0.5 < 5e-3
     for name, ref in new_stats.items():
         assert torch.allclose(model.params[name].double(), ref, rtol=1e-4, atol=1e-6), name
+
+
+def test_config0_liver_only_256x256_bs2_against_the_device_float64_oracle():
+    """BASELINE.json configs[0] at its REAL size (NetworksV2/UNet.yml: Liver only = 2 classes, 256x256x3, bs 2, default loss
+    weights "none"): same checker and bars as the configs[1] test above -- logits 1e-3, loss 1e-4, argmax masks equal outside
+    1e-3 margins, whole-gradient L2 < 5e-3, moving statistics."""
+    args = make_args(classes=["Liver"], batch_size=2, im_height=256, im_width=256, loss_weight_type="none",
+                     loss_numeric_w=None, metrics_train=["Dice"])
+    images, labels = synth(2, 256, 256, 2)
+    model, inputs = build(args, images, labels)
+    net, params = oracle_for(args)
+    model.params.load_state(params)
+    assert model.params.num_trainable() == 31037698            # SURVEY.md 8a
+    p64 = {k: v.double().cuda() for k, v in params.items()}
+    total, _, logits, grads, new_stats = net.loss_and_grads(
+        p64, torch.from_numpy(images).double().cuda(), torch.from_numpy(labels).long().cuda(), **loss_kwargs(args))
+    model.params.zero_grad()
+    loss = model(inputs, "train", **YML)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - total.item()) < 1e-4 * max(1.0, abs(total.item()))
+    got = model.layers["logits"].double()
+    assert got.shape[-1] == 2 and (got - logits).abs().max().item() < 1e-3
+    srt = torch.sort(logits, -1).values
+    safe = (srt[..., -1] - srt[..., -2]) > 1e-3
+    assert bool((got.argmax(-1) == logits.argmax(-1))[safe].all()) and safe.double().mean().item() > 0.99
+    num = den = 0.0
+    for name in model.params.trainable_names():
+        d = model.params[name].grad.double() - grads[name]
+        num += float((d * d).sum())
+        den += float((grads[name] * grads[name]).sum())
+    assert (num / den) ** 0.5 < 5e-3
+    for name, ref in new_stats.items():
+        assert torch.allclose(model.params[name].double(), ref, rtol=1e-4, atol=1e-6), name
+    assert "Liver/Dice" in model.metrics_dict and "Tumor/Dice" not in model.metrics_dict
