@@ -160,6 +160,9 @@ def main():
                     help="fp32 = the headline configuration (exact fp32 MFMA); bf16 = BASELINE.json configs[2]'s mode: bf16 "
                          "matrix cores + bf16 storage of activations / activation gradients, fp32 accumulate / statistics / "
                          "master weights (use --size 512 --batch 8); bf16c = bf16 MFMA operands only, fp32 storage (round 1)")
+    ap.add_argument("--dp-rehearsal", action="store_true",
+                    help="with --gpus 1: run the data-parallel code path (process group on RCCL, bucketed all-reduce launched from "
+                         "backward, 1/N in the optimiser) in a world of ONE rank -- the production path on the one GPU a test box has")
     ap.add_argument("--launch-check", action="store_true",
                     help="self-test of the multi-rank launch only (no kernels, no GPU needed): every rank joins the process "
                          "group, rank 0 prints the ranks it saw as a `launch-check` line")
@@ -188,6 +191,16 @@ def main():
     # ranks (UNETK_DIST_BACKEND=gloo: RCCL refuses two ranks on one device)
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     backend = os.environ.get("UNETK_DIST_BACKEND", "nccl")                               # "nccl" = RCCL over xGMI
+    dp_on = world > 1 or a.dp_rehearsal
+    if a.dp_rehearsal and world == 1:
+        import socket as _socket
+        s_ = _socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1]))
+        s_.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend=backend, rank=0, world_size=1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl" and torch.cuda.device_count() < world:
@@ -228,8 +241,9 @@ def main():
     data = input_fn("train", params)
     model = {c.__name__: c for c in models.MODEL_ZOO}[a.model](args)
     solver = Solver(args)
-    strategy = DistributionStrategy("mirrored", world, rank) if world > 1 else None
+    strategy = DistributionStrategy("mirrored", world, rank) if dp_on else None
     solver.strategy = strategy
+    solver.dp_rehearsal = bool(a.dp_rehearsal)
 
     def inputs_of(batch):
         features, labels = batch
@@ -268,6 +282,17 @@ def main():
     prof = ops.PROFILE
     ops.PROFILE = None
     loss_val = float(loss.detach())
+    # the HBM-bound passes (norm / pool / head / first layer / optimiser) by algorithmic bytes: three more steps, outside the
+    # timed region (their event pairs are host work the metric must not carry)
+    prof_hbm = None
+    if not a.no_kernel_events:             # every rank steps (the all-reduce is collective); rank 0 records
+        if prof is not None:
+            ops.PROFILE, ops.PROFILE_HBM = [], True
+        for _ in range(3):
+            one_step()
+        torch.cuda.synchronize()
+        if prof is not None:
+            prof_hbm, ops.PROFILE, ops.PROFILE_HBM = ops.PROFILE, None, False
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
     rank_ms, n_ranks_seen = [own / a.steps * 1e3], 1
     if world > 1:
@@ -284,7 +309,7 @@ def main():
     # ---- data-parallel diagnostics (N > 1): what the buckets did, how long the compute stream waited for them, and this
     # rank's step WITHOUT the all-reduce (3 extra untimed-by-the-metric steps, replicas may drift afterwards: the run is over)
     dp_diag = None
-    if world > 1:
+    if dp_on:
         bk = getattr(solver, "_buckets", None)
         dp_diag = {"buckets": len(bk.buckets) if bk is not None else 0,
                    "buckets_fired_in_backward": bk.last["fired_in_backward"] if bk is not None and bk.last else None,
@@ -301,6 +326,7 @@ def main():
             one_step()
         torch.cuda.synchronize()
         dp_diag["compute_only_ms_per_step"] = round((time.perf_counter() - tc) / 3 * 1e3, 3)
+        dp_diag["backend"] = backend
         dist.barrier()
 
     if rank == 0:
@@ -338,15 +364,14 @@ def main():
             out["data_parallel"] = dp_diag
         if prof:
             agg, hbm = {}, {}
-            for tag, flops, e0, e1, nbytes in prof:
-                secs = e0.elapsed_time(e1) * 1e-3
+            for tag, flops, e0, e1, nbytes in (prof_hbm or []):
                 if nbytes:                      # HBM-bound passes: algorithmic bytes (each operand once) / time
                     h = hbm.setdefault(tag, [0, 0.0, 0.0])
                     h[0] += 1
                     h[1] += nbytes
-                    h[2] += secs
-                if not flops:
-                    continue
+                    h[2] += e0.elapsed_time(e1) * 1e-3
+            for tag, flops, e0, e1, nbytes in prof:
+                secs = e0.elapsed_time(e1) * 1e-3
                 d = agg.setdefault(tag, [0, 0.0, 0.0])
                 d[0] += 1
                 d[1] += flops
@@ -354,7 +379,7 @@ def main():
             out["hbm_kernels"] = sorted(
                 [{"kernel": tag, "launches": cnt, "avg_launch_ms": round(secs / cnt * 1e3, 4), "avg_launch_mbytes": round(nb / cnt / 1e6, 2),
                   "achieved_gbps": round(nb / secs / 1e9, 1), "frac_of_hbm_peak": round(nb / secs / HBM_PEAK_BPS, 4),
-                  "total_ms_per_step": round(secs / a.steps * 1e3, 3)} for tag, (cnt, nb, secs) in hbm.items()],
+                  "total_ms_per_step": round(secs / 3 * 1e3, 3)} for tag, (cnt, nb, secs) in hbm.items()],
                 key=lambda k: -k["total_ms_per_step"])
             kern = []
             for tag, (cnt, flops, secs) in agg.items():
@@ -398,7 +423,7 @@ def main():
         if not a.no_cpu_baseline and world == 1 and a.model == "UNet":
             out["cpu_baseline"] = cpu_baseline(a.size)
         print(json.dumps(out, ensure_ascii=False), flush=True)
-    if world > 1:
+    if dp_on:
         dist.destroy_process_group()
 
 

@@ -104,6 +104,7 @@ class Solver(object):
         self.overlap_allreduce = True       # bucketed all-reduce launched from backward (distribution_utils.GradBuckets)
         self.bucket_bytes = 32 << 20
         self._buckets = None
+        self.dp_rehearsal = False           # run the data-parallel path (buckets, all-reduce) in a world of ONE (bench.py --dp-rehearsal)
 
     @property
     def args(self):
@@ -223,7 +224,7 @@ class Solver(object):
     def apply_gradients(self, store, l2, lr):
         """One optimiser step on the flat buffers; gradients are already in store.grad."""
         world = self.strategy.num_replicas_in_sync if self.strategy is not None else 1
-        if world > 1:
+        if world > 1 or (self.dp_rehearsal and self.strategy is not None):
             if self._buckets is not None and self._buckets.store is store:
                 self._buckets.finish()              # buckets were all-reduced while backward ran
             else:
@@ -261,7 +262,7 @@ class Solver(object):
         store = model.params
         store.zero_grad()
         world = self.strategy.num_replicas_in_sync if self.strategy is not None else 1
-        if world > 1 and self.overlap_allreduce and hasattr(store, "tensors"):
+        if (world > 1 or (self.dp_rehearsal and self.strategy is not None)) and self.overlap_allreduce and hasattr(store, "tensors"):
             if self._buckets is None or self._buckets.store is not store:
                 if self._buckets is not None:
                     self._buckets.remove()

@@ -185,6 +185,7 @@ struct WgParams {
   // the splits fills the chip: three times the tiles per block, a third of the slab traffic.
   int kd, dshift0, dsd, din, spg;
   int64_t dplane;
+  int dbg;             // conv_wgrad_bf16s.hip probe build (-DUNETK_V3_PROBE): UNETK_V3_FLAGS
 };
 // conv_wgrad.hip: dw[9][Cin][Cout] = filter gradient of one 2-D tap plane; ws layout as unetk_conv3x3_wgrad
 size_t unetk_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int kd = 1);

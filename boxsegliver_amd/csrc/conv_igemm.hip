@@ -359,6 +359,10 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvParams p) {
       if (gh >= p.H || gw >= p.W) continue;
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
       if (CIN > 0) {
+        // two-wide vectors so that the compiler emits v_pk_fma_f32 (two IEEE fmas per instruction: bit-identical to the
+        // scalar chain, half the vector issue slots -- this kernel is VALU-bound: 27 x 4 fmas per pixel and thread)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
           const float* xp = &smem[((r + t / 3) * 18 + c + t % 3) * CIN];
@@ -366,9 +370,12 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvParams p) {
           for (int ci = 0; ci < CIN; ++ci) {
             const float xv = xp[ci];
             const float4 wv = wreg[t * CIN + ci];
-            a.x = fmaf(xv, wv.x, a.x); a.y = fmaf(xv, wv.y, a.y); a.z = fmaf(xv, wv.z, a.z); a.w = fmaf(xv, wv.w, a.w);
+            const f32x2 x2 = {xv, xv};
+            a01 = __builtin_elementwise_fma(x2, f32x2{wv.x, wv.y}, a01);
+            a23 = __builtin_elementwise_fma(x2, f32x2{wv.z, wv.w}, a23);
           }
         }
+        a = make_float4(a01.x, a01.y, a23.x, a23.y);
       } else {
         for (int t = 0; t < 9; ++t) {
           const float* xp = &smem[((r + t / 3) * 18 + c + t % 3) * cin];

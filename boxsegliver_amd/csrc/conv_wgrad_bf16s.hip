@@ -22,6 +22,8 @@
 //     into slabs + the fixed-order slab reduction of conv_wgrad.hip => bit-reproducible, no atomics.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int TW = 16, TH = 8, HWD = TW + 2;
@@ -55,6 +57,8 @@ __device__ __forceinline__ bf16x8 frag(uint32_t a, uint32_t b, uint32_t c, uint3
   return __builtin_bit_cast(bf16x8, make_uint4(a, b, c, d));
 }
 
+// PF: the first fragments of tile t + 1 are requested during tile t (two tiles of load flight); !PF: behind the barrier (three)
+template <bool PF>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][STAGE_B]; reused as the reduction scratch
   const int tid = threadIdx.x;
@@ -92,12 +96,44 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
       rel_w[i] = pix % TW;
     }
   }
+  // Per lane and piece, the byte offset of its 16-byte chunk from the tile's origin pixel (h0, w0) -- constant over the tiles
+  // (pieces that are not part of the tile -- rows past the halo, the 40th piece -- read the origin itself: their LDS
+  // bytes are never used).  An INTERIOR tile (halo inside the image: all but the border tiles) then needs no per-lane
+  // work at all: one scalar base per operand and the offset register.  Round 2 recomputed row / column / validity / a
+  // 64-bit product per lane and piece for every tile: 3.5 vector instructions per MFMA (rocprofv3 SQ_INSTS_VALU), issued
+  // by both waves of a SIMD at the same time, next to a matrix pipe that leaves the vector unit 24 of every 32 cycles.
+  uint32_t poff[IPW];
+#pragma unroll
+  for (int i = 0; i < IPW; ++i) {
+    const int j = wave + 8 * i;
+    const bool real = rel_h[i] < (1 << 19);
+    const bool is_x = j < NP_X;
+    const int64_t o = real ? ((int64_t)rel_h[i] * p.W + rel_w[i]) * (is_x ? p.xs : p.ys) + lchunk * 8 : 0;
+    poff[i] = (uint32_t)(o * 2);        // wraps for the negative offsets of the halo's first row / column: added mod 2^32 to a
+  }                                     // 32-bit origin offset below
   auto issue_tile = [&](int tile, int stage) {
     const int tw_i = tile % p.tiles_w;
     const int th_i = (tile / p.tiles_w) % p.tiles_h;
     const int n_tile = tile / (p.tiles_w * p.tiles_h);
     const int h0 = th_i * TH, w0 = tw_i * TW;
     const int64_t ximg = p.xa.off(n_tile), yimg = p.ya.off(n_tile);
+    const bool interior = h0 >= 1 && w0 >= 1 && h0 + TH + 1 <= p.H && w0 + TW + 1 <= p.W;
+    if (interior) {
+      // origin offsets inside the image fit 32 bits (checked on the host); the image bases are wave-uniform pointers
+      const char* xo = reinterpret_cast<const char*>(xb + ximg + ci0);
+      const char* yo = reinterpret_cast<const char*>(dyb + yimg + co0);
+      const uint32_t xorg = (uint32_t)((h0 * p.W + w0) * p.xs) * 2u, yorg = (uint32_t)((h0 * p.W + w0) * p.ys) * 2u;
+#pragma unroll
+      for (int i = 0; i < IPW; ++i) {
+        const int j = wave + 8 * i;
+        const bool is_x = j < NP_X;
+        const char* src = (is_x ? xo : yo) + (uint32_t)((is_x ? xorg : yorg) + poff[i]);
+        char* dst = smem + stage * STAGE_B + j * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
       const int j = wave + 8 * i;
@@ -133,16 +169,24 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
   const int t_end = min(t_begin + p.tiles_per_split, p.total_tiles);
 
   // prologue: three tiles in flight (indices clamped to the block's last tile: the ring then always holds IPW loads per
-  // stage and "tile t has landed" is vmcnt(2 * IPW))
+  // stage and "tile t + 1 has landed" is vmcnt(IPW))
   if (t_begin < t_end) {
 #pragma unroll
     for (int k = 0; k < NSTAGE - 1; ++k) issue_tile(min(t_begin + k, t_end - 1), k);
   }
   // The main loop is hand-synchronised.  __syncthreads() carries a fence that waits for ALL outstanding memory operations
-  // (vmcnt(0): the three tiles in flight!), and the compiler guards every LDS read that follows a direct-to-LDS load with
+  // (vmcnt(0): the tiles in flight!), and the compiler guards every LDS read that follows a direct-to-LDS load with
   // another vmcnt(0) (it cannot tell the ring's stages apart) -- together they serialised loads and MFMAs (measured:
   // time = loads + compute).  So: a bare s_barrier after a counted vmcnt, and the transposed reads are inline asm with
   // counted lgkmcnt waits whose "+v" operands tie the consuming MFMAs behind them.
+  //
+  // Round 3 (what tools/mfma_mix_bf16.hip and the conv kernel's probe build showed about loops of this shape):
+  //   * the barrier at the top of tile t now guarantees tile t + 1 (vmcnt(IPW): two tiles of flight instead of three, still
+  //     4-5 us), so the FIRST fragments of tile t + 1 are requested during the last MFMAs of tile t: no wave sits behind the
+  //     barrier waiting for LDS;
+  //   * waves 0..3 request tile t + 3 behind the barrier, waves 4..7 (their SIMD partners: waves are dealt to the SIMDs
+  //     cyclically) in the middle of the tile: five direct-to-LDS loads hold a wave at issue for several hundred cycles,
+  //     and this way one partner requests while the other feeds the matrix pipe.
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 #define TR_READ(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define LGKM_WAIT3(n, r0, r1, r2) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(r0), "+v"(r1), "+v"(r2))
@@ -161,27 +205,51 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
     acc[(kh_) * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(HI(a0), LO(a1), HI(a1), LO(a2)), bb, acc[(kh_) * 3 + 2], 0, 0, 0); \
   }
   constexpr int AROW = HWD * 128, BROW = TW * 128;     // bytes between consecutive halo rows / dy tile rows
-  int stage = 0;
-  for (int tile = t_begin; tile < t_end; ++tile, stage = (stage + 1) & (NSTAGE - 1)) {
-    static_assert(IPW == 5 && NSTAGE == 4, "the wait count below is (NSTAGE - 2) * IPW");
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // this wave's pieces of `tile` have landed (two younger tiles may fly) ...
-    __builtin_amdgcn_s_barrier();                      // ... everybody's have, and every wave is done reading the stage of tile - 1
-    issue_tile(min(tile + NSTAGE - 1, t_end - 1), (stage + NSTAGE - 1) & (NSTAGE - 1));
-
-    // this wave's four tile rows r = 4 ks + rr read halo rows 4 ks + 0 .. 5 (parity of the swizzle = parity of the local
-    // index, 4 ks being even) and dy rows 4 ks + 0 .. 3.  Halo row hr serves the pairs (rr, kh = hr - rr).
-    const uint32_t xa0 = lds0 + stage * STAGE_B + ks * (TH / 2) * AROW + a_off0;   // even local halo rows
-    const uint32_t xa1 = lds0 + stage * STAGE_B + ks * (TH / 2) * AROW + a_off1;   // odd
-    const uint32_t yb = lds0 + stage * STAGE_B + XH_B + ks * (TH / 2) * BROW + b_off;
-    uint64_t B00, B01, B10, B11, B20, B21, B30, B31;
-    uint64_t P0, P1, P2, Q0, Q1, Q2;                   // halo rows, double-buffered: even rows in P, odd rows in Q
+  static_assert(IPW == 5 && NSTAGE == 4, "the wait counts below: vmcnt(IPW) = one younger tile in flight");
+  uint64_t B00, B01, B10, B11, B20, B21, B30, B31;
+  uint64_t P0, P1, P2, Q0, Q1, Q2;                     // halo rows, double-buffered: even rows in P, odd rows in Q
+  const uint32_t a0_rel = ks * (TH / 2) * AROW + a_off0, a1_rel = ks * (TH / 2) * AROW + a_off1;
+  const uint32_t b_rel = XH_B + ks * (TH / 2) * BROW + b_off;
+  if (PF && t_begin < t_end) {
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // this wave's pieces of tiles 0 and 1 have landed ...
+    __builtin_amdgcn_s_barrier();                      // ... everybody's
+    // the first requests of tile 0: dy rows 0, 1 and halo row 0 -- the order the steady state leaves them in
+    const uint32_t yb = lds0 + b_rel, xa0 = lds0 + a0_rel;
     TR_READ(B00, yb, 0 * BROW);            TR_READ(B01, yb, 0 * BROW + 512);
     TR_READ(B10, yb, 1 * BROW);            TR_READ(B11, yb, 1 * BROW + 512);
     TR_READ(P0, xa0, 0 * AROW);            TR_READ(P1, xa0, 0 * AROW + 512);   TR_READ(P2, xa0, 0 * AROW + 1024);
+  }
+  int stage = 0;
+  for (int tile = t_begin; tile < t_end; ++tile, stage = (stage + 1) & (NSTAGE - 1)) {
+    if constexpr (PF) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // this wave's pieces of tile + 1 have landed (tile + 2 may fly) ...
+    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");              // ... of this tile (two younger tiles may fly)
+#ifdef UNETK_V3_PROBE
+    if (!(p.dbg & 16))
+#endif
+    __builtin_amdgcn_s_barrier();                      // ... everybody's have, and every wave is done reading the stage of tile - 1
+#ifdef UNETK_V3_PROBE
+    if (!(p.dbg & 4))
+#endif
+    if (wave < 4) issue_tile(min(tile + NSTAGE - 1, t_end - 1), (stage + NSTAGE - 1) & (NSTAGE - 1));
+
+    // this wave's four tile rows r = 4 ks + rr read halo rows 4 ks + 0 .. 5 (parity of the swizzle = parity of the local
+    // index, 4 ks being even) and dy rows 4 ks + 0 .. 3.  Halo row hr serves the pairs (rr, kh = hr - rr).
+    const uint32_t xa0 = lds0 + stage * STAGE_B + a0_rel;   // even local halo rows
+    const uint32_t xa1 = lds0 + stage * STAGE_B + a1_rel;   // odd
+    const uint32_t yb = lds0 + stage * STAGE_B + b_rel;
+    const int nstage = (stage + 1) & (NSTAGE - 1);
+    const uint32_t nxa0 = lds0 + nstage * STAGE_B + a0_rel, nyb = lds0 + nstage * STAGE_B + b_rel;
+    // outstanding (oldest first): B00 B01 B10 B11 P0 P1 P2 of this tile, requested during the previous one (PF) or here
+    if constexpr (!PF) {
+      TR_READ(B00, yb, 0 * BROW);            TR_READ(B01, yb, 0 * BROW + 512);
+      TR_READ(B10, yb, 1 * BROW);            TR_READ(B11, yb, 1 * BROW + 512);
+      TR_READ(P0, xa0, 0 * AROW);            TR_READ(P1, xa0, 0 * AROW + 512);   TR_READ(P2, xa0, 0 * AROW + 1024);
+    }
     // hr = 0: prefetch row 1 and dy row 2
     TR_READ(Q0, xa1, 1 * AROW);            TR_READ(Q1, xa1, 1 * AROW + 512);   TR_READ(Q2, xa1, 1 * AROW + 1024);
     TR_READ(B20, yb, 2 * BROW);            TR_READ(B21, yb, 2 * BROW + 512);
     LGKM_WAIT5(5, P0, P1, P2, B00, B01);
+    asm volatile("" : "+v"(B10), "+v"(B11));
     ROW_MFMA(0, P0, P1, P2, B00, B01);
     // hr = 1 (in Q): prefetch row 2 -> P is free once the MFMAs above have read it (program order), dy row 3
     {
@@ -198,19 +266,36 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
       ROW_MFMA(1, R0, R1, R2, B10, B11);
       ROW_MFMA(2, R0, R1, R2, B00, B01);
     }
+#ifdef UNETK_V3_PROBE
+    if (!(p.dbg & 4))
+#endif
+    if (wave >= 4) issue_tile(min(tile + NSTAGE - 1, t_end - 1), (stage + NSTAGE - 1) & (NSTAGE - 1));
     // hr = 3 (in Q): prefetch row 4 into P
     TR_READ(P0, xa0, 4 * AROW);            TR_READ(P1, xa0, 4 * AROW + 512);   TR_READ(P2, xa0, 4 * AROW + 1024);
     LGKM_WAIT5(3, Q0, Q1, Q2, B30, B31);
     ROW_MFMA(0, Q0, Q1, Q2, B30, B31);
     ROW_MFMA(1, Q0, Q1, Q2, B20, B21);
     ROW_MFMA(2, Q0, Q1, Q2, B10, B11);
+    // dy rows 0, 1 are done: request them for the NEXT tile (its stage became visible at this tile's barrier)
+    if constexpr (PF) {
+      asm volatile("s_nop 0" : "+v"(B00), "+v"(B01), "+v"(B10), "+v"(B11));      // orders the requests behind the MFMAs above
+      TR_READ(B00, nyb, 0 * BROW);           TR_READ(B01, nyb, 0 * BROW + 512);
+      TR_READ(B10, nyb, 1 * BROW);           TR_READ(B11, nyb, 1 * BROW + 512);
+    }
     // hr = 4 (in P): prefetch row 5 into Q
     TR_READ(Q0, xa1, 5 * AROW);            TR_READ(Q1, xa1, 5 * AROW + 512);   TR_READ(Q2, xa1, 5 * AROW + 1024);
-    LGKM_WAIT3(3, P0, P1, P2);
+    if constexpr (PF) LGKM_WAIT3(7, P0, P1, P2);
+    else LGKM_WAIT3(3, P0, P1, P2);
     ROW_MFMA(1, P0, P1, P2, B30, B31);
     ROW_MFMA(2, P0, P1, P2, B20, B21);
+    if constexpr (PF) {      // halo row 0 of the next tile
+      asm volatile("s_nop 0" : "+v"(P0), "+v"(P1), "+v"(P2));
+      TR_READ(P0, nxa0, 0 * AROW);           TR_READ(P1, nxa0, 0 * AROW + 512);  TR_READ(P2, nxa0, 0 * AROW + 1024);
+      LGKM_WAIT3(3, Q0, Q1, Q2);
+    } else {
+      LGKM_WAIT3(0, Q0, Q1, Q2);
+    }
     // hr = 5 (in Q)
-    LGKM_WAIT3(0, Q0, Q1, Q2);
     ROW_MFMA(2, Q0, Q1, Q2, B30, B31);
   }
 #undef TR_READ
@@ -223,8 +308,11 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
   // ---- sum the two pixel-row halves through LDS (fixed order), then the ks == 0 waves write the split's slab
   float* red = reinterpret_cast<float*>(smem);  // [4 waves][144][64 lanes]
   const int pidx = wci * 2 + wco;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-fetches still in flight must land before LDS is reused
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the clamped re-fetches and the fragment requests behind the last tile
   __syncthreads();
+#ifdef UNETK_V3_PROBE
+  if (p.dbg & 32) { if (acc[0][0] == 12345.f) p.slab[0] = 1.f; return; }
+#endif
   if (ks == 1) {
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -367,7 +455,11 @@ int unetk_wgrad_bf16s_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipS
   if (!plan(p.N, p.H, p.W, p.Cin, p.Cout, &pl)) return UNETK_E_UNSUPPORTED;
   if (ws_bytes < unetk_wgrad_bf16s_ws_bytes(p.N, p.H, p.W, p.Cin, p.Cout)) return UNETK_E_WORKSPACE;
   if (p.ys % 8 != 0 || (!pl.small && p.xs % 8 != 0)) return UNETK_E_BADARG;       // 16-byte chunks of 8 bf16
+  if ((int64_t)p.H * p.W * (p.xs > p.ys ? p.xs : p.ys) * 2 >= (int64_t(1) << 31)) return UNETK_E_UNSUPPORTED;   // 32-bit offsets inside an image
   p.zeros = nullptr;
+#ifdef UNETK_V3_PROBE
+  { const char* e = getenv("UNETK_V3_FLAGS"); p.dbg = e ? atoi(e) : 0; }
+#endif
   p.slab = pl.S == 1 ? dw : (float*)ws + 64;           // a single split writes the gradient in place
   p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.total_tiles = pl.total_tiles;
   p.tiles_per_split = pl.tiles_per_split; p.n_ci_tiles = pl.n_ci_tiles; p.n_co_tiles = pl.n_co_tiles;
@@ -378,13 +470,21 @@ int unetk_wgrad_bf16s_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipS
   } else {
     static bool attr_done = false;
     if (!attr_done) {
-      hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+      hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16s_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16s_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
       if (e != hipSuccess) return (int)e;
       attr_done = true;
     }
-    hipLaunchKernelGGL(conv3x3_wgrad_bf16s_kernel, dim3(pl.S * pl.n_ci_tiles * pl.n_co_tiles), dim3(512), LDS_B, st, p);
+    static int deep = -1;          // UNETK_WGRAD_DEEP=1 (measurement): three tiles of load flight, first fragments behind the barrier
+    if (deep < 0) { const char* e = getenv("UNETK_WGRAD_DEEP"); deep = e ? atoi(e) : 0; }
+    if (deep) hipLaunchKernelGGL(conv3x3_wgrad_bf16s_kernel<false>, dim3(pl.S * pl.n_ci_tiles * pl.n_co_tiles), dim3(512), LDS_B, st, p);
+    else hipLaunchKernelGGL(conv3x3_wgrad_bf16s_kernel<true>, dim3(pl.S * pl.n_ci_tiles * pl.n_co_tiles), dim3(512), LDS_B, st, p);
     UNETK_LAUNCH_CHECK();
   }
   if (pl.S == 1) return UNETK_OK;
+#ifdef UNETK_V3_PROBE
+  if (p.dbg & 32) return UNETK_OK;
+#endif
   return unetk_launch_slab_reduce((const float*)ws + 64, pl.S, (int64_t)9 * p.Cin * p.Cout, dw, st);
 }

@@ -39,6 +39,7 @@ class _Workspace(object):
 WORKSPACE = _Workspace()
 FUSE_NBR = True         # conv2's input gradient also emits conv1's norm-backward reduction (unetk_conv3x3_dgrad_nbr)
 FUSED_NBR = {}          # dx.data_ptr() -> (producer y.data_ptr(), shape, partials, rows, dx._version); consumed by the producer's backward
+PROFILE_HBM = False     # bench.py: also time the HBM-bound passes (by algorithmic bytes)
 DEBUG_CAPTURE = None    # tools/: set to a list to record each conv unit's backward operands
 PROFILE_SHAPES = False  # bench.py --detail: one row per (kernel, layer shape)
 PROFILE = None          # bench.py: set to a list -> (kernel tag, algorithmic FLOPs, start event, end event)
@@ -109,7 +110,10 @@ class _PackCache(object):
         return wp_f, wp_d
 
     def _repack_all(self):
-        dead = [k for k, e in self.entries.items() if e["flat"]() is None]
+        # strong references for the duration of the call: a collection cycle in the middle of it (a freed model's flat buffer)
+        # must not turn a weak reference dead between this check and its use below
+        held = {k: e["flat"]() for k, e in self.entries.items()}
+        dead = [k for k, f in held.items() if f is None]
         for k in dead:
             del self.entries[k]
             self.table = None
@@ -132,8 +136,8 @@ class _PackCache(object):
         tab, n_items, total = self.table
         check(_abi.lib().unetk_pack_many(ptr(tab), n_items, total, stream_ptr()), "pack_many")
         self.batched += 1
-        for e in live:
-            e["gen"] = (PARAM_GEN, e["flat"]()._version)
+        for k, e in self.entries.items():
+            e["gen"] = (PARAM_GEN, held[k]._version)
 
 
 PACKS = _PackCache()
@@ -145,7 +149,9 @@ class _Timed(object):
 
     def __init__(self, tag, flops, shape=None, nbytes=0):
         """flops: algorithmic FLOPs of a matrix kernel; nbytes: algorithmic HBM bytes (each operand once) of an HBM-bound pass."""
-        self.on = PROFILE is not None
+        # HBM-bound passes (flops == 0) are timed only on request: their ~60 extra event pairs per step are host work bench.py's
+        # timed region must not carry
+        self.on = PROFILE is not None and (flops > 0 or PROFILE_HBM)
         self.tag, self.flops, self.nbytes = (tag if not (PROFILE_SHAPES and shape) else "{} [{}]".format(tag, shape)), flops, nbytes
 
     def __enter__(self):

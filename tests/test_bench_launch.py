@@ -69,3 +69,18 @@ def test_bench_two_ranks_from_a_plain_shell_gloo_rehearsal():
     assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2" and out["scaling"] == "weak"
     assert out["value"] > 0 and out["rank_ms_per_step_min"] <= out["rank_ms_per_step_max"] <= out["ms_per_step"] * 1.5
     assert "roofline" in out and out["roofline"]["achieved"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_runs_the_rccl_data_parallel_path_in_a_world_of_one():
+    """the production data-parallel path -- process group on RCCL ("nccl"), GradBuckets launched from backward
+    hooks, finish() joining the compute stream, 1/N in the optimiser kernel -- driven through bench.py itself on the one GPU
+    of the test box; the line carries the diagnostics an 8-GPU run will be read with."""
+    r = _run(["--gpus", "1", "--dp-rehearsal", "--steps", "3", "--warmup", "1", "--batch", "4", "--size", "64", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _line(r.stdout)
+    dp = out["data_parallel"]
+    assert dp["backend"] == "nccl" and dp["buckets"] >= 3 and dp["buckets_fired_in_backward"] == dp["buckets"]
+    assert dp["allreduce_bytes"] == 31037763 * 4 + (dp["allreduce_bytes"] - 31037763 * 4)      # both flat buffers (padding included)
+    assert dp["allreduce_exposed_ms"] is not None and dp["allreduce_exposed_ms"] >= 0.0
+    assert dp["compute_only_ms_per_step"] > 0 and 0.2 < dp["dp_efficiency_vs_compute_only"] < 1.5

@@ -8,7 +8,7 @@ OUT="$ROOT/gpurun_out/probe_v3"
 mkdir -p "$OUT"
 cd "$ROOT"
 cp boxsegliver_amd/lib/libunetk.so /tmp/libunetk_real.so
-rm -f build/conv_igemm_bf16s.o      # the objects travel with the tree: force this one
+rm -f build/conv_igemm_bf16s.o build/conv_wgrad_bf16s.o     # the objects travel with the tree: force these
 UNETK_EXTRA_FLAGS=-DUNETK_V3_PROBE bash boxsegliver_amd/csrc/build.sh > "$OUT/build.log" 2>&1
 for f in ${PROBE_FLAGS:-0 4 8 16 32 20 60}; do
   UNETK_V3_FLAGS=$f timeout -k 10 300 python bench.py --dtype bf16 --size 512 --batch 8 --steps 6 --warmup 2 --no-cpu-baseline --detail \
@@ -16,4 +16,4 @@ for f in ${PROBE_FLAGS:-0 4 8 16 32 20 60}; do
   echo "flag $f done"
 done
 cp /tmp/libunetk_real.so boxsegliver_amd/lib/libunetk.so
-rm -f build/conv_igemm_bf16s.o
+rm -f build/conv_igemm_bf16s.o build/conv_wgrad_bf16s.o
