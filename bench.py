@@ -407,8 +407,13 @@ def main():
                 # MODE>: plain / accumulating / fused-reduction epilogue; <..., BS, NBR> for bf16): launch-weighted mean
                 groups = {}
                 for k, v in pmc.items():
-                    t = re.sub(r"(,1,1,[012]|,true,(true|false)|(,1)+)>$", lambda m: ",true>" if "true" in m.group(0)[:6] else ">",
-                               k.replace(" ", ""))
+                    t = k.replace(" ", "")
+                    if t.startswith("conv3x3_bf16s_kernel<"):            # round-3 kernel: <NT8, NBR> -> the bench tag <NT8[,nbr]>
+                        t = t.replace(",false>", ">").replace(",true>", ",nbr>")
+                    elif t.startswith("conv3x3_wgrad_bf16s_kernel<"):    # <PF>: one tag
+                        t = "conv3x3_wgrad_bf16s_kernel"
+                    else:
+                        t = re.sub(r"(,1,1,[012]|,true,(true|false)|(,1)+)>$", lambda m: ",true>" if "true" in m.group(0)[:6] else ">", t)
                     g = groups.setdefault(t, [0, 0.0])
                     g[0] += v["launches"]
                     g[1] += v["launches"] * v["hbm_bytes_per_launch_corrected"]

@@ -168,6 +168,33 @@ class _Timed(object):
         return False
 
 
+class _NoTimer(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_TIMER = _NoTimer()
+
+
+def _timed(tag_fn, flops, fmt=None, args=(), nbytes_fn=None):
+    """Timer of a matrix kernel; tag_fn / the shape string / nbytes_fn are evaluated only when bench.py asked for events."""
+    if PROFILE is None:
+        return _NO_TIMER
+    tag = tag_fn() if callable(tag_fn) else tag_fn
+    return _Timed(tag, flops, fmt.format(*args) if fmt else None, nbytes_fn(tag) if nbytes_fn else 0)
+
+
+def _timed_hbm(tag, t, passes, extra=0):
+    """Timer of an HBM-bound pass moving `passes` x the bytes of tensor `t` (+ extra); a shared no-op unless bench.py asked
+    for these (the byte count is not even computed then: these wrappers sit on the host path of every step)."""
+    if PROFILE is None or not PROFILE_HBM:
+        return _NO_TIMER
+    return _Timed(tag, 0.0, None, t.numel() * t.element_size() * passes + extra)
+
+
 def _igemm_tag(cin, cout, bf16=False, h=0, n=1 << 20, w=1 << 10, nbr=False):
     """Kernel name of a conv3x3 forward / input-gradient launch (mirrors the dispatch of conv_igemm*.hip; bench labels)."""
     def cdiv(a, b):
@@ -386,10 +413,9 @@ def conv3x3_fwd(x, w, cout, want_stats=True, y=None, bf16=False, dilation=1):
         stats = torch.empty((2, rows, cout), dtype=torch.float32, device=x.device)
     nws = _abi.lib().unetk_conv3x3_ws_bytes(ctypes.byref(d)) if prec == _abi.FP32 else 0     # stream-K scratch (small planes)
     ws = WORKSPACE.get(nws, x.device) if nws else None
-    tag = _igemm_tag(cin, cout, bf16, h, n, wd)
-    # the first layer's direct kernel is HBM-bound (writes 64 channels per pixel from 3): report it by bytes as well
-    nb = (x.numel() * x.element_size() + y.numel() * y.element_size()) if tag == "conv3x3_direct_kernel" else 0
-    with _Timed(tag, 18.0 * n * h * wd * cin * cout, "fwd {}x{}x{} {}->{}".format(n, h, wd, cin, cout), nb):
+    # the first layer's direct kernel is HBM-bound (writes 64 channels per pixel from 3): reported by bytes as well
+    with _timed(lambda: _igemm_tag(cin, cout, bf16, h, n, wd), 18.0 * n * h * wd * cin * cout, "fwd {}x{}x{} {}->{}", (n, h, wd, cin, cout),
+                lambda tag: (x.numel() * x.element_size() + y.numel() * y.element_size()) if tag == "conv3x3_direct_kernel" else 0):
         check(_abi.lib().unetk_conv3x3_fwd_ws(ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(stats), ptr(ws), nws,
                                               stream_ptr()), "conv3x3_fwd")
     return y, stats, rows
@@ -410,8 +436,8 @@ def conv3x3_dgrad(dy, wp_dgrad, cin, x_stride=None, dx=None, bf16=False, dilatio
         rows = _abi.lib().unetk_conv3x3_dgrad_nbr_rows(ctypes.byref(d))
         if rows > 0 and py.dtype == dx.dtype and tuple(py.shape) == tuple(dx.shape) and py.is_contiguous():
             part = torch.empty((2, rows, cin), dtype=torch.float32, device=dy.device)
-            with _Timed(_igemm_tag(cout, cin, bf16, h, n, wd, nbr=True), 18.0 * n * h * wd * cin * cout,
-                        "dgrad+nbr {}x{}x{} {}->{}".format(n, h, wd, cout, cin)):
+            with _timed(lambda: _igemm_tag(cout, cin, bf16, h, n, wd, nbr=True), 18.0 * n * h * wd * cin * cout,
+                        "dgrad+nbr {}x{}x{} {}->{}", (n, h, wd, cout, cin)):
                 check(_abi.lib().unetk_conv3x3_dgrad_nbr(ctypes.byref(d), ptr(dy), ptr(wp_dgrad), ptr(dx), ptr(py), cin,
                                                          ptr(paff[2]), ptr(paff[3]), ptr(paff[0]), ptr(paff[1]),
                                                          1 if per_sample else 0, ptr(part), stream_ptr()),
@@ -423,7 +449,7 @@ def conv3x3_dgrad(dy, wp_dgrad, cin, x_stride=None, dx=None, bf16=False, dilatio
             return dx
     nws = _abi.lib().unetk_conv3x3_ws_bytes(ctypes.byref(d)) if prec == _abi.FP32 else 0
     ws = WORKSPACE.get(nws, dy.device) if nws else None
-    with _Timed(_igemm_tag(cout, cin, bf16, h, n, wd), 18.0 * n * h * wd * cin * cout, "dgrad {}x{}x{} {}->{}".format(n, h, wd, cout, cin)):
+    with _timed(lambda: _igemm_tag(cout, cin, bf16, h, n, wd), 18.0 * n * h * wd * cin * cout, "dgrad {}x{}x{} {}->{}", (n, h, wd, cout, cin)):
         check(_abi.lib().unetk_conv3x3_dgrad_ws(ctypes.byref(d), ptr(dy), ptr(wp_dgrad), ptr(dx), ptr(ws), nws, stream_ptr()),
               "conv3x3_dgrad")
     return dx
@@ -448,7 +474,7 @@ def conv3x3_wgrad(x, dy, bf16=False, dilation=1, out=None):
         tag = "conv3x3_wgrad_kernel<bf16>(+slab_reduce)"
     if prec == _abi.BF16S:
         tag = "conv3x3_wgrad_bf16s_kernel(+slab_reduce)" if cin % 64 == 0 else "conv3x3_wgrad_c3_bf16s_kernel(+slab_reduce)"
-    with _Timed(tag, 18.0 * n * h * wd * cin * cout, "{}x{}x{} {}->{}".format(n, h, wd, cin, cout)):
+    with _timed(tag, 18.0 * n * h * wd * cin * cout, "{}x{}x{} {}->{}", (n, h, wd, cin, cout)):
         check(_abi.lib().unetk_conv3x3_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes,
                                              stream_ptr()), "conv3x3_wgrad")
     return dw
@@ -558,7 +584,7 @@ def norm_apply_relu(d, y, aff, z, guide=None, gw=None, gb=None, den=None):
     d.storage = _storage_of(y)
     if den is not None:
         assert den.is_contiguous() and tuple(den.shape) == (d.N, d.C), (tuple(den.shape), d.N, d.C)
-    with _Timed("norm_apply_relu", 0.0, None, y.numel() * y.element_size() * 2):          # read y, write z
+    with _timed_hbm("norm_apply_relu", y, 2):          # read y, write z
         check(_abi.lib().unetk_norm_apply_relu(ctypes.byref(d), ptr(y), ptr(aff[2]), ptr(aff[3]), ptr(den), ptr(guide),
                                                ptr(gw), ptr(gb), ptr(z), stream_ptr()), "norm_apply_relu")
     return z
@@ -585,8 +611,7 @@ def norm_relu_bwd(d, y, dz, aff, has_gamma, has_beta, guide=None, gw=None, gb=No
     ws = WORKSPACE.get(nbytes, dev)
     pre_part, pre_rows = pre if pre is not None else (None, 0)
     # reduction pass reads (dz, y) unless its partials came from the producing kernel; the apply pass reads (dz, y), writes dy
-    with _Timed("norm_relu_bwd" + ("(apply only)" if pre is not None else "(reduce+apply)"), 0.0, None,
-                y.numel() * y.element_size() * (3 if pre is not None else 5)):
+    with _timed_hbm("norm_relu_bwd(apply only)" if pre is not None else "norm_relu_bwd(reduce+apply)", y, 3 if pre is not None else 5):
         check(_abi.lib().unetk_norm_relu_bwd_pre(ctypes.byref(d), ptr(y), ptr(dz), _pix_stride_nd(dz), ptr(aff[2]), ptr(aff[3]),
                                                  ptr(aff[0]), ptr(aff[1]), ptr(den), ptr(guide), ptr(gw), ptr(gb), ptr(dy),
                                                  ptr(dgamma), ptr(dbeta), ptr(dden), ptr(dgw), ptr(dgb), ptr(pre_part),
@@ -646,7 +671,7 @@ def maxpool2_fwd(x):
     n, h, w, c = x.shape
     p = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
     fn = _abi.lib().unetk_maxpool2_fwd_bf16 if _storage_of(x) == _abi.BF16S else _abi.lib().unetk_maxpool2_fwd
-    with _Timed("maxpool2_fwd", 0.0, None, (x.numel() + p.numel()) * x.element_size()):
+    with _timed_hbm("maxpool2_fwd", p, 5):            # reads x (4 p), writes p
         check(fn(ptr(x), _pix_stride(x), ptr(p), n, h, w, c, stream_ptr()), "maxpool2_fwd")
     return p
 
@@ -660,7 +685,7 @@ def maxpool2_bwd(x, p, dp, add=None):
         assert tuple(add.shape) == (n, h, w, c) and add.stride(3) == 1 and add.dtype == x.dtype
     fn = _abi.lib().unetk_maxpool2_bwd_bf16 if _storage_of(x) == _abi.BF16S else _abi.lib().unetk_maxpool2_bwd
     # reads x, p, dp (+ the skip gradient), writes dx
-    with _Timed("maxpool2_bwd", 0.0, None, (x.numel() * (3 if add is not None else 2) + 2 * p.numel()) * x.element_size()):
+    with _timed_hbm("maxpool2_bwd", p, (4 * 3 if add is not None else 4 * 2) + 2):
         check(fn(ptr(x), _pix_stride(x), ptr(p), ptr(dp.contiguous()), ptr(add),
                  _pix_stride(add) if add is not None else 0, ptr(dx), n, h, w, c, stream_ptr()), "maxpool2_bwd")
     return dx
@@ -699,7 +724,7 @@ def deconv2x2_fwd(x, wp_fwd, bias, cat, coff, cout, bf16=False):
     assert x.dtype == storage_dtype(prec) and cat.dtype == x.dtype, (x.dtype, cat.dtype, prec)
     d = DeconvDesc(n, h, w, cin, cout, _pix_stride(cat), coff, prec)
     tag = {0: "pw_gemm_kernel<fwd>", 1: "pw_gemm_bf16_kernel<fwd>", 2: "pw_gemm_bf16_kernel<fwd,bs>"}[prec]
-    with _Timed(tag, 8.0 * n * h * w * cin * cout, "{}x{}x{} {}->{}".format(n, h, w, cin, cout)):
+    with _timed(tag, 8.0 * n * h * w * cin * cout, "{}x{}x{} {}->{}", (n, h, w, cin, cout)):
         check(_abi.lib().unetk_deconv2x2_fwd(ctypes.byref(d), ptr(x), ptr(wp_fwd), ptr(bias), ptr(cat), stream_ptr()),
               "deconv2x2_fwd")
     return cat
@@ -719,9 +744,8 @@ def deconv2x2_bwd(x, wp_dgrad, cat, dcat, coff, cout, bf16=False, out_w=None, ou
     dw = out_w if out_w is not None else torch.empty((2, 2, cout, cin), dtype=torch.float32, device=x.device)
     db = out_b if out_b is not None else torch.empty((cout,), dtype=torch.float32, device=x.device)
     assert tuple(dw.shape) == (2, 2, cout, cin) and dw.is_contiguous()
-    with _Timed("deconv2x2_bwd{}(relu_bwd+pw_gemm<dgrad>+deconv_wgrad)".format({0: "", 1: "<bf16>", 2: "<bf16s>"}[prec]),
-                16.0 * n * h * w * cin * cout,
-                "{}x{}x{} {}->{}".format(n, h, w, cin, cout)):
+    with _timed(lambda: "deconv2x2_bwd{}(relu_bwd+pw_gemm<dgrad>+deconv_wgrad)".format({0: "", 1: "<bf16>", 2: "<bf16s>"}[prec]),
+                16.0 * n * h * w * cin * cout, "{}x{}x{} {}->{}", (n, h, w, cin, cout)):
         check(_abi.lib().unetk_deconv2x2_bwd(ctypes.byref(d), ptr(x), ptr(wp_dgrad), ptr(cat), ptr(dcat), ptr(dx),
                                              ptr(dw), ptr(db), ptr(ws), nbytes, stream_ptr()), "deconv2x2_bwd")
     return dx, dw, db
@@ -806,7 +830,7 @@ def head_fwd(d, z, w, b, labels, pixel_w=None, want_probs=False):
         raise _abi.UnetkError("head: bad descriptor")
     result = torch.zeros((nres,), dtype=torch.float32, device=dev)
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)    # kept for backward (weight tables)
-    with _Timed("head_fwd", 0.0, None, z.numel() * z.element_size() + npix * (4 + 4 * d.ncls * (2 if want_probs else 1))):
+    with _timed_hbm("head_fwd", z, 1, npix * (4 + 4 * d.ncls * (2 if want_probs else 1))):
         check(_abi.lib().unetk_head_fwd(ctypes.byref(d), ptr(z), ptr(w), ptr(b), ptr(labels), ptr(pixel_w), ptr(logits),
                                         ptr(probs), ptr(result), ptr(ws), nbytes, stream_ptr()), "head_fwd")
     return logits, probs, result, ws
@@ -818,7 +842,7 @@ def head_bwd(d, z, w, labels, pixel_w, logits, result, ws, xent_scale, dice_scal
     dw = out_w if out_w is not None else torch.empty((d.C, d.ncls), dtype=torch.float32, device=z.device)
     db = out_b if out_b is not None else torch.empty((d.ncls,), dtype=torch.float32, device=z.device)
     assert tuple(dw.shape) == (d.C, d.ncls) and dw.is_contiguous()
-    with _Timed("head_bwd", 0.0, None, 2 * z.numel() * z.element_size() + d.N * d.HW * (4 + 4 * d.ncls)):
+    with _timed_hbm("head_bwd", z, 2, d.N * d.HW * (4 + 4 * d.ncls)):
         check(_abi.lib().unetk_head_bwd(ctypes.byref(d), ptr(z), ptr(w), ptr(labels), ptr(pixel_w), ptr(logits), ptr(result),
                                         float(xent_scale), float(dice_scale), ptr(dev_scales), ptr(dz), ptr(dw), ptr(db),
                                         ptr(ws), ws.numel(), stream_ptr()), "head_bwd")
@@ -868,7 +892,7 @@ def lits_batch(slices, seg_slices, sample_tab, clip, out_hw, channels, lab_scale
 
 
 def adam_step(p, g, m, v, lr_t, beta1, beta2, eps, gscale=1.0, l2=0.0, decoupled_wd=0.0):
-    with _Timed("adam_step", 0.0, None, p.numel() * 4 * 7):            # reads p, g, m, v; writes p, m, v
+    with _timed_hbm("adam_step", p, 7):            # reads p, g, m, v; writes p, m, v
         check(_abi.lib().unetk_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr_t, beta1, beta2, eps, gscale, l2,
                                          decoupled_wd, stream_ptr()), "adam_step")
     bump_param_gen()

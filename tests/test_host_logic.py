@@ -179,3 +179,15 @@ def test_profiles_readme_is_generated_from_the_committed_profiles():
     assert out.returncode == 0, out.stderr[-2000:]
     with open(os.path.join(root, "profiles", "r02_README.md")) as f:
         assert out.stdout == f.read()
+
+
+def test_round3_profiles_readme_is_generated_from_the_committed_profiles():
+    """Same for profiles/r03_README.md (tools/profiles_readme_r03.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "profiles_readme_r03.py")], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    with open(os.path.join(root, "profiles", "r03_README.md")) as f:
+        assert out.stdout == f.read()
