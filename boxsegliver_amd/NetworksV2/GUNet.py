@@ -28,8 +28,10 @@ context vector as [bs, L, 1] through 1-D conv + ReLU stacks and "same" max-pools
 flattened into mlp(num_base=5) = fc6 ..; the last layer starts at weights 0 / biases 1.
 `ct_conv` (`_context_subnets_conv`, GUNet.py:83-116; the nf2 pipeline's [bs, 32, 32, 3] context): three conv units of the model's
 own arg_scope, spatial mean (ops.SpatialMean), fully_connected(200) and fully_connected(n_mod), he_normal.
-Not built (raise NotImplementedError): ct_conv with --use_se; --fix or --use_se
-combined with each other or with --dropout / after_affine; after_affine together with --without_norm.
+Built as flag combinations of the same kernels (round 3, tests/test_gpu_gunet_combos.py): --fix with --use_context (the guide
+branch's ReLU together with the density gains: norm kernels <G, D, L>), after_affine with --without_norm.
+Not built (raise NotImplementedError): ct_conv with --use_se; --use_se with --dropout (the gate pools the dropped-out values);
+after_affine with --fix / --use_se (a ReLU / an in-op gate stands between the affine and the weights it would fold into).
 --without_norm (GUNet.py:251-252,314-315): every unit = conv + bias (* density gain + guide term) + ReLU, the norm stage
 of the fused kernels reduced to the per-channel shift (unetk_norm_desc.affine_only).
 """
@@ -202,9 +204,10 @@ class GUNet(base.BaseNet):
 
     def _net_arg_scope(self, *args, **kwargs):
         """GUNet.py:240-257: as UNet (decoder norm = _get_normalization defaults), pools with SAME."""
-        fix = bool(getattr(self.args, "fix", False)) and self.use_spatial_guide and not self._concat_guide
-        if (fix and self.use_context_guide) or (self.use_se and self.use_context_guide and self.dropout):
-            raise NotImplementedError("GUNet --fix with --use_context, and --use_se with --dropout, are not built")
+        if self.use_se and self.use_context_guide and self.dropout:
+            # the SE gate pools the DROPPED-OUT normalised output (GUNet.py:189-201): that mean does not follow from the conv's
+            # statistic partials, it needs a reduction pass of its own -- not built
+            raise NotImplementedError("GUNet --use_se with --dropout is not built")
         self._norm = ("none", {}) if getattr(self.args, "without_norm", False) else self._get_normalization()
         return self._norm
 
@@ -288,8 +291,6 @@ class GUNet(base.BaseNet):
         norm_with_center = kwargs.get("norm_with_center", False)
         norm_with_scale = kwargs.get("norm_with_scale", False)
         after_affine = bool(kwargs.get("after_affine", False))
-        if after_affine and getattr(self.args, "without_norm", False):
-            raise NotImplementedError("GUNet after_affine together with --without_norm is not built")
         images = self._inputs["images"]
         if not images.is_cuda:
             raise ops._abi.UnetkError("GUNet runs on the GPU only: move `images` to cuda (no CPU path)")

@@ -174,7 +174,7 @@ __device__ __forceinline__ float4 drop4(uint32_t seed, uint32_t idx, float keep,
 // z = relu((y*scale + shift) [* den] [+ guide . gw + gb])
 template <int G, bool D, bool L = false, typename T = float>
 __global__ __launch_bounds__(256) void norm_apply_relu_kernel(ApplyArgs a) {
-  static_assert(!(L && (D || G == 0)), "the leaky guide needs a guide and no density gains");
+  static_assert(!(L && G == 0), "the leaky guide needs a guide");
   const T* ay = static_cast<const T*>(a.y);
   T* az = static_cast<T*>(a.z);
   const int cq = threadIdx.x % a.cq_n, rl = threadIdx.x / a.cq_n;
@@ -275,10 +275,11 @@ struct BwdArgs {
 // pass 1.  With dt = du * den (dt = du without density), du = dz * (u > 0), xhat = (y - mean) rstd, t = y*scale + shift:
 //   partial[0] = sum dt, partial[1] = sum dt*xhat, partial[2+g] = sum du*guide_g,
 //   D only: partial[2+G] = sum du (guide bias gradient), partial[3+G] = sum du*t (density gradient, per sample)
-//   L only: partial[2+g] = sum du*lrelu'(s)*guide_g, partial[2+G] = sum du*lrelu'(s)  (s = guide . gw + gb)
+//   L: partial[2+g] = sum du*lrelu'(s)*guide_g, partial[2+G] = sum du*lrelu'(s)  (s = guide . gw + gb; with D as well the
+//   guide-bias row 2+G holds this sum instead of sum du, and 3+G the density gradient: GUNet --fix with --use_context)
 template <int G, bool D, bool L = false, typename T = float>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
-  constexpr int K = 2 + G + (D ? 2 : 0) + (L ? 1 : 0);
+  constexpr int K = 2 + G + (D ? 2 : (L ? 1 : 0));
   const T* ay = static_cast<const T*>(a.y);
   const T* adz = static_cast<const T*>(a.dz);
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [K][rpi][C]
@@ -373,10 +374,11 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
     s[1].f += dt * ((v.f - mu.f) * rs.f);                                     \
     _Pragma("unroll") for (int g = 0; g < G; ++g) s[2 + g].f += dg * gg[g];  \
     if (D) {                                                                  \
-      s[2 + G].f += du;                                                       \
+      s[2 + G].f += dg;                                                       \
       s[3 + G].f += du * m.f * fmaf(v.f, sc0.f, sh0.f);                       \
+    } else if (L) {                                                           \
+      s[2 + G].f += dg;                                                       \
     }                                                                         \
-    if (L) s[2 + G].f += dg;                                                  \
   }
       NBR(x) NBR(y) NBR(z) NBR(w)
 #undef NBR
@@ -572,7 +574,8 @@ int bwd_blocks(const NormGeom& g) {
     default: { constexpr int GG = 4; CALL; } break; \
   }
 #define GD_DISPATCH_T(TT, G_, D_, L_, KERN, ...)                                               \
-  if (L_) { GL_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, false, true, TT>), __VA_ARGS__)); }   \
+  if (L_ && D_) { GL_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, true, true, TT>), __VA_ARGS__)); } \
+  else if (L_) { GL_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, false, true, TT>), __VA_ARGS__)); }   \
   else if (D_) { G_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, true, false, TT>), __VA_ARGS__)); } \
   else { G_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, false, false, TT>), __VA_ARGS__)); }
 // S_: tensors in HBM are bf16 (UNETK_BF16S) instead of fp32
@@ -655,7 +658,7 @@ extern "C" int unetk_norm_apply_relu(const unetk_norm_desc* d, const void* y, co
   const int64_t cap = g.L > 1 ? (4096 + g.L - 1) / g.L : 4096;
   if (gx > cap) gx = cap;
   const bool leaky = d->guide_leaky != 0;
-  if (leaky && (d->guide_ch < 1 || den != nullptr)) return UNETK_E_UNSUPPORTED;
+  if (leaky && d->guide_ch < 1) return UNETK_E_UNSUPPORTED;
   GD_DISPATCH(bs, d->guide_ch, den != nullptr, leaky, norm_apply_relu_kernel, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, a);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
@@ -714,8 +717,8 @@ extern "C" int unetk_norm_relu_bwd_pre(const unetk_norm_desc* d, const void* y, 
   hipStream_t st = (hipStream_t)stream;
   const NormGeom g = geom(d, D);
   const bool leaky = d->guide_leaky != 0;
-  if (leaky && (G < 1 || D)) return UNETK_E_UNSUPPORTED;
-  const int K = 2 + G + (D ? 2 : 0) + (leaky ? 1 : 0);
+  if (leaky && G < 1) return UNETK_E_UNSUPPORTED;
+  const int K = 2 + G + (D ? 2 : (leaky ? 1 : 0));
   const int nblk = bwd_blocks(g);
   float* partial = (float*)ws;
   float* sums = partial + (size_t)K * g.L * nblk * d->C;
