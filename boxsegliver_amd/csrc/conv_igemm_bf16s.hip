@@ -52,14 +52,18 @@ constexpr int HALO_B = HALO_UNITS * 16;
 constexpr int HPW = 6;                          // halo requests per wave and chunk: five whole pieces + 20 lanes of the last two rows
 constexpr int HTAIL = (HALO_UNITS - 40 * 64) / 8;               // 20 units per wave
 static_assert(HALO_UNITS == 40 * 64 + 8 * HTAIL && HTAIL <= 64 && HPW == 6, "halo image = 5 pieces per wave + a partial sixth");
-constexpr int RING = 6;
+#ifndef UNETK_V3_RING
+#define UNETK_V3_RING 6
+#endif
+constexpr int RING = UNETK_V3_RING;          // filter-panel slots; the panel of step s + RING - 1 is requested at step s
+constexpr int FLIGHT = RING - 2;             // steps between a panel's request and the barrier that needs it landed
 constexpr int SLOT_B = 8192;
 constexpr int OFF_RING = 2 * HALO_B;
 constexpr int OFF_RED = OFF_RING + RING * SLOT_B;               // [2][8 waves][128] floats
 constexpr int LDS_B = OFF_RED + 2 * 8 * 128 * 4;
 static_assert(LDS_B <= 160 * 1024, "LDS budget");
 static_assert(OFF_RING % 256 == 0 && SLOT_B % 256 == 0, "B addresses: the rep XOR acts on bits 4..7 only");
-static_assert(RING == 6, "slot(tap, chunk parity) = (3 parity + tap) % 6 and the vmcnt table below assume six slots");
+static_assert(RING >= 4 && RING <= 9 && 2 * HALO_B + RING * SLOT_B + 8192 <= 160 * 1024, "ring depth vs LDS");
 
 __device__ const uint32_t kZeros[16] = {};      // source of out-of-image halo units
 
@@ -112,11 +116,12 @@ constexpr int HTAPS = 3, HPT = HPW / HTAPS;
 static_assert(HTAPS * HPT == HPW, "halo pieces per wave");
 constexpr int tap9(int t) { return ((t % 9) + 9) % 9; }
 constexpr int ops_at(int t) { return 1 + (tap9(t) < HTAPS ? HPT : 0); }
-// s_waitcnt vmcnt at the top of tap t: this wave's piece of the NEXT step's panel was requested RING - 2 = 4 steps ago as the
-// first load of that step; younger are that step's halo pieces and the three steps since.  At tap 8 the next chunk's halo
+// s_waitcnt vmcnt at the top of tap t: this wave's piece of the NEXT step's panel was requested FLIGHT = RING - 2 steps ago as the
+// first load of that step; younger are that step's halo pieces and the steps since.  At tap 8 the next chunk's halo
 // (last requested at tap HTAPS - 1) must have landed as well: the loads of the taps since are younger.
 constexpr int vm_need(int t) {
-  int n = ops_at(t - 4) - 1 + ops_at(t - 3) + ops_at(t - 2) + ops_at(t - 1);
+  int n = ops_at(t - FLIGHT) - 1;
+  for (int k = 1; k < FLIGHT; ++k) n += ops_at(t - k);
   if (t == 8) {
     int h = 0;
     for (int k = HTAPS; k < 8; ++k) h += ops_at(k);
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(ConvParams p) {
   static_for<HPW>([&](auto ic) { issue_halo(ic, 0); });
   static_for<RING - 1>([&](auto sc) {
     constexpr int S = decltype(sc)::value;
-    issue_panel(pan_cur, (uint32_t)S * tap_b, S);       // chunk 0, taps 0..4 (nchunks >= 1)
+    issue_panel(pan_cur, (uint32_t)S * tap_b, S);       // chunk 0, taps 0..RING-2 (< 9; nchunks >= 1)
   });
   zero_acc();
   wait_vm<0>();
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(ConvParams p) {
         if ((p.dbg & 64) && c == 0 && after_full) wait_vm<vm_need(T9) + NSTORE>();      // never wait for the stores in the first chunk
         else
 #endif
-        if (T9 < 4 && c == 0 && after_full) wait_vm<vm_need(T9) + NSTORE>();   // the stores of the last tile are younger
+        if (T9 < FLIGHT && c == 0 && after_full) wait_vm<vm_need(T9) + NSTORE>();   // the stores of the last tile are younger
         else wait_vm<vm_need(T9)>();
 #ifdef UNETK_V3_PROBE
         if (!(p.dbg & 16))
@@ -331,14 +336,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(ConvParams p) {
 #ifdef UNETK_V3_PROBE
           if (p.dbg & 4) return;
 #endif
-          // panel of step + 5 into the slot of step - 1 (free behind the barrier): tap (T9 + 5) % 9 of chunk
-          // c + (T9 + 5) / 9 -- of the next tile behind the last chunk
-          constexpr int PT = (T9 + 5) % 9, DC = (T9 + 5) / 9;
+          // panel of step + RING - 1 into the slot of step - 1 (free behind the barrier): tap (T9 + RING - 1) % 9 of chunk
+          // c + (T9 + RING - 1) / 9 -- of the next tile behind the last chunk
+          constexpr int PT = (T9 + RING - 1) % 9, DC = (T9 + RING - 1) / 9;
           const int pc = c + DC;
           const bool over = pc >= nchunks;
           const char* base = over ? pan_nxt : pan_cur;
           const uint32_t off = (uint32_t)PT * tap_b + (over ? 0u : (uint32_t)pc * chunk_b);
+#ifdef UNETK_V3_PROBE
+          if (!(p.dbg & 512))
+#endif
           issue_panel(base, off, fslot);
+#ifdef UNETK_V3_PROBE
+          if (!(p.dbg & 256))
+#endif
           if constexpr (T9 < HTAPS) {
             issue_halo(std::integral_constant<int, T9 * HPT>{}, hb_req);
             issue_halo(std::integral_constant<int, T9 * HPT + 1>{}, hb_req);
@@ -509,7 +520,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(ConvParams p) {
 // A build with -DUNETK_V3_PROBE (tools/probe_v3.sh; never the shipped library) adds switches that give WRONG RESULTS and
 // exist to time the parts of the loop: 4 = no staging requests in the main loop, 8 = every halo read hits tile 0 of image 0
 // (cache-resident), 16 = no barriers in the main loop, 32 = no tile epilogue, 64 = the waits of a tile's first chunk never
-// cover the previous tile's stores, 128 = no output stores.
+// cover the previous tile's stores, 128 = no output stores, 256 = no halo requests, 512 = no filter-panel requests.
 static int v3_flags() {
   static int f = -1;
   if (f < 0) {

@@ -76,8 +76,10 @@ def test_unet_config2_shape_bf16_storage_against_device_float64_oracle_of_the_sa
     the oracle that restates the same arithmetic and the same storage roundings, in float64 on the device.
     The two differ only where fp32-vs-fp64 accumulation moves a stored value across a bf16 rounding boundary (a whole
     bf16 ulp, 0.4-0.8 % of the value, on ~0.1 % of the elements per layer -- each kernel is pinned to half an ulp on
-    identical operands in tests/test_gpu_bf16s.py).  Measured: loss 8e-6, logits mean 5.8e-3 / max 4.6e-2 (range ~8),
-    masks equal wherever the top-2 margin exceeds the largest logit difference, whole-gradient L2 2.6e-2.
+    identical operands in tests/test_gpu_bf16s.py).  Measured (round 3 kernels): loss 1.2e-6, logits mean 5.8e-3 / max 4.3e-2
+    (range ~8), 99.67 % of the argmax masks equal -- all of them wherever the top-2 margin exceeds the largest logit
+    difference --, whole-gradient L2 2.55e-2.  The bars below sit at >= 2x these figures; that this one-step drift is noise and
+    not bias is what tests/test_gpu_bf16_e2e.py shows (training trajectories, signed mean errors).
     The fp32-grade bars (logits 1e-3, gradient 5e-3) are out of reach for ANY two implementations that store bf16 and
     accumulate in different orders; they hold for the fp32 mode (configs[1], test_gpu_unet.py)."""
     model, loss, total, logits, grads = _config2_pair("bf16", 2)
@@ -89,11 +91,11 @@ def test_unet_config2_shape_bf16_storage_against_device_float64_oracle_of_the_sa
     print("cfg2 bf16s: loss", abs(loss.item() - total.item()), "logits max", d.max().item(), "mean", d.mean().item(),
           "argmax agree", (got.argmax(-1) == logits.argmax(-1)).double().mean().item(), "gradL2", gl2)
     assert abs(loss.item() - total.item()) < 1e-4 * max(1.0, abs(total.item()))
-    assert d.mean().item() < 1e-2 and d.max().item() < 0.1
+    assert d.mean().item() < 1.2e-2 and d.max().item() < 0.1
     safe = margin > d.max().item() * 1.0001                       # masks equal wherever the margin exceeds the logit error
     assert bool((got.argmax(-1) == logits.argmax(-1))[safe].all()) and safe.double().mean().item() > 0.95
-    assert (got.argmax(-1) == logits.argmax(-1)).double().mean().item() > 0.995
-    assert gl2 < 5e-2
+    assert (got.argmax(-1) == logits.argmax(-1)).double().mean().item() > 0.993
+    assert gl2 < 5.5e-2
 
 
 def test_unet_config2_shape_bf16_compute_only_mode():
