@@ -111,23 +111,35 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
     const int64_t o = real ? ((int64_t)rel_h[i] * p.W + rel_w[i]) * (is_x ? p.xs : p.ys) + lchunk * 8 : 0;
     poff[i] = (uint32_t)(o * 2);        // wraps for the negative offsets of the halo's first row / column: added mod 2^32 to a
   }                                     // 32-bit origin offset below
-  auto issue_tile = [&](int tile, int stage) {
+  struct TileSrc {          // where a tile's pieces come from: wave-uniform, computed once per tile
+    int h0, w0;
+    int64_t ximg, yimg;
+    bool interior;
+    const char *xo, *yo;    // interior tiles: image bases + 32-bit origin offsets (fit 32 bits: checked on the host)
+    uint32_t xorg, yorg;
+  };
+  auto locate = [&](int tile) {
+    TileSrc ts;
     const int tw_i = tile % p.tiles_w;
     const int th_i = (tile / p.tiles_w) % p.tiles_h;
     const int n_tile = tile / (p.tiles_w * p.tiles_h);
-    const int h0 = th_i * TH, w0 = tw_i * TW;
-    const int64_t ximg = p.xa.off(n_tile), yimg = p.ya.off(n_tile);
-    const bool interior = h0 >= 1 && w0 >= 1 && h0 + TH + 1 <= p.H && w0 + TW + 1 <= p.W;
-    if (interior) {
-      // origin offsets inside the image fit 32 bits (checked on the host); the image bases are wave-uniform pointers
-      const char* xo = reinterpret_cast<const char*>(xb + ximg + ci0);
-      const char* yo = reinterpret_cast<const char*>(dyb + yimg + co0);
-      const uint32_t xorg = (uint32_t)((h0 * p.W + w0) * p.xs) * 2u, yorg = (uint32_t)((h0 * p.W + w0) * p.ys) * 2u;
+    ts.h0 = th_i * TH; ts.w0 = tw_i * TW;
+    ts.ximg = p.xa.off(n_tile); ts.yimg = p.ya.off(n_tile);
+    ts.interior = ts.h0 >= 1 && ts.w0 >= 1 && ts.h0 + TH + 1 <= p.H && ts.w0 + TW + 1 <= p.W;
+    ts.xo = reinterpret_cast<const char*>(xb + ts.ximg + ci0);
+    ts.yo = reinterpret_cast<const char*>(dyb + ts.yimg + co0);
+    ts.xorg = (uint32_t)((ts.h0 * p.W + ts.w0) * p.xs) * 2u;
+    ts.yorg = (uint32_t)((ts.h0 * p.W + ts.w0) * p.ys) * 2u;
+    return ts;
+  };
+  auto issue_pieces = [&](const TileSrc& ts, int stage, int mask) {
+    if (ts.interior) {
 #pragma unroll
       for (int i = 0; i < IPW; ++i) {
+        if (!(mask & (1 << i))) continue;
         const int j = wave + 8 * i;
         const bool is_x = j < NP_X;
-        const char* src = (is_x ? xo : yo) + (uint32_t)((is_x ? xorg : yorg) + poff[i]);
+        const char* src = (is_x ? ts.xo : ts.yo) + (uint32_t)((is_x ? ts.xorg : ts.yorg) + poff[i]);
         char* dst = smem + stage * STAGE_B + j * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -137,12 +149,12 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
       const int j = wave + 8 * i;
-      {
+      if (mask & (1 << i)) {
         const bool is_x = j < NP_X;
-        const int gh = h0 + rel_h[i], gw = w0 + rel_w[i];
+        const int gh = ts.h0 + rel_h[i], gw = ts.w0 + rel_w[i];
         const bool ok = gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
         const int64_t pixoff = (int64_t)gh * p.W + gw;
-        const bf16_t* src = is_x ? xb + ximg + pixoff * p.xs + ci0 + lchunk * 8 : dyb + yimg + pixoff * p.ys + co0 + lchunk * 8;
+        const bf16_t* src = is_x ? xb + ts.ximg + pixoff * p.xs + ci0 + lchunk * 8 : dyb + ts.yimg + pixoff * p.ys + co0 + lchunk * 8;
         if (!ok) src = reinterpret_cast<const bf16_t*>(kZeroPage) + (lane & 7) * 8;
         char* dst = smem + stage * STAGE_B + j * 1024;   // wave-uniform; lanes land at dst + lane * 16 B
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -150,6 +162,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
       }
     }
   };
+  auto issue_tile = [&](int tile, int stage) { issue_pieces(locate(tile), stage, (1 << IPW) - 1); };
 
   // ---- fragment addressing.  16-lane group g = lane >> 4: channel 16-block (g & 1) of the wave's 32, pixel half h = g >> 1.
   const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, g16 = (lane >> 4) & 1;
@@ -228,7 +241,13 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
 #endif
     __builtin_amdgcn_s_barrier();                      // ... everybody's have, and every wave is done reading the stage of tile - 1
 #ifdef UNETK_V3_PROBE
-    if (!(p.dbg & 4))
+    const bool spread = p.dbg & 2048;      // one piece behind each of the first five MFMA groups instead of five in a row
+    TileSrc ts_next;
+    if (spread) ts_next = locate(min(tile + NSTAGE - 1, t_end - 1));
+#define SPREAD_PIECE(i) if (spread) issue_pieces(ts_next, (stage + NSTAGE - 1) & (NSTAGE - 1), 1 << (i));
+    if (!(p.dbg & (4 | 2048)))
+#else
+#define SPREAD_PIECE(i)
 #endif
     if (wave < 4) issue_tile(min(tile + NSTAGE - 1, t_end - 1), (stage + NSTAGE - 1) & (NSTAGE - 1));
 
@@ -251,6 +270,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
     LGKM_WAIT5(5, P0, P1, P2, B00, B01);
     asm volatile("" : "+v"(B10), "+v"(B11));
     ROW_MFMA(0, P0, P1, P2, B00, B01);
+    SPREAD_PIECE(0)
     // hr = 1 (in Q): prefetch row 2 -> P is free once the MFMAs above have read it (program order), dy row 3
     {
       uint64_t R0, R1, R2;
@@ -259,6 +279,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
       LGKM_WAIT5(7, Q0, Q1, Q2, B10, B11);
       ROW_MFMA(0, Q0, Q1, Q2, B10, B11);
       ROW_MFMA(1, Q0, Q1, Q2, B00, B01);
+      SPREAD_PIECE(1)
       // hr = 2 (in R): prefetch row 3 into Q
       TR_READ(Q0, xa1, 3 * AROW);          TR_READ(Q1, xa1, 3 * AROW + 512);   TR_READ(Q2, xa1, 3 * AROW + 1024);
       LGKM_WAIT5(5, R0, R1, R2, B20, B21);
@@ -266,8 +287,9 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
       ROW_MFMA(1, R0, R1, R2, B10, B11);
       ROW_MFMA(2, R0, R1, R2, B00, B01);
     }
+    SPREAD_PIECE(2)
 #ifdef UNETK_V3_PROBE
-    if (!(p.dbg & 4))
+    if (!(p.dbg & (4 | 2048)))
 #endif
     if (wave >= 4) issue_tile(min(tile + NSTAGE - 1, t_end - 1), (stage + NSTAGE - 1) & (NSTAGE - 1));
     // hr = 3 (in Q): prefetch row 4 into P
@@ -276,6 +298,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
     ROW_MFMA(0, Q0, Q1, Q2, B30, B31);
     ROW_MFMA(1, Q0, Q1, Q2, B20, B21);
     ROW_MFMA(2, Q0, Q1, Q2, B10, B11);
+    SPREAD_PIECE(3)
     // dy rows 0, 1 are done: request them for the NEXT tile (its stage became visible at this tile's barrier)
     if constexpr (PF) {
       asm volatile("s_nop 0" : "+v"(B00), "+v"(B01), "+v"(B10), "+v"(B11));      // orders the requests behind the MFMAs above
@@ -288,6 +311,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
     else LGKM_WAIT3(3, P0, P1, P2);
     ROW_MFMA(1, P0, P1, P2, B30, B31);
     ROW_MFMA(2, P0, P1, P2, B20, B21);
+    SPREAD_PIECE(4)
     if constexpr (PF) {      // halo row 0 of the next tile
       asm volatile("s_nop 0" : "+v"(P0), "+v"(P1), "+v"(P2));
       TR_READ(P0, nxa0, 0 * AROW);           TR_READ(P1, nxa0, 0 * AROW + 512);  TR_READ(P2, nxa0, 0 * AROW + 1024);
@@ -298,6 +322,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
     // hr = 5 (in Q)
     ROW_MFMA(2, Q0, Q1, Q2, B30, B31);
   }
+#undef SPREAD_PIECE
 #undef TR_READ
 #undef LGKM_WAIT3
 #undef LGKM_WAIT5

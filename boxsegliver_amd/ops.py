@@ -12,6 +12,7 @@ Reference call sites replaced (relative to the reference repo root):
   HeadLoss      : logits 1x1 conv + loss + metrics                     UNet.py:97-155, loss_metrics.py:115-339
 """
 import ctypes
+import os
 
 import torch
 
@@ -235,6 +236,42 @@ def alias(t, offset_elems=0, size=None, stride=None):
     return out
 
 
+# ----------------------------------------------------------------------------- filter gradients on a second HIP stream
+class _Side(object):
+    """The filter gradient of a conv unit hangs off backward's critical chain (norm backward -> input gradient -> the
+    previous unit's norm backward ...): nothing downstream reads dW before the optimiser.  With UNETK_SIDE_WGRAD=1 it is
+    launched on a second HIP stream, ordered behind the main stream's dy, so the HBM-bound passes of the chain (norm
+    backward, pool backward) can share the chip with it.  The main stream waits for the side stream at the end of the
+    backward pass (autograd engine callback) and before a data-parallel bucket is all-reduced; dy and x are handed to the
+    caching allocator as in use on the side stream (record_stream); the side stream has its own scratch buffer."""
+    enabled = os.environ.get("UNETK_SIDE_WGRAD", "0") == "1"
+    stream = None
+    pending = False
+    ws = _Workspace()
+
+
+def side_join():
+    """Order the current stream behind everything queued on the side stream (no-op when nothing is pending)."""
+    if _Side.pending:
+        torch.cuda.current_stream().wait_stream(_Side.stream)
+        _Side.pending = False
+
+
+def _wgrad_on_side(x, dy, bf16, dilation, out):
+    if _Side.stream is None:
+        _Side.stream = torch.cuda.Stream(device=x.device)
+    side = _Side.stream
+    side.wait_stream(torch.cuda.current_stream())          # dy has been queued on the main stream
+    with torch.cuda.stream(side):
+        dw = conv3x3_wgrad(x, dy, bf16=bf16, dilation=dilation, out=out, ws_pool=_Side.ws)
+    dy.record_stream(side)
+    x.record_stream(side)
+    if not _Side.pending:
+        _Side.pending = True
+        torch.autograd.Variable._execution_engine.queue_callback(side_join)
+    return dw
+
+
 # ----------------------------------------------------------------------------- in-place parameter gradients
 class _GradSink(object):
     """Parameter gradients written by the backward kernels straight into the variable's slice of the flat gradient
@@ -455,7 +492,7 @@ def conv3x3_dgrad(dy, wp_dgrad, cin, x_stride=None, dx=None, bf16=False, dilatio
     return dx
 
 
-def conv3x3_wgrad(x, dy, bf16=False, dilation=1, out=None):
+def conv3x3_wgrad(x, dy, bf16=False, dilation=1, out=None, ws_pool=None):
     _require_cuda(x, dy)
     n, h, wd, cin = x.shape
     cout = dy.shape[3]
@@ -466,7 +503,7 @@ def conv3x3_wgrad(x, dy, bf16=False, dilation=1, out=None):
     nbytes = _abi.lib().unetk_conv3x3_wgrad_ws_bytes(ctypes.byref(d))
     if nbytes == 0:
         raise _abi.UnetkError("conv3x3_wgrad: unsupported shape Cin={} Cout={}".format(cin, cout))
-    ws = WORKSPACE.get(nbytes, x.device)
+    ws = (ws_pool or WORKSPACE).get(nbytes, x.device)
     dw = out if out is not None else torch.empty((3, 3, cin, cout), dtype=torch.float32, device=x.device)
     assert tuple(dw.shape) == (3, 3, cin, cout) and dw.is_contiguous()
     tag = "conv3x3_wgrad_kernel(+slab_reduce)" if cin % 64 == 0 else "conv3x3_wgrad_c3_kernel(+slab_reduce)"
@@ -1097,9 +1134,13 @@ class Conv3x3NormRelu(_Op):
             ctx.se_graph = None
         if ctx.desc.dropout_keep > 0 and den is not None and not ctx.needs_input_grad[11]:
             dden = None
-        dw = conv3x3_wgrad(x, dy, bf16=ctx.bf16, dilation=ctx.dilation, out=sw)
+        on_side = _Side.enabled and not debug and sw is not None and ctx.need_dx
+        if not on_side:
+            dw = conv3x3_wgrad(x, dy, bf16=ctx.bf16, dilation=ctx.dilation, out=sw)
         dx = conv3x3_dgrad(dy, ctx.wp_d, x.shape[3], bf16=ctx.bf16, dilation=ctx.dilation,
                            producer=ctx.producer if DEBUG_CAPTURE is None else None) if ctx.need_dx else None
+        if on_side:      # behind the input gradient in issue order: the chain's next kernel is queued first
+            dw = _wgrad_on_side(x, dy, ctx.bf16, ctx.dilation, sw)
         if DEBUG_CAPTURE is not None:
             DEBUG_CAPTURE.append(dict(x=x, y=y, dilation=ctx.dilation, z=ctx.z_dbg, gamma=ctx.gb_dbg[0], beta=ctx.gb_dbg[1], aff=aff, dz=dz, dy=dy, dw=dw,
                                       dx=dx, dgamma=dgamma, dbeta=dbeta, w=ctx.w_dbg, guide=guide, gw=gw, gb=gb,

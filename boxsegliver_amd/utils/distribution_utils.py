@@ -134,6 +134,7 @@ class GradBuckets(object):
     def _launch(self, b):
         grp, lo, hi, _ = self.buckets[b]
         self._fired[b] = True
+        ops.side_join()                       # filter gradients queued on the side stream (ops._Side) must be in the bucket
         self._works.append(dist.all_reduce(self.store.grad[grp][lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def arm(self):

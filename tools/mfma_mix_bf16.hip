@@ -11,6 +11,11 @@
 //   STG  0: nothing staged    1: global_load_dwordx4 -> nine-deep register ring -> ds_write_b128 (round-2 kernel: one filter-panel
 //        piece per step per thread + five halo pieces per nine steps)    2: direct-to-LDS loads (global_load_lds_dwordx4: one
 //        filter-panel piece + one halo piece per wave and step), counted vmcnt before the barrier
+//        what a direct-to-LDS request costs the loop (variants of 2):  3: never waited for   5: no loads, two ds_write_b128 per
+//        thread and step (the same bytes into LDS from registers)   6: both pieces from a cache-resident source   7: twice the
+//        requests
+//        8: register staging by hand: 4 + 5 (requests into a three-step register ring, ds_write_b128 behind the barrier)
+//        4: the same two requests as plain global_load_dwordx4 into registers (never read, never written to LDS; cache-resident source: compare with 6)
 //   NWV  waves per block: 8 (one block per CU) or 4 (two blocks per CU, each a 256 x 128 tile)
 // LDS image = the layout planned for the round-3 kernel: halo [34 rows][20-pixel pitch][64 B] with the 16-byte channel
 // units XOR-swizzled by the pixel column (conflict-free ds_read_b128 for every tap shift), filter-panel ring of six 8 KiB slots.
@@ -38,10 +43,17 @@ constexpr int lds_b(int nwv) { return 2 * halo_b(nwv) + ring_n(nwv) * SLOT_B + 1
 
 #define DS_READ128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 // wait until at most N LDS operations are outstanding; the "+v" operands tie the consuming MFMAs behind the wait
+// -DRDS=16 (default): the 16x16x32 variant re-reads the A fragments in the second half-step (16 ds_read_b128 per wave and step);
+// 12: it keeps them (what the shipped kernel does);  8: no A reads at all (B only) -- how the loop time follows the LDS read volume
+#ifndef RDS
+#define RDS 16
+#endif
 template <int N>
 __device__ __forceinline__ void wait_lgkm(u32x4* S, int n) {
-  static_assert(N == 6 || N == 8, "fragment set size");
-  if constexpr (N == 6)
+  static_assert(N == 6 || N == 8 || N == 4, "fragment set size");
+  if constexpr (N == 4)
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(S[0]), "+v"(S[1]), "+v"(S[2]), "+v"(S[3]), "+v"(S[4]), "+v"(S[5]), "+v"(S[6]), "+v"(S[7]));
+  else if constexpr (N == 6)
     asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(S[0]), "+v"(S[1]), "+v"(S[2]), "+v"(S[3]), "+v"(S[4]), "+v"(S[5]));
   else
     asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(S[0]), "+v"(S[1]), "+v"(S[2]), "+v"(S[3]), "+v"(S[4]), "+v"(S[5]), "+v"(S[6]), "+v"(S[7]));
@@ -118,6 +130,13 @@ __global__ __launch_bounds__(NWV * 64, 2) void mix(const uint4* __restrict__ src
   if (STG == 1)
     for (int t = 0; t < 9; ++t) wring[t] = *reinterpret_cast<const u32x4*>(&src[(gi + t * 512u) & 0xfffff]);
 
+  constexpr bool DMA = STG == 2 || STG == 3 || STG == 6 || STG == 7 || STG == 8 || STG == 9;
+  constexpr int REP = STG == 7 ? 2 : 1;
+  u32x4 jsum = {0, 0, 0, 0};
+  u32x4 j0 = {0, 0, 0, 0}, j1 = {0, 0, 0, 0};
+  u32x4 jr[6];
+  for (auto& v : jr) v = u32x4{0, 0, 0, 0};
+
   u32x4 X[RD], Y[RD];     // hand-pipelined fragment sets: A fragments first, then B
 
   // issue the reads of (tap T, k-half G) of panel slot `bslot` into set S.  32x32x16: TM + TN reads cover 16 channels;
@@ -130,7 +149,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void mix(const uint4* __restrict__ src
     if constexpr (M16) {
       // A: four pixel rows of this wave (all 32 channels each); B: couts tiles G*4 .. G*4+3.  Both halves read all A rows
       // again (4 + 4 reads per 16 MFMAs) -- or keep A: here the A fragments are re-read, the conservative count.
-      read_n<KH * ROWB, ROWB, 4>(S, a);
+      if constexpr (RDS == 16 || (RDS == 12 && G == 0)) read_n<KH * ROWB, ROWB, 4>(S, a);
       read_n<G * 4 * 256, 256, 4>(S + 4, b);
     } else {
       read_n<KH * ROWB, 2 * ROWB, TM>(S, a);
@@ -163,9 +182,10 @@ __global__ __launch_bounds__(NWV * 64, 2) void mix(const uint4* __restrict__ src
     static_for<9>([&](auto tc) {
       constexpr int T = decltype(tc)::value;
       // ---- top of the step: staged data of the NEXT step has landed (own pieces), then everybody's
-      if constexpr (STG == 2) {
+      if constexpr (DMA && STG != 3) {
         // own panel piece(s) of step + 1 (requested RING - 2 steps ago): younger = that step's halo piece + (RING - 3) whole steps
-        if constexpr (NWV == 8) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        if constexpr (NWV == 8 && REP == 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else if constexpr (NWV == 8) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       }
       if constexpr (BAR > 0) {
@@ -174,23 +194,59 @@ __global__ __launch_bounds__(NWV * 64, 2) void mix(const uint4* __restrict__ src
           __builtin_amdgcn_s_barrier();
         }
       }
-      if constexpr (STG == 2) {
+      if constexpr (DMA) {
         // filter-panel piece of step + RING - 1 (L2-resident: all blocks walk the same 1.2 MB) and a halo piece (streamed)
         const uint32_t pslot = (slot + RING - 1 >= RING ? slot - 1 : slot + RING - 1) * SLOT_B;
         constexpr int PPW = 8 / NWV;
+        const bool on = STG == 8 ? lane == 0 : (STG == 9 ? lane < 16 : true);
 #pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-          const uint4* g = src + (((step * 512u) & 0xffff) + (wave * PPW + j) * 64 + lane);
-          char* dst = smem + 2 * HALO_B + pslot + (wave * PPW + j) * 1024;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                           (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        for (int rep = 0; rep < REP; ++rep) {
+#pragma unroll
+          for (int j = 0; j < PPW; ++j) {
+            const uint4* g = src + (((step * 512u) & 0xffff) + (wave * PPW + j) * 64 + lane);
+            char* dst = smem + 2 * HALO_B + pslot + (wave * PPW + j) * 1024;
+            if (on)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                               (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+          }
+          {
+            const uint4* g = STG == 6 ? src + (((step * 512u + 4096u) & 0xffff) + wave * 64 + lane)
+                                      : src + ((gi * 16u + step * 65536u + (lane >> 2) * 16u + (lane & 3)) & 0xfffff);
+            char* dst = smem + (hoff ? 0 : HALO_B) + ((T * NWV + wave) % (HALO_B / 1024)) * 1024;
+            if (on)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                               (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+          }
         }
-        {
-          const uint4* g = src + ((gi * 16u + step * 65536u + (lane >> 2) * 16u + (lane & 3)) & 0xfffff);
-          char* dst = smem + (hoff ? 0 : HALO_B) + ((T * NWV + wave) % (HALO_B / 1024)) * 1024;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                           (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
+      }
+      if constexpr (STG == 4) {
+        // the two requests of this step (cache-resident, as STG 6) as plain global_load_dwordx4 into two registers quadruples that
+        // nothing reads inside the loop (no LDS write at all).  The compiler does not know the loads are asynchronous: the
+        // generated code was checked to keep j0 / j1 in the same physical registers for the whole loop (no other use of them).
+        const uint4* g0 = &src[((step * 512u) & 0xffff) + wave * 64 + lane];
+        const uint4* g1 = &src[((step * 512u + 4096u) & 0xffff) + wave * 64 + lane];
+        asm volatile("s_waitcnt vmcnt(7)\n\tglobal_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off"
+                     : "+v"(j0), "+v"(j1) : "v"(g0), "v"(g1) : "memory");
+      }
+      if constexpr (STG == 8) {
+        // register staging with hand-placed requests: the two pieces requested three steps ago (cache-resident source, as 6) go
+        // from registers to LDS by ds_write_b128 right behind the barrier (LDS operations complete in order: they are done
+        // before the reads this wave waits for later in the step, i.e. before the next barrier -- no extra wait), then their
+        // registers take this step's requests.  Generated code checked: ring registers are not touched between request and write.
+        constexpr int R = (T % 3) * 2;
+        const uint32_t pslot = (slot + RING - 1 >= RING ? slot - 1 : slot + RING - 1) * SLOT_B;
+        const uint32_t d0 = lds0 + 2 * HALO_B + pslot + tid * 16;
+        const uint32_t d1 = lds0 + (hoff ? 0 : HALO_B) + ((T * NWV + wave) % (HALO_B / 1024)) * 1024 + lane * 16;
+        const uint4* g0 = &src[((step * 512u) & 0xffff) + wave * 64 + lane];
+        const uint4* g1 = &src[((step * 512u + 4096u) & 0xffff) + wave * 64 + lane];
+        asm volatile("s_waitcnt vmcnt(4)\n\tds_write_b128 %2, %0\n\tds_write_b128 %3, %1\n\t"
+                     "global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off"
+                     : "+v"(jr[R]), "+v"(jr[R + 1]) : "v"(d0), "v"(d1), "v"(g0), "v"(g1) : "memory");
+      }
+      if constexpr (STG == 5) {     // the same bytes into LDS from registers: two ds_write_b128 per thread
+        const uint32_t pslot = (slot + RING - 1 >= RING ? slot - 1 : slot + RING - 1) * SLOT_B;
+        *reinterpret_cast<u32x4*>(smem + 2 * HALO_B + pslot + tid * 16) = ra;
+        *reinterpret_cast<u32x4*>(smem + (hoff ? 0 : HALO_B) + ((T * NWV + wave) % (HALO_B / 1024)) * 1024 + lane * 16) = rb;
       }
       if constexpr (STG == 1) {
         if (T == 0)
@@ -201,12 +257,12 @@ __global__ __launch_bounds__(NWV * 64, 2) void mix(const uint4* __restrict__ src
       const uint32_t nslot = (slot + 1 == RING ? 0 : slot + 1);
       if constexpr (HP == 2) {
         issue(tc, std::integral_constant<int, 1>{}, Y, hoff, bslot);
-        wait_lgkm<RD>(X, 0);
+        wait_lgkm<(M16 && RDS != 16) ? 4 : RD>(X, 0);         // the count = reads of the set issued just above
         mfmas(std::integral_constant<int, 0>{}, X);
         // next step's first k-half (its panel slot became visible at this step's barrier)
         issue(std::integral_constant<int, (T + 1) % 9>{}, std::integral_constant<int, 0>{}, X, T == 8 ? (hoff ? 0u : (uint32_t)HALO_B) : hoff,
               nslot * SLOT_B);
-        wait_lgkm<RD>(Y, 0);
+        wait_lgkm<(M16 && RDS == 8) ? 4 : RD>(Y, 0);
         mfmas(std::integral_constant<int, 1>{}, Y);
       } else if constexpr (HP == 1) {
         constexpr int KH = T / 3, KW = T % 3;
@@ -255,10 +311,16 @@ __global__ __launch_bounds__(NWV * 64, 2) void mix(const uint4* __restrict__ src
     });
     hoff = hoff ? 0u : (uint32_t)HALO_B;
   }
-  if (STG == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (STG == 4) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(j0), "+v"(j1) :: "memory"); jsum ^= j0 ^ j1; }
+  if (STG == 8) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(jr[0]), "+v"(jr[1]), "+v"(jr[2]), "+v"(jr[3]), "+v"(jr[4]), "+v"(jr[5]) :: "memory");
+    for (auto& v : jr) jsum ^= v;
+  }
   float sum = 0.f;
   for (auto& r : acc) for (auto& cc : r) for (int i = 0; i < 16; ++i) sum += cc[i];
   for (auto& r : acc4) for (auto& cc : r) for (int i = 0; i < 4; ++i) sum += cc[i];
+  sum += __uint_as_float(jsum.x & 0xff);
   if (HP == 2) sum += __uint_as_float(X[0].x & 0xff) + __uint_as_float(Y[0].x & 0xff);
   out[blockIdx.x * NT + tid] = sum;
 }
@@ -289,6 +351,7 @@ void run(const uint4* src, float* out, const char* what) {
 
 int main(int argc, char** argv) {
   const bool zeros = argc > 1 && argv[1][0] == 'z';
+  const bool dma_only = argc > 1 && argv[1][0] == 'd';      // only the staging-cost variants
   uint4* src; float* out;
   const size_t n = 1 << 20;                   // 16 MiB of bf16 bit patterns
   uint32_t* hs = (uint32_t*)malloc(n * 16);
@@ -300,7 +363,18 @@ int main(int argc, char** argv) {
   }
   hipMalloc(&src, n * 16 + 65536); hipMalloc(&out, 1 << 22);
   hipMemcpy(src, hs, n * 16, hipMemcpyHostToDevice);
-  printf("data: %s\n", zeros ? "zeros" : "random bf16");
+  printf("data: %s; 16x16x32 variants: %d ds_read_b128 per wave and step\n", zeros ? "zeros" : "random bf16", RDS);
+  if (dma_only) {
+    run<2, 2, 1, 0, 8>(src, out, "16x16x32 pipelined + barrier, nothing staged");
+    run<2, 2, 1, 2, 8>(src, out, "+ LDS-DMA: 2 requests (2 KiB) per wave and step");
+    run<2, 2, 1, 3, 8>(src, out, "  the same, never waited for");
+    run<2, 2, 1, 6, 8>(src, out, "  both pieces from a cache-resident source");
+    run<2, 2, 1, 7, 8>(src, out, "  twice the requests");
+    run<2, 2, 1, 4, 8>(src, out, "  as global_load_dwordx4 into registers (cached source), no LDS write");
+    run<2, 2, 1, 5, 8>(src, out, "  no loads: 2 ds_write_b128 per thread and step");
+    run<2, 2, 1, 8, 8>(src, out, "  register staging: loads + ds_write_b128 three steps later (cached source)");
+    return 0;
+  }
   run<0, 0, 0, 0, 8>(src, out, "32x32x16 4x2, operands in registers");
   run<0, 1, 0, 0, 8>(src, out, "+ LDS operand reads (compiler-scheduled)");
   run<0, 1, 1, 0, 8>(src, out, "+ barrier per step (16 MFMAs per wave)");

@@ -110,6 +110,16 @@ random bf16 operands; `_zeros.txt` = the same on zeros, `_pmc_busy.txt` = busy s
 {mix}
 ```
 
+`{R}_mfma_mix_bf16_staging.txt` (`/tmp/mfma_mix_bf16 d`, built with `-DRDS=16 | 12 | 8`: what 16 KiB staged per CU and step cost the
+loop by each path, at three LDS read volumes; 12 reads per wave and step is the shipped kernel's):
+
+```
+{stg}
+```
+
+`{R}_probe_wgrad_spread.json`: the filter gradient's five requests per wave and tile in a row (shipped) against one behind each
+MFMA group: {spread}.
+
 `{R}_probe_conv_loop_parts.json` -- the REAL round-3 forward / input-gradient kernel with parts of its loop switched off (ms per
 launch; columns 0 / 64 / 128 / 32 from a later call than 4 / 8 / 16 / 20 / 60):
 
@@ -140,6 +150,9 @@ launch; columns 0 / 64 / 128 / 32 from a later call than 4 / 8 / 16 / 20 / 60):
     ts=rf.get("traffic_source", "-"), cores=cb["cores"], cv=cb["value"], c8=cb["bs8"]["value"], c0=cb["cfg0"]["value"],
     hbmf=hbm_table(h), bv=hb["value"], bms=hb["ms_per_step"], btf=hb["whole_step_tflops"], bp=100 * hb["whole_step_frac_of_dtype_peak"],
     b256=h256["value"], bc=hc["value"], gbn=gbn["value"], gbe=gb["value"], bk=kern_table(hb), hbmb=hbm_table(hb),
+    stg=txt("mfma_mix_bf16_staging.txt"),
+    spread=", ".join("{} {:.4f} / {:.4f} ms".format(k.split(" [")[1].rstrip("]"), v["0"], v["2048"]) for k, v in list(json.load(open(
+        os.path.join(ROOT, "profiles", R + "_probe_wgrad_spread.json")))["layers"].items())[:4]),
     mfb="\n".join(txt("pmc_mfma_busy_bf16.txt").splitlines()[:13]), mix=txt("mfma_mix_bf16_random.txt"),
     pc=parts_table(conv, ("64x64 1024->512", "512x512 64->64]", "256x256 128->128]", "512x512 64->128")),
     pw=parts_table(wg, ("256x256 128->128", "512x512 64->64", "64x64 1024->512")),
