@@ -89,28 +89,30 @@ class UNet(base.BaseNet):
             self._norm = self._get_normalization()
         return self._norm
 
-    def _conv_unit(self, x, scope, out=None):
+    def _conv_unit(self, x, scope, out=None, pool=False):
+        """One slim.conv2d(x, C, 3) unit.  pool=True: the unit whose activation feeds slim.max_pool2d and the skip connection
+        (UNet.py:80-81,93) -- returns (pooled, activation) from ONE autograd node (ops.Conv3x3NormReluPool)."""
         p = self.params
         kind, nparams = self._norm
         if kind == "none":           # UNet.py:47-48: conv + bias + ReLU
             spec = ops.NormSpec("none", 0.0, 0.0, self.is_training, self.compute_bf16)
-            z = ops.Conv3x3NormRelu.apply(x, p[scope + "/weights"], None, p[scope + "/biases"], None, None, spec, out,
-                                          None, None, None)
+            var = (None, p[scope + "/biases"], None, None)
         elif kind == "batch_norm":
             bn = scope + "/BatchNorm"
             spec = ops.NormSpec("batch_norm", nparams["eps"], nparams["decay"], bool(nparams["is_training"]),
                                 self.compute_bf16)
-            z = ops.Conv3x3NormRelu.apply(x, p[scope + "/weights"], p[bn + "/gamma"], p[bn + "/beta"],
-                                          p[bn + "/moving_mean"], p[bn + "/moving_variance"], spec, out, None, None,
-                                          None)
+            var = (p[bn + "/gamma"], p[bn + "/beta"], p[bn + "/moving_mean"], p[bn + "/moving_variance"])
         else:                        # slim.instance_norm defaults: centre + scale, eps 1e-6
             inn = scope + "/InstanceNorm"
             spec = ops.NormSpec("instance_norm", nparams["eps"], 0.0, self.is_training, self.compute_bf16)
-            z = ops.Conv3x3NormRelu.apply(x, p[scope + "/weights"], p[inn + "/gamma"], p[inn + "/beta"], None, None,
-                                          spec, out, None, None, None)
+            var = (p[inn + "/gamma"], p[inn + "/beta"], None, None)
+        if pool:
+            pooled, z = ops.Conv3x3NormReluPool.apply(x, p[scope + "/weights"], var[0], var[1], var[2], var[3], spec, out)
+        else:
+            z = ops.Conv3x3NormRelu.apply(x, p[scope + "/weights"], var[0], var[1], var[2], var[3], spec, out, None, None, None)
         if self._taps is not None:
             self._taps[scope] = z
-        return z
+        return (pooled, z) if pool else z
 
     # ------------------------------------------------------------------ network
     def _build_network(self, *args, **kwargs):
@@ -144,10 +146,9 @@ class UNet(base.BaseNet):
                 tensor_out = self._conv_unit(tensor_out, s + "1")
                 cat = torch.empty((n, hh, ww, 2 * c), dtype=self.storage_dtype, device=dev)
                 skip_view = ops.alias(cat, 0, (n, hh, ww, c), cat.stride())
-                tensor_out = self._conv_unit(tensor_out, s + "2", out=skip_view)
-                self._layers["Encode{:d}".format(i + 1)] = tensor_out
+                tensor_out, skips[i] = self._conv_unit(tensor_out, s + "2", out=skip_view, pool=True)
+                self._layers["Encode{:d}".format(i + 1)] = skips[i]
                 cats[i] = cat
-                tensor_out, skips[i] = ops.MaxPoolSkip.apply(tensor_out)
                 c *= 2
                 hh //= 2
                 ww //= 2

@@ -250,6 +250,43 @@ __global__ __launch_bounds__(256) void norm_apply_relu_kernel(ApplyArgs a) {
   }
 }
 
+// z = relu(y * scale + shift) AND p = max_pool2d(z, 2, 2) in one pass (plain units whose activation feeds the pool:
+// ops.Conv3x3NormReluPool): a thread owns a window, writes its four z and their maximum -- the pool's read of z disappears.
+template <typename T>
+__global__ __launch_bounds__(256) void norm_apply_relu_pool_kernel(ApplyArgs a, void* pooled, int H, int W, int L) {
+  const T* ay = static_cast<const T*>(a.y);
+  T* az = static_cast<T*>(a.z);
+  T* ap = static_cast<T*>(pooled);
+  const int cq = threadIdx.x % a.cq_n, rl = threadIdx.x / a.cq_n;
+  if (rl >= a.rpi) return;
+  const int n = blockIdx.y;
+  const float4 sc = ldg4(a.scale + (int64_t)n * a.sst + cq * 4);
+  const float4 sh = ldg4(a.shift + (int64_t)n * a.sst + cq * 4);
+  const int Wo = W >> 1;
+  const int64_t per_img = (int64_t)(H >> 1) * Wo;
+  const int64_t Q = a.P >> 2;
+  for (int64_t q = (int64_t)blockIdx.x * a.rpi + rl; q < Q; q += (int64_t)gridDim.x * a.rpi) {
+    const int64_t img = L > 1 ? n : q / per_img;
+    const int64_t r = L > 1 ? q : q - img * per_img;
+    const int ho = (int)(r / Wo), wo = (int)(r - (int64_t)ho * Wo);
+    const int64_t pix = (img * H + 2 * ho) * W + 2 * wo;
+    const int64_t off[4] = {0, 1, W, (int64_t)W + 1};
+    float4 v[4], u[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = ld4(ay + (pix + off[i]) * a.C + cq * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u[i].x = fmaxf(fmaf(v[i].x, sc.x, sh.x), 0.f); u[i].y = fmaxf(fmaf(v[i].y, sc.y, sh.y), 0.f);
+      u[i].z = fmaxf(fmaf(v[i].z, sc.z, sh.z), 0.f); u[i].w = fmaxf(fmaf(v[i].w, sc.w, sh.w), 0.f);
+      st4(az + (pix + off[i]) * a.zs + cq * 4, u[i]);
+    }
+    float4 m;          // rounding to the storage type is monotonic: max of the stored values = stored max
+    m.x = fmaxf(fmaxf(u[0].x, u[1].x), fmaxf(u[2].x, u[3].x)); m.y = fmaxf(fmaxf(u[0].y, u[1].y), fmaxf(u[2].y, u[3].y));
+    m.z = fmaxf(fmaxf(u[0].z, u[1].z), fmaxf(u[2].z, u[3].z)); m.w = fmaxf(fmaxf(u[0].w, u[1].w), fmaxf(u[2].w, u[3].w));
+    st4(ap + (img * per_img + r) * a.C + cq * 4, m);
+  }
+}
+
 struct BwdArgs {
   const void* y;        // T = float or bf16_t (d->storage): y, dz and dy share it
   const void* dz;
@@ -583,6 +620,126 @@ int bwd_blocks(const NormGeom& g) {
   if (S_) { GD_DISPATCH_T(bf16_t, G_, D_, L_, KERN, __VA_ARGS__) } \
   else { GD_DISPATCH_T(float, G_, D_, L_, KERN, __VA_ARGS__) }
 
+// ---- plain unit whose activation feeds a 2 x 2 max-pool AND the skip connection (UNet.py:80-81,93: every encoder level's
+// second conv): the pool's backward is folded into both passes.  dz of pixel i of a window = dskip_i + (i is the window's
+// first maximum of z ? dp : 0) (TF MaxPoolGrad's rule, pool.hip), with z = relu(y * scale + shift) re-evaluated from y by the
+// forward's own expression and rounded as the forward stored it; the sum is rounded to the storage type as the separate
+// pool-backward pass stored it.  Saves that pass: 3.25 tensor transits of the 8.25 the three passes moved.
+struct PoolArgs {
+  const void* dp;       // [N][H/2][W/2][C], dense
+  int H, W;
+};
+template <typename T>
+__device__ __forceinline__ float round_as(float v);
+template <>
+__device__ __forceinline__ float round_as<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float round_as<bf16_t>(float v) { return unetk_round_bf16(v); }
+
+// window q of launch group n -> its four pixels' y, routed dz (d) and masked gradient du; f(pixel, y, du) per pixel
+template <typename T, class F>
+__device__ __forceinline__ void pool_window(const BwdArgs& a, const PoolArgs& pa, int n, int64_t q, int cq, const float4& sc,
+                                            const float4& sh, F&& f) {
+  const int Wo = pa.W >> 1;
+  const int64_t per_img = (int64_t)(pa.H >> 1) * Wo;
+  const int64_t img = a.L > 1 ? n : q / per_img;
+  const int64_t r = a.L > 1 ? q : q - img * per_img;
+  const int ho = (int)(r / Wo), wo = (int)(r - (int64_t)ho * Wo);
+  const int64_t pix = (img * pa.H + 2 * ho) * pa.W + 2 * wo;               // global pixel index of the window's corner
+  const int64_t off[4] = {0, 1, pa.W, (int64_t)pa.W + 1};
+  const T* ay = static_cast<const T*>(a.y);
+  const T* ask = static_cast<const T*>(a.dz);
+  float4 v[4], d[4], u[4], z[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i] = ld4(ay + (pix + off[i]) * a.C + cq * 4);
+    d[i] = ld4(ask + (pix + off[i]) * a.dzs + cq * 4);
+  }
+  const float4 g = ld4(static_cast<const T*>(pa.dp) + ((img * per_img + r) * a.C + cq * 4));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    u[i].x = fmaf(v[i].x, sc.x, sh.x); u[i].y = fmaf(v[i].y, sc.y, sh.y); u[i].z = fmaf(v[i].z, sc.z, sh.z); u[i].w = fmaf(v[i].w, sc.w, sh.w);
+    z[i].x = round_as<T>(fmaxf(u[i].x, 0.f)); z[i].y = round_as<T>(fmaxf(u[i].y, 0.f));
+    z[i].z = round_as<T>(fmaxf(u[i].z, 0.f)); z[i].w = round_as<T>(fmaxf(u[i].w, 0.f));
+  }
+#define PWIN(c)                                                                   \
+  {                                                                               \
+    const float m = fmaxf(fmaxf(z[0].c, z[1].c), fmaxf(z[2].c, z[3].c));          \
+    const bool e0 = z[0].c == m;                                                  \
+    const bool e1 = !e0 && z[1].c == m;                                           \
+    const bool e2 = !e0 && !e1 && z[2].c == m;                                    \
+    const bool e3 = !e0 && !e1 && !e2;                                            \
+    d[0].c = round_as<T>(d[0].c + (e0 ? g.c : 0.f));                              \
+    d[1].c = round_as<T>(d[1].c + (e1 ? g.c : 0.f));                              \
+    d[2].c = round_as<T>(d[2].c + (e2 ? g.c : 0.f));                              \
+    d[3].c = round_as<T>(d[3].c + (e3 ? g.c : 0.f));                              \
+  }
+  PWIN(x) PWIN(y) PWIN(z) PWIN(w)
+#undef PWIN
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float4 du;
+    du.x = u[i].x > 0.f ? d[i].x : 0.f; du.y = u[i].y > 0.f ? d[i].y : 0.f;
+    du.z = u[i].z > 0.f ? d[i].z : 0.f; du.w = u[i].w > 0.f ? d[i].w : 0.f;
+    f(pix + off[i], v[i], du);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_reduce_pool_kernel(BwdArgs a, PoolArgs pa) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][rpi][C]
+  const int cq = threadIdx.x % a.cq_n, rl = threadIdx.x / a.cq_n;
+  const int n = blockIdx.y;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  if (rl < a.rpi) {
+    const int64_t so = (int64_t)n * a.sst + cq * 4;
+    const float4 mu = ldg4(a.mean + so), rs = ldg4(a.rstd + so), sc = ldg4(a.scale + so), sh = ldg4(a.shift + so);
+    const int64_t Q = a.P >> 2;                                    // windows of this launch group
+    for (int64_t q = (int64_t)blockIdx.x * a.rpi + rl; q < Q; q += (int64_t)gridDim.x * a.rpi)
+      pool_window<T>(a, pa, n, q, cq, sc, sh, [&](int64_t, const float4& v, const float4& du) {
+        s0.x += du.x; s0.y += du.y; s0.z += du.z; s0.w += du.w;
+        s1.x += du.x * ((v.x - mu.x) * rs.x); s1.y += du.y * ((v.y - mu.y) * rs.y);
+        s1.z += du.z * ((v.z - mu.z) * rs.z); s1.w += du.w * ((v.w - mu.w) * rs.w);
+      });
+    stg4(&smem[(0 * a.rpi + rl) * a.C + cq * 4], s0);
+    stg4(&smem[(1 * a.rpi + rl) * a.C + cq * 4], s1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * a.C; i += 256) {
+    const int k = i / a.C, c = i - k * a.C;
+    float t = 0.f;
+    for (int j = 0; j < a.rpi; ++j) t += smem[(k * a.rpi + j) * a.C + c];
+    a.partial[(((int64_t)k * a.L + n) * gridDim.x + blockIdx.x) * a.C + c] = t;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_apply_pool_kernel(BwdArgs a, PoolArgs pa) {
+  const int cq = threadIdx.x % a.cq_n, rl = threadIdx.x / a.cq_n;
+  if (rl >= a.rpi) return;
+  T* ady = static_cast<T*>(a.dy);
+  const int n = blockIdx.y;
+  const int64_t so = (int64_t)n * a.sst + cq * 4;
+  const float4 mu = ldg4(a.mean + so), rs = ldg4(a.rstd + so), sc = ldg4(a.scale + so), sh = ldg4(a.shift + so);
+  float4 k1 = ldg4(a.ksum + (int64_t)n * a.kst + cq * 4), k2 = ldg4(a.ksum + a.krow + (int64_t)n * a.kst + cq * 4);
+  k1.x *= a.inv_ps; k1.y *= a.inv_ps; k1.z *= a.inv_ps; k1.w *= a.inv_ps;
+  k2.x *= a.inv_ps; k2.y *= a.inv_ps; k2.z *= a.inv_ps; k2.w *= a.inv_ps;
+  if (a.plain) {
+    k1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    k2 = k1;
+  }
+  const int64_t Q = a.P >> 2;
+  for (int64_t q = (int64_t)blockIdx.x * a.rpi + rl; q < Q; q += (int64_t)gridDim.x * a.rpi)
+    pool_window<T>(a, pa, n, q, cq, sc, sh, [&](int64_t pix, const float4& v, const float4& du) {
+      float4 o;
+      o.x = sc.x * (du.x - k1.x - ((v.x - mu.x) * rs.x) * k2.x);
+      o.y = sc.y * (du.y - k1.y - ((v.y - mu.y) * rs.y) * k2.y);
+      o.z = sc.z * (du.z - k1.z - ((v.z - mu.z) * rs.z) * k2.z);
+      o.w = sc.w * (du.w - k1.w - ((v.w - mu.w) * rs.w) * k2.w);
+      st4(ady + pix * a.C + cq * 4, o);
+    });
+}
+
 }  // namespace
 
 extern "C" size_t unetk_norm_finalize_ws_bytes(const unetk_norm_desc* d, int stat_rows) {
@@ -660,6 +817,34 @@ extern "C" int unetk_norm_apply_relu(const unetk_norm_desc* d, const void* y, co
   const bool leaky = d->guide_leaky != 0;
   if (leaky && d->guide_ch < 1) return UNETK_E_UNSUPPORTED;
   GD_DISPATCH(bs, d->guide_ch, den != nullptr, leaky, norm_apply_relu_kernel, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, a);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+// unetk_norm_apply_relu of a plain unit (no guide / density / dropout / post-shift) + unetk_maxpool2_fwd of its activation in one
+// pass: z as there (pixel stride d->z_stride), pooled [N, H/2, W/2, C] dense.  d->HW = H * W, W given here, both even.
+extern "C" int unetk_norm_apply_relu_pool(const unetk_norm_desc* d, int W, const void* y, const float* scale, const float* shift,
+                                          void* z, void* pooled, void* stream) {
+  UNETK_REQUIRE(norm_desc_ok(d) && y && scale && shift && z && pooled && d->z_stride >= d->C);
+  if (!norm_supported(d) || d->z_stride % 4 != 0) return UNETK_E_UNSUPPORTED;
+  if (d->guide_ch > 0 || d->guide_leaky || d->dropout_keep > 0.f) return UNETK_E_UNSUPPORTED;
+  if (W < 2 || (W & 1) || d->HW % W != 0 || ((d->HW / W) & 1)) return UNETK_E_UNSUPPORTED;
+  const bool bs = d->storage == UNETK_BF16S;
+  UNETK_REQUIRE(d->storage == UNETK_FP32 || bs);
+  UNETK_REQUIRE(bs ? (unetk_aligned8(y) && unetk_aligned8(z) && unetk_aligned8(pooled))
+                   : (unetk_aligned16(y) && unetk_aligned16(z) && unetk_aligned16(pooled)));
+  UNETK_REQUIRE(unetk_aligned16(scale) && unetk_aligned16(shift));
+  const NormGeom g = geom(d, false);
+  ApplyArgs a{};
+  a.y = y; a.scale = scale; a.shift = shift; a.z = z; a.P = g.P; a.C = d->C; a.zs = d->z_stride; a.cq_n = g.cq_n; a.rpi = g.rpi;
+  a.sst = g.sst;
+  int64_t gx = ((g.P >> 2) + g.rpi - 1) / g.rpi;
+  const int64_t cap = g.L > 1 ? (4096 + g.L - 1) / g.L : 4096;
+  if (gx > cap) gx = cap;
+  if (bs) hipLaunchKernelGGL(norm_apply_relu_pool_kernel<bf16_t>, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, a, pooled,
+                             d->HW / W, W, g.L);
+  else hipLaunchKernelGGL(norm_apply_relu_pool_kernel<float>, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, a, pooled,
+                          d->HW / W, W, g.L);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
@@ -785,6 +970,59 @@ extern "C" int unetk_norm_relu_bwd_pre(const unetk_norm_desc* d, const void* y, 
   const int64_t cap = g.L > 1 ? (4096 + g.L - 1) / g.L : 4096;
   if (gx > cap) gx = cap;
   GD_DISPATCH(bs, G, D, leaky, norm_bwd_apply_kernel, dim3((int)gx, g.L), dim3(256), 0, st, a);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+// The backward of a plain unit (no guide / density / dropout) whose output z feeds max_pool2d AND the skip connection:
+// dz is never materialised.  dskip = the skip's gradient (pixel stride dskip_stride: a channel slice of the concat
+// buffer's gradient), dp = the pooled tensor's gradient [N, H/2, W/2, C]; d->HW = H * W with W given here.
+extern "C" int unetk_norm_relu_bwd_pool(const unetk_norm_desc* d, int W, const void* y, const void* dskip, int dskip_stride,
+                                        const void* dp, const float* scale, const float* shift, const float* mean,
+                                        const float* rstd, void* dy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                        void* stream) {
+  UNETK_REQUIRE(norm_desc_ok(d) && y && dskip && dp && scale && shift && mean && rstd && dy && ws && dskip_stride >= d->C);
+  if (!norm_supported(d) || dskip_stride % 4 != 0) return UNETK_E_UNSUPPORTED;
+  if (d->guide_ch > 0 || d->guide_leaky || d->dropout_keep > 0.f) return UNETK_E_UNSUPPORTED;
+  if (W < 2 || (W & 1) || d->HW % W != 0 || ((d->HW / W) & 1)) return UNETK_E_UNSUPPORTED;
+  const bool bs = d->storage == UNETK_BF16S;
+  UNETK_REQUIRE(d->storage == UNETK_FP32 || bs);
+  UNETK_REQUIRE(bs ? (unetk_aligned8(y) && unetk_aligned8(dskip) && unetk_aligned8(dp) && unetk_aligned8(dy))
+                   : (unetk_aligned16(y) && unetk_aligned16(dskip) && unetk_aligned16(dp) && unetk_aligned16(dy)));
+  UNETK_REQUIRE(unetk_aligned16(ws));
+  if (ws_bytes < unetk_norm_bwd_ws_bytes(d)) return UNETK_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const NormGeom g = geom(d, false);
+  const int K = 2;
+  const int nblk = bwd_blocks(g);
+  float* partial = (float*)ws;
+  float* sums = partial + (size_t)K * g.L * nblk * d->C;
+  float* psum = sums + (size_t)K * g.L * d->C;
+  float* tmp1 = psum + (size_t)K * d->C;
+  float* tmp2 = tmp1 + unetk_rows_reduce_tmp_floats(K * g.L, UNETK_RR_DIRECT_ROWS + 1, d->C);
+  BwdArgs a{};
+  a.y = y; a.dz = dskip; a.scale = scale; a.shift = shift; a.mean = mean; a.rstd = rstd; a.partial = partial; a.dy = dy;
+  a.P = g.P; a.inv_ps = 1.0f / (float)g.Ps; a.C = d->C; a.dzs = dskip_stride; a.cq_n = g.cq_n; a.rpi = g.rpi;
+  a.L = g.L; a.plain = d->affine_only; a.sst = g.sst;
+  if (d->per_sample) { a.ksum = sums; a.kst = d->C; a.krow = g.L * d->C; }
+  else { a.ksum = sums; a.kst = 0; a.krow = d->C; }                 // batch statistics: one launch group
+  PoolArgs pa{dp, d->HW / W, W};
+  const size_t lds = (size_t)K * g.rpi * d->C * sizeof(float);
+  const bool last1 = g.L == 1;
+  if (bs) hipLaunchKernelGGL(norm_bwd_reduce_pool_kernel<bf16_t>, dim3(nblk, g.L), dim3(256), lds, st, a, pa);
+  else hipLaunchKernelGGL(norm_bwd_reduce_pool_kernel<float>, dim3(nblk, g.L), dim3(256), lds, st, a, pa);
+  UNETK_LAUNCH_CHECK();
+  int rc = unetk_rows_reduce_alias(partial, K * g.L, nblk, d->C, sums, tmp1, last1 ? dbeta : nullptr, last1 ? dgamma : nullptr, st);
+  if (rc != UNETK_OK) return rc;
+  if (!last1) {
+    rc = unetk_rows_reduce_alias(sums, K, g.L, d->C, psum, tmp2, dbeta, dgamma, st);
+    if (rc != UNETK_OK) return rc;
+  }
+  int64_t gx = ((g.P >> 2) + g.rpi - 1) / g.rpi;
+  const int64_t cap = g.L > 1 ? (4096 + g.L - 1) / g.L : 4096;
+  if (gx > cap) gx = cap;
+  if (bs) hipLaunchKernelGGL(norm_bwd_apply_pool_kernel<bf16_t>, dim3((int)gx, g.L), dim3(256), 0, st, a, pa);
+  else hipLaunchKernelGGL(norm_bwd_apply_pool_kernel<float>, dim3((int)gx, g.L), dim3(256), 0, st, a, pa);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }

@@ -659,6 +659,39 @@ def norm_relu_bwd(d, y, dz, aff, has_gamma, has_beta, guide=None, gw=None, gb=No
     return dy, dgamma, dbeta, dgw, dgb
 
 
+def norm_apply_relu_pool(d, y, aff, z):
+    """z = relu(y * scale + shift) and max_pool2d(z, 2, 2) in one pass (unetk_norm_apply_relu_pool); returns the pooled tensor."""
+    d.storage = _storage_of(y)
+    n, h, w, c = y.shape
+    pooled = torch.empty((n, h // 2, w // 2, c), dtype=y.dtype, device=y.device)
+    with _timed_hbm("norm_apply_relu_pool", y, 2.25):
+        check(_abi.lib().unetk_norm_apply_relu_pool(ctypes.byref(d), int(w), ptr(y), ptr(aff[2]), ptr(aff[3]), ptr(z), ptr(pooled),
+                                                    stream_ptr()), "norm_apply_relu_pool")
+    return pooled
+
+
+def norm_relu_bwd_pool(d, y, dskip, dp, aff, has_gamma, has_beta, out_gamma=None, out_beta=None):
+    """norm_relu_bwd of a plain unit whose activation feeds max_pool2d AND the skip connection, with the pool's backward
+    folded in (unetk_norm_relu_bwd_pool): dz = dskip + route(dp) is never written.  y [N, H, W, C]."""
+    dev = y.device
+    assert dskip.dtype == y.dtype and dp.dtype == y.dtype and dp.is_contiguous()
+    d.storage = _storage_of(y)
+    dy = torch.empty_like(y)
+    dgamma = (out_gamma if out_gamma is not None else torch.empty((d.C,), dtype=torch.float32, device=dev)) if has_gamma else None
+    dbeta = (out_beta if out_beta is not None else torch.empty((d.C,), dtype=torch.float32, device=dev)) if has_beta else None
+    nbytes = _abi.lib().unetk_norm_bwd_ws_bytes(ctypes.byref(d))
+    if nbytes == 0:
+        raise _abi.UnetkError("norm_relu_bwd_pool: unsupported channel count {}".format(d.C))
+    ws = WORKSPACE.get(nbytes, dev)
+    # both passes read (y, dskip) and a quarter-size dp; the apply pass writes dy
+    with _timed_hbm("norm_relu_bwd_pool(reduce+apply)", y, 5.5):
+        check(_abi.lib().unetk_norm_relu_bwd_pool(ctypes.byref(d), int(y.shape[2]), ptr(y), ptr(dskip), _pix_stride_nd(dskip),
+                                                  ptr(dp), ptr(aff[2]), ptr(aff[3]), ptr(aff[0]), ptr(aff[1]), ptr(dy),
+                                                  ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream_ptr()),
+              "norm_relu_bwd_pool")
+    return dy, dgamma, dbeta
+
+
 norm_relu_bwd_nd = norm_relu_bwd     # rank-agnostic (dz pixel stride = stride of the second-to-last axis)
 
 
@@ -1070,7 +1103,12 @@ class Conv3x3NormRelu(_Op):
                 gains = se(pooled, f_leaf)
             den = gains.detach().contiguous()
             se_graph = (g_leaf, b_leaf, pooled, gains, xhat_mean, f_leaf)
-        norm_apply_relu(d, y, aff, z, guide, gw, gb, den)
+        ctx.pooled = None
+        if getattr(ctx, "want_pool", False) and POOL_FUSED and se is None and den is None and g_ch == 0 and gb is None \
+                and d.dropout_keep == 0 and y.shape[1] % 2 == 0 and y.shape[2] % 2 == 0:
+            ctx.pooled = norm_apply_relu_pool(d, y, aff, z)        # Conv3x3NormReluPool: the pool rides on the apply pass
+        else:
+            norm_apply_relu(d, y, aff, z, guide, gw, gb, den)
         # a unit another conv unit may fuse its input gradient with (see conv3x3_dgrad): plain normalised units only
         simple = (not plain and se is None and den is None and g_ch == 0 and gb is None and d.dropout_keep == 0)
         if spec.training:
@@ -1097,19 +1135,31 @@ class Conv3x3NormRelu(_Op):
 
     @staticmethod
     def backward(ctx, dz):
+        return Conv3x3NormRelu._backward(ctx, dz)
+
+    @staticmethod
+    def _backward(ctx, dz, pool=None):
+        """`pool` = (dp, dskip): the unit's activation fed max_pool2d and the skip connection (Conv3x3NormReluPool) and its
+        gradient dz = dskip + route(dp) is formed inside the norm backward's two passes instead of being written first."""
         x, y, aff, guide, gw, gb, den = ctx.saved_tensors
-        pre = FUSED_NBR.pop(dz.data_ptr(), None) if DEBUG_CAPTURE is None else None
-        if pre is not None and not (ctx.simple and pre[0] == y.data_ptr() and pre[1] == tuple(dz.shape) and dz.is_contiguous()
-                                    and pre[4] == dz._version):
-            pre = None
-        if dz.stride(3) != 1:
-            dz = dz.contiguous()
-        if dz.dtype != y.dtype:
-            raise _abi.UnetkError("gradient dtype {} does not match the stored activations ({})".format(dz.dtype, y.dtype))
+        pre = None
+        if pool is None:
+            pre = FUSED_NBR.pop(dz.data_ptr(), None) if DEBUG_CAPTURE is None else None
+            if pre is not None and not (ctx.simple and pre[0] == y.data_ptr() and pre[1] == tuple(dz.shape) and dz.is_contiguous()
+                                        and pre[4] == dz._version):
+                pre = None
+            if dz.stride(3) != 1:
+                dz = dz.contiguous()
+            if dz.dtype != y.dtype:
+                raise _abi.UnetkError("gradient dtype {} does not match the stored activations ({})".format(dz.dtype, y.dtype))
         dden = dfeat = None
         debug = DEBUG_CAPTURE is not None            # the checkers read the returned tensors
         sw, sg, sb = (None, None, None) if debug else (_take(ctx.sinks[0]), _take(ctx.sinks[1]), _take(ctx.sinks[2]))
-        if den is None:
+        if pool is not None:
+            dy, dgamma, dbeta = norm_relu_bwd_pool(ctx.desc, y, pool[1], pool[0], aff, ctx.has[0], ctx.has[1],
+                                                   out_gamma=sg, out_beta=sb)
+            dgw = dgb = None
+        elif den is None:
             dy, dgamma, dbeta, dgw, dgb = norm_relu_bwd(ctx.desc, y, dz, aff, ctx.has[0], ctx.has[1], guide, gw, gb,
                                                         out_gamma=sg, out_beta=sb, pre=(pre[2], pre[3]) if pre else None)
         else:
@@ -1147,6 +1197,42 @@ class Conv3x3NormRelu(_Op):
                                       dgw=dgw, dgb=dgb, per_sample=bool(ctx.desc.per_sample), bf16=ctx.bf16, den=den,
                                       dden=dden, guide_leaky=bool(ctx.desc.guide_leaky), plain=bool(ctx.desc.affine_only)))
         return dx, _ret(dw, sw), _ret(dgamma, sg), _ret(dbeta, sb), None, None, None, None, None, dgw, dgb, dden, None, dfeat
+
+
+POOL_FUSED = os.environ.get("UNETK_POOL_FUSED", "1") != "0"     # 0: separate pool-backward pass (measurement)
+
+
+class Conv3x3NormReluPool(_Op):
+    """(p, z) = (max_pool2d(z, 2, 2), z) with z = Conv3x3NormRelu(x, ...): the second conv of an encoder level, whose
+    activation feeds the pool and -- through the concat buffer it was written into -- the skip connection
+    (NetworksV2/UNet.py:79-81,93).  One node for conv unit + pool so that the backward gets BOTH gradients of z, dp and
+    dskip, and never writes their sum: unetk_norm_relu_bwd_pool routes dp to each window's first maximum and adds dskip
+    inside the norm backward's reduction and apply passes (the MaxPoolSkip node's pass over z / dz disappears).  Plain
+    normalised units only (what UNet's encoder is); anything else takes the two separate passes."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, moving_mean, moving_var, spec, out):
+        ctx.want_pool = True
+        z = Conv3x3NormRelu.forward(ctx, x, w, gamma, beta, moving_mean, moving_var, spec, out, None, None, None)
+        p = ctx.pooled if ctx.pooled is not None else maxpool2_fwd(z)
+        ctx.pooled = None
+        if spec.training:
+            ctx.pool_zp = (z, p)       # both alive anyway: z is the skip inside the concat buffer, p the next unit's input
+        return p, z
+
+    @staticmethod
+    def backward(ctx, dp, dskip):
+        z, p = ctx.pool_zp
+        ctx.pool_zp = None
+        if dskip is not None and dskip.stride(3) != 1:
+            dskip = dskip.contiguous()
+        plain_unit = ctx.saved_tensors[3] is None and ctx.saved_tensors[5] is None and ctx.saved_tensors[6] is None \
+            and ctx.desc.dropout_keep == 0 and getattr(ctx, "se_graph", None) is None
+        if POOL_FUSED and DEBUG_CAPTURE is None and plain_unit and dp is not None and dskip is not None \
+                and dp.dtype == z.dtype and dskip.dtype == z.dtype:
+            return Conv3x3NormRelu._backward(ctx, None, pool=(dp.contiguous(), dskip))[:8]
+        dz = dskip if dp is None else maxpool2_bwd(z, p, dp, dskip)
+        return Conv3x3NormRelu._backward(ctx, dz)[:8]
 
 
 class FullyConnected(_Op):

@@ -256,6 +256,23 @@ int unetk_norm_relu_bwd_pre(const unetk_norm_desc* d, const void* y, const void*
                             float* dgamma, float* dbeta, float* dden, float* dgw, float* dgb,
                             const float* pre_partials, int pre_rows, void* ws, size_t ws_bytes, void* stream);
 
+/* unetk_norm_apply_relu of a plain unit (no guide / density / dropout) + unetk_maxpool2_fwd of its activation in ONE pass
+ * (NetworksV2/UNet.py:79-80: slim.conv2d ... slim.max_pool2d): z as unetk_norm_apply_relu writes it (pixel stride
+ * d->z_stride), pooled [N, H/2, W/2, C] dense.  d->HW = H * W, W given here, both even. */
+int unetk_norm_apply_relu_pool(const unetk_norm_desc* d, int W, const void* y, const float* scale, const float* shift,
+                               void* z, void* pooled, void* stream);
+
+/* unetk_norm_relu_bwd for a plain unit (no guide / density / dropout) whose activation z feeds max_pool2d(2, 2) AND the skip
+ * connection (NetworksV2/UNet.py:80-81,93: the second conv of every encoder level): replaces unetk_maxpool2_bwd (with its
+ * `add` operand) + unetk_norm_relu_bwd -- the gradient of z, dskip + route(dp), is formed on the fly in both passes from
+ * dskip (the skip's gradient: pixel stride dskip_stride, a channel slice of the concat buffer's gradient), dp (the pooled
+ * tensor's gradient, [N, H/2, W/2, C] dense) and z re-evaluated from y; first maximum in window scan order takes dp
+ * (TF MaxPoolGrad).  d->HW = H * W, W given here, both even.  Workspace: unetk_norm_bwd_ws_bytes(d). */
+int unetk_norm_relu_bwd_pool(const unetk_norm_desc* d, int W, const void* y, const void* dskip, int dskip_stride,
+                             const void* dp, const float* scale, const float* shift, const float* mean,
+                             const float* rstd, void* dy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                             void* stream);
+
 /* GUNet --use_se (GUNet.py:192-201): the SE gate's input is pooled[b][c] = mean over the sample's pixels of the normalised
  * conv output, so the loss reaches y once more through it.  The norm backward is linear in dt, and this part of dt is the
  * per-(sample, channel) constant g[b][c] / HW: after unetk_norm_relu_bwd,  dy += scale * (A[b][c] - xhat * k2[group][c])
