@@ -687,6 +687,113 @@ __global__ __launch_bounds__(256) void deconv_wgrad_bf16s_kernel(DwParams p) {
   }
 }
 
+// Round 3: the same contraction with every byte read ONCE per (co, ci) panel and four times the MFMAs per LDS read.  The kernel
+// above is HBM-bound at a quarter of the stream rate: a block owns ONE sub-pixel of a 64 x 64 panel, so x is fetched 4 x Cout/64
+// times and dpre Cin/64 times, and a wave issues 4 transposed reads per MFMA.  Here a 512-thread block owns all FOUR sub-pixels
+// of a 64 (co) x 128 (ci) panel: a 64-pixel tile = four dpre images [64 px][64 co] + two x images [64 px][64 ci] (48 KB of LDS,
+// same swizzle), wave (ab, ci half) holds 2 x 2 accumulators (8 transposed reads per 4 MFMAs), the next tile waits in
+// registers (6 x 16 B per thread).  Needs Cin % 128 == 0 and Cout % 64 == 0 (every transposed conv of UNet / GUNet).
+__global__ __launch_bounds__(512) void deconv_wgrad_bf16s4_kernel(DwParams p) {
+  constexpr int KT = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];   // [4 ab][KT][128 B] dpre, [2 halves][KT][128 B] x
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ab_w = wave >> 1, cih = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  int bid = blockIdx.x;
+  const int ci_t = bid % p.n_ci_tiles; bid /= p.n_ci_tiles;
+  const int co_t = bid % p.n_co_tiles; bid /= p.n_co_tiles;
+  const int split = bid;
+  const int co0 = co_t * 64, ci0 = ci_t * 128;
+  const bf16_t* xb = reinterpret_cast<const bf16_t*>(p.x);
+  const bf16_t* db = reinterpret_cast<const bf16_t*>(p.dpre);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int mb = split * p.m_per_split, me = min(mb + p.m_per_split, p.M);
+  // thread -> pixel row tid >> 3 of the tile, 16-byte chunk q = tid & 7 of each of the six images
+  const int row = tid >> 3, q = tid & 7;
+  const int HWp = p.H * p.W;
+  int nn, yy, xx;
+  {
+    const int m0 = mb + row;
+    nn = m0 / HWp;
+    const int rem = m0 - nn * HWp;
+    yy = rem / p.W; xx = rem - yy * p.W;
+  }
+  uint4 va[4], vb[2];
+  auto load_tile = [&](int mt) {      // (nn, yy, xx) = pixel mt + row; advanced by KT afterwards
+    const int m = mt + row;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) va[i] = make_uint4(0u, 0u, 0u, 0u);
+    vb[0] = vb[1] = make_uint4(0u, 0u, 0u, 0u);
+    if (m < me) {
+      const int64_t o = p.da.off(nn) + ((int64_t)(2 * yy) * 2 * p.W + 2 * xx) * p.Cout + co0 + q * 8;
+      va[0] = *reinterpret_cast<const uint4*>(db + o);
+      va[1] = *reinterpret_cast<const uint4*>(db + o + p.Cout);
+      va[2] = *reinterpret_cast<const uint4*>(db + o + (int64_t)2 * p.W * p.Cout);
+      va[3] = *reinterpret_cast<const uint4*>(db + o + (int64_t)2 * p.W * p.Cout + p.Cout);
+      const bf16_t* xr = xb + (int64_t)m * p.Cin + ci0 + q * 8;
+      vb[0] = *reinterpret_cast<const uint4*>(xr);
+      vb[1] = *reinterpret_cast<const uint4*>(xr + 64);
+    }
+    xx += KT;
+    while (xx >= p.W) {
+      xx -= p.W;
+      if (++yy == p.H) { yy = 0; ++nn; }
+    }
+  };
+  const int st_off = row * 128 + ((q ^ (((row >> 1) & 1) << 2)) << 4);
+  // fragment addressing (deconv_wgrad_bf16s_kernel): 32-channel block b of a 64-channel image
+  const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, g16 = (lane >> 4) & 1;
+  const int sw = (q4 >> 1) << 2;
+  int foff[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) foff[b] = (8 * h + q4) * 128 + (((2 * (b * 2 + g16) + (p4 >> 1)) ^ sw) << 4) + 8 * (p4 & 1);
+  const char* at = smem_c + ab_w * (KT * 128);
+  const char* bt = smem_c + (4 + cih) * (KT * 128);
+  if (mb < me) load_tile(mb);
+  for (int mt = mb; mt < me; mt += KT) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(smem_c + i * (KT * 128) + st_off) = va[i];
+    *reinterpret_cast<uint4*>(smem_c + 4 * (KT * 128) + st_off) = vb[0];
+    *reinterpret_cast<uint4*>(smem_c + 5 * (KT * 128) + st_off) = vb[1];
+    __syncthreads();
+    if (mt + KT < me) load_tile(mt + KT);
+#pragma unroll
+    for (int s = 0; s < KT / 16; ++s) {
+      bf16x8 af[2], bf[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const uint2 a0 = tr_read(at, s * 16 * 128 + foff[b]), a1 = tr_read(at, s * 16 * 128 + 4 * 128 + foff[b]);
+        const uint2 b0 = tr_read(bt, s * 16 * 128 + foff[b]), b1 = tr_read(bt, s * 16 * 128 + 4 * 128 + foff[b]);
+        af[b] = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+        bf[b] = __builtin_bit_cast(bf16x8, make_uint4(b0.x, b0.y, b1.x, b1.y));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  float* out = p.slab + ((int64_t)split * 4 + ab_w) * p.Cout * p.Cin;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + i * 32 + mfma32_row(r, h);
+        out[(int64_t)co * p.Cin + ci0 + cih * 64 + j * 32 + l31] = acc[i][j][r];
+      }
+}
+
 // wp_fwd[q][n=(bc,co)][j] = w[bc][co][4q+j]   (K = Cin)
 // wp_dgrad[q][n=ci][j]    = w_flat[(4q+j)][ci] with w_flat = [(bc,co)][ci]   (K = 4*Cout)
 __global__ void pack_deconv_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ wp_fwd,
@@ -852,12 +959,29 @@ bool deconv_desc_ok(const unetk_deconv3d_desc* d) {
 struct DwPlan {
   int S, m_per_split, nblk_bias;
 };
+inline bool dw_bf16s4(const unetk_deconv3d_desc* d) {
+  return d->precision == UNETK_BF16S && d->kd == 1 && d->Cin % 128 == 0 && d->Cout % 64 == 0;
+}
 DwPlan dw_plan(const unetk_deconv3d_desc* d) {
   DwPlan pl{};
   const int M = d->N * d->D * d->H * d->W;
   // fp32: one block takes all four sub-pixels of its (co, ci) panel (deconv_wgrad4_kernel) -- ~768 blocks of 40 KB LDS;
   // the bf16 kernels take one sub-pixel per block -- ~1024 blocks
   const bool four = d->precision == UNETK_FP32;
+  if (dw_bf16s4(d)) {     // deconv_wgrad_bf16s4_kernel: 64-pixel tiles, (Cout / 64) x (Cin / 128) panels, one block per CU and more
+    const int panels = (d->Cin / 128) * (d->Cout / 64);
+    int S = (256 + panels - 1) / panels;
+    const int mtiles = (M + 63) / 64;
+    if (S > mtiles) S = mtiles;
+    const int tiles_per = (mtiles + S - 1) / S;
+    pl.m_per_split = tiles_per * 64;
+    pl.S = (mtiles + tiles_per - 1) / tiles_per;
+    const ColMap m = unetk_colmap(d->Cout);
+    int64_t g = ((int64_t)4 * d->kd * M + m.rows_per_iter - 1) / m.rows_per_iter;
+    if (g > UNETK_COL_BLOCKS) g = UNETK_COL_BLOCKS;
+    pl.nblk_bias = (int)g;
+    return pl;
+  }
   const int panels = (four ? 1 : 4) * (d->Cin / 64) * ((d->Cout + 63) / 64);
   int S = ((four ? 768 : 1024) + panels - 1) / panels;
   const int mtiles = (M + 127) / 128;
@@ -1055,7 +1179,16 @@ extern "C" int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const void* xv, 
       if (e != hipSuccess) return (int)e;
       attr_done = true;
     }
-    if (bs)
+    if (dw_bf16s4(d)) {
+      static bool attr4 = false;
+      if (!attr4) {
+        hipError_t e = hipFuncSetAttribute((const void*)deconv_wgrad_bf16s4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 64 * 128);
+        if (e != hipSuccess) return (int)e;
+        attr4 = true;
+      }
+      q.n_ci_tiles = d->Cin / 128;
+      hipLaunchKernelGGL(deconv_wgrad_bf16s4_kernel, dim3(pl.S * q.n_co_tiles * q.n_ci_tiles), dim3(512), (size_t)6 * 64 * 128, st, q);
+    } else if (bs)
       hipLaunchKernelGGL(deconv_wgrad_bf16s_kernel, dim3(grid), dim3(256), (size_t)2 * 128 * 128, st, q);
     else if (q.bf16)
       hipLaunchKernelGGL(deconv_wgrad_kernel<true>, dim3(grid), dim3(256), (size_t)2 * 128 * 64 * sizeof(float), st, q);

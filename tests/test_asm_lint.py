@@ -29,7 +29,7 @@ def test_every_kernel_compiles_and_matrix_kernels_are_found(rows):
     assert len(rows) > 100
     for stem in ("conv3x3_igemm_kernel<", "conv3x3_igemm_bf16_kernel<", "conv3x3_wgrad_kernel<", "pw_gemm_kernel<",
                  "conv3x3_igemm_lin_kernel<", "deconv_wgrad_kernel<", "conv3x3_wgrad_c3_kernel", "conv3x3_wgrad_bf16s_kernel",
-                 "deconv_wgrad_bf16s_kernel", "deconv_wgrad4_kernel"):
+                 "deconv_wgrad_bf16s_kernel", "deconv_wgrad_bf16s4_kernel", "deconv_wgrad4_kernel", "conv3x3_bf16s_kernel<"):
         assert any(stem in n for n in names), stem
 
 

@@ -36,6 +36,7 @@ EXPECT = [
     ("conv3x3_wgrad_bf16s_kernel", "v_mfma_f32_32x32x16_bf16"),
     ("conv3x3_bf16s_kernel", "v_mfma_f32_16x16x32_bf16"),
     ("deconv_wgrad_bf16s_kernel", "v_mfma_f32_32x32x16_bf16"),
+    ("deconv_wgrad_bf16s4_kernel", "v_mfma_f32_32x32x16_bf16"),
     ("deconv_wgrad4_kernel", "v_mfma_f32_32x32x2_f32"),
 ]
 
