@@ -223,6 +223,8 @@ def _igemm_tag(cin, cout, bf16=False, h=0, n=1 << 20, w=1 << 10, nbr=False):
         return "conv3x3_igemm_kernel<4,1,2,2>" if big(64) else "conv3x3_igemm_kernel<4,1,1,2>"
     if cin % 16 == 0 and cout % 32 == 0:
         return "conv3x3_igemm_kernel<4,1,2,1>"
+    if cout == 64 and 1 <= cin <= 5:            # first layers on the matrix pipe (conv_igemm.hip)
+        return "conv3x3_c3_mfma_kernel"
     return "conv3x3_direct_kernel"
 
 
@@ -452,7 +454,7 @@ def conv3x3_fwd(x, w, cout, want_stats=True, y=None, bf16=False, dilation=1):
     ws = WORKSPACE.get(nws, x.device) if nws else None
     # the first layer's direct kernel is HBM-bound (writes 64 channels per pixel from 3): reported by bytes as well
     with _timed(lambda: _igemm_tag(cin, cout, bf16, h, n, wd), 18.0 * n * h * wd * cin * cout, "fwd {}x{}x{} {}->{}", (n, h, wd, cin, cout),
-                lambda tag: (x.numel() * x.element_size() + y.numel() * y.element_size()) if tag == "conv3x3_direct_kernel" else 0):
+                lambda tag: (x.numel() * x.element_size() + y.numel() * y.element_size()) if tag in ("conv3x3_direct_kernel", "conv3x3_c3_mfma_kernel") else 0):
         check(_abi.lib().unetk_conv3x3_fwd_ws(ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(stats), ptr(ws), nws,
                                               stream_ptr()), "conv3x3_fwd")
     return y, stats, rows

@@ -32,6 +32,7 @@ EXPECT = [
     ("conv3x3_igemm_lin_kernel", "v_mfma_f32_32x32x2_f32"),
     ("pw_gemm_kernel", "v_mfma_f32_32x32x2_f32"),
     ("conv3x3_wgrad_c3_kernel", "v_mfma_f32_32x32x2_f32"),
+    ("conv3x3_c3_mfma_kernel", "v_mfma_f32_32x32x2_f32"),
     ("conv3x3_wgrad_c3_bf16s_kernel", "v_mfma_f32_32x32x2_f32"),     # fp32 image x bf16 dy: exact fp32 contraction
     ("conv3x3_wgrad_bf16s_kernel", "v_mfma_f32_32x32x16_bf16"),
     ("conv3x3_bf16s_kernel", "v_mfma_f32_16x16x32_bf16"),
