@@ -290,8 +290,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_kernel(WgParams p) {
   // COT = 64: waves = (pixel-row half) x (co half); COT = 32 (UNet3D conv_e0/conv1, 30 channels padded): four row quarters
   constexpr int NCO = COT / 32, KS = 4 / NCO, RPW = TH / KS, PP = 256 / COT, NPIECE = TH * TW / PP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* dyt = smem;                       // [128 pixels][COT]   (NPIECE pieces of 1 KiB)
-  float* xh = smem + TH * TW * COT;        // [180 pixels][4]
+  // two buffers of { dy tile [128 pixels][COT] (NPIECE pieces of 1 KiB), x halo [180 pixels][4] }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -311,13 +310,19 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_kernel(WgParams p) {
 
   const int t_begin = split * p.tiles_per_split;
   const int t_end = min(t_begin + p.tiles_per_split, p.total_tiles);
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  // Two tile buffers (round 3): the next tile's dy streams into the other buffer (direct-to-LDS) and its halo values wait in
+  // registers while this tile is contracted -- the loop used to be load -> wait -> barrier -> MFMAs with nothing in flight
+  // during the MFMAs.
+  constexpr int BUF_F = TH * TW * COT + HALO_PIX * 4;          // floats per buffer: dy tile + x halo
+  constexpr int NXH = (HALO_PIX * 4 + 255) / 256;
+  float xr[NXH];
+  auto issue = [&](int tile, int buf) {
     const int tw_i = tile % p.tiles_w;
     const int th_i = (tile / p.tiles_w) % p.tiles_h;
     const int n_img = tile / (p.tiles_w * p.tiles_h);
     const int h0 = th_i * TH, w0 = tw_i * TW;
     const int64_t ximg = p.xa.off(n_img), yimg = p.ya.off(n_img);
-    __syncthreads();   // previous tile's fragment reads are done
+    float* dst = smem + buf * BUF_F;
 #pragma unroll
     for (int i = 0; i < NPIECE / 4; ++i) {          // dy: piece j = wave + 4 i covers pixels PP j .. PP j + PP - 1
       const int j = wave + 4 * i;
@@ -326,17 +331,31 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_kernel(WgParams p) {
       const float* src = (gh < p.H && gw < p.W) ? p.dy + yimg + ((int64_t)gh * p.W + gw) * p.ys + q * 4
                                                 : kZeroPage + (q & 15) * 4;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(dyt + j * 256), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(dst + j * 256), 16, 0, 0);
     }
-    for (int idx = tid; idx < HALO_PIX * 4; idx += 256) {
+#pragma unroll
+    for (int i = 0; i < NXH; ++i) {
+      const int idx = tid + i * 256;
       const int pix = idx >> 2, c = idx & 3;
       const int gh = h0 - 1 + pix / HWD, gw = w0 - 1 + pix % HWD;
-      float v = 0.f;
-      if (c < cin && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W) v = p.x[ximg + ((int64_t)gh * p.W + gw) * p.xs + c];
-      xh[idx] = v;
+      xr[i] = 0.f;
+      if (idx < HALO_PIX * 4 && c < cin && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W)
+        xr[i] = p.x[ximg + ((int64_t)gh * p.W + gw) * p.xs + c];
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  };
+  if (t_begin < t_end) issue(t_begin, 0);
+  int buf = 0;
+  for (int tile = t_begin; tile < t_end; ++tile, buf ^= 1) {
+    const float* dyt = smem + buf * BUF_F;
+    float* xh = smem + buf * BUF_F + TH * TW * COT;
+#pragma unroll
+    for (int i = 0; i < NXH; ++i) {                  // (the compiler waits for the halo loads here)
+      const int idx = tid + i * 256;
+      if (idx < HALO_PIX * 4) xh[idx] = xr[i];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's dy has landed (nothing younger is in flight)
+    __syncthreads();                                   // ... everybody's; and the other buffer's readers are done
+    if (tile + 1 < t_end) issue(tile + 1, buf ^ 1);
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       const int r = kq * RPW + rr;
@@ -662,7 +681,14 @@ int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_
     else rc = launch_wgrad<32, 32, false>(p, grid, st);
     if (rc != UNETK_OK) return rc;
   } else if (9 * p.Cin <= 32 && (p.Cout == 64 || p.Cout == 32) && p.ys % 4 == 0) {
-    const size_t lds3 = (size_t)(TH * TW * p.Cout + HALO_PIX * 4) * sizeof(float);
+    const size_t lds3 = (size_t)2 * (TH * TW * p.Cout + HALO_PIX * 4) * sizeof(float);      // two tile buffers: 71 KB at Cout = 64
+    static bool attr3 = false;
+    if (!attr3) {
+      hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_c3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         2 * (TH * TW * 64 + HALO_PIX * 4) * (int)sizeof(float));
+      if (e != hipSuccess) return (int)e;
+      attr3 = true;
+    }
     if (p.Cout == 64) hipLaunchKernelGGL(conv3x3_wgrad_c3_kernel<64>, dim3(pl.S), dim3(256), lds3, st, p);
     else hipLaunchKernelGGL(conv3x3_wgrad_c3_kernel<32>, dim3(pl.S), dim3(256), lds3, st, p);
     UNETK_LAUNCH_CHECK();

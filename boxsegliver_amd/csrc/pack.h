@@ -42,6 +42,25 @@ __device__ __host__ __forceinline__ int conv_bf16s_pos(int c, int Nout) {
   return m * 16 + ((c >> 2) ^ ((m >> 1) << 1));
 }
 
+// Input-gradient packs transpose the filter: item i = (t, q, n) takes a few consecutive floats of filter ROW n, and with i
+// running along n the 64 lanes of a wave touch 64 different rows -- 16 or 32 bytes of each 128-byte line, the rest of the line
+// being fetched again by other blocks on other XCDs (measured: the pack of a step read 8x its bytes, 0.2 ms).  The items
+// are therefore dealt to the threads in tiles of QL consecutive q x 64 / QL consecutive n: QL lanes share a row's line.  A
+// bijection of [0, T x Q x Cin) when Q % QL == 0 and Cin % (64 / QL) == 0, else the identity.
+__device__ __forceinline__ int64_t dgrad_item(int64_t i, int Cin, int Q, int QL) {
+  const int NL = 64 / QL;
+  if (Q % QL != 0 || Cin % NL != 0) return i;
+  const int l = (int)(i & 63);
+  const int64_t blk = i >> 6;
+  const int q_l = l % QL, n_l = l / QL;
+  const int nt_n = Cin / NL;
+  const int nt = (int)(blk % nt_n);
+  const int64_t rest = blk / nt_n;
+  const int qt = (int)(rest % (Q / QL));
+  const int64_t t = rest / (Q / QL);
+  return (t * Q + qt * QL + q_l) * Cin + nt * NL + n_l;
+}
+
 // conv3x3 fp32, K4-interleaved: wp[t][q][n][j] = B_t[k = 4q + j][n]; forward B_t[ci][co] = w[t][ci][co],
 // dgrad B_t[co][ci] = w[8 - t][ci][co].  Items: 9 * Cin * Cout / 4.
 __device__ __forceinline__ void conv3x3_f32(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ wp_fwd,
@@ -55,6 +74,7 @@ __device__ __forceinline__ void conv3x3_f32(const float* __restrict__ w, int Cin
     stg4(wp_fwd + i * 4, make_float4(s[0], s[Cout], s[2 * (int64_t)Cout], s[3 * (int64_t)Cout]));
   }
   if (wp_dgrad != nullptr) {
+    i = dgrad_item(i, Cin, Cout / 4, 8);
     const int n = (int)(i % Cin);
     const int64_t r = i / Cin;
     const int q = (int)(r % (Cout / 4));
@@ -83,6 +103,7 @@ __device__ __forceinline__ void conv3x3_bf16(const float* __restrict__ w, int Ci
     wp_fwd[i] = v;
   }
   if (wp_dgrad != nullptr) {
+    i = dgrad_item(i, Cin, Cout / 8, 4);
     int n = (int)(i % Cin);
     if (perm) n = conv_bf16s_chan(n, Cin);
     const int64_t r = i / Cin;
