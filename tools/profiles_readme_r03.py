@@ -70,9 +70,10 @@ Written by `tools/profiles_readme_r03.py` from the files next to it.  `{R}_bench
 `gpurun` call of `tools/refresh_profiles.sh` (one device; the script holds the command lines); `{R}_mfma_mix_bf16_*` from
 `tools/probe_bf16.sh`; `{R}_probe_*_loop_parts.json` from `tools/probe_v3.sh` (a `-DUNETK_V3_PROBE` build, timing only);
 `{R}_pmc_sq_bf16.json` from two `rocprofv3 --pmc` passes of eight SQ counters each.  Boxes of the pool differ by 3-6 % on the
-same binary (matrix-heavy kernels most): other calls of this round read 13.8-14.6 ms for the bf16 step below.
+same binary (matrix-heavy kernels most): other calls of this round read 13.0-14.1 ms for the bf16 step below and
+75.2-77.4 ms for the fp32 headline.
 
-## Headline (BASELINE.json configs[1]) -- unchanged kernels, re-measured
+## Headline (BASELINE.json configs[1]) -- matrix kernels unchanged; pool passes folded into the norm passes, first layer on the matrix pipe
 
 `{R}_bench_n1.json` -- `python bench.py --steps 10 --warmup 3`: **{hv} slices/s, {hms} ms/step = {htf} TFLOP/s = {hp:.1f} % of the
 fp32 peak** (round 2: 416.70 / 76.795 ms; round 1: 402.0).  Dominant kernel `{rk}`: {ra} TFLOP/s = {rfp:.1f} % of 157.3,
