@@ -99,6 +99,11 @@ __global__ void weight_table_kernel(unetk_head_desc d, const int* __restrict__ h
   for (int k = 0; k < d.ncls; ++k) wn[b * d.ncls + k] = cw[k] / wsum * (float)d.HW;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
 template <int NCLS>
 __device__ __forceinline__ void pixel_logits(const float4 zv, const float (&wr)[4][NCLS], const float (&bias)[NCLS],
                                              int lpp, float (&lg)[NCLS]) {
@@ -108,7 +113,18 @@ __device__ __forceinline__ void pixel_logits(const float4 zv, const float (&wr)[
     s = fmaf(zv.y, wr[1][k], s);
     s = fmaf(zv.z, wr[2][k], s);
     s = fmaf(zv.w, wr[3][k], s);
-    for (int o = lpp >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lpp == 16) {
+      // C = 64 (every 2-D net): the 16 lanes of a pixel are one DPP row -- quad swaps, then the half-row and row mirrors, sum
+      // it on the vector pipe.  The generic loop below compiles to ds_bpermute (an LDS crossbar instruction with a computed
+      // address and its own wait) four times per class and pixel: that, not the softmax tail, was what held this kernel at
+      // 0.2 ms whatever the storage type.
+      s += dpp_f<0xB1>(s);       // quad_perm [1, 0, 3, 2]
+      s += dpp_f<0x4E>(s);       // quad_perm [2, 3, 0, 1]
+      s += dpp_f<0x141>(s);      // row_half_mirror
+      s += dpp_f<0x140>(s);      // row_mirror
+    } else {
+      for (int o = lpp >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    }
     lg[k] = s + bias[k];
   }
 }
