@@ -319,6 +319,8 @@ def main():
         if bk is not None:
             bk.remove()
             solver._buckets = None
+        # the same per-launch events as the timed region had on this rank: the difference must be the all-reduce path alone
+        ops.PROFILE = [] if prof is not None else None
         one_step()
         torch.cuda.synchronize()
         tc = time.perf_counter()
@@ -326,6 +328,7 @@ def main():
             one_step()
         torch.cuda.synchronize()
         dp_diag["compute_only_ms_per_step"] = round((time.perf_counter() - tc) / 3 * 1e3, 3)
+        ops.PROFILE = None
         dp_diag["backend"] = backend
         dist.barrier()
 

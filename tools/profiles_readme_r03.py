@@ -84,6 +84,10 @@ steps OUTSIDE the timed region) and, for N > 1 or `--dp-rehearsal`, `data_parall
 
 {hbmf}
 
+`{R}_bench_n1_dp_rehearsal.json` / `{R}_bench_bf16_512_bs8_dp_rehearsal.json` -- the same commands with `--dp-rehearsal`: the
+data-parallel path (gradient buckets, RCCL all-reduce from inside backward, stream joins) in a world of ONE rank, what the
+driver's N > 1 runs add on top of the step: {dpf} (fp32) and {dpb} (bf16).
+
 ## bf16 storage mode (BASELINE.json configs[2] shape: 512x512 bs 8 per GPU)
 
 `{R}_bench_bf16_512_bs8.json`: **{bv} slices/s, {bms} ms/step = {btf} TFLOP/s = {bp:.1f} % of the dense bf16 peak** (round 2: 551.16 /
@@ -151,6 +155,7 @@ launch; columns 0 / 64 / 128 / 32 from a later call than 4 / 8 / 16 / 20 / 60):
     ts=rf.get("traffic_source", "-"), cores=cb["cores"], cv=cb["value"], c8=cb["bs8"]["value"], c0=cb["cfg0"]["value"],
     hbmf=hbm_table(h), bv=hb["value"], bms=hb["ms_per_step"], btf=hb["whole_step_tflops"], bp=100 * hb["whole_step_frac_of_dtype_peak"],
     b256=h256["value"], bc=hc["value"], gbn=gbn["value"], gbe=gb["value"], bk=kern_table(hb), hbmb=hbm_table(hb),
+    dpf=json.dumps(J("bench_n1_dp_rehearsal")["data_parallel"]), dpb=json.dumps(J("bench_bf16_512_bs8_dp_rehearsal")["data_parallel"]),
     stg=txt("mfma_mix_bf16_staging.txt"),
     spread=", ".join("{} {:.4f} / {:.4f} ms".format(k.split(" [")[1].rstrip("]"), v["0"], v["2048"]) for k, v in list(json.load(open(
         os.path.join(ROOT, "profiles", R + "_probe_wgrad_spread.json")))["layers"].items())[:4]),
