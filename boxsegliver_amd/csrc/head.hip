@@ -238,14 +238,26 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(unetk_head_desc d, const 
 // one thread per sample; then thread 0 combines in sample order
 __global__ void head_finalize_kernel(unetk_head_desc d, const float* __restrict__ part, int bps, int nq,
                                      float* __restrict__ result) {
-  extern __shared__ double sh[];  // [N][3]: ce_sum, present, dice_term; then [N][nq] column sums
+  extern __shared__ double sh[];  // [N][3]: ce_sum, present, dice_term; [N][nq] column sums; [N * nq][L] slice sums
   const int ncls = d.ncls;
   double* colsum = sh + (int64_t)d.N * 3;
-  // one thread per (sample, quantity): the bps partial rows in fixed order (same sums as a per-sample loop, 8x the threads)
-  for (int t = threadIdx.x; t < d.N * nq; t += blockDim.x) {
-    const int b = t / nq, i = t - b * nq;
+  double* slice = colsum + (int64_t)d.N * nq;
+  // L threads per (sample, quantity), each a fixed-order sum over every L-th partial row, combined in slice order: one
+  // thread walking all bps rows (864 of them for a 96^3 patch) made this single-block kernel 90 us of serial loads
+  const int P = d.N * nq;
+  int L = 1;
+  while (L < 64 && 2 * L * P <= (int)blockDim.x) L *= 2;
+  for (int t = threadIdx.x; t < P * L; t += blockDim.x) {
+    const int pq = t / L, sl = t - pq * L;
+    const int b = pq / nq, i = pq - b * nq;
     double a = 0.0;
-    for (int j = 0; j < bps; ++j) a += (double)part[((int64_t)b * bps + j) * nq + i];
+    for (int j = sl; j < bps; j += L) a += (double)part[((int64_t)b * bps + j) * nq + i];
+    slice[t] = a;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < P; t += blockDim.x) {
+    double a = 0.0;
+    for (int k = 0; k < L; ++k) a += slice[t * L + k];
     colsum[t] = a;
   }
   __syncthreads();
@@ -477,8 +489,13 @@ extern "C" int unetk_head_fwd(const unetk_head_desc* d, const void* z, const flo
   }
   UNETK_LAUNCH_CHECK();
   if (labels) {
-    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), (size_t)d->N * (3 + L.nq) * sizeof(double), st, *d, part,
-                       bps, L.nq, result);
+    {
+      const int P = d->N * L.nq;
+      int Ls = 1;
+      while (Ls < 64 && 2 * Ls * P <= 1024) Ls *= 2;        // the kernel's own choice for 1024 threads
+      hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(1024),
+                         ((size_t)d->N * (3 + L.nq) + (size_t)P * Ls) * sizeof(double), st, *d, part, bps, L.nq, result);
+    }
     UNETK_LAUNCH_CHECK();
   }
   return UNETK_OK;
