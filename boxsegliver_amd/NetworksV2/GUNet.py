@@ -30,8 +30,10 @@ flattened into mlp(num_base=5) = fc6 ..; the last layer starts at weights 0 / bi
 own arg_scope, spatial mean (ops.SpatialMean), fully_connected(200) and fully_connected(n_mod), he_normal.
 Built as flag combinations of the same kernels (round 3, tests/test_gpu_gunet_combos.py): --fix with --use_context (the guide
 branch's ReLU together with the density gains: norm kernels <G, D, L>), after_affine with --without_norm.
-Not built (raise NotImplementedError): ct_conv with --use_se; --use_se with --dropout (the gate pools the dropped-out values);
-after_affine with --fix / --use_se (a ReLU / an in-op gate stands between the affine and the weights it would fold into).
+Round 3, late: ct_conv with --use_se (the conv subnet emits the plain gain vector, the gate slices it) and after_affine with
+--use_se (the affine's gamma multiplies the gate's output inside the op's autograd graph).
+Not built (raise NotImplementedError): --use_se with --dropout (the gate pools the dropped-out values); after_affine with --fix
+(a ReLU stands between the affine and the guide weights it would fold into).
 --without_norm (GUNet.py:251-252,314-315): every unit = conv + bias (* density gain + guide term) + ReLU, the norm stage
 of the fused kernels reduced to the per-channel shift (unetk_norm_desc.affine_only).
 """
@@ -313,14 +315,18 @@ class GUNet(base.BaseNet):
             if self.ct_conv:
                 if context.dim() != 4 or context.shape[0] != n or not context.is_cuda:      # GUNet.py:279: [bs, 32, 32, 3]
                     raise ValueError("ct_conv: context must be a [bs, h, w, c] device tensor, got {}".format(tuple(context.shape)))
-                if self.use_se:
-                    raise NotImplementedError("GUNet ct_conv with --use_se is not built")
             elif context.dim() != 2 or context.shape[0] != n or not context.is_cuda:
                 raise ValueError("context must be a [bs, L] device tensor, got {}".format(tuple(context.shape)))
             fc_ch = [] if self.ct_conv else list(kwargs.get("context_fc_channels", [256]))
+            # GUNet.py:95-97: the conv subnet always emits the plain gain count (its `use_se` argument is unused); --use_se
+            # then cuts context_fc_channels[-1] columns per unit off that vector (GUNet.py:193-194)
             context_dims = [int(context.shape[-1])] + fc_ch + \
-                [n_modulator_params_se(fc_ch[-1], nds, mod_layers) if self.use_se else
+                [n_modulator_params_se(fc_ch[-1], nds, mod_layers) if (self.use_se and not self.ct_conv) else
                  n_modulator_params(base_channels, nds, mod_layers)]
+            if self.use_se and self.ct_conv:
+                need = n_modulator_params_se(list(kwargs.get("context_fc_channels", [256]))[-1], nds, mod_layers)
+                if need > context_dims[-1]:      # tf.slice past the end of the gain vector
+                    raise ValueError("--use_se slices {} columns off a context vector of {}".format(need, context_dims[-1]))
         if self.params is None:
             in_ch = self.channel * (3 if getattr(self.args, "img_grad", False) else 1)      # GUNet.py:335-338
             gc = int(getattr(self.args, "guide_channel", 1))
@@ -400,7 +406,9 @@ class GUNet(base.BaseNet):
                         den_all, p["{}/context/fc{}/weights".format(nm, fc_base + li)],
                         p["{}/context/fc{}/biases".format(nm, fc_base + li)], not last, None if last else keep, seed)
                 self._layers["context_params"] = den_all
-            se_len = int(context_dims[-2]) if (context_dims and self.use_se) else 0
+            se_len = 0
+            if context_dims and self.use_se:      # context_feature_length = context_fc_channels[-1] (GUNet.py:343-345)
+                se_len = int(list(kwargs.get("context_fc_channels", [256]))[-1])
 
             if self._concat_guide:
                 gs = self._inputs["sp_guide"].to(torch.float32)
@@ -448,9 +456,20 @@ class GUNet(base.BaseNet):
                             gw, gb = self._fixed_guide(i, j, c, guide, gw, spec)
                         else:
                             gb = p["{}/spatial/conv{}/biases".format(nm, i + 1)][(j - 1) * c:j * c]
-                    if after_affine:
-                        if fix or spec.se is not None:
-                            raise NotImplementedError("GUNet after_affine with --fix / --use_se is not built")
+                    if after_affine and spec.se is not None and not fix:
+                        # the gate's gains are formed inside the op: the affine's gamma joins them THERE (a factor behind the
+                        # sigmoid, inside the gate's autograd graph, so gamma gets its gradient with the gate's own variables);
+                        # guide weights and post-shift fold as below
+                        ga, ba = p[scope + "/ChannelWiseAffine/gamma"], p[scope + "/ChannelWiseAffine/beta"]
+                        inner = spec.se
+                        spec.se = (lambda pooled, feat, _g=inner, _ga=ga: _g(pooled, feat) * _ga)
+                        if mod:
+                            gw, gb = gw * ga, gb * ga + ba
+                        else:
+                            gb = ba
+                    elif after_affine:
+                        if fix:
+                            raise NotImplementedError("GUNet after_affine with --fix is not built")
                         # (t * den + sp) * ga + ba == t * (den ga) + guide . (gw ga) + (gb ga + ba): the channel-wise affine
                         # folds into the gains / guide weights the kernel already takes (tiny [bs, C] / [g, C] products)
                         ga, ba = p[scope + "/ChannelWiseAffine/gamma"], p[scope + "/ChannelWiseAffine/beta"]

@@ -198,6 +198,9 @@ class GUNet2DOracle(object):
                 n_mod = init_channels * sum(2 ** i for i in range(num_down_samples + 1) if i in mod_layers) * 2
             self.context_dims = [context_length] + list(context_fc_channels) + [n_mod]
             if context_model == "ct_conv":                             # context_length = the context image's channels
+                # GUNet.py:95-97: `_context_subnets_conv` sizes its last layer for the PLAIN gains whatever `use_se` says
+                # (its use_se argument is unused); --use_se then slices context_fc_channels[-1] columns per unit off it
+                n_mod = init_channels * sum(2 ** i for i in range(num_down_samples + 1) if i in mod_layers) * 2
                 self.context_dims = [context_length, n_mod]
         self.img_grad = img_grad                                       # GUNet.py:335-338
         self.init_channels, self.nds = init_channels, num_down_samples
