@@ -504,6 +504,8 @@ int unetk_wgrad_bf16s_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipS
   if ((int64_t)p.H * p.W * (p.xs > p.ys ? p.xs : p.ys) * 2 >= (int64_t(1) << 31)) return UNETK_E_UNSUPPORTED;   // 32-bit offsets inside an image
   p.zeros = nullptr;
 #ifdef UNETK_V3_PROBE
+  // probe build only (tools/probe_v3.sh; WRONG results, timing): 4 = no staging requests, 16 = no barriers, 32 = no epilogue
+  // (LDS exchange, slab store, slab_reduce), 2048 = one request behind each of the first five MFMA groups instead of five in a row
   { const char* e = getenv("UNETK_V3_FLAGS"); p.dbg = e ? atoi(e) : 0; }
 #endif
   p.slab = pl.S == 1 ? dw : (float*)ws + 64;           // a single split writes the gradient in place
