@@ -24,6 +24,9 @@ $T python bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/
 $T python bench.py --dtype bf16 --size 512 --batch 8 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_bf16_512_bs8.json"
 $T python bench.py --dtype bf16 --model GUNet --batch 8 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_bf16_gunet_bs8.json"
 $T python bench.py --dtype bf16c --size 512 --batch 8 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_bf16c_512_bs8.json"
+$T python bench.py --dp-rehearsal --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_n1_dp_rehearsal.json"
+$T python bench.py --dp-rehearsal --dtype bf16 --size 512 --batch 8 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_bf16_512_bs8_dp_rehearsal.json"
+$T python bench.py --dtype bf16 --model GUNet --batch 8 --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-events > "$OUT/bench_bf16_gunet_bs8_noevents.json"
 echo "bf16 benches done"
 
 # rocprofv3: kernel trace + stats (own run), then the two PMC passes (own runs, kernel-trace only)
