@@ -32,8 +32,10 @@ Built as flag combinations of the same kernels (round 3, tests/test_gpu_gunet_co
 branch's ReLU together with the density gains: norm kernels <G, D, L>), after_affine with --without_norm.
 Round 3, late: ct_conv with --use_se (the conv subnet emits the plain gain vector, the gate slices it) and after_affine with
 --use_se (the affine's gamma multiplies the gate's output inside the op's autograd graph).
-Not built (raise NotImplementedError): --use_se with --dropout (the gate pools the dropped-out values); after_affine with --fix
-(a ReLU stands between the affine and the guide weights it would fold into).
+--use_se with --dropout: the gate pools the dropped-out values -- two per-sample sums of their own in the forward
+(unetk_norm_drop_pool) and a masked extra term in the backward (unetk_norm_se_bwd_add_drop).
+Not built (raise NotImplementedError): after_affine with --fix (a ReLU stands between the affine and the guide weights it would
+fold into).
 --without_norm (GUNet.py:251-252,314-315): every unit = conv + bias (* density gain + guide term) + ReLU, the norm stage
 of the fused kernels reduced to the per-channel shift (unetk_norm_desc.affine_only).
 """
@@ -206,10 +208,6 @@ class GUNet(base.BaseNet):
 
     def _net_arg_scope(self, *args, **kwargs):
         """GUNet.py:240-257: as UNet (decoder norm = _get_normalization defaults), pools with SAME."""
-        if self.use_se and self.use_context_guide and self.dropout:
-            # the SE gate pools the DROPPED-OUT normalised output (GUNet.py:189-201): that mean does not follow from the conv's
-            # statistic partials, it needs a reduction pass of its own -- not built
-            raise NotImplementedError("GUNet --use_se with --dropout is not built")
         self._norm = ("none", {}) if getattr(self.args, "without_norm", False) else self._get_normalization()
         return self._norm
 

@@ -96,6 +96,8 @@ _SIGNATURES = {
                                         P, c_size_t, P]),
     "unetk_norm_apply_relu_pool": (c_int, [POINTER(NormDesc), c_int, P, P, P, P, P, P]),
     "unetk_norm_relu_bwd_pool": (c_int, [POINTER(NormDesc), c_int, P, P, c_int, P, P, P, P, P, P, P, P, P, c_size_t, P]),
+    "unetk_norm_drop_pool": (c_int, [POINTER(NormDesc), P, P, P, P, P]),
+    "unetk_norm_se_bwd_add_drop": (c_int, [POINTER(NormDesc), P, P, P, P, P, P, P, P, P]),
     "unetk_norm_se_bwd_add": (c_int, [POINTER(NormDesc), P, P, P, P, P, P, P, P]),
     "unetk_fc_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, P]),
     "unetk_fc_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),

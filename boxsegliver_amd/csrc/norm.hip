@@ -582,6 +582,72 @@ __global__ __launch_bounds__(256) void norm_se_bwd_add_kernel(const T* __restric
   }
 }
 
+// GUNet --use_se with --dropout (GUNet.py:189-201): the gate pools the DROPPED-OUT normalised output,
+//   pooled[b][c] = mean_p m_p (gamma xhat_p + beta) = gamma * mean_p(m_p xhat_p) + beta * mean_p(m_p),
+// which does not follow from the conv's statistic partials: sums[0][b][c] = sum_p m_p xhat_p, sums[1][b][c] = sum_p m_p, the mask
+// regenerated from (seed, element index) as in the apply / backward passes.  One block per sample, fixed summation order.
+template <typename T>
+__global__ __launch_bounds__(256) void norm_drop_pool_kernel(const T* __restrict__ y, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, float* __restrict__ sums, int64_t P,
+                                                             int C, int cq_n, int rpi, int sst, int N, float keep, uint32_t seed) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][rpi][C]
+  const int cq = threadIdx.x % cq_n, rl = threadIdx.x / cq_n;
+  const int n = blockIdx.x;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  if (rl < rpi) {
+    const int64_t so = (int64_t)n * sst + cq * 4;
+    const float4 mu = ldg4(mean + so), rs = ldg4(rstd + so);
+    const float inv_keep = 1.0f / keep;
+    const int64_t base = (int64_t)n * P;
+    for (int64_t pix = rl; pix < P; pix += rpi) {
+      const float4 v = ld4(y + (base + pix) * C + cq * 4);
+      const float4 m = drop4(seed, (uint32_t)((base + pix) * C + cq * 4), keep, inv_keep);
+      s0.x += m.x * ((v.x - mu.x) * rs.x); s0.y += m.y * ((v.y - mu.y) * rs.y);
+      s0.z += m.z * ((v.z - mu.z) * rs.z); s0.w += m.w * ((v.w - mu.w) * rs.w);
+      s1.x += m.x; s1.y += m.y; s1.z += m.z; s1.w += m.w;
+    }
+    stg4(&smem[(0 * rpi + rl) * C + cq * 4], s0);
+    stg4(&smem[(1 * rpi + rl) * C + cq * 4], s1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int k = i / C, c = i - k * C;
+    float t = 0.f;
+    for (int j = 0; j < rpi; ++j) t += smem[(k * rpi + j) * C + c];
+    sums[((int64_t)k * N + n) * C + c] = t;
+  }
+}
+
+// ... and its way back: dt gets m_p * E[b][c] (E = d loss / d pooled / HW), and the norm backward being linear in dt,
+//   dy += scale * (m_p E[b][c] - k1 - xhat k2),  k1 / k2 = the statistics group's means of m E and m E xhat (from the host:
+// they follow from the two sums above).
+template <typename T>
+__global__ __launch_bounds__(256) void norm_se_bwd_add_drop_kernel(const T* __restrict__ y, T* __restrict__ dy,
+                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                   const float* __restrict__ scale, const float* __restrict__ E,
+                                                                   const float* __restrict__ k1, const float* __restrict__ k2,
+                                                                   int64_t P, int C, int cq_n, int rpi, int sst, float keep,
+                                                                   uint32_t seed) {
+  const int cq = threadIdx.x % cq_n, rl = threadIdx.x / cq_n;
+  if (rl >= rpi) return;
+  const int n = blockIdx.y;
+  const int64_t so = (int64_t)n * sst + cq * 4;
+  const float4 mu = ldg4(mean + so), rs = ldg4(rstd + so), sc = ldg4(scale + so);
+  const float4 ev = ldg4(E + (int64_t)n * C + cq * 4), k1v = ldg4(k1 + so), k2v = ldg4(k2 + so);
+  const float inv_keep = 1.0f / keep;
+  const int64_t base = (int64_t)n * P;
+  for (int64_t pix = (int64_t)blockIdx.x * rpi + rl; pix < P; pix += (int64_t)gridDim.x * rpi) {
+    const float4 v = ld4(y + (base + pix) * C + cq * 4);
+    const float4 m = drop4(seed, (uint32_t)((base + pix) * C + cq * 4), keep, inv_keep);
+    float4 o = ld4(dy + (base + pix) * C + cq * 4);
+    o.x += sc.x * (m.x * ev.x - k1v.x - (v.x - mu.x) * rs.x * k2v.x);
+    o.y += sc.y * (m.y * ev.y - k1v.y - (v.y - mu.y) * rs.y * k2v.y);
+    o.z += sc.z * (m.z * ev.z - k1v.z - (v.z - mu.z) * rs.z * k2v.z);
+    o.w += sc.w * (m.w * ev.w - k1v.w - (v.w - mu.w) * rs.w * k2v.w);
+    st4(dy + (base + pix) * C + cq * 4, o);
+  }
+}
+
 bool norm_desc_ok(const unetk_norm_desc* d) {
   return d && d->N > 0 && d->HW > 0 && d->C > 0 && d->guide_ch >= 0 && d->guide_ch <= MAXG;
 }
@@ -1023,6 +1089,53 @@ extern "C" int unetk_norm_relu_bwd_pool(const unetk_norm_desc* d, int W, const v
   if (gx > cap) gx = cap;
   if (bs) hipLaunchKernelGGL(norm_bwd_apply_pool_kernel<bf16_t>, dim3((int)gx, g.L), dim3(256), 0, st, a, pa);
   else hipLaunchKernelGGL(norm_bwd_apply_pool_kernel<float>, dim3((int)gx, g.L), dim3(256), 0, st, a, pa);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+// --use_se with --dropout, forward: sums [2][N][C] = per (sample, channel) sum of m * xhat and of m (see norm_drop_pool_kernel);
+// d->dropout_keep / dropout_seed as in unetk_norm_apply_relu.  mean / rstd [groups][C] from unetk_norm_finalize.
+extern "C" int unetk_norm_drop_pool(const unetk_norm_desc* d, const void* y, const float* mean, const float* rstd, float* sums,
+                                    void* stream) {
+  UNETK_REQUIRE(norm_desc_ok(d) && y && mean && rstd && sums);
+  if (!norm_supported(d) || d->affine_only) return UNETK_E_UNSUPPORTED;
+  if (!(d->dropout_keep > 0.f && d->dropout_keep <= 1.f)) return UNETK_E_BADARG;
+  const bool bs = d->storage == UNETK_BF16S;
+  UNETK_REQUIRE(d->storage == UNETK_FP32 || bs);
+  UNETK_REQUIRE(bs ? unetk_aligned8(y) : unetk_aligned16(y));
+  const NormGeom g = geom(d, true);            // one launch group per sample
+  const size_t lds = (size_t)2 * g.rpi * d->C * sizeof(float);
+  if (bs)
+    hipLaunchKernelGGL(norm_drop_pool_kernel<bf16_t>, dim3(d->N), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)y, mean, rstd,
+                       sums, g.P, d->C, g.cq_n, g.rpi, g.sst, d->N, d->dropout_keep, d->dropout_seed);
+  else
+    hipLaunchKernelGGL(norm_drop_pool_kernel<float>, dim3(d->N), dim3(256), lds, (hipStream_t)stream, (const float*)y, mean, rstd,
+                       sums, g.P, d->C, g.cq_n, g.rpi, g.sst, d->N, d->dropout_keep, d->dropout_seed);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+// ... backward: dy += scale * (m E[b][c] - k1 - xhat k2); E [N][C], k1 / k2 [groups][C] (groups = N under instance norm, else 1).
+extern "C" int unetk_norm_se_bwd_add_drop(const unetk_norm_desc* d, const void* y, void* dy, const float* mean, const float* rstd,
+                                          const float* scale, const float* E, const float* k1, const float* k2, void* stream) {
+  UNETK_REQUIRE(norm_desc_ok(d) && y && dy && mean && rstd && scale && E && k1 && k2);
+  if (!norm_supported(d)) return UNETK_E_UNSUPPORTED;
+  if (!(d->dropout_keep > 0.f && d->dropout_keep <= 1.f)) return UNETK_E_BADARG;
+  const bool bs = d->storage == UNETK_BF16S;
+  UNETK_REQUIRE(d->storage == UNETK_FP32 || bs);
+  UNETK_REQUIRE(bs ? (unetk_aligned8(y) && unetk_aligned8(dy)) : (unetk_aligned16(y) && unetk_aligned16(dy)));
+  UNETK_REQUIRE(unetk_aligned16(E) && unetk_aligned16(k1) && unetk_aligned16(k2) && unetk_aligned16(mean) && unetk_aligned16(rstd) &&
+                unetk_aligned16(scale));
+  NormGeom g = geom(d, true);
+  int64_t gx = (g.P + g.rpi - 1) / g.rpi;
+  const int64_t cap = (4096 + g.L - 1) / g.L;
+  if (gx > cap) gx = cap;
+  if (bs)
+    hipLaunchKernelGGL(norm_se_bwd_add_drop_kernel<bf16_t>, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y,
+                       (bf16_t*)dy, mean, rstd, scale, E, k1, k2, g.P, d->C, g.cq_n, g.rpi, g.sst, d->dropout_keep, d->dropout_seed);
+  else
+    hipLaunchKernelGGL(norm_se_bwd_add_drop_kernel<float>, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, (const float*)y,
+                       (float*)dy, mean, rstd, scale, E, k1, k2, g.P, d->C, g.cq_n, g.rpi, g.sst, d->dropout_keep, d->dropout_seed);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }

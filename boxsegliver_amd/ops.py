@@ -994,6 +994,22 @@ def guide_moments(guide, per_sample):
     return out
 
 
+def norm_drop_pool(d, y, aff):
+    """--use_se with --dropout: (sum_p m_p xhat_p, sum_p m_p) per (sample, channel), [2, N, C] (unetk_norm_drop_pool)."""
+    d.storage = _storage_of(y)
+    sums = torch.empty((2, d.N, d.C), dtype=torch.float32, device=y.device)
+    check(_abi.lib().unetk_norm_drop_pool(ctypes.byref(d), ptr(y), ptr(aff[0]), ptr(aff[1]), ptr(sums), stream_ptr()),
+          "norm_drop_pool")
+    return sums
+
+
+def norm_se_bwd_add_drop(d, y, dy, aff, e_mat, k1, k2):
+    check(_abi.lib().unetk_norm_se_bwd_add_drop(ctypes.byref(d), ptr(y), ptr(dy), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]),
+                                                ptr(e_mat.contiguous()), ptr(k1.contiguous()), ptr(k2.contiguous()),
+                                                stream_ptr()), "norm_se_bwd_add_drop")
+    return dy
+
+
 def norm_se_bwd_add(d, y, dy, aff, a_mat, k2):
     check(_abi.lib().unetk_norm_se_bwd_add(ctypes.byref(d), ptr(y), ptr(dy), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]),
                                            ptr(a_mat.contiguous()), ptr(k2.contiguous()), stream_ptr()), "norm_se_bwd_add")
@@ -1053,8 +1069,8 @@ class Conv3x3NormRelu(_Op):
         plain = spec.kind == "none"
         se = getattr(spec, "se", None)
         use_batch_stats = (spec.training or spec.per_sample) and not plain
-        if se is not None and (plain or den is not None or getattr(spec, "dropout", None)):
-            raise _abi.UnetkError("--use_se needs a normalised unit, no other density gain and no --dropout")
+        if se is not None and (plain or den is not None):
+            raise _abi.UnetkError("--use_se needs a normalised unit and no other density gain")
         y, stats, rows = conv3x3_fwd(x, wp_f, cout, want_stats=use_batch_stats or se is not None, bf16=bf16, dilation=dilation)
         z = out if out is not None else torch.empty_like(y)
         g_ch = 0 if guide is None else guide.shape[-1]
@@ -1089,14 +1105,22 @@ class Conv3x3NormRelu(_Op):
             # gamma * xhat_mean[b, c] + beta with xhat_mean from the per-sample means of the raw conv output (the same
             # statistic partials, reduced per sample); the tiny [N, C] graph below is ordinary torch autograd, run
             # backwards from inside this node's backward (the gains' gradient is only known there)
-            ps = norm_desc(y.shape, True)
-            mean_b = norm_finalize(ps, stats, rows, None, None, spec.eps, 0.0, True, None, None, y.device)[0]    # [N, C]
-            xhat_mean = ((mean_b - aff[0]) * aff[1]).detach()
+            m_mean = None
+            if d.dropout_keep > 0:
+                # --dropout as well (GUNet.py:189-201): the gate pools the DROPPED-OUT value, mean_hw(m (gamma xhat + beta)) =
+                # gamma * mean(m xhat) + beta * mean(m): two per-sample sums of their own (unetk_norm_drop_pool)
+                sums = norm_drop_pool(d, y, aff)
+                xhat_mean, m_mean = (sums[0] / float(d.HW)).detach(), (sums[1] / float(d.HW)).detach()
+            else:
+                ps = norm_desc(y.shape, True)
+                mean_b = norm_finalize(ps, stats, rows, None, None, spec.eps, 0.0, True, None, None, y.device)[0]    # [N, C]
+                xhat_mean = ((mean_b - aff[0]) * aff[1]).detach()
             with torch.enable_grad():
                 g_leaf = gamma.detach().requires_grad_(True) if gamma is not None else None
                 b_leaf = beta.detach().requires_grad_(True) if beta is not None else None
                 pooled = xhat_mean if g_leaf is None else xhat_mean * g_leaf
-                pooled = pooled if b_leaf is None else pooled + b_leaf
+                if b_leaf is not None:
+                    pooled = pooled + (b_leaf if m_mean is None else m_mean * b_leaf)
                 pooled = pooled + torch.zeros_like(xhat_mean).requires_grad_(True) if not pooled.requires_grad else pooled
                 pooled.retain_grad()
                 # the context slice comes from the OUTER graph (the context MLP): inside, a detached leaf stands in for it
@@ -1104,7 +1128,7 @@ class Conv3x3NormRelu(_Op):
                 f_leaf = se_feat.detach().requires_grad_(True) if se_feat is not None else None
                 gains = se(pooled, f_leaf)
             den = gains.detach().contiguous()
-            se_graph = (g_leaf, b_leaf, pooled, gains, xhat_mean, f_leaf)
+            se_graph = (g_leaf, b_leaf, pooled, gains, xhat_mean, f_leaf, m_mean)
         ctx.pooled = None
         if getattr(ctx, "want_pool", False) and POOL_FUSED and se is None and den is None and g_ch == 0 and gb is None \
                 and d.dropout_keep == 0 and y.shape[1] % 2 == 0 and y.shape[2] % 2 == 0:
@@ -1168,7 +1192,7 @@ class Conv3x3NormRelu(_Op):
             dy, dgamma, dbeta, dgw, dgb, dden = norm_relu_bwd(ctx.desc, y, dz, aff, ctx.has[0], ctx.has[1], guide, gw, gb,
                                                               den, out_gamma=sg, out_beta=sb)
         if getattr(ctx, "se_graph", None) is not None:
-            g_leaf, b_leaf, pooled, gains, xhat_mean, f_leaf = ctx.se_graph
+            g_leaf, b_leaf, pooled, gains, xhat_mean, f_leaf, m_mean = ctx.se_graph
             torch.autograd.backward(gains, dden)              # FC parameters accumulate here; pooled.grad = d loss / d pooled
             gp = pooled.grad
             dfeat = f_leaf.grad if f_leaf is not None else None
@@ -1176,7 +1200,15 @@ class Conv3x3NormRelu(_Op):
                 dgamma = dgamma + g_leaf.grad if dgamma is not None else g_leaf.grad
             if b_leaf is not None and b_leaf.grad is not None:
                 dbeta = dbeta + b_leaf.grad if dbeta is not None else b_leaf.grad
-            if not ctx.desc.per_sample:                       # under instance norm the pooled value does not depend on y
+            if m_mean is not None:
+                # with dropout the pooled value depends on y under either norm: dt gets m_p * E[b, c]; the statistics terms of
+                # the (linear) norm backward follow from the forward's two sums: mean(m E) = E mean(m), mean(m E xhat) = E mean(m xhat)
+                e_mat = gp / float(ctx.desc.HW)
+                k1, k2 = e_mat * m_mean, e_mat * xhat_mean
+                if not ctx.desc.per_sample:
+                    k1, k2 = k1.mean(dim=0, keepdim=True), k2.mean(dim=0, keepdim=True)
+                norm_se_bwd_add_drop(ctx.desc, y, dy, aff, e_mat, k1, k2)
+            elif not ctx.desc.per_sample:                     # under instance norm the pooled value does not depend on y
                 hw = float(ctx.desc.HW)
                 a_mat = gp / hw
                 k2 = (a_mat * xhat_mean).mean(dim=0, keepdim=True)

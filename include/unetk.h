@@ -282,6 +282,15 @@ int unetk_norm_se_bwd_add(const unetk_norm_desc* d, const void* y, void* dy, con
                           const float* rstd, const float* scale, const float* A, const float* k2,
                           void* stream);
 
+/* GUNet --use_se together with --dropout (NetworksV2/GUNet.py:189-201: the gate pools the DROPPED-OUT normalised output).
+ * Forward: sums [2][N][C] = per (sample, channel) sum over the pixels of mask * xhat and of mask (xhat = (y - mean) rstd, the
+ * 0 | 1/keep mask of d->dropout_keep / d->dropout_seed as the norm kernels regenerate it); pooled = gamma * sums[0] / HW +
+ * beta * sums[1] / HW.  Backward: dy += scale * (mask * E[n][c] - k1 - xhat * k2) with E = d loss / d pooled / HW [N][C] and
+ * k1, k2 [groups][C] the statistics group's means of mask E and mask E xhat (groups = N under instance norm, else 1). */
+int unetk_norm_drop_pool(const unetk_norm_desc* d, const void* y, const float* mean, const float* rstd, float* sums, void* stream);
+int unetk_norm_se_bwd_add_drop(const unetk_norm_desc* d, const void* y, void* dy, const float* mean, const float* rstd,
+                               const float* scale, const float* E, const float* k1, const float* k2, void* stream);
+
 /* ---------------------------------------------------------------- GUNet's context MLP (GUNet.py:136-150 `_context_subnets`)
  * slim.fully_connected(x, n): y[B][n] = act(x[B][k] . w[k][n] + b[n]), TF weight layout [in, out]; relu = 1 for the
  * hidden layers, 0 for the last (activation_fn=None), 2 = tf.nn.sigmoid (the SE gate of GUNet --use_se, GUNet.py:199).  slim.dropout(keep_prob) in training: mask from a counter

@@ -3,14 +3,15 @@
 the same fused norm kernels (guide branch with ReLU from folded per-sample weights, density gains, affine_only), so these are
 parity cases against the oracle, not new kernels.  Late round 3: after_affine with --use_se (the affine's gamma joins the gate's
 output inside the op's autograd graph) and ct_conv with --use_se (GUNet.py:95-97: the conv subnet emits the plain gain vector,
-the gate slices context_fc_channels[-1] columns per unit off it).  Still refused (NotImplementedError): --use_se with --dropout
-(the gate pools the dropped-out values), after_affine with --fix (a ReLU stands between the affine and the guide weights)."""
+the gate slices context_fc_channels[-1] columns per unit off it), --use_se with --dropout (the gate pools the dropped-out values:
+unetk_norm_drop_pool / unetk_norm_se_bwd_add_drop).  Still refused (NotImplementedError): after_affine with --fix (a ReLU stands
+between the affine and the guide weights)."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import gunet2d
-from test_gpu_gunet import YML, _setup_variant, _whole_net_check, kwargs_of, make_args
+from test_gpu_gunet import YML, _setup_variant, _whole_net_check, kwargs_of, make_args, unit_mask_host
 
 pytestmark = pytest.mark.gpu
 
@@ -91,3 +92,67 @@ def test_gunet_conv_context_subnet_with_use_se_matches_oracle():
     model.params.load_state(params)
     tensors = (torch.from_numpy(images), torch.from_numpy(guide), torch.from_numpy(labels).long(), context)
     _whole_net_check(model, inputs, net, params, tensors, args, yml, {"context": context, "drop_masks": None})
+
+
+@pytest.mark.parametrize("kind", ["instance_norm", "batch_norm"])
+def test_se_gate_on_dropped_out_values_against_float64_autograd(kind):
+    """The unit itself, where nothing is ill-conditioned: conv -> norm -> dropout mask -> gate(mean_hw(masked)) -> gains -> ReLU
+    against float64 autograd with the mask the kernels regenerate.  Every gradient (input, filter, gamma, beta, the gate's own
+    weights) to rounding: this is the proof of unetk_norm_drop_pool / unetk_norm_se_bwd_add_drop; the whole-net test below only
+    adds the wiring."""
+    import math
+    import torch.nn.functional as F
+    from boxsegliver_amd import ops
+    torch.manual_seed(0)
+    n, h, w, cin, c = 2, 16, 16, 64, 64
+    x = torch.randn(n, h, w, cin, device="cuda", requires_grad=True)
+    wt = (torch.randn(3, 3, cin, c, device="cuda") / math.sqrt(9 * cin)).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(c, device="cuda")).requires_grad_(True)
+    beta = (0.2 * torch.randn(c, device="cuda")).requires_grad_(True)
+    wg = (0.3 * torch.randn(c, c, device="cuda")).requires_grad_(True)
+    r = torch.randn(n, h, w, c, device="cuda")
+    seed, keep = 12345, 0.7
+    spec = ops.NormSpec(kind, 1e-5, 0.9, True, 0)
+    spec.dropout = (keep, seed)
+    spec.se = lambda pooled, feat: torch.sigmoid(pooled @ wg)
+    bn = kind == "batch_norm"
+    mm, mv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    z = ops.Conv3x3NormRelu.apply(x, wt, gamma, beta, mm if bn else None, mv if bn else None, spec, None, None, None, None, None, 1, None)
+    (z * r).sum().backward()
+    got = [t.grad.double().cpu() for t in (x, wt, gamma, beta, wg)]
+    m = torch.from_numpy(unit_mask_host(seed, (n, h, w, c), keep)).double()
+    xd, wd = x.detach().double().cpu().requires_grad_(True), wt.detach().double().cpu().requires_grad_(True)
+    gd, bd = gamma.detach().double().cpu().requires_grad_(True), beta.detach().double().cpu().requires_grad_(True)
+    wgd = wg.detach().double().cpu().requires_grad_(True)
+    y = F.conv2d(xd.permute(0, 3, 1, 2), wd.permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
+    dims = (0, 1, 2) if bn else (1, 2)
+    mu, var = y.mean(dims, keepdim=True), y.var(dims, unbiased=False, keepdim=True)
+    v = ((y - mu) / torch.sqrt(var + 1e-5) * gd + bd) * m
+    zr = torch.relu(v * torch.sigmoid(v.mean((1, 2)) @ wgd)[:, None, None, :])
+    assert float((z.detach().double().cpu() - zr.detach()).abs().max()) < 2e-5
+    (zr * r.double().cpu()).sum().backward()
+    for name, a, b in zip(("dx", "dw", "dgamma", "dbeta", "dgate"), got, (xd.grad, wd.grad, gd.grad, bd.grad, wgd.grad)):
+        assert float((a - b).norm() / b.norm()) < 1e-5, name
+
+
+@pytest.mark.parametrize("normalizer", ["instance_norm", "batch_norm"])
+def test_gunet_use_se_with_dropout_matches_oracle(normalizer):
+    """--use_se + --dropout 0.3 through the whole net: the first conv unit of every encoder block is masked after its norm and the
+    gate pools the MASKED value (GUNet.py:189-201); the oracle gets the masks the kernels regenerate.  At 64 x 64 (a 4 x 4
+    bridge): at 32 x 32 the 2 x 2 instance-norm level turns single ReLU flips into 3-6 % of the whole gradient vector (see
+    test_gpu_gunet.py), which says nothing about this combination."""
+    yml = dict(YML, context_fc_channels=[32, 16])
+    args = make_args(normalizer=normalizer, dropout=0.3, use_context=True, use_se=True, side_dropout=0.0, im_height=64, im_width=64)
+    model, inputs, net, params, tensors = _setup_variant(args, yml, dict(use_se=True), ctx_len=10, size=64)
+    calls = getattr(model, "_dropout_calls", 0)
+    masks = {}
+    for i in range(5):                                   # the seeds GUNet._build_network will use in the next training call
+        c = 64 * 2 ** i
+        seed = int(args.seed) * 7919 + (calls + 1 + i + 1) * 131 + i       # (the context MLP draws one call number first)
+        masks["GUNet/Encode/down_conv{}/mod_conv1".format(i + 1)] = torch.from_numpy(
+            unit_mask_host(seed, (2, 64 >> i, 64 >> i, c), 0.7))
+    _whole_net_check(model, inputs, net, params, tensors, args, yml, {"unit_masks": masks, "context": tensors[3]}, grad_tol=5e-2)
+    model(inputs, "eval", **yml)                          # no dropout outside training: the plain --use_se path
+    p64 = {k: v.double() for k, v in model.params.state_dict().items()}
+    ref, _ = net.forward(p64, tensors[0].double(), tensors[1].double(), False, context=tensors[3].double())
+    assert np.abs(model.layers["logits"].cpu().numpy() - ref.numpy()).max() < 1e-3
