@@ -34,8 +34,8 @@ Round 3, late: ct_conv with --use_se (the conv subnet emits the plain gain vecto
 --use_se (the affine's gamma multiplies the gate's output inside the op's autograd graph).
 --use_se with --dropout: the gate pools the dropped-out values -- two per-sample sums of their own in the forward
 (unetk_norm_drop_pool) and a masked extra term in the backward (unetk_norm_se_bwd_add_drop).
-Not built (raise NotImplementedError): after_affine with --fix (a ReLU stands between the affine and the guide weights it would
-fold into).
+after_affine with --fix: the affine's gamma folds into the guide weights THROUGH the guide branch's ReLU by its sign (per-channel
+slopes of the activation) and its beta follows behind the activation: unetk_norm_desc.guide_leaky == 3 (the gb block).
 --without_norm (GUNet.py:251-252,314-315): every unit = conv + bias (* density gain + guide term) + ReLU, the norm stage
 of the fused kernels reduced to the per-channel shift (unetk_norm_desc.affine_only).
 """
@@ -465,9 +465,21 @@ class GUNet(base.BaseNet):
                             gw, gb = gw * ga, gb * ga + ba
                         else:
                             gb = ba
+                    elif after_affine and fix:
+                        # (t * den + relu(sg)) * ga + ba = t * (den ga) + ga relu(sg) + ba with sg = guide . gw + gb the folded
+                        # guide branch.  ga joins gw / gb (s = ga sg): ga relu(sg) = relu(s) where ga >= 0 and min(s, 0) where
+                        # ga < 0 -- per-channel slopes (1, 0) / (0, 1) of the guide activation -- and ba follows BEHIND it: the
+                        # gb block [bias, slope+, slope-, post-shift] of unetk_norm_desc.guide_leaky == 3.  ga, ba and the
+                        # guide's own variables get their gradients through these host-side products.
+                        if spec.se is not None:
+                            raise NotImplementedError("GUNet after_affine with --fix AND --use_se is not built")
+                        ga, ba = p[scope + "/ChannelWiseAffine/gamma"], p[scope + "/ChannelWiseAffine/beta"]
+                        den = ga.expand(n, c) if den is None else den * ga
+                        gw, gb = gw * ga, gb * ga
+                        pos = (ga.detach() >= 0).to(torch.float32)
+                        gb = torch.stack((gb, pos.expand_as(gb), (1.0 - pos).expand_as(gb), ba.expand_as(gb)), dim=-2).contiguous()
+                        spec.guide_post = True
                     elif after_affine:
-                        if fix:
-                            raise NotImplementedError("GUNet after_affine with --fix is not built")
                         # (t * den + sp) * ga + ba == t * (den ga) + guide . (gw ga) + (gb ga + ba): the channel-wise affine
                         # folds into the gains / guide weights the kernel already takes (tiny [bs, C] / [g, C] products)
                         ga, ba = p[scope + "/ChannelWiseAffine/gamma"], p[scope + "/ChannelWiseAffine/beta"]

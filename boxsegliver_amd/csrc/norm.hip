@@ -150,6 +150,7 @@ struct ApplyArgs {
   int64_t P;
   int C, zs, cq_n, rpi, gw_stride, gw_coff, sst;
   int gw_ns, gb_ns;     // per-sample strides of gw / gb (0 = shared by the batch)
+  int post;             // guide_leaky == 3: per-channel slopes + post-shift in the gb block (see post_act)
   float alpha;          // leaky slope of the guide branch (L)
   float keep;           // dropout keep probability, 0 = no dropout
   uint32_t seed;
@@ -163,6 +164,24 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(
 // alpha = d->guide_alpha: 0.2 for LGNet, 0 (plain ReLU) for GUNet --fix
 __device__ __forceinline__ float lrelu(float s, float al) { return s > 0.f ? s : al * s; }
 __device__ __forceinline__ float lrelu_grad(float s, float al) { return s > 0.f ? 1.f : al; }
+// guide_leaky == 3 ("post"): the guide branch's activation has PER-CHANNEL slopes for s > 0 / s <= 0 and a per-channel shift is
+// added behind it: u = t * den + (s > 0 ? ap : an) * s + ps, s = guide . gw + gb.  This is GUNet after_affine with --fix,
+//   (t * den + relu(sg)) * gamma' + beta' = t * (den gamma') + gamma' relu(sg) + beta',
+// with gamma' folded into gw / gb on the host (s = gamma' sg): gamma' relu(sg) = relu(s) where gamma' >= 0 (slopes 1, 0) and
+// = min(s, 0) where gamma' < 0 (slopes 0, 1).  The gb block is then [4][gw_stride]: bias, ap, an, ps.
+struct PostV { float4 ap, an, ps; };
+__device__ __forceinline__ float4 post_act(const float4& s, const PostV& q) {
+  return make_float4((s.x > 0.f ? q.ap.x : q.an.x) * s.x + q.ps.x, (s.y > 0.f ? q.ap.y : q.an.y) * s.y + q.ps.y,
+                     (s.z > 0.f ? q.ap.z : q.an.z) * s.z + q.ps.z, (s.w > 0.f ? q.ap.w : q.an.w) * s.w + q.ps.w);
+}
+__device__ __forceinline__ float4 post_slope(const float4& s, const PostV& q) {
+  return make_float4(s.x > 0.f ? q.ap.x : q.an.x, s.y > 0.f ? q.ap.y : q.an.y, s.z > 0.f ? q.ap.z : q.an.z, s.w > 0.f ? q.ap.w : q.an.w);
+}
+__device__ __forceinline__ PostV post_load(const float* gb_chan, int gw_stride) {
+  PostV q;
+  q.ap = ldg4(gb_chan + gw_stride); q.an = ldg4(gb_chan + 2 * gw_stride); q.ps = ldg4(gb_chan + 3 * gw_stride);
+  return q;
+}
 
 // slim.dropout between the two convs of a modulated block (GUNet.py:189-190): the mask multiplies the NORMALISED value
 // before the density gain / guide term; kept entries are scaled by 1 / keep.  Regenerated from (seed, element) in every pass.
@@ -190,6 +209,8 @@ __global__ __launch_bounds__(256) void norm_apply_relu_kernel(ApplyArgs a) {
   float4 gwv[G > 0 ? G : 1];
   float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.gb) gbv = ldg4(a.gb + (int64_t)n * a.gb_ns + a.gw_coff + cq * 4);   // guide bias, or a bare post-shift when G == 0
+  PostV pq{};
+  if (L && a.post) pq = post_load(a.gb + (int64_t)n * a.gb_ns + a.gw_coff + cq * 4, a.gw_stride);
   const bool drop = a.keep > 0.f;
   const float inv_keep = drop ? 1.0f / a.keep : 1.f;
   if (!L && !drop) sh = add4(sh, gbv);                 // with dropout the post-shift is added after the mask
@@ -237,7 +258,8 @@ __global__ __launch_bounds__(256) void norm_apply_relu_kernel(ApplyArgs a) {
         const float gg = a.guide[(base + pix) * G + g];
         s.x = fmaf(gg, gwv[g].x, s.x); s.y = fmaf(gg, gwv[g].y, s.y); s.z = fmaf(gg, gwv[g].z, s.z); s.w = fmaf(gg, gwv[g].w, s.w);
       }
-      u.x += lrelu(s.x, a.alpha); u.y += lrelu(s.y, a.alpha); u.z += lrelu(s.z, a.alpha); u.w += lrelu(s.w, a.alpha);
+      if (a.post) u = add4(u, post_act(s, pq));
+      else { u.x += lrelu(s.x, a.alpha); u.y += lrelu(s.y, a.alpha); u.z += lrelu(s.z, a.alpha); u.w += lrelu(s.w, a.alpha); }
     } else {
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -307,6 +329,7 @@ struct BwdArgs {
   int gw_ns, gb_ns;     // per-sample strides of gw / gb (0 = shared)
   float alpha, keep;
   uint32_t seed;
+  int post;             // guide_leaky == 3 (see post_act)
 };
 
 // pass 1.  With dt = du * den (dt = du without density), du = dz * (u > 0), xhat = (y - mean) rstd, t = y*scale + shift:
@@ -314,9 +337,11 @@ struct BwdArgs {
 //   D only: partial[2+G] = sum du (guide bias gradient), partial[3+G] = sum du*t (density gradient, per sample)
 //   L: partial[2+g] = sum du*lrelu'(s)*guide_g, partial[2+G] = sum du*lrelu'(s)  (s = guide . gw + gb; with D as well the
 //   guide-bias row 2+G holds this sum instead of sum du, and 3+G the density gradient: GUNet --fix with --use_context)
-template <int G, bool D, bool L = false, typename T = float>
+//   P (guide_leaky == 3, with D and L): one more row, partial[4+G] = sum du -- the gradient of the post-shift
+template <int G, bool D, bool L = false, typename T = float, bool P = false>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
-  constexpr int K = 2 + G + (D ? 2 : (L ? 1 : 0));
+  static_assert(!P || (D && L), "the post vectors come with the leaky guide and the density gains");
+  constexpr int K = 2 + G + (D ? 2 : (L ? 1 : 0)) + (P ? 1 : 0);
   const T* ay = static_cast<const T*>(a.y);
   const T* adz = static_cast<const T*>(a.dz);
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [K][rpi][C]
@@ -335,6 +360,8 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
     float4 gwv[G > 0 ? G : 1];
     float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.gb) gbv = ldg4(a.gb + (int64_t)n * a.gb_ns + a.gw_coff + cq * 4);
+    PostV pq{};
+    if (P) pq = post_load(a.gb + (int64_t)n * a.gb_ns + a.gw_coff + cq * 4, a.gw_stride);
     const bool drop = a.keep > 0.f;
     const float inv_keep = drop ? 1.0f / a.keep : 1.f;
     if (!L && !drop) sh = add4(sh, gbv);
@@ -393,8 +420,13 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
           gg[g] = a.guide[(base + pix) * G + g];
           sg.x = fmaf(gg[g], gwv[g].x, sg.x); sg.y = fmaf(gg[g], gwv[g].y, sg.y); sg.z = fmaf(gg[g], gwv[g].z, sg.z); sg.w = fmaf(gg[g], gwv[g].w, sg.w);
         }
-        u.x += lrelu(sg.x, a.alpha); u.y += lrelu(sg.y, a.alpha); u.z += lrelu(sg.z, a.alpha); u.w += lrelu(sg.w, a.alpha);
-        ls = make_float4(lrelu_grad(sg.x, a.alpha), lrelu_grad(sg.y, a.alpha), lrelu_grad(sg.z, a.alpha), lrelu_grad(sg.w, a.alpha));
+        if (P) {
+          u = add4(u, post_act(sg, pq));
+          ls = post_slope(sg, pq);
+        } else {
+          u.x += lrelu(sg.x, a.alpha); u.y += lrelu(sg.y, a.alpha); u.z += lrelu(sg.z, a.alpha); u.w += lrelu(sg.w, a.alpha);
+          ls = make_float4(lrelu_grad(sg.x, a.alpha), lrelu_grad(sg.y, a.alpha), lrelu_grad(sg.z, a.alpha), lrelu_grad(sg.w, a.alpha));
+        }
       } else {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -413,6 +445,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
     if (D) {                                                                  \
       s[2 + G].f += dg;                                                       \
       s[3 + G].f += du * m.f * fmaf(v.f, sc0.f, sh0.f);                       \
+      if (P) s[4 + G].f += du;                                                \
     } else if (L) {                                                           \
       s[2 + G].f += dg;                                                       \
     }                                                                         \
@@ -450,6 +483,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdArgs a) {
   float4 gwv[G > 0 ? G : 1];
   float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.gb) gbv = ldg4(a.gb + (int64_t)n * a.gb_ns + a.gw_coff + cq * 4);   // guide bias, or a bare post-shift when G == 0
+  PostV pq{};
+  if (L && a.post) pq = post_load(a.gb + (int64_t)n * a.gb_ns + a.gw_coff + cq * 4, a.gw_stride);
   const bool drop = a.keep > 0.f;
   const float inv_keep = drop ? 1.0f / a.keep : 1.f;
   if (!L && !drop) sh = add4(sh, gbv);
@@ -512,7 +547,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdArgs a) {
         const float gg = a.guide[(base + pix) * G + g];
         sg.x = fmaf(gg, gwv[g].x, sg.x); sg.y = fmaf(gg, gwv[g].y, sg.y); sg.z = fmaf(gg, gwv[g].z, sg.z); sg.w = fmaf(gg, gwv[g].w, sg.w);
       }
-      u.x += lrelu(sg.x, a.alpha); u.y += lrelu(sg.y, a.alpha); u.z += lrelu(sg.z, a.alpha); u.w += lrelu(sg.w, a.alpha);
+      if (a.post) u = add4(u, post_act(sg, pq));
+      else { u.x += lrelu(sg.x, a.alpha); u.y += lrelu(sg.y, a.alpha); u.z += lrelu(sg.z, a.alpha); u.w += lrelu(sg.w, a.alpha); }
     } else {
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -552,6 +588,18 @@ __global__ void norm_bwd_guide_ps_kernel(const float* __restrict__ sums, int N, 
   const int n = i / C, c = i - n * C;
   if (dgb) dgb[i] = sums[((int64_t)kb * N + n) * C + c];
   for (int g = 0; g < G; ++g) dgw[((int64_t)n * G + g) * C + c] = sums[((int64_t)(2 + g) * N + n) * C + c];
+}
+
+// guide_leaky == 3: dgb block [groups][4][C] from src[k][groups][C] (the per-sample sums, or their total with groups = 1)
+__global__ void norm_bwd_post_block_kernel(const float* __restrict__ src, int groups, int C, int G, float* __restrict__ dgb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= groups * C) return;
+  const int n = i / C, c = i - n * C;
+  float* o = dgb + (int64_t)n * 4 * C + c;
+  o[0] = src[((int64_t)(2 + G) * groups + n) * C + c];
+  o[C] = 0.f;
+  o[2 * C] = 0.f;
+  o[3 * C] = src[((int64_t)(4 + G) * groups + n) * C + c];
 }
 
 // GUNet --use_se: the SE gate reads pooled[b][c] = mean over the sample's pixels of the normalised conv output, so the
@@ -874,7 +922,8 @@ extern "C" int unetk_norm_apply_relu(const unetk_norm_desc* d, const void* y, co
   if (d->dropout_keep < 0.f || d->dropout_keep > 1.f) return UNETK_E_BADARG;
   if (d->guide_per_sample && g.L != d->N) return UNETK_E_UNSUPPORTED;      // needs one launch group per sample
   ApplyArgs a{y, scale, shift, den, guide, gw, gb, z, g.P, d->C, d->z_stride, g.cq_n, g.rpi, d->gw_stride, d->gw_coff, g.sst,
-              d->guide_per_sample ? d->guide_ch * d->gw_stride : 0, d->guide_per_sample ? d->gw_stride : 0,
+              d->guide_per_sample ? d->guide_ch * d->gw_stride : 0,
+              d->guide_per_sample ? (d->guide_leaky == 3 ? 4 : 1) * d->gw_stride : 0, d->guide_leaky == 3 ? 1 : 0,
               d->guide_leaky == 2 ? d->guide_alpha : 0.2f,
               d->dropout_keep, d->dropout_seed};
   int64_t gx = (g.P + g.rpi - 1) / g.rpi;
@@ -882,6 +931,7 @@ extern "C" int unetk_norm_apply_relu(const unetk_norm_desc* d, const void* y, co
   if (gx > cap) gx = cap;
   const bool leaky = d->guide_leaky != 0;
   if (leaky && d->guide_ch < 1) return UNETK_E_UNSUPPORTED;
+  if (d->guide_leaky == 3 && (den == nullptr || gb == nullptr)) return UNETK_E_UNSUPPORTED;     // post vectors: with density gains only
   GD_DISPATCH(bs, d->guide_ch, den != nullptr, leaky, norm_apply_relu_kernel, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, a);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
@@ -919,7 +969,7 @@ extern "C" size_t unetk_norm_bwd_ws_bytes(const unetk_norm_desc* d) {
   if (!norm_desc_ok(d) || !norm_supported(d)) return 0;
   // sized for the density variant (K + 2 rows, N launch groups): a superset of every other case
   const NormGeom g = geom(d, true);
-  const int K = 4 + d->guide_ch;
+  const int K = 5 + d->guide_ch;          // density + leaky guide + post-shift row: the largest variant
   NormGeom g1 = geom(d, false);
   int nblk = bwd_blocks(g);
   const int nblk1 = bwd_blocks(g1);
@@ -969,7 +1019,9 @@ extern "C" int unetk_norm_relu_bwd_pre(const unetk_norm_desc* d, const void* y, 
   const NormGeom g = geom(d, D);
   const bool leaky = d->guide_leaky != 0;
   if (leaky && G < 1) return UNETK_E_UNSUPPORTED;
-  const int K = 2 + G + (D ? 2 : (leaky ? 1 : 0));
+  const bool post = d->guide_leaky == 3;     // dgb is then the gradient of the whole gb block: [4][C] ([N][4][C] per sample)
+  if (post && (!D || !gb || pre_partials != nullptr)) return UNETK_E_UNSUPPORTED;
+  const int K = 2 + G + (D ? 2 : (leaky ? 1 : 0)) + (post ? 1 : 0);
   const int nblk = bwd_blocks(g);
   float* partial = (float*)ws;
   float* sums = partial + (size_t)K * g.L * nblk * d->C;
@@ -984,8 +1036,9 @@ extern "C" int unetk_norm_relu_bwd_pre(const unetk_norm_desc* d, const void* y, 
   if (d->dropout_keep < 0.f || d->dropout_keep > 1.f) return UNETK_E_BADARG;
   if (d->dropout_keep > 0.f && (gb || G > 0) && !D && !leaky) return UNETK_E_UNSUPPORTED;   // the guide-bias sum needs the density variant (pass den = 1)
   if (d->guide_per_sample && g.L != d->N) return UNETK_E_UNSUPPORTED;
-  a.gw_ns = d->guide_per_sample ? G * d->gw_stride : 0; a.gb_ns = d->guide_per_sample ? d->gw_stride : 0;
+  a.gw_ns = d->guide_per_sample ? G * d->gw_stride : 0; a.gb_ns = d->guide_per_sample ? (post ? 4 : 1) * d->gw_stride : 0;
   a.alpha = d->guide_leaky == 2 ? d->guide_alpha : 0.2f; a.keep = d->dropout_keep; a.seed = d->dropout_seed;
+  a.post = post ? 1 : 0;
   // the statistics sums of the dy formula: per launch group when the statistics are per sample, else the batch totals
   if (d->per_sample) { a.ksum = sums; a.kst = d->C; a.krow = g.L * d->C; }
   else if (g.L == 1) { a.ksum = sums; a.kst = 0; a.krow = d->C; }
@@ -1003,7 +1056,12 @@ extern "C" int unetk_norm_relu_bwd_pre(const unetk_norm_desc* d, const void* y, 
     rc = unetk_rows_reduce_alias(pre_partials, K * g.L, pre_rows / g.L, d->C, sums, tmp1, last1 ? al0 : nullptr,
                                  last1 ? al1 : nullptr, st);   // -> sums[K][L][C]
   } else {
-    GD_DISPATCH(bs, G, D, leaky, norm_bwd_reduce_kernel, dim3(nblk, g.L), dim3(256), lds, st, a);
+    if (post) {
+      if (bs) { GL_DISPATCH(G, hipLaunchKernelGGL((norm_bwd_reduce_kernel<GG, true, true, bf16_t, true>), dim3(nblk, g.L), dim3(256), lds, st, a)); }
+      else { GL_DISPATCH(G, hipLaunchKernelGGL((norm_bwd_reduce_kernel<GG, true, true, float, true>), dim3(nblk, g.L), dim3(256), lds, st, a)); }
+    } else {
+      GD_DISPATCH(bs, G, D, leaky, norm_bwd_reduce_kernel, dim3(nblk, g.L), dim3(256), lds, st, a);
+    }
     UNETK_LAUNCH_CHECK();
     rc = unetk_rows_reduce_alias(partial, K * g.L, nblk, d->C, sums, tmp1, last1 ? al0 : nullptr, last1 ? al1 : nullptr,
                                  st);                          // -> sums[K][L][C]
@@ -1018,13 +1076,19 @@ extern "C" int unetk_norm_relu_bwd_pre(const unetk_norm_desc* d, const void* y, 
   const bool gps = d->guide_per_sample != 0;
   if (!simple) {
     hipLaunchKernelGGL(norm_bwd_params_kernel, dim3((d->C + 255) / 256), dim3(256), 0, st, psum, d->C, gps ? 0 : G,
-                       (D || leaky) ? 1 : 0, dgamma, dbeta, gps ? nullptr : dgw, gps ? nullptr : dgb);
+                       (D || leaky) ? 1 : 0, dgamma, dbeta, gps ? nullptr : dgw, (gps || post) ? nullptr : dgb);
     UNETK_LAUNCH_CHECK();
   }
   if (gps) {   // dgw [N][G][C], dgb [N][C]: the per-launch-group sums, not their total
     const int kb = (D || leaky) ? 2 + G : 0;
     hipLaunchKernelGGL(norm_bwd_guide_ps_kernel, dim3((d->N * d->C + 255) / 256), dim3(256), 0, st, sums, d->N, d->C, G, kb, dgw,
-                       dgb);
+                       post ? nullptr : dgb);
+    UNETK_LAUNCH_CHECK();
+  }
+  if (post) {  // gradient of the gb block: bias row = sum dg, slope rows = 0 (constants of the fold's sign), post-shift row = sum du
+    const int groups = gps ? d->N : 1;
+    hipLaunchKernelGGL(norm_bwd_post_block_kernel, dim3((groups * d->C + 255) / 256), dim3(256), 0, st, gps ? sums : psum, groups,
+                       d->C, G, dgb);
     UNETK_LAUNCH_CHECK();
   }
   if (D) {   // density gradient: the per-sample row sum du * t

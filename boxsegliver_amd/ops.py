@@ -638,12 +638,13 @@ def norm_relu_bwd(d, y, dz, aff, has_gamma, has_beta, guide=None, gw=None, gb=No
     dden = torch.empty_like(den) if den is not None else None
     dgamma = (out_gamma if out_gamma is not None else torch.empty((d.C,), dtype=torch.float32, device=dev)) if has_gamma else None
     dbeta = (out_beta if out_beta is not None else torch.empty((d.C,), dtype=torch.float32, device=dev)) if has_beta else None
+    blk = (4,) if d.guide_leaky == 3 else ()       # guide_leaky == 3: gb is the block [bias, slope+, slope-, post-shift] and so is its gradient
     if d.guide_per_sample:
         dgw = torch.empty((d.N, d.guide_ch, d.C), dtype=torch.float32, device=dev) if d.guide_ch else None
-        dgb = torch.empty((d.N, d.C), dtype=torch.float32, device=dev) if (d.guide_ch or gb is not None) else None
+        dgb = torch.empty((d.N,) + blk + (d.C,), dtype=torch.float32, device=dev) if (d.guide_ch or gb is not None) else None
     else:
         dgw = torch.empty((d.guide_ch, d.C), dtype=torch.float32, device=dev) if d.guide_ch else None
-        dgb = torch.empty((d.C,), dtype=torch.float32, device=dev) if (d.guide_ch or gb is not None) else None
+        dgb = torch.empty(blk + (d.C,), dtype=torch.float32, device=dev) if (d.guide_ch or gb is not None) else None
     nbytes = _abi.lib().unetk_norm_bwd_ws_bytes(ctypes.byref(d))
     if nbytes == 0:
         raise _abi.UnetkError("norm_relu_bwd: unsupported channel count {}".format(d.C))
@@ -1026,6 +1027,7 @@ class NormSpec(object):
         self.guide_leaky = False   # LGNet: leaky-ReLU on the guide branch before it is added
         self.guide_alpha = 0.2     # its slope (tf.nn.leaky_relu default); 0 = the ReLU of GUNet --fix
         self.guide_per_sample = False   # gw [N, g, C] / gb [N, C]: per-sample folded guide weights (--fix under instance norm)
+        self.guide_post = False    # gb is the block [bias, slope for s > 0, slope for s <= 0, post-shift] x C (after_affine + --fix)
         self.dropout = None        # (keep_prob, seed): slim.dropout on the normalised value (GUNet --dropout), training only
         self.se = None             # GUNet --use_se: callable (pooled [N, C], context slice) -> gains [N, C] (torch graph)
         self.bf16 = precision_of(bf16)   # 0 fp32 | 1 UNETK_BF16 (bf16 operands, fp32 tensors) | 2 UNETK_BF16S (+ bf16 tensors)
@@ -1083,6 +1085,8 @@ class Conv3x3NormRelu(_Op):
             alpha = float(getattr(spec, "guide_alpha", 0.2))
             d.guide_leaky = 1 if alpha == 0.2 else 2           # 1 = tf.nn.leaky_relu's default slope, 2 = guide_alpha
             d.guide_alpha = alpha
+        if g_ch and getattr(spec, "guide_post", False):       # GUNet after_affine + --fix: gb = [bias, slope+, slope-, post-shift] rows
+            d.guide_leaky = 3
         if getattr(spec, "guide_per_sample", False):
             d.guide_per_sample = 1
             d.gw_stride = cout

@@ -200,7 +200,11 @@ typedef struct unetk_norm_desc {
   int32_t guide_ch, gw_stride, gw_coff;
   int32_t affine_only;         /* 1 = no normalisation (--without_norm, UNet.py:47-48: conv + bias + ReLU):
                                   backward skips the statistics terms, dbeta is the bias gradient */
-  int32_t guide_leaky;         /* 1 = LGNet's guide branch (LGNet.py:30-55): the 1x1 guide conv is followed by
+  int32_t guide_leaky;         /* 3 = per-channel activation + post-shift on the guide branch (GUNet after_affine with --fix,
+                                  GUNet.py:213-214,299-304): gb is a block of four rows of gw_stride floats -- bias, slope for
+                                  s > 0, slope for s <= 0, post-shift -- and u = t * den + slope(s) * s + post-shift with
+                                  s = guide . gw + bias; needs den; dgb comes back as the same block (slope rows zero);
+                                  1 = LGNet's guide branch (LGNet.py:30-55): the 1x1 guide conv is followed by
                                   tf.nn.leaky_relu (alpha 0.2) before the add: u = t + lrelu(guide . gw + gb);
                                   needs guide_ch > 0, no density gains */
   int32_t storage;             /* UNETK_FP32: y / z / dz / dy are fp32; UNETK_BF16S: they are bf16 in memory (strides in

@@ -4,8 +4,9 @@ the same fused norm kernels (guide branch with ReLU from folded per-sample weigh
 parity cases against the oracle, not new kernels.  Late round 3: after_affine with --use_se (the affine's gamma joins the gate's
 output inside the op's autograd graph) and ct_conv with --use_se (GUNet.py:95-97: the conv subnet emits the plain gain vector,
 the gate slices context_fc_channels[-1] columns per unit off it), --use_se with --dropout (the gate pools the dropped-out values:
-unetk_norm_drop_pool / unetk_norm_se_bwd_add_drop).  Still refused (NotImplementedError): after_affine with --fix (a ReLU stands
-between the affine and the guide weights)."""
+unetk_norm_drop_pool / unetk_norm_se_bwd_add_drop), after_affine with --fix (the affine's gamma folds into the guide weights
+through the guide branch's ReLU by its SIGN -- per-channel slopes of the activation -- and its beta follows behind the
+activation: unetk_norm_desc.guide_leaky == 3)."""
 import numpy as np
 import pytest
 import torch
@@ -156,3 +157,26 @@ def test_gunet_use_se_with_dropout_matches_oracle(normalizer):
     p64 = {k: v.double() for k, v in model.params.state_dict().items()}
     ref, _ = net.forward(p64, tensors[0].double(), tensors[1].double(), False, context=tensors[3].double())
     assert np.abs(model.layers["logits"].cpu().numpy() - ref.numpy()).max() < 1e-3
+
+
+@pytest.mark.parametrize("normalizer,use_context", [("instance_norm", False), ("batch_norm", True), ("instance_norm", True)])
+def test_gunet_after_affine_with_fix_matches_oracle(normalizer, use_context):
+    """relu((t * den + relu(norm(conv1x1(guide)))) * gamma' + beta') with gamma' of BOTH signs: where gamma' < 0 the folded guide
+    branch is min(s, 0) instead of relu(s) (slopes (0, 1)), and beta' must not pass through the guide's ReLU."""
+    yml = dict(YML, after_affine=True, context_fc_channels=[32, 16])
+    args = make_args(normalizer=normalizer, fix=True, use_context=use_context, side_dropout=0.0, im_height=64, im_width=64)
+    model, inputs, net, params, tensors = _setup_variant(args, yml, dict(after_affine=True, fix=True),
+                                                         ctx_len=10 if use_context else 0, size=64)
+    flipped = 0
+    for name in list(params):
+        if name.endswith("ChannelWiseAffine/gamma"):
+            params[name] = params[name].clone()
+            params[name][1::2] *= -1.0                     # every other channel: a negative affine scale
+            flipped += 1
+    assert flipped == 10
+    model.params.load_state(params)
+    _whole_net_check(model, inputs, net, params, tensors, args, yml, {"context": tensors[3]} if use_context else {}, grad_tol=5e-2)
+    for nm_ in ("GUNet/Encode/down_conv2/mod_conv1/ChannelWiseAffine/gamma", "GUNet/Encode/down_conv2/mod_conv1/ChannelWiseAffine/beta",
+                "GUNet/spatial/conv2/weights"):
+        g = model.params[nm_].grad
+        assert g is not None and float(g.abs().sum()) > 0, nm_
