@@ -191,3 +191,35 @@ def test_round3_profiles_readme_is_generated_from_the_committed_profiles():
     assert out.returncode == 0, out.stderr[-2000:]
     with open(os.path.join(root, "profiles", "r03_README.md")) as f:
         assert out.stdout == f.read()
+
+
+def test_input_gradient_pack_item_order_is_a_bijection():
+    """csrc/pack.h dgrad_item: the order in which the threads of unetk_pack_many take the items of an input-gradient pack (QL
+    lanes share a filter row's cache line) must visit every item exactly once, for every layer shape the nets have -- restated
+    here (the device function is four integer divisions) and checked as a permutation; the packed bytes themselves are
+    compared on the GPU (tests/test_gpu_pack_cache.py, tests/test_gpu_bf16s*.py)."""
+    import numpy as np
+
+    def dgrad_item(i, cin, q, ql):
+        nl = 64 // ql
+        if q % ql or cin % nl:
+            return i
+        l, blk = i & 63, i >> 6
+        q_l, n_l = l % ql, l // ql
+        nt_n = cin // nl
+        nt, rest = blk % nt_n, blk // nt_n
+        qt, t = rest % (q // ql), rest // (q // ql)
+        return (t * q + qt * ql + q_l) * cin + nt * nl + n_l
+
+    for cin, cout in [(64, 64), (128, 64), (64, 128), (256, 512), (1024, 1024), (3, 64), (20, 36), (64, 32)]:
+        for ql, per in ((8, 4), (4, 8)):                      # fp32 packs: 4 floats per item, 8 lanes per row; bf16: 8 and 4
+            if cout % per:
+                continue
+            q = cout // per
+            total = 9 * q * cin
+            idx = np.arange(total, dtype=np.int64)
+            out = np.array([dgrad_item(int(i), cin, q, ql) for i in idx[:: max(1, total // 20000)]])
+            assert out.min() >= 0 and out.max() < total
+            if total <= 200000:
+                full = np.array([dgrad_item(int(i), cin, q, ql) for i in idx])
+                assert np.array_equal(np.sort(full), idx), (cin, cout, ql)
