@@ -220,8 +220,26 @@ class GUNet(base.BaseNet):
                                 bool(np_["is_training"]), self.compute_bf16)
         return ops.NormSpec("instance_norm", np_["eps"], 0.0, self.is_training, self.compute_bf16)
 
-    def _unit(self, x, scope, spec, out=None, guide=None, gw=None, gb=None, den=None, se_feat=None):
+    def _unit(self, x, scope, spec, out=None, guide=None, gw=None, gb=None, den=None, se_feat=None, pool=False):
+        """One conv unit.  pool=True (the block's second conv, whose activation feeds the pool and the skip): a PLAIN unit -- no
+        guide, gains, gate or dropout, e.g. level 0 of the shipped GUNet configs (mod_layers [1, 2, 3, 4]) -- returns
+        (pooled, activation) from ONE node (ops.Conv3x3NormReluPool: the pool rides on the norm passes); any other unit takes
+        ops.MaxPoolSkip behind it as before."""
         p = self.params
+        if pool:
+            plain_unit = guide is None and gb is None and den is None and se_feat is None and getattr(spec, "se", None) is None \
+                and getattr(spec, "dropout", None) is None
+            if not plain_unit:
+                z = self._unit(x, scope, spec, out, guide, gw, gb, den, se_feat)
+                pooled, skip = ops.MaxPoolSkip.apply(z)
+                return pooled, skip
+            ns = scope + ("/BatchNorm" if spec.kind == "batch_norm" else "/InstanceNorm")
+            var = (None, p[scope + "/biases"], None, None) if spec.kind == "none" else \
+                (p.get(ns + "/gamma"), p.get(ns + "/beta"), p.get(ns + "/moving_mean"), p.get(ns + "/moving_variance"))
+            pooled, z = ops.Conv3x3NormReluPool.apply(x, p[scope + "/weights"], var[0], var[1], var[2], var[3], spec, out)
+            if self._taps is not None:
+                self._taps[scope] = z
+            return pooled, z
         if spec.kind == "none":
             z = ops.Conv3x3NormRelu.apply(x, p[scope + "/weights"], None, p[scope + "/biases"], None, None, spec, out,
                                           guide, gw, gb, den, 1, se_feat)
@@ -488,7 +506,11 @@ class GUNet(base.BaseNet):
                             gw, gb = gw * ga, gb * ga + ba
                         else:
                             gb = ba
-                    x = self._unit(x, scope, spec, out, guide, gw, gb, den, se_feat)
+                    fuse_pool = j == 2 and i < nds and not (i == 0 and self._concat_guide and self._mid_cat)
+                    if fuse_pool:
+                        x, skips[i] = self._unit(x, scope, spec, out, guide, gw, gb, den, se_feat, pool=True)
+                    else:
+                        x = self._unit(x, scope, spec, out, guide, gw, gb, den, se_feat)
                 if i < nds:
                     if i == 0 and self._concat_guide and self._mid_cat:
                         # UNetInter.py:124-129: pool(concat(level-0 output, guide)); zero channels up to the padded width
@@ -496,8 +518,7 @@ class GUNet(base.BaseNet):
                         gs = self._inputs["sp_guide"].to(torch.float32)
                         zpad = torch.zeros((n, hh, ww, self._mid_pad - c - gs.shape[3]), dtype=torch.float32, device=dev)
                         x = ops.MaxPool2x2.apply(torch.cat((x, gs, zpad), dim=-1))
-                    else:
-                        x, skips[i] = ops.MaxPoolSkip.apply(x)
+                    # (else: the block's second unit already returned the pooled tensor and the skip, see _unit(pool=True))
                     hh //= 2
                     ww //= 2
 

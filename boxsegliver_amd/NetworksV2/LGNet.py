@@ -76,10 +76,10 @@ class LGNet(GUNet):
         self._norm = self._get_normalization()
         return self._norm
 
-    def _lg_unit(self, x, scope, out=None, guide=None, gw=None, gb=None):
+    def _lg_unit(self, x, scope, out=None, guide=None, gw=None, gb=None, pool=False):
         spec = self._spec()
         spec.guide_leaky = guide is not None
-        return self._unit(x, scope, spec, out, guide, gw, gb)
+        return self._unit(x, scope, spec, out, guide, gw, gb, pool=pool)
 
     def _build_network(self, *args, **kwargs):
         mod_layers = kwargs.get("mod_layers", [[0, 1], [1, 0]])
@@ -135,14 +135,13 @@ class LGNet(GUNet):
                     cat = torch.empty((n, hh, ww, 2 * c), dtype=torch.float32, device=dev)
                     out = ops.alias(cat, 0, (n, hh, ww, c), cat.stride())
                     cats[i] = cat
-                if g_ch and i in mod_layers[0]:
-                    x = self._lg_unit(x, scope + "/conv2", out, *sp("e", i))
-                else:
-                    x = self._lg_unit(x, scope + "/conv2", out)
-                if i < 4:
-                    x, skips[i] = ops.MaxPoolSkip.apply(x)
+                guided = sp("e", i) if (g_ch and i in mod_layers[0]) else ()
+                if i < 4:      # the pool rides on the unit's norm passes when the unit is plain (GUNet._unit, pool=True)
+                    x, skips[i] = self._lg_unit(x, scope + "/conv2", out, *guided, pool=True)
                     hh //= 2
                     ww //= 2
+                else:
+                    x = self._lg_unit(x, scope + "/conv2", out, *guided)
             for i in (3, 2, 1, 0):
                 d = "{}/conv_d{}".format(nm, i)
                 x = ops.DeconvConcat.apply(x, p[d + "/up/weights"], p[d + "/up/biases"], skips[i], cats[i], False)
