@@ -428,24 +428,15 @@ template <int CIN, typename TY = float>
 __global__ __launch_bounds__(256) void conv3x3_c3_mfma_kernel(ConvParams p) {
   static_assert(CIN >= 1 && CIN <= 5, "K = 9 Cin <= 46");
   constexpr int K = 9 * CIN, NS = (K + 1) / 2, COUT = 64;
+  constexpr int NH = (180 * CIN + 255) / 256;                    // halo values per thread
   extern __shared__ __attribute__((aligned(16))) float smem[];  // halo [180 * CIN] (+ pad), then the waves' statistic rows [2][4][64]
   float* halo = smem;
   float* red = smem + ((180 * CIN + 3) & ~3);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
-  const int mtile = blockIdx.x;
-  const int tw_i = mtile % p.tiles_w;
-  const int th_i = (mtile / p.tiles_w) % p.tiles_h;
-  const int n_img = mtile / (p.tiles_w * p.tiles_h);
-  const int h0 = th_i * 8, w0 = tw_i * TW;
-  const int64_t ximg = p.xa.off(n_img);
-  for (int i = tid; i < 180 * CIN; i += 256) {
-    const int pix = i / CIN, ci = i - pix * CIN;
-    const int ih = h0 + pix / 18 - 1, iw = w0 + pix % 18 - 1;
-    halo[i] = (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) ? p.x[ximg + ((int64_t)ih * p.W + iw) * p.xs + ci] : 0.f;
-  }
-  // filter values of this lane: rows k = 2 s + h of the HWIO filter [9 Cin][64], channels 2 l31 and 2 l31 + 1
+  // filter values of this lane: rows k = 2 s + h of the HWIO filter [9 Cin][64], channels 2 l31 and 2 l31 + 1 -- loaded ONCE: the
+  // block is persistent (a block per tile spent most of its life on this load and the first halo's round trip)
   float b0[NS], b1[NS];
   int aoff[NS];
   const int pr = 2 * wave + (l31 >> 4), pc = l31 & 15;            // this lane's pixel of the tile (the A operand's row)
@@ -460,48 +451,79 @@ __global__ __launch_bounds__(256) void conv3x3_c3_mfma_kernel(ConvParams p) {
     const int t = kk / CIN, ci = kk - t * CIN;
     aoff[s2] = ((pr + t / 3) * 18 + pc + t % 3) * CIN + ci;
   }
-  f32x16 acc0, acc1;
+  const int n_tiles = p.N * p.tiles_h * p.tiles_w;
+  // the next tile's halo waits in registers while this tile is contracted and stored
+  float hreg[NH];
+  auto fetch = [&](int mtile) {
+    const int tw_i = mtile % p.tiles_w;
+    const int th_i = (mtile / p.tiles_w) % p.tiles_h;
+    const int n_img = mtile / (p.tiles_w * p.tiles_h);
+    const int h0 = th_i * 8, w0 = tw_i * TW;
+    const int64_t ximg = p.xa.off(n_img);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
-  __syncthreads();
-#pragma unroll
-  for (int s2 = 0; s2 < NS; ++s2) {
-    const float a = halo[aoff[s2]];          // k >= K: b is zero, any finite a will do
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[s2], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[s2], acc1, 0, 0, 0);
-  }
-  float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-  TY* yimg = reinterpret_cast<TY*>(p.y) + p.ya.off(n_img) + 2 * l31;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int pix = wave * 32 + mfma32_row(r, h);
-    const int gh = h0 + (pix >> 4), gw = w0 + (pix & 15);
-    if (gh < p.H && gw < p.W) {
-      float v0 = acc0[r], v1 = acc1[r];
-      TY* yp = yimg + ((int64_t)gh * p.W + gw) * p.ys;
-      if constexpr (std::is_same<TY, float>::value) {
-        if (p.accumulate) {
-          const float2 o = *reinterpret_cast<const float2*>(yp);
-          v0 += o.x; v1 += o.y;
-        }
-        *reinterpret_cast<float2*>(yp) = make_float2(v0, v1);
-      } else {
-        *reinterpret_cast<uint32_t*>(yp) = unetk_pk_bf16(v0, v1);
-      }
-      s0 += v0; s1 += v1; q0 += v0 * v0; q1 += v1 * v1;
+    for (int j = 0; j < NH; ++j) {
+      const int i = tid + j * 256;
+      const int pix = i / CIN, ci = i - pix * CIN;
+      const int ih = h0 + pix / 18 - 1, iw = w0 + pix % 18 - 1;
+      hreg[j] = (i < 180 * CIN && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) ? p.x[ximg + ((int64_t)ih * p.W + iw) * p.xs + ci] : 0.f;
     }
-  }
-  if (p.stat != nullptr) {
-    s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32); q0 += __shfl_xor(q0, 32); q1 += __shfl_xor(q1, 32);
-    if (h == 0) {
-      red[(0 * 4 + wave) * COUT + 2 * l31] = s0; red[(0 * 4 + wave) * COUT + 2 * l31 + 1] = s1;
-      red[(1 * 4 + wave) * COUT + 2 * l31] = q0; red[(1 * 4 + wave) * COUT + 2 * l31 + 1] = q1;
+  };
+  if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
+  for (int mtile = blockIdx.x; mtile < n_tiles; mtile += gridDim.x) {
+    const int tw_i = mtile % p.tiles_w;
+    const int th_i = (mtile / p.tiles_w) % p.tiles_h;
+    const int n_img = mtile / (p.tiles_w * p.tiles_h);
+    const int h0 = th_i * 8, w0 = tw_i * TW;
+    __syncthreads();                         // the previous tile's halo and statistic rows have been read
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const int i = tid + j * 256;
+      if (i < 180 * CIN) halo[i] = hreg[j];
     }
     __syncthreads();
-    if (tid < 2 * COUT) {
-      const int k = tid / COUT, c = tid - k * COUT;
-      p.stat[((int64_t)k * p.stat_rows + mtile) * COUT + c] =
-          red[(k * 4 + 0) * COUT + c] + red[(k * 4 + 1) * COUT + c] + red[(k * 4 + 2) * COUT + c] + red[(k * 4 + 3) * COUT + c];
+    if (mtile + (int)gridDim.x < n_tiles) fetch(mtile + gridDim.x);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+      const float a = halo[aoff[s2]];          // k >= K: b is zero, any finite a will do
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[s2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[s2], acc1, 0, 0, 0);
+    }
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    TY* yimg = reinterpret_cast<TY*>(p.y) + p.ya.off(n_img) + 2 * l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pix = wave * 32 + mfma32_row(r, h);
+      const int gh = h0 + (pix >> 4), gw = w0 + (pix & 15);
+      if (gh < p.H && gw < p.W) {
+        float v0 = acc0[r], v1 = acc1[r];
+        TY* yp = yimg + ((int64_t)gh * p.W + gw) * p.ys;
+        if constexpr (std::is_same<TY, float>::value) {
+          if (p.accumulate) {
+            const float2 o = *reinterpret_cast<const float2*>(yp);
+            v0 += o.x; v1 += o.y;
+          }
+          *reinterpret_cast<float2*>(yp) = make_float2(v0, v1);
+        } else {
+          *reinterpret_cast<uint32_t*>(yp) = unetk_pk_bf16(v0, v1);
+        }
+        s0 += v0; s1 += v1; q0 += v0 * v0; q1 += v1 * v1;
+      }
+    }
+    if (p.stat != nullptr) {
+      s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32); q0 += __shfl_xor(q0, 32); q1 += __shfl_xor(q1, 32);
+      if (h == 0) {
+        red[(0 * 4 + wave) * COUT + 2 * l31] = s0; red[(0 * 4 + wave) * COUT + 2 * l31 + 1] = s1;
+        red[(1 * 4 + wave) * COUT + 2 * l31] = q0; red[(1 * 4 + wave) * COUT + 2 * l31 + 1] = q1;
+      }
+      __syncthreads();
+      if (tid < 2 * COUT) {
+        const int k = tid / COUT, c = tid - k * COUT;
+        p.stat[((int64_t)k * p.stat_rows + mtile) * COUT + c] =
+            red[(k * 4 + 0) * COUT + c] + red[(k * 4 + 1) * COUT + c] + red[(k * 4 + 2) * COUT + c] + red[(k * 4 + 3) * COUT + c];
+      }
     }
   }
 }
@@ -679,10 +701,11 @@ int unetk_conv_run(ConvParams p, hipStream_t st) {
   if (lds > 64 * 1024) return UNETK_E_UNSUPPORTED;
   if (p.Cout == 64 && p.Cin >= 1 && p.Cin <= 5) {      // first layers: the matrix-pipe variant
     const size_t l3 = ((size_t)((180 * p.Cin + 3) & ~3) + 2 * 4 * 64) * sizeof(float);
+    const int c3_grid = n_mtiles < 256 * 6 ? n_mtiles : 256 * 6;      // persistent: six resident blocks per CU walk the tiles
 #define C3_LAUNCH(CI)                                                                                              \
   case CI:                                                                                                         \
-    if (p.ybf16) hipLaunchKernelGGL((conv3x3_c3_mfma_kernel<CI, bf16_t>), dim3(n_mtiles), dim3(256), l3, st, p);   \
-    else hipLaunchKernelGGL((conv3x3_c3_mfma_kernel<CI, float>), dim3(n_mtiles), dim3(256), l3, st, p);            \
+    if (p.ybf16) hipLaunchKernelGGL((conv3x3_c3_mfma_kernel<CI, bf16_t>), dim3(c3_grid), dim3(256), l3, st, p);   \
+    else hipLaunchKernelGGL((conv3x3_c3_mfma_kernel<CI, float>), dim3(c3_grid), dim3(256), l3, st, p);            \
     break;
     if (p.ybf16 && p.accumulate) return UNETK_E_UNSUPPORTED;
     switch (p.Cin) { C3_LAUNCH(1) C3_LAUNCH(2) C3_LAUNCH(3) C3_LAUNCH(4) C3_LAUNCH(5) default: break; }
