@@ -121,26 +121,30 @@ def _cpu_oracle_steps(size, n_classes, bs, warm, timed):
     return statistics.median(times)
 
 
-def cpu_baseline(size, timed=3):
+def cpu_baseline(size, full=False):
     """SURVEY.md 8d "CPU baseline beside it": the reference's own TF-1.13 CPU path cannot run (TensorFlow is not
-    installable), so the labelled substitute is the oracle on this host's cores: BASELINE.json configs[0]
-    (Liver only = 2 classes, bs 2) and the configs[1]-shaped workload at bs 2 (3 classes), fwd+bwd+TF-Adam, median of
-    `timed` steps after one warm-up each, plus the configs[1] shape at bs 8 (two timed steps: ~1 minute of CPU work in
-    all).  `value` is the configs[1]-shaped bs-2 one (the metric's workload)."""
+    installable), so the labelled substitute is the oracle on this host's cores, fwd+bwd+TF-Adam: the
+    configs[1]-shaped workload at bs 2 (3 classes; median of 2 timed steps after one warm-up) = `value`, and BASELINE.json
+    configs[0] (Liver only = 2 classes, bs 2; one timed step after one warm-up) -- ~25 s of CPU work in all, so the default
+    run is not mostly oracle.  --cpu-baseline-full adds the configs[1] shape at bs 8 (SURVEY.md 8d "bs 2 and bs 8", ~40 s more)."""
     threads = torch.get_num_threads()
     bs = 2
-    dt1 = _cpu_oracle_steps(size, 3, bs, 1, timed)
-    dt0 = _cpu_oracle_steps(size, 2, bs, 1, timed)
-    dt8 = _cpu_oracle_steps(size, 3, 8, 1, 2)          # SURVEY.md 8d: "bs 2 and bs 8"
-    return {"value": round(bs / dt1, 4), "unit": "slices/s", "cores": threads, "kind": "port",
-            "bs8": {"value": round(8 / dt8, 4), "unit": "slices/s",
-                    "sample": "same workload at bs 8, median of 2 timed steps after 1 warm-up, {:.2f} s/step".format(dt8)},
-            "sample": "oracle (PyTorch-CPU restatement, not TF): UNet {0}x{0}x3 3-class bs {1} (configs[1] shape at bs 2), "
-                      "fwd+bwd+Adam, median of {2} timed steps after 1 warm-up, {3:.2f} s/step, {4} torch threads, "
-                      "host os.cpu_count()={5}".format(size, bs, timed, dt1, threads, os.cpu_count()),
-            "cfg0": {"value": round(bs / dt0, 4), "unit": "slices/s",
-                     "sample": "same, BASELINE.json configs[0]: Liver only (2 classes) bs 2, median of {} steps, "
-                               "{:.2f} s/step".format(timed, dt0)}}
+    t_start = time.perf_counter()
+    dt1 = _cpu_oracle_steps(size, 3, bs, 1, 2)
+    dt0 = _cpu_oracle_steps(size, 2, bs, 1, 1)
+    out = {"value": round(bs / dt1, 4), "unit": "slices/s", "cores": threads, "kind": "port",
+           "sample": "oracle (PyTorch-CPU restatement, not TF): UNet {0}x{0}x3 3-class bs {1} (configs[1] shape at bs 2), "
+                     "fwd+bwd+Adam, median of 2 timed steps after 1 warm-up, {2:.2f} s/step, {3} torch threads, "
+                     "host os.cpu_count()={4}".format(size, bs, dt1, threads, os.cpu_count()),
+           "cfg0": {"value": round(bs / dt0, 4), "unit": "slices/s",
+                    "sample": "same, BASELINE.json configs[0]: Liver only (2 classes) bs 2, 1 timed step after 1 warm-up, "
+                              "{:.2f} s/step".format(dt0)}}
+    if full:
+        dt8 = _cpu_oracle_steps(size, 3, 8, 1, 2)
+        out["bs8"] = {"value": round(8 / dt8, 4), "unit": "slices/s",
+                      "sample": "same workload at bs 8, median of 2 timed steps after 1 warm-up, {:.2f} s/step".format(dt8)}
+    out["wall_s"] = round(time.perf_counter() - t_start, 1)
+    return out
 
 
 def main():
@@ -151,6 +155,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="slices per GPU per step")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the oracle at bs 8 (~40 s more of CPU work)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP-event timing")
     ap.add_argument("--detail", action="store_true", help="break the kernel table down by layer shape")
     ap.add_argument("--model", default="UNet", choices=["UNet", "GUNet", "UNet3D", "UNetInter", "LGNet", "SmallUNet", "InterUNet"],
@@ -260,27 +265,41 @@ def main():
         solver(loss, model)
         return loss
 
-    for _ in range(a.warmup):
-        one_step()
-
-    # per-launch HIP events (the roofline block): on every fourth step of the timed region -- each event pair is host work and a
-    # marker packet in the stream (0.25 ms per step over ~60 matrix launches: 0.3 % of the fp32 step, 2 % of the bf16 one), and
-    # the metric should carry as little of its own instrumentation as possible; five sampled steps of 20 give 100+ launches
-    # of the dominant kernel
+    # The roofline block: on every fourth step of the timed region the library's kernel trace is on (csrc/prof.hip): each
+    # launch then carries start / stop events bound to its DISPATCH (hipExtLaunchKernelGGL), so a kernel's duration is the GPU's
+    # own begin -> end interval -- what rocprofv3 --kernel-trace reports -- and no host gap can land in it (round 3 bracketed
+    # the C-ABI call with hipEventRecord pairs, which swallow the host's time whenever the stream has drained:
+    # tools/probe_ext_events.hip).  A traced launch costs ~7 us more host time, hence the sampling; the events are created
+    # before the timed region, sized by the launch count of the LAST warm-up step (traced for that purpose).
     prof_list = [] if (rank == 0 and not a.no_kernel_events) else None
     ev_stride = 1 if a.steps <= 4 else 4
     n_ev_steps = len(range(0, a.steps, ev_stride))
-    ops.PROFILE = None
     ops.PROFILE_SHAPES = bool(a.detail)
+    launches_per_step = 4096
+    for j in range(a.warmup):
+        if j == a.warmup - 1 and prof_list is not None:
+            ops.profile_begin(0)
+            ops.profile_on([])
+        one_step()
+    if prof_list is not None:
+        ops.profile_on(None)
+        torch.cuda.synchronize()
+        if a.warmup > 0:
+            launches_per_step = ops._abi.lib().unetk_prof_mark()
+        ops.profile_begin(launches_per_step * n_ev_steps + 64)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]   # per-step HIP events (no host sync)
+    host_ms = []
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(a.steps):
-        ops.PROFILE = prof_list if i % ev_stride == 0 else None
+        if prof_list is not None:
+            ops.profile_on(prof_list if i % ev_stride == 0 else None)
+        h0 = time.perf_counter()
         loss = one_step()
+        host_ms.append((time.perf_counter() - h0) * 1e3)
         marks[i + 1].record()
     torch.cuda.synchronize()
     own = time.perf_counter() - t0                  # this rank's own time for its K steps
@@ -288,19 +307,9 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     prof = prof_list
-    ops.PROFILE = None
+    ops.profile_on(None)
     loss_val = float(loss.detach())
-    # the HBM-bound passes (norm / pool / head / first layer / optimiser) by algorithmic bytes: three more steps, outside the
-    # timed region (their event pairs are host work the metric must not carry)
-    prof_hbm = None
-    if not a.no_kernel_events:             # every rank steps (the all-reduce is collective); rank 0 records
-        if prof is not None:
-            ops.PROFILE, ops.PROFILE_HBM = [], True
-        for _ in range(3):
-            one_step()
-        torch.cuda.synchronize()
-        if prof is not None:
-            prof_hbm, ops.PROFILE, ops.PROFILE_HBM = ops.PROFILE, None, False
+    trace_ms, trace_names = ops.profile_read() if prof is not None else ([], [])
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
     rank_ms, n_ranks_seen = [own / a.steps * 1e3], 1
     if world > 1:
@@ -332,11 +341,11 @@ def main():
         torch.cuda.synchronize()
         tc = time.perf_counter()
         for j in range(4):
-            ops.PROFILE = [] if (prof is not None and j % ev_stride == 0) else None
+            ops.profile_on([] if (prof is not None and j % ev_stride == 0) else None)
             one_step()
         torch.cuda.synchronize()
         dp_diag["compute_only_ms_per_step"] = round((time.perf_counter() - tc) / 4 * 1e3, 3)
-        ops.PROFILE = None
+        ops.profile_on(None)
         dp_diag["backend"] = backend
         dist.barrier()
 
@@ -373,24 +382,49 @@ def main():
         if dp_diag is not None:
             dp_diag["dp_efficiency_vs_compute_only"] = round(dp_diag["compute_only_ms_per_step"] / ms, 4)
             out["data_parallel"] = dp_diag
+        ev_steps = [step_ms[i] for i in range(a.steps) if i % ev_stride == 0]
+        plain_steps = [step_ms[i] for i in range(a.steps) if i % ev_stride != 0] or ev_steps
+        out["step_ms_event_steps"] = round(statistics.median(ev_steps), 3)      # steps whose launches carried events
+        out["step_ms_plain_steps"] = round(statistics.median(plain_steps), 3)   # steps without
+        # host time to ENQUEUE a step (no sync inside): far below the step time = the GPU never waits for the host
+        host_plain = [host_ms[i] for i in range(a.steps) if i % ev_stride != 0] or host_ms
+        out["host_ms_per_step"] = round(statistics.median(host_plain), 3)
+        out["host_ms_per_traced_step"] = round(statistics.median([host_ms[i] for i in range(a.steps) if i % ev_stride == 0]), 3)
         if prof:
-            agg, hbm = {}, {}
-            for tag, flops, e0, e1, nbytes in (prof_hbm or []):
-                if nbytes:                      # HBM-bound passes: algorithmic bytes (each operand once) / time
-                    h = hbm.setdefault(tag, [0, 0.0, 0.0])
+            # op brackets -> (tag, FLOPs, bytes, kernel time = sum of the dispatches the call launched, its longest kernel)
+            agg, hbm, by_name, main_of = {}, {}, {}, {}
+            covered = 0.0
+            for tag, flops, i0, i1, nbytes in prof:
+                ms_in = trace_ms[i0:i1]
+                secs = sum(ms_in) * 1e-3
+                covered += secs
+                if flops > 0:
+                    d = agg.setdefault(tag, [0, 0.0, 0.0])
+                    d[0] += 1
+                    d[1] += flops
+                    d[2] += secs
+                    if ms_in:       # the call's matrix kernel = its longest dispatch, when that IS the call (a filter gradient and
+                        j = max(range(len(ms_in)), key=ms_in.__getitem__)     # its slab reduction; not the three GEMMs of a
+                        if ms_in[j] >= 0.8 * sum(ms_in):                      # transposed conv's backward: those stay by op tag)
+                            main_of[i0 + j] = flops
+                if nbytes:                                    # HBM-bound passes: algorithmic bytes (each operand once) / time
+                    h = hbm.setdefault(tag, [0, 0, 0.0])
                     h[0] += 1
                     h[1] += nbytes
-                    h[2] += e0.elapsed_time(e1) * 1e-3
-            for tag, flops, e0, e1, nbytes in prof:
-                secs = e0.elapsed_time(e1) * 1e-3
-                d = agg.setdefault(tag, [0, 0.0, 0.0])
-                d[0] += 1
-                d[1] += flops
-                d[2] += secs
+                    h[2] += secs
+            for j, (ms_j, name) in enumerate(zip(trace_ms, trace_names)):
+                r = by_name.setdefault(name, [0, 0.0, 0.0])
+                r[0] += 1
+                r[1] += ms_j
+                r[2] += main_of.get(j, 0.0)
+            total_kernel_ms = sum(trace_ms) / n_ev_steps
+            out["traced_launches_per_step"] = len(trace_ms) // n_ev_steps
+            out["gpu_kernel_ms_per_step"] = round(total_kernel_ms, 3)           # every kernel of the library, own GPU time
+            out["gpu_kernel_ms_outside_op_brackets"] = round(total_kernel_ms - covered * 1e3 / n_ev_steps, 3)
             out["hbm_kernels"] = sorted(
                 [{"kernel": tag, "launches": cnt, "avg_launch_ms": round(secs / cnt * 1e3, 4), "avg_launch_mbytes": round(nb / cnt / 1e6, 2),
                   "achieved_gbps": round(nb / secs / 1e9, 1), "frac_of_hbm_peak": round(nb / secs / HBM_PEAK_BPS, 4),
-                  "total_ms_per_step": round(secs / 3 * 1e3, 3)} for tag, (cnt, nb, secs) in hbm.items()],
+                  "total_ms_per_step": round(secs / n_ev_steps * 1e3, 3)} for tag, (cnt, nb, secs) in hbm.items() if secs > 0],
                 key=lambda k: -k["total_ms_per_step"])
             kern = []
             for tag, (cnt, flops, secs) in agg.items():
@@ -398,37 +432,41 @@ def main():
                              "avg_launch_gflop": round(flops / cnt / 1e9, 3),
                              "achieved_tflops": round(flops / secs / 1e12, 2), "total_ms_per_step": round(secs / n_ev_steps * 1e3, 3)})
             kern.sort(key=lambda k: -k["total_ms_per_step"])
-            top = kern[0]
-            kpeak = BF16_PEAK_TFLOPS if "bf16" in top["kernel"] else FP32_PEAK_TFLOPS
-            out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved_tflops"],
+            # the same launches by their REAL kernel names (one row per instantiation, as rocprofv3 --stats prints them)
+            trace = []
+            for name, (cnt, ms_sum, flops) in by_name.items():
+                row = {"name": name, "calls": cnt, "avg_ms": round(ms_sum / cnt, 4), "total_ms_per_step": round(ms_sum / n_ev_steps, 3)}
+                if flops > 0:
+                    row["avg_gflop"] = round(flops / cnt / 1e9, 3)
+                    row["achieved_tflops"] = round(flops / ms_sum / 1e9, 2)
+                trace.append(row)
+            trace.sort(key=lambda r: -r["total_ms_per_step"])
+            sum_tables = sum(k["total_ms_per_step"] for k in kern) + sum(k["total_ms_per_step"] for k in out["hbm_kernels"]
+                                                                         if k["kernel"] not in agg)
+            out["sum_kernels_plus_hbm_kernels_ms"] = round(sum_tables, 3)
+            out["kernels_fit_step"] = bool(sum_tables <= ms and total_kernel_ms <= out["step_ms_event_steps"])
+            top = next(r for r in trace if "achieved_tflops" in r)         # the matrix kernel with the most time in the step
+            kpeak = BF16_PEAK_TFLOPS if "bf16" in top["name"] else FP32_PEAK_TFLOPS
+            out["roofline"] = {"bound": "mfma", "kernel": top["name"], "achieved": top["achieved_tflops"],
                                "peak": kpeak, "unit": "TFLOP/s",
                                "frac": round(top["achieved_tflops"] / kpeak, 4), "traffic": None,
-                               "avg_launch_ms": top["avg_launch_ms"], "avg_launch_gflop": top["avg_launch_gflop"]}
+                               "avg_launch_ms": top["avg_ms"], "avg_launch_gflop": top["avg_gflop"], "launches": top["calls"],
+                               "timing": "start/stop events bound to each dispatch (hipExtLaunchKernelGGL) on the launch stream, "
+                                         "{} of the {} timed steps".format(n_ev_steps, a.steps)}
             out["kernels"] = kern
+            out["kernel_trace"] = trace[:24]
             # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside the process, so it
             # comes from the committed rocprofv3 --pmc summary of this same command (profiles/rNN_pmc_traffic*.json,
             # tools/pmc_summary.py; newest round wins) and ONLY when that file names this exact kernel -- else null.
             try:
                 import glob
-                import re
                 suffix = {"fp32": "", "bf16": "_bf16", "bf16c": "_bf16c"}[a.dtype]
                 files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic" + suffix + ".json")))
                 pmc = json.load(open(files[-1]))["kernels"] if files else {}
-                # the tag names the tile configuration; the PMC table lists its instantiations separately (<..., S = 1, DIL = 1,
-                # MODE>: plain / accumulating / fused-reduction epilogue; <..., BS, NBR> for bf16): launch-weighted mean
-                groups = {}
-                for k, v in pmc.items():
-                    t = k.replace(" ", "")
-                    if t.startswith("conv3x3_bf16s_kernel<"):            # round-3 kernel: <NT8, NBR> -> the bench tag <NT8[,nbr]>
-                        t = t.replace(",false>", ">").replace(",true>", ",nbr>")
-                    elif t.startswith("conv3x3_wgrad_bf16s_kernel<"):    # <PF>: one tag
-                        t = "conv3x3_wgrad_bf16s_kernel"
-                    else:
-                        t = re.sub(r"(,1,1,[012]|,true,(true|false)|(,1)+)>$", lambda m: ",true>" if "true" in m.group(0)[:6] else ">", t)
-                    g = groups.setdefault(t, [0, 0.0])
-                    g[0] += v["launches"]
-                    g[1] += v["launches"] * v["hbm_bytes_per_launch_corrected"]
-                key = groups.get(top["kernel"].split("(")[0].replace(" ", ""))
+                # the PMC table is keyed like rocprofv3's kernel names minus "void ", the anonymous namespace and the arguments
+                want = top["name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                hit = pmc.get(want)
+                key = (hit["launches"], hit["launches"] * hit["hbm_bytes_per_launch_corrected"]) if hit else None
                 shape_ok = (a.size, a.batch) == ((256, 32) if a.dtype == "fp32" else (512, 8))     # the shapes the PMC passes ran
                 if key and key[0] and shape_ok and a.model == "UNet":
                     out["roofline"]["traffic"] = round(key[1] / key[0])
@@ -437,7 +475,7 @@ def main():
             except (OSError, KeyError, ValueError, IndexError):
                 pass
         if not a.no_cpu_baseline and world == 1 and a.model == "UNet":
-            out["cpu_baseline"] = cpu_baseline(a.size)
+            out["cpu_baseline"] = cpu_baseline(a.size, a.cpu_baseline_full)
         print(json.dumps(out, ensure_ascii=False), flush=True)
     if dp_on:
         dist.destroy_process_group()

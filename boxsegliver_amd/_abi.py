@@ -12,7 +12,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 _LIB = None
 LIB_PATH = os.environ.get("UNETK_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libunetk.so")
 
-ABI_VERSION = 7            # must equal unetk_abi_version() of the loaded library (checked in lib())
+ABI_VERSION = 8            # must equal unetk_abi_version() of the loaded library (checked in lib())
 UNETK_MAX_CLASSES = 8
 W_NONE, W_NUMERICAL, W_PROPORTION, W_PIXELMAP = 0, 1, 2, 3
 
@@ -62,6 +62,11 @@ P = c_void_p
 _SIGNATURES = {
     "unetk_lits_batch": (c_int, [POINTER(LitsDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "unetk_abi_version": (c_int, []),
+    "unetk_prof_reset": (c_int, [c_int]),
+    "unetk_prof_enable": (c_int, [c_int]),
+    "unetk_prof_mark": (c_int, []),
+    "unetk_prof_read": (c_int, [c_int, c_int, POINTER(c_float)]),
+    "unetk_prof_name": (c_int, [c_int, ctypes.c_char_p, c_int]),
     "unetk_error_string": (c_char_p, [c_int]),
     "unetk_conv3x3_pack": (c_int, [P, c_int, c_int, P, P, P]),
     "unetk_pack_item_blocks": (c_int, [c_int, c_int, c_int]),

@@ -9,7 +9,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function ${UNETK_EXTRA_FLAGS:-}"
 objs=()
 pids=()
-for src in conv_igemm conv_igemm_lin conv_igemm_bf16 conv_igemm_bf16s conv_wgrad conv_wgrad_bf16s conv3d deconv norm reduce pool head weights lits fc conv1d pack optim; do
+for src in conv_igemm conv_igemm_lin conv_igemm_bf16 conv_igemm_bf16s conv_wgrad conv_wgrad_bf16s conv3d deconv norm reduce pool head weights lits fc conv1d pack optim prof; do
   o="$ROOT/build/$src.o"
   if [[ ! -f "$o" || "$HERE/$src.hip" -nt "$o" || "$HERE/common.h" -nt "$o" || "$HERE/pack.h" -nt "$o" || "$ROOT/include/unetk.h" -nt "$o" ]]; then
     rm -f "$o"                                  # a failed compile must not leave a stale object for the link

@@ -1,9 +1,26 @@
 // Shared device/host helpers for libunetk (gfx950 only).
 #pragma once
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "unetk.h"
+
+// Every kernel launch of the library.  With the kernel trace on (prof.hip, unetk_prof_enable: bench.py's roofline block) the
+// dispatch carries a start / stop event pair bound to the kernel itself, so its duration is the GPU's own begin -> end
+// interval, independent of what the host does around the launch; off (always, outside bench.py) it is hipLaunchKernelGGL.
+extern int g_unetk_prof_on;
+void unetk_prof_pair(const void* fn, hipEvent_t* a, hipEvent_t* b);
+#define UNETK_LAUNCH(kern, grid, block, lds, st, ...)                                                   \
+  do {                                                                                                  \
+    if (__builtin_expect(g_unetk_prof_on, 0)) {                                                         \
+      hipEvent_t pa_, pb_;                                                                              \
+      unetk_prof_pair(reinterpret_cast<const void*>(kern), &pa_, &pb_);                                 \
+      hipExtLaunchKernelGGL(kern, grid, block, lds, st, pa_, pb_, 0, __VA_ARGS__);                      \
+    } else {                                                                                            \
+      hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                      \
+    }                                                                                                   \
+  } while (0)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

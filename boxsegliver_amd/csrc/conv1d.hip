@@ -128,7 +128,7 @@ extern "C" int unetk_conv1d_fwd(const float* x, const float* w, const float* b, 
                                 int k, int relu, void* stream) {
   UNETK_REQUIRE(x && w && y && B > 0 && L > 0 && Cin > 0 && Cout > 0);
   if (k != 1 && k != 3) return UNETK_E_UNSUPPORTED;
-  hipLaunchKernelGGL(conv1d_fwd_kernel, dim3(ew_blocks((int64_t)B * L * Cout)), dim3(256), 0, (hipStream_t)stream, x, w, b,
+  UNETK_LAUNCH(conv1d_fwd_kernel, dim3(ew_blocks((int64_t)B * L * Cout)), dim3(256), 0, (hipStream_t)stream, x, w, b,
                      y, B, L, Cin, Cout, k, relu);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
@@ -140,13 +140,13 @@ extern "C" int unetk_conv1d_bwd(const float* x, const float* w, const float* y, 
   if (k != 1 && k != 3) return UNETK_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int64_t n = (int64_t)B * L * Cout;
-  hipLaunchKernelGGL(conv1d_bwd_pre_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, y, dy, dpre_ws, n, relu);
+  UNETK_LAUNCH(conv1d_bwd_pre_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, y, dy, dpre_ws, n, relu);
   UNETK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(conv1d_bwd_w_kernel, dim3(ew_blocks((int64_t)k * Cin * Cout)), dim3(256), 0, st, x, dpre_ws, dw, db, B,
+  UNETK_LAUNCH(conv1d_bwd_w_kernel, dim3(ew_blocks((int64_t)k * Cin * Cout)), dim3(256), 0, st, x, dpre_ws, dw, db, B,
                      L, Cin, Cout, k);
   UNETK_LAUNCH_CHECK();
   if (dx) {
-    hipLaunchKernelGGL(conv1d_bwd_x_kernel, dim3(ew_blocks((int64_t)B * L * Cin)), dim3(256), 0, st, dpre_ws, w, dx, B, L,
+    UNETK_LAUNCH(conv1d_bwd_x_kernel, dim3(ew_blocks((int64_t)B * L * Cin)), dim3(256), 0, st, dpre_ws, w, dx, B, L,
                        Cin, Cout, k);
     UNETK_LAUNCH_CHECK();
   }
@@ -155,7 +155,7 @@ extern "C" int unetk_conv1d_bwd(const float* x, const float* w, const float* y, 
 
 extern "C" int unetk_maxpool1d_fwd(const float* x, float* y, int B, int L, int C, void* stream) {
   UNETK_REQUIRE(x && y && B > 0 && L > 0 && C > 0);
-  hipLaunchKernelGGL(maxpool1d_fwd_kernel, dim3(ew_blocks((int64_t)B * ((L + 1) / 2) * C)), dim3(256), 0,
+  UNETK_LAUNCH(maxpool1d_fwd_kernel, dim3(ew_blocks((int64_t)B * ((L + 1) / 2) * C)), dim3(256), 0,
                      (hipStream_t)stream, x, y, B, L, C);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
@@ -163,7 +163,7 @@ extern "C" int unetk_maxpool1d_fwd(const float* x, float* y, int B, int L, int C
 
 extern "C" int unetk_maxpool1d_bwd(const float* x, const float* dy, float* dx, int B, int L, int C, void* stream) {
   UNETK_REQUIRE(x && dy && dx && B > 0 && L > 0 && C > 0);
-  hipLaunchKernelGGL(maxpool1d_bwd_kernel, dim3(ew_blocks((int64_t)B * ((L + 1) / 2) * C)), dim3(256), 0,
+  UNETK_LAUNCH(maxpool1d_bwd_kernel, dim3(ew_blocks((int64_t)B * ((L + 1) / 2) * C)), dim3(256), 0,
                      (hipStream_t)stream, x, dy, dx, B, L, C);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;

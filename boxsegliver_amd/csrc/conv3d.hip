@@ -269,7 +269,7 @@ extern "C" int unetk_conv3d_fwd(const unetk_conv3d_desc* d, const float* x, cons
     const ColMap m = unetk_colmap(d->Cout);
     if (d->Cout > 1024) return UNETK_E_UNSUPPORTED;
     const size_t lds = stat_partials ? (size_t)2 * m.rows_per_iter * d->Cout * sizeof(float) : 0;
-    hipLaunchKernelGGL(subsample2_stats_kernel, dim3(d->N * SUB_BPS), dim3(256), lds, st, T, y, stat_partials, g.Do,
+    UNETK_LAUNCH(subsample2_stats_kernel, dim3(d->N * SUB_BPS), dim3(256), lds, st, T, y, stat_partials, g.Do,
                        d->H, d->W, g.Ho, g.Wo, d->Cout, d->y_stride, g.off_h, g.off_w, m.cq_n, m.rows_per_iter, SUB_BPS,
                        d->N * SUB_BPS);
     UNETK_LAUNCH_CHECK();
@@ -293,7 +293,7 @@ int dilated_dy(const unetk_conv3d_desc* d, const Geo3& g, const float* dy, void*
   const int64_t npix_out = (int64_t)d->N * g.Do * g.Ho * g.Wo;
   int64_t grid = (npix_out * (d->Cout / 4) + 255) / 256;
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(dilate2_kernel, dim3((int)grid), dim3(256), 0, st, dy, d->y_stride, Z, npix_out, d->H, d->W, g.Ho,
+  UNETK_LAUNCH(dilate2_kernel, dim3((int)grid), dim3(256), 0, st, dy, d->y_stride, Z, npix_out, d->H, d->W, g.Ho,
                      g.Wo, d->Cout, g.off_h, g.off_w);
   UNETK_LAUNCH_CHECK();
   *z = Z;

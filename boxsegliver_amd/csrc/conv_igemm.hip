@@ -598,7 +598,7 @@ int launch_igemm_mode(const ConvParams& p, int n_mtiles, hipStream_t st) {
     attr_done = true;
   }
   const int grid = n_mtiles * p.n_ntiles;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, st, p);
+  UNETK_LAUNCH(kern, dim3(grid), dim3(WM * WN * 64), lds, st, p);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
@@ -704,8 +704,8 @@ int unetk_conv_run(ConvParams p, hipStream_t st) {
     const int c3_grid = n_mtiles < 256 * 6 ? n_mtiles : 256 * 6;      // persistent: six resident blocks per CU walk the tiles
 #define C3_LAUNCH(CI)                                                                                              \
   case CI:                                                                                                         \
-    if (p.ybf16) hipLaunchKernelGGL((conv3x3_c3_mfma_kernel<CI, bf16_t>), dim3(c3_grid), dim3(256), l3, st, p);   \
-    else hipLaunchKernelGGL((conv3x3_c3_mfma_kernel<CI, float>), dim3(c3_grid), dim3(256), l3, st, p);            \
+    if (p.ybf16) UNETK_LAUNCH((conv3x3_c3_mfma_kernel<CI, bf16_t>), dim3(c3_grid), dim3(256), l3, st, p);   \
+    else UNETK_LAUNCH((conv3x3_c3_mfma_kernel<CI, float>), dim3(c3_grid), dim3(256), l3, st, p);            \
     break;
     if (p.ybf16 && p.accumulate) return UNETK_E_UNSUPPORTED;
     switch (p.Cin) { C3_LAUNCH(1) C3_LAUNCH(2) C3_LAUNCH(3) C3_LAUNCH(4) C3_LAUNCH(5) default: break; }
@@ -716,23 +716,23 @@ int unetk_conv_run(ConvParams p, hipStream_t st) {
   if (p.ybf16) {      // UNETK_BF16S first layer: fp32 image in, bf16 out
     if (p.accumulate) return UNETK_E_UNSUPPORTED;
     switch (p.Cin) {
-      case 1: hipLaunchKernelGGL((conv3x3_direct_kernel<1, bf16_t>), dim3(n_mtiles), dim3(256), lds, st, p); break;
-      case 2: hipLaunchKernelGGL((conv3x3_direct_kernel<2, bf16_t>), dim3(n_mtiles), dim3(256), lds, st, p); break;
-      case 3: hipLaunchKernelGGL((conv3x3_direct_kernel<3, bf16_t>), dim3(n_mtiles), dim3(256), lds, st, p); break;
-      case 4: hipLaunchKernelGGL((conv3x3_direct_kernel<4, bf16_t>), dim3(n_mtiles), dim3(256), lds, st, p); break;
-      case 5: hipLaunchKernelGGL((conv3x3_direct_kernel<5, bf16_t>), dim3(n_mtiles), dim3(256), lds, st, p); break;
-      default: hipLaunchKernelGGL((conv3x3_direct_kernel<0, bf16_t>), dim3(n_mtiles), dim3(256), lds, st, p); break;
+      case 1: UNETK_LAUNCH((conv3x3_direct_kernel<1, bf16_t>), dim3(n_mtiles), dim3(256), lds, st, p); break;
+      case 2: UNETK_LAUNCH((conv3x3_direct_kernel<2, bf16_t>), dim3(n_mtiles), dim3(256), lds, st, p); break;
+      case 3: UNETK_LAUNCH((conv3x3_direct_kernel<3, bf16_t>), dim3(n_mtiles), dim3(256), lds, st, p); break;
+      case 4: UNETK_LAUNCH((conv3x3_direct_kernel<4, bf16_t>), dim3(n_mtiles), dim3(256), lds, st, p); break;
+      case 5: UNETK_LAUNCH((conv3x3_direct_kernel<5, bf16_t>), dim3(n_mtiles), dim3(256), lds, st, p); break;
+      default: UNETK_LAUNCH((conv3x3_direct_kernel<0, bf16_t>), dim3(n_mtiles), dim3(256), lds, st, p); break;
     }
     UNETK_LAUNCH_CHECK();
     return UNETK_OK;
   }
   switch (p.Cin) {
-    case 1: hipLaunchKernelGGL(conv3x3_direct_kernel<1>, dim3(n_mtiles), dim3(256), lds, st, p); break;
-    case 2: hipLaunchKernelGGL(conv3x3_direct_kernel<2>, dim3(n_mtiles), dim3(256), lds, st, p); break;
-    case 3: hipLaunchKernelGGL(conv3x3_direct_kernel<3>, dim3(n_mtiles), dim3(256), lds, st, p); break;
-    case 4: hipLaunchKernelGGL(conv3x3_direct_kernel<4>, dim3(n_mtiles), dim3(256), lds, st, p); break;
-    case 5: hipLaunchKernelGGL(conv3x3_direct_kernel<5>, dim3(n_mtiles), dim3(256), lds, st, p); break;
-    default: hipLaunchKernelGGL(conv3x3_direct_kernel<0>, dim3(n_mtiles), dim3(256), lds, st, p); break;
+    case 1: UNETK_LAUNCH(conv3x3_direct_kernel<1>, dim3(n_mtiles), dim3(256), lds, st, p); break;
+    case 2: UNETK_LAUNCH(conv3x3_direct_kernel<2>, dim3(n_mtiles), dim3(256), lds, st, p); break;
+    case 3: UNETK_LAUNCH(conv3x3_direct_kernel<3>, dim3(n_mtiles), dim3(256), lds, st, p); break;
+    case 4: UNETK_LAUNCH(conv3x3_direct_kernel<4>, dim3(n_mtiles), dim3(256), lds, st, p); break;
+    case 5: UNETK_LAUNCH(conv3x3_direct_kernel<5>, dim3(n_mtiles), dim3(256), lds, st, p); break;
+    default: UNETK_LAUNCH(conv3x3_direct_kernel<0>, dim3(n_mtiles), dim3(256), lds, st, p); break;
   }
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
@@ -754,7 +754,7 @@ extern "C" int unetk_conv3x3_pack(const float* w, int Cin, int Cout, float* wp_f
   UNETK_REQUIRE(unetk_aligned16(w) && unetk_aligned16(wp_fwd) && unetk_aligned16(wp_dgrad));
   const int64_t total = (int64_t)9 * Cin * Cout / 4;
   const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, wp_fwd,
+  UNETK_LAUNCH(pack_conv3x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, wp_fwd,
                      wp_dgrad);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;

@@ -364,7 +364,7 @@ int launch_bf16(const ConvParams& p, int n_mtiles, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(n_mtiles * p.n_ntiles), dim3(WM * WN * 64), lds, st, p);
+  UNETK_LAUNCH(kern, dim3(n_mtiles * p.n_ntiles), dim3(WM * WN * 64), lds, st, p);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
@@ -438,7 +438,7 @@ extern "C" int unetk_conv3x3_pack_bf16(const float* w_hwio, int Cin, int Cout, v
   UNETK_REQUIRE((!wp_fwd || unetk_aligned16(wp_fwd)) && (!wp_dgrad || unetk_aligned16(wp_dgrad)));
   const int64_t total = (int64_t)9 * Cin * Cout / 8;
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(pack_conv3x3_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_hwio, Cin, Cout,
+  UNETK_LAUNCH(pack_conv3x3_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_hwio, Cin, Cout,
                      (uint4*)wp_fwd, (uint4*)wp_dgrad, 0);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
@@ -451,7 +451,7 @@ extern "C" int unetk_conv3x3_pack_bf16s(const float* w_hwio, int Cin, int Cout, 
   UNETK_REQUIRE((!wp_fwd || unetk_aligned16(wp_fwd)) && (!wp_dgrad || unetk_aligned16(wp_dgrad)));
   const int64_t total = (int64_t)9 * Cin * Cout / 8;
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(pack_conv3x3_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_hwio, Cin, Cout,
+  UNETK_LAUNCH(pack_conv3x3_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_hwio, Cin, Cout,
                      (uint4*)wp_fwd, (uint4*)wp_dgrad, 1);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;

@@ -559,7 +559,7 @@ static int launch_v3(const ConvParams& p, hipStream_t st) {
     n_cu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount : 8;
   }
   const int grid = p.ptiles < n_cu ? p.ptiles : n_cu;       // one resident block per CU (146 KB of LDS), >= 8 blocks
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_B, st, p);
+  UNETK_LAUNCH(kern, dim3(grid), dim3(512), LDS_B, st, p);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }

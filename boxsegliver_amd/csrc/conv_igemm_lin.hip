@@ -574,7 +574,7 @@ int launch_lin(const ConvParams& p, int n_mtiles, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(n_mtiles * p.n_ntiles), dim3(WM * WN * 64), lds, st, p);
+  UNETK_LAUNCH(kern, dim3(n_mtiles * p.n_ntiles), dim3(WM * WN * 64), lds, st, p);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
@@ -718,9 +718,9 @@ int launch_lin_sk(const ConvParams& p, const SkPlan& sk, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(sk.whole + sk.G), dim3(WM * WN * 64), lds, st, p);
+  UNETK_LAUNCH(kern, dim3(sk.whole + sk.G), dim3(WM * WN * 64), lds, st, p);
   UNETK_LAUNCH_CHECK();
-  hipLaunchKernelGGL((lin_sk_fixup_kernel<BM, BN>), dim3(sk.tiles - sk.whole), dim3(256), 0, st, p, sk.G);
+  UNETK_LAUNCH((lin_sk_fixup_kernel<BM, BN>), dim3(sk.tiles - sk.whole), dim3(256), 0, st, p, sk.G);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }

@@ -478,11 +478,11 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 int unetk_launch_slab_reduce(const float* slab, int S, int64_t n, float* dst, hipStream_t st) {
   const int64_t n4 = n >> 2;
   if (S >= 64) {
-    hipLaunchKernelGGL(slab_reduce_kernel<16>, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, slab, S, n, dst);
+    UNETK_LAUNCH(slab_reduce_kernel<16>, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, slab, S, n, dst);
   } else if (S >= 8) {
-    hipLaunchKernelGGL(slab_reduce_kernel<4>, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, slab, S, n, dst);
+    UNETK_LAUNCH(slab_reduce_kernel<4>, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, slab, S, n, dst);
   } else {
-    hipLaunchKernelGGL(slab_reduce_kernel<1>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, slab, S, n, dst);
+    UNETK_LAUNCH(slab_reduce_kernel<1>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, slab, S, n, dst);
   }
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
@@ -573,7 +573,7 @@ int launch_wgrad(const WgParams& p, int grid, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), WG_LDS_BYTES, st, p);
+  UNETK_LAUNCH(kern, dim3(grid), dim3(512), WG_LDS_BYTES, st, p);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
@@ -689,19 +689,19 @@ int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_
       if (e != hipSuccess) return (int)e;
       attr3 = true;
     }
-    if (p.Cout == 64) hipLaunchKernelGGL(conv3x3_wgrad_c3_kernel<64>, dim3(pl.S), dim3(256), lds3, st, p);
-    else hipLaunchKernelGGL(conv3x3_wgrad_c3_kernel<32>, dim3(pl.S), dim3(256), lds3, st, p);
+    if (p.Cout == 64) UNETK_LAUNCH(conv3x3_wgrad_c3_kernel<64>, dim3(pl.S), dim3(256), lds3, st, p);
+    else UNETK_LAUNCH(conv3x3_wgrad_c3_kernel<32>, dim3(pl.S), dim3(256), lds3, st, p);
     UNETK_LAUNCH_CHECK();
   } else {
     const int PL = 256 / p.Cout;
     const size_t lds = (size_t)PL * 9 * p.Cin * p.Cout * sizeof(float);
     if (lds > (p.Cin == 9 ? 150 : 64) * 1024) return UNETK_E_UNSUPPORTED;
     switch (p.Cin) {
-      case 1: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<1>, dim3(pl.S), dim3(256), lds, st, p); break;
-      case 2: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<2>, dim3(pl.S), dim3(256), lds, st, p); break;
-      case 3: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<3>, dim3(pl.S), dim3(256), lds, st, p); break;
-      case 4: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<4>, dim3(pl.S), dim3(256), lds, st, p); break;
-      case 5: hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<5>, dim3(pl.S), dim3(256), lds, st, p); break;
+      case 1: UNETK_LAUNCH(conv3x3_wgrad_smallc_kernel<1>, dim3(pl.S), dim3(256), lds, st, p); break;
+      case 2: UNETK_LAUNCH(conv3x3_wgrad_smallc_kernel<2>, dim3(pl.S), dim3(256), lds, st, p); break;
+      case 3: UNETK_LAUNCH(conv3x3_wgrad_smallc_kernel<3>, dim3(pl.S), dim3(256), lds, st, p); break;
+      case 4: UNETK_LAUNCH(conv3x3_wgrad_smallc_kernel<4>, dim3(pl.S), dim3(256), lds, st, p); break;
+      case 5: UNETK_LAUNCH(conv3x3_wgrad_smallc_kernel<5>, dim3(pl.S), dim3(256), lds, st, p); break;
       case 9: {
         static bool attr_done = false;
         if (!attr_done) {
@@ -710,7 +710,7 @@ int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_
           if (e != hipSuccess) return (int)e;
           attr_done = true;
         }
-        hipLaunchKernelGGL(conv3x3_wgrad_smallc_kernel<9>, dim3(pl.S), dim3(256), lds, st, p);
+        UNETK_LAUNCH(conv3x3_wgrad_smallc_kernel<9>, dim3(pl.S), dim3(256), lds, st, p);
         break;
       }
       default: return UNETK_E_UNSUPPORTED;

@@ -513,7 +513,7 @@ int unetk_wgrad_bf16s_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipS
   p.tiles_per_split = pl.tiles_per_split; p.n_ci_tiles = pl.n_ci_tiles; p.n_co_tiles = pl.n_co_tiles;
   if (pl.small) {
     const size_t lds3 = (size_t)(TH * TW * CT + HALO_PIX * 4) * sizeof(float);
-    hipLaunchKernelGGL(conv3x3_wgrad_c3_bf16s_kernel, dim3(pl.S), dim3(256), lds3, st, p);
+    UNETK_LAUNCH(conv3x3_wgrad_c3_bf16s_kernel, dim3(pl.S), dim3(256), lds3, st, p);
     UNETK_LAUNCH_CHECK();
   } else {
     static bool attr_done = false;
@@ -526,8 +526,8 @@ int unetk_wgrad_bf16s_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipS
     }
     static int deep = -1;          // UNETK_WGRAD_DEEP=1 (measurement): three tiles of load flight, first fragments behind the barrier
     if (deep < 0) { const char* e = getenv("UNETK_WGRAD_DEEP"); deep = e ? atoi(e) : 0; }
-    if (deep) hipLaunchKernelGGL(conv3x3_wgrad_bf16s_kernel<false>, dim3(pl.S * pl.n_ci_tiles * pl.n_co_tiles), dim3(512), LDS_B, st, p);
-    else hipLaunchKernelGGL(conv3x3_wgrad_bf16s_kernel<true>, dim3(pl.S * pl.n_ci_tiles * pl.n_co_tiles), dim3(512), LDS_B, st, p);
+    if (deep) UNETK_LAUNCH(conv3x3_wgrad_bf16s_kernel<false>, dim3(pl.S * pl.n_ci_tiles * pl.n_co_tiles), dim3(512), LDS_B, st, p);
+    else UNETK_LAUNCH(conv3x3_wgrad_bf16s_kernel<true>, dim3(pl.S * pl.n_ci_tiles * pl.n_co_tiles), dim3(512), LDS_B, st, p);
     UNETK_LAUNCH_CHECK();
   }
   if (pl.S == 1) return UNETK_OK;

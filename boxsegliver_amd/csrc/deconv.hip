@@ -815,7 +815,7 @@ int launch_pw_bf16(const PwParams& p, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr size_t lds = (size_t)(2 * BM * PSQ + 2 * (CKB / 8) * BN) * 16;
   const int n_mtiles = (p.M + BM - 1) / BM;
-  hipLaunchKernelGGL((pw_gemm_bf16_kernel<MODE, WM, WN, TM, TN, BS>), dim3(n_mtiles * p.n_ntiles), dim3(WM * WN * 64), lds, st,
+  UNETK_LAUNCH((pw_gemm_bf16_kernel<MODE, WM, WN, TM, TN, BS>), dim3(n_mtiles * p.n_ntiles), dim3(WM * WN * 64), lds, st,
                      p);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
@@ -826,7 +826,7 @@ int launch_pw(const PwParams& p, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr size_t lds = (size_t)(2 * BM * PS + 2 * CK * BN) * sizeof(float);
   const int n_mtiles = (p.M + BM - 1) / BM;
-  hipLaunchKernelGGL((pw_gemm_kernel<MODE, WM, WN, TM, TN>), dim3(n_mtiles * p.n_ntiles), dim3(WM * WN * 64), lds, st, p);
+  UNETK_LAUNCH((pw_gemm_kernel<MODE, WM, WN, TM, TN>), dim3(n_mtiles * p.n_ntiles), dim3(WM * WN * 64), lds, st, p);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
@@ -1024,7 +1024,7 @@ static int deconv_pack_bf16_impl(const float* w, int kd, int Cin, int Cout, void
   if (grid > 4096) grid = 4096;
   for (int a = 0; a < kd; ++a) {
     const int64_t o = (int64_t)a * Cin * Cout / 2;        // 16-B units per tap
-    hipLaunchKernelGGL(pack_deconv_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+    UNETK_LAUNCH(pack_deconv_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        w + (int64_t)a * 4 * Cin * Cout, Cin, Cout, wp_fwd ? (uint4*)wp_fwd + o : nullptr,
                        wp_dgrad ? (uint4*)wp_dgrad + o : nullptr, perm);
     UNETK_LAUNCH_CHECK();
@@ -1055,7 +1055,7 @@ extern "C" int unetk_deconv3d_pack(const float* w, int kd, int Cin, int Cout, fl
   if (grid > 4096) grid = 4096;
   for (int a = 0; a < kd; ++a) {
     const int64_t o = (int64_t)a * 4 * Cin * Cout;
-    hipLaunchKernelGGL(pack_deconv_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w + o, Cin, Cout,
+    UNETK_LAUNCH(pack_deconv_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w + o, Cin, Cout,
                        wp_fwd ? wp_fwd + o : nullptr, wp_dgrad ? wp_dgrad + o : nullptr);
     UNETK_LAUNCH_CHECK();
   }
@@ -1131,12 +1131,12 @@ extern "C" int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const void* xv, 
   // 1. ReLU backward over the whole up half + bias-grad partials
   const ColMap cm = unetk_colmap(d->Cout);
   if (bs)     // dpre is bf16 in the same workspace region (half of it used)
-    hipLaunchKernelGGL(relu_bwd_bias_kernel<bf16_t>, dim3(pl.nblk_bias), dim3(256),
+    UNETK_LAUNCH(relu_bwd_bias_kernel<bf16_t>, dim3(pl.nblk_bias), dim3(256),
                        (size_t)cm.rows_per_iter * d->Cout * sizeof(float), st, (const bf16_t*)catv, (const bf16_t*)dcatv,
                        d->out_stride, d->out_coff, (bf16_t*)dpre, bpart, (int64_t)4 * d->kd * M, d->Cout, cm.cq_n,
                        cm.rows_per_iter);
   else
-    hipLaunchKernelGGL(relu_bwd_bias_kernel<float>, dim3(pl.nblk_bias), dim3(256),
+    UNETK_LAUNCH(relu_bwd_bias_kernel<float>, dim3(pl.nblk_bias), dim3(256),
                        (size_t)cm.rows_per_iter * d->Cout * sizeof(float), st, cat, dcat, d->out_stride, d->out_coff, dpre,
                        bpart, (int64_t)4 * d->kd * M, d->Cout, cm.cq_n, cm.rows_per_iter);
   UNETK_LAUNCH_CHECK();
@@ -1163,7 +1163,7 @@ extern "C" int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const void* xv, 
     q.m_per_split = pl.m_per_split; q.n_co_tiles = (d->Cout + 63) / 64; q.n_ci_tiles = d->Cin / 64; q.da = da;
     const int grid = pl.S * 4 * q.n_co_tiles * q.n_ci_tiles;
     if (d->precision == UNETK_FP32) {
-      hipLaunchKernelGGL(deconv_wgrad4_kernel, dim3(pl.S * q.n_co_tiles * q.n_ci_tiles), dim3(256), 0, st, q);
+      UNETK_LAUNCH(deconv_wgrad4_kernel, dim3(pl.S * q.n_co_tiles * q.n_ci_tiles), dim3(256), 0, st, q);
       UNETK_LAUNCH_CHECK();
       rc = unetk_launch_slab_reduce(slab, pl.S, (int64_t)4 * d->Cin * d->Cout, dw + (int64_t)a * 4 * d->Cin * d->Cout, st);
       if (rc != UNETK_OK) return rc;
@@ -1187,13 +1187,13 @@ extern "C" int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const void* xv, 
         attr4 = true;
       }
       q.n_ci_tiles = d->Cin / 128;
-      hipLaunchKernelGGL(deconv_wgrad_bf16s4_kernel, dim3(pl.S * q.n_co_tiles * q.n_ci_tiles), dim3(512), (size_t)6 * 64 * 128, st, q);
+      UNETK_LAUNCH(deconv_wgrad_bf16s4_kernel, dim3(pl.S * q.n_co_tiles * q.n_ci_tiles), dim3(512), (size_t)6 * 64 * 128, st, q);
     } else if (bs)
-      hipLaunchKernelGGL(deconv_wgrad_bf16s_kernel, dim3(grid), dim3(256), (size_t)2 * 128 * 128, st, q);
+      UNETK_LAUNCH(deconv_wgrad_bf16s_kernel, dim3(grid), dim3(256), (size_t)2 * 128 * 128, st, q);
     else if (q.bf16)
-      hipLaunchKernelGGL(deconv_wgrad_kernel<true>, dim3(grid), dim3(256), (size_t)2 * 128 * 64 * sizeof(float), st, q);
+      UNETK_LAUNCH(deconv_wgrad_kernel<true>, dim3(grid), dim3(256), (size_t)2 * 128 * 64 * sizeof(float), st, q);
     else
-      hipLaunchKernelGGL(deconv_wgrad_kernel<false>, dim3(grid), dim3(256), (size_t)2 * 128 * 64 * sizeof(float), st, q);
+      UNETK_LAUNCH(deconv_wgrad_kernel<false>, dim3(grid), dim3(256), (size_t)2 * 128 * 64 * sizeof(float), st, q);
     UNETK_LAUNCH_CHECK();
     rc = unetk_launch_slab_reduce(slab, pl.S, (int64_t)4 * d->Cin * d->Cout, dw + (int64_t)a * 4 * d->Cin * d->Cout, st);
     if (rc != UNETK_OK) return rc;

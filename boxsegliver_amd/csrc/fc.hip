@@ -74,7 +74,7 @@ extern "C" int unetk_fc_fwd(const float* x, const float* w, const float* b, floa
                             int relu, float keep_prob, uint32_t seed, void* stream) {
   UNETK_REQUIRE(x && w && y && B > 0 && k > 0 && n > 0 && B <= 65535);
   UNETK_REQUIRE(!mask || (keep_prob > 0.f && keep_prob <= 1.f));
-  hipLaunchKernelGGL(fc_fwd_kernel, dim3((n + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, w, b, y, mask, k, n,
+  UNETK_LAUNCH(fc_fwd_kernel, dim3((n + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, w, b, y, mask, k, n,
                      relu, keep_prob, seed);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
@@ -84,12 +84,12 @@ extern "C" int unetk_fc_bwd(const float* x, const float* w, const float* y, cons
                             float* dw, float* db, float* dpre_ws, int B, int k, int n, int relu, void* stream) {
   UNETK_REQUIRE(x && w && y && dy && dw && dpre_ws && B > 0 && k > 0 && n > 0 && B <= 65535 && k <= 65535);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(fc_bwd_pre_kernel, dim3((n + 255) / 256), dim3(256), 0, st, y, mask, dy, dpre_ws, db, B, n, relu);
+  UNETK_LAUNCH(fc_bwd_pre_kernel, dim3((n + 255) / 256), dim3(256), 0, st, y, mask, dy, dpre_ws, db, B, n, relu);
   UNETK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(fc_bwd_w_kernel, dim3((n + 255) / 256, k), dim3(256), 0, st, x, dpre_ws, dw, B, k, n);
+  UNETK_LAUNCH(fc_bwd_w_kernel, dim3((n + 255) / 256, k), dim3(256), 0, st, x, dpre_ws, dw, B, k, n);
   UNETK_LAUNCH_CHECK();
   if (dx) {
-    hipLaunchKernelGGL(fc_bwd_x_kernel, dim3(k, B), dim3(64), 0, st, dpre_ws, w, dx, k, n);
+    UNETK_LAUNCH(fc_bwd_x_kernel, dim3(k, B), dim3(64), 0, st, dpre_ws, w, dx, k, n);
     UNETK_LAUNCH_CHECK();
   }
   return UNETK_OK;

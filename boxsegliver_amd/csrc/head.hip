@@ -466,9 +466,9 @@ extern "C" int unetk_head_fwd(const unetk_head_desc* d, const void* z, const flo
       int* hist = (int*)(wsf + L.hist_off);
       hipError_t e = hipMemsetAsync(hist, 0, (size_t)d->N * d->ncls * sizeof(int), st);
       if (e != hipSuccess) return (int)e;
-      hipLaunchKernelGGL(label_hist_kernel, dim3(d->N * L.bps), dim3(256), 0, st, labels, d->HW, d->ncls, L.bps, hist);
+      UNETK_LAUNCH(label_hist_kernel, dim3(d->N * L.bps), dim3(256), 0, st, labels, d->HW, d->ncls, L.bps, hist);
       UNETK_LAUNCH_CHECK();
-      hipLaunchKernelGGL(weight_table_kernel, dim3((d->N + 63) / 64), dim3(64), 0, st, *d, hist, wn);
+      UNETK_LAUNCH(weight_table_kernel, dim3((d->N + 63) / 64), dim3(64), 0, st, *d, hist, wn);
       UNETK_LAUNCH_CHECK();
     }
   }
@@ -481,10 +481,10 @@ extern "C" int unetk_head_fwd(const unetk_head_desc* d, const void* z, const flo
     part_eff = wsf + L.part_off;
   }
   if (bs) {
-    HEAD_DISPATCH(d->ncls, hipLaunchKernelGGL((head_fwd_kernel<K_, bf16_t>), dim3(d->N * bps), dim3(256), 0, st, *d,
+    HEAD_DISPATCH(d->ncls, UNETK_LAUNCH((head_fwd_kernel<K_, bf16_t>), dim3(d->N * bps), dim3(256), 0, st, *d,
                                               (const bf16_t*)z, w, b, labels, pixel_w, wn, logits, probs, part_eff, bps));
   } else {
-    HEAD_DISPATCH(d->ncls, hipLaunchKernelGGL((head_fwd_kernel<K_, float>), dim3(d->N * bps), dim3(256), 0, st, *d,
+    HEAD_DISPATCH(d->ncls, UNETK_LAUNCH((head_fwd_kernel<K_, float>), dim3(d->N * bps), dim3(256), 0, st, *d,
                                               (const float*)z, w, b, labels, pixel_w, wn, logits, probs, part_eff, bps));
   }
   UNETK_LAUNCH_CHECK();
@@ -493,7 +493,7 @@ extern "C" int unetk_head_fwd(const unetk_head_desc* d, const void* z, const flo
       const int P = d->N * L.nq;
       int Ls = 1;
       while (Ls < 64 && 2 * Ls * P <= 1024) Ls *= 2;        // the kernel's own choice for 1024 threads
-      hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(1024),
+      UNETK_LAUNCH(head_finalize_kernel, dim3(1), dim3(1024),
                          ((size_t)d->N * (3 + L.nq) + (size_t)P * Ls) * sizeof(double), st, *d, part, bps, L.nq, result);
     }
     UNETK_LAUNCH_CHECK();
@@ -523,11 +523,11 @@ extern "C" int unetk_head_bwd(const unetk_head_desc* d, const void* z, const flo
   const size_t lds = (size_t)gpb * d->C * d->ncls * sizeof(float);
   if (lds > 64 * 1024) return UNETK_E_UNSUPPORTED;
   if (bs) {
-    HEAD_DISPATCH(d->ncls, hipLaunchKernelGGL((head_bwd_kernel<K_, bf16_t>), dim3(L.bwd_nblk), dim3(256), lds, st, *d,
+    HEAD_DISPATCH(d->ncls, UNETK_LAUNCH((head_bwd_kernel<K_, bf16_t>), dim3(L.bwd_nblk), dim3(256), lds, st, *d,
                                               (const bf16_t*)z, w, labels, pixel_w, wn, logits, result, xent_scale,
                                               dice_scale, dev_scales, (bf16_t*)dz, pw, pb));
   } else {
-    HEAD_DISPATCH(d->ncls, hipLaunchKernelGGL((head_bwd_kernel<K_, float>), dim3(L.bwd_nblk), dim3(256), lds, st, *d,
+    HEAD_DISPATCH(d->ncls, UNETK_LAUNCH((head_bwd_kernel<K_, float>), dim3(L.bwd_nblk), dim3(256), lds, st, *d,
                                               (const float*)z, w, labels, pixel_w, wn, logits, result, xent_scale,
                                               dice_scale, dev_scales, (float*)dz, pw, pb));
   }
@@ -542,7 +542,7 @@ extern "C" int unetk_head_predict(const float* probs, int64_t npix, int ncls, ui
   UNETK_REQUIRE(probs && npix > 0 && ncls >= 2 && ncls <= MAXC && (argmax || preds));
   int64_t g = (npix + 255) / 256;
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(head_predict_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, probs, npix, ncls, argmax, preds);
+  UNETK_LAUNCH(head_predict_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, probs, npix, ncls, argmax, preds);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }

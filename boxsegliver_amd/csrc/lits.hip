@@ -84,7 +84,7 @@ extern "C" int unetk_lits_batch(const unetk_lits_desc* d, const uint16_t* slices
   const int64_t total = (int64_t)d->N * d->H * d->W;
   int64_t grid = (total + 255) / 256;
   if (grid > 65536) grid = 65536;
-  hipLaunchKernelGGL(lits_batch_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, *d, slices, seg_slices,
+  UNETK_LAUNCH(lits_batch_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, *d, slices, seg_slices,
                      sample_tab, clip, images, labels);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;

@@ -725,10 +725,10 @@ int bwd_blocks(const NormGeom& g) {
     default: { constexpr int GG = 4; CALL; } break; \
   }
 #define GD_DISPATCH_T(TT, G_, D_, L_, KERN, ...)                                               \
-  if (L_ && D_) { GL_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, true, true, TT>), __VA_ARGS__)); } \
-  else if (L_) { GL_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, false, true, TT>), __VA_ARGS__)); }   \
-  else if (D_) { G_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, true, false, TT>), __VA_ARGS__)); } \
-  else { G_DISPATCH(G_, hipLaunchKernelGGL((KERN<GG, false, false, TT>), __VA_ARGS__)); }
+  if (L_ && D_) { GL_DISPATCH(G_, UNETK_LAUNCH((KERN<GG, true, true, TT>), __VA_ARGS__)); } \
+  else if (L_) { GL_DISPATCH(G_, UNETK_LAUNCH((KERN<GG, false, true, TT>), __VA_ARGS__)); }   \
+  else if (D_) { G_DISPATCH(G_, UNETK_LAUNCH((KERN<GG, true, false, TT>), __VA_ARGS__)); } \
+  else { G_DISPATCH(G_, UNETK_LAUNCH((KERN<GG, false, false, TT>), __VA_ARGS__)); }
 // S_: tensors in HBM are bf16 (UNETK_BF16S) instead of fp32
 #define GD_DISPATCH(S_, G_, D_, L_, KERN, ...)                      \
   if (S_) { GD_DISPATCH_T(bf16_t, G_, D_, L_, KERN, __VA_ARGS__) } \
@@ -886,7 +886,7 @@ extern "C" int unetk_norm_finalize(const unetk_norm_desc* d, const float* stat_p
       rows = 64;
     }
     const int update_moving = (!d->per_sample && training && moving_mean && moving_var) ? 1 : 0;
-    hipLaunchKernelGGL(norm_reduce_finalize_kernel, dim3(((d->C + 15) / 16) * g.Ns), dim3(256), 0, st, src, rows, g.Ns, d->C,
+    UNETK_LAUNCH(norm_reduce_finalize_kernel, dim3(((d->C + 15) / 16) * g.Ns), dim3(256), 0, st, src, rows, g.Ns, d->C,
                        (double)g.Ps, gamma, beta, eps, decay, update_moving, moving_mean, moving_var, mean_out, rstd_out,
                        scale_out, shift_out);
     UNETK_LAUNCH_CHECK();
@@ -896,7 +896,7 @@ extern "C" int unetk_norm_finalize(const unetk_norm_desc* d, const float* stat_p
   }
   const int update_moving = (!d->per_sample && training && moving_mean && moving_var) ? 1 : 0;
   const int total = g.Ns * d->C;
-  hipLaunchKernelGGL(norm_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sums, g.Ns, d->C, (double)g.Ps,
+  UNETK_LAUNCH(norm_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sums, g.Ns, d->C, (double)g.Ps,
                      gamma, beta, eps, decay, use_moving, update_moving, moving_mean, moving_var, mean_out, rstd_out,
                      scale_out, shift_out);
   UNETK_LAUNCH_CHECK();
@@ -957,9 +957,9 @@ extern "C" int unetk_norm_apply_relu_pool(const unetk_norm_desc* d, int W, const
   int64_t gx = ((g.P >> 2) + g.rpi - 1) / g.rpi;
   const int64_t cap = g.L > 1 ? (4096 + g.L - 1) / g.L : 4096;
   if (gx > cap) gx = cap;
-  if (bs) hipLaunchKernelGGL(norm_apply_relu_pool_kernel<bf16_t>, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, a, pooled,
+  if (bs) UNETK_LAUNCH(norm_apply_relu_pool_kernel<bf16_t>, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, a, pooled,
                              d->HW / W, W, g.L);
-  else hipLaunchKernelGGL(norm_apply_relu_pool_kernel<float>, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, a, pooled,
+  else UNETK_LAUNCH(norm_apply_relu_pool_kernel<float>, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, a, pooled,
                           d->HW / W, W, g.L);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
@@ -1057,8 +1057,8 @@ extern "C" int unetk_norm_relu_bwd_pre(const unetk_norm_desc* d, const void* y, 
                                  last1 ? al1 : nullptr, st);   // -> sums[K][L][C]
   } else {
     if (post) {
-      if (bs) { GL_DISPATCH(G, hipLaunchKernelGGL((norm_bwd_reduce_kernel<GG, true, true, bf16_t, true>), dim3(nblk, g.L), dim3(256), lds, st, a)); }
-      else { GL_DISPATCH(G, hipLaunchKernelGGL((norm_bwd_reduce_kernel<GG, true, true, float, true>), dim3(nblk, g.L), dim3(256), lds, st, a)); }
+      if (bs) { GL_DISPATCH(G, UNETK_LAUNCH((norm_bwd_reduce_kernel<GG, true, true, bf16_t, true>), dim3(nblk, g.L), dim3(256), lds, st, a)); }
+      else { GL_DISPATCH(G, UNETK_LAUNCH((norm_bwd_reduce_kernel<GG, true, true, float, true>), dim3(nblk, g.L), dim3(256), lds, st, a)); }
     } else {
       GD_DISPATCH(bs, G, D, leaky, norm_bwd_reduce_kernel, dim3(nblk, g.L), dim3(256), lds, st, a);
     }
@@ -1075,19 +1075,19 @@ extern "C" int unetk_norm_relu_bwd_pre(const unetk_norm_desc* d, const void* y, 
   }
   const bool gps = d->guide_per_sample != 0;
   if (!simple) {
-    hipLaunchKernelGGL(norm_bwd_params_kernel, dim3((d->C + 255) / 256), dim3(256), 0, st, psum, d->C, gps ? 0 : G,
+    UNETK_LAUNCH(norm_bwd_params_kernel, dim3((d->C + 255) / 256), dim3(256), 0, st, psum, d->C, gps ? 0 : G,
                        (D || leaky) ? 1 : 0, dgamma, dbeta, gps ? nullptr : dgw, (gps || post) ? nullptr : dgb);
     UNETK_LAUNCH_CHECK();
   }
   if (gps) {   // dgw [N][G][C], dgb [N][C]: the per-launch-group sums, not their total
     const int kb = (D || leaky) ? 2 + G : 0;
-    hipLaunchKernelGGL(norm_bwd_guide_ps_kernel, dim3((d->N * d->C + 255) / 256), dim3(256), 0, st, sums, d->N, d->C, G, kb, dgw,
+    UNETK_LAUNCH(norm_bwd_guide_ps_kernel, dim3((d->N * d->C + 255) / 256), dim3(256), 0, st, sums, d->N, d->C, G, kb, dgw,
                        post ? nullptr : dgb);
     UNETK_LAUNCH_CHECK();
   }
   if (post) {  // gradient of the gb block: bias row = sum dg, slope rows = 0 (constants of the fold's sign), post-shift row = sum du
     const int groups = gps ? d->N : 1;
-    hipLaunchKernelGGL(norm_bwd_post_block_kernel, dim3((groups * d->C + 255) / 256), dim3(256), 0, st, gps ? sums : psum, groups,
+    UNETK_LAUNCH(norm_bwd_post_block_kernel, dim3((groups * d->C + 255) / 256), dim3(256), 0, st, gps ? sums : psum, groups,
                        d->C, G, dgb);
     UNETK_LAUNCH_CHECK();
   }
@@ -1139,8 +1139,8 @@ extern "C" int unetk_norm_relu_bwd_pool(const unetk_norm_desc* d, int W, const v
   PoolArgs pa{dp, d->HW / W, W};
   const size_t lds = (size_t)K * g.rpi * d->C * sizeof(float);
   const bool last1 = g.L == 1;
-  if (bs) hipLaunchKernelGGL(norm_bwd_reduce_pool_kernel<bf16_t>, dim3(nblk, g.L), dim3(256), lds, st, a, pa);
-  else hipLaunchKernelGGL(norm_bwd_reduce_pool_kernel<float>, dim3(nblk, g.L), dim3(256), lds, st, a, pa);
+  if (bs) UNETK_LAUNCH(norm_bwd_reduce_pool_kernel<bf16_t>, dim3(nblk, g.L), dim3(256), lds, st, a, pa);
+  else UNETK_LAUNCH(norm_bwd_reduce_pool_kernel<float>, dim3(nblk, g.L), dim3(256), lds, st, a, pa);
   UNETK_LAUNCH_CHECK();
   int rc = unetk_rows_reduce_alias(partial, K * g.L, nblk, d->C, sums, tmp1, last1 ? dbeta : nullptr, last1 ? dgamma : nullptr, st);
   if (rc != UNETK_OK) return rc;
@@ -1151,8 +1151,8 @@ extern "C" int unetk_norm_relu_bwd_pool(const unetk_norm_desc* d, int W, const v
   int64_t gx = ((g.P >> 2) + g.rpi - 1) / g.rpi;
   const int64_t cap = g.L > 1 ? (4096 + g.L - 1) / g.L : 4096;
   if (gx > cap) gx = cap;
-  if (bs) hipLaunchKernelGGL(norm_bwd_apply_pool_kernel<bf16_t>, dim3((int)gx, g.L), dim3(256), 0, st, a, pa);
-  else hipLaunchKernelGGL(norm_bwd_apply_pool_kernel<float>, dim3((int)gx, g.L), dim3(256), 0, st, a, pa);
+  if (bs) UNETK_LAUNCH(norm_bwd_apply_pool_kernel<bf16_t>, dim3((int)gx, g.L), dim3(256), 0, st, a, pa);
+  else UNETK_LAUNCH(norm_bwd_apply_pool_kernel<float>, dim3((int)gx, g.L), dim3(256), 0, st, a, pa);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
@@ -1170,10 +1170,10 @@ extern "C" int unetk_norm_drop_pool(const unetk_norm_desc* d, const void* y, con
   const NormGeom g = geom(d, true);            // one launch group per sample
   const size_t lds = (size_t)2 * g.rpi * d->C * sizeof(float);
   if (bs)
-    hipLaunchKernelGGL(norm_drop_pool_kernel<bf16_t>, dim3(d->N), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)y, mean, rstd,
+    UNETK_LAUNCH(norm_drop_pool_kernel<bf16_t>, dim3(d->N), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)y, mean, rstd,
                        sums, g.P, d->C, g.cq_n, g.rpi, g.sst, d->N, d->dropout_keep, d->dropout_seed);
   else
-    hipLaunchKernelGGL(norm_drop_pool_kernel<float>, dim3(d->N), dim3(256), lds, (hipStream_t)stream, (const float*)y, mean, rstd,
+    UNETK_LAUNCH(norm_drop_pool_kernel<float>, dim3(d->N), dim3(256), lds, (hipStream_t)stream, (const float*)y, mean, rstd,
                        sums, g.P, d->C, g.cq_n, g.rpi, g.sst, d->N, d->dropout_keep, d->dropout_seed);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
@@ -1195,10 +1195,10 @@ extern "C" int unetk_norm_se_bwd_add_drop(const unetk_norm_desc* d, const void* 
   const int64_t cap = (4096 + g.L - 1) / g.L;
   if (gx > cap) gx = cap;
   if (bs)
-    hipLaunchKernelGGL(norm_se_bwd_add_drop_kernel<bf16_t>, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y,
+    UNETK_LAUNCH(norm_se_bwd_add_drop_kernel<bf16_t>, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y,
                        (bf16_t*)dy, mean, rstd, scale, E, k1, k2, g.P, d->C, g.cq_n, g.rpi, g.sst, d->dropout_keep, d->dropout_seed);
   else
-    hipLaunchKernelGGL(norm_se_bwd_add_drop_kernel<float>, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, (const float*)y,
+    UNETK_LAUNCH(norm_se_bwd_add_drop_kernel<float>, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, (const float*)y,
                        (float*)dy, mean, rstd, scale, E, k1, k2, g.P, d->C, g.cq_n, g.rpi, g.sst, d->dropout_keep, d->dropout_seed);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
@@ -1217,10 +1217,10 @@ extern "C" int unetk_norm_se_bwd_add(const unetk_norm_desc* d, const void* y, vo
   const int64_t cap = (4096 + g.L - 1) / g.L;
   if (gx > cap) gx = cap;
   if (bs)
-    hipLaunchKernelGGL(norm_se_bwd_add_kernel<bf16_t>, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y,
+    UNETK_LAUNCH(norm_se_bwd_add_kernel<bf16_t>, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y,
                        (bf16_t*)dy, mean, rstd, scale, A, k2, g.P, d->C, g.cq_n, g.rpi, g.sst);
   else
-    hipLaunchKernelGGL(norm_se_bwd_add_kernel<float>, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, (const float*)y,
+    UNETK_LAUNCH(norm_se_bwd_add_kernel<float>, dim3((int)gx, g.L), dim3(256), 0, (hipStream_t)stream, (const float*)y,
                        (float*)dy, mean, rstd, scale, A, k2, g.P, d->C, g.cq_n, g.rpi, g.sst);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;

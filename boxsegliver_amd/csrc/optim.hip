@@ -98,7 +98,7 @@ extern "C" int unetk_adam_step(float* p, const float* g, float* m, float* v, int
                                float beta2, float eps, float gscale, float l2, float decoupled_wd, void* stream) {
   UNETK_REQUIRE(p && g && m && v && n > 0);
   UNETK_REQUIRE(unetk_aligned16(p) && unetk_aligned16(g) && unetk_aligned16(m) && unetk_aligned16(v));
-  hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(n >> 2)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, beta1,
+  UNETK_LAUNCH(adam_kernel, dim3(flat_grid(n >> 2)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, beta1,
                      beta2, eps, gscale, l2, decoupled_wd);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
@@ -107,7 +107,7 @@ extern "C" int unetk_adam_step(float* p, const float* g, float* m, float* v, int
 extern "C" int unetk_momentum_step(float* p, const float* g, float* acc, int64_t n, float lr, float mom, int nesterov,
                                    float gscale, float l2, void* stream) {
   UNETK_REQUIRE(p && g && acc && n > 0);
-  hipLaunchKernelGGL(momentum_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, acc, n, lr, mom,
+  UNETK_LAUNCH(momentum_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, acc, n, lr, mom,
                      nesterov, gscale, l2);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
@@ -118,15 +118,15 @@ extern "C" int unetk_sumsq(const float* p, int64_t n, float* out, void* ws, size
   if (ws_bytes < 1024 * sizeof(double)) return UNETK_E_WORKSPACE;
   int nb = flat_grid(n);
   if (nb > 1024) nb = 1024;
-  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, n, (double*)ws,
+  UNETK_LAUNCH(sumsq_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, n, (double*)ws,
                      unetk_aligned16(p) ? 1 : 0);
   UNETK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ws, nb, out);
+  UNETK_LAUNCH(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ws, nb, out);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
 
-extern "C" int unetk_abi_version(void) { return 7; }   // 2: unetk_conv_desc.precision, UNETK_BF16; 3: density modulation, unetk_fc_*; 4: unetk_conv_desc.dilation; 5: UNETK_BF16S (bf16 storage), unetk_norm_desc.storage, unetk_head_desc.storage; 6: norm dropout / guide_alpha / guide_per_sample, unetk_norm_se_bwd_add, fc sigmoid; 7: unetk_conv3x3_dgrad_nbr, unetk_norm_relu_bwd_pre, unetk_conv1d_*, unetk_maxpool1d_*, unetk_spatial_mean_*, unetk_conv3x3_*_ws, unetk_pack_many
+extern "C" int unetk_abi_version(void) { return 8; }   // 2: unetk_conv_desc.precision, UNETK_BF16; 3: density modulation, unetk_fc_*; 4: unetk_conv_desc.dilation; 5: UNETK_BF16S (bf16 storage), unetk_norm_desc.storage, unetk_head_desc.storage; 6: norm dropout / guide_alpha / guide_per_sample, unetk_norm_se_bwd_add, fc sigmoid; 7: unetk_conv3x3_dgrad_nbr, unetk_norm_relu_bwd_pre, unetk_conv1d_*, unetk_maxpool1d_*, unetk_spatial_mean_*, unetk_conv3x3_*_ws, unetk_pack_many; 8: unetk_prof_* (kernel trace)
 
 extern "C" const char* unetk_error_string(int code) {
   switch (code) {

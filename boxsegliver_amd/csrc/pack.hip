@@ -62,7 +62,7 @@ extern "C" int unetk_pack_item_blocks(int kind, int Cin, int Cout) {
 
 extern "C" int unetk_pack_many(const unetk_pack_item* items_dev, int n_items, int total_blocks, void* stream) {
   UNETK_REQUIRE(items_dev && n_items > 0 && total_blocks > 0 && unetk_aligned16(items_dev));
-  hipLaunchKernelGGL(pack_many_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n_items);
+  UNETK_LAUNCH(pack_many_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n_items);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }

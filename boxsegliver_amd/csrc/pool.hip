@@ -173,7 +173,7 @@ __global__ void sobel_concat_kernel(const float* __restrict__ x, float* __restri
 
 extern "C" int unetk_sobel_concat(const float* x, float* out, int N, int H, int W, int C, int ch, void* stream) {
   UNETK_REQUIRE(x && out && N > 0 && H > 1 && W > 1 && C > 0 && ch >= 0 && ch < C);
-  hipLaunchKernelGGL(sobel_concat_kernel, dim3(ew_grid((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, x, out, N, H,
+  UNETK_LAUNCH(sobel_concat_kernel, dim3(ew_grid((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, x, out, N, H,
                      W, C, ch);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
@@ -201,7 +201,7 @@ extern "C" int unetk_flip_axpy(const float* x, float* out, int N, int H, int W, 
                                int accumulate, void* stream) {
   UNETK_REQUIRE(x && out && x != out && N > 0 && H > 0 && W > 0 && C > 0);
   const int64_t total = (int64_t)N * H * W * C;
-  hipLaunchKernelGGL(flip_axpy_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, out, N, H, W, C, flip_h,
+  UNETK_LAUNCH(flip_axpy_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, out, N, H, W, C, flip_h,
                      flip_w, scale, accumulate);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
@@ -210,7 +210,7 @@ extern "C" int unetk_flip_axpy(const float* x, float* out, int N, int H, int W, 
 extern "C" int unetk_image_gradients(const float* x, float* out, int N, int H, int W, int C, void* stream) {
   UNETK_REQUIRE(x && out && N > 0 && H > 0 && W > 0 && C > 0);
   const int64_t total = (int64_t)N * H * W * C;
-  hipLaunchKernelGGL(image_gradients_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, out, N, H, W, C);
+  UNETK_LAUNCH(image_gradients_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, out, N, H, W, C);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
@@ -221,7 +221,7 @@ extern "C" int unetk_maxpool2_fwd(const float* x, int x_stride, float* p, int N,
   if (C % 4 != 0 || x_stride % 4 != 0) return UNETK_E_UNSUPPORTED;
   UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(p));
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_stride, p, N,
+  UNETK_LAUNCH(maxpool2_fwd_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_stride, p, N,
                      H, W, C);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
@@ -232,7 +232,7 @@ extern "C" int unetk_maxpool2_fwd_bf16(const void* x, int x_stride, void* p, int
   if (C % 4 != 0 || x_stride % 4 != 0) return UNETK_E_UNSUPPORTED;
   UNETK_REQUIRE(unetk_aligned8(x) && unetk_aligned8(p));
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+  UNETK_LAUNCH(maxpool2_fwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, x_stride, (bf16_t*)p, N, H, W, C);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
@@ -245,7 +245,7 @@ extern "C" int unetk_maxpool2_bwd(const float* x, int x_stride, const float* p, 
   UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(p) && unetk_aligned16(dp) && unetk_aligned16(dx));
   UNETK_REQUIRE(!add || (add_stride >= C && add_stride % 4 == 0 && unetk_aligned16(add)));
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_stride, p, dp,
+  UNETK_LAUNCH(maxpool2_bwd_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_stride, p, dp,
                      add, add_stride, dx, N, H, W, C);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
@@ -258,7 +258,7 @@ extern "C" int unetk_maxpool2_bwd_bf16(const void* x, int x_stride, const void* 
   UNETK_REQUIRE(unetk_aligned8(x) && unetk_aligned8(p) && unetk_aligned8(dp) && unetk_aligned8(dx));
   UNETK_REQUIRE(!add || (add_stride >= C && add_stride % 4 == 0 && unetk_aligned8(add)));
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+  UNETK_LAUNCH(maxpool2_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, x_stride, (const bf16_t*)p, (const bf16_t*)dp, (const bf16_t*)add, add_stride,
                      (bf16_t*)dx, N, H, W, C);
   UNETK_LAUNCH_CHECK();
@@ -269,7 +269,7 @@ extern "C" int unetk_avgpool2_fwd(const float* x, float* p, int N, int H, int W,
   UNETK_REQUIRE(x && p && N > 0 && H > 1 && W > 1 && C > 0);
   if ((H & 1) || (W & 1)) return UNETK_E_UNSUPPORTED;
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
-  hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, p, N, H, W, C);
+  UNETK_LAUNCH(avgpool2_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, p, N, H, W, C);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
@@ -301,7 +301,7 @@ __global__ void spatial_mean_bwd_kernel(const float* __restrict__ dy, float* __r
 
 extern "C" int unetk_spatial_mean_fwd(const float* x, float* y, int N, int64_t HW, int C, void* stream) {
   UNETK_REQUIRE(x && y && N > 0 && N <= 65535 && HW > 0 && C > 0);
-  hipLaunchKernelGGL(spatial_mean_fwd_kernel, dim3((C + 63) / 64, N), dim3(256), 0, (hipStream_t)stream, x, y, HW, C);
+  UNETK_LAUNCH(spatial_mean_fwd_kernel, dim3((C + 63) / 64, N), dim3(256), 0, (hipStream_t)stream, x, y, HW, C);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
@@ -309,7 +309,7 @@ extern "C" int unetk_spatial_mean_fwd(const float* x, float* y, int N, int64_t H
 extern "C" int unetk_spatial_mean_bwd(const float* dy, float* dx, int N, int64_t HW, int C, void* stream) {
   UNETK_REQUIRE(dy && dx && N > 0 && HW > 0 && C > 0);
   const int64_t total = (int64_t)N * HW * C;
-  hipLaunchKernelGGL(spatial_mean_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, HW, C, total);
+  UNETK_LAUNCH(spatial_mean_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, HW, C, total);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
@@ -318,7 +318,7 @@ extern "C" int unetk_guide_moments(const float* guide, int N, int64_t HW, int G,
   UNETK_REQUIRE(guide && out && N > 0 && HW > 0 && G > 0 && G <= 4);
   const int groups = per_sample ? N : 1;
   const int64_t P = per_sample ? HW : (int64_t)N * HW;
-  hipLaunchKernelGGL(guide_moments_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, guide, P, G, out);
+  UNETK_LAUNCH(guide_moments_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, guide, P, G, out);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }

@@ -92,7 +92,7 @@ size_t unetk_rows_reduce_tmp_floats(int K, int rows, int C) { return rows > UNET
 int unetk_rows_reduce_l1(const float* src, int K, int rows, int C, float* tmp, hipStream_t st) {
   const int RB = 64;
   const int cblocks = (C + 63) / 64;
-  hipLaunchKernelGGL(rows_reduce_l1_kernel, dim3(cblocks * RB * K), dim3(256), 0, st, src, rows, C, RB, tmp);
+  UNETK_LAUNCH(rows_reduce_l1_kernel, dim3(cblocks * RB * K), dim3(256), 0, st, src, rows, C, RB, tmp);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }
@@ -113,9 +113,9 @@ int unetk_rows_reduce_alias(const float* src, int K, int rows, int C, float* dst
   }
   const int cblocks = (C + 15) / 16;
   if (wide && unetk_aligned16(src)) {
-    hipLaunchKernelGGL(rows_reduce_final_wide_kernel, dim3(cblocks * K), dim3(256), 0, st, src, rows, C, dst, alias0, alias1);
+    UNETK_LAUNCH(rows_reduce_final_wide_kernel, dim3(cblocks * K), dim3(256), 0, st, src, rows, C, dst, alias0, alias1);
   } else {
-    hipLaunchKernelGGL(rows_reduce_final_kernel, dim3(cblocks * K), dim3(256), 0, st, src, rows, C, dst);
+    UNETK_LAUNCH(rows_reduce_final_kernel, dim3(cblocks * K), dim3(256), 0, st, src, rows, C, dst);
     hipError_t e = hipSuccess;
     if (alias0) e = hipMemcpyAsync(alias0, dst, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess && alias1 && K > 1)

@@ -120,12 +120,12 @@ extern "C" int unetk_boundary_weights(const int32_t* labels, int N, int H, int W
   int32_t* has_ring = (int32_t*)(row_sums + (size_t)N * H);
   hipError_t e = hipMemsetAsync(has_ring, 0, (size_t)N * 4, st);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(edt_columns_kernel, dim3((N * W + 255) / 256), dim3(256), 0, st, labels, N, H, W, g, has_ring);
+  UNETK_LAUNCH(edt_columns_kernel, dim3((N * W + 255) / 256), dim3(256), 0, st, labels, N, H, W, g, has_ring);
   UNETK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(edt_rows_kernel, dim3(N * H), dim3(256), (size_t)W * 4, st, g, has_ring, N, H, W, wmap, row_sums);
+  UNETK_LAUNCH(edt_rows_kernel, dim3(N * H), dim3(256), (size_t)W * 4, st, g, has_ring, N, H, W, wmap, row_sums);
   UNETK_LAUNCH_CHECK();
   const int gx = (int)min((int64_t)1024, ((int64_t)H * W + 255) / 256);
-  hipLaunchKernelGGL(edt_normalise_kernel, dim3(gx, N), dim3(256), 0, st, wmap, row_sums, N, H, W);
+  UNETK_LAUNCH(edt_normalise_kernel, dim3(gx, N), dim3(256), 0, st, wmap, row_sums, N, H, W);
   UNETK_LAUNCH_CHECK();
   return UNETK_OK;
 }

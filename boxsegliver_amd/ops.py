@@ -40,10 +40,9 @@ class _Workspace(object):
 WORKSPACE = _Workspace()
 FUSE_NBR = True         # conv2's input gradient also emits conv1's norm-backward reduction (unetk_conv3x3_dgrad_nbr)
 FUSED_NBR = {}          # dx.data_ptr() -> (producer y.data_ptr(), shape, partials, rows, dx._version); consumed by the producer's backward
-PROFILE_HBM = False     # bench.py: also time the HBM-bound passes (by algorithmic bytes)
 DEBUG_CAPTURE = None    # tools/: set to a list to record each conv unit's backward operands
 PROFILE_SHAPES = False  # bench.py --detail: one row per (kernel, layer shape)
-PROFILE = None          # bench.py: set to a list -> (kernel tag, algorithmic FLOPs, start event, end event)
+PROFILE = None          # bench.py (profile_on): a list -> (op tag, algorithmic FLOPs, first trace record, end record, algorithmic bytes)
 
 
 # ----------------------------------------------------------------------------- packed-filter cache
@@ -146,27 +145,51 @@ PK_CONV_F32, PK_CONV_BF16, PK_DECONV_F32, PK_DECONV_BF16 = 0, 1, 2, 3
 
 
 class _Timed(object):
-    """HIP events on the CURRENT stream (the one the kernel is launched on) around one C-ABI call."""
+    """Brackets one C-ABI call with two marks of the library's kernel trace (csrc/prof.hip): while bench.py has the trace on,
+    every kernel the call launches carries start / stop events bound to its dispatch, and the bracket is the half-open range of
+    trace records [i0, i1) -- its time is the sum of those kernels' own GPU durations (what rocprofv3 --kernel-trace reports),
+    with no host gap inside whatever the stream's queue depth was."""
 
     def __init__(self, tag, flops, shape=None, nbytes=0):
         """flops: algorithmic FLOPs of a matrix kernel; nbytes: algorithmic HBM bytes (each operand once) of an HBM-bound pass."""
-        # HBM-bound passes (flops == 0) are timed only on request: their ~60 extra event pairs per step are host work bench.py's
-        # timed region must not carry
-        self.on = PROFILE is not None and (flops > 0 or PROFILE_HBM)
+        self.on = PROFILE is not None
         self.tag, self.flops, self.nbytes = (tag if not (PROFILE_SHAPES and shape) else "{} [{}]".format(tag, shape)), flops, nbytes
 
     def __enter__(self):
         if self.on:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
-            self.e0.record()
+            self.i0 = _abi.lib().unetk_prof_mark()
         return self
 
     def __exit__(self, *exc):
         if self.on and exc[0] is None:
-            self.e1.record()
-            PROFILE.append((self.tag, self.flops, self.e0, self.e1, self.nbytes))
+            PROFILE.append((self.tag, self.flops, self.i0, _abi.lib().unetk_prof_mark(), self.nbytes))
         return False
+
+
+def profile_begin(reserve_launches=0):
+    """bench.py: forget the kernel trace and pre-create its events (host work that must not sit in a timed region)."""
+    check(_abi.lib().unetk_prof_reset(int(reserve_launches)), "prof_reset")
+
+
+def profile_on(records):
+    """Trace every launch of the library from here on and collect the op brackets into `records` (a list); None = off."""
+    global PROFILE
+    PROFILE = records
+    check(_abi.lib().unetk_prof_enable(1 if records is not None else 0), "prof_enable")
+
+
+def profile_read():
+    """After a synchronize: (durations in ms, kernel names) of every traced launch since profile_begin()."""
+    lib = _abi.lib()
+    n = lib.unetk_prof_mark()
+    ms = (ctypes.c_float * max(n, 1))()
+    if n:
+        check(lib.unetk_prof_read(0, n, ms), "prof_read")
+    names, buf = [], ctypes.create_string_buffer(512)
+    for i in range(n):
+        check(lib.unetk_prof_name(i, buf, 512), "prof_name")
+        names.append(buf.value.decode())
+    return list(ms)[:n], names
 
 
 class _NoTimer(object):
@@ -191,7 +214,7 @@ def _timed(tag_fn, flops, fmt=None, args=(), nbytes_fn=None):
 def _timed_hbm(tag, t, passes, extra=0):
     """Timer of an HBM-bound pass moving `passes` x the bytes of tensor `t` (+ extra); a shared no-op unless bench.py asked
     for these (the byte count is not even computed then: these wrappers sit on the host path of every step)."""
-    if PROFILE is None or not PROFILE_HBM:
+    if PROFILE is None:
         return _NO_TIMER
     return _Timed(tag, 0.0, None, t.numel() * t.element_size() * passes + extra)
 

@@ -486,6 +486,25 @@ int unetk_momentum_step(float* p, const float* g, float* acc, int64_t n, float l
 /* out[0] = sum(p^2) (fp64 accumulate) -- for the reported regularisation loss. ws >= 8 KiB. */
 int unetk_sumsq(const float* p, int64_t n, float* out, void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------- kernel trace (measurement only; bench.py)
+ * SURVEY.md 8d asks for the dominant kernel's launch duration "measured live inside bench.py with HIP events ... on the
+ * stream the kernel is launched on".  The reference has no counterpart (its profiling is tf.train.ProfilerHook,
+ * core/estimator.py:688-690).  While enabled, EVERY kernel this library launches carries a start / stop event pair bound to
+ * the dispatch (hipExtLaunchKernelGGL), i.e. the GPU's own begin -> end interval of that kernel -- what rocprofv3
+ * --kernel-trace reports -- independent of host gaps around the launch.  Process-wide diagnostic state, off by default; the
+ * only exception to the "no global mutable state" rule above.  No call here synchronises.
+ *   unetk_prof_reset(n)     forget all records; pre-create events for n launches (outside any timed region)
+ *   unetk_prof_enable(on)   start / stop recording (records accumulate across enable periods until the next reset)
+ *   unetk_prof_mark()       number of launches recorded so far: a caller brackets one ABI call with two marks
+ *   unetk_prof_read(...)    durations in ms of records [first, first + count); the stream must have been synchronised
+ *                           (else hipErrorNotReady is returned)
+ *   unetk_prof_name(i,...)  demangled kernel name of record i, as rocprofv3 prints it */
+int unetk_prof_reset(int reserve_launches);
+int unetk_prof_enable(int on);
+int unetk_prof_mark(void);
+int unetk_prof_read(int first, int count, float* ms_out);
+int unetk_prof_name(int i, char* buf, int cap);
+
 #ifdef __cplusplus
 }
 #endif
