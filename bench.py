@@ -154,6 +154,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="slices per GPU per step")
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--depth", type=int, default=0,
+                    help="UNet3D: patch depth (default = --size, i.e. a cube); the reference's own 3-D script trains "
+                         "--depth 10 --size 256 --batch 4 (threed_script/201_unet_v1.sh:26)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the oracle at bs 8 (~40 s more of CPU work)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP-event timing")
@@ -231,11 +234,14 @@ def main():
         gflop_unit = 288.9 * (a.size / 256.0) ** 2
         workload_name = "GUNet + 1-ch spatial guide {0}x{0}x3 bs={1}/GPU fp32 instance_norm (BASELINE.json configs[3])"
     elif a.model == "UNet3D":       # BASELINE.json configs[4]: 96^3 patches, instance norm (201_unet_v1.sh:39)
-        args.classes, args.im_channel, args.im_depth, args.normalizer = ["NF"], 1, a.size, "instance_norm"
+        depth = a.depth or a.size
+        args.classes, args.im_channel, args.im_depth, args.normalizer = ["NF"], 1, depth, "instance_norm"
         args.loss_numeric_w, args.use_spatial, args.weight_decay_rate = [1.0, 1.0], False, 3e-5
         input_fn = synthetic.input_fn_3d
-        gflop_unit = 1612.92 * (a.size / 96.0) ** 3
-        workload_name = "UNet3D {0}x{0}x{0}x1 bs={1}/GPU fp32 instance_norm (BASELINE.json configs[4])"
+        gflop_unit = 1612.92 * (depth * a.size * a.size / 96.0 ** 3)       # every level's voxel count scales with D * H * W
+        workload_name = "UNet3D " + str(depth) + "x{0}x{0}x1 bs={1}/GPU fp32 instance_norm " + \
+            ("(BASELINE.json configs[4])" if depth == a.size == 96 else
+             "(the reference's 3-D training shape, threed_script/201_unet_v1.sh)" if (depth, a.size) == (10, 256) else "(off-config shape)")
     elif a.model in ("UNetInter", "LGNet", "SmallUNet", "InterUNet"):     # the other MODEL_ZOO nets: guide as a second input
         args.use_spatial, args.use_context, args.guide_channel, args.normalizer = True, False, 1, "instance_norm"
         args.side_dropout, args.dropout, args.use_se, args.fix, args.mid_cat = 0.5, None, False, False, False
@@ -330,6 +336,8 @@ def main():
         bk = getattr(solver, "_buckets", None)
         dp_diag = {"buckets": len(bk.buckets) if bk is not None else 0,
                    "buckets_fired_in_backward": bk.last["fired_in_backward"] if bk is not None and bk.last else None,
+                   "bucket_launch_progress": bk.last["launch_progress"] if bk is not None and bk.last else None,
+                   "bucket_bytes": bk.last["bucket_bytes"] if bk is not None and bk.last else None,
                    "allreduce_exposed_ms": round(bk.exposed_ms(), 4) if bk is not None and bk.exposed_ms() is not None else None,
                    "allreduce_bytes": int(sum(g.numel() for g in model.params.grad.values()) * 4)}
         solver.strategy = None

@@ -62,6 +62,7 @@ P = c_void_p
 _SIGNATURES = {
     "unetk_lits_batch": (c_int, [POINTER(LitsDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "unetk_abi_version": (c_int, []),
+    "unetk_nan_watch": (c_int, [P, P, c_int32, P]),
     "unetk_prof_reset": (c_int, [c_int]),
     "unetk_prof_enable": (c_int, [c_int]),
     "unetk_prof_mark": (c_int, []),

@@ -21,6 +21,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
+from .. import ops
 from ..NetworksV2.base import ModeKeys
 from ..utils import tf_checkpoint
 
@@ -170,6 +171,7 @@ class CustomEstimator(object):
         self._warm_start_from = warm_start_from
         self.predictions = None
         self._eval_iter_fn = None
+        self._nan_flag = None          # int32[2] on the device: (a NaN loss was seen, at step) -- _train_model
         self.double_dataloader_modes = self._params.get("double_dataloader_modes", None)
         if self.double_dataloader_modes and len(self.double_dataloader_modes) != 2:
             raise ValueError("double_dataloader_modes need a list of 2 elements for specifying input_fn modes")
@@ -308,6 +310,12 @@ class CustomEstimator(object):
             self.predictions = spec.predictions
             done += 1
             step = solver.global_step
+            # NanTensorHook(loss) (reference core/estimator.py:676) runs EVERY step; here a one-thread kernel sets a sticky
+            # device flag and the host reads it where it synchronises anyway (log steps, before each checkpoint)
+            if spec.loss.is_cuda:
+                if self._nan_flag is None:
+                    self._nan_flag = torch.zeros(2, dtype=torch.int32, device=spec.loss.device)
+                ops.nan_watch(spec.loss.detach().to(torch.float32).reshape(1), self._nan_flag, step)
             if step % log_step == 0 or done == 1:
                 # the logged loss and "<Class>/<Metric>" scalars are replica MEANS (strategy.reduce, :576,:585); log steps
                 # are the same on every rank, so the collective is safe; host sync only at log steps
@@ -317,6 +325,7 @@ class CustomEstimator(object):
                 loss_val = float(red(spec.loss).detach())
                 if math.isnan(loss_val):
                     raise NanLossDuringTrainingError()          # NanTensorHook, estimator.py:676
+                self._raise_if_nan_seen(dp)                     # a NaN at any step since the last poll
                 last_loss = loss_val
                 vals = {"loss": loss_val, "lr": spec.train_op, "step": step}
                 for k, v in spec.model.metrics_dict.items():
@@ -330,6 +339,7 @@ class CustomEstimator(object):
             for h in hooks:
                 h.after_run(ctx, spec)
             if save_steps and step % save_steps == 0:
+                self._raise_if_nan_seen(self._dp_or_none())     # never checkpoint a model a NaN step has gone through
                 self.save_checkpoint()
             if steps is not None and done >= steps:
                 break
@@ -339,8 +349,27 @@ class CustomEstimator(object):
             h.end(session)
         if last_loss is None and done:
             last_loss = float(spec.loss)
+        self._raise_if_nan_seen(self._dp_or_none())
         self.save_checkpoint()
         return last_loss
+
+    def _dp_or_none(self):
+        d = self._train_distribution
+        return d if (d is not None and d.num_replicas_in_sync > 1) else None
+
+    def _raise_if_nan_seen(self, dp):
+        """Poll the sticky NaN flag (one small device -> host read; every rank calls this at the same steps, so under data
+        parallelism the flag is max-reduced first and all ranks stop together)."""
+        if self._nan_flag is None:
+            return
+        flag = self._nan_flag
+        if dp is not None:
+            flag = flag.clone()
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        seen, at = (int(v) for v in flag.tolist())
+        if seen:
+            log.error("NaN loss at step %d", at)
+            raise NanLossDuringTrainingError()
 
     # ------------------------------------------------------------------ eval
     def evaluate_online(self, session=None, predict_keys=None, steps=None, yield_single_examples=False):

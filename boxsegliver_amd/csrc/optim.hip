@@ -126,7 +126,23 @@ extern "C" int unetk_sumsq(const float* p, int64_t n, float* out, void* ws, size
   return UNETK_OK;
 }
 
-extern "C" int unetk_abi_version(void) { return 8; }   // 2: unetk_conv_desc.precision, UNETK_BF16; 3: density modulation, unetk_fc_*; 4: unetk_conv_desc.dilation; 5: UNETK_BF16S (bf16 storage), unetk_norm_desc.storage, unetk_head_desc.storage; 6: norm dropout / guide_alpha / guide_per_sample, unetk_norm_se_bwd_add, fc sigmoid; 7: unetk_conv3x3_dgrad_nbr, unetk_norm_relu_bwd_pre, unetk_conv1d_*, unetk_maxpool1d_*, unetk_spatial_mean_*, unetk_conv3x3_*_ws, unetk_pack_many; 8: unetk_prof_* (kernel trace)
+// NanTensorHook(loss) of the reference (core/estimator.py:676) without a host sync per step: a sticky device flag.
+__global__ void nan_watch_kernel(const float* __restrict__ value, int32_t* __restrict__ flag, int32_t step) {
+  const float v = value[0];
+  if (v != v && flag[0] == 0) {
+    flag[0] = 1;
+    flag[1] = step;
+  }
+}
+
+extern "C" int unetk_nan_watch(const float* value, int32_t* flag, int32_t step, void* stream) {
+  UNETK_REQUIRE(value && flag);
+  UNETK_LAUNCH(nan_watch_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, value, flag, step);
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
+extern "C" int unetk_abi_version(void) { return 8; }   // 2: unetk_conv_desc.precision, UNETK_BF16; 3: density modulation, unetk_fc_*; 4: unetk_conv_desc.dilation; 5: UNETK_BF16S (bf16 storage), unetk_norm_desc.storage, unetk_head_desc.storage; 6: norm dropout / guide_alpha / guide_per_sample, unetk_norm_se_bwd_add, fc sigmoid; 7: unetk_conv3x3_dgrad_nbr, unetk_norm_relu_bwd_pre, unetk_conv1d_*, unetk_maxpool1d_*, unetk_spatial_mean_*, unetk_conv3x3_*_ws, unetk_pack_many; 8: unetk_prof_* (kernel trace), unetk_nan_watch
 
 extern "C" const char* unetk_error_string(int code) {
   switch (code) {

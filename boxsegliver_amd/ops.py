@@ -324,8 +324,14 @@ class _Op(torch.autograd.Function):
 
     @classmethod
     def apply(cls, *args, **kwargs):
+        # saved and restored: an op applied INSIDE another op's forward (the SE gate's FullyConnected under
+        # torch.enable_grad()) must not leave its own answer behind for the outer forward's grad_sink() calls
+        prev = _GradSink.tape
         _GradSink.tape = torch.is_grad_enabled()
-        return super(_Op, cls).apply(*args, **kwargs)
+        try:
+            return super(_Op, cls).apply(*args, **kwargs)
+        finally:
+            _GradSink.tape = prev
 
 
 def new_step(bufs=None):
@@ -337,6 +343,8 @@ def new_step(bufs=None):
         spans = [(b.data_ptr(), b.data_ptr() + b.numel() * b.element_size()) for b in bufs]
         _GradSink.written.difference_update([k for k in _GradSink.written if any(lo <= k < hi for lo, hi in spans)])
     FUSED_NBR.clear()
+    if _Side.pending:           # a backward that raised left filter gradients on the side stream un-joined
+        side_join()
 
 
 def grad_sink(p, ctx=None):
@@ -1007,6 +1015,13 @@ def sumsq(p):
     return out
 
 
+def nan_watch(value, flag, step):
+    """flag (int32[2], zeroed by the caller) becomes (1, step) at the first step whose `value` (a device scalar) is NaN."""
+    _require_cuda(value, flag)
+    assert value.dtype == torch.float32 and flag.dtype == torch.int32 and flag.numel() >= 2
+    check(_abi.lib().unetk_nan_watch(ptr(value), ptr(flag), int(step), stream_ptr()), "nan_watch")
+
+
 def guide_moments(guide, per_sample):
     """[groups, G + G*G]: E[g_i] and E[g_i g_j] of a (pooled) guide [N, H, W, G] per statistics group (GUNet --fix)."""
     _require_cuda(guide)
@@ -1168,7 +1183,10 @@ class Conv3x3NormRelu(_Op):
             src = getattr(x, "_unetk_unit", None)
             ctx.producer = src if (need_dx and src is not None and dilation == 1) else None
             ctx.simple = simple
-            ctx.save_for_backward(x, y, aff, guide, gw, gb, den)
+            if getattr(ctx, "want_pool", False):
+                ctx.unit_saved = (x, y, aff, guide, gw, gb, den)       # Conv3x3NormReluPool saves these together with its outputs
+            else:
+                ctx.save_for_backward(x, y, aff, guide, gw, gb, den)
             ctx.se_graph = se_graph
             ctx.wp_d = wp_d
             ctx.need_dx = need_dx
@@ -1194,7 +1212,7 @@ class Conv3x3NormRelu(_Op):
     def _backward(ctx, dz, pool=None):
         """`pool` = (dp, dskip): the unit's activation fed max_pool2d and the skip connection (Conv3x3NormReluPool) and its
         gradient dz = dskip + route(dp) is formed inside the norm backward's two passes instead of being written first."""
-        x, y, aff, guide, gw, gb, den = ctx.saved_tensors
+        x, y, aff, guide, gw, gb, den = ctx.saved_tensors[:7]
         pre = None
         if pool is None:
             pre = FUSED_NBR.pop(dz.data_ptr(), None) if DEBUG_CAPTURE is None else None
@@ -1278,13 +1296,16 @@ class Conv3x3NormReluPool(_Op):
         p = ctx.pooled if ctx.pooled is not None else maxpool2_fwd(z)
         ctx.pooled = None
         if spec.training:
-            ctx.pool_zp = (z, p)       # both alive anyway: z is the skip inside the concat buffer, p the next unit's input
+            # the node's own outputs go through save_for_backward like its inputs (a plain attribute would tie
+            # p -> grad_fn -> ctx -> p into a cycle that only a backward run breaks); both are alive anyway: z is the skip
+            # inside the concat buffer, p the next unit's input
+            ctx.save_for_backward(*(ctx.unit_saved + (z, p)))
+            ctx.unit_saved = None
         return p, z
 
     @staticmethod
     def backward(ctx, dp, dskip):
-        z, p = ctx.pool_zp
-        ctx.pool_zp = None
+        z, p = ctx.saved_tensors[7:9]
         if dskip is not None and dskip.stride(3) != 1:
             dskip = dskip.contiguous()
         plain_unit = ctx.saved_tensors[3] is None and ctx.saved_tensors[5] is None and ctx.saved_tensors[6] is None \

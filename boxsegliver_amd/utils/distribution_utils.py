@@ -81,22 +81,36 @@ class GradBuckets(object):
 
     def __init__(self, store, strategy, bucket_bytes=32 << 20):
         self.store, self.strategy = store, strategy
-        self.buckets = []                     # (group, lo, hi, n_vars)
+        self.buckets = []                     # (group, lo, hi, n_vars), in LAUNCH order = expected completion order
         self._bucket_of = {}
         self._hooks = []
-        for grp in ("reg", "noreg"):
-            names = sorted((n for n in store.trainable_names() if store.where[n][0] == grp),
-                           key=lambda n: -store.where[n][1])
-            hi, members = store.grad[grp].numel(), []
-            for k, name in enumerate(names):
-                off = store.where[name][1]
-                members.append(name)
-                if (hi - off) * 4 >= bucket_bytes or k == len(names) - 1:
-                    lo = 0 if k == len(names) - 1 else off
-                    for m in members:
-                        self._bucket_of[m] = len(self.buckets)
-                    self.buckets.append((grp, lo, hi, len(members)))
-                    hi, members = lo, []
+        # One walk over the variables in reverse forward order (= the order their gradients arrive in), cutting BOTH flat
+        # buffers at the same places: when the regularised buffer's current slice reaches `bucket_bytes` it is closed, and
+        # the norm parameters (gamma / beta, the other buffer) met on the way form the next bucket.  So bucket indices follow
+        # arrival time across both buffers -- a gamma / beta bucket waits for the filters of ITS OWN part of the network,
+        # not for the first layer's (round 3 numbered every "reg" bucket before any "noreg" one: the norm parameters'
+        # all-reduce could only start when backward was over).
+        names = list(reversed(store.trainable_names()))
+        hi = {g: store.grad[g].numel() for g in ("reg", "noreg")}
+        cur = {"reg": [], "noreg": []}
+
+        def close(grp, final):
+            if not cur[grp]:
+                return
+            lo = 0 if final else store.where[cur[grp][-1]][1]
+            assert all(store.where[a][1] > store.where[b][1] for a, b in zip(cur[grp], cur[grp][1:])), "offsets follow the specs"
+            for m in cur[grp]:
+                self._bucket_of[m] = len(self.buckets)
+            self.buckets.append((grp, lo, hi[grp], len(cur[grp])))
+            hi[grp], cur[grp] = lo, []
+
+        for k, name in enumerate(names):
+            grp, off = store.where[name][0], store.where[name][1]
+            cur[grp].append(name)
+            final = k == len(names) - 1
+            if final or (grp == "reg" and (hi["reg"] - off) * 4 >= bucket_bytes):
+                close("reg", final)
+                close("noreg", final)
         self._sink_keys = []
         self.history, self.last = [], None
         for name in store.trainable_names():
@@ -134,6 +148,7 @@ class GradBuckets(object):
     def _launch(self, b):
         grp, lo, hi, _ = self.buckets[b]
         self._fired[b] = True
+        self._launch_pos[b] = len(self._arrived)      # how many variables had arrived when this bucket went out
         ops.side_join()                       # filter gradients queued on the side stream (ops._Side) must be in the bucket
         self._works.append(dist.all_reduce(self.store.grad[grp][lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
@@ -141,6 +156,7 @@ class GradBuckets(object):
         """Call before backward of every step."""
         self._pending = [b[3] for b in self.buckets]
         self._fired = [False] * len(self.buckets)
+        self._launch_pos = [None] * len(self.buckets)
         self._ready = [False] * len(self.buckets)
         self._next = 0
         self._works = []
@@ -152,7 +168,11 @@ class GradBuckets(object):
         `last` (buckets, how many were launched from inside backward, and -- on a GPU -- HIP events bracketing the wait on
         the compute stream: the all-reduce time backward did not hide; read with exposed_ms() after a synchronize)."""
         self._armed = False
-        in_backward = sum(self._fired)
+        n_vars = len(self._bucket_of)
+        # launched while gradients were still outstanding, i.e. with backward work left to hide the transfer behind (a bucket
+        # launched from the very last arrival's hook is "in backward" by the clock but overlaps nothing)
+        in_backward = sum(1 for b in range(len(self.buckets)) if self._fired[b] and self._launch_pos[b] < n_vars)
+        launch_pos = list(self._launch_pos)
         for b in range(len(self.buckets)):
             self._ready[b] = True
         self._launch_ready()
@@ -165,7 +185,10 @@ class GradBuckets(object):
         if ev is not None:
             ev[1].record()
         self._works = []
-        self.last = {"buckets": len(self.buckets), "fired_in_backward": in_backward, "events": ev}
+        self.last = {"buckets": len(self.buckets), "fired_in_backward": in_backward, "events": ev,
+                     # per bucket: the fraction of the variables that had arrived when it was launched (None = by finish())
+                     "launch_progress": [None if p is None else round(p / float(max(n_vars, 1)), 4) for p in launch_pos],
+                     "bucket_bytes": [(hi - lo) * 4 for _, lo, hi, _ in self.buckets]}
         self.history.append(self.last)
         if len(self.history) > 64:
             del self.history[0]

@@ -486,6 +486,11 @@ int unetk_momentum_step(float* p, const float* g, float* acc, int64_t n, float l
 /* out[0] = sum(p^2) (fp64 accumulate) -- for the reported regularisation loss. ws >= 8 KiB. */
 int unetk_sumsq(const float* p, int64_t n, float* out, void* ws, size_t ws_bytes, void* stream);
 
+/* tf.train.NanTensorHook(loss) (core/estimator.py:676: every step, raises NanLossDuringTrainingError) without a host sync
+ * per step: if value[0] is NaN and flag[0] == 0, set flag[0] = 1 and flag[1] = step (sticky; the caller zeroes flag[0..1]
+ * once and reads it whenever it synchronises anyway: log steps, and before every checkpoint it writes). */
+int unetk_nan_watch(const float* value, int32_t* flag, int32_t step, void* stream);
+
 /* ---------------------------------------------------------------- kernel trace (measurement only; bench.py)
  * SURVEY.md 8d asks for the dominant kernel's launch duration "measured live inside bench.py with HIP events ... on the
  * stream the kernel is launched on".  The reference has no counterpart (its profiling is tf.train.ProfilerHook,

@@ -6,6 +6,8 @@ needs minutes per step there).  configs[1] (UNet bs 32) lives in test_gpu_unet.p
   configs[3]  GUNet + 1-channel spatial guide, instance norm, 256x256, bs 8 per GPU
   configs[2]  UNet 512x512, bs 8 per GPU, bf16 mode -- against the oracle restating the SAME bf16 arithmetic
   configs[4]  UNet3D, one 96^3 patch per GPU (the 8-GPU layout of SURVEY.md 8e)
+and the shape the reference's own 3-D script trains (threed_script/201_unet_v1.sh:22-46): UNet3D on 10 x 256 x 256 x 1
+patches, instance norm, loss_numeric_w 1 1, bs 4 (and bs 1 = its 4-GPU mirrored layout).
 """
 import numpy as np
 import pytest
@@ -137,3 +139,62 @@ def test_unet3d_config4_patch_against_device_float64_oracle():
     assert abs(loss.item() - total.item()) < 1e-4 * max(1.0, abs(total.item()))
     _check_logits(model.layers["logits"].double(), logits, 1e-3)
     assert _grad_l2(model, grads, logical=True) < 5e-3
+
+
+@pytest.mark.parametrize("bs", [4, 1])
+def test_unet3d_reference_script_shape_10x256x256_against_device_float64_oracle(bs):
+    """The reference's own 3-D training shape (threed_script/201_unet_v1.sh:22-46: --im_depth 10 --im_height 256 --im_width 256
+    --im_channel 1 --batch_size 4 --normalizer instance_norm --loss_numeric_w 1 1 --weight_decay_rate 0.00003; network
+    NetworksV2/UNet3D.py:123-186).  At 256-wide planes the fine levels take the TILED kernels on depth-strided plane views
+    (the 96^3 patch of configs[4] runs its 12 / 24-wide levels on the linear-pixel kernels) and the (2,2,2) bridge turns depth
+    10 into 5.  Whole step against the oracle in float64 on the device, then every unit's backward on identical operands."""
+    import test_gpu_unet3d as t
+    from boxsegliver_amd import ops
+    from boxsegliver_amd.NetworksV2.UNet3D import UNet3D
+    from boxsegliver_amd.data.synthetic import make_batch_3d
+    from oracle import unet3d
+    args = t.make_args(batch_size=bs, im_depth=10, im_height=256, im_width=256)
+    images, labels, _ = make_batch_3d(bs, 10, 256, 256, 1, 2, 201)
+    inputs = {"images": torch.from_numpy(images).cuda(), "labels": torch.from_numpy(labels).cuda()}
+    model = UNet3D(args)
+    model(inputs, "eval", **t.YML)
+    net = unet3d.UNet3DOracle(1, 2, normalizer=args.normalizer)
+    params = unet3d.init_params(net.specs, seed=5)
+    g = torch.Generator().manual_seed(9)
+    for name, _, kind in net.specs:
+        if kind == "gamma":
+            params[name] = 0.5 + torch.rand(params[name].shape, generator=g)
+        elif kind in ("beta", "bias"):
+            params[name] = 0.1 * torch.randn(params[name].shape, generator=g)
+    model.params.load_state(params)
+    p64 = {k: v.double().cuda() for k, v in params.items()}
+    total, _, logits, grads, _ = net.loss_and_grads(p64, inputs["images"].double(), inputs["labels"].long(),
+                                                    **t.kwargs_of(args))
+    ops.DEBUG_CAPTURE = []
+    try:
+        model.params.zero_grad()
+        loss = model(inputs, "train", **t.YML)
+        loss.backward()
+        torch.cuda.synchronize()
+        captured = ops.DEBUG_CAPTURE
+    finally:
+        ops.DEBUG_CAPTURE = None
+    assert abs(loss.item() - total.item()) < 1e-4 * max(1.0, abs(total.item()))
+    assert tuple(model.layers["logits"].shape) == (bs, 10, 256, 256, 2)
+    _check_logits(model.layers["logits"].double(), logits, 1e-3)
+    assert _grad_l2(model, grads, logical=True) < 5e-3
+    del logits, grads, p64
+    convs = [c for c in captured if c["kind"] == "conv3d"]
+    deconvs = [c for c in captured if c["kind"] == "deconv3d"]
+    assert len(convs) == 18 and len(deconvs) == 4
+    assert sorted(set(c["y"].shape[1] for c in convs)) == [5, 10]          # the (2,2,2) bridge: depth 10 -> 5
+    for c in convs:
+        t.check_conv3d_unit(c, dev="cuda")
+    for c in deconvs:
+        t.check_deconv3d(c, dev="cuda")
+    # the same step again without the capture (the production path: in-place parameter gradients): bit-identical loss
+    model.params.zero_grad()
+    loss2 = model(inputs, "train", **t.YML)
+    loss2.backward()
+    torch.cuda.synchronize()
+    assert loss2.item() == loss.item()

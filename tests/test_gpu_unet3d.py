@@ -55,8 +55,15 @@ def kwargs_of(args):
                 weight_decay_rate=args.weight_decay_rate)
 
 
-def check_conv3d_unit(c):
-    d64 = lambda t: None if t is None else t.detach().cpu().double().requires_grad_(True)
+def _rel_t(got, ref):
+    return ((got.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def check_conv3d_unit(c, dev="cpu"):
+    """One conv3d + norm + ReLU unit's backward in float64 on the operands the device used (dev = "cuda": the float64
+    evaluation itself runs on the GPU through the oracle's torch ops -- the checker for full-size layers)."""
+    d64 = lambda t: None if t is None else t.detach().to(dev).double().requires_grad_(True)
+    to = lambda t: t.detach().to(dev)
     y, g, b = d64(c["y"]), d64(c["gamma"]), d64(c["beta"])
     tol = 5e-4 if (c["per_sample"] and y.shape[1] * y.shape[2] * y.shape[3] <= 16) else 2e-5
     if c.get("plain"):                  # --without_norm: conv + bias + ReLU
@@ -64,33 +71,34 @@ def check_conv3d_unit(c):
     elif c["per_sample"]:
         z = tf_ops.instance_norm(y, g, b, eps=1e-6)
     else:
-        z, _, _ = tf_ops.batch_norm(y, g, b, torch.zeros(y.shape[-1], dtype=torch.float64),
-                                    torch.ones(y.shape[-1], dtype=torch.float64), True)
+        z, _, _ = tf_ops.batch_norm(y, g, b, torch.zeros(y.shape[-1], dtype=torch.float64, device=dev),
+                                    torch.ones(y.shape[-1], dtype=torch.float64, device=dev), True)
     if c.get("z") is not None:          # the device's own ReLU mask (see test_gpu_unet.check_unit_backward)
-        (z * (c["z"].detach().cpu() > 0).double()).backward(c["dz"].detach().cpu().double())
+        (z * (to(c["z"]) > 0).double()).backward(to(c["dz"]).double())
     else:
-        torch.relu(z).backward(c["dz"].detach().cpu().double())
-    assert rel(c["dy"].cpu().numpy(), y.grad.numpy()) < tol
+        torch.relu(z).backward(to(c["dz"]).double())
+    assert _rel_t(to(c["dy"]), y.grad) < tol
     if g is not None:
-        assert rel(c["dgamma"].cpu().numpy(), g.grad.numpy()) < tol
-    assert rel(c["dbeta"].cpu().numpy(), b.grad.numpy()) < tol
-    x = c["x"].detach().cpu().double().contiguous().requires_grad_(True)
-    w = c["w"].cpu().double().requires_grad_(True)
-    tf_ops.conv_nd_same(x, w, stride=c["stride"]).backward(c["dy"].detach().cpu().double())
-    assert rel(c["dw"].cpu().numpy(), w.grad.numpy()) < 2e-5
+        assert _rel_t(to(c["dgamma"]), g.grad) < tol
+    assert _rel_t(to(c["dbeta"]), b.grad) < tol
+    x = to(c["x"]).double().contiguous().requires_grad_(True)
+    w = to(c["w"]).double().requires_grad_(True)
+    tf_ops.conv_nd_same(x, w, stride=c["stride"]).backward(to(c["dy"]).double())
+    assert _rel_t(to(c["dw"]), w.grad) < 2e-5
     if c["dx"] is not None:
-        assert rel(c["dx"].cpu().numpy(), x.grad.numpy()) < 2e-5
+        assert _rel_t(to(c["dx"]), x.grad) < 2e-5
 
 
-def check_deconv3d(c):
-    x = c["x"].detach().cpu().double().requires_grad_(True)
-    w = c["w"].cpu().double().requires_grad_(True)
+def check_deconv3d(c, dev="cpu"):
+    to = lambda t: t.detach().to(dev)
+    x = to(c["x"]).double().requires_grad_(True)
+    w = to(c["w"]).double().requires_grad_(True)
     coff, kd = c["coff"], c["kd"]
     pre = tf_ops.conv_transpose_ks(x, w, (kd, 2, 2))
-    mask = (c["cat"][..., coff:].cpu() > 0).double()
-    (pre * mask).backward(c["dcat"][..., coff:].detach().cpu().double())
-    assert rel(c["dx"].cpu().numpy(), x.grad.numpy()) < 2e-5
-    assert rel(c["dw"].cpu().numpy(), w.grad.numpy()) < 2e-5
+    mask = (to(c["cat"][..., coff:]) > 0).double()
+    (pre * mask).backward(to(c["dcat"][..., coff:]).double())
+    assert _rel_t(to(c["dx"]), x.grad) < 2e-5
+    assert _rel_t(to(c["dw"]), w.grad) < 2e-5
 
 
 def test_unet3d_matches_oracle_and_padding_is_exact():
