@@ -147,6 +147,92 @@ def cpu_baseline(size, full=False):
     return out
 
 
+def infer_main(a, args, model, inputs_of, data, gflop_unit, workload_name, rank, world):
+    """--mode infer: EvaluateVolume's per-slab work (evaluators/evaluator_liver.py `_slab_probability` / `_predict_case`, the
+    device-side restatement of the reference's evaluator_liver.py:616-678,704-766) on resident synthetic slabs.  One step =
+    one slab of --batch slices: forward in EVAL mode (moving statistics; conv + norm + ReLU [+ pool] fused per unit), softmax,
+    mirror variants un-flipped and averaged on the device; every --case-slabs steps a case ends: concatenation, argmax
+    (unetk_head_predict) and ONE uint8 device -> host copy.  Forward-only algorithmic FLOPs = a third of fwd+bwd."""
+    from boxsegliver_amd import ops
+    from boxsegliver_amd.evaluators import evaluator_liver as ev
+    from boxsegliver_amd.core import models
+    args.eval_mirror, args.random_flip = bool(a.mirror), (3 if a.mirror else 0)
+    params = {"args": args, "model": type(model), "model_instances": [model], "model_args": (),
+              "model_kwargs": dict(models.get_model_params(args, build_metrics=False)["model_kwargs"])}
+    evaluator = ev.EvaluateVolume(estimator=None, model_dir="/nonexistent", params=params)
+    feats = []
+    for _ in range(2):
+        inp = inputs_of(next(data))
+        inp.pop("labels", None)
+        feats.append(inp)
+    n_fwd = 1 + len(evaluator.mirror_variants)
+    slabs = []
+
+    def one_step(i):
+        slabs.append(evaluator._slab_probability(model, feats[i % 2]))
+        if len(slabs) == a.case_slabs:
+            volume = torch.cat(slabs)
+            amax, _ = ops.head_predict(volume.contiguous(), volume.shape[-1], want_preds=False)
+            host = amax.view(volume.shape[:-1]).cpu()           # the case's segmentation: one uint8 copy (a host sync per case)
+            del slabs[:]
+            return host
+        return None
+
+    prof_list = [] if (rank == 0 and not a.no_kernel_events) else None
+    ev_stride = 1 if a.steps <= 4 else 4
+    n_ev_steps = len(range(0, a.steps, ev_stride))
+    for j in range(a.warmup):
+        one_step(j)
+    del slabs[:]
+    if prof_list is not None:
+        ops.profile_begin(4096 * n_ev_steps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        if prof_list is not None:
+            ops.profile_on(prof_list if i % ev_stride == 0 else None)
+        one_step(i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.profile_on(None)
+    trace_ms, trace_names = ops.profile_read() if prof_list is not None else ([], [])
+    ms = elapsed / a.steps * 1e3
+    slices = a.batch * a.steps / elapsed
+    fwd_gflop = gflop_unit / 3.0                               # fwd + dgrad + wgrad are three equal contractions
+    tfl = slices * n_fwd * fwd_gflop / 1e3
+    wl = (workload_name or "UNet 2D Liver+Tumor {0}x{0}x3 bs={1}/GPU fp32").format(a.size, a.batch)
+    out = {"metric": "CT slices/sec (volume evaluation, forward only{})".format(", mirror TTA x4" if a.mirror else ""),
+           "value": round(slices, 2), "unit": "slices/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32" if a.dtype == "fp32" else "bf16", "data": "synthetic",
+           "config": {"workload": wl + ", EvaluateVolume slab loop (eval mode, moving statistics), {} forward(s) per slab, "
+                                     "a case = {} slabs".format(n_fwd, a.case_slabs),
+                      "global_batch": a.batch, "parallelism": "dp1", "forwards_per_slab": n_fwd},
+           "forward_tflops": round(tfl, 2), "forward_frac_of_fp32_peak": round(tfl / FP32_PEAK_TFLOPS, 4),
+           "fused_eval_epilogue": bool(ops.FUSE_EVAL)}
+    if prof_list:
+        agg, hbm = {}, {}
+        for tag, flops, i0, i1, nbytes in prof_list:
+            secs = sum(trace_ms[i0:i1]) * 1e-3
+            if flops > 0:
+                d = agg.setdefault(tag, [0, 0.0, 0.0])
+                d[0] += 1; d[1] += flops; d[2] += secs
+            elif nbytes:
+                h = hbm.setdefault(tag, [0, 0, 0.0])
+                h[0] += 1; h[1] += nbytes; h[2] += secs
+        out["gpu_kernel_ms_per_step"] = round(sum(trace_ms) / n_ev_steps, 3)
+        out["kernels"] = sorted([{"kernel": t, "launches": c, "avg_launch_ms": round(sc / c * 1e3, 4),
+                                  "achieved_tflops": round(f / sc / 1e12, 2), "total_ms_per_step": round(sc / n_ev_steps * 1e3, 3)}
+                                 for t, (c, f, sc) in agg.items() if sc > 0], key=lambda k: -k["total_ms_per_step"])
+        out["hbm_kernels"] = sorted([{"kernel": t, "launches": c, "avg_launch_ms": round(sc / c * 1e3, 4),
+                                      "achieved_gbps": round(nb / sc / 1e9, 1), "total_ms_per_step": round(sc / n_ev_steps * 1e3, 3)}
+                                     for t, (c, nb, sc) in hbm.items() if sc > 0], key=lambda k: -k["total_ms_per_step"])
+        top = out["kernels"][0]
+        out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved_tflops"], "peak": FP32_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(top["achieved_tflops"] / FP32_PEAK_TFLOPS, 4), "traffic": None}
+    print(json.dumps(out, ensure_ascii=False), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,6 +254,13 @@ def main():
                     help="fp32 = the headline configuration (exact fp32 MFMA); bf16 = BASELINE.json configs[2]'s mode: bf16 "
                          "matrix cores + bf16 storage of activations / activation gradients, fp32 accumulate / statistics / "
                          "master weights (use --size 512 --batch 8); bf16c = bf16 MFMA operands only, fp32 storage (round 1)")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+                    help="train = the headline metric (fwd+bwd+optimiser); infer = the volume evaluator's slab loop "
+                         "(evaluators/evaluator_liver.py:616-766: forward with moving statistics, softmax, mirror un-flip / "
+                         "averaging, per-case argmax + one uint8 copy to the host) on synthetic slabs: slices/s, forward only")
+    ap.add_argument("--mirror", action="store_true", help="--mode infer: --eval_mirror --random_flip 3 (the un-mirrored slab + "
+                                                          "three flipped variants, averaged: evaluator_liver.py:648-655)")
+    ap.add_argument("--case-slabs", type=int, default=8, help="--mode infer: slabs (steps) per case; a case ends with cat + argmax + D2H")
     ap.add_argument("--dp-rehearsal", action="store_true",
                     help="with --gpus 1: run the data-parallel code path (process group on RCCL, bucketed all-reduce launched from "
                          "backward, 1/N in the optimiser) in a world of ONE rank -- the production path on the one GPU a test box has")
@@ -263,6 +356,8 @@ def main():
         return inp
 
     model(inputs_of(next(data)), "eval", **YML)                                   # create variables
+    if a.mode == "infer":
+        return infer_main(a, args, model, inputs_of, data, gflop_unit, workload_name, rank, world)
     if strategy is not None:
         strategy.broadcast_(list(model.params.flat.values()))                      # identical replicas
 

@@ -156,6 +156,12 @@ struct ConvParams {
   const void* ny;
   const float *nsc, *nsh, *nmu, *nrs;
   int nys, nsst;
+  // inference epilogue (unetk_conv3x3_fwd_affine): the normaliser's per-channel (scale, shift) are known before the conv runs
+  // (moving statistics / --without_norm), so the epilogue writes z = relu(acc * asc[c] + ash[c]) instead of the raw output,
+  // and -- pool != nullptr -- also max_pool2d(z, 2, 2) into pool[N, H/2, W/2, .] (pixel stride pool_s; H and W even)
+  const float *asc, *ash;
+  void* pool;
+  int pool_s;
   // stream-K scheduling of the linear-pixel kernel (conv_igemm_lin.hip): slab for the pieces of split tiles
   // ([sk_tiles][sk_maxp][BM][BN] floats, caller's workspace; nullptr = one block per tile), chunks per tile, tiles
   float* sk_slab;

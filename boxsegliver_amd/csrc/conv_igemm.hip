@@ -52,9 +52,14 @@ constexpr int TW = 16;   // spatial tile width
 // MODE 1 = the epilogue accumulates (y += acc: depth taps of a 3-D conv) -- also its own instantiation: the sixteen old
 // values per fragment it keeps in flight are 32 registers the plain kernel does not need (114 -> 71 VGPRs, i.e. three
 // waves per SIMD instead of two next to the 64 accumulator registers).
+// MODE 3 / 4 (inference, unetk_conv3x3_fwd_affine): the epilogue applies the normaliser's (scale, shift) + ReLU to the
+// accumulators and stores the ACTIVATION (no raw output, no statistics, no second pass); MODE 4 also stores max_pool2d(z, 2, 2):
+// a 32-row fragment is two tile rows x 16 columns and a lane holds columns {0-3, 8-11} + 4 h of BOTH rows, i.e. four whole
+// 2 x 2 windows -- the pool is four register maxima, no shuffles.
 template <int WM, int WN, int TM, int TN, int S = 1, int DIL = 1, int MODE = 0>
 __global__ __launch_bounds__(WM* WN * 64, (TM * TN == 8 ? 2 : 1)) void conv3x3_igemm_kernel(ConvParams p) {
-  constexpr bool NBR = MODE == 2, ACC = MODE == 1;
+  constexpr bool NBR = MODE == 2, ACC = MODE == 1, AFF = MODE >= 3, POOL = MODE == 4;
+  static_assert(!AFF || (S == 1 && DIL == 1), "the fused inference epilogue is for plain 3x3 convs");
   static_assert(S == 1 || DIL == 1, "strided atrous convs are not needed");
   static_assert(!NBR || (S == 1 && DIL == 1), "the fused reduction is for plain 3x3 convs");
   constexpr int NT = WM * WN * 64;
@@ -245,6 +250,44 @@ __global__ __launch_bounds__(WM* WN * 64, (TM * TN == 8 ? 2 : 1)) void conv3x3_i
         }
       }
     }
+    if constexpr (AFF) {
+      float sc[TN], sh[TN];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        sc[tn] = p.asc[n0 + (wn * TN + tn) * 32 + l31];
+        sh[tn] = p.ash[n0 + (wn * TN + tn) * 32 + l31];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = mfma32_row(r, h);
+        const int gh = h0 + 2 * sub + (i >> 4), gw = w0 + (i & 15);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn][r] = fmaxf(fmaf(acc[tm][tn][r], sc[tn], sh[tn]), 0.f);
+        if (gh < p.H && gw < p.W) {
+          float* yp = p.y + yimg + ((int64_t)gh * p.W + gw) * p.ys + n0 + wn * TN * 32 + l31;
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) yp[tn * 32] = acc[tm][tn][r];
+        }
+      }
+      if constexpr (POOL) {
+        // window q of the lane: registers 2 q, 2 q + 1 (tile row 2 sub) and 8 + 2 q, 9 + 2 q (tile row 2 sub + 1)
+        const int Hp = p.H >> 1, Wp = p.W >> 1;
+        float* pimg = static_cast<float*>(p.pool) + (int64_t)n_img * Hp * Wp * p.pool_s + n0 + wn * TN * 32 + l31;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = mfma32_row(2 * q, h);
+          const int gh = h0 + 2 * sub, gw = w0 + (i & 15);
+          if (gh < p.H && gw < p.W) {
+            float* pp = pimg + ((int64_t)(gh >> 1) * Wp + (gw >> 1)) * p.pool_s;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+              pp[tn * 32] = fmaxf(fmaxf(acc[tm][tn][2 * q], acc[tm][tn][2 * q + 1]),
+                                  fmaxf(acc[tm][tn][8 + 2 * q], acc[tm][tn][9 + 2 * q]));
+          }
+        }
+      }
+      continue;
+    }
     if constexpr (NBR) {
       // fused norm-backward reduction of the producing unit (see ConvParams::ny): its raw output at this fragment's
       // pixels, eight rows' loads issued together (all sixteen cost 32 more live registers; the 2-D input gradient never
@@ -297,6 +340,7 @@ __global__ __launch_bounds__(WM* WN * 64, (TM * TN == 8 ? 2 : 1)) void conv3x3_i
       }
     }
   }
+  if constexpr (AFF) return;
   if (p.stat != nullptr) {
     float* red = smem;  // [2][WM][BN]; all LDS reads of the main loop are behind its last barrier
 #pragma unroll
@@ -424,7 +468,8 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvParams p) {
 // per-lane constant) and filter values from registers.  Accumulator column l31 of tile t is output channel 2 l31 + t, so a
 // lane stores a channel PAIR per pixel (8 bytes fp32, 4 bytes bf16: 256- / 128-byte rows per store instruction) straight
 // from the accumulators; statistics = per-lane column sums, the two row halves by a shuffle, the four waves through LDS.
-template <int CIN, typename TY = float>
+// AFF: the inference epilogue (see conv3x3_igemm_kernel MODE 3): the activation relu(acc * scale + shift) is stored, no statistics.
+template <int CIN, typename TY = float, bool AFF = false>
 __global__ __launch_bounds__(256) void conv3x3_c3_mfma_kernel(ConvParams p) {
   static_assert(CIN >= 1 && CIN <= 5, "K = 9 Cin <= 46");
   constexpr int K = 9 * CIN, NS = (K + 1) / 2, COUT = 64;
@@ -450,6 +495,11 @@ __global__ __launch_bounds__(256) void conv3x3_c3_mfma_kernel(ConvParams p) {
     b1[s2] = on ? wv.y : 0.f;
     const int t = kk / CIN, ci = kk - t * CIN;
     aoff[s2] = ((pr + t / 3) * 18 + pc + t % 3) * CIN + ci;
+  }
+  float asc0 = 1.f, asc1 = 1.f, ash0 = 0.f, ash1 = 0.f;
+  if constexpr (AFF) {
+    asc0 = p.asc[2 * l31]; asc1 = p.asc[2 * l31 + 1];
+    ash0 = p.ash[2 * l31]; ash1 = p.ash[2 * l31 + 1];
   }
   const int n_tiles = p.N * p.tiles_h * p.tiles_w;
   // the next tile's halo waits in registers while this tile is contracted and stored
@@ -499,9 +549,13 @@ __global__ __launch_bounds__(256) void conv3x3_c3_mfma_kernel(ConvParams p) {
       const int gh = h0 + (pix >> 4), gw = w0 + (pix & 15);
       if (gh < p.H && gw < p.W) {
         float v0 = acc0[r], v1 = acc1[r];
+        if constexpr (AFF) {
+          v0 = fmaxf(fmaf(v0, asc0, ash0), 0.f);
+          v1 = fmaxf(fmaf(v1, asc1, ash1), 0.f);
+        }
         TY* yp = yimg + ((int64_t)gh * p.W + gw) * p.ys;
         if constexpr (std::is_same<TY, float>::value) {
-          if (p.accumulate) {
+          if (!AFF && p.accumulate) {
             const float2 o = *reinterpret_cast<const float2*>(yp);
             v0 += o.x; v1 += o.y;
           }
@@ -512,7 +566,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_mfma_kernel(ConvParams p) {
         s0 += v0; s1 += v1; q0 += v0 * v0; q1 += v1 * v1;
       }
     }
-    if (p.stat != nullptr) {
+    if (!AFF && p.stat != nullptr) {
       s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32); q0 += __shfl_xor(q0, 32); q1 += __shfl_xor(q1, 32);
       if (h == 0) {
         red[(0 * 4 + wave) * COUT + 2 * l31] = s0; red[(0 * 4 + wave) * COUT + 2 * l31 + 1] = s1;
@@ -606,6 +660,15 @@ int launch_igemm_mode(const ConvParams& p, int n_mtiles, hipStream_t st) {
 template <int WM, int WN, int TM, int TN, int S = 1, int DIL = 1, bool NBR = false>
 int launch_igemm(const ConvParams& p, int n_mtiles, hipStream_t st) {
   if constexpr (NBR) return launch_igemm_mode<WM, WN, TM, TN, S, DIL, 2>(p, n_mtiles, st);
+  if (p.asc != nullptr) {       // inference epilogue: (scale, shift) + ReLU [+ 2 x 2 max-pool]
+    if constexpr (S == 1 && DIL == 1) {
+      if (p.accumulate || p.stat != nullptr) return UNETK_E_UNSUPPORTED;
+      return p.pool != nullptr ? launch_igemm_mode<WM, WN, TM, TN, 1, 1, 4>(p, n_mtiles, st)
+                               : launch_igemm_mode<WM, WN, TM, TN, 1, 1, 3>(p, n_mtiles, st);
+    } else {
+      return UNETK_E_UNSUPPORTED;
+    }
+  }
   if (p.accumulate) return launch_igemm_mode<WM, WN, TM, TN, S, DIL, 1>(p, n_mtiles, st);
   return launch_igemm_mode<WM, WN, TM, TN, S, DIL, 0>(p, n_mtiles, st);
 }
@@ -627,7 +690,7 @@ int unetk_conv_stat_rows(int N, int H, int W, int Cin, int Cout, int spg, int st
 bool unetk_conv_stride2_ok(int Cin, int Cout) { return Cin % CK == 0 && Cout % 64 == 0; }
 
 int unetk_conv_run(ConvParams p, hipStream_t st) {
-  if (p.ny != nullptr && (p.stride == 2 || p.dil == 2)) return UNETK_E_UNSUPPORTED;
+  if ((p.ny != nullptr || p.asc != nullptr) && (p.stride == 2 || p.dil == 2)) return UNETK_E_UNSUPPORTED;
   if (p.stride == 2) {   // p.H x p.W = output extent, p.Hin x p.Win = input extent
     if (p.bf16 || !unetk_conv_stride2_ok(p.Cin, p.Cout) || p.xs % 4 != 0) return UNETK_E_UNSUPPORTED;
     p.tiles_h = (p.H + s2_th(p.Cout) - 1) / s2_th(p.Cout);
@@ -655,9 +718,10 @@ int unetk_conv_run(ConvParams p, hipStream_t st) {
     return launch_igemm<4, 1, 1, 2, 1, 2>(p, n_mt, st);
   }
   if (p.dil > 2 || p.dil < 0) return UNETK_E_UNSUPPORTED;
-  if (p.bf16) return unetk_conv_run_bf16(p, st);
+  if (p.bf16) return p.asc != nullptr ? UNETK_E_UNSUPPORTED : unetk_conv_run_bf16(p, st);
   if (p.spg < 1) p.spg = 1;
-  if (unetk_conv_lin_ok(p.N, p.H, p.W, p.Cin, p.Cout, p.spg)) return unetk_conv_run_lin(p, st);   // small planes: linear M
+  if (unetk_conv_lin_ok(p.N, p.H, p.W, p.Cin, p.Cout, p.spg))                                     // small planes: linear M
+    return (p.asc != nullptr && (p.pool != nullptr || p.accumulate || p.kd > 1)) ? UNETK_E_UNSUPPORTED : unetk_conv_run_lin(p, st);
   const ConvCfg cfg = pick_cfg(p.Cin, p.Cout);
   const int th = tile_rows(p.N, p.H, p.W, p.Cin, p.Cout, p.spg, p.ny != nullptr);
   const bool small = cfg.id == 0 && th == 4, big = cfg.id <= 1 && th == 16;
@@ -704,15 +768,20 @@ int unetk_conv_run(ConvParams p, hipStream_t st) {
     const int c3_grid = n_mtiles < 256 * 6 ? n_mtiles : 256 * 6;      // persistent: six resident blocks per CU walk the tiles
 #define C3_LAUNCH(CI)                                                                                              \
   case CI:                                                                                                         \
-    if (p.ybf16) UNETK_LAUNCH((conv3x3_c3_mfma_kernel<CI, bf16_t>), dim3(c3_grid), dim3(256), l3, st, p);   \
-    else UNETK_LAUNCH((conv3x3_c3_mfma_kernel<CI, float>), dim3(c3_grid), dim3(256), l3, st, p);            \
+    if (p.asc != nullptr) {                                                                                        \
+      if (p.ybf16) UNETK_LAUNCH((conv3x3_c3_mfma_kernel<CI, bf16_t, true>), dim3(c3_grid), dim3(256), l3, st, p);  \
+      else UNETK_LAUNCH((conv3x3_c3_mfma_kernel<CI, float, true>), dim3(c3_grid), dim3(256), l3, st, p);           \
+    } else if (p.ybf16) UNETK_LAUNCH((conv3x3_c3_mfma_kernel<CI, bf16_t>), dim3(c3_grid), dim3(256), l3, st, p);   \
+    else UNETK_LAUNCH((conv3x3_c3_mfma_kernel<CI, float>), dim3(c3_grid), dim3(256), l3, st, p);                   \
     break;
     if (p.ybf16 && p.accumulate) return UNETK_E_UNSUPPORTED;
+    if (p.asc != nullptr && (p.pool != nullptr || p.accumulate || p.stat != nullptr)) return UNETK_E_UNSUPPORTED;
     switch (p.Cin) { C3_LAUNCH(1) C3_LAUNCH(2) C3_LAUNCH(3) C3_LAUNCH(4) C3_LAUNCH(5) default: break; }
 #undef C3_LAUNCH
     UNETK_LAUNCH_CHECK();
     return UNETK_OK;
   }
+  if (p.asc != nullptr) return UNETK_E_UNSUPPORTED;      // the generic direct kernel has no inference epilogue
   if (p.ybf16) {      // UNETK_BF16S first layer: fp32 image in, bf16 out
     if (p.accumulate) return UNETK_E_UNSUPPORTED;
     switch (p.Cin) {
@@ -802,6 +871,34 @@ extern "C" int unetk_conv3x3_fwd_ws(const unetk_conv_desc* d, const void* x, con
   p.xa = unetk_dense_addr(p.H, p.W, p.xs);
   p.ya = unetk_dense_addr(p.H, p.W, p.ys);
   if (ws && unetk_aligned16(ws) && ws_bytes > 0) { p.sk_slab = (float*)ws; p.sk_slab_bytes = ws_bytes; }
+  return unetk_conv_run(p, (hipStream_t)stream);
+}
+
+// ---- inference: conv + (scale, shift) + ReLU [+ 2 x 2 max-pool] in one pass
+extern "C" int unetk_conv3x3_fwd_affine_ok(const unetk_conv_desc* d, int with_pool) {
+  if (!conv_desc_ok(d) || d->dilation > 1 || d->precision != UNETK_FP32) return 0;
+  if (with_pool && ((d->H | d->W) & 1)) return 0;
+  if (pick_cfg(d->Cin, d->Cout).id >= 0)       // the small-plane (linear-pixel) kernel has the affine epilogue but no pool
+    return (unetk_conv_lin_ok(d->N, d->H, d->W, d->Cin, d->Cout, 1) && with_pool) ? 0 : 1;
+  return (d->Cout == 64 && d->Cin >= 1 && d->Cin <= 5 && !with_pool) ? 1 : 0;
+}
+
+extern "C" int unetk_conv3x3_fwd_affine(const unetk_conv_desc* d, const void* x, const void* w, const float* scale,
+                                        const float* shift, void* z, void* pooled, int pooled_stride, void* ws,
+                                        size_t ws_bytes, void* stream) {
+  UNETK_REQUIRE(conv_desc_ok(d) && x && w && z && scale && shift);
+  UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(w) && unetk_aligned16(z));
+  UNETK_REQUIRE(d->y_stride % 4 == 0 && (pooled == nullptr || pooled_stride >= d->Cout));
+  if (!unetk_conv3x3_fwd_affine_ok(d, pooled != nullptr)) return UNETK_E_UNSUPPORTED;
+  if (pick_cfg(d->Cin, d->Cout).id >= 0) UNETK_REQUIRE(d->x_stride % 4 == 0);
+  ConvParams p{};
+  p.x = (const float*)x; p.wp = (const float*)w; p.y = (float*)z; p.stat = nullptr;
+  p.asc = scale; p.ash = shift; p.pool = pooled; p.pool_s = pooled_stride;
+  if (ws && unetk_aligned16(ws) && ws_bytes > 0) { p.sk_slab = (float*)ws; p.sk_slab_bytes = ws_bytes; }   // stream-K scratch
+  p.dil = d->dilation;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.xs = d->x_stride; p.ys = d->y_stride;
+  p.xa = unetk_dense_addr(p.H, p.W, p.xs);
+  p.ya = unetk_dense_addr(p.H, p.W, p.ys);
   return unetk_conv_run(p, (hipStream_t)stream);
 }
 

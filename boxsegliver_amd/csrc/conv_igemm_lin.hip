@@ -440,12 +440,20 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
         }
         if (pb + delta < P1) {
           float* rp = p.y + img + (int64_t)rem * p.ys + n0 + wn * TN * 32 + l31;
+          if (p.asc != nullptr) {      // inference epilogue (unetk_conv3x3_fwd_affine): the activation, no statistics
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn) {
-            const float v = acc[tm][tn][r];
-            rp[tn * 32] = v;
-            ssum[tn] += v;
-            ssq[tn] += v * v;
+            for (int tn = 0; tn < TN; ++tn) {
+              const int ch = n0 + (wn * TN + tn) * 32 + l31;
+              rp[tn * 32] = fmaxf(fmaf(acc[tm][tn][r], p.asc[ch], p.ash[ch]), 0.f);
+            }
+          } else {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+              const float v = acc[tm][tn][r];
+              rp[tn * 32] = v;
+              ssum[tn] += v;
+              ssq[tn] += v * v;
+            }
           }
         }
       }
@@ -539,6 +547,11 @@ __global__ __launch_bounds__(256) void lin_sk_fixup_kernel(ConvParams p, int G) 
     }
     const int pix = P0 + row;
     const int plane = pix / HW, rem = pix - plane * HW;
+    if (p.asc != nullptr) {            // inference epilogue on the summed pieces
+      const float4 sc = ldg4(p.asc + n0 + cq * 4), sh = ldg4(p.ash + n0 + cq * 4);
+      v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+      v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+    }
     stg4(p.y + p.ya.off(plane) + (int64_t)rem * p.ys + n0 + cq * 4, v);
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;

@@ -38,6 +38,7 @@ class _Workspace(object):
 
 
 WORKSPACE = _Workspace()
+FUSE_EVAL = os.environ.get("UNETK_FUSE_EVAL", "1") != "0"    # inference: conv + (scale, shift) + ReLU [+ pool] in one kernel (0: two passes, measurement)
 FUSE_NBR = True         # conv2's input gradient also emits conv1's norm-backward reduction (unetk_conv3x3_dgrad_nbr)
 FUSED_NBR = {}          # dx.data_ptr() -> (producer y.data_ptr(), shape, partials, rows, dx._version); consumed by the producer's backward
 DEBUG_CAPTURE = None    # tools/: set to a list to record each conv unit's backward operands
@@ -489,6 +490,27 @@ def conv3x3_fwd(x, w, cout, want_stats=True, y=None, bf16=False, dilation=1):
         check(_abi.lib().unetk_conv3x3_fwd_ws(ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(stats), ptr(ws), nws,
                                               stream_ptr()), "conv3x3_fwd")
     return y, stats, rows
+
+
+def conv3x3_fwd_affine(x, w, cout, scale, shift, z=None, pool=False):
+    """Inference: z = relu(conv3x3(x, w) * scale + shift) [and max_pool2d(z, 2, 2)] in one kernel (unetk_conv3x3_fwd_affine);
+    w as for conv3x3_fwd.  Returns (z, pooled or None); raises UNETK_E_UNSUPPORTED shapes (ask conv3x3_fwd_affine_ok first)."""
+    _require_cuda(x, w)
+    n, h, wd, cin = x.shape
+    if z is None:
+        z = torch.empty((n, h, wd, cout), dtype=torch.float32, device=x.device)
+    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(x), _pix_stride(z), _abi.FP32, 1)
+    pooled = torch.empty((n, h // 2, wd // 2, cout), dtype=torch.float32, device=x.device) if pool else None
+    nws = _abi.lib().unetk_conv3x3_ws_bytes(ctypes.byref(d))
+    ws = WORKSPACE.get(nws, x.device) if nws else None
+    check(_abi.lib().unetk_conv3x3_fwd_affine(ctypes.byref(d), ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(z), ptr(pooled), cout,
+                                              ptr(ws), nws, stream_ptr()), "conv3x3_fwd_affine")
+    return z, pooled
+
+
+def conv3x3_fwd_affine_ok(n, h, wd, cin, cout, pool=False):
+    d = ConvDesc(n, h, wd, cin, cout, cin, cout, _abi.FP32, 1)
+    return _abi.lib().unetk_conv3x3_fwd_affine_ok(ctypes.byref(d), 1 if pool else 0) == 1
 
 
 def conv3x3_dgrad(dy, wp_dgrad, cin, x_stride=None, dx=None, bf16=False, dilation=1, producer=None):
@@ -1111,6 +1133,31 @@ class Conv3x3NormRelu(_Op):
         use_batch_stats = (spec.training or spec.per_sample) and not plain
         if se is not None and (plain or den is not None):
             raise _abi.UnetkError("--use_se needs a normalised unit and no other density gain")
+        # ---- inference fast path: the affine is known before the conv (moving statistics / --without_norm), so conv +
+        # (scale, shift) + ReLU [+ the 2 x 2 max-pool the unit feeds] are ONE kernel and the raw output never exists
+        if FUSE_EVAL and not spec.training and not use_batch_stats and se is None and den is None and guide is None \
+                and gb is None and precision_of(bf16) == _abi.FP32 and dilation == 1:
+            n_, h_, w_ = x.shape[0], x.shape[1], x.shape[2]
+            z = out if out is not None else torch.empty((n_, h_, w_, cout), dtype=torch.float32, device=x.device)
+            fd = ConvDesc(n_, h_, w_, cin, cout, _pix_stride(x), _pix_stride(z), _abi.FP32, 1)
+            want_pool = bool(getattr(ctx, "want_pool", False)) and POOL_FUSED
+            with_pool = want_pool and _abi.lib().unetk_conv3x3_fwd_affine_ok(ctypes.byref(fd), 1) == 1
+            if with_pool or _abi.lib().unetk_conv3x3_fwd_affine_ok(ctypes.byref(fd), 0) == 1:
+                nd = norm_desc((n_, h_, w_, cout), False, _pix_stride(z), 0, 0, 0)
+                if plain:
+                    sc, sh = torch.ones_like(beta), beta.detach().contiguous()
+                else:
+                    aff = norm_finalize(nd, None, 0, gamma, beta, spec.eps, spec.decay, False, moving_mean, moving_var, x.device)
+                    sc, sh = aff[2], aff[3]
+                pooled = torch.empty((n_, h_ // 2, w_ // 2, cout), dtype=torch.float32, device=x.device) if with_pool else None
+                tag = _igemm_tag(cin, cout, False, h_, n_, w_) + ("+affine+relu+pool" if with_pool else "+affine+relu")
+                nws = _abi.lib().unetk_conv3x3_ws_bytes(ctypes.byref(fd))
+                ws = WORKSPACE.get(nws, x.device) if nws else None
+                with _timed(tag, 18.0 * n_ * h_ * w_ * cin * cout, "infer {}x{}x{} {}->{}", (n_, h_, w_, cin, cout)):
+                    check(_abi.lib().unetk_conv3x3_fwd_affine(ctypes.byref(fd), ptr(x), ptr(wp_f), ptr(sc), ptr(sh), ptr(z),
+                                                              ptr(pooled), cout, ptr(ws), nws, stream_ptr()), "conv3x3_fwd_affine")
+                ctx.pooled = pooled
+                return alias(z) if out is not None else z
         y, stats, rows = conv3x3_fwd(x, wp_f, cout, want_stats=use_batch_stats or se is not None, bf16=bf16, dilation=dilation)
         z = out if out is not None else torch.empty_like(y)
         g_ch = 0 if guide is None else guide.shape[-1]

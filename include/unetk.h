@@ -140,6 +140,22 @@ int unetk_conv3x3_fwd_ws(const unetk_conv_desc* d, const void* x, const void* w,
 int unetk_conv3x3_dgrad_ws(const unetk_conv_desc* d, const void* dy, const void* w, void* dx, void* ws,
                            size_t ws_bytes, void* stream);
 
+/* Inference (mode == EVAL, NetworksV2/base.py:71-79: is_training False -> slim.batch_norm uses the moving statistics;
+ * --without_norm: conv + bias + ReLU, UNet.py:47-48): the normaliser's per-channel affine is known BEFORE the conv runs, so
+ * the conv, slim.batch_norm and ReLU of one slim.conv2d(x, C, 3) -- and, when the unit feeds one, slim.max_pool2d(z, 2, 2)
+ * (UNet.py:81) -- are ONE pass: z = relu(conv(x, w) * scale[c] + shift[c]) is written straight to z (pixel stride
+ * d->y_stride: a channel slice of the decoder's concat buffer), the raw conv output never reaches memory.  SURVEY.md 7
+ * step 2 / 8b `unetk_conv_fwd(..., scale, shift, ...)`.  scale / shift: [Cout] floats (unetk_norm_finalize rows 2, 3).
+ * pooled != NULL: also pooled[N, H/2, W/2, .] (pixel stride pooled_stride) = max over each 2 x 2 window of z; H, W even.
+ * ws / ws_bytes: the stream-K scratch of unetk_conv3x3_ws_bytes (small planes), may be NULL / 0.
+ * unetk_conv3x3_fwd_affine_ok = 1 when the shape has the fused kernel (fp32: the tiled kernels, the Cout = 64 first layers
+ * and -- without the pool -- the small-plane linear-pixel kernel; not strided or atrous convs, not the generic direct
+ * kernel) -- else the caller runs conv + unetk_norm_apply_relu. */
+int unetk_conv3x3_fwd_affine_ok(const unetk_conv_desc* d, int with_pool);
+int unetk_conv3x3_fwd_affine(const unetk_conv_desc* d, const void* x, const void* w, const float* scale,
+                             const float* shift, void* z, void* pooled, int pooled_stride, void* ws, size_t ws_bytes,
+                             void* stream);
+
 /* The same input gradient, fused with the norm-backward REDUCTION of the unit that produced the conv's input (the
  * slim.repeat(x, 2, slim.conv2d, ...) pairs of UNet.py:79,85,94: conv2's dx is the dz of conv1's norm + ReLU): while the
  * dx tile is in registers the epilogue reads prod_y (conv1's raw output, same [N,H,W,Cin], pixel stride prod_y_stride;
