@@ -63,6 +63,7 @@ _SIGNATURES = {
     "unetk_lits_batch": (c_int, [POINTER(LitsDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "unetk_abi_version": (c_int, []),
     "unetk_nan_watch": (c_int, [P, P, c_int32, P]),
+    "unetk_png_unfilter": (c_int, [P, c_int64, c_int, c_int, c_int, c_int, P, c_int64, P, P]),
     "unetk_conv3x3_fwd_affine_ok": (c_int, [POINTER(ConvDesc), c_int]),
     "unetk_conv3x3_fwd_affine": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, c_int, P, c_size_t, P]),
     "unetk_prof_reset": (c_int, [c_int]),

@@ -76,6 +76,96 @@ __global__ __launch_bounds__(256) void lits_batch_kernel(unetk_lits_desc d, cons
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// PNG scanline un-filtering on the device (the loader of the resident slice store, data/lits.py).
+//
+// The reference decodes its PNG slices with cv2 on tf.data threads (DataLoader/Liver/input_pipeline.py:243-284; they were
+// written by SimpleITK / libpng with ADAPTIVE row filters, DataLoader/Liver/extract.py:176-187).  Here the host only inflates
+// the zlib stream (zlib releases the GIL: a thread pool scales) and uploads the FILTERED scanlines; this kernel undoes the
+// five PNG filter types and writes native-endian pixels straight into the resident store.
+//
+// Every filter is  cur[i] = line[i] + pred(a, b, c)  mod 256 per byte lane, a = left pixel, b = the pixel above, c = above-left
+// (None: 0, Sub: a, Up: b, Average: (a + b) >> 1, Paeth).  Average and Paeth chain through BOTH a (this row) and b (the row
+// above), so the dependency is a wavefront: one wave per image, lane r owns row y0 + r of a 64-row band and runs ONE pixel
+// behind lane r - 1 -- at step t it takes pixel i = t - r, its `b` is the value lane r - 1 produced at step t - 1 (a DPP
+// shuffle), `c` its previous `b`, `a` its own previous output.  A band is w + 63 steps whatever mix of filter types its rows
+// use; the band's last row goes through LDS to lane 0 of the next band (written at step i + 63, read at step i of the NEXT
+// band).  Bytes in, bytes out: the host's inflate rate (a few thousand slices/s) is the pipeline's limit, not this kernel.
+constexpr int PNG_MAX_W = 4096;
+
+template <int BPP>
+__global__ __launch_bounds__(64) void png_unfilter_kernel(const uint8_t* __restrict__ filt, int64_t in_stride, int h, int w,
+                                                          void* __restrict__ out, int64_t out_stride, int32_t* __restrict__ status) {
+  __shared__ uint8_t lastrow[PNG_MAX_W * BPP];
+  const int lane = threadIdx.x;
+  const uint8_t* src = filt + (int64_t)blockIdx.x * in_stride;
+  const int rowb = w * BPP + 1;
+  for (int i = lane; i < w * BPP; i += 64) lastrow[i] = 0;           // the row above row 0 is zero
+  __syncthreads();
+  for (int y0 = 0; y0 < h; y0 += 64) {
+    const int y = y0 + lane;
+    const bool active = y < h;
+    const uint8_t* line = src + (int64_t)(active ? y : 0) * rowb;
+    const int ft = active ? line[0] : 0;
+    if (active && ft > 4) atomicOr(status, 1);                         // not a PNG filter type: the caller raises
+    line += 1;
+    const bool last_of_band = lane == 63 || y == h - 1;
+    int a0 = 0, a1 = 0, c0 = 0, c1 = 0, o0 = 0, o1 = 0;
+    for (int t = 0; t < w + 63; ++t) {
+      const int i = t - lane;
+      int b0 = __shfl_up(o0, 1), b1 = BPP == 2 ? __shfl_up(o1, 1) : 0;
+      const bool on = active && i >= 0 && i < w;
+      if (lane == 0 && on) {
+        b0 = lastrow[i * BPP];
+        if (BPP == 2) b1 = lastrow[i * BPP + 1];
+      }
+      if (on) {
+        const int x0 = line[i * BPP], x1 = BPP == 2 ? line[i * BPP + 1] : 0;
+        int p0 = 0, p1 = 0;
+        if (ft == 1) { p0 = a0; p1 = a1; }
+        else if (ft == 2) { p0 = b0; p1 = b1; }
+        else if (ft == 3) { p0 = (a0 + b0) >> 1; p1 = (a1 + b1) >> 1; }
+        else if (ft == 4) {
+          const int q0 = a0 + b0 - c0, pa0 = abs(q0 - a0), pb0 = abs(q0 - b0), pc0 = abs(q0 - c0);
+          p0 = (pa0 <= pb0 && pa0 <= pc0) ? a0 : (pb0 <= pc0 ? b0 : c0);
+          const int q1 = a1 + b1 - c1, pa1 = abs(q1 - a1), pb1 = abs(q1 - b1), pc1 = abs(q1 - c1);
+          p1 = (pa1 <= pb1 && pa1 <= pc1) ? a1 : (pb1 <= pc1 ? b1 : c1);
+        }
+        o0 = (x0 + p0) & 255;
+        o1 = (x1 + p1) & 255;
+        c0 = b0; c1 = b1; a0 = o0; a1 = o1;
+        if (BPP == 2)      // PNG samples are big-endian
+          static_cast<uint16_t*>(out)[(int64_t)blockIdx.x * out_stride + (int64_t)y * w + i] = (uint16_t)((o0 << 8) | o1);
+        else
+          static_cast<uint8_t*>(out)[(int64_t)blockIdx.x * out_stride + (int64_t)y * w + i] = (uint8_t)o0;
+        if (last_of_band) {
+          lastrow[i * BPP] = (uint8_t)o0;
+          if (BPP == 2) lastrow[i * BPP + 1] = (uint8_t)o1;
+        }
+      }
+    }
+    __syncthreads();       // the band's last row is complete before the next band's lane 0 reads it
+  }
+}
+
+extern "C" int unetk_png_unfilter(const uint8_t* filtered, int64_t image_stride_bytes, int n_images, int h, int w, int bit_depth,
+                                  void* out, int64_t out_image_stride, int32_t* status, void* stream) {
+  UNETK_REQUIRE(filtered && out && status && n_images > 0 && h > 0 && w > 0 && w <= PNG_MAX_W);
+  UNETK_REQUIRE(bit_depth == 8 || bit_depth == 16);
+  const int bpp = bit_depth / 8;
+  UNETK_REQUIRE(image_stride_bytes >= (int64_t)h * (w * bpp + 1) && out_image_stride >= (int64_t)h * w);
+  if (bpp == 2) {
+    UNETK_REQUIRE((((uintptr_t)out) & 1u) == 0);
+    UNETK_LAUNCH(png_unfilter_kernel<2>, dim3(n_images), dim3(64), 0, (hipStream_t)stream, filtered, image_stride_bytes, h, w, out,
+                 out_image_stride, status);
+  } else {
+    UNETK_LAUNCH(png_unfilter_kernel<1>, dim3(n_images), dim3(64), 0, (hipStream_t)stream, filtered, image_stride_bytes, h, w, out,
+                 out_image_stride, status);
+  }
+  UNETK_LAUNCH_CHECK();
+  return UNETK_OK;
+}
+
 extern "C" int unetk_lits_batch(const unetk_lits_desc* d, const uint16_t* slices, const uint8_t* seg_slices,
                                 const int32_t* sample_tab, const float* clip, float* images, int32_t* labels,
                                 void* stream) {

@@ -9,7 +9,9 @@ On-disk format (the reference's own): `<root>/png/volume-<PID>/<slice:03d>_im.pn
 Design: the reference feeds the GPU from tf.data CPU threads (PNG decode + crop + resize per sample per step).  An
 MI355X has 288 GB of HBM and the whole decoded training set is ~35 GB as uint16, so `SliceStore` decodes every slice ONCE
 and keeps it on the device; a step's batch is then the host-side sampler (a few hundred integer operations) + one gather
-kernel (`unetk_lits_batch`).  The PNG codec is a small pure-Python/zlib one (no cv2 / PIL in this image).
+kernel (`unetk_lits_batch`).  Decoding: zlib inflate on host threads, the five PNG row filters undone on the device
+(`unetk_png_unfilter`), pixels written straight into the resident store (no cv2 / PIL in this image; `png_decode` is the
+host-side checker of that path).
 
 The sampler restates the reference's selection logic literally (forced tumor / liver shares, crop placement around the
 object box, random zoom and window level) on a `random.Random(seed)` / `numpy.random.RandomState(seed)` pair instead
@@ -59,8 +61,11 @@ def add_arguments(parser):
 
 
 # ------------------------------------------------------------------------------------------------- PNG codec
-def png_decode(data):
-    """8- or 16-bit grayscale, non-interlaced PNG -> ndarray (uint8 / uint16)."""
+def png_inflate(data):
+    """Host half of the loader: parse the chunks of a non-interlaced 8- / 16-bit grayscale PNG and inflate its IDAT stream.
+    Returns (width, height, bit_depth, filtered) with `filtered` = uint8 [height * (1 + width * bit_depth / 8)]: per row one
+    filter-type byte + the filtered scanline -- what `unetk_png_unfilter` turns into pixels on the device.  zlib.decompress
+    releases the GIL, so a thread pool of these scales with the cores."""
     if data[:8] != b"\x89PNG\r\n\x1a\n":
         raise ValueError("not a PNG file")
     pos, idat, hdr = 8, [], None
@@ -74,12 +79,25 @@ def png_decode(data):
             idat.append(body)
         elif typ == b"IEND":
             break
+    if hdr is None:
+        raise ValueError("PNG without an IHDR chunk")
     w, h, depth, ctype, _, _, interlace = hdr
     if ctype != 0 or interlace != 0 or depth not in (8, 16):
         raise ValueError("only non-interlaced 8/16-bit grayscale PNGs are supported")
+    raw = np.frombuffer(zlib.decompress(b"".join(idat) if len(idat) != 1 else idat[0]), dtype=np.uint8)
+    if raw.size != h * (w * depth // 8 + 1):
+        raise ValueError("PNG data stream has {} bytes, expected {}".format(raw.size, h * (w * depth // 8 + 1)))
+    return w, h, depth, raw
+
+
+def png_decode(data):
+    """8- or 16-bit grayscale, non-interlaced PNG -> ndarray (uint8 / uint16), entirely on the HOST.  The checker of the
+    device path (tests) and a tool for small files (data/extract.py round trips): Average / Paeth rows run through a per-byte
+    Python loop, far too slow for a dataset -- `SliceStore` decodes through png_inflate + unetk_png_unfilter instead."""
+    w, h, depth, flat = png_inflate(data)
     bpp = depth // 8
     stride = w * bpp
-    raw = np.frombuffer(zlib.decompress(b"".join(idat)), dtype=np.uint8).reshape(h, stride + 1)
+    raw = flat.reshape(h, stride + 1)
     out = np.zeros((h, stride), dtype=np.uint8)
     prev = np.zeros(stride, dtype=np.int32)
     for y in range(h):
@@ -93,7 +111,7 @@ def png_decode(data):
             cur = line.copy()
             for k in range(bpp):
                 cur[k::bpp] = np.cumsum(line[k::bpp]) & 255
-        else:                                               # Average / Paeth: sequential
+        elif ft in (3, 4):                                  # Average / Paeth: sequential
             cur = np.zeros(stride, dtype=np.int32)
             for i in range(stride):
                 a = cur[i - bpp] if i >= bpp else 0
@@ -106,6 +124,8 @@ def png_decode(data):
                     pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
                     pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
                 cur[i] = (line[i] + pred) & 255
+        else:
+            raise ValueError("invalid PNG filter type {}".format(ft))
         out[y] = cur
         prev = cur
     if depth == 8:
@@ -113,20 +133,44 @@ def png_decode(data):
     return (out[:, 0::2].astype(np.uint16) << 8 | out[:, 1::2].astype(np.uint16)).copy()
 
 
-def png_encode(arr):
-    """ndarray uint8 / uint16 [h, w] -> PNG bytes (filter 0; used to write synthetic datasets in tests / tools)."""
+def png_filter_rows(arr, filters):
+    """The FILTERED scanlines of `arr` (uint8 / uint16 [h, w]) with filter type filters[y % len(filters)] on row y -- the
+    inverse of the five PNG un-filters, vectorised (filtering only needs the unfiltered neighbours).  uint8 [h, 1 + stride]."""
+    arr = np.ascontiguousarray(arr)
+    h, w = arr.shape
+    bpp = 2 if arr.dtype == np.uint16 else 1
+    rows = np.frombuffer(arr.astype(">u2").tobytes() if bpp == 2 else arr.astype(np.uint8).tobytes(), dtype=np.uint8)
+    rows = rows.reshape(h, w * bpp).astype(np.int32)
+    left = np.concatenate([np.zeros((h, bpp), np.int32), rows[:, :-bpp]], axis=1)                      # a
+    up = np.concatenate([np.zeros((1, w * bpp), np.int32), rows[:-1]], axis=0)                         # b
+    upleft = np.concatenate([np.zeros((h, bpp), np.int32), up[:, :-bpp]], axis=1)                      # c
+    p = left + up - upleft
+    pa, pb, pc = np.abs(p - left), np.abs(p - up), np.abs(p - upleft)
+    paeth = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, up, upleft))
+    preds = [np.zeros_like(rows), left, up, (left + up) >> 1, paeth]
+    ft = np.array([int(filters[y % len(filters)]) for y in range(h)], dtype=np.int64)
+    out = np.empty((h, 1 + w * bpp), dtype=np.uint8)
+    out[:, 0] = ft
+    for t in range(5):
+        sel = ft == t
+        out[sel, 1:] = ((rows[sel] - preds[t][sel]) & 255).astype(np.uint8)
+    return out
+
+
+def png_encode(arr, filters=None, level=6):
+    """ndarray uint8 / uint16 [h, w] -> PNG bytes.  filters: None = type 0 on every row; else a sequence of filter types
+    (0 None, 1 Sub, 2 Up, 3 Average, 4 Paeth) applied cyclically per row -- libpng picks them adaptively, so real files mix
+    all five (used to write synthetic datasets in tests / tools and by data/extract.py)."""
     arr = np.ascontiguousarray(arr)
     h, w = arr.shape
     depth = 16 if arr.dtype == np.uint16 else 8
-    body = arr.astype(">u2").tobytes() if depth == 16 else arr.astype(np.uint8).tobytes()
-    stride = w * depth // 8
-    raw = b"".join(b"\x00" + body[y * stride:(y + 1) * stride] for y in range(h))
+    raw = png_filter_rows(arr, filters if filters is not None else (0,)).tobytes()
 
     def chunk(typ, payload):
         return struct.pack(">I", len(payload)) + typ + payload + struct.pack(">I", zlib.crc32(typ + payload) & 0xffffffff)
 
     return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, 0, 0, 0, 0)) + \
-        chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
+        chunk(b"IDAT", zlib.compress(raw, level)) + chunk(b"IEND", b"")
 
 
 # ------------------------------------------------------------------------------------------------- dataset lists
@@ -204,21 +248,86 @@ def collect_datasets(root, test_fold, mode, filter_tumor_size=0, filter_only_liv
 # ------------------------------------------------------------------------------------------------- resident slices
 class SliceStore(object):
     """Every slice of the given cases decoded once and kept in device memory: `im` int16-typed storage of the uint16
-    pixels [n_slices, h, w], `lb` uint8 [n_slices, h, w]; `offset[pid] + z` indexes slice z of case pid."""
+    pixels [n_slices, h, w], `lb` uint8 [n_slices, h, w]; `offset[pid] + z` indexes slice z of case pid.
 
-    def __init__(self, root, cases, device):
+    Loading (round 4; the reference decodes per sample per step with cv2 on tf.data threads, input_pipeline.py:243-284):
+    the store is allocated up front from meta.json's `size` fields; a thread pool reads the files and inflates their zlib
+    streams (the GIL is released in both), `chunk` slices at a time, into one of two pinned staging buffers; each chunk is
+    uploaded as FILTERED scanlines and `unetk_png_unfilter` writes the pixels straight into the store's slots while the
+    pool already inflates the next chunk.  Peak host memory = the two staging buffers (2 x chunk x 0.77 MB at 512 x 512),
+    whatever the dataset's size.  Under data parallelism (`strategy` with N > 1 replicas) each rank decodes the slices
+    [r::N] ... of its contiguous share and the shares are exchanged rank by rank over the process group (RCCL / xGMI), so the
+    node reads and inflates the dataset once, not N times."""
+
+    def __init__(self, root, cases, device, strategy=None, chunk=256, threads=None):
+        import concurrent.futures
+        import os
         root = Path(root)
-        self.offset, ims, lbs, n = {}, [], [], 0
+        self.device = device
+        self.offset, files, n = {}, [], 0
+        hw = None
         for case in cases:
             pid, depth = int(case["PID"]), int(case["size"][0])
             self.offset[pid] = n
-            for z in range(depth):
-                ims.append(png_decode((root / "png" / "volume-{:d}".format(pid) / "{:03d}_im.png".format(z)).read_bytes()))
-                lbs.append(png_decode((root / "png" / "volume-{:d}".format(pid) / "{:03d}_lb.png".format(z)).read_bytes()))
+            cur = (int(case["size"][1]), int(case["size"][2]))
+            if hw is not None and cur != hw:
+                raise ValueError("the resident store needs slices of one size, got {} and {}".format(hw, cur))
+            hw = cur
+            d = root / "png" / "volume-{:d}".format(pid)
+            files.extend((d / "{:03d}_im.png".format(z), d / "{:03d}_lb.png".format(z)) for z in range(depth))
             n += depth
-        self.im = torch.from_numpy(np.stack(ims).view(np.int16)).to(device)
-        self.lb = torch.from_numpy(np.stack(lbs)).to(device)
-        self.device = device
+        if n == 0:
+            raise ValueError("no slices to load")
+        h, w = hw
+        self.im = torch.empty((n, h, w), dtype=torch.int16, device=device)        # the uint16 pixels' bit patterns
+        self.lb = torch.empty((n, h, w), dtype=torch.uint8, device=device)
+        world = strategy.num_replicas_in_sync if strategy is not None else 1
+        rank = strategy.rank if strategy is not None else 0
+        share = [(n * r) // world for r in range(world + 1)]                       # rank r decodes slices [share[r], share[r + 1])
+        lo, hi = share[rank], share[rank + 1]
+        im_row, lb_row = h * (2 * w + 1), h * (w + 1)
+        chunk = max(1, min(int(chunk), hi - lo))
+        stage = [(torch.empty((chunk, im_row), dtype=torch.uint8).pin_memory() if device.type == "cuda" else torch.empty((chunk, im_row), dtype=torch.uint8),
+                  torch.empty((chunk, lb_row), dtype=torch.uint8).pin_memory() if device.type == "cuda" else torch.empty((chunk, lb_row), dtype=torch.uint8))
+                 for _ in range(2)]
+        dev_stage = [(torch.empty((chunk, im_row), dtype=torch.uint8, device=device),
+                      torch.empty((chunk, lb_row), dtype=torch.uint8, device=device)) for _ in range(2)]
+        done = [None, None]                                                        # event: the device has consumed stage k
+        status = torch.zeros(1, dtype=torch.int32, device=device)
+
+        def inflate(slot, j, pair):
+            for path, dst, depth_bits in ((pair[0], stage[slot][0], 16), (pair[1], stage[slot][1], 8)):
+                pw, ph, pd, raw = png_inflate(path.read_bytes())
+                if (ph, pw, pd) != (h, w, depth_bits):
+                    raise ValueError("{}: {}x{} {}-bit, expected {}x{} {}-bit".format(path, ph, pw, pd, h, w, depth_bits))
+                dst[j].numpy()[:] = raw
+
+        workers = int(threads or min(32, (os.cpu_count() or 8)))
+        with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
+            k = 0
+            for c0 in range(lo, hi, chunk):
+                slot, cnt = k & 1, min(chunk, hi - c0)
+                if done[slot] is not None:
+                    done[slot].synchronize()                                       # its previous upload has left the pinned buffer
+                for f in [pool.submit(inflate, slot, j, files[c0 + j]) for j in range(cnt)]:
+                    f.result()
+                for which, depth_bits, dst in ((0, 16, self.im), (1, 8, self.lb)):
+                    dev_stage[slot][which][:cnt].copy_(stage[slot][which][:cnt], non_blocking=True)
+                    ops.png_unfilter(dev_stage[slot][which][:cnt], h, w, depth_bits, dst[c0:c0 + cnt], status)
+                if device.type == "cuda":
+                    done[slot] = torch.cuda.Event()
+                    done[slot].record()
+                k += 1
+        if int(status.item()) != 0:
+            raise ValueError("a PNG row carries an invalid filter type (corrupt file under {})".format(root / "png"))
+        if world > 1:
+            import torch.distributed as dist
+            for r in range(world):                                                 # every rank's share to everyone (uneven shares: one broadcast each)
+                if share[r + 1] > share[r]:
+                    dist.broadcast(self.im[share[r]:share[r + 1]].view(torch.uint8), src=r)    # bytes: every backend moves uint8
+                    dist.broadcast(self.lb[share[r]:share[r + 1]], src=r)
+        self.load_stats = {"slices": n, "decoded_here": hi - lo, "chunk": chunk, "threads": workers,
+                           "staging_bytes": 2 * chunk * (im_row + lb_row)}
 
 
 # ------------------------------------------------------------------------------------------------- sampler
@@ -386,7 +495,7 @@ def input_fn(mode, params):
     if key not in params:
         cases = collect_datasets(root, args.test_fold, "train" if mode == "train" else "val",
                                  filter_tumor_size=getattr(args, "filter_size", 0))
-        params[key] = (SliceStore(root, cases, device), cases)
+        params[key] = (SliceStore(root, cases, device, strategy=params.get("strategy")), cases)
     store, cases = params[key]
     if len(cases) == 0:
         raise ValueError("No valid dataset found!")

@@ -103,6 +103,7 @@ def run(args, sub, pipe, guided=False, dataset_params=None):
         extra.setdefault("lits_root", args.lits_root)
     if strategy is not None:
         extra.setdefault("rank", strategy.rank)
+        extra.setdefault("strategy", strategy)       # data/lits.SliceStore: each rank decodes 1/N of the dataset, then exchange
 
     if args.mode == ModeKeys.TRAIN:
         run_config = estimator_lib.RunConfig(model_dir=args.model_dir, train_distribute=strategy, save_checkpoints_steps=5000,

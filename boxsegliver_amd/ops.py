@@ -1037,6 +1037,18 @@ def sumsq(p):
     return out
 
 
+def png_unfilter(filtered, h, w, bit_depth, out, status):
+    """filtered uint8 [n, h * (1 + w * bit_depth / 8)] (inflated PNG rows) -> out [n, h, w] (uint8, or int16 / uint16 storage
+    for 16-bit samples) on the device; status int32[1] collects invalid filter types (unetk_png_unfilter)."""
+    _require_cuda(filtered, out, status)
+    n = filtered.shape[0]
+    assert filtered.dtype == torch.uint8 and filtered.is_contiguous() and out.is_contiguous() and tuple(out.shape) == (n, h, w)
+    assert out.element_size() == bit_depth // 8 and filtered.shape[1] >= h * (1 + w * bit_depth // 8)
+    check(_abi.lib().unetk_png_unfilter(ptr(filtered), filtered.stride(0), n, h, w, bit_depth, ptr(out), h * w, ptr(status),
+                                        stream_ptr()), "png_unfilter")
+    return out
+
+
 def nan_watch(value, flag, step):
     """flag (int32[2], zeroed by the caller) becomes (1, step) at the first step whose `value` (a device scalar) is NaN."""
     _require_cuda(value, flag)

@@ -145,7 +145,7 @@ int unetk_conv3x3_dgrad_ws(const unetk_conv_desc* d, const void* dy, const void*
  * the conv, slim.batch_norm and ReLU of one slim.conv2d(x, C, 3) -- and, when the unit feeds one, slim.max_pool2d(z, 2, 2)
  * (UNet.py:81) -- are ONE pass: z = relu(conv(x, w) * scale[c] + shift[c]) is written straight to z (pixel stride
  * d->y_stride: a channel slice of the decoder's concat buffer), the raw conv output never reaches memory.  SURVEY.md 7
- * step 2 / 8b `unetk_conv_fwd(..., scale, shift, ...)`.  scale / shift: [Cout] floats (unetk_norm_finalize rows 2, 3).
+ * step 2 / 8b: the conv forward taking (scale, shift).  scale / shift: [Cout] floats (unetk_norm_finalize rows 2, 3).
  * pooled != NULL: also pooled[N, H/2, W/2, .] (pixel stride pooled_stride) = max over each 2 x 2 window of z; H, W even.
  * ws / ws_bytes: the stream-K scratch of unetk_conv3x3_ws_bytes (small planes), may be NULL / 0.
  * unetk_conv3x3_fwd_affine_ok = 1 when the shape has the fused kernel (fp32: the tiled kernels, the Cout = 64 first layers
@@ -484,6 +484,14 @@ typedef struct unetk_lits_desc {
   uint32_t seed;
   float noise_scale; /* 0 = no noise (eval_online) */
 } unetk_lits_desc;
+/* PNG row un-filtering for the resident slice store (the reference decodes with cv2 on tf.data threads,
+ * DataLoader/Liver/input_pipeline.py:243-284; its PNGs come from SimpleITK / libpng with adaptive row filters,
+ * DataLoader/Liver/extract.py:176-187).  filtered: n_images inflated IDAT streams of non-interlaced grayscale PNGs, image k at
+ * filtered + k * image_stride_bytes, each h rows of (1 filter-type byte + w * bit_depth / 8 bytes).  out: image k at element
+ * k * out_image_stride, h * w samples, uint8 (bit_depth 8) or native-endian uint16 (bit_depth 16).  All five filter types
+ * (None, Sub, Up, Average, Paeth).  status[0] |= 1 if a row carries a filter type > 4 (the caller zeroes it and raises). */
+int unetk_png_unfilter(const uint8_t* filtered, int64_t image_stride_bytes, int n_images, int h, int w, int bit_depth,
+                       void* out, int64_t out_image_stride, int32_t* status, void* stream);
 int unetk_lits_batch(const unetk_lits_desc* d, const uint16_t* slices, const uint8_t* seg_slices,
                      const int32_t* sample_tab, const float* clip, float* images, int32_t* labels,
                      void* stream);

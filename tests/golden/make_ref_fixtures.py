@@ -172,7 +172,21 @@ def main():
     ev.clear_metrics()
     with open(os.path.join(HERE, "ref_save_metrics.json"), "w") as f:
         json.dump({"rows": rows, "file": table}, f, indent=1, sort_keys=True)
-    print("wrote ref_config_surface.json, ref_surface.npz, ref_k_folds.json, ref_save_metrics.json")
+    write_meta_excerpt()
+    print("wrote ref_config_surface.json, ref_surface.npz, ref_k_folds.json, ref_save_metrics.json, ref_meta_excerpt.json")
+
+
+def write_meta_excerpt(pids=(3, 5, 32, 4)):
+    """5. Four cases of the shipped DataLoader/Liver/prepare/meta.json, verbatim (data the reference holds for its input
+    pipeline: volume extents, liver boxes, per-slice tumour boxes / moments): two ordinary tumour cases, one without tumours
+    and the case with the most tumour slices.  `collect_datasets` / `parse_case` / `TrainSampler` must digest the real schema."""
+    with open(os.path.join(REF, "DataLoader/Liver/prepare/meta.json")) as f:
+        meta = json.load(f)
+    pick = [c for c in meta if int(c["PID"]) in pids]
+    assert len(pick) == len(pids)
+    with open(os.path.join(HERE, "ref_meta_excerpt.json"), "w") as f:
+        json.dump({"source": "DataLoader/Liver/prepare/meta.json (131 cases), cases " + ", ".join(str(p) for p in sorted(pids)),
+                   "n_cases_in_file": len(meta), "cases": pick}, f, sort_keys=True)
 
 
 if __name__ == "__main__":

@@ -170,3 +170,54 @@ def test_sampler_distribution_matches_the_policy():
     assert lz[:z0].sum() == 0 and lz[z1:].sum() == 0 and lz[z0:z1].min() > 0.7 * lz[z0:z1].mean()
     az = np.bincount(zs[2], minlength=12)
     assert az.min() > 0.6 * az.mean()
+
+
+def test_real_meta_json_excerpt_is_digested_by_the_dataset_collection_and_the_sampler(tmp_path):
+    """Four cases of the reference's shipped DataLoader/Liver/prepare/meta.json (tests/golden/ref_meta_excerpt.json: data
+    copied verbatim by make_ref_fixtures.py) through collect_datasets -> parse_case -> TrainSampler: the real schema (real
+    lists, not strings; 500-800-slice volumes; a case without tumours; 244 tumour slices in one case)."""
+    import argparse
+    import os
+    ex = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_meta_excerpt.json")))
+    assert ex["n_cases_in_file"] == 131 and [c["PID"] for c in ex["cases"]] == [3, 4, 5, 32]
+    (tmp_path / "meta.json").write_text(json.dumps(ex["cases"]))
+    (tmp_path / "k_folds.txt").write_text("Fold 0:3 4\nFold 1:5\nFold 2:32\n")
+    train = lits.collect_datasets(tmp_path, 2, "train")
+    assert [c["PID"] for c in train] == [3, 4, 5]
+    raw = {c["PID"]: c for c in ex["cases"]}
+    for c in train:
+        r = raw[c["PID"]]
+        ft = r["tumor_slices_from_to"]
+        assert c["size"] == r["size"] and c["bbox"] == r["bbox"] and c["tumor_slices_index"] == r["tumor_slices_index"]
+        assert [len(b) for b in c["slices"]] == [ft[i + 1] - ft[i] for i in range(len(ft) - 1)]       # filter_size 0 keeps all
+        assert [b for per in c["slices"] for b in per] == r["tumor_slices"]
+        z0, y0, x0, z1, y1, x1 = c["bbox"]
+        assert all(z0 <= z < z1 for z in c["tumor_slices_index"])                                      # tumours lie inside the liver's z range
+        assert all(y0 <= b[0] and b[2] <= y1 and x0 <= b[1] and b[3] <= x1 for per in c["slices"] for b in per)
+    # the case without tumours survives as a liver-only validation case unless it has no liver slices either
+    val = lits.collect_datasets(tmp_path, 2, "eval_online", filter_only_liver_in_val=False)
+    assert [c["PID"] for c in val] == [32] and val[0]["slices"] == [] and val[0]["tumor_slices_index"] == []
+    assert lits.collect_datasets(tmp_path, 2, "eval_online") == []                                     # ... and is dropped by default
+    # filter_size drops small tumours and the slices that hold nothing else
+    big = lits.collect_datasets(tmp_path, 2, "train", filter_tumor_size=200)
+    for c, full in zip(big, train):
+        areas, ft = raw[c["PID"]]["tumor_slices_areas"], raw[c["PID"]]["tumor_slices_from_to"]
+        keep = [z for i, z in enumerate(full["tumor_slices_index"]) if any(a > 200 for a in areas[ft[i]:ft[i + 1]])]
+        assert c["tumor_slices_index"] == keep and len(c["slices"]) == len(keep)
+    # the sampler's tables on the real extents: 512 x 512 slices, crops inside the slice, forced tumour / liver shares
+    cfg = argparse.Namespace(im_height=256, im_width=256, im_channel=3)
+    sm = lits.TrainSampler(train, 32, cfg, liver_percent=0.66, tumor_percent=0.5, random_scale=(1.0, 1.4),
+                           random_window_level=True, random_flip=3, seed=5)
+    offs, n = {}, 0
+    for c in train:
+        offs[c["PID"]] = n
+        n += c["size"][0]
+    for _ in range(20):
+        b = sm.draw()
+        assert (b["kind"][:16] == 0).all() and (b["kind"][16:22] == 1).all() and (b["kind"][22:] == 2).all()
+        oy, ox, ch, cw = b["box"].T
+        assert (oy >= 0).all() and (ox >= 0).all() and (oy + ch <= 512).all() and (ox + cw <= 512).all()
+        for k in range(16):                                      # tumour samples sit on a tumour slice of their case
+            assert b["z"][k] in raw[int(b["pid"][k])]["tumor_slices_index"]
+        tab, clip, pids = sm.table(offs)
+        assert tab.shape == (32, 10) and tab[:, :4].max() < n and (tab[:, 3] >= 0).all()
