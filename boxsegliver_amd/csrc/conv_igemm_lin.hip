@@ -631,12 +631,21 @@ int unetk_conv_stat_rows_lin(int N, int H, int W, int spg, int Cout) {
   return (N / spg) * (int)(((int64_t)spg * H * W + bm - 1) / bm);
 }
 
-static int lin_rows_bound(int H, int W, int bm = LIN_BM) { return (bm + W - 1) / W + 1 + 2 + 2 * ((bm + H * W - 1) / (H * W)); }
+// Padded rows a block of bm linear pixels may touch.  General case: ceil(bm / W) + 1 pixel rows (a block may start mid-row),
+// the halo row above and below, and an extra pair of zero rows per plane boundary it crosses.  ALIGNED case (round 4: the
+// 64- / 128-wide dy planes of UNet3D at the reference's 10 x 256 x 256 training shape): when W divides bm and bm divides the
+// plane, every block is whole rows of ONE plane -- bm / W rows + the two halo rows, which are the plane's own pad rows at its
+// edges.  (Those shapes used to fail the LDS bound and fell back to a zero-dilated dy: four times the MFMA work.)
+static int lin_rows_bound(int H, int W, int bm = LIN_BM) {
+  if (bm % W == 0 && (H * W) % bm == 0) return bm / W + 2;
+  return (bm + W - 1) / W + 1 + 2 + 2 * ((bm + H * W - 1) / (H * W));
+}
 
 // Tap-subset / scatter variant (input gradient of a stride-2 conv): p.H x p.W = dy plane, p.Cin = dy channels,
 // p.Cout = dx channels, p.ntaps / tap_off / tap_panel / os / ooh / oow / Hd / Wd set by the caller.
 bool unetk_conv_lin_gen_ok(int H, int W, int Cin, int Cout) {
-  return Cin % CK == 0 && Cout % 32 == 0 && lin_rows_bound(H, W) * (W + 2) <= LIN_MAXPIX;
+  const int bm = Cout % 128 == 0 ? 64 : LIN_BM;      // the four-class kernel's pixel block (unetk_conv_run_lin_gen)
+  return Cin % CK == 0 && Cout % 32 == 0 && lin_rows_bound(H, W, bm) * (W + 2) <= LIN_MAXPIX;
 }
 
 int unetk_conv_run_lin_gen(ConvParams p, hipStream_t st) {
@@ -668,6 +677,7 @@ int unetk_conv_run_lin_gen(ConvParams p, hipStream_t st) {
     return launch_lin<4, 1, 1, 1, true, true>(p, n_mt, st);
   }
   if (p.Cout % 64 != 0 || p.kd > 1) return UNETK_E_UNSUPPORTED;   // fused depth taps exist in the four-class variant only
+  if (lin_rows_bound(p.H, p.W) * (p.W + 2) > LIN_MAXPIX) return UNETK_E_UNSUPPORTED;
   const int n_mtiles = unetk_conv_stat_rows_lin(p.N, p.H, p.W, p.spg, 0);
   p.stat_rows = n_mtiles;
   p.lin_pix = lin_rows_bound(p.H, p.W) * (p.W + 2);
