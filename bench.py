@@ -201,6 +201,8 @@ def infer_main(a, args, model, inputs_of, data, gflop_unit, workload_name, rank,
     fwd_gflop = gflop_unit / 3.0                               # fwd + dgrad + wgrad are three equal contractions
     tfl = slices * n_fwd * fwd_gflop / 1e3
     wl = (workload_name or "UNet 2D Liver+Tumor {0}x{0}x3 bs={1}/GPU fp32").format(a.size, a.batch)
+    if a.dtype == "bf16":
+        wl = wl.replace(" fp32", " bf16-MFMA + bf16 activation storage")
     out = {"metric": "CT slices/sec (volume evaluation, forward only{})".format(", mirror TTA x4" if a.mirror else ""),
            "value": round(slices, 2), "unit": "slices/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -209,6 +211,7 @@ def infer_main(a, args, model, inputs_of, data, gflop_unit, workload_name, rank,
                                      "a case = {} slabs".format(n_fwd, a.case_slabs),
                       "global_batch": a.batch, "parallelism": "dp1", "forwards_per_slab": n_fwd},
            "forward_tflops": round(tfl, 2), "forward_frac_of_fp32_peak": round(tfl / FP32_PEAK_TFLOPS, 4),
+           "forward_frac_of_dtype_peak": round(tfl / (FP32_PEAK_TFLOPS if a.dtype == "fp32" else BF16_PEAK_TFLOPS), 4),
            "fused_eval_epilogue": bool(ops.FUSE_EVAL)}
     if prof_list:
         agg, hbm = {}, {}
@@ -228,8 +231,9 @@ def infer_main(a, args, model, inputs_of, data, gflop_unit, workload_name, rank,
                                       "achieved_gbps": round(nb / sc / 1e9, 1), "total_ms_per_step": round(sc / n_ev_steps * 1e3, 3)}
                                      for t, (c, nb, sc) in hbm.items() if sc > 0], key=lambda k: -k["total_ms_per_step"])
         top = out["kernels"][0]
-        out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved_tflops"], "peak": FP32_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(top["achieved_tflops"] / FP32_PEAK_TFLOPS, 4), "traffic": None}
+        kpeak = BF16_PEAK_TFLOPS if "bf16" in top["kernel"] else FP32_PEAK_TFLOPS
+        out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved_tflops"], "peak": kpeak,
+                           "unit": "TFLOP/s", "frac": round(top["achieved_tflops"] / kpeak, 4), "traffic": None}
     print(json.dumps(out, ensure_ascii=False), flush=True)
 
 

@@ -718,7 +718,7 @@ int unetk_conv_run(ConvParams p, hipStream_t st) {
     return launch_igemm<4, 1, 1, 2, 1, 2>(p, n_mt, st);
   }
   if (p.dil > 2 || p.dil < 0) return UNETK_E_UNSUPPORTED;
-  if (p.bf16) return p.asc != nullptr ? UNETK_E_UNSUPPORTED : unetk_conv_run_bf16(p, st);
+  if (p.bf16) return (p.asc != nullptr && p.bf16 != UNETK_BF16S) ? UNETK_E_UNSUPPORTED : unetk_conv_run_bf16(p, st);
   if (p.spg < 1) p.spg = 1;
   if (unetk_conv_lin_ok(p.N, p.H, p.W, p.Cin, p.Cout, p.spg))                                     // small planes: linear M
     return (p.asc != nullptr && (p.pool != nullptr || p.accumulate || p.kd > 1)) ? UNETK_E_UNSUPPORTED : unetk_conv_run_lin(p, st);
@@ -876,11 +876,17 @@ extern "C" int unetk_conv3x3_fwd_ws(const unetk_conv_desc* d, const void* x, con
 
 // ---- inference: conv + (scale, shift) + ReLU [+ 2 x 2 max-pool] in one pass
 extern "C" int unetk_conv3x3_fwd_affine_ok(const unetk_conv_desc* d, int with_pool) {
-  if (!conv_desc_ok(d) || d->dilation > 1 || d->precision != UNETK_FP32) return 0;
+  if (!conv_desc_ok(d) || d->dilation > 1 || d->precision == UNETK_BF16) return 0;
   if (with_pool && ((d->H | d->W) & 1)) return 0;
+  const bool first = pick_cfg(d->Cin, d->Cout).id < 0 && d->Cout == 64 && d->Cin >= 1 && d->Cin <= 5;   // Encode1/conv1 on the matrix pipe
+  if (d->precision == UNETK_BF16S) {     // the persistent bf16-storage kernel (and the first layer: fp32 image in, bf16 out)
+    if (unetk_conv_bf16_ok(d->Cin, d->Cout))
+      return unetk_conv_bf16s_v3_ok(d->N, d->H, d->W, d->Cin, d->Cout, d->x_stride, d->y_stride) ? 1 : 0;
+    return (first && !with_pool) ? 1 : 0;
+  }
   if (pick_cfg(d->Cin, d->Cout).id >= 0)       // the small-plane (linear-pixel) kernel has the affine epilogue but no pool
     return (unetk_conv_lin_ok(d->N, d->H, d->W, d->Cin, d->Cout, 1) && with_pool) ? 0 : 1;
-  return (d->Cout == 64 && d->Cin >= 1 && d->Cin <= 5 && !with_pool) ? 1 : 0;
+  return (first && !with_pool) ? 1 : 0;
 }
 
 extern "C" int unetk_conv3x3_fwd_affine(const unetk_conv_desc* d, const void* x, const void* w, const float* scale,
@@ -888,10 +894,14 @@ extern "C" int unetk_conv3x3_fwd_affine(const unetk_conv_desc* d, const void* x,
                                         size_t ws_bytes, void* stream) {
   UNETK_REQUIRE(conv_desc_ok(d) && x && w && z && scale && shift);
   UNETK_REQUIRE(unetk_aligned16(x) && unetk_aligned16(w) && unetk_aligned16(z));
-  UNETK_REQUIRE(d->y_stride % 4 == 0 && (pooled == nullptr || pooled_stride >= d->Cout));
+  UNETK_REQUIRE(d->y_stride % 4 == 0 && (pooled == nullptr || (pooled_stride >= d->Cout && unetk_aligned16(pooled))));
   if (!unetk_conv3x3_fwd_affine_ok(d, pooled != nullptr)) return UNETK_E_UNSUPPORTED;
   if (pick_cfg(d->Cin, d->Cout).id >= 0) UNETK_REQUIRE(d->x_stride % 4 == 0);
   ConvParams p{};
+  if (d->precision == UNETK_BF16S) {
+    if (unetk_conv_bf16_ok(d->Cin, d->Cout)) p.bf16 = UNETK_BF16S;      // bf16 in, bf16 out
+    else p.ybf16 = 1;                                                   // first layer: fp32 image in, bf16 out
+  }
   p.x = (const float*)x; p.wp = (const float*)w; p.y = (float*)z; p.stat = nullptr;
   p.asc = scale; p.ash = shift; p.pool = pooled; p.pool_s = pooled_stride;
   if (ws && unetk_aligned16(ws) && ws_bytes > 0) { p.sk_slab = (float*)ws; p.sk_slab_bytes = ws_bytes; }   // stream-K scratch

@@ -392,6 +392,7 @@ int unetk_conv_run_bf16(ConvParams p, hipStream_t st) {
     if (cfg.id == 4 || p.accumulate) return UNETK_E_UNSUPPORTED;     // Cout % 64 != 0 / 3-D depth taps: not in this mode
     if (unetk_conv_bf16s_v3_ok(p.N, p.H, p.W, p.Cin, p.Cout, p.xs, p.ys) && (p.ny == nullptr || (p.Cout % 128 == 0 && p.nys % 8 == 0)))
       return unetk_conv_bf16s_v3_run(p, st);
+    if (p.asc != nullptr) return UNETK_E_UNSUPPORTED;      // the inference epilogue lives in the persistent kernel only
     if (p.xs % 8 != 0 || p.ys % 2 != 0) return UNETK_E_BADARG;
     p.tiles_h = (p.H + cfg.th - 1) / cfg.th;
     p.tiles_w = (p.W + TW - 1) / TW;

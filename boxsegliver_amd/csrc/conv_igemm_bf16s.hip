@@ -135,8 +135,13 @@ struct TileAt {
   int h0, w0, n0, mt, n_img;
 };
 
-template <int NT8, bool NBR>
+// AFF (inference, unetk_conv3x3_fwd_affine): 1 = the epilogue stores the ACTIVATION relu(acc * scale[c] + shift[c]) (rounded to
+// bf16 once, from the fp32 accumulator) instead of the raw output, no statistics; 2 = and max_pool2d(z, 2, 2): a lane holds
+// rows wave * 4 + tm and columns 4 kq + r of 8 (4) channels, i.e. four whole 2 x 2 windows -- register maxima, 4 more stores.
+template <int NT8, bool NBR, int AFF = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(ConvParams p) {
+  static_assert(!(NBR && AFF), "one epilogue variant per instantiation");
+  constexpr int NST = NSTORE + (AFF == 2 ? 4 : 0);      // output stores per wave and full tile
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   constexpr int BN = NT8 * 16;                  // output channels per tile
   constexpr int HB = NT8 / 2;                   // B fragments per half-step
@@ -317,10 +322,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(ConvParams p) {
         constexpr int NT9 = (T9 + 1) % 9, NKH = NT9 / 3, NKW = NT9 % 3;
         // ---- top: my piece of the next step's panel (and, at tap 8, of the next chunk's halo) has landed; everybody's
 #ifdef UNETK_V3_PROBE
-        if ((p.dbg & 64) && c == 0 && after_full) wait_vm<vm_need(T9) + NSTORE>();      // never wait for the stores in the first chunk
+        if ((p.dbg & 64) && c == 0 && after_full) wait_vm<vm_need(T9) + NST>();      // never wait for the stores in the first chunk
         else
 #endif
-        if (T9 < FLIGHT && c == 0 && after_full) wait_vm<vm_need(T9) + NSTORE>();   // the stores of the last tile are younger
+        if (T9 < FLIGHT && c == 0 && after_full) wait_vm<vm_need(T9) + NST>();   // the stores of the last tile are younger
         else wait_vm<vm_need(T9)>();
 #ifdef UNETK_V3_PROBE
         if (!(p.dbg & 16))
@@ -427,6 +432,43 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(ConvParams p) {
         for (int j = 0; j < NT8; ++j) { nsc[j] = p.nsc[o + j]; nsh[j] = p.nsh[o + j]; nmu[j] = p.nmu[o + j]; nrs[j] = p.nrs[o + j]; }
         nyb = static_cast<const bf16_t*>(p.ny) + (int64_t)cur.n_img * p.H * p.W * p.nys + cur.n0 + l15 * NT8;
       }
+      if constexpr (AFF != 0) {
+        // the normaliser's affine + ReLU on the fp32 accumulators, in place (they are zeroed behind the epilogue anyway)
+        float asc[NT8], ash[NT8];
+#pragma unroll
+        for (int j = 0; j < NT8; ++j) { asc[j] = p.asc[cur.n0 + l15 * NT8 + j]; ash[j] = p.ash[cur.n0 + l15 * NT8 + j]; }
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int j = 0; j < NT8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[tm][j][r] = fmaxf(fmaf(acc[tm][j][r], asc[j], ash[j]), 0.f);
+        if constexpr (AFF == 2) {
+          const int Hp = p.H >> 1, Wp = p.W >> 1;
+          bf16_t* pb = reinterpret_cast<bf16_t*>(p.pool) + (int64_t)cur.n_img * Hp * Wp * p.pool_s + cur.n0 + l15 * NT8;
+#pragma unroll
+          for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+            for (int rp = 0; rp < 2; ++rp) {
+              const int gh = cur.h0 + wave * 4 + 2 * tp, gw = cur.w0 + 4 * kq + 2 * rp;
+              if (gh < p.H && gw < p.W) {
+                uint32_t pk[NT8 / 2];
+#pragma unroll
+                for (int j = 0; j < NT8 / 2; ++j) {
+                  // the maximum of the four ROUNDED activations = the rounded maximum (rounding is monotone)
+                  const float m0 = fmaxf(fmaxf(acc[2 * tp][2 * j][2 * rp], acc[2 * tp][2 * j][2 * rp + 1]),
+                                         fmaxf(acc[2 * tp + 1][2 * j][2 * rp], acc[2 * tp + 1][2 * j][2 * rp + 1]));
+                  const float m1 = fmaxf(fmaxf(acc[2 * tp][2 * j + 1][2 * rp], acc[2 * tp][2 * j + 1][2 * rp + 1]),
+                                         fmaxf(acc[2 * tp + 1][2 * j + 1][2 * rp], acc[2 * tp + 1][2 * j + 1][2 * rp + 1]));
+                  pk[j] = unetk_pk_bf16(m0, m1);
+                }
+                bf16_t* pp = pb + ((int64_t)(gh >> 1) * Wp + (gw >> 1)) * p.pool_s;
+                if constexpr (NT8 == 8) *reinterpret_cast<u32x4*>(pp) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                else *reinterpret_cast<uint2*>(pp) = make_uint2(pk[0], pk[1]);
+              }
+            }
+        }
+      }
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm) {
         const int gh = cur.h0 + wave * 4 + tm;
@@ -464,7 +506,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(ConvParams p) {
                 ssum[2 * j] += du0; ssq[2 * j] += du0 * ((q0 - nmu[2 * j]) * nrs[2 * j]);
                 ssum[2 * j + 1] += du1; ssq[2 * j + 1] += du1 * ((q1 - nmu[2 * j + 1]) * nrs[2 * j + 1]);
               }
-            } else {
+            } else if constexpr (AFF == 0) {
 #pragma unroll
               for (int j = 0; j < NT8; ++j) {
                 const float v = acc[tm][j][r];
@@ -476,7 +518,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(ConvParams p) {
       }
       after_full = !NBR && cur.h0 + TH <= p.H && cur.w0 + TW <= p.W;      // every store instruction was issued
       zero_acc();
-      if (p.stat != nullptr) {
+      if (AFF == 0 && p.stat != nullptr) {
         float* red = reinterpret_cast<float*>(smem + OFF_RED);      // [2][8][BN]
 #pragma unroll
         for (int j = 0; j < NT8; ++j) {
@@ -542,9 +584,9 @@ bool unetk_conv_bf16s_v3_ok(int N, int H, int W, int Cin, int Cout, int xs, int 
 
 int unetk_conv_bf16s_v3_stat_rows(int N, int H, int W) { return N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW); }
 
-template <int NT8, bool NBR>
+template <int NT8, bool NBR, int AFF = 0>
 static int launch_v3(const ConvParams& p, hipStream_t st) {
-  auto kern = conv3x3_bf16s_kernel<NT8, NBR>;
+  auto kern = conv3x3_bf16s_kernel<NT8, NBR, AFF>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
@@ -575,8 +617,16 @@ int unetk_conv_bf16s_v3_run(ConvParams p, hipStream_t st) {
   p.ptiles = p.stat_rows * p.n_ntiles;
   p.dbg = v3_flags();
   if (p.ny != nullptr) {
-    if (bn != 128 || p.nys % 8 != 0) return UNETK_E_UNSUPPORTED;
+    if (bn != 128 || p.nys % 8 != 0 || p.asc != nullptr) return UNETK_E_UNSUPPORTED;
     return launch_v3<8, true>(p, st);
+  }
+  if (p.asc != nullptr) {         // inference epilogue: (scale, shift) + ReLU [+ 2 x 2 max-pool]
+    if (p.stat != nullptr) return UNETK_E_UNSUPPORTED;
+    if (p.pool != nullptr) {
+      if (((p.H | p.W) & 1) || p.pool_s % (bn == 128 ? 8 : 4) != 0) return UNETK_E_UNSUPPORTED;
+      return bn == 128 ? launch_v3<8, false, 2>(p, st) : launch_v3<4, false, 2>(p, st);
+    }
+    return bn == 128 ? launch_v3<8, false, 1>(p, st) : launch_v3<4, false, 1>(p, st);
   }
   return bn == 128 ? launch_v3<8, false>(p, st) : launch_v3<4, false>(p, st);
 }

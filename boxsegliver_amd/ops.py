@@ -492,15 +492,16 @@ def conv3x3_fwd(x, w, cout, want_stats=True, y=None, bf16=False, dilation=1):
     return y, stats, rows
 
 
-def conv3x3_fwd_affine(x, w, cout, scale, shift, z=None, pool=False):
+def conv3x3_fwd_affine(x, w, cout, scale, shift, z=None, pool=False, bf16=False):
     """Inference: z = relu(conv3x3(x, w) * scale + shift) [and max_pool2d(z, 2, 2)] in one kernel (unetk_conv3x3_fwd_affine);
     w as for conv3x3_fwd.  Returns (z, pooled or None); raises UNETK_E_UNSUPPORTED shapes (ask conv3x3_fwd_affine_ok first)."""
     _require_cuda(x, w)
     n, h, wd, cin = x.shape
+    prec = precision_of(bf16)
     if z is None:
-        z = torch.empty((n, h, wd, cout), dtype=torch.float32, device=x.device)
-    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(x), _pix_stride(z), _abi.FP32, 1)
-    pooled = torch.empty((n, h // 2, wd // 2, cout), dtype=torch.float32, device=x.device) if pool else None
+        z = torch.empty((n, h, wd, cout), dtype=storage_dtype(prec), device=x.device)
+    d = ConvDesc(n, h, wd, cin, cout, _pix_stride(x), _pix_stride(z), prec, 1)
+    pooled = torch.empty((n, h // 2, wd // 2, cout), dtype=z.dtype, device=x.device) if pool else None
     nws = _abi.lib().unetk_conv3x3_ws_bytes(ctypes.byref(d))
     ws = WORKSPACE.get(nws, x.device) if nws else None
     check(_abi.lib().unetk_conv3x3_fwd_affine(ctypes.byref(d), ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(z), ptr(pooled), cout,
@@ -508,8 +509,8 @@ def conv3x3_fwd_affine(x, w, cout, scale, shift, z=None, pool=False):
     return z, pooled
 
 
-def conv3x3_fwd_affine_ok(n, h, wd, cin, cout, pool=False):
-    d = ConvDesc(n, h, wd, cin, cout, cin, cout, _abi.FP32, 1)
+def conv3x3_fwd_affine_ok(n, h, wd, cin, cout, pool=False, bf16=False):
+    d = ConvDesc(n, h, wd, cin, cout, cin, cout, precision_of(bf16), 1)
     return _abi.lib().unetk_conv3x3_fwd_affine_ok(ctypes.byref(d), 1 if pool else 0) == 1
 
 
@@ -1147,22 +1148,23 @@ class Conv3x3NormRelu(_Op):
             raise _abi.UnetkError("--use_se needs a normalised unit and no other density gain")
         # ---- inference fast path: the affine is known before the conv (moving statistics / --without_norm), so conv +
         # (scale, shift) + ReLU [+ the 2 x 2 max-pool the unit feeds] are ONE kernel and the raw output never exists
+        fprec = precision_of(bf16)          # UNETK_BF16S: bf16 activations in and out (the first layer reads the fp32 image)
         if FUSE_EVAL and not spec.training and not use_batch_stats and se is None and den is None and guide is None \
-                and gb is None and precision_of(bf16) == _abi.FP32 and dilation == 1:
+                and gb is None and fprec in (_abi.FP32, _abi.BF16S) and dilation == 1:
             n_, h_, w_ = x.shape[0], x.shape[1], x.shape[2]
-            z = out if out is not None else torch.empty((n_, h_, w_, cout), dtype=torch.float32, device=x.device)
-            fd = ConvDesc(n_, h_, w_, cin, cout, _pix_stride(x), _pix_stride(z), _abi.FP32, 1)
+            z = out if out is not None else torch.empty((n_, h_, w_, cout), dtype=storage_dtype(fprec), device=x.device)
+            fd = ConvDesc(n_, h_, w_, cin, cout, _pix_stride(x), _pix_stride(z), fprec, 1)
             want_pool = bool(getattr(ctx, "want_pool", False)) and POOL_FUSED
             with_pool = want_pool and _abi.lib().unetk_conv3x3_fwd_affine_ok(ctypes.byref(fd), 1) == 1
-            if with_pool or _abi.lib().unetk_conv3x3_fwd_affine_ok(ctypes.byref(fd), 0) == 1:
+            if (with_pool or _abi.lib().unetk_conv3x3_fwd_affine_ok(ctypes.byref(fd), 0) == 1) and z.dtype == storage_dtype(fprec):
                 nd = norm_desc((n_, h_, w_, cout), False, _pix_stride(z), 0, 0, 0)
                 if plain:
                     sc, sh = torch.ones_like(beta), beta.detach().contiguous()
                 else:
                     aff = norm_finalize(nd, None, 0, gamma, beta, spec.eps, spec.decay, False, moving_mean, moving_var, x.device)
                     sc, sh = aff[2], aff[3]
-                pooled = torch.empty((n_, h_ // 2, w_ // 2, cout), dtype=torch.float32, device=x.device) if with_pool else None
-                tag = _igemm_tag(cin, cout, False, h_, n_, w_) + ("+affine+relu+pool" if with_pool else "+affine+relu")
+                pooled = torch.empty((n_, h_ // 2, w_ // 2, cout), dtype=z.dtype, device=x.device) if with_pool else None
+                tag = _igemm_tag(cin, cout, bf16, h_, n_, w_) + ("+affine+relu+pool" if with_pool else "+affine+relu")
                 nws = _abi.lib().unetk_conv3x3_ws_bytes(ctypes.byref(fd))
                 ws = WORKSPACE.get(nws, x.device) if nws else None
                 with _timed(tag, 18.0 * n_ * h_ * w_ * cin * cout, "infer {}x{}x{} {}->{}", (n_, h_, w_, cin, cout)):

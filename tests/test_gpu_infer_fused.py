@@ -140,3 +140,89 @@ def test_unet_eval_takes_the_fused_path_and_matches_two_pass_and_oracle(variant)
     fused = [r for r in rec if "+affine+relu" in r[0]]
     assert len(fused) == 18 and sum(1 for r in fused if r[0].endswith("+pool")) >= 2
     assert not [r for r in rec if r[0] in ("norm_apply_relu_pool", "norm_apply_relu")]
+
+
+# ------------------------------------------------------------------------------------------------ bf16 storage mode
+BF16_SHAPES = [
+    # N, H, W, Cin, Cout, pool    (the persistent bf16-storage kernel: >= 200 tiles of 32 x 16 pixels)
+    (8, 128, 128, 64, 128, True),     # 128-channel tiles
+    (8, 128, 128, 128, 64, True),     # 64-channel tiles
+    (8, 96, 80, 64, 256, True),       # two channel tiles, several chunks
+    (20, 50, 70, 64, 128, False),     # ragged rows and columns: no pool
+]
+
+
+@pytest.mark.parametrize("shape", BF16_SHAPES)
+def test_bf16_storage_fused_affine_relu_pool_against_float64_of_the_same_operands(ops, shape):
+    """UNETK_BF16S: the activation is rounded to bf16 ONCE, from the fp32 accumulator after the affine and the ReLU (the
+    two-pass path rounds the raw output first): checked against float64 on the rounded operands to half a bf16 ulp of the
+    result, the pooled tensor bitwise against the maximum of the stored activations."""
+    n, h, w, cin, cout, pool = shape
+    B = ops._abi.BF16S
+    assert ops.conv3x3_fwd_affine_ok(n, h, w, cin, cout, pool, bf16=B)
+    rng = np.random.default_rng(abs(hash(shape)) % 2**31)
+    x = torch.from_numpy(rng.standard_normal((n, h, w, cin)).astype(np.float32)).cuda().to(torch.bfloat16)
+    wt = torch.from_numpy((rng.standard_normal((3, 3, cin, cout)) / math.sqrt(9 * cin)).astype(np.float32)).cuda()
+    sc = torch.from_numpy(((0.5 + rng.random(cout)) * np.where(rng.random(cout) < 0.2, -1.0, 1.0)).astype(np.float32)).cuda()
+    sh = torch.from_numpy((0.3 * rng.standard_normal(cout)).astype(np.float32)).cuda()
+    wp = ops.conv3x3_pack(wt, want_dgrad=False, bf16=B)[0]
+    buf = torch.full((n, h, w, cout + 64), -7.0, device="cuda", dtype=torch.bfloat16)
+    zv = buf[..., :cout]
+    z, p = ops.conv3x3_fwd_affine(x, wp, cout, sc, sh, z=zv, pool=pool, bf16=B)
+    torch.cuda.synchronize()
+    assert float((buf[..., cout:].float() + 7.0).abs().max()) == 0.0
+    xr = x.double()
+    wr = wt.to(torch.bfloat16).double()
+    ref = torch.relu(torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), wr.permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1) * sc.double()
+                     + sh.double())
+    got = zv.double()
+    ulp = torch.maximum(ref.abs(), torch.tensor(1e-30, device="cuda", dtype=torch.float64)) * 2.0 ** -8     # half a bf16 ulp <= |v| 2^-8
+    assert bool(((got - ref).abs() <= ulp * 1.02 + 2e-5).all())
+    if pool:
+        assert torch.equal(p, torch.nn.functional.max_pool2d(zv.float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).to(torch.bfloat16))
+
+
+def test_unet_bf16_storage_eval_takes_the_fused_path_and_stays_within_the_mode_s_bars():
+    """--compute_dtype bf16 evaluation at 256 x 256 bs 8 (the two finest levels are large enough for the persistent kernel): fused and two-pass forwards agree to bf16 rounding noise (the fused
+    path rounds once per unit instead of twice), both match the oracle restating the bf16 arithmetic within the bars of
+    tests/test_gpu_bf16s.py, and the persistent kernel's fused instantiations ran."""
+    import test_gpu_unet as t
+    from boxsegliver_amd import ops
+    args = t.make_args(batch_size=8, im_height=256, im_width=256, compute_dtype="bf16")
+    images, labels = t.synth(8, 256, 256, 3)
+    model, inputs = t.build(args, images, labels)
+    net, params = t.oracle_for(args)
+    g = torch.Generator().manual_seed(3)
+    for name, _, kind in net.specs:
+        if kind == "moving_mean":
+            params[name] = 0.1 * torch.randn(params[name].shape, generator=g)
+        elif kind == "moving_var":
+            params[name] = 0.5 + torch.rand(params[name].shape, generator=g)
+    model.params.load_state(params)
+    p64 = {k: v.double().cuda() for k, v in params.items()}
+    net.bf16 = 2
+    lg_ref, _ = net.forward(p64, inputs["images"].double(), False)
+    runs = {}
+    for fuse in (True, False):
+        ops.FUSE_EVAL = fuse
+        try:
+            model(inputs, "eval", **t.YML)
+            torch.cuda.synchronize()
+            runs[fuse] = model.layers["logits"].double().clone()
+        finally:
+            ops.FUSE_EVAL = True
+    for r in runs.values():
+        d = (r - lg_ref).abs()
+        assert d.mean().item() < 1e-2 and d.max().item() < 0.1
+        assert (r.argmax(-1) == lg_ref.argmax(-1)).double().mean().item() > 0.99
+    assert (runs[True] - runs[False]).abs().mean().item() < 1e-2
+    ops.profile_begin(0)
+    rec = []
+    ops.profile_on(rec)
+    try:
+        model(inputs, "eval", **t.YML)
+    finally:
+        ops.profile_on(None)
+    torch.cuda.synchronize()
+    fused = [r for r in rec if "+affine+relu" in r[0]]
+    assert len(fused) >= 8 and any("conv3x3_bf16s_kernel" in r[0] and r[0].endswith("+pool") for r in fused)
