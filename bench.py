@@ -588,5 +588,19 @@ def main():
         dist.destroy_process_group()
 
 
+def _main_with_clean_stdout():
+    """stdout carries the ONE JSON line and nothing else: libraries that print to file descriptor 1 on their own (RCCL's version
+    banner at communicator creation, amdgpu.ids notices) are sent to stderr while the benchmark runs."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    real = os.fdopen(saved, "w", buffering=1)
+    sys.stdout = real
+    try:
+        main()
+    finally:
+        sys.stdout.flush()
+
+
 if __name__ == "__main__":
-    main()
+    _main_with_clean_stdout()
