@@ -621,19 +621,21 @@ bool unetk_conv_lin_ok(int N, int H, int W, int Cin, int Cout, int spg) {
 // stream-K also for short K (24 chunks).  Round 4, UNet3D 96^3 in one call: all off 20.81 / 38.32 ms (one / two patches), bit 0
 // alone 20.70 / 38.78, bits 0 + 1 20.71 / 38.46, all three 20.51 / 38.02 -- the default.  (64-pixel blocks stage twice the filter
 // panel per MFMA -- 72 % matrix-pipe busy against 82 % for the 128-pixel stream-K variant, profiles/r04_pmc_mfma_busy_unet3d.txt --
-// and with every tile cut into K pieces the block count no longer has to fit the CU count.)
-static int lin_tune() {
+// and with every tile cut into K pieces the block count no longer has to fit the CU count.)  Applied to 3-D layers (spg > 1)
+// only: the 2-D nets' small planes keep the round-2 schedule (no measurable change on GUNet bs 8: 383.5 vs 383.5 slices/s, and
+// a different split of the K range is a different fp32 summation order).
+static int lin_tune(int spg) {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("UNETK_LIN_TUNE");
     v = e ? atoi(e) : 7;
   }
-  return v;
+  return spg > 1 ? v : 0;
 }
 
 static int lin_bm(int N, int H, int W, int Cout, int spg) {
   if (Cout % 128 != 0) return LIN_BM;
-  if (lin_tune() & 1) return LIN_BM;
+  if (lin_tune(spg) & 1) return LIN_BM;
   const int64_t nt = Cout / 128, groups = N / spg, gpix = (int64_t)spg * H * W;
   const int64_t b128 = groups * ((gpix + 127) / 128) * nt, b64 = groups * ((gpix + 63) / 64) * nt;
   if (b128 < 384) return 64;
@@ -730,12 +732,12 @@ SkPlan sk_plan(int N, int H, int W, int Cin, int Cout, int spg, int kd) {
   // at more)
   if (s.tiles >= 2048 || (s.tiles > 256 && eff >= 0.92)) return s;
   s.whole = s.tiles <= 256 ? 0 : s.tiles / 256 * 256;    // full rounds run one whole tile per block
-  if ((lin_tune() & 2) && s.tiles <= 1024) s.whole = 0;
+  if ((lin_tune(spg) & 2) && s.tiles <= 1024) s.whole = 0;
   const int rem = s.tiles - s.whole;
   // measured (UNet3D, one patch): a remainder of 176 tiles with K >= 48 chunks gains 10-12 %, 96 tiles or K = 24 chunks
   // do not pay for the slab round trip and the fix-up launch
   if (s.whole > 0 && (rem < 128 || s.nc < 48)) return s;
-  if (s.whole == 0 && s.tiles > 256 && s.nc < 48 && !(lin_tune() & 4)) return s;
+  if (s.whole == 0 && s.tiles > 256 && s.nc < 48 && !(lin_tune(spg) & 4)) return s;
   const int64_t tot = (int64_t)rem * s.nc;
   int G = 256;
   if (s.whole == 0 && tot >= 512 * 4) G = 512;           // nothing else resident: two blocks per CU

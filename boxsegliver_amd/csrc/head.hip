@@ -154,6 +154,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(unetk_head_desc d, const 
 #pragma unroll
   for (int i = 0; i < NQ; ++i) q[i] = 0.f;
 
+  // (Round 4, measured and not kept: ONE LANE PER PIXEL for C = 64 -- the wave's 64 x 64 tile staged through LDS with a
+  // conflict-free transposed read, a 64-term fma chain per class against the filter read back from LDS as broadcasts, no
+  // cross-lane traffic, 98 VGPRs -- was no faster in fp32 (0.177 vs 0.171 ms at 256^2 bs 32) and twice as slow on bf16 input
+  // (0.245 vs 0.128 ms at 512^2 bs 8): with 70 KB of LDS per block only two waves per SIMD are resident, and this kernel lives
+  // on loads in flight, not on vector issue slots.)
   // A group of lpp lanes shares a pixel's channel dot products (xor-shuffle sums leave the logits in every lane).  The
   // softmax / loss / metric arithmetic that follows is ~100 instructions per pixel: done by ONE lane of the group it made
   // the kernel VALU-bound at 1.3-2.7 TB/s.  So a group takes lpp consecutive pixels per pass and lane j keeps pixel j's
