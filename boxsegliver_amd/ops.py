@@ -298,6 +298,29 @@ def _wgrad_on_side(x, dy, bf16, dilation, out):
     return dw
 
 
+# 3-D layers: the filter gradient runs on the side stream BESIDE the input gradient.  UNet3D at one or two patches per GPU is a
+# sequence of 100-800 us launches of a few hundred tiles whose tails leave CUs idle (and the bridge's 27-54 blocks never fill the
+# chip); two such launches side by side share it.  Same kernels, same results bit for bit.  Measured in one call, 96^3: 20.52 ->
+# 20.29 ms at one patch, 38.0 -> 37.6 at two (the bridge alone: no gain; 10 x 256 x 256: no change).  Threshold in output
+# voxels of the layer (0 = never); UNETK_SIDE_WGRAD3D overrides.
+SIDE_WGRAD3D_VOXELS = int(os.environ.get("UNETK_SIDE_WGRAD3D", str(1 << 20)))
+
+
+def _wgrad3d_on_side(x, dy, d, out):
+    if _Side.stream is None:
+        _Side.stream = torch.cuda.Stream(device=x.device)
+    side = _Side.stream
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        dw = conv3d_wgrad(x, dy, d, out=out, ws_pool=_Side.ws)
+    dy.record_stream(side)
+    x.record_stream(side)
+    if not _Side.pending:
+        _Side.pending = True
+        torch.autograd.Variable._execution_engine.queue_callback(side_join)
+    return dw
+
+
 # ----------------------------------------------------------------------------- in-place parameter gradients
 class _GradSink(object):
     """Parameter gradients written by the backward kernels straight into the variable's slice of the flat gradient
@@ -639,11 +662,12 @@ def conv3d_dgrad(dy, wp_dgrad, d):
     return dx
 
 
-def conv3d_wgrad(x, dy, d, out=None):
+def conv3d_wgrad(x, dy, d, out=None, ws_pool=None):
     assert x.stride(-2) == d.x_stride and dy.is_contiguous()
     dw = out if out is not None else torch.empty((d.kd, 3, 3, d.Cin, d.Cout), dtype=torch.float32, device=x.device)
     assert tuple(dw.shape) == (d.kd, 3, 3, d.Cin, d.Cout) and dw.is_contiguous()
-    ws, nbytes = _ws3d(d, x.device)
+    nbytes = _abi.lib().unetk_conv3d_ws_bytes(ctypes.byref(d))
+    ws = (ws_pool or WORKSPACE).get(nbytes, x.device)
     flops = 2.0 * dy.numel() / d.Cout * d.kd * 9 * d.Cin * d.Cout
     with _Timed("conv3d_wgrad", flops, "k{}s{}{} {}".format(d.kd, d.sd, d.shw, tuple(x.shape))):
         check(_abi.lib().unetk_conv3d_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes, stream_ptr()),
@@ -1543,9 +1567,14 @@ class Conv3dNormRelu(_Op):
         debug = DEBUG_CAPTURE is not None
         sw, sg, sb = (None, None, None) if debug else (_take(ctx.sinks[0]), _take(ctx.sinks[1]), _take(ctx.sinks[2]))
         dy, dgamma, dbeta, _, _ = norm_relu_bwd_nd(ctx.nd, y, dz, aff, ctx.has[0], ctx.has[1], out_gamma=sg, out_beta=sb)
-        dw = conv3d_wgrad(x, dy, ctx.d, out=sw)
+        voxels = dy.numel() // dy.shape[-1]
+        on_side = (not debug) and sw is not None and ctx.need_dx and 0 < voxels <= SIDE_WGRAD3D_VOXELS
+        if not on_side:
+            dw = conv3d_wgrad(x, dy, ctx.d, out=sw)
         dense = conv3d_desc(x.shape, ctx.d.Cout, ctx.d.kd, (ctx.d.sd, ctx.d.shw, ctx.d.shw))   # dx is dense
         dx = conv3d_dgrad(dy, ctx.wp_d, dense) if ctx.need_dx else None
+        if on_side:
+            dw = _wgrad3d_on_side(x, dy, ctx.d, sw)
         if DEBUG_CAPTURE is not None:
             DEBUG_CAPTURE.append(dict(kind="conv3d", x=x, y=y, w=ctx.dbg[0], gamma=ctx.dbg[1], beta=ctx.dbg[2],
                                       stride=ctx.dbg[3], z=ctx.dbg[4], dz=dz, dy=dy, dw=dw, dx=dx, dgamma=dgamma, dbeta=dbeta,
