@@ -10,8 +10,8 @@ Design: the reference feeds the GPU from tf.data CPU threads (PNG decode + crop 
 MI355X has 288 GB of HBM and the whole decoded training set is ~35 GB as uint16, so `SliceStore` decodes every slice ONCE
 and keeps it on the device; a step's batch is then the host-side sampler (a few hundred integer operations) + one gather
 kernel (`unetk_lits_batch`).  Decoding: zlib inflate on host threads, the five PNG row filters undone on the device
-(`unetk_png_unfilter`), pixels written straight into the resident store (no cv2 / PIL in this image; `png_decode` is the
-host-side checker of that path).
+(`unetk_png_unfilter`), pixels written straight into the resident store (no cv2 / PIL in this image; the host-side
+checker of that path, a pure-numpy PNG decoder, lives with the test infrastructure: `oracle/lits_ops.png_decode`).
 
 The sampler restates the reference's selection logic literally (forced tumor / liver shares, crop placement around the
 object box, random zoom and window level) on a `random.Random(seed)` / `numpy.random.RandomState(seed)` pair instead
@@ -88,49 +88,6 @@ def png_inflate(data):
     if raw.size != h * (w * depth // 8 + 1):
         raise ValueError("PNG data stream has {} bytes, expected {}".format(raw.size, h * (w * depth // 8 + 1)))
     return w, h, depth, raw
-
-
-def png_decode(data):
-    """8- or 16-bit grayscale, non-interlaced PNG -> ndarray (uint8 / uint16), entirely on the HOST.  The checker of the
-    device path (tests) and a tool for small files (data/extract.py round trips): Average / Paeth rows run through a per-byte
-    Python loop, far too slow for a dataset -- `SliceStore` decodes through png_inflate + unetk_png_unfilter instead."""
-    w, h, depth, flat = png_inflate(data)
-    bpp = depth // 8
-    stride = w * bpp
-    raw = flat.reshape(h, stride + 1)
-    out = np.zeros((h, stride), dtype=np.uint8)
-    prev = np.zeros(stride, dtype=np.int32)
-    for y in range(h):
-        ft = int(raw[y, 0])
-        line = raw[y, 1:].astype(np.int32)
-        if ft == 0:
-            cur = line
-        elif ft == 2:
-            cur = (line + prev) & 255
-        elif ft == 1:                                       # Sub: byte lanes are independent running sums mod 256
-            cur = line.copy()
-            for k in range(bpp):
-                cur[k::bpp] = np.cumsum(line[k::bpp]) & 255
-        elif ft in (3, 4):                                  # Average / Paeth: sequential
-            cur = np.zeros(stride, dtype=np.int32)
-            for i in range(stride):
-                a = cur[i - bpp] if i >= bpp else 0
-                b = prev[i]
-                c = prev[i - bpp] if i >= bpp else 0
-                if ft == 3:
-                    pred = (a + b) >> 1
-                else:
-                    p = a + b - c
-                    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
-                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
-                cur[i] = (line[i] + pred) & 255
-        else:
-            raise ValueError("invalid PNG filter type {}".format(ft))
-        out[y] = cur
-        prev = cur
-    if depth == 8:
-        return out.copy()
-    return (out[:, 0::2].astype(np.uint16) << 8 | out[:, 1::2].astype(np.uint16)).copy()
 
 
 def png_filter_rows(arr, filters):

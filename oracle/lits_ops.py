@@ -61,3 +61,65 @@ def process_sample(slices, seg, box, clip, out_hw, lab_scale=64, flip_lr=False, 
     if flip_ud:
         img, lab = img[::-1], lab[::-1]
     return np.ascontiguousarray(img), np.ascontiguousarray(lab)
+
+
+def png_decode(data):
+    """8- or 16-bit grayscale, non-interlaced PNG -> ndarray (uint8 / uint16), entirely on the HOST: the checker of the product's
+    loader (boxsegliver_amd.data.lits.SliceStore: zlib inflate on host threads + unetk_png_unfilter on the device).  The five
+    row filters as the PNG specification defines them (what cv2.imread undoes in the reference's pipeline,
+    DataLoader/Liver/input_pipeline.py:243-284); Average / Paeth rows run through a per-byte Python loop -- small images only."""
+    import struct
+    import zlib
+    if data[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError("not a PNG file")
+    pos, idat, hdr = 8, [], None
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        chunk = data[pos + 8:pos + 8 + n]
+        pos += 12 + n
+        if typ == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", chunk)
+        elif typ == b"IDAT":
+            idat.append(chunk)
+        elif typ == b"IEND":
+            break
+    w, h, depth, ctype, _, _, interlace = hdr
+    if ctype != 0 or interlace != 0 or depth not in (8, 16):
+        raise ValueError("only non-interlaced 8/16-bit grayscale PNGs are supported")
+    flat = np.frombuffer(zlib.decompress(b"".join(idat)), dtype=np.uint8)
+    bpp = depth // 8
+    stride = w * bpp
+    raw = flat.reshape(h, stride + 1)
+    out = np.zeros((h, stride), dtype=np.uint8)
+    prev = np.zeros(stride, dtype=np.int32)
+    for y in range(h):
+        ft = int(raw[y, 0])
+        line = raw[y, 1:].astype(np.int32)
+        if ft == 0:
+            cur = line
+        elif ft == 2:
+            cur = (line + prev) & 255
+        elif ft == 1:                                       # Sub: byte lanes are independent running sums mod 256
+            cur = line.copy()
+            for k in range(bpp):
+                cur[k::bpp] = np.cumsum(line[k::bpp]) & 255
+        elif ft in (3, 4):                                  # Average / Paeth: sequential
+            cur = np.zeros(stride, dtype=np.int32)
+            for i in range(stride):
+                a = cur[i - bpp] if i >= bpp else 0
+                b = prev[i]
+                c = prev[i - bpp] if i >= bpp else 0
+                if ft == 3:
+                    pred = (a + b) >> 1
+                else:
+                    p = a + b - c
+                    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[i] = (line[i] + pred) & 255
+        else:
+            raise ValueError("invalid PNG filter type {}".format(ft))
+        out[y] = cur
+        prev = cur
+    if depth == 8:
+        return out.copy()
+    return (out[:, 0::2].astype(np.uint16) << 8 | out[:, 1::2].astype(np.uint16)).copy()

@@ -5,6 +5,8 @@ libpng with adaptive filters, DataLoader/Liver/extract.py:176-187, and are decod
 import json
 
 import numpy as np
+
+from oracle import lits_ops
 import pytest
 import torch
 
@@ -42,7 +44,7 @@ def test_png_unfilter_all_five_filter_types_bit_exact(h, w, depth):
     for k, (b, a) in enumerate(zip(files, imgs)):
         np.testing.assert_array_equal(got[k], a)
         if h * w <= 70 * 37:                                  # the host decoder's per-byte loop: small images only
-            np.testing.assert_array_equal(lits.png_decode(b), a)
+            np.testing.assert_array_equal(lits_ops.png_decode(b), a)
     # a corrupt filter byte is reported, not decoded as something
     bad = filt.clone()
     bad[0, 0] = 9

@@ -4,6 +4,8 @@ import json
 
 import numpy as np
 
+from oracle import lits_ops
+
 from boxsegliver_amd.data import extract, lits, nii_kits
 from boxsegliver_amd.utils import array_kits
 
@@ -56,8 +58,8 @@ def test_export_meta_and_png(tmp_path):
     assert np.allclose(m["tumor_centers"][0], [2.5, 11.5, 14.5]) and np.allclose(m["tumor_slices_centers"][2], [21.0, 25.5])
     # slices: 16-bit (clip(HU) + 200) * 64, labels * 64
     for z in (0, 3, 7):
-        im = lits.png_decode((out / "volume-7" / "{:03d}_im.png".format(z)).read_bytes())
-        lb = lits.png_decode((out / "volume-7" / "{:03d}_lb.png".format(z)).read_bytes())
+        im = lits_ops.png_decode((out / "volume-7" / "{:03d}_im.png".format(z)).read_bytes())
+        lb = lits_ops.png_decode((out / "volume-7" / "{:03d}_lb.png".format(z)).read_bytes())
         assert im.dtype == np.uint16 and lb.dtype == np.uint8
         np.testing.assert_array_equal(im, ((np.clip(vol[z], -200, 250) + 200) * 64).astype(np.uint16))
         np.testing.assert_array_equal(lb, lab[z] * 64)
