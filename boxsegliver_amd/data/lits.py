@@ -212,9 +212,9 @@ class SliceStore(object):
     streams (the GIL is released in both), `chunk` slices at a time, into one of two pinned staging buffers; each chunk is
     uploaded as FILTERED scanlines and `unetk_png_unfilter` writes the pixels straight into the store's slots while the
     pool already inflates the next chunk.  Peak host memory = the two staging buffers (2 x chunk x 0.77 MB at 512 x 512),
-    whatever the dataset's size.  Under data parallelism (`strategy` with N > 1 replicas) each rank decodes the slices
-    [r::N] ... of its contiguous share and the shares are exchanged rank by rank over the process group (RCCL / xGMI), so the
-    node reads and inflates the dataset once, not N times."""
+    whatever the dataset's size.  Under data parallelism (`strategy` with N > 1 replicas) each rank decodes its contiguous
+    1/N share of the slices and the shares are broadcast rank by rank over the process group (RCCL / xGMI), so the node reads
+    and inflates the dataset once, not N times."""
 
     def __init__(self, root, cases, device, strategy=None, chunk=256, threads=None):
         import concurrent.futures
