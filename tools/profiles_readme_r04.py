@@ -71,6 +71,7 @@ def pct(d):
 h, hn, hb, hc, h256 = J("bench_n1"), J("bench_n1_noevents"), J("bench_bf16_512_bs8"), J("bench_bf16c_512_bs8"), J("bench_bf16_256_bs32")
 g, gb, gbn = J("bench_gunet_bs8"), J("bench_bf16_gunet_bs8"), J("bench_bf16_gunet_bs8_noevents")
 u1, u2, r4, r1 = J("bench_unet3d_96_bs1"), J("bench_unet3d_96_bs2"), J("bench_unet3d_10x256_bs4"), J("bench_unet3d_10x256_bs1")
+u1d, r4d = J("bench_unet3d_96_bs1_by_layer"), J("bench_unet3d_10x256_bs4_by_layer")
 inf, inf2, infm, infb, infb2, infg = J("bench_infer_bs32"), J("bench_infer_bs32_twopass"), J("bench_infer_bs32_mirror"), \
     J("bench_infer_bf16_512_bs8"), J("bench_infer_bf16_512_bs8_twopass"), J("bench_infer_gunet_bs8")
 others = [J("bench_{}_bs8".format(m)) for m in ("UNetInter", "LGNet", "SmallUNet", "InterUNet")]
@@ -147,9 +148,17 @@ two-pass path (`UNETK_FUSE_EVAL=0`: conv, then `norm_apply_relu[_pool]`):
 | **10 x 256 x 256, bs 4** (the reference's own 3-D training shape, `threed_script/201_unet_v1.sh:26`) | **{r4v}** | {r4ms} | {r4p:.1f} % |
 | 10 x 256 x 256, bs 1 (its 4-GPU mirrored layout) | {r1v} | {r1ms} | {r1p:.1f} % |
 
-`{R}_bench_unet3d_10x256_bs4.json` by layer (`--detail`), the ops below 100 TFLOP/s:
+UNet3D runs its conv3d filter gradients on a second stream beside the input gradients (bit-identical results; 96^3 at one patch:
+{u1dms} ms on one stream -> {u1ms} ms); kernels then overlap and stretch each other, so the by-layer tables come from `--detail` runs,
+which use ONE stream (`{R}_bench_unet3d_96_bs1_by_layer.json`: {u1dv} patches/s, `{R}_bench_unet3d_10x256_bs4_by_layer.json`: {r4dv}).
+
+`{R}_bench_unet3d_10x256_bs4_by_layer.json`, the ops below 100 TFLOP/s:
 
 {r4k}
+
+`{R}_bench_unet3d_96_bs1_by_layer.json`, the ops below 80 TFLOP/s:
+
+{u1k}
 
 Matrix-pipe busy share and held clock at one 96^3 patch (`{R}_pmc_mfma_busy_unet3d.txt`):
 
@@ -221,7 +230,9 @@ per-byte Python loop (~0.3-0.5 s per slice).
     ik=kern_table(inf, 8),
     u1v=u1["value"], u1ms=u1["ms_per_step"], u1p=pct(u1), u2v=u2["value"], u2ms=u2["ms_per_step"], u2p=pct(u2),
     r4v=r4["value"], r4ms=r4["ms_per_step"], r4p=pct(r4), r1v=r1["value"], r1ms=r1["ms_per_step"], r1p=pct(r1),
-    r4k=kern_table({"kernels": [k for k in r4["kernels"] if k["achieved_tflops"] < 100.0]}, 14),
+    r4k=kern_table({"kernels": [k for k in r4d["kernels"] if k["achieved_tflops"] < 100.0]}, 14),
+    u1k=kern_table({"kernels": [k for k in u1d["kernels"] if k["achieved_tflops"] < 80.0]}, 16),
+    u1dms=u1d["ms_per_step"], u1dv=u1d["value"], r4dv=r4d["value"],
     mfu="\n".join(txt("pmc_mfma_busy_unet3d.txt").splitlines()[:16]),
     bv=hb["value"], bms=hb["ms_per_step"], btf=hb["whole_step_tflops"], bp=pct(hb), b256=h256["value"], bc=hc["value"],
     gbn=gbn["value"], gbe=gb["value"], bk=kern_table(hb), tile=txt("mfma_tile_bf16_random.txt") + "\n" + txt("mfma_tile_bf16_zeros.txt"),

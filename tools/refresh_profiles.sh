@@ -17,10 +17,13 @@ echo "bench_n1 done"
 $T python bench.py --steps 20 --warmup 5 --no-kernel-events --no-cpu-baseline > "$OUT/bench_n1_noevents.json"
 $T python bench.py --steps 10 --warmup 3 --detail --no-cpu-baseline > "$OUT/bench_n1_by_layer.json"
 $T python bench.py --model GUNet --batch 8 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_gunet_bs8.json"
-$T python bench.py --model UNet3D --size 96 --batch 2 --steps 5 --warmup 2 --detail --no-cpu-baseline > "$OUT/bench_unet3d_96_bs2.json"
-$T python bench.py --model UNet3D --size 96 --batch 1 --steps 5 --warmup 2 --detail --no-cpu-baseline > "$OUT/bench_unet3d_96_bs1.json"
+$T python bench.py --model UNet3D --size 96 --batch 2 --steps 8 --warmup 2 --no-cpu-baseline > "$OUT/bench_unet3d_96_bs2.json"
+$T python bench.py --model UNet3D --size 96 --batch 1 --steps 8 --warmup 2 --no-cpu-baseline > "$OUT/bench_unet3d_96_bs1.json"
+# by layer: --detail runs UNet3D on ONE stream (its filter gradients otherwise overlap the input gradients and stretch them)
+$T python bench.py --model UNet3D --size 96 --batch 1 --steps 8 --warmup 2 --detail --no-cpu-baseline > "$OUT/bench_unet3d_96_bs1_by_layer.json"
 # the reference's own 3-D training shape (threed_script/201_unet_v1.sh:26): 10 x 256 x 256 patches, bs 4 (and bs 1 = its 4-GPU layout)
-$T python bench.py --model UNet3D --depth 10 --size 256 --batch 4 --steps 8 --warmup 2 --detail --no-cpu-baseline > "$OUT/bench_unet3d_10x256_bs4.json"
+$T python bench.py --model UNet3D --depth 10 --size 256 --batch 4 --steps 8 --warmup 2 --no-cpu-baseline > "$OUT/bench_unet3d_10x256_bs4.json"
+$T python bench.py --model UNet3D --depth 10 --size 256 --batch 4 --steps 8 --warmup 2 --detail --no-cpu-baseline > "$OUT/bench_unet3d_10x256_bs4_by_layer.json"
 $T python bench.py --model UNet3D --depth 10 --size 256 --batch 1 --steps 8 --warmup 2 --no-cpu-baseline > "$OUT/bench_unet3d_10x256_bs1.json"
 for m in UNetInter LGNet SmallUNet InterUNet; do
   $T python bench.py --model $m --batch 8 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_${m}_bs8.json"
@@ -59,7 +62,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bf16" -o bf16
   python3 "$ROOT/bench.py" --dtype bf16 --size 512 --batch 8 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/prof_bf16.log" 2>&1
 echo "kernel trace bf16 (512x512 bs 8) done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_u3d" -o u3d -- \
-  python3 "$ROOT/bench.py" --model UNet3D --size 96 --batch 1 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/prof_u3d.log" 2>&1
+  python3 "$ROOT/bench.py" --model UNet3D --size 96 --batch 1 --steps 5 --warmup 2 --detail --no-cpu-baseline --no-kernel-events > "$OUT/prof_u3d.log" 2>&1
 echo "kernel trace UNet3D done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- \
   python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_fetch.log" 2>&1
@@ -83,7 +86,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma_bf16" -o mfma -- \
   python3 "$ROOT/bench.py" --dtype bf16 --size 512 --batch 8 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_mfma_bf16.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma_u3d" -o mfma -- \
-  python3 "$ROOT/bench.py" --model UNet3D --size 96 --batch 1 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_mfma_u3d.log" 2>&1
+  python3 "$ROOT/bench.py" --model UNet3D --size 96 --batch 1 --steps 2 --warmup 1 --detail --no-cpu-baseline --no-kernel-events > "$OUT/pmc_mfma_u3d.log" 2>&1
 echo "pmc mfma done"
 cd "$ROOT"
 python tools/pmc_mfma.py "$(find "$OUT/pmc_mfma" -name '*counter_collection.csv' | head -1)" "$OUT/pmc_mfma_busy.txt"
