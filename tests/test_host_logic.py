@@ -169,28 +169,21 @@ def test_synthetic_input_contract():
 
 
 def test_profiles_readme_is_generated_from_the_committed_profiles():
-    """profiles/r02_README.md is written by tools/profiles_readme.py from the bench lines, rocprofv3 tables and PMC
+    """profiles/rNN_README.md (round 4 on) is written by tools/profiles_readme.py from the bench lines, rocprofv3 tables and PMC
     summaries next to it: regenerating it must give the committed text (numbers in the prose cannot drift from the files)."""
+    import glob
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "profiles_readme.py"), "r02"], stdout=subprocess.PIPE,
-                         stderr=subprocess.PIPE, text=True, cwd=root)
-    assert out.returncode == 0, out.stderr[-2000:]
-    with open(os.path.join(root, "profiles", "r02_README.md")) as f:
-        assert out.stdout == f.read()
-
-
-def test_round3_profiles_readme_is_generated_from_the_committed_profiles():
-    """Same for profiles/r03_README.md (tools/profiles_readme_r03.py)."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "profiles_readme_r03.py")], stdout=subprocess.PIPE,
-                         stderr=subprocess.PIPE, text=True, cwd=root)
-    assert out.returncode == 0, out.stderr[-2000:]
-    with open(os.path.join(root, "profiles", "r03_README.md")) as f:
-        assert out.stdout == f.read()
+    rounds = sorted(os.path.basename(p)[:3] for p in glob.glob(os.path.join(root, "profiles", "r*_README.md")))
+    rounds = [r for r in rounds if r >= "r04"]
+    assert rounds
+    for r in rounds:
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "profiles_readme.py"), r], stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        with open(os.path.join(root, "profiles", r + "_README.md")) as f:
+            assert out.stdout == f.read(), r
 
 
 def test_input_gradient_pack_item_order_is_a_bijection():
