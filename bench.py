@@ -147,6 +147,49 @@ def cpu_baseline(size, full=False):
     return out
 
 
+def dice_vs_oracle(steps=120, size=64, bs=8):
+    """BASELINE.json metric "... Dice vs ref": part of the cpu_baseline leg (the only place bench.py touches the oracle), outside
+    the timed region.  The headline network (UNet.yml sizes, 3 classes, batch norm, numerical loss weights) is trained for `steps`
+    TF-Adam steps at size x size, bs `bs`, from identical variables on the same learnable synthetic stream, once on the HIP path
+    (fp32) and once on the oracle in float64 (on the device: the oracle is a torch restatement; as the CHECKER only); then
+    Liver/Dice and Tumor/Dice (loss_metrics.py:261-301) on held-out batches.  `max_abs_diff` is what north_star bounds by 1e-3;
+    tests/test_gpu_train_dice.py asserts it on a longer run."""
+    import numpy as np
+    from boxsegliver_amd.NetworksV2.UNet import UNet
+    from boxsegliver_amd.core.solver import Solver
+    from oracle import train_parity as tp
+    from oracle import unet2d
+    t0 = time.perf_counter()
+    args = make_args(bs, 1, size)
+    args.learning_policy, args.tag = "period_step", "dice_vs_oracle"
+    train, held = tp.stream(12, bs, size, 2026), tp.stream(4, bs, size, 99)
+    dev = lambda b: {"images": torch.from_numpy(b[0]).cuda(), "labels": torch.from_numpy(b[1]).cuda()}   # noqa: E731
+    model = UNet(args)
+    model(dev(train[0]), "eval", **YML)
+    net = unet2d.UNet2DOracle(3, 3, init_channels=YML["init_channels"], num_down_samples=YML["num_down_samples"])
+    params = unet2d.init_params(net.specs, seed=11)
+    model.params.load_state(params)
+    solver = Solver(args)
+    for s in range(steps):
+        solver(model(dev(train[s % len(train)]), "train", **YML), model)
+    hip = {"Liver/Dice": [], "Tumor/Dice": []}
+    for b in held:
+        with torch.no_grad():
+            model(dev(b), "train", **YML)                 # batch statistics, as oracle/train_parity.heldout
+        for k in hip:
+            hip[k].append(float(model.metrics_dict[k]))
+    hip = {k: float(np.mean(v)) for k, v in hip.items()}
+    kw = dict(loss_type="xentropy", loss_weight_type="numerical", numeric_w=args.loss_numeric_w,
+              weight_decay_rate=args.weight_decay_rate)
+    p_ref, _ = tp.train(net, params, train, steps, args.learning_rate, kw, device="cuda", dtype=torch.float64)
+    ref, _, _ = tp.heldout(net, p_ref, held, ["Background", "Liver", "Tumor"], device="cuda", dtype=torch.float64)
+    return {"max_abs_diff": round(max(abs(hip[k] - ref[k]) for k in ref), 6), "hip_fp32": {k: round(v, 6) for k, v in hip.items()},
+            "oracle_f64": {k: round(v, 6) for k, v in ref.items()}, "tolerance": 1e-3,
+            "sample": "UNet (64 ch, 4 levels, BN) {0}x{0}x3 bs {1}, {2} TF-Adam steps from identical variables on the same synthetic "
+                      "stream; held-out Liver/Dice, Tumor/Dice (batch statistics); oracle in float64 on the device".format(size, bs, steps),
+            "wall_s": round(time.perf_counter() - t0, 1)}
+
+
 def infer_main(a, args, model, inputs_of, data, gflop_unit, workload_name, rank, world):
     """--mode infer: EvaluateVolume's per-slab work (evaluators/evaluator_liver.py `_slab_probability` / `_predict_case`, the
     device-side restatement of the reference's evaluator_liver.py:616-678,704-766) on resident synthetic slabs.  One step =
@@ -590,6 +633,8 @@ def main():
                 pass
         if not a.no_cpu_baseline and world == 1 and a.model == "UNet":
             out["cpu_baseline"] = cpu_baseline(a.size, a.cpu_baseline_full)
+            if a.dtype == "fp32":
+                out["dice_vs_oracle"] = dice_vs_oracle()
         print(json.dumps(out, ensure_ascii=False), flush=True)
     if dp_on:
         dist.destroy_process_group()

@@ -10,8 +10,9 @@ Design: the reference feeds the GPU from tf.data CPU threads (PNG decode + crop 
 MI355X has 288 GB of HBM and the whole decoded training set is ~35 GB as uint16, so `SliceStore` decodes every slice ONCE
 and keeps it on the device; a step's batch is then the host-side sampler (a few hundred integer operations) + one gather
 kernel (`unetk_lits_batch`).  Decoding: zlib inflate on host threads, the five PNG row filters undone on the device
-(`unetk_png_unfilter`), pixels written straight into the resident store (no cv2 / PIL in this image; the host-side
-checker of that path, a pure-numpy PNG decoder, lives with the test infrastructure: `oracle/lits_ops.png_decode`).
+(`unetk_png_unfilter`), pixels written straight into the resident store (the product needs neither cv2 nor PIL; the host-side
+checker of that path, a pure-numpy PNG decoder, lives with the test infrastructure: `oracle/lits_ops.png_decode`, and both
+halves are pinned by files a third-party encoder wrote: tests/golden/png/, made with Pillow).
 
 The sampler restates the reference's selection logic literally (forced tumor / liver shares, crop placement around the
 object box, random zoom and window level) on a `random.Random(seed)` / `numpy.random.RandomState(seed)` pair instead
@@ -33,6 +34,7 @@ from ..utils import distribution_utils
 
 IM_SCALE = 64
 LB_SCALE = 64
+PNG_MAX_WIDTH = 4096           # csrc/lits.hip: unetk_png_unfilter keeps a band's carried row in LDS
 LIVER_PERCENT = 0.66
 TUMOR_PERCENT = 0.5
 RND_SCALE = (1.0, 1.4)
@@ -87,6 +89,11 @@ def png_inflate(data):
     raw = np.frombuffer(zlib.decompress(b"".join(idat) if len(idat) != 1 else idat[0]), dtype=np.uint8)
     if raw.size != h * (w * depth // 8 + 1):
         raise ValueError("PNG data stream has {} bytes, expected {}".format(raw.size, h * (w * depth // 8 + 1)))
+    if w > PNG_MAX_WIDTH:
+        raise ValueError("PNG is {} pixels wide; unetk_png_unfilter takes rows of at most {}".format(w, PNG_MAX_WIDTH))
+    if h and int(raw[::w * depth // 8 + 1].max()) > 4:       # the device kernel's status word stays as the backstop
+        raise ValueError("PNG row {} carries filter type {} (corrupt file)".format(
+            int(np.argmax(raw[::w * depth // 8 + 1] > 4)), int(raw[::w * depth // 8 + 1].max())))
     return w, h, depth, raw
 
 
@@ -254,31 +261,45 @@ class SliceStore(object):
 
         def inflate(slot, j, pair):
             for path, dst, depth_bits in ((pair[0], stage[slot][0], 16), (pair[1], stage[slot][1], 8)):
-                pw, ph, pd, raw = png_inflate(path.read_bytes())
+                try:
+                    pw, ph, pd, raw = png_inflate(path.read_bytes())
+                except (ValueError, zlib.error) as e:
+                    raise ValueError("{}: {}".format(path, e))
                 if (ph, pw, pd) != (h, w, depth_bits):
                     raise ValueError("{}: {}x{} {}-bit, expected {}x{} {}-bit".format(path, ph, pw, pd, h, w, depth_bits))
                 dst[j].numpy()[:] = raw
 
         workers = int(threads or min(32, (os.cpu_count() or 8)))
-        with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
-            k = 0
-            for c0 in range(lo, hi, chunk):
-                slot, cnt = k & 1, min(chunk, hi - c0)
-                if done[slot] is not None:
-                    done[slot].synchronize()                                       # its previous upload has left the pinned buffer
-                for f in [pool.submit(inflate, slot, j, files[c0 + j]) for j in range(cnt)]:
-                    f.result()
-                for which, depth_bits, dst in ((0, 16, self.im), (1, 8, self.lb)):
-                    dev_stage[slot][which][:cnt].copy_(stage[slot][which][:cnt], non_blocking=True)
-                    ops.png_unfilter(dev_stage[slot][which][:cnt], h, w, depth_bits, dst[c0:c0 + cnt], status)
-                if device.type == "cuda":
-                    done[slot] = torch.cuda.Event()
-                    done[slot].record()
-                k += 1
-        if int(status.item()) != 0:
-            raise ValueError("a PNG row carries an invalid filter type (corrupt file under {})".format(root / "png"))
+        failure = None                     # a rank that cannot decode its share must not leave the others in the exchange below
+        try:
+            with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
+                k = 0
+                for c0 in range(lo, hi, chunk):
+                    slot, cnt = k & 1, min(chunk, hi - c0)
+                    if done[slot] is not None:
+                        done[slot].synchronize()                                   # its previous upload has left the pinned buffer
+                    for f in [pool.submit(inflate, slot, j, files[c0 + j]) for j in range(cnt)]:
+                        f.result()
+                    for which, depth_bits, dst in ((0, 16, self.im), (1, 8, self.lb)):
+                        dev_stage[slot][which][:cnt].copy_(stage[slot][which][:cnt], non_blocking=True)
+                        ops.png_unfilter(dev_stage[slot][which][:cnt], h, w, depth_bits, dst[c0:c0 + cnt], status)
+                    if device.type == "cuda":
+                        done[slot] = torch.cuda.Event()
+                        done[slot].record()
+                    k += 1
+            if int(status.item()) != 0:
+                raise ValueError("a PNG row carries an invalid filter type (corrupt file under {})".format(root / "png"))
+        except (ValueError, OSError) as e:
+            failure = e
         if world > 1:
             import torch.distributed as dist
+            bad = torch.tensor([1 if failure is not None else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)                             # everybody learns of a failure BEFORE the exchange
+            if int(bad.item()) and failure is None:
+                failure = ValueError("another rank could not decode its share of the slices under {}".format(root / "png"))
+        if failure is not None:
+            raise failure
+        if world > 1:
             for r in range(world):                                                 # every rank's share to everyone (uneven shares: one broadcast each)
                 if share[r + 1] > share[r]:
                     dist.broadcast(self.im[share[r]:share[r + 1]].view(torch.uint8), src=r)    # bytes: every backend moves uint8

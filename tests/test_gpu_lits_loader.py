@@ -52,6 +52,28 @@ def test_png_unfilter_all_five_filter_types_bit_exact(h, w, depth):
     assert int(status.item()) == 1
 
 
+def test_png_written_by_a_third_party_encoder_decodes_on_the_device():
+    """tests/golden/png/*.png come from Pillow (zlib + adaptive row filters, one file with its stream cut into several IDAT
+    chunks; tests/golden/make_png_fixtures.py): png_inflate + unetk_png_unfilter give the committed pixels bit for bit."""
+    import glob
+    import os
+    from boxsegliver_amd import ops
+    from boxsegliver_amd.data import lits
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "png")
+    px = np.load(os.path.join(here, "pixels.npz"))
+    names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(here, "*.png")))
+    assert len(names) >= 5 and sorted(px.files) == names
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for name in names:
+        want = px[name]
+        w, h, depth, raw = lits.png_inflate(open(os.path.join(here, name + ".png"), "rb").read())
+        assert (h, w, depth) == (want.shape[0], want.shape[1], 8 * want.dtype.itemsize)
+        out = torch.empty((1, h, w), dtype=torch.int16 if depth == 16 else torch.uint8, device="cuda")
+        ops.png_unfilter(torch.from_numpy(raw.copy())[None].cuda(), h, w, depth, out, status)
+        np.testing.assert_array_equal(out.cpu().numpy().view(want.dtype)[0], want)
+    assert int(status.item()) == 0
+
+
 def _write_dataset(root, n_cases, depth, size, rng, filters):
     from boxsegliver_amd.data import lits
     meta, truth = [], {}
