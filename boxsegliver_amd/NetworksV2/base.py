@@ -61,7 +61,12 @@ class ParamStore(object):
         self.flat = {g: torch.zeros(max(sizes[g], 4), dtype=torch.float32, device=device) for g in sizes}
         for g in ("reg", "noreg"):                        # filters that are views of these keep their packed forms (ops._PackCache)
             ops.register_param_buffer(self.flat[g])
-        self.grad = {g: torch.zeros_like(self.flat[g]) for g in ("reg", "noreg")}
+        # ONE allocation [noreg | reg] for the gradients: the norm parameters' gradients lie directly in front of the first layers'
+        # filter gradients, so the data-parallel path's LAST bucket (distribution_utils.GradBuckets) carries them in the same
+        # collective, and zero_grad is one fill
+        n_noreg, n_reg = self.flat["noreg"].numel(), self.flat["reg"].numel()
+        self.gbuf = torch.zeros(n_noreg + n_reg, dtype=torch.float32, device=device)
+        self.grad = {"noreg": self.gbuf[:n_noreg], "reg": self.gbuf[n_noreg:]}
         self.tensors = OrderedDict()
         for name, shape, kind in self.specs:
             grp, off, n, shp, _ = self.where[name]
@@ -85,8 +90,7 @@ class ParamStore(object):
 
     def zero_grad(self):
         ops.new_step(self.grad.values())      # the backward kernels may write each of THIS store's gradient slots in place once per step
-        for g in self.grad.values():
-            g.zero_()
+        self.gbuf.zero_()
         for name in self.trainable_names():
             grp, off, n, shp, _ = self.where[name]
             t = self.tensors[name]

@@ -345,6 +345,7 @@ class CustomEstimator(object):
                 break
             if max_steps is not None and step >= max_steps:
                 break
+        self._raise_if_nan_seen(self._dp_or_none())         # before the hooks' final evaluation / best-checkpoint save
         for h in hooks:
             h.end(session)
         if last_loss is None and done:
@@ -352,6 +353,12 @@ class CustomEstimator(object):
         self._raise_if_nan_seen(self._dp_or_none())
         self.save_checkpoint()
         return last_loss
+
+    def poll_nan(self):
+        """For hooks, on EVERY rank, before work that would consume or persist the variables (an evaluation, a best-checkpoint
+        save): raises NanLossDuringTrainingError if any step since the last poll saw a NaN loss (the flag is max-reduced under
+        data parallelism, so all ranks stop together).  One small device -> host read."""
+        self._raise_if_nan_seen(self._dp_or_none())
 
     def _dp_or_none(self):
         d = self._train_distribution

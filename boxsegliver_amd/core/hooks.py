@@ -61,6 +61,13 @@ def _strategy(session):
     return st if st is not None and st.num_replicas_in_sync > 1 else None
 
 
+def _poll_nan(session):
+    """Estimator.poll_nan on every rank (fake sessions of the host tests have no estimator / no such method)."""
+    poll = getattr(getattr(session, "estimator", None), "poll_nan", None)
+    if poll is not None:
+        poll()
+
+
 class LogLearningRateHook(SessionRunHook):
     """core/hooks.py:471-518: log (and record) the learning rate every N steps."""
 
@@ -261,6 +268,7 @@ class EvaluatorHook(SessionRunHook):
             self._evaluate(session, last_step)
 
     def _evaluate(self, session, step):
+        _poll_nan(session)                  # never evaluate -- or save as "best" -- variables a NaN step has gone through
         results = self._evaluator.run_with_session(session)
         if self._save_interval and (step // self._save_interval != self._last_interval_step // self._save_interval):
             self._better_result = None                                  # new interval
@@ -336,6 +344,7 @@ class EvaluatorHookV2(SessionRunHook):
             self._evaluate(session, last_step)
 
     def _evaluate(self, session, step):
+        _poll_nan(session)
         results = self._evaluator.run_with_session(session)
         if self._trigger_counter <= 1:
             return False

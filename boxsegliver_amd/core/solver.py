@@ -102,7 +102,7 @@ class Solver(object):
         self._state = None
         self.strategy = None                # set by the estimator for data parallelism
         self.overlap_allreduce = True       # bucketed all-reduce launched from backward (distribution_utils.GradBuckets)
-        self.bucket_bytes = 32 << 20
+        self.bucket_bytes = 64 << 20
         self._buckets = None
         self.dp_rehearsal = False           # run the data-parallel path (buckets, all-reduce) in a world of ONE (bench.py --dp-rehearsal)
 

@@ -29,6 +29,16 @@ constexpr int MAXG = 4;   // guide channels
 #ifndef UNETK_NORM_GROUPS
 #define UNETK_NORM_GROUPS 4
 #endif
+// the same for bf16 storage (8-byte loads per thread: twice the groups keep the same bytes in flight) and for the reduction pass
+#ifndef UNETK_NORM_GROUPS_BF
+#define UNETK_NORM_GROUPS_BF 4
+#endif
+#ifndef UNETK_NORM_RGROUPS
+#define UNETK_NORM_RGROUPS 2
+#endif
+#ifndef UNETK_NORM_RGROUPS_BF
+#define UNETK_NORM_RGROUPS_BF 2
+#endif
 
 struct NormGeom {
   int Ns;        // statistic groups (1 for batch norm, N for instance norm)
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(256) void norm_apply_relu_kernel(ApplyArgs a) {
     // plain units (every unit of UNet / UNet3D): NP ADJACENT row groups per pass, all loads issued before any is used.
     // Measured on the headline step: NP = 2 -> 84.0 to 79.4 us per launch; pairing pix with pix + grid stride instead
     // (two far-apart streams per block) was 7 % SLOWER than no pairing.
-    constexpr int NP = UNETK_NORM_GROUPS;
+    constexpr int NP = sizeof(T) == 2 ? UNETK_NORM_GROUPS_BF : UNETK_NORM_GROUPS;
     for (pix = (int64_t)blockIdx.x * NP * a.rpi + rl; pix < a.P; pix += NP * pstep) {
       float4 v[NP];
 #pragma unroll
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(BwdArgs a) {
     if (G == 0 && !D && !L && !drop && UNETK_NORM_GROUPS > 1) {
       // plain units: two adjacent row groups per pass (four loads in flight), summed in pixel order (four groups measured
       // slower here -- 101 vs 105 us -- while they help the apply passes)
-      constexpr int NP = 2;
+      constexpr int NP = sizeof(T) == 2 ? UNETK_NORM_RGROUPS_BF : UNETK_NORM_RGROUPS;
       for (pix = (int64_t)blockIdx.x * NP * a.rpi + rl; pix < a.P; pix += NP * pstep) {
         float4 v[NP], d[NP];
 #pragma unroll
@@ -504,7 +514,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(BwdArgs a) {
   int64_t pix = (int64_t)blockIdx.x * a.rpi + rl;
   if (G == 0 && !D && !L && !drop && UNETK_NORM_GROUPS > 1) {
     // plain units: NP adjacent row groups per pass, 2 NP loads in flight (see norm_apply_relu_kernel): 130.1 -> 116.8 us
-    constexpr int NP = UNETK_NORM_GROUPS;
+    constexpr int NP = sizeof(T) == 2 ? UNETK_NORM_GROUPS_BF : UNETK_NORM_GROUPS;
     for (pix = (int64_t)blockIdx.x * NP * a.rpi + rl; pix < a.P; pix += NP * pstep) {
       float4 v[NP], d[NP];
 #pragma unroll

@@ -304,6 +304,7 @@ def _wgrad_on_side(x, dy, bf16, dilation, out):
 # 20.29 ms at one patch, 38.0 -> 37.6 at two (the bridge alone: no gain; 10 x 256 x 256: no change).  Threshold in output
 # voxels of the layer (0 = never); UNETK_SIDE_WGRAD3D overrides.
 SIDE_WGRAD3D_VOXELS = int(os.environ.get("UNETK_SIDE_WGRAD3D", str(1 << 20)))
+SIDE_WGRAD3D_FIRST = os.environ.get("UNETK_SIDE_WGRAD3D_FIRST", "1") == "1"      # see Conv3dNormRelu.backward (round-5 A/B)
 
 
 def _wgrad3d_on_side(x, dy, d, out):
@@ -1571,10 +1572,12 @@ class Conv3dNormRelu(_Op):
         on_side = (not debug) and sw is not None and ctx.need_dx and 0 < voxels <= SIDE_WGRAD3D_VOXELS
         if not on_side:
             dw = conv3d_wgrad(x, dy, ctx.d, out=sw)
+        elif SIDE_WGRAD3D_FIRST:
+            dw = _wgrad3d_on_side(x, dy, ctx.d, sw)      # queued behind dy only: runs BESIDE this layer's input gradient
         dense = conv3d_desc(x.shape, ctx.d.Cout, ctx.d.kd, (ctx.d.sd, ctx.d.shw, ctx.d.shw))   # dx is dense
         dx = conv3d_dgrad(dy, ctx.wp_d, dense) if ctx.need_dx else None
-        if on_side:
-            dw = _wgrad3d_on_side(x, dy, ctx.d, sw)
+        if on_side and not SIDE_WGRAD3D_FIRST:
+            dw = _wgrad3d_on_side(x, dy, ctx.d, sw)      # queued behind the input gradient: runs beside the NEXT unit's norm backward
         if DEBUG_CAPTURE is not None:
             DEBUG_CAPTURE.append(dict(kind="conv3d", x=x, y=y, w=ctx.dbg[0], gamma=ctx.dbg[1], beta=ctx.dbg[2],
                                       stride=ctx.dbg[3], z=ctx.dbg[4], dz=dz, dy=dy, dw=dw, dx=dx, dgamma=dgamma, dbeta=dbeta,
@@ -1721,6 +1724,9 @@ class HeadLoss(_Op):
 
     @staticmethod
     def forward(ctx, z, w, b, labels, pixel_w, desc, want_probs):
+        # undefined gradients stay None: autograd otherwise zero-fills a [N, H, W, classes] tensor per step for each of the
+        # non-differentiable outputs (logits, probabilities: 2 x 25 MB at the headline shape) only to hand it to backward
+        ctx.set_materialize_grads(False)
         w2 = w.reshape(desc.C, desc.ncls)
         logits, probs, result, ws = head_fwd(desc, z, w2, b, labels, pixel_w, want_probs)
         ctx.save_for_backward(z, w2, labels, pixel_w, logits, result, ws)

@@ -68,6 +68,9 @@ class DistributionStrategy(object):
             ops.bump_param_gen()              # the variables changed behind torch's version counters' back
 
 
+_PROBE = os.environ.get("UNETK_DP_PROBE", "")      # measurement switches of GradBuckets (never set in production)
+
+
 class GradBuckets(object):
     """Gradient all-reduce overlapped with backward.
 
@@ -79,38 +82,45 @@ class GradBuckets(object):
     launches whatever did not fire (variables that received no gradient) and makes the compute stream wait.
     The reference packs into num_packs=2 tensors (distribution_utils.py:94-95) and leaves the overlap to TF."""
 
-    def __init__(self, store, strategy, bucket_bytes=32 << 20):
+    def __init__(self, store, strategy, bucket_bytes=64 << 20, tail_bytes=4 << 20):
         self.store, self.strategy = store, strategy
-        self.buckets = []                     # (group, lo, hi, n_vars), in LAUNCH order = expected completion order
+        self.buckets = []                     # (lo, hi, n_vars) in elements of store.gbuf, in LAUNCH order = expected completion order
         self._bucket_of = {}
         self._hooks = []
-        # One walk over the variables in reverse forward order (= the order their gradients arrive in), cutting BOTH flat
-        # buffers at the same places: when the regularised buffer's current slice reaches `bucket_bytes` it is closed, and
-        # the norm parameters (gamma / beta, the other buffer) met on the way form the next bucket.  So bucket indices follow
-        # arrival time across both buffers -- a gamma / beta bucket waits for the filters of ITS OWN part of the network,
-        # not for the first layer's (round 3 numbered every "reg" bucket before any "noreg" one: the norm parameters'
-        # all-reduce could only start when backward was over).
+        # ParamStore keeps both gradient buffers in ONE allocation, [noreg | reg].  One walk over the variables in reverse forward
+        # order (= the order their gradients arrive in) cuts the filter gradients ("reg") from the end into buckets of about
+        # `bucket_bytes`; the norm parameters (gamma / beta: 47 KB in all for the U-Net) all ride in the LAST bucket -- the first
+        # layers' filters, whose slice starts where the noreg buffer ends, so the bucket is one contiguous range.  Round 4 gave
+        # the norm parameters met between two cuts a collective of their own: 8 collectives per step, and on a 13 ms step each
+        # costs ~30 us on the GPU whatever its size (the stream hand-over: measured in a world of one, where no byte moves:
+        # profiles/r05_dp_rehearsal_probe.txt) -- now 3 for the U-Net: 86 MB (the decoder and the deep levels: complete when 55 % of
+        # the variables have arrived), 35 MB, and a last bucket that is cut where no more than `tail_bytes` of filters remain, so
+        # that what cannot overlap backward (it completes with the very last gradient) stays small: 2.2 MB + gamma / beta.
+        gbuf = store.gbuf
+        n_noreg = store.grad["noreg"].numel()
+        assert store.grad["noreg"].data_ptr() == gbuf.data_ptr() and store.grad["reg"].data_ptr() == gbuf.data_ptr() + 4 * n_noreg
         names = list(reversed(store.trainable_names()))
-        hi = {g: store.grad[g].numel() for g in ("reg", "noreg")}
-        cur = {"reg": [], "noreg": []}
+        hi = store.grad["reg"].numel()
+        cur, noreg = [], []
 
-        def close(grp, final):
-            if not cur[grp]:
+        def close(final):
+            nonlocal hi, cur
+            members = cur + (noreg if final else [])
+            if not members:
                 return
-            lo = 0 if final else store.where[cur[grp][-1]][1]
-            assert all(store.where[a][1] > store.where[b][1] for a, b in zip(cur[grp], cur[grp][1:])), "offsets follow the specs"
-            for m in cur[grp]:
+            lo = 0 if final else store.where[cur[-1]][1]
+            assert all(store.where[a][1] > store.where[b][1] for a, b in zip(cur, cur[1:])), "offsets follow the specs"
+            for m in members:
                 self._bucket_of[m] = len(self.buckets)
-            self.buckets.append((grp, lo, hi[grp], len(cur[grp])))
-            hi[grp], cur[grp] = lo, []
+            self.buckets.append((0 if final else n_noreg + lo, n_noreg + hi, len(members)))
+            hi, cur = lo, []
 
         for k, name in enumerate(names):
             grp, off = store.where[name][0], store.where[name][1]
-            cur[grp].append(name)
+            (cur if grp == "reg" else noreg).append(name)
             final = k == len(names) - 1
-            if final or (grp == "reg" and (hi["reg"] - off) * 4 >= bucket_bytes):
-                close("reg", final)
-                close("noreg", final)
+            if final or (grp == "reg" and ((hi - off) * 4 >= bucket_bytes or (off * 4 <= tail_bytes < hi * 4))):
+                close(final)
         self._sink_keys = []
         self.history, self.last = [], None
         for name in store.trainable_names():
@@ -129,6 +139,8 @@ class GradBuckets(object):
         def hook(_param):
             # a variable arrives ONCE per step: autograd also runs the post-accumulate hook of a variable whose
             # gradient the kernels wrote in place (it sees an undefined gradient), after the op's own call
+            if _PROBE == "late":               # measurement only: nothing is launched from backward, finish() sends every bucket
+                return
             if self._armed and name not in self._arrived:
                 self._arrived.add(name)
                 self._pending[b] -= 1
@@ -146,15 +158,17 @@ class GradBuckets(object):
             self._next += 1
 
     def _launch(self, b):
-        grp, lo, hi, _ = self.buckets[b]
+        lo, hi, _ = self.buckets[b]
         self._fired[b] = True
         self._launch_pos[b] = len(self._arrived)      # how many variables had arrived when this bucket went out
         ops.side_join()                       # filter gradients queued on the side stream (ops._Side) must be in the bucket
-        self._works.append(dist.all_reduce(self.store.grad[grp][lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        if _PROBE == "nolaunch":              # measurement only (bench.py --dp-rehearsal): the hooks' cost without the collective
+            return
+        self._works.append(dist.all_reduce(self.store.gbuf[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def arm(self):
         """Call before backward of every step."""
-        self._pending = [b[3] for b in self.buckets]
+        self._pending = [b[2] for b in self.buckets]
         self._fired = [False] * len(self.buckets)
         self._launch_pos = [None] * len(self.buckets)
         self._ready = [False] * len(self.buckets)
@@ -188,7 +202,7 @@ class GradBuckets(object):
         self.last = {"buckets": len(self.buckets), "fired_in_backward": in_backward, "events": ev,
                      # per bucket: the fraction of the variables that had arrived when it was launched (None = by finish())
                      "launch_progress": [None if p is None else round(p / float(max(n_vars, 1)), 4) for p in launch_pos],
-                     "bucket_bytes": [(hi - lo) * 4 for _, lo, hi, _ in self.buckets]}
+                     "bucket_bytes": [(hi - lo) * 4 for lo, hi, _ in self.buckets]}
         self.history.append(self.last)
         if len(self.history) > 64:
             del self.history[0]

@@ -152,7 +152,7 @@ def test_bucketed_overlapped_allreduce_equals_plain_allreduce_gloo_world2():
         with tempfile.TemporaryDirectory() as d:
             mp.spawn(_bucket_worker, args=(world, _free_port(), d, overlap), nprocs=world, join=True)
             res[overlap] = [torch.load(os.path.join(d, "r{}.pt".format(i))) for i in range(world)]
-    assert res[True][0]["n_buckets"] >= 4
+    assert res[True][0]["n_buckets"] >= 3          # filter buckets; the norm parameters ride in the last one (round 5)
     assert all(all(f) for f in res[True][0]["fired"])
     for g in ("reg", "noreg", "stats"):
         assert torch.equal(res[True][0]["flat"][g], res[True][1]["flat"][g])
@@ -272,7 +272,7 @@ def test_shared_variable_and_uneven_arrival_order_under_buckets_gloo(world):
             np.testing.assert_allclose(res[True][0]["flat"][g].numpy(), res[False][0]["flat"][g].numpy(), rtol=1e-5, atol=1e-8)
     # single-use variables were written in place (5 of them), the shared one was not
     assert res[True][0]["written"] == [5, 5, 5]
-    assert res[True][0]["diag"]["buckets"] >= 5
+    assert res[True][0]["diag"]["buckets"] >= 4          # one bucket per filter variable; gamma / beta ride in the last (round 5)
     model = _SinkModel()
     st = {g: (torch.zeros_like(model.params.flat[g]), torch.zeros_like(model.params.flat[g])) for g in ("reg", "noreg")}
     from boxsegliver_amd import ops

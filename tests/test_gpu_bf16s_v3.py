@@ -45,6 +45,12 @@ SHAPES = [
     (8, 256, 128, 64, 64),     # 64 output channels (4 x 4 accumulator tiles per wave), 1024 tiles = four per block
     (14, 100, 50, 128, 64),    # ragged, 64 couts, 4 chunks
     (1, 512, 512, 64, 128),    # one image, 512 tiles
+    # round 5, the drained epilogue of the 64-channel tiles (a tile's output is converted / stored / summed inside the NEXT tile's
+    # K loop): four chunks with four tiles per block; ragged planes with up to two tiles per block (ragged tiles take the one-shot
+    # epilogue between drained ones); three tiles per block in one image
+    (8, 256, 128, 128, 64),
+    (12, 200, 72, 64, 64),
+    (3, 512, 256, 64, 64),
 ]
 
 
