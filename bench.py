@@ -222,7 +222,7 @@ def infer_main(a, args, model, inputs_of, data, gflop_unit, workload_name, rank,
         return None
 
     prof_list = [] if (rank == 0 and not a.no_kernel_events) else None
-    ev_stride = 1 if a.steps <= 4 else 4
+    ev_stride = 1 if a.steps <= 4 else max(4, -(-a.steps // 3))      # at most three traced steps (they run single-stream and carry the events: ~3 % slower)
     n_ev_steps = len(range(0, a.steps, ev_stride))
     for j in range(a.warmup):
         one_step(j)
@@ -391,9 +391,14 @@ def main():
     # UNet3D runs its filter gradients on a second stream beside the input gradients (ops.SIDE_WGRAD3D_VOXELS): kernels then
     # overlap in time and stretch each other, so their durations no longer add up to the step.  --detail (the by-layer table)
     # switches that off to attribute time to layers; `value` of a --detail run is therefore the single-stream step.
-    side3d = a.model == "UNet3D" and ops.SIDE_WGRAD3D_VOXELS > 0 and not a.detail
-    if a.model == "UNet3D" and a.detail:
-        ops.SIDE_WGRAD3D_VOXELS = 0
+    # Round 5: the fp32 2-D units do the same (ops._Side: + 1.6 % on the headline step), and every TRACED step (each fourth) runs
+    # on one stream, so the kernel tables, the roofline block and kernels_fit_step describe single-stream steps while `value`
+    # is over all steps.
+    prec_flag = {"fp32": 0, "bf16c": 1, "bf16": 2}[a.dtype]
+    side3d = (not a.detail) and ((a.model == "UNet3D" and ops.SIDE_WGRAD3D_VOXELS > 0) or
+                                 (a.model != "UNet3D" and ops.side_wgrad_on(prec_flag)))
+    if a.detail:
+        ops.side_streams_pause(True)
     params = {"args": args, "rank": rank, "device": torch.device("cuda", torch.cuda.current_device())}
     data = input_fn("train", params)
     model = {c.__name__: c for c in models.MODEL_ZOO}[a.model](args)
@@ -426,7 +431,7 @@ def main():
     # tools/probe_ext_events.hip).  A traced launch costs ~7 us more host time, hence the sampling; the events are created
     # before the timed region, sized by the launch count of the LAST warm-up step (traced for that purpose).
     prof_list = [] if (rank == 0 and not a.no_kernel_events) else None
-    ev_stride = 1 if a.steps <= 4 else 4
+    ev_stride = 1 if a.steps <= 4 else max(4, -(-a.steps // 3))      # at most three traced steps (they run single-stream and carry the events: ~3 % slower)
     n_ev_steps = len(range(0, a.steps, ev_stride))
     ops.PROFILE_SHAPES = bool(a.detail)
     launches_per_step = 4096
@@ -451,6 +456,10 @@ def main():
     for i in range(a.steps):
         if prof_list is not None:
             ops.profile_on(prof_list if i % ev_stride == 0 else None)
+            # traced steps run on ONE stream: the filter gradients otherwise run beside the input gradients on a second
+            # stream (ops._Side) and the two stretch each other -- durations that no longer add up to the step.  The other
+            # steps run as production does; `value` is over all of them.
+            ops.side_streams_pause(bool(a.detail) or i % ev_stride == 0)
         h0 = time.perf_counter()
         loss = one_step()
         host_ms.append((time.perf_counter() - h0) * 1e3)
@@ -462,6 +471,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = prof_list
     ops.profile_on(None)
+    ops.side_streams_pause(bool(a.detail))
     loss_val = float(loss.detach())
     trace_ms, trace_names = ops.profile_read() if prof is not None else ([], [])
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
@@ -534,7 +544,8 @@ def main():
             "whole_step_tflops": round(slices * gflop_unit / 1e3, 2),
             "whole_step_frac_of_fp32_peak": round(slices * gflop_unit / 1e3 / (FP32_PEAK_TFLOPS * world), 4),
             "whole_step_frac_of_dtype_peak": round(slices * gflop_unit / 1e3 / (peak * world), 4),
-            "side_stream_filter_gradients": bool(side3d),      # True: kernels overlap, per-kernel times do not add up to the step
+            "side_stream_filter_gradients": bool(side3d),      # True: on the untraced steps filter gradients run beside input gradients
+            "traced_steps_single_stream": True,
         }
         if dp_diag is not None:
             dp_diag["dp_efficiency_vs_compute_only"] = round(dp_diag["compute_only_ms_per_step"] / ms, 4)
@@ -601,7 +612,8 @@ def main():
             sum_tables = sum(k["total_ms_per_step"] for k in kern) + sum(k["total_ms_per_step"] for k in out["hbm_kernels"]
                                                                          if k["kernel"] not in agg)
             out["sum_kernels_plus_hbm_kernels_ms"] = round(sum_tables, 3)
-            out["kernels_fit_step"] = bool(sum_tables <= ms and total_kernel_ms <= out["step_ms_event_steps"]) if not side3d else None
+            # against the traced steps' own duration (they run on one stream; the untraced ones may overlap kernels and be shorter)
+            out["kernels_fit_step"] = bool(sum_tables <= out["step_ms_event_steps"] and total_kernel_ms <= out["step_ms_event_steps"])
             top = next(r for r in trace if "achieved_tflops" in r)         # the matrix kernel with the most time in the step
             kpeak = BF16_PEAK_TFLOPS if "bf16" in top["name"] else FP32_PEAK_TFLOPS
             out["roofline"] = {"bound": "mfma", "kernel": top["name"], "achieved": top["achieved_tflops"],

@@ -167,6 +167,19 @@ struct ConvParams {
   float* sk_slab;
   size_t sk_slab_bytes;
   int sk_tiles, sk_nc, sk_maxp, sk_whole;
+  // grouped taps (conv_igemm_lin.hip GRP, plain variant; round 5): a STRIDED conv on small output planes as a stride-1
+  // contraction over a space-to-depth copy of its input (conv3d.hip s2d_kernel: x[2a + p] -> xs[a][class p], the parity
+  // classes side by side on the channel axis).  Output o reads input 2 o + k (SAME padding of an even extent: 0 before, 1
+  // after): class k & 1 at offset k >> 1.  The K sequence is ng groups x Cin / 16 chunks; group g = one (depth tap, in-plane
+  // class): its 16-channel chunks start at channel g_chan[g] of an xs pixel, are read from the plane shifted by g_dz[g], and
+  // are contracted with g_ntaps[g] <= 4 taps -- halo offset g_off (4 x row + column, 0..2 each, in the padded plane) and
+  // filter panel g_panel (0..26 in wp).  Exactly the layer's kd x 9 tap-products; every MFMA row is an output pixel.
+  int ng;
+  int g_chan[12], g_dz[12], g_ntaps[12], g_off[12][4], g_panel[12][4];
+  // four-class input gradient with depth STRIDE 2 (the (2,2,2) layer; conv_igemm_lin.hip FUSED): both depth parities of dx in
+  // one launch -- the second half of the pixel tiles writes the planes at p.y + dpar_yoff
+  int dpar;
+  int64_t dpar_yoff;
 };
 bool unetk_conv_lin_gen_ok(int H, int W, int Cin, int Cout);
 int unetk_conv_run_lin_gen(ConvParams p, hipStream_t st);

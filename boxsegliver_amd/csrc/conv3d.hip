@@ -14,6 +14,8 @@
 //     parity-plane variant was measured and dropped: it stages the same bytes, which is what bounds that kernel).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 struct Geo3 {
@@ -111,6 +113,28 @@ __global__ __launch_bounds__(256) void dilate2_kernel(const float* __restrict__ 
   }
 }
 
+// space-to-depth (round 5): xs[po][ho][wo][cls * C + c] = x[po * sd + cd][2 ho + ph][2 wo + pw][c], cls = (cd * 2 + ph) * 2 + pw
+// (cd only with depth stride 2): the parity classes of a strided conv's input side by side on the channel axis, so that the
+// conv is a stride-1 contraction over xs with tap subsets (conv_igemm_lin.hip GRP)
+__global__ __launch_bounds__(256) void s2d_kernel(const float* __restrict__ x, int xs_in, float* __restrict__ out, int64_t npix_out,
+                                                  int Do, int D, int H, int W, int Ho, int Wo, int C, int sd) {
+  const int cq_n = C >> 2, ncls = sd == 2 ? 8 : 4;
+  const int64_t total = npix_out * ncls * cq_n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % cq_n);
+    int64_t r = i / cq_n;
+    const int cls = (int)(r % ncls); r /= ncls;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho); r /= Ho;
+    const int po = (int)(r % Do);
+    const int64_t n = r / Do;
+    const int cd = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
+    const int64_t plane = n * D + (int64_t)po * sd + cd;
+    const float4 v = ldg4(x + ((plane * H + 2 * ho + ph) * W + 2 * wo + pw) * xs_in + cq * 4);
+    stg4(out + ((((n * Do + po) * Ho + ho) * Wo + wo) * ncls + cls) * (int64_t)C + cq * 4, v);
+  }
+}
+
 inline ImgAddr planes(int HW_floats, int group, int step, int planes_total) {
   ImgAddr a;
   a.img_stride = (int64_t)step * HW_floats;
@@ -120,6 +144,20 @@ inline ImgAddr planes(int HW_floats, int group, int step, int planes_total) {
 }
 
 const int SUB_BPS = 64;   // subsample blocks per sample
+
+// A strided conv whose OUTPUT planes are small (W < 32: the linear-pixel kernel's range) and whose input extents are even
+// (SAME padding then puts the one pad row / column / plane behind the data): forward = space-to-depth + grouped taps.
+// UNETK_S2LIN=0 (measurement): the tiled stride-2 kernel as before.
+bool s2lin_ok(const unetk_conv3d_desc* d, const Geo3& g) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("UNETK_S2LIN"); on = e ? atoi(e) : 1; }
+  if (!on || d->shw != 2 || (d->H & 1) || (d->W & 1) || d->Cin % 16 != 0) return false;
+  if (d->sd == 2 && ((d->D & 1) || d->kd != 3)) return false;
+  return unetk_conv_lin_ok(d->N * g.Do, g.Ho, g.Wo, d->Cin, d->Cout, g.Do);
+}
+inline size_t s2lin_xs_floats(const unetk_conv3d_desc* d, const Geo3& g) {
+  return ((size_t)d->N * g.Do * g.Ho * g.Wo * (d->sd == 2 ? 8 : 4) * d->Cin + 63) & ~(size_t)63;
+}
 
 }  // namespace
 
@@ -147,6 +185,7 @@ extern "C" int unetk_conv3d_stat_rows(const unetk_conv3d_desc* d) {
   if (!desc_ok(d)) return UNETK_E_BADARG;
   const Geo3 g = geo3(d);
   if (d->shw == 2) {
+    if (s2lin_ok(d, g)) return unetk_conv_stat_rows_lin(d->N * g.Do, g.Ho, g.Wo, g.Do, d->Cout);
     if (unetk_conv_stride2_ok(d->Cin, d->Cout)) return unetk_conv_stat_rows(d->N * g.Do, g.Ho, g.Wo, d->Cin, d->Cout, g.Do, 2);
     return d->N * SUB_BPS;
   }
@@ -168,6 +207,11 @@ extern "C" size_t unetk_conv3d_ws_bytes(const unetk_conv3d_desc* d) {
     size_t sb = unetk_wgrad_strided_ws_bytes(d->N * g.Do, g.Ho, g.Wo, d->Cin, d->Cout);
     if (sb > bytes) bytes = sb;
     sb = unetk_wgrad_strided_ws_bytes(d->N * g.Do, g.Ho, g.Wo, d->Cin, d->Cout, d->kd);
+    if (sb > bytes) bytes = sb;
+  }
+  if (s2lin_ok(d, g)) {              // space-to-depth copy of x + the stream-K slab of the grouped-tap forward
+    const size_t sb = s2lin_xs_floats(d, g) * sizeof(float) +
+                      unetk_conv_lin_sk_bytes(d->N * g.Do, g.Ho, g.Wo, d->Cin, d->Cout, g.Do, d->kd * 4);
     if (sb > bytes) bytes = sb;
   }
   if (d->shw == 1 && d->sd == 1) {   // stream-K slabs of the small-plane kernel, forward and input gradient
@@ -210,6 +254,46 @@ extern "C" int unetk_conv3d_fwd(const unetk_conv3d_desc* d, const float* x, cons
     p.kd = 3; p.dshift0 = -g.pb_d; p.dstep = 1;
     if (ws && unetk_aligned16(ws)) { p.sk_slab = (float*)ws; p.sk_slab_bytes = ws_bytes; }
     return unetk_conv_run(p, st);
+  }
+  if (s2lin_ok(d, g) && ws && unetk_aligned16(ws) && ws_bytes >= unetk_conv3d_ws_bytes(d)) {
+    // small OUTPUT planes (UNet3D's 24^2 / 12^2 / 6^2 levels behind a stride-2 layer): space-to-depth copy of x, then ONE
+    // launch of the linear-pixel kernel over kd x 4 tap groups (K = kd x 9 x Cin, every MFMA row an output pixel, stream-K)
+    float* XS = (float*)ws;
+    const int ncls = d->sd == 2 ? 8 : 4;
+    const int64_t npix_out = (int64_t)d->N * g.Do * g.Ho * g.Wo;
+    int64_t grid = (npix_out * ncls * (d->Cin / 4) + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    UNETK_LAUNCH(s2d_kernel, dim3((int)grid), dim3(256), 0, st, x, d->x_stride, XS, npix_out, g.Do, d->D, d->H, d->W, g.Ho, g.Wo,
+                 d->Cin, d->sd);
+    UNETK_LAUNCH_CHECK();
+    ConvParams p{};
+    p.x = XS; p.wp = wp; p.y = y; p.stat = stat_partials;
+    p.N = d->N * g.Do; p.H = g.Ho; p.W = g.Wo; p.Cin = d->Cin; p.Cout = d->Cout;
+    p.xs = ncls * d->Cin; p.ys = d->y_stride;
+    p.xa = planes(g.Ho * g.Wo * ncls * d->Cin, g.Do, 1, g.Do);
+    p.ya = planes(g.Ho * g.Wo * d->y_stride, g.Do, 1, g.Do);
+    p.spg = g.Do;
+    int ng = 0;
+    for (int kd_ = 0; kd_ < d->kd; ++kd_) {
+      const int cd = d->sd == 2 ? (kd_ & 1) : 0;
+      const int dz = d->sd == 2 ? (kd_ >> 1) : kd_ - g.pb_d;      // depth stride 1: input plane = do + kd - pb
+      for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw, ++ng) {
+          p.g_chan[ng] = ((cd * 2 + ph) * 2 + pw) * d->Cin;
+          p.g_dz[ng] = dz;
+          int nt = 0;
+          for (int kh = ph; kh < 3; kh += 2)
+            for (int kw = pw; kw < 3; kw += 2, ++nt) {
+              p.g_off[ng][nt] = 4 * ((kh >> 1) + 1) + ((kw >> 1) + 1);      // output o reads class k & 1 at o + (k >> 1)
+              p.g_panel[ng][nt] = kd_ * 9 + kh * 3 + kw;
+            }
+          p.g_ntaps[ng] = nt;
+        }
+    }
+    p.ng = ng;
+    const size_t xsb = s2lin_xs_floats(d, g) * sizeof(float);
+    p.sk_slab = (float*)((char*)ws + xsb); p.sk_slab_bytes = ws_bytes - xsb;
+    return unetk_conv_run_lin(p, st);
   }
   if (native && d->kd == 3) {
     // natively strided (3,3,3) conv (UNet3D's (1,2,2) and (2,2,2) down-sampling layers): the three depth taps are contracted
@@ -318,6 +402,36 @@ extern "C" int unetk_conv3d_dgrad(const unetk_conv3d_desc* d, const float* dy, c
     // depth stride 1 with three depth taps (UNet3D's (1,2,2) layers): every dx plane receives all three taps, so they are
     // contracted in ONE launch (K = 3 x taps x Cout) -- no memset, no accumulation passes
     const bool fuse_d = d->kd == 3 && d->sd == 1 && d->Cin % 32 == 0;
+    // depth stride 2 (the (2,2,2) bridge; round 5): dx plane di = 2 do + dt (pad-before 0 for an even depth), so the EVEN dx
+    // planes receive the taps dt = 0 (do = di / 2) and dt = 2 (do = di / 2 - 1), the ODD ones dt = 1 alone -- two launches that
+    // each write their planes once (fused taps; no memset, no read-modify-write of dx: three accumulating launches before)
+    static int s2d_on = -1;
+    if (s2d_on < 0) { const char* e = getenv("UNETK_S2LIN"); s2d_on = e ? atoi(e) : 1; }
+    if (s2d_on && d->kd == 3 && d->sd == 2 && (d->D & 1) == 0 && g.pb_d == 0 && d->Cin % 32 == 0) {
+      ConvParams p{};
+      p.x = dy; p.wp = wp_dgrad; p.y = dx;
+      p.N = d->N * g.Do; p.H = g.Ho; p.W = g.Wo; p.Cin = d->Cout; p.Cout = d->Cin;
+      p.xs = d->y_stride; p.ys = d->x_stride;
+      p.xa = planes(HWy, g.Do, 1, g.Do);
+      p.ya = planes(HWx, g.Do, 2, d->D);
+      p.spg = g.Do;
+      p.dshift0 = 0; p.dstep = -1;           // even planes: dy plane do = di / 2 - dt' for the fused taps dt' = 0, 1 (dt = 0, 2)
+      p.dpar = 1; p.dpar_yoff = HWx;          // odd planes: one plane further
+      p.os = 2; p.Hd = d->H; p.Wd = d->W;
+      for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+          const int q = ph * 2 + pw;
+          p.ooh[q] = ph - pbh;
+          p.oow[q] = pw - pbw;
+          for (int kh = ph; kh < 3; kh += 2)
+            for (int kw = pw; kw < 3; kw += 2) {
+              p.tap_off[q][p.ntaps[q]] = 4 * ((ph - kh) / 2 + 1) + ((pw - kw) / 2 + 1);
+              p.tap_panel[q][p.ntaps[q]] = 8 - (kh * 3 + kw);
+              ++p.ntaps[q];
+            }
+        }
+      return unetk_conv_run_lin_gen(p, st);
+    }
     const bool multi = !fuse_d && (d->kd > 1 || d->sd > 1);
     if (multi) {
       hipError_t e = hipMemsetAsync(dx, 0, (size_t)d->N * d->D * HWx * sizeof(float), st);

@@ -50,8 +50,13 @@ __device__ __forceinline__ int sk_block_of(int64_t pos, int64_t tot, int G) {   
 // ACC: the plain variant's epilogue accumulates (y += acc, one depth tap of an unfused 3-D conv).  Its own instantiation:
 // the row pointers and old values it keeps in flight cost 60+ registers (the 128 x 128 stream-K variant ran at ONE wave
 // per SIMD with them: 210 + 64 registers).
-template <int WM, int WN, int TM, int TN, bool GEN = false, bool FUSED = false, bool SK = false, bool ACC = false>
+// GRP (plain variant, with or without SK; round 5): GROUPED TAPS -- the K sequence is p.ng groups x Cin / 16 chunks, every group
+// with its own channel offset inside an input pixel, plane shift and list of <= 4 taps (ConvParams::ng ...): a strided conv
+// on small output planes runs as a stride-1 contraction over a space-to-depth copy of its input (conv3d.hip).  UNet3D's
+// (2,2,2) bridge (6 x 6 output planes) took the TILED stride-2 kernel at 28 % tile fill: 0.31 ms = 25 TFLOP/s.
+template <int WM, int WN, int TM, int TN, bool GEN = false, bool FUSED = false, bool SK = false, bool ACC = false, bool GRP = false>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))) void conv3x3_igemm_lin_kernel(ConvParams p) {
+  static_assert(!(GRP && (GEN || ACC)), "grouped taps are a flag of the plain variant");
   static_assert(!(ACC && (GEN || SK)), "ACC is a flag of the plain variant (the GEN variants test p.accumulate)");
   static_assert(GEN || !FUSED, "FUSED is a GEN variant");
   static_assert(!(SK && GEN), "stream-K is for the plain variant");
@@ -99,7 +104,12 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
   const int ntile = bid % p.n_ntiles;
   const int mtile_all = bid / p.n_ntiles;
   const int q = (GEN && !FUSED) ? (mtile_all & 3) : 0;          // parity class; its 4 blocks of a tile are neighbours (L2)
-  const int mtile = (GEN && !FUSED) ? (mtile_all >> 2) : mtile_all;
+  // FUSED with p.dpar (depth stride 2, both depth parities of dx in ONE launch: twice the blocks for a layer whose 6 x 6 dy planes
+  // give 108): pixel tiles [0, stat_rows) write the even dx planes from two fused depth taps (panels 0 and 2), tiles
+  // [stat_rows, 2 stat_rows) the odd planes from the tap 1 alone
+  const int dpar = (FUSED && p.dpar && mtile_all >= p.stat_rows) ? 1 : 0;
+  const int mtile = (GEN && !FUSED) ? (mtile_all >> 2) : mtile_all - dpar * p.stat_rows;
+  float* const ybase = p.y + (dpar ? p.dpar_yoff : 0);
   const int n0 = ntile * BN;
 
   const int HW = p.H * p.W, WP = p.W + 2, HP = p.H + 2;
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
     hlds[r] = slot < npix ? slot * PS + q * 4 : -1;
     hdep[r] = plane % p.spg;
   }
-  const int KD = ((!GEN || FUSED) && p.kd > 1) ? p.kd : 1;   // fused depth taps: plain variant and the four-class GEN variant
+  const int KD = GRP ? 1 : ((FUSED && p.dpar) ? (dpar ? 1 : 2) : (((!GEN || FUSED) && p.kd > 1) ? p.kd : 1));   // fused depth taps
   const int cin4 = p.Cin >> 2;
   int64_t woff[WR];
 #pragma unroll
@@ -144,12 +154,12 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
   const int nchunks = p.Cin / CK;
   // chunk index cc runs over (depth tap, 16-channel chunk); one depth tap = a plane shift inside the sample
   auto load_halo = [&](int cc) {
-    const int dt = KD > 1 ? cc / nchunks : 0, c = cc - dt * nchunks;
-    const int shift = KD > 1 ? p.dshift0 + dt * p.dstep : 0;
-    const int64_t soff = (int64_t)shift * p.xa.img_stride + c * CK;
+    const int dt = (GRP || KD > 1) ? cc / nchunks : 0, c = cc - dt * nchunks;      // GRP: dt = the group
+    const int shift = GRP ? p.g_dz[dt] : (KD > 1 ? p.dshift0 + dt * p.dstep : 0);
+    const int64_t soff = (int64_t)shift * p.xa.img_stride + c * CK + (GRP ? p.g_chan[dt] : 0);
 #pragma unroll
     for (int r = 0; r < HR; ++r) {
-      const bool ok = hok[r] && (KD == 1 || (hdep[r] + shift >= 0 && hdep[r] + shift < p.spg));
+      const bool ok = hok[r] && ((!GRP && KD == 1) || (hdep[r] + shift >= 0 && hdep[r] + shift < p.spg));
       hreg[r] = ok ? ldg4(p.x + hoff[r] + soff) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
@@ -158,9 +168,10 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
     for (int r = 0; r < HR; ++r)
       if (hlds[r] >= 0) *reinterpret_cast<float4*>(&halo[buf * HALO_F + hlds[r]]) = hreg[r];
   };
-  auto load_w = [&](int cc, int t) {
-    const int dt = KD > 1 ? cc / nchunks : 0, c = cc - dt * nchunks;
-    const float* base = p.wp + ((int64_t)(dt * 9 + t) * cin4 + c * (CK / 4)) * p.Cout * 4;
+  auto load_w = [&](int cc, int t) {      // GRP: t = the tap's position in its group's list
+    const int dt = (GRP || KD > 1) ? cc / nchunks : 0, c = cc - dt * nchunks;
+    const int panel = GRP ? p.g_panel[dt][t] : ((FUSED && p.dpar) ? (dpar ? 9 + t : dt * 18 + t) : dt * 9 + t);
+    const float* base = p.wp + ((int64_t)panel * cin4 + c * (CK / 4)) * p.Cout * 4;
 #pragma unroll
     for (int r = 0; r < WR; ++r)
       if (tid + r * NT < WF4) wreg[r] = ldg4(base + woff[r]);
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
 #pragma unroll
         for (int r = 0; r < 16; ++r) accq[qq][tm][tn][r] = 0.f;
 
-  const int nchunks_all = KD * nchunks;
+  const int nchunks_all = (GRP ? p.ng : KD) * nchunks;
   const int c_hi = SK ? min(nchunks_all, c_lo + (int)(sk_s1 - sk_s)) : nchunks_all;
   load_halo(c_lo);
   load_w(c_lo, GEN ? p.tap_panel[q][0] : 0);
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
             }
             const int hi = p.os * aa + p.ooh[qq], wi = p.os * bb + p.oow[qq];
             const bool ok = pb + delta < P1 && hi >= 0 && hi < p.Hd && wi >= 0 && wi < p.Wd;
-            rowp[r4] = ok ? p.y + img + ((int64_t)hi * p.Wd + wi) * p.ys + n0 + wn * TN * 32 + l31 : nullptr;
+            rowp[r4] = ok ? ybase + img + ((int64_t)hi * p.Wd + wi) * p.ys + n0 + wn * TN * 32 + l31 : nullptr;
           }
           float prior[4][TN];
 #pragma unroll
@@ -367,6 +378,41 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
   }
 
   int step = 0;
+  if constexpr (GRP) {
+    for (int c = c_lo; c < c_hi; ++c) {
+      const float* hb = halo + ((c - c_lo) & 1) * HALO_F;
+      const bool more_chunks = (c + 1 < c_hi);
+      const int g = c / nchunks, nt = p.g_ntaps[g];
+      for (int ti = 0; ti < nt; ++ti, ++step) {
+        const bool last = ti == nt - 1;
+        const bool has_next = !last || more_chunks;
+        if (has_next) load_w(last ? c + 1 : c, last ? 0 : ti + 1);
+        if (last && more_chunks) load_halo(c + 1);
+        const float* wb = wbuf + (step & 1) * WB_F;
+        const int toff = ((p.g_off[g][ti] >> 2) * WP + (p.g_off[g][ti] & 3)) * PS;
+#pragma unroll
+        for (int gg = 0; gg < CK / 8; ++gg) {
+          float4 a[TM], b[TN];
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const float4*>(&hb[abase[tm] + toff + 8 * gg]);
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const float4*>(&wb[bbase + (2 * gg * BN + tn * 32) * 4]);
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].z, b[tn].z, acc[tm][tn], 0, 0, 0);
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].w, b[tn].w, acc[tm][tn], 0, 0, 0);
+            }
+        }
+        if (has_next) store_w((step + 1) & 1);
+        if (last && more_chunks) store_halo((c + 1 - c_lo) & 1);
+        __syncthreads();
+      }
+    }
+  } else
   for (int c = c_lo; c < c_hi; ++c) {
     const float* hb = halo + ((c - c_lo) & 1) * HALO_F;
     const bool more_chunks = (c + 1 < c_hi);
@@ -574,15 +620,15 @@ __global__ __launch_bounds__(256) void lin_sk_fixup_kernel(ConvParams p, int G) 
   }
 }
 
-template <int WM, int WN, int TM, int TN, bool GEN = false, bool FUSED = false, bool ACC = false>
+template <int WM, int WN, int TM, int TN, bool GEN = false, bool FUSED = false, bool ACC = false, bool GRP = false>
 int launch_lin(const ConvParams& p, int n_mtiles, hipStream_t st) {
-  if constexpr (!GEN && !ACC) {
+  if constexpr (!GEN && !ACC && !GRP) {
     if (p.accumulate) return launch_lin<WM, WN, TM, TN, false, false, true>(p, n_mtiles, st);
   }
   constexpr int BN = WN * TN * 32;
   constexpr size_t lds_max = (size_t)(2 * LIN_MAXPIX * PS + 2 * CK * BN) * sizeof(float);
   const size_t lds = (size_t)(2 * p.lin_pix * PS + 2 * CK * BN) * sizeof(float);
-  auto kern = conv3x3_igemm_lin_kernel<WM, WN, TM, TN, GEN, FUSED, false, ACC>;
+  auto kern = conv3x3_igemm_lin_kernel<WM, WN, TM, TN, GEN, FUSED, false, ACC, GRP>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
@@ -682,19 +728,19 @@ int unetk_conv_run_lin_gen(ConvParams p, hipStream_t st) {
     p.stat_rows = n_mt;
     p.lin_pix = lin_rows_bound(p.H, p.W, bm) * (p.W + 2);
     if (p.Cout % 128 == 0) {
-      if ((int64_t)n_mt * (p.Cout / 128) < 128) {   // UNet3D's (2,2,2) layer: 6 x 6 dy planes = 27 pixel tiles -- 64 x 64 tiles
+      if ((int64_t)n_mt * (p.dpar ? 2 : 1) * (p.Cout / 128) < 128) {   // UNet3D's (2,2,2) layer: 6 x 6 dy planes = 27 pixel tiles -- 64 x 64 tiles
         p.n_ntiles = p.Cout / 64;                   // double the blocks (54 -> 108 per depth tap: 0.49 -> 0.42 ms; the short
-        return launch_lin<2, 2, 1, 1, true, true>(p, n_mt, st);   // steps of such tiles are latency-bound, not MFMA-bound)
+        return launch_lin<2, 2, 1, 1, true, true>(p, n_mt * (p.dpar ? 2 : 1), st);   // steps of such tiles are latency-bound, not MFMA-bound)
       }
       p.n_ntiles = p.Cout / 128;
-      return launch_lin<2, 2, 1, 2, true, true>(p, n_mt, st);
+      return launch_lin<2, 2, 1, 2, true, true>(p, n_mt * (p.dpar ? 2 : 1), st);
     }
     if (p.Cout % 64 == 0) {
       p.n_ntiles = p.Cout / 64;
-      return launch_lin<4, 1, 1, 2, true, true>(p, n_mt, st);
+      return launch_lin<4, 1, 1, 2, true, true>(p, n_mt * (p.dpar ? 2 : 1), st);
     }
     p.n_ntiles = p.Cout / 32;                                     // UNet3D conv_e1/conv1: dx has 32 channels
-    return launch_lin<4, 1, 1, 1, true, true>(p, n_mt, st);
+    return launch_lin<4, 1, 1, 1, true, true>(p, n_mt * (p.dpar ? 2 : 1), st);
   }
   if (p.Cout % 64 != 0 || p.kd > 1) return UNETK_E_UNSUPPORTED;   // fused depth taps exist in the four-class variant only
   if (lin_rows_bound(p.H, p.W) * (p.W + 2) > LIN_MAXPIX) return UNETK_E_UNSUPPORTED;
@@ -751,12 +797,12 @@ SkPlan sk_plan(int N, int H, int W, int Cin, int Cout, int spg, int kd) {
   return s;
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool GRP = false>
 int launch_lin_sk(const ConvParams& p, const SkPlan& sk, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr size_t lds_max = (size_t)(2 * LIN_MAXPIX * PS + 2 * CK * BN) * sizeof(float);
   const size_t lds = (size_t)(2 * p.lin_pix * PS + 2 * CK * BN) * sizeof(float);
-  auto kern = conv3x3_igemm_lin_kernel<WM, WN, TM, TN, false, false, true>;
+  auto kern = conv3x3_igemm_lin_kernel<WM, WN, TM, TN, false, false, true, false, GRP>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
@@ -785,6 +831,32 @@ int unetk_conv_run_lin(ConvParams p, hipStream_t st) {
   p.tiles_h = p.tiles_w = 0;
   p.lin_pix = lin_rows_bound(p.H, p.W, bm) * (p.W + 2);
   if (p.xs % 4 != 0) return UNETK_E_BADARG;
+  if (p.ng > 0) {      // grouped taps (a strided conv over its space-to-depth input, conv3d.hip): K sequence = ng x Cin / 16 chunks
+    if (p.ng > 12 || p.accumulate || p.kd > 1 || p.asc != nullptr) return UNETK_E_UNSUPPORTED;
+    for (int g = 0; g < p.ng; ++g)
+      if (p.g_ntaps[g] < 1 || p.g_ntaps[g] > 4) return UNETK_E_BADARG;
+    if (p.sk_slab != nullptr && p.ys % 4 == 0) {
+      const SkPlan sk = sk_plan(p.N, p.H, p.W, p.Cin, p.Cout, p.spg, p.ng);
+      if (sk.on && p.sk_slab_bytes >= sk.bytes && unetk_aligned16(p.sk_slab)) {
+        p.sk_tiles = sk.tiles; p.sk_nc = sk.nc; p.sk_maxp = sk.maxp; p.sk_whole = sk.whole;
+        p.n_ntiles = p.Cout / sk.bn;
+        if (bm == 64) return launch_lin_sk<2, 2, 1, 2, true>(p, sk, st);
+        if (p.Cout % 128 == 0) return launch_lin_sk<2, 2, 2, 2, true>(p, sk, st);
+        return launch_lin_sk<4, 1, 1, 2, true>(p, sk, st);
+      }
+    }
+    p.sk_slab = nullptr;
+    if (bm == 64) {
+      p.n_ntiles = p.Cout / 128;
+      return launch_lin<2, 2, 1, 2, false, false, false, true>(p, n_mtiles, st);
+    }
+    if (p.Cout % 128 == 0) {
+      p.n_ntiles = p.Cout / 128;
+      return launch_lin<2, 2, 2, 2, false, false, false, true>(p, n_mtiles, st);
+    }
+    p.n_ntiles = p.Cout / 64;
+    return launch_lin<4, 1, 1, 2, false, false, false, true>(p, n_mtiles, st);
+  }
   if (p.sk_slab != nullptr && !p.accumulate && p.ys % 4 == 0) {
     const SkPlan sk = sk_plan(p.N, p.H, p.W, p.Cin, p.Cout, p.spg, p.kd);
     if (sk.on && p.sk_slab_bytes >= sk.bytes && unetk_aligned16(p.sk_slab)) {

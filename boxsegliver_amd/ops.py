@@ -270,10 +270,29 @@ class _Side(object):
     backward, pool backward) can share the chip with it.  The main stream waits for the side stream at the end of the
     backward pass (autograd engine callback) and before a data-parallel bucket is all-reduced; dy and x are handed to the
     caching allocator as in use on the side stream (record_stream); the side stream has its own scratch buffer."""
-    enabled = os.environ.get("UNETK_SIDE_WGRAD", "0") == "1"
+    # Round 5: with the filter gradient queued BEFORE the unit's input gradient (SIDE_WGRAD_FIRST: the side stream then waits for
+    # dy only and the two kernels really share the chip) the fp32 headline step gains 1.6 % in a same-call A/B (75.40 / 75.24 ->
+    # 74.16 ms: the ~1.3 ms launches' tails fill each other), GUNet bs 8 nothing (21.44 vs 21.33-21.46), bf16 storage loses
+    # (13.33 / 13.28 -> 13.42: its kernels hold all of a CU's LDS).  Default: on for fp32 units, off for the bf16 modes;
+    # UNETK_SIDE_WGRAD=0 / 1 forces it off / on everywhere.
+    mode = os.environ.get("UNETK_SIDE_WGRAD", "auto")
+    enabled = mode != "0"
+    paused = False          # bench.py: traced steps run on one stream (per-kernel durations that add up to the step)
     stream = None
     pending = False
     ws = _Workspace()
+
+
+def side_wgrad_on(prec):
+    """Does a 2-D conv unit of precision `prec` run its filter gradient on the side stream?"""
+    if not _Side.enabled or _Side.paused:
+        return False
+    return _Side.mode == "1" or precision_of(prec) == _abi.FP32
+
+
+def side_streams_pause(paused):
+    """bench.py: pause (True) / resume (False) every use of the side stream (2-D and 3-D filter gradients)."""
+    _Side.paused = bool(paused)
 
 
 def side_join():
@@ -304,6 +323,7 @@ def _wgrad_on_side(x, dy, bf16, dilation, out):
 # 20.29 ms at one patch, 38.0 -> 37.6 at two (the bridge alone: no gain; 10 x 256 x 256: no change).  Threshold in output
 # voxels of the layer (0 = never); UNETK_SIDE_WGRAD3D overrides.
 SIDE_WGRAD3D_VOXELS = int(os.environ.get("UNETK_SIDE_WGRAD3D", str(1 << 20)))
+SIDE_WGRAD_FIRST = os.environ.get("UNETK_SIDE_WGRAD_FIRST", "1") == "1"          # the same ordering for the 2-D units (UNETK_SIDE_WGRAD=1)
 SIDE_WGRAD3D_FIRST = os.environ.get("UNETK_SIDE_WGRAD3D_FIRST", "1") == "1"      # see Conv3dNormRelu.backward (round-5 A/B)
 
 
@@ -1349,12 +1369,14 @@ class Conv3x3NormRelu(_Op):
             ctx.se_graph = None
         if ctx.desc.dropout_keep > 0 and den is not None and not ctx.needs_input_grad[11]:
             dden = None
-        on_side = _Side.enabled and not debug and sw is not None and ctx.need_dx
+        on_side = side_wgrad_on(ctx.bf16) and not debug and sw is not None and ctx.need_dx
         if not on_side:
             dw = conv3x3_wgrad(x, dy, bf16=ctx.bf16, dilation=ctx.dilation, out=sw)
+        elif SIDE_WGRAD_FIRST:      # queued behind dy only: runs beside this unit's input gradient
+            dw = _wgrad_on_side(x, dy, ctx.bf16, ctx.dilation, sw)
         dx = conv3x3_dgrad(dy, ctx.wp_d, x.shape[3], bf16=ctx.bf16, dilation=ctx.dilation,
                            producer=ctx.producer if DEBUG_CAPTURE is None else None) if ctx.need_dx else None
-        if on_side:      # behind the input gradient in issue order: the chain's next kernel is queued first
+        if on_side and not SIDE_WGRAD_FIRST:      # behind the input gradient in issue order: beside the next unit's norm backward
             dw = _wgrad_on_side(x, dy, ctx.bf16, ctx.dilation, sw)
         if DEBUG_CAPTURE is not None:
             DEBUG_CAPTURE.append(dict(x=x, y=y, dilation=ctx.dilation, z=ctx.z_dbg, gamma=ctx.gb_dbg[0], beta=ctx.gb_dbg[1], aff=aff, dz=dz, dy=dy, dw=dw,
@@ -1569,7 +1591,7 @@ class Conv3dNormRelu(_Op):
         sw, sg, sb = (None, None, None) if debug else (_take(ctx.sinks[0]), _take(ctx.sinks[1]), _take(ctx.sinks[2]))
         dy, dgamma, dbeta, _, _ = norm_relu_bwd_nd(ctx.nd, y, dz, aff, ctx.has[0], ctx.has[1], out_gamma=sg, out_beta=sb)
         voxels = dy.numel() // dy.shape[-1]
-        on_side = (not debug) and sw is not None and ctx.need_dx and 0 < voxels <= SIDE_WGRAD3D_VOXELS
+        on_side = (not debug) and sw is not None and ctx.need_dx and 0 < voxels <= SIDE_WGRAD3D_VOXELS and not _Side.paused
         if not on_side:
             dw = conv3d_wgrad(x, dy, ctx.d, out=sw)
         elif SIDE_WGRAD3D_FIRST:

@@ -13,7 +13,8 @@ def _run(dtype, side, steps):
     import test_gpu_unet as t
     from boxsegliver_amd import ops
     from boxsegliver_amd.core.solver import Solver
-    ops._Side.enabled = side
+    saved = (ops._Side.enabled, ops._Side.mode)
+    ops._Side.enabled, ops._Side.mode = side, ("1" if side else "0")      # "1": every precision (the default takes fp32 units only)
     try:
         bs, size = 4, 128
         args = t.make_args(batch_size=bs, im_height=size, im_width=size, compute_dtype=dtype, learning_rate=1e-3)
@@ -31,7 +32,7 @@ def _run(dtype, side, steps):
         torch.cuda.synchronize()
         return losses, grads, {k: v.clone() for k, v in model.params.flat.items()}
     finally:
-        ops._Side.enabled = False
+        ops._Side.enabled, ops._Side.mode = saved
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
