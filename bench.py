@@ -293,6 +293,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the oracle at bs 8 (~40 s more of CPU work)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP-event timing")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="every step on ONE stream (filter gradients otherwise run beside input gradients on a second stream): "
+                         "what the traced steps do anyway; for rocprofv3 runs whose per-kernel averages are compared with the line's")
     ap.add_argument("--detail", action="store_true", help="break the kernel table down by layer shape")
     ap.add_argument("--model", default="UNet", choices=["UNet", "GUNet", "UNet3D", "UNetInter", "LGNet", "SmallUNet", "InterUNet"],
                     help="UNet = the headline workload (BASELINE.json configs[1]); GUNet / UNet3D = configs[3] / [4] "
@@ -395,9 +398,10 @@ def main():
     # on one stream, so the kernel tables, the roofline block and kernels_fit_step describe single-stream steps while `value`
     # is over all steps.
     prec_flag = {"fp32": 0, "bf16c": 1, "bf16": 2}[a.dtype]
-    side3d = (not a.detail) and ((a.model == "UNet3D" and ops.SIDE_WGRAD3D_VOXELS > 0) or
+    one_stream = bool(a.detail or a.single_stream)
+    side3d = (not one_stream) and ((a.model == "UNet3D" and ops.SIDE_WGRAD3D_VOXELS > 0) or
                                  (a.model != "UNet3D" and ops.side_wgrad_on(prec_flag)))
-    if a.detail:
+    if one_stream:
         ops.side_streams_pause(True)
     params = {"args": args, "rank": rank, "device": torch.device("cuda", torch.cuda.current_device())}
     data = input_fn("train", params)
@@ -459,7 +463,7 @@ def main():
             # traced steps run on ONE stream: the filter gradients otherwise run beside the input gradients on a second
             # stream (ops._Side) and the two stretch each other -- durations that no longer add up to the step.  The other
             # steps run as production does; `value` is over all of them.
-            ops.side_streams_pause(bool(a.detail) or i % ev_stride == 0)
+            ops.side_streams_pause(one_stream or i % ev_stride == 0)
         h0 = time.perf_counter()
         loss = one_step()
         host_ms.append((time.perf_counter() - h0) * 1e3)
@@ -471,7 +475,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = prof_list
     ops.profile_on(None)
-    ops.side_streams_pause(bool(a.detail))
+    ops.side_streams_pause(one_stream)
     loss_val = float(loss.detach())
     trace_ms, trace_names = ops.profile_read() if prof is not None else ([], [])
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]

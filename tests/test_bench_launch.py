@@ -88,7 +88,8 @@ def test_bench_runs_the_rccl_data_parallel_path_in_a_world_of_one():
     # first layers' filters and norm parameters, complete only with the very last gradient) wait for the end of backward
     prog = dp["bucket_launch_progress"]
     assert all(p is not None for p in prog) and prog == sorted(prog)
-    assert prog[0] < 0.5 and sum(1 for p in prog if p < 1.0) >= dp["buckets"] - 2
+    # (round 5: three buckets -- 86 MB complete when 55 % of the variables have arrived, 35 MB, and a <= 4 MB tail with gamma / beta)
+    assert prog[0] < 0.6 and sum(1 for p in prog if p < 1.0) >= dp["buckets"] - 2
     assert dp["buckets_fired_in_backward"] == sum(1 for p in prog if p < 1.0)
     assert dp["allreduce_exposed_ms"] is not None and dp["allreduce_exposed_ms"] >= 0.0
     assert dp["compute_only_ms_per_step"] > 0 and 0.2 < dp["dp_efficiency_vs_compute_only"] < 1.5

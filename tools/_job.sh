@@ -1,14 +1,12 @@
 set -e
-mkdir -p gpurun_out/r5f
-timeout -k 10 900 python -m pytest tests/test_gpu_unet3d.py -x -q > gpurun_out/r5f/pytest.log 2>&1 || { tail -60 gpurun_out/r5f/pytest.log; exit 1; }
-tail -3 gpurun_out/r5f/pytest.log
-bash tools/ab_run.sh s2lin "--model UNet3D --size 96 --batch 1 --steps 8 --warmup 2" base:UNETK_S2LIN=0 base:UNETK_S2LIN=1
-ROUNDS=1 bash tools/ab_run.sh s2lin_d "--model UNet3D --size 96 --batch 1 --steps 8 --warmup 2 --detail" base:UNETK_S2LIN=0 base:UNETK_S2LIN=1
-python - <<'PY'
-import json,glob
-for f in sorted(glob.glob('gpurun_out/ab/s2lin_d/*.json')):
-    d=json.loads(open(f).read().strip().splitlines()[-1])
-    print(f, d['value'])
-    for r in d['kernels']:
-        if 's12' in r['kernel'] or 's22' in r['kernel']: print('   %-60s %.4f ms %6.1f TF' % (r['kernel'], r['avg_launch_ms'], r['achieved_tflops']))
-PY
+mkdir -p gpurun_out/r5h
+ROUNDS=3 bash tools/ab_run.sh ldw_plain "--dtype bf16 --size 512 --batch 8 --steps 20 --warmup 5 --no-kernel-events" base:UNETK_V3_LDW=0 base:UNETK_V3_LDW=1
+ROOT=$(pwd)
+cd /tmp && export TMPDIR=/tmp
+for v in 0 1; do
+  export UNETK_V3_LDW=$v
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$ROOT/gpurun_out/r5h/pmc_ldw$v" -o mfma -- \
+    python3 "$ROOT/bench.py" --dtype bf16 --size 512 --batch 8 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > "$ROOT/gpurun_out/r5h/pmc_ldw$v.log" 2>&1
+  python3 "$ROOT/tools/pmc_mfma.py" "$(find "$ROOT/gpurun_out/r5h/pmc_ldw$v" -name '*counter_collection.csv' | head -1)" "$ROOT/gpurun_out/r5h/pmc_mfma_busy_ldw$v.txt" | head -14
+  rm -rf "$ROOT/gpurun_out/r5h/pmc_ldw$v"
+done

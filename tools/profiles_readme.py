@@ -81,18 +81,39 @@ ll = json.load(open(os.path.join(ROOT, "profiles", R + "_lits_load.json")))
 rf, cb = h["roofline"], h["cpu_baseline"]
 st32 = stats_rows("bench_kernel_stats")
 
-print("""# Round 4 profiles (one MI355X, gfx950, ROCm 7.2)
+R5 = """
+## Round 5: what changed in how the line is produced, and this round's same-call A/Bs
+
+* **Filter gradients on a second stream** are now the default for the fp32 2-D units too (`ops._Side`, queued BEFORE the unit's input
+  gradient so that the two kernels really share the chip): headline 75.40 / 75.24 -> 74.16 ms in a same-call A/B; UNet3D 96^3 at one
+  patch 20.51 -> 19.97 ms from the same re-ordering; GUNet bs 8 no change; bf16 storage loses (13.28-13.33 -> 13.42 ms: kept off).
+  `bench.py` runs its TRACED steps (at most three) on one stream, so the kernel tables, `roofline` and `kernels_fit_step` describe
+  single-stream steps while `value` is over all timed steps (`side_stream_filter_gradients`, `traced_steps_single_stream`); the rocprofv3
+  runs of this set use `--single-stream` for the same reason (their per-kernel averages are compared with the line's below).
+* `r05_unet3d_s2lin_ab.txt` -- UNet3D's stride-2 layers with small output planes: space-to-depth copy + the linear-pixel kernel with
+  grouped taps (stream-K), and the (2,2,2) input gradient as one launch: 20.31 / 20.39 -> 19.91 / 19.95 ms.
+* `r05_dp_rehearsal_probe.txt` -- where the data-parallel path lost 2-2.7 % in a world of one: not in the ~100 Python hooks
+  (efficiency 0.9995 with the collectives skipped) but ~30-40 us of stream hand-over per COLLECTIVE; 8 -> 3 collectives per step.
+* `r05_probe_ilv_epilogue.txt` (+ `.patch`) -- the 64-channel bf16 kernel's tile epilogue drained inside the next tile's K loop:
+  parity-green, 13-18 % SLOWER per launch.  Not kept.
+* `r05_probe_loader_waves.txt` (+ `.patch`) -- four loader waves for the same kernel: the kernel is 9-17 % FASTER, the step 2 % SLOWER
+  (every other matrix kernel of the step runs 4 % slower behind it: clock).  Not kept.
+* `r05_probe_norm_mirror.txt` -- norm-pass traversal order probe (no gain).
+"""
+
+print("""# Round {rn} profiles (one MI355X, gfx950, ROCm 7.2)
+{r5}
 
 Written by `tools/profiles_readme.py {R}` from the files next to it.  Everything here comes from two `gpurun` calls on the final tree of
 the round: `tools/refresh_profiles.sh bench` (`{R}_bench_*.json`, `{R}_lits_load.json`, the probe outputs) and
 `tools/refresh_profiles.sh prof` (`{R}_*kernel_stats.csv`, `{R}_pmc_*`) -- the script holds the command lines.  Boxes of the pool differ
 by 3-6 % on matrix-heavy kernels.
 
-## How a kernel is timed now (the round-3 review's first item)
+## How a kernel is timed (since round 4)
 
 `bench.py` no longer brackets a C-ABI call with `hipEventRecord` pairs (such a bracket swallows the host's time whenever the stream has
 drained: `{R}_probe_ext_events.txt`, `tools/probe_ext_events.hip` -- a 1.000 ms kernel reads 4.1-4.4 ms behind a 3 ms host stall).  The
-library itself traces its launches (`csrc/prof.hip`, `unetk_prof_*`): on every fourth timed step each launch goes through
+library itself traces its launches (`csrc/prof.hip`, `unetk_prof_*`): on the traced steps ({tr_note}) each launch goes through
 `hipExtLaunchKernelGGL` with a start and a stop event BOUND TO THE DISPATCH, so a duration is the GPU's own begin -> end interval of that
 kernel -- the quantity `rocprofv3 --kernel-trace` reports -- whatever the host does around the launch:
 
@@ -101,7 +122,7 @@ kernel -- the quantity `rocprofv3 --kernel-trace` reports -- whatever the host d
 ```
 
 The line carries the cross-checks the review asked for: `step_ms_event_steps` {ev} / `step_ms_plain_steps` {pl} ms (a traced launch costs
-~7 us of host time and a few us on the GPU: traced steps are {evd:.2f} ms slower, which is why only every fourth step is traced),
+~7 us of host time and a few us on the GPU: traced steps are {evd:.2f} ms slower, which is why only a few steps are traced),
 `host_ms_per_step` {host} (the host enqueues a {pl}-ms step in {host} ms: the GPU never waits for it), `gpu_kernel_ms_per_step` {gk}
 (every kernel of the library, own GPU time, per traced step), `sum_kernels_plus_hbm_kernels_ms` {sk} and **`kernels_fit_step`: {fit}**.
 The same command without tracing (`{R}_bench_n1_noevents.json`): {hnv} slices/s.
@@ -170,8 +191,8 @@ Matrix-pipe busy share and held clock at one 96^3 patch (`{R}_pmc_mfma_busy_unet
 
 ## bf16 storage mode (BASELINE.json configs[2] shape: 512 x 512 bs 8 per GPU)
 
-`{R}_bench_bf16_512_bs8.json`: **{bv} slices/s, {bms} ms/step = {btf} TFLOP/s = {bp:.1f} % of the dense bf16 peak** (kernels unchanged
-since round 3: 613.26 on its box).  `{R}_bench_bf16_256_bs32.json`: {b256} slices/s; `{R}_bench_bf16c_512_bs8.json` (bf16 operands, fp32
+`{R}_bench_bf16_512_bs8.json`: **{bv} slices/s, {bms} ms/step = {btf} TFLOP/s = {bp:.1f} % of the dense bf16 peak** (matrix kernels unchanged
+since round 3: 613.26 on its box; round 5's two schedule probes of the 64-channel kernel are below).  `{R}_bench_bf16_256_bs32.json`: {b256} slices/s; `{R}_bench_bf16c_512_bs8.json` (bf16 operands, fp32
 storage): {bc}; GUNet bs 8 in bf16: {gbn} slices/s untraced, {gbe} traced.
 
 {bk}
@@ -218,6 +239,7 @@ per-byte Python loop (~0.3-0.5 s per slice).
 ## UNet3D 96^3 bs 1 (`{R}_bench_unet3d_kernel_stats.csv`)
 
 {t3d}""".format(
+    rn=int(R[1:]), r5=R5 if R >= "r05" else "", tr_note=("at most three of the timed steps, run on ONE stream" if R >= "r05" else "every fourth timed step"),
     R=R, ext=txt("probe_ext_events.txt"), ev=h["step_ms_event_steps"], pl=h["step_ms_plain_steps"],
     evd=h["step_ms_event_steps"] - h["step_ms_plain_steps"], host=h["host_ms_per_step"], gk=h["gpu_kernel_ms_per_step"],
     sk=h["sum_kernels_plus_hbm_kernels_ms"], fit=h["kernels_fit_step"], hnv=hn["value"], agree=agree_table(h, st32),

@@ -56,10 +56,10 @@ if [[ "$PART" == "bench" ]]; then exit 0; fi
 # rocprofv3: kernel trace + stats (own run), then the two PMC passes (own runs, kernel-trace only)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_fp32" -o fp32 -- \
-  python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/prof_fp32.log" 2>&1
+  python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --single-stream > "$OUT/prof_fp32.log" 2>&1
 echo "kernel trace fp32 done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bf16" -o bf16 -- \
-  python3 "$ROOT/bench.py" --dtype bf16 --size 512 --batch 8 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > "$OUT/prof_bf16.log" 2>&1
+  python3 "$ROOT/bench.py" --dtype bf16 --size 512 --batch 8 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events --single-stream > "$OUT/prof_bf16.log" 2>&1
 echo "kernel trace bf16 (512x512 bs 8) done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_u3d" -o u3d -- \
   python3 "$ROOT/bench.py" --model UNet3D --size 96 --batch 1 --steps 5 --warmup 2 --detail --no-cpu-baseline --no-kernel-events > "$OUT/prof_u3d.log" 2>&1
