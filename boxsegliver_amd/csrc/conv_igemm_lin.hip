@@ -647,15 +647,28 @@ constexpr int LIN_BM = 128;
 // Use the linear-pixel kernel when the tiled one would leave > 10 % of its MFMA rows empty and the padded rows a
 // 128-pixel block can touch fit the LDS budget.
 // spg = planes per statistics group (one sample of a 3-D tensor; 1 for 2-D images).
+// UNETK_LIN_2D (measurement, round 5; read once): bit 0 = 32-wide planes whose tiled grid cannot fill the chip take this kernel too
+// (the 32 x 32 level of a 2-D net at 8 slices per GPU: 512 blocks of 64 pixels x 128 couts at ~120 TFLOP/s in the tiled kernel),
+// bits 1..3 = lin_tune's bits 0..2 for 2-D planes (128-pixel blocks, stream-K over all tiles, stream-K for short K).
+static int lin_2d() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("UNETK_LIN_2D");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 bool unetk_conv_lin_ok(int N, int H, int W, int Cin, int Cout, int spg) {
-  if (Cin % CK != 0 || Cout % 64 != 0 || W >= 32 || spg < 1 || N % spg != 0) return false;
+  const int wmax = (lin_2d() & 1) && spg == 1 ? 33 : 32;
+  if (Cin % CK != 0 || Cout % 64 != 0 || W >= wmax || spg < 1 || N % spg != 0) return false;
   const int64_t gpix = (int64_t)spg * H * W;
   const int64_t lin = (gpix + LIN_BM - 1) / LIN_BM * LIN_BM;                                   // MFMA rows issued per group
   const int64_t tiled = (int64_t)spg * ((H + 7) / 8) * 8 * ((W + 15) / 16) * 16;
   // ... or when the tiled kernel's grid cannot fill the chip (the 16 x 16 bridge of a 2-D net at 8 slices per GPU: 128 or
   // 256 blocks of 64 pixels x 128 couts for 256 CUs, 47-100 TFLOP/s): this kernel has the stream-K schedule
   const int64_t tiled_blocks = (int64_t)(N / spg) * tiled / 64 * (Cout / (Cout % 128 == 0 ? 128 : 64));
-  const bool starved = Cout % 128 == 0 && tiled_blocks <= 256 && gpix % 64 == 0;
+  const bool starved = Cout % 128 == 0 && tiled_blocks <= (((lin_2d() & 1) && spg == 1) ? 512 : 256) && gpix % 64 == 0;
   if (lin * 10 > tiled * 9 && !starved) return false;
   const int rows = (LIN_BM + W - 1) / W + 1 + 2 + 2 * ((LIN_BM + H * W - 1) / (H * W));
   return rows * (W + 2) <= LIN_MAXPIX;
@@ -676,7 +689,7 @@ static int lin_tune(int spg) {
     const char* e = getenv("UNETK_LIN_TUNE");
     v = e ? atoi(e) : 7;
   }
-  return spg > 1 ? v : 0;
+  return spg > 1 ? v : (lin_2d() >> 1);
 }
 
 static int lin_bm(int N, int H, int W, int Cout, int spg) {

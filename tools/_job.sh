@@ -1,12 +1,10 @@
 set -e
-mkdir -p gpurun_out/r5h
-ROUNDS=3 bash tools/ab_run.sh ldw_plain "--dtype bf16 --size 512 --batch 8 --steps 20 --warmup 5 --no-kernel-events" base:UNETK_V3_LDW=0 base:UNETK_V3_LDW=1
-ROOT=$(pwd)
-cd /tmp && export TMPDIR=/tmp
-for v in 0 1; do
-  export UNETK_V3_LDW=$v
-  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$ROOT/gpurun_out/r5h/pmc_ldw$v" -o mfma -- \
-    python3 "$ROOT/bench.py" --dtype bf16 --size 512 --batch 8 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > "$ROOT/gpurun_out/r5h/pmc_ldw$v.log" 2>&1
-  python3 "$ROOT/tools/pmc_mfma.py" "$(find "$ROOT/gpurun_out/r5h/pmc_ldw$v" -name '*counter_collection.csv' | head -1)" "$ROOT/gpurun_out/r5h/pmc_mfma_busy_ldw$v.txt" | head -14
-  rm -rf "$ROOT/gpurun_out/r5h/pmc_ldw$v"
-done
+ROUNDS=1 bash tools/ab_run.sh lin2d_gunet2 "--model GUNet --batch 8 --steps 10 --warmup 3 --detail" base base:UNETK_LIN_2D=1 base:UNETK_LIN_2D=15 base:UNETK_LIN_2D=7 base
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/ab/lin2d_gunet2/*.json')):
+    d=json.loads(open(f).read().strip().splitlines()[-1])
+    print(f.split('/')[-1], d['value'])
+    for r in d['kernels']:
+        if '8x32x32' in r['kernel'] and ('fwd' in r['kernel'] or 'dgrad' in r['kernel']) and 'deconv' not in r['kernel'] and 'pw_' not in r['kernel']: print('   %-75s %.4f %6.1f' % (r['kernel'], r['avg_launch_ms'], r['achieved_tflops']))
+PY
