@@ -322,9 +322,13 @@ def _wgrad_on_side(x, dy, bf16, dilation, out):
 # chip); two such launches side by side share it.  Same kernels, same results bit for bit.  Measured in one call, 96^3: 20.52 ->
 # 20.29 ms at one patch, 38.0 -> 37.6 at two (the bridge alone: no gain; 10 x 256 x 256: no change).  Threshold in output
 # voxels of the layer (0 = never); UNETK_SIDE_WGRAD3D overrides.
+# Round 5 (the advisor's finding): round 4 queued the side-stream launch AFTER the input gradient, so the side stream's
+# wait_stream(main) made the filter gradient wait for that input gradient too -- it ran beside the NEXT unit's norm backward, not
+# beside "its" input gradient as the text above says.  *_FIRST (default): it is queued BEFORE the input gradient, behind dy only.
+# Same-call A/Bs: UNet3D 96^3 at one patch 20.51 -> 19.97 ms, at two 37.83 -> 36.93; the fp32 2-D headline 75.3 -> 74.2 ms.
 SIDE_WGRAD3D_VOXELS = int(os.environ.get("UNETK_SIDE_WGRAD3D", str(1 << 20)))
-SIDE_WGRAD_FIRST = os.environ.get("UNETK_SIDE_WGRAD_FIRST", "1") == "1"          # the same ordering for the 2-D units (UNETK_SIDE_WGRAD=1)
-SIDE_WGRAD3D_FIRST = os.environ.get("UNETK_SIDE_WGRAD3D_FIRST", "1") == "1"      # see Conv3dNormRelu.backward (round-5 A/B)
+SIDE_WGRAD_FIRST = os.environ.get("UNETK_SIDE_WGRAD_FIRST", "1") == "1"          # the 2-D units (see _Side)
+SIDE_WGRAD3D_FIRST = os.environ.get("UNETK_SIDE_WGRAD3D_FIRST", "1") == "1"      # the 3-D units (Conv3dNormRelu.backward)
 
 
 def _wgrad3d_on_side(x, dy, d, out):

@@ -565,3 +565,31 @@ def test_plateau_hook_is_collective_under_dp_gloo_world2():
     assert min(r[0]["lrs"]) < 1e-3                     # the mean loss did plateau: the rate was decayed at least once
     assert r[0]["stopped_at"] is not None              # ... and training stopped, on both ranks at the same step
     assert sched["best"] == pytest.approx(r[0]["state"]["best"])
+
+
+def test_bucket_layout_three_buckets_with_a_small_tail_and_norm_parameters_in_the_last():
+    """Round 5: one gradient allocation [noreg | reg]; the filter gradients are cut from the end into buckets of >= bucket_bytes, a
+    last bucket is cut where no more than tail_bytes of filters remain, and every gamma / beta rides in that last bucket -- one
+    contiguous range starting at the beginning of the allocation (utils/distribution_utils.GradBuckets)."""
+    from boxsegliver_amd.NetworksV2.base import ParamStore
+    from boxsegliver_amd.utils.distribution_utils import DistributionStrategy, GradBuckets
+    specs = []
+    for i, n in enumerate([100, 200, 3000, 5000, 7000, 4000]):            # forward order: small first layers, big deep ones
+        specs += [("L{}/weights".format(i), (n,), "conv_w"), ("L{}/gamma".format(i), (8,), "gamma"), ("L{}/beta".format(i), (8,), "beta")]
+    store = ParamStore(specs, torch.device("cpu"))
+    n_noreg = store.grad["noreg"].numel()
+    assert store.grad["noreg"].data_ptr() == store.gbuf.data_ptr()
+    assert store.grad["reg"].data_ptr() == store.gbuf.data_ptr() + 4 * n_noreg
+    b = GradBuckets(store, DistributionStrategy("one_device", 1, 0), bucket_bytes=8000 * 4, tail_bytes=400 * 4)
+    try:
+        spans = [(lo, hi) for lo, hi, _ in b.buckets]
+        # contiguous cover of the whole allocation, launch order = from the end
+        assert spans[-1][0] == 0 and spans[0][1] == store.gbuf.numel()
+        assert all(spans[i][0] == spans[i + 1][1] for i in range(len(spans) - 1))
+        # the tail: at most tail_bytes of filters + every norm parameter
+        assert spans[-1][1] - n_noreg <= 400 and spans[-1][1] - n_noreg == 300        # L0 + L1
+        assert all(b._bucket_of["L{}/{}".format(i, k)] == len(spans) - 1 for i in range(6) for k in ("gamma", "beta"))
+        assert b._bucket_of["L5/weights"] == 0 and b._bucket_of["L1/weights"] == len(spans) - 1
+        assert len(spans) == 3 and sum(n for _, _, n in b.buckets) == len(specs)
+    finally:
+        b.remove()
