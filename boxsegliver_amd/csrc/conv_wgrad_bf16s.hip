@@ -43,6 +43,7 @@ static_assert(LDS_B <= 160 * 1024, "LDS budget");
 // the fp32 kernel memsets a page of its workspace per call instead -- one more launch)
 __device__ const uint32_t kZeroPage[32] = {};
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
@@ -207,6 +208,26 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
 #define LO(v) ((uint32_t)(v))
 #define HI(v) ((uint32_t)((v) >> 32))
   // MFMAs of one halo row hr (12 pixels of this lane's channel in a0 a1 a2) against the dy row rr_: filter row kh = hr - rr_
+#ifdef UNETK_WG16_PROBE
+  // timing probe (WRONG results): every 32x32x16 MFMA replaced by TWO 16x16x32 MFMAs on the same operand registers -- the same
+  // matrix-pipe cycles, LDS traffic and register count -- to see what the MFMA shape alone does to this kernel's clock
+  f32x4 accp[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) accp[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define MF2(t_, A_, B_)                                                                                                    \
+  accp[t_][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_, B_, accp[t_][0], 0, 0, 0);                                     \
+  accp[t_][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_, B_, accp[t_][1], 0, 0, 0);
+#define ROW_MFMA(kh_, a0, a1, a2, b0, b1)                                                                                  \
+  {                                                                                                                        \
+    const bf16x8 bb = frag(LO(b0), HI(b0), LO(b1), HI(b1));                                                                \
+    MF2((kh_) * 3 + 0, frag(LO(a0), HI(a0), LO(a1), HI(a1)), bb)                                                           \
+    MF2((kh_) * 3 + 1, frag(__builtin_amdgcn_alignbit(HI(a0), LO(a0), 16), __builtin_amdgcn_alignbit(LO(a1), HI(a0), 16),  \
+                            __builtin_amdgcn_alignbit(HI(a1), LO(a1), 16), __builtin_amdgcn_alignbit(LO(a2), HI(a1), 16)), bb) \
+    MF2((kh_) * 3 + 2, frag(HI(a0), LO(a1), HI(a1), LO(a2)), bb)                                                           \
+  }
+#else
 #define ROW_MFMA(kh_, a0, a1, a2, b0, b1)                                                                                  \
   {                                                                                                                        \
     const bf16x8 bb = frag(LO(b0), HI(b0), LO(b1), HI(b1));                                                                \
@@ -217,6 +238,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
         bb, acc[(kh_) * 3 + 1], 0, 0, 0);                                                                                  \
     acc[(kh_) * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(HI(a0), LO(a1), HI(a1), LO(a2)), bb, acc[(kh_) * 3 + 2], 0, 0, 0); \
   }
+#endif
   constexpr int AROW = HWD * 128, BROW = TW * 128;     // bytes between consecutive halo rows / dy tile rows
   static_assert(IPW == 5 && NSTAGE == 4, "the wait counts below: vmcnt(IPW) = one younger tile in flight");
   uint64_t B00, B01, B10, B11, B20, B21, B30, B31;
@@ -330,6 +352,15 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16s_kernel(WgParams p) {
 #undef LO
 #undef HI
 
+#ifdef UNETK_WG16_PROBE
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][4 * j + r] += accp[t][j][r];
+#undef MF2
+#endif
   // ---- sum the two pixel-row halves through LDS (fixed order), then the ks == 0 waves write the split's slab
   float* red = reinterpret_cast<float*>(smem);  // [4 waves][144][64 lanes]
   const int pidx = wci * 2 + wco;

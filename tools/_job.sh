@@ -1,20 +1,12 @@
-mkdir -p gpurun_out/r5j
-sample() { while true; do rocm-smi --showpower --showclocks --csv 2>/dev/null | tail -n +2 | head -2 | tr '\n' ' ' >> "$1"; echo >> "$1"; sleep 0.2; done; }
-for rep in 1 2; do
-for v in 0 1; do
-  sample gpurun_out/r5j/smi_ldw${v}_$rep.csv & SP=$!
-  UNETK_LIB=$PWD/ab/ldw/libunetk.so UNETK_V3_LDW=$v timeout -k 10 300 python bench.py --dtype bf16 --size 512 --batch 8 --steps 600 --warmup 10 --no-cpu-baseline --no-kernel-events > gpurun_out/r5j/bench_ldw${v}_$rep.json 2> gpurun_out/r5j/bench_ldw${v}_$rep.err
-  kill $SP; wait $SP 2>/dev/null
-done
-done
+set -e
+bash tools/ab_run.sh wg16 "--dtype bf16 --size 512 --batch 8 --steps 10 --warmup 3 --detail" base wg16
 python - <<'PY'
-import re,statistics,json,glob
-for f in sorted(glob.glob('gpurun_out/r5j/smi_*.csv')):
-    rows=[]
-    for l in open(f):
-        m=re.findall(r'\((\d+)Mhz\)', l); p=re.findall(r',([\d.]+)\s*$', l.strip())
-        if len(m)>=3 and p: rows.append((int(m[2]), float(p[0])))
-    busy=[r for r in rows if r[1]>900]
-    d=json.loads(open(f.replace('smi_','bench_').replace('.csv','.json')).read().strip().splitlines()[-1])
-    print(f.split('/')[-1], 'ms/step %.3f' % d['ms_per_step'], 'n', len(busy), 'sclk median', statistics.median([b[0] for b in busy]), 'power median', statistics.median([b[1] for b in busy]))
+import json,glob
+for f in sorted(glob.glob('gpurun_out/ab/wg16/*_r2.json')):
+    d=json.loads(open(f).read().strip().splitlines()[-1])
+    def tot(pred): return sum(x['total_ms_per_step'] for x in d['kernels'] if pred(x['kernel']))
+    print(f.split('/')[-1], d['ms_per_step'], 'wgrad', round(tot(lambda k:'wgrad_bf16s' in k),3), '<8>', round(tot(lambda k:'kernel<8' in k),3), '<4>', round(tot(lambda k:'<4>' in k),3))
+    for r in d['kernels']:
+        if 'wgrad_bf16s' in r['kernel'] and ('64->64' in r['kernel'] or '512->512' in r['kernel'] or '128->128' in r['kernel']): print('   ', r['kernel'], r['avg_launch_ms'])
 PY
+ROUNDS=2 bash tools/ab_run.sh wg16_plain "--dtype bf16 --size 512 --batch 8 --steps 20 --warmup 5 --no-kernel-events" base wg16
