@@ -12,7 +12,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 _LIB = None
 LIB_PATH = os.environ.get("UNETK_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libunetk.so")
 
-ABI_VERSION = 8            # must equal unetk_abi_version() of the loaded library (checked in lib())
+ABI_VERSION = 9            # must equal unetk_abi_version() of the loaded library (checked in lib())
 UNETK_MAX_CLASSES = 8
 W_NONE, W_NUMERICAL, W_PROPORTION, W_PIXELMAP = 0, 1, 2, 3
 
@@ -136,6 +136,8 @@ _SIGNATURES = {
     "unetk_deconv3d_fwd": (c_int, [POINTER(Deconv3dDesc), P, P, P, P, P]),
     "unetk_deconv3d_bwd_ws_bytes": (c_size_t, [POINTER(Deconv3dDesc)]),
     "unetk_deconv3d_bwd": (c_int, [POINTER(Deconv3dDesc), P, P, P, P, P, P, P, P, c_size_t, P]),
+    "unetk_deconv3d_bwd_parts": (c_int, [POINTER(Deconv3dDesc), P, P, P, P, P, P, P, P, c_size_t, c_int, P]),
+    "unetk_deconv2x2_bwd_parts": (c_int, [POINTER(DeconvDesc), P, P, P, P, P, P, P, P, c_size_t, c_int, P]),
     "unetk_head_result_floats": (c_size_t, [POINTER(HeadDesc)]),
     "unetk_head_ws_bytes": (c_size_t, [POINTER(HeadDesc)]),
     "unetk_head_fwd": (c_int, [POINTER(HeadDesc), P, P, P, P, P, P, P, P, P, c_size_t, P]),

@@ -1104,12 +1104,22 @@ extern "C" size_t unetk_deconv3d_bwd_ws_bytes(const unetk_deconv3d_desc* d) {
 extern "C" int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const void* xv, const void* wpv,
                                   const void* catv, const void* dcatv, void* dxv, float* dw, float* dbias, void* ws,
                                   size_t ws_bytes, void* stream) {
+  return unetk_deconv3d_bwd_parts(d, xv, wpv, catv, dcatv, dxv, dw, dbias, ws, ws_bytes, 3, stream);
+}
+
+// parts: bit 0 = ReLU backward + bias gradient + input gradient (writes the masked, re-laid gradient `dpre` into ws),
+// bit 1 = filter gradient (reads dpre from the SAME ws: after a bit-0 call, on any stream ordered behind it).  The filter
+// gradient is off backward's critical chain, so the host may run it on a second stream beside the next unit's kernels
+// (ops.deconv_bwd; round 5).
+extern "C" int unetk_deconv3d_bwd_parts(const unetk_deconv3d_desc* d, const void* xv, const void* wpv,
+                                        const void* catv, const void* dcatv, void* dxv, float* dw, float* dbias, void* ws,
+                                        size_t ws_bytes, int parts, void* stream) {
   const float* x = (const float*)xv;
   const float* wp_dgrad = (const float*)wpv;
   const float* cat = (const float*)catv;
   const float* dcat = (const float*)dcatv;
   float* dx = (float*)dxv;
-  UNETK_REQUIRE(deconv_desc_ok(d) && x && wp_dgrad && cat && dcat && dx && dw && ws);
+  UNETK_REQUIRE(deconv_desc_ok(d) && x && wp_dgrad && cat && dcat && dx && dw && ws && parts >= 1 && parts <= 3);
   const bool bs = d->precision == UNETK_BF16S;
   if (bs && (d->kd != 1 || d->Cout % 64 != 0 || d->out_stride % 4 != 0)) return UNETK_E_UNSUPPORTED;
   if (d->Cin % 64 != 0 || d->Cout % 32 != 0 || d->out_stride % 4 != 0 || d->out_coff % 4 != 0)
@@ -1128,6 +1138,8 @@ extern "C" int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const void* xv, 
   off = (off + 3) & ~(size_t)3;
   float* slab = dpre + off;
 
+  int rc = UNETK_OK;
+  if (parts & 1) {
   // 1. ReLU backward over the whole up half + bias-grad partials
   const ColMap cm = unetk_colmap(d->Cout);
   if (bs)     // dpre is bf16 in the same workspace region (half of it used)
@@ -1140,14 +1152,16 @@ extern "C" int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const void* xv, 
                        (size_t)cm.rows_per_iter * d->Cout * sizeof(float), st, cat, dcat, d->out_stride, d->out_coff, dpre,
                        bpart, (int64_t)4 * d->kd * M, d->Cout, cm.cq_n, cm.rows_per_iter);
   UNETK_LAUNCH_CHECK();
-  int rc = unetk_rows_reduce(bpart, 1, pl.nblk_bias, d->Cout, dbias ? dbias : bsink, btmp, st);
+  rc = unetk_rows_reduce(bpart, 1, pl.nblk_bias, d->Cout, dbias ? dbias : bsink, btmp, st);
   if (rc != UNETK_OK) return rc;
+  }
 
   const int64_t plane = (int64_t)4 * d->H * d->W * d->Cout;            // one dpre depth plane
   ImgAddr da;
   da.group = d->D; da.img_stride = d->kd * plane; da.group_stride = (int64_t)d->kd * d->D * plane;
   for (int a = 0; a < d->kd; ++a) {
     // 2. input gradient: [M x 4Cout] . [4Cout x Cin], accumulated over depth taps
+    if (parts & 1) {
     PwParams p{};
     p.bf16 = d->precision;
     p.a = dpre + a * plane; p.wp = tap_panel(wp_dgrad, a, d); p.bias = nullptr; p.out = dx;
@@ -1155,6 +1169,8 @@ extern "C" int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const void* xv, 
     p.oa = da; p.accumulate = a > 0 ? 1 : 0;
     rc = run_pw<1>(p, st);
     if (rc != UNETK_OK) return rc;
+    }
+    if (!(parts & 2)) continue;
 
     // 3. filter gradient of this depth tap
     DwParams q{};
@@ -1217,6 +1233,14 @@ extern "C" size_t unetk_deconv2x2_bwd_ws_bytes(const unetk_deconv_desc* d) {
   if (!d) return 0;
   const unetk_deconv3d_desc e = from2d(d);
   return unetk_deconv3d_bwd_ws_bytes(&e);
+}
+
+extern "C" int unetk_deconv2x2_bwd_parts(const unetk_deconv_desc* d, const void* x, const void* wp_dgrad, const void* cat,
+                                         const void* dcat, void* dx, float* dw, float* dbias, void* ws, size_t ws_bytes,
+                                         int parts, void* stream) {
+  UNETK_REQUIRE(d && dbias);
+  const unetk_deconv3d_desc e = from2d(d);
+  return unetk_deconv3d_bwd_parts(&e, x, wp_dgrad, cat, dcat, dx, dw, dbias, ws, ws_bytes, parts, stream);
 }
 
 extern "C" int unetk_deconv2x2_bwd(const unetk_deconv_desc* d, const void* x, const void* wp_dgrad, const void* cat,

@@ -906,6 +906,39 @@ def deconv2x2_fwd(x, wp_fwd, bias, cat, coff, cout, bf16=False):
     return cat
 
 
+# Round 5: the transposed conv's filter gradient on the side stream as well.  Its backward is ReLU mask -> input gradient -> filter
+# gradient in one C call; only dx is on backward's critical chain.  unetk_deconv*_bwd_parts does the first two on the main stream
+# and the filter gradient (which reads the masked gradient the first part left in the scratch buffer) on the side stream, beside
+# the next unit's norm backward / input gradient.  The scratch buffer is then the op's own (the shared WORKSPACE is rewritten by
+# the next op on the main stream).  Needs the in-place gradient slot (otherwise autograd would add dw on the main stream at once).
+SIDE_DECONV = os.environ.get("UNETK_SIDE_DECONV", "1") == "1"
+
+
+def _deconv_bwd_call(fn_parts, fn_whole, d, nbytes, args, side_ok, x, tag, what):
+    """args = (x, wp_dgrad, cat, dcat, dx, dw, db) pointers' owners; returns nothing (dx / dw / db are filled)."""
+    xx, wp, cat, dcat, dx, dw, db = args
+    if not (side_ok and SIDE_DECONV and not _Side.paused):
+        ws = WORKSPACE.get(nbytes, xx.device)
+        check(fn_whole(ctypes.byref(d), ptr(xx), ptr(wp), ptr(cat), ptr(dcat), ptr(dx), ptr(dw), ptr(db), ptr(ws), nbytes,
+                       stream_ptr()), what)
+        return
+    ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=xx.device)
+    check(fn_parts(ctypes.byref(d), ptr(xx), ptr(wp), ptr(cat), ptr(dcat), ptr(dx), ptr(dw), ptr(db), ptr(ws), nbytes, 1,
+                   stream_ptr()), what)
+    if _Side.stream is None:
+        _Side.stream = torch.cuda.Stream(device=xx.device)
+    side = _Side.stream
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        check(fn_parts(ctypes.byref(d), ptr(xx), ptr(wp), ptr(cat), ptr(dcat), ptr(dx), ptr(dw), ptr(db), ptr(ws), nbytes, 2,
+                       stream_ptr()), what)
+    ws.record_stream(side)
+    xx.record_stream(side)
+    if not _Side.pending:
+        _Side.pending = True
+        torch.autograd.Variable._execution_engine.queue_callback(side_join)
+
+
 def deconv2x2_bwd(x, wp_dgrad, cat, dcat, coff, cout, bf16=False, out_w=None, out_b=None):
     n, h, w, cin = x.shape
     prec = precision_of(bf16)
@@ -915,15 +948,15 @@ def deconv2x2_bwd(x, wp_dgrad, cat, dcat, coff, cout, bf16=False, out_w=None, ou
     nbytes = _abi.lib().unetk_deconv2x2_bwd_ws_bytes(ctypes.byref(d))
     if nbytes == 0:
         raise _abi.UnetkError("deconv2x2_bwd: unsupported shape Cin={} Cout={}".format(cin, cout))
-    ws = WORKSPACE.get(nbytes, x.device)
     dx = torch.empty_like(x)
     dw = out_w if out_w is not None else torch.empty((2, 2, cout, cin), dtype=torch.float32, device=x.device)
     db = out_b if out_b is not None else torch.empty((cout,), dtype=torch.float32, device=x.device)
     assert tuple(dw.shape) == (2, 2, cout, cin) and dw.is_contiguous()
+    side_ok = out_w is not None and DEBUG_CAPTURE is None and side_wgrad_on(bf16)
     with _timed(lambda: "deconv2x2_bwd{}(relu_bwd+pw_gemm<dgrad>+deconv_wgrad)".format({0: "", 1: "<bf16>", 2: "<bf16s>"}[prec]),
                 16.0 * n * h * w * cin * cout, "{}x{}x{} {}->{}", (n, h, w, cin, cout)):
-        check(_abi.lib().unetk_deconv2x2_bwd(ctypes.byref(d), ptr(x), ptr(wp_dgrad), ptr(cat), ptr(dcat), ptr(dx),
-                                             ptr(dw), ptr(db), ptr(ws), nbytes, stream_ptr()), "deconv2x2_bwd")
+        _deconv_bwd_call(_abi.lib().unetk_deconv2x2_bwd_parts, _abi.lib().unetk_deconv2x2_bwd, d, nbytes,
+                         (x, wp_dgrad, cat, dcat, dx, dw, db), side_ok, x, None, "deconv2x2_bwd")
     return dx, dw, db
 
 
@@ -967,14 +1000,14 @@ def deconv3d_bwd(x, wp_dgrad, cat, dcat, coff, cout, kd, want_dbias, out_w=None)
     nbytes = _abi.lib().unetk_deconv3d_bwd_ws_bytes(ctypes.byref(d))
     if nbytes == 0:
         raise _abi.UnetkError("deconv3d_bwd: unsupported shape Cin={} Cout={}".format(cin, cout))
-    ws = WORKSPACE.get(nbytes, x.device)
     dx = torch.empty_like(x)
     dw = out_w if out_w is not None else torch.empty((kd, 2, 2, cout, cin), dtype=torch.float32, device=x.device)
     assert tuple(dw.shape) == (kd, 2, 2, cout, cin) and dw.is_contiguous()
     db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_dbias else None
+    side_ok = out_w is not None and DEBUG_CAPTURE is None and _Side.enabled and SIDE_WGRAD3D_VOXELS > 0
     with _Timed("deconv3d_bwd", 16.0 * kd * n * dd * h * w * cin * cout, "kd{} {}".format(kd, tuple(x.shape))):
-        check(_abi.lib().unetk_deconv3d_bwd(ctypes.byref(d), ptr(x), ptr(wp_dgrad), ptr(cat), ptr(dcat), ptr(dx),
-                                            ptr(dw), ptr(db), ptr(ws), nbytes, stream_ptr()), "deconv3d_bwd")
+        _deconv_bwd_call(_abi.lib().unetk_deconv3d_bwd_parts, _abi.lib().unetk_deconv3d_bwd, d, nbytes,
+                         (x, wp_dgrad, cat, dcat, dx, dw, db), side_ok, x, None, "deconv3d_bwd")
     return dx, dw, db
 
 

@@ -420,6 +420,15 @@ size_t unetk_deconv3d_bwd_ws_bytes(const unetk_deconv3d_desc* d);
 int unetk_deconv3d_bwd(const unetk_deconv3d_desc* d, const void* x, const void* wp_dgrad,
                        const void* cat, const void* dcat, void* dx, float* dw, float* dbias,
                        void* ws, size_t ws_bytes, void* stream);
+/* The same in two parts (ABI 9): parts bit 0 = ReLU backward + dbias + dx (leaves the masked, re-laid gradient in ws), bit 1 = dw
+ * (reads it from the SAME ws; any stream ordered behind the bit-0 call).  The filter gradient is off the critical chain of the
+ * backward pass (TF schedules Conv2DBackpropFilter beside the rest of the graph the same way); parts = 3 is unetk_deconv3d_bwd. */
+int unetk_deconv3d_bwd_parts(const unetk_deconv3d_desc* d, const void* x, const void* wp_dgrad,
+                             const void* cat, const void* dcat, void* dx, float* dw, float* dbias,
+                             void* ws, size_t ws_bytes, int parts, void* stream);
+int unetk_deconv2x2_bwd_parts(const unetk_deconv_desc* d, const void* x, const void* wp_dgrad,
+                              const void* cat, const void* dcat, void* dx, float* dw, float* dbias,
+                              void* ws, size_t ws_bytes, int parts, void* stream);
 
 /* ---------------------------------------------------------------- logits + loss head
  * UNet.py:97-135 + loss_metrics.py:115-231,261-339.

@@ -30,7 +30,7 @@ def test_header_symbols_all_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(_abi.EXPORTED_SYMBOLS)
-    assert lib.unetk_abi_version() == _abi.ABI_VERSION == 8
+    assert lib.unetk_abi_version() == _abi.ABI_VERSION == 9
 
 
 def test_abi_argument_validation_without_gpu():

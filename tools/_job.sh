@@ -1,12 +1,8 @@
 set -e
-bash tools/ab_run.sh wg16 "--dtype bf16 --size 512 --batch 8 --steps 10 --warmup 3 --detail" base wg16
-python - <<'PY'
-import json,glob
-for f in sorted(glob.glob('gpurun_out/ab/wg16/*_r2.json')):
-    d=json.loads(open(f).read().strip().splitlines()[-1])
-    def tot(pred): return sum(x['total_ms_per_step'] for x in d['kernels'] if pred(x['kernel']))
-    print(f.split('/')[-1], d['ms_per_step'], 'wgrad', round(tot(lambda k:'wgrad_bf16s' in k),3), '<8>', round(tot(lambda k:'kernel<8' in k),3), '<4>', round(tot(lambda k:'<4>' in k),3))
-    for r in d['kernels']:
-        if 'wgrad_bf16s' in r['kernel'] and ('64->64' in r['kernel'] or '512->512' in r['kernel'] or '128->128' in r['kernel']): print('   ', r['kernel'], r['avg_launch_ms'])
-PY
-ROUNDS=2 bash tools/ab_run.sh wg16_plain "--dtype bf16 --size 512 --batch 8 --steps 20 --warmup 5 --no-kernel-events" base wg16
+mkdir -p gpurun_out/r5k
+timeout -k 10 900 python -m pytest tests/test_gpu_side_wgrad.py tests/test_gpu_ops.py tests/test_gpu_unet3d.py tests/test_gpu_unet.py -x -q > gpurun_out/r5k/pytest.log 2>&1 || { tail -40 gpurun_out/r5k/pytest.log; exit 1; }
+tail -3 gpurun_out/r5k/pytest.log
+ROUNDS=2 bash tools/ab_run.sh sdec_u3d "--model UNet3D --size 96 --batch 1 --steps 8 --warmup 2" base:UNETK_SIDE_DECONV=0 base:UNETK_SIDE_DECONV=1
+ROUNDS=2 bash tools/ab_run.sh sdec_unet "--steps 10 --warmup 3" base:UNETK_SIDE_DECONV=0 base:UNETK_SIDE_DECONV=1
+ROUNDS=1 bash tools/ab_run.sh sdec_gunet "--model GUNet --batch 8 --steps 10 --warmup 3" base:UNETK_SIDE_DECONV=0 base:UNETK_SIDE_DECONV=1 base:UNETK_SIDE_DECONV=0 base:UNETK_SIDE_DECONV=1
+ROUNDS=1 bash tools/ab_run.sh sdec_u3d10 "--model UNet3D --depth 10 --size 256 --batch 4 --steps 8 --warmup 2" base:UNETK_SIDE_DECONV=0 base:UNETK_SIDE_DECONV=1
