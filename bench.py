@@ -506,16 +506,21 @@ def main():
         if bk is not None:
             bk.remove()
             solver._buckets = None
-        # the same share of per-launch events as the timed region had on this rank: the difference must be the all-reduce path alone
+        # EXACTLY the timed region again -- the same number of steps, the same steps traced (events, one stream) -- without the
+        # all-reduce path: the difference must be that path alone.  (Round 4 ran four steps with one traced: with three traced
+        # single-stream steps of ten in the timed region the two shares no longer matched and the ratio read 0.95.)
         one_step()
         torch.cuda.synchronize()
         tc = time.perf_counter()
-        for j in range(4):
-            ops.profile_on([] if (prof is not None and j % ev_stride == 0) else None)
+        for j in range(a.steps):
+            if prof is not None:
+                ops.profile_on([] if j % ev_stride == 0 else None)
+                ops.side_streams_pause(one_stream or j % ev_stride == 0)
             one_step()
         torch.cuda.synchronize()
-        dp_diag["compute_only_ms_per_step"] = round((time.perf_counter() - tc) / 4 * 1e3, 3)
+        dp_diag["compute_only_ms_per_step"] = round((time.perf_counter() - tc) / a.steps * 1e3, 3)
         ops.profile_on(None)
+        ops.side_streams_pause(one_stream)
         dp_diag["backend"] = backend
         dist.barrier()
 
