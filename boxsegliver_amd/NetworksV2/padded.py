@@ -31,6 +31,26 @@ class PaddedParamStore(ParamStore):
         phys = [(n, tuple(self.pads[n][0]) if n in self.pads else tuple(s), k) for n, s, k in specs]
         super(PaddedParamStore, self).__init__(phys, device, bias_decay)
         self.logical_shape = {n: tuple(s) for n, s, _ in specs}
+        # the conv kernels skip the padded groups of their contraction axis (ops.conv3d_desc live8; include/unetk.h
+        # unetk_conv3d_desc.cin_live8): the masks ride on the filter tensors handed out by p[name]
+        for n, _, kind in specs:
+            if kind == "conv_w" and n in self.pads and len(self.pads[n][0]) == 5:
+                self.tensors[n].unetk_live8 = self.live8_masks(n)
+
+    def live8_masks(self, name):
+        """(Cin mask, Cout mask) of a padded [kd, kh, kw, Cin, Cout] filter: bit i = physical channels [8 i, 8 i + 8) hold a
+        logical channel; 0 where the axis does not fit a 64-bit mask of 8-channel groups (the kernels then contract it all)."""
+        phys, axis_maps = self.pads[name]
+        lshape = self.logical_shape[name]
+        out = []
+        for ax in (3, 4):
+            m = 0
+            if phys[ax] % 16 == 0 and phys[ax] <= 512:
+                for _, ln, ps in axis_maps.get(ax, [(0, lshape[ax], 0)]):
+                    for g in range(ps // 8, (ps + ln + 7) // 8):
+                        m |= 1 << g
+            out.append(m)
+        return tuple(out)
 
     def _blocks(self, name):
         """Yield (logical index tuple, physical index tuple) of every dense block of the variable."""

@@ -12,7 +12,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 _LIB = None
 LIB_PATH = os.environ.get("UNETK_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libunetk.so")
 
-ABI_VERSION = 9            # must equal unetk_abi_version() of the loaded library (checked in lib())
+ABI_VERSION = 10            # must equal unetk_abi_version() of the loaded library (checked in lib())
 UNETK_MAX_CLASSES = 8
 W_NONE, W_NUMERICAL, W_PROPORTION, W_PIXELMAP = 0, 1, 2, 3
 
@@ -32,7 +32,8 @@ class DeconvDesc(Structure):
 
 class Conv3dDesc(Structure):
     _fields_ = [("N", c_int32), ("D", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
-                ("kd", c_int32), ("sd", c_int32), ("shw", c_int32), ("x_stride", c_int32), ("y_stride", c_int32)]
+                ("kd", c_int32), ("sd", c_int32), ("shw", c_int32), ("x_stride", c_int32), ("y_stride", c_int32),
+                ("cin_live8", ctypes.c_uint32 * 2), ("cout_live8", ctypes.c_uint32 * 2)]
 
 
 class Deconv3dDesc(Structure):

@@ -180,7 +180,37 @@ struct ConvParams {
   // one launch -- the second half of the pixel tiles writes the planes at p.y + dpar_yoff
   int dpar;
   int64_t dpar_yoff;
+  // live K chunks (conv_igemm_lin.hip; round 5): the caller promises that only the listed 16-channel chunks of the contraction
+  // axis carry non-zero filter rows (a channel-padded net: 240 real channels in 256, a concat of two such halves in 512), so
+  // the K sequence visits klive[0 .. nlive) only; bit i of khalf = of live chunk i only channels 0..7 are real (120 in 128):
+  // the plain variant runs half its MFMAs there.  nlive = 0: every chunk.
+  int nlive;
+  unsigned khalf;
+  int klive[32];
 };
+// live8: bit i = channels [8 i, 8 i + 8) of a K-channel contraction axis hold a real channel (0 = no information: all live)
+inline int unetk_live_chunks(const uint32_t live8[2], int K) {
+  const uint64_t m = (uint64_t)live8[0] | ((uint64_t)live8[1] << 32);
+  if (m == 0 || K % 16 != 0 || K > 512) return K / 16;
+  int n = 0;
+  for (int c = 0; c < K / 16; ++c) n += ((m >> (2 * c)) & 3) != 0;
+  return n > 0 ? n : K / 16;
+}
+inline void unetk_set_klive(ConvParams& p, const uint32_t live8[2], int K, bool halves) {
+  const uint64_t m = (uint64_t)live8[0] | ((uint64_t)live8[1] << 32);
+  p.nlive = 0; p.khalf = 0;
+  if (m == 0 || K % 16 != 0 || K > 512) return;
+  int n = 0;
+  unsigned half = 0;
+  for (int c = 0; c < K / 16; ++c) {
+    const int b = (int)((m >> (2 * c)) & 3);
+    if (b == 0) continue;
+    if (b == 1 && halves) half |= 1u << n;
+    p.klive[n++] = c;
+  }
+  if (n == 0 || (n == K / 16 && half == 0)) return;
+  p.nlive = n; p.khalf = half;
+}
 bool unetk_conv_lin_gen_ok(int H, int W, int Cin, int Cout);
 int unetk_conv_run_lin_gen(ConvParams p, hipStream_t st);
 int unetk_conv_run(ConvParams p, hipStream_t st);          // conv_igemm.hip: picks the tile configuration

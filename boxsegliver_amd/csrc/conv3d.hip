@@ -192,6 +192,18 @@ extern "C" int unetk_conv3d_stat_rows(const unetk_conv3d_desc* d) {
   return unetk_conv_stat_rows(d->N * g.Do, d->H, d->W, d->Cin, d->Cout, g.Do);
 }
 
+// UNETK_KSKIP (measurement; read once): bit 0 = skip the dead 16-channel chunks of a channel-padded contraction axis
+// (unetk_conv3d_desc.cin_live8 / cout_live8), bit 1 = half the MFMAs on a chunk whose upper 8 channels are padding.  Default 3.
+static int kskip() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("UNETK_KSKIP"); v = e ? atoi(e) : 3; }
+  return v;
+}
+static int live_k(const uint32_t live8[2], int K) { return (kskip() & 1) ? 16 * unetk_live_chunks(live8, K) : K; }
+static void set_live(ConvParams& p, const uint32_t live8[2], int K) {
+  if (kskip() & 1) unetk_set_klive(p, live8, K, (kskip() & 2) != 0);
+}
+
 extern "C" size_t unetk_conv3d_ws_bytes(const unetk_conv3d_desc* d) {
   if (!desc_ok(d)) return 0;
   const Geo3 g = geo3(d);
@@ -211,12 +223,12 @@ extern "C" size_t unetk_conv3d_ws_bytes(const unetk_conv3d_desc* d) {
   }
   if (s2lin_ok(d, g)) {              // space-to-depth copy of x + the stream-K slab of the grouped-tap forward
     const size_t sb = s2lin_xs_floats(d, g) * sizeof(float) +
-                      unetk_conv_lin_sk_bytes(d->N * g.Do, g.Ho, g.Wo, d->Cin, d->Cout, g.Do, d->kd * 4);
+                      unetk_conv_lin_sk_bytes(d->N * g.Do, g.Ho, g.Wo, live_k(d->cin_live8, d->Cin), d->Cout, g.Do, d->kd * 4);
     if (sb > bytes) bytes = sb;
   }
   if (d->shw == 1 && d->sd == 1) {   // stream-K slabs of the small-plane kernel, forward and input gradient
-    const size_t kf = unetk_conv_lin_sk_bytes(d->N * d->D, d->H, d->W, d->Cin, d->Cout, d->D, d->kd);
-    const size_t kb = unetk_conv_lin_sk_bytes(d->N * d->D, d->H, d->W, d->Cout, d->Cin, d->D, d->kd);
+    const size_t kf = unetk_conv_lin_sk_bytes(d->N * d->D, d->H, d->W, live_k(d->cin_live8, d->Cin), d->Cout, d->D, d->kd);
+    const size_t kb = unetk_conv_lin_sk_bytes(d->N * d->D, d->H, d->W, live_k(d->cout_live8, d->Cout), d->Cin, d->D, d->kd);
     if (kf > bytes) bytes = kf;
     if (kb > bytes) bytes = kb;
   }
@@ -252,6 +264,7 @@ extern "C" int unetk_conv3d_fwd(const unetk_conv3d_desc* d, const float* x, cons
     p.ya = planes(d->H * d->W * d->y_stride, d->D, 1, d->D);
     p.spg = d->D;
     p.kd = 3; p.dshift0 = -g.pb_d; p.dstep = 1;
+    set_live(p, d->cin_live8, d->Cin);
     if (ws && unetk_aligned16(ws)) { p.sk_slab = (float*)ws; p.sk_slab_bytes = ws_bytes; }
     return unetk_conv_run(p, st);
   }
@@ -291,6 +304,7 @@ extern "C" int unetk_conv3d_fwd(const unetk_conv3d_desc* d, const float* x, cons
         }
     }
     p.ng = ng;
+    set_live(p, d->cin_live8, d->Cin);
     const size_t xsb = s2lin_xs_floats(d, g) * sizeof(float);
     p.sk_slab = (float*)((char*)ws + xsb); p.sk_slab_bytes = ws_bytes - xsb;
     return unetk_conv_run_lin(p, st);
@@ -417,6 +431,7 @@ extern "C" int unetk_conv3d_dgrad(const unetk_conv3d_desc* d, const float* dy, c
       p.spg = g.Do;
       p.dshift0 = 0; p.dstep = -1;           // even planes: dy plane do = di / 2 - dt' for the fused taps dt' = 0, 1 (dt = 0, 2)
       p.dpar = 1; p.dpar_yoff = HWx;          // odd planes: one plane further
+      set_live(p, d->cout_live8, d->Cout);
       p.os = 2; p.Hd = d->H; p.Wd = d->W;
       for (int ph = 0; ph < 2; ++ph)
         for (int pw = 0; pw < 2; ++pw) {
@@ -453,6 +468,7 @@ extern "C" int unetk_conv3d_dgrad(const unetk_conv3d_desc* d, const float* dy, c
       p.accumulate = multi ? 1 : 0;
       p.spg = hi - lo + 1;
       if (fuse_d) { p.kd = 3; p.dshift0 = g.pb_d; p.dstep = -1; }   // dx[di] = sum_dt dy[di + pb - dt] * w[dt]
+      set_live(p, d->cout_live8, d->Cout);
       p.os = 2; p.Hd = d->H; p.Wd = d->W;
       for (int ph = 0; ph < 2; ++ph)
         for (int pw = 0; pw < 2; ++pw) {
@@ -485,6 +501,7 @@ extern "C" int unetk_conv3d_dgrad(const unetk_conv3d_desc* d, const float* dy, c
     p.ya = planes(d->H * d->W * d->x_stride, d->D, 1, d->D);
     p.spg = d->D;
     p.kd = 3; p.dshift0 = g.pb_d; p.dstep = -1;
+    set_live(p, d->cout_live8, d->Cout);
     if (ws && unetk_aligned16(ws)) { p.sk_slab = (float*)ws; p.sk_slab_bytes = ws_bytes; }
     return unetk_conv_run(p, st);
   }

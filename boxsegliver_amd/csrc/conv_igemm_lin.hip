@@ -15,6 +15,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace {
 
 constexpr int CK = 16;
@@ -54,8 +56,11 @@ __device__ __forceinline__ int sk_block_of(int64_t pos, int64_t tot, int G) {   
 // with its own channel offset inside an input pixel, plane shift and list of <= 4 taps (ConvParams::ng ...): a strided conv
 // on small output planes runs as a stride-1 contraction over a space-to-depth copy of its input (conv3d.hip).  UNet3D's
 // (2,2,2) bridge (6 x 6 output planes) took the TILED stride-2 kernel at 28 % tile fill: 0.31 ms = 25 TFLOP/s.
-template <int WM, int WN, int TM, int TN, bool GEN = false, bool FUSED = false, bool SK = false, bool ACC = false, bool GRP = false>
+// KHALF (round 5; plain variant): chunks flagged in p.khalf contract their lower 8 channels only (a 120-in-128 padded K axis).
+template <int WM, int WN, int TM, int TN, bool GEN = false, bool FUSED = false, bool SK = false, bool ACC = false, bool GRP = false,
+          bool KHALF = false>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))) void conv3x3_igemm_lin_kernel(ConvParams p) {
+  static_assert(!(KHALF && (GEN || GRP)), "half chunks are a flag of the plain variant");
   static_assert(!(GRP && (GEN || ACC)), "grouped taps are a flag of the plain variant");
   static_assert(!(ACC && (GEN || SK)), "ACC is a flag of the plain variant (the GEN variants test p.accumulate)");
   static_assert(GEN || !FUSED, "FUSED is a GEN variant");
@@ -151,10 +156,11 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
   }
 
   float4 hreg[HR], wreg[WR];
-  const int nchunks = p.Cin / CK;
+  const int nchunks = p.nlive ? p.nlive : p.Cin / CK;          // live chunks of a channel-padded K axis (common.h)
   // chunk index cc runs over (depth tap, 16-channel chunk); one depth tap = a plane shift inside the sample
   auto load_halo = [&](int cc) {
-    const int dt = (GRP || KD > 1) ? cc / nchunks : 0, c = cc - dt * nchunks;      // GRP: dt = the group
+    const int dt = (GRP || KD > 1) ? cc / nchunks : 0, cl = cc - dt * nchunks;     // GRP: dt = the group
+    const int c = p.nlive ? p.klive[cl] : cl;
     const int shift = GRP ? p.g_dz[dt] : (KD > 1 ? p.dshift0 + dt * p.dstep : 0);
     const int64_t soff = (int64_t)shift * p.xa.img_stride + c * CK + (GRP ? p.g_chan[dt] : 0);
 #pragma unroll
@@ -169,7 +175,8 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
       if (hlds[r] >= 0) *reinterpret_cast<float4*>(&halo[buf * HALO_F + hlds[r]]) = hreg[r];
   };
   auto load_w = [&](int cc, int t) {      // GRP: t = the tap's position in its group's list
-    const int dt = (GRP || KD > 1) ? cc / nchunks : 0, c = cc - dt * nchunks;
+    const int dt = (GRP || KD > 1) ? cc / nchunks : 0, cl = cc - dt * nchunks;
+    const int c = p.nlive ? p.klive[cl] : cl;
     const int panel = GRP ? p.g_panel[dt][t] : ((FUSED && p.dpar) ? (dpar ? 9 + t : dt * 18 + t) : dt * 9 + t);
     const float* base = p.wp + ((int64_t)panel * cin4 + c * (CK / 4)) * p.Cout * 4;
 #pragma unroll
@@ -412,10 +419,23 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
         __syncthreads();
       }
     }
-  } else
+  } else {
+  unsigned hmask = 0;        // p.khalf rotated to the current chunk's place in the live list (KHALF)
+  int hleft = 0;
+  if constexpr (KHALF) {
+    const int cl0 = c_lo % nchunks;
+    hmask = p.khalf >> cl0;
+    hleft = nchunks - cl0;
+  }
   for (int c = c_lo; c < c_hi; ++c) {
     const float* hb = halo + ((c - c_lo) & 1) * HALO_F;
     const bool more_chunks = (c + 1 < c_hi);
+    // a chunk whose upper 8 channels are padding (p.khalf) skips the second half of every tap's MFMAs
+    const bool half = KHALF && (hmask & 1);
+    if constexpr (KHALF) {
+      hmask >>= 1;
+      if (--hleft == 0) { hmask = p.khalf; hleft = nchunks; }      // next depth tap: the list starts over
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t, ++step) {
       const bool has_next = (t < 8) || more_chunks;
@@ -426,6 +446,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
       const int toff = ((t / 3) * WP + (t % 3)) * PS;
 #pragma unroll
       for (int g = 0; g < CK / 8; ++g) {
+        if (KHALF && g == 1 && half) continue;
         float4 a[TM], b[TN];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -448,6 +469,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
       if (t == 5 && more_chunks) store_halo((c + 1 - c_lo) & 1);
       __syncthreads();
     }
+  }
   }
 
   if (SK && (c_lo != 0 || c_hi != nchunks_all)) {
@@ -620,15 +642,15 @@ __global__ __launch_bounds__(256) void lin_sk_fixup_kernel(ConvParams p, int G) 
   }
 }
 
-template <int WM, int WN, int TM, int TN, bool GEN = false, bool FUSED = false, bool ACC = false, bool GRP = false>
+template <int WM, int WN, int TM, int TN, bool GEN = false, bool FUSED = false, bool ACC = false, bool GRP = false, bool KHALF = false>
 int launch_lin(const ConvParams& p, int n_mtiles, hipStream_t st) {
   if constexpr (!GEN && !ACC && !GRP) {
-    if (p.accumulate) return launch_lin<WM, WN, TM, TN, false, false, true>(p, n_mtiles, st);
+    if (p.accumulate) return launch_lin<WM, WN, TM, TN, false, false, true>(p, n_mtiles, st);   // (half chunks run whole there)
   }
   constexpr int BN = WN * TN * 32;
   constexpr size_t lds_max = (size_t)(2 * LIN_MAXPIX * PS + 2 * CK * BN) * sizeof(float);
   const size_t lds = (size_t)(2 * p.lin_pix * PS + 2 * CK * BN) * sizeof(float);
-  auto kern = conv3x3_igemm_lin_kernel<WM, WN, TM, TN, GEN, FUSED, false, ACC, GRP>;
+  auto kern = conv3x3_igemm_lin_kernel<WM, WN, TM, TN, GEN, FUSED, false, ACC, GRP, KHALF>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
@@ -810,12 +832,12 @@ SkPlan sk_plan(int N, int H, int W, int Cin, int Cout, int spg, int kd) {
   return s;
 }
 
-template <int WM, int WN, int TM, int TN, bool GRP = false>
+template <int WM, int WN, int TM, int TN, bool GRP = false, bool KHALF = false>
 int launch_lin_sk(const ConvParams& p, const SkPlan& sk, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr size_t lds_max = (size_t)(2 * LIN_MAXPIX * PS + 2 * CK * BN) * sizeof(float);
   const size_t lds = (size_t)(2 * p.lin_pix * PS + 2 * CK * BN) * sizeof(float);
-  auto kern = conv3x3_igemm_lin_kernel<WM, WN, TM, TN, false, false, true, false, GRP>;
+  auto kern = conv3x3_igemm_lin_kernel<WM, WN, TM, TN, false, false, true, false, GRP, KHALF>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
@@ -849,7 +871,7 @@ int unetk_conv_run_lin(ConvParams p, hipStream_t st) {
     for (int g = 0; g < p.ng; ++g)
       if (p.g_ntaps[g] < 1 || p.g_ntaps[g] > 4) return UNETK_E_BADARG;
     if (p.sk_slab != nullptr && p.ys % 4 == 0) {
-      const SkPlan sk = sk_plan(p.N, p.H, p.W, p.Cin, p.Cout, p.spg, p.ng);
+      const SkPlan sk = sk_plan(p.N, p.H, p.W, p.nlive ? p.nlive * CK : p.Cin, p.Cout, p.spg, p.ng);
       if (sk.on && p.sk_slab_bytes >= sk.bytes && unetk_aligned16(p.sk_slab)) {
         p.sk_tiles = sk.tiles; p.sk_nc = sk.nc; p.sk_maxp = sk.maxp; p.sk_whole = sk.whole;
         p.n_ntiles = p.Cout / sk.bn;
@@ -871,10 +893,12 @@ int unetk_conv_run_lin(ConvParams p, hipStream_t st) {
     return launch_lin<4, 1, 1, 2, false, false, false, true>(p, n_mtiles, st);
   }
   if (p.sk_slab != nullptr && !p.accumulate && p.ys % 4 == 0) {
-    const SkPlan sk = sk_plan(p.N, p.H, p.W, p.Cin, p.Cout, p.spg, p.kd);
+    const SkPlan sk = sk_plan(p.N, p.H, p.W, p.nlive ? p.nlive * CK : p.Cin, p.Cout, p.spg, p.kd);
     if (sk.on && p.sk_slab_bytes >= sk.bytes && unetk_aligned16(p.sk_slab)) {
       p.sk_tiles = sk.tiles; p.sk_nc = sk.nc; p.sk_maxp = sk.maxp; p.sk_whole = sk.whole;
       p.n_ntiles = p.Cout / sk.bn;
+      if (p.khalf != 0 && bm == 64) return launch_lin_sk<2, 2, 1, 2, false, true>(p, sk, st);
+      if (p.khalf != 0 && p.Cout % 128 == 0) return launch_lin_sk<2, 2, 2, 2, false, true>(p, sk, st);
       if (bm == 64) return launch_lin_sk<2, 2, 1, 2>(p, sk, st);
       if (p.Cout % 128 == 0) return launch_lin_sk<2, 2, 2, 2>(p, sk, st);
       return launch_lin_sk<4, 1, 1, 2>(p, sk, st);
@@ -883,10 +907,12 @@ int unetk_conv_run_lin(ConvParams p, hipStream_t st) {
   p.sk_slab = nullptr;
   if (bm == 64) {
     p.n_ntiles = p.Cout / 128;
+    if (p.khalf != 0 && !p.accumulate) return launch_lin<2, 2, 1, 2, false, false, false, false, true>(p, n_mtiles, st);
     return launch_lin<2, 2, 1, 2>(p, n_mtiles, st);
   }
   if (p.Cout % 128 == 0) {
     p.n_ntiles = p.Cout / 128;
+    if (p.khalf != 0 && !p.accumulate) return launch_lin<2, 2, 2, 2, false, false, false, false, true>(p, n_mtiles, st);
     return launch_lin<2, 2, 2, 2>(p, n_mtiles, st);
   }
   p.n_ntiles = p.Cout / 64;

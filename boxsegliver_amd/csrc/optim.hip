@@ -142,7 +142,7 @@ extern "C" int unetk_nan_watch(const float* value, int32_t* flag, int32_t step, 
   return UNETK_OK;
 }
 
-extern "C" int unetk_abi_version(void) { return 9; }   // 2: unetk_conv_desc.precision, UNETK_BF16; 3: density modulation, unetk_fc_*; 4: unetk_conv_desc.dilation; 5: UNETK_BF16S (bf16 storage), unetk_norm_desc.storage, unetk_head_desc.storage; 6: norm dropout / guide_alpha / guide_per_sample, unetk_norm_se_bwd_add, fc sigmoid; 7: unetk_conv3x3_dgrad_nbr, unetk_norm_relu_bwd_pre, unetk_conv1d_*, unetk_maxpool1d_*, unetk_spatial_mean_*, unetk_conv3x3_*_ws, unetk_pack_many; 8: unetk_prof_* (kernel trace), unetk_nan_watch; 9: unetk_deconv{2x2,3d}_bwd_parts
+extern "C" int unetk_abi_version(void) { return 10; }   // 2: unetk_conv_desc.precision, UNETK_BF16; 3: density modulation, unetk_fc_*; 4: unetk_conv_desc.dilation; 5: UNETK_BF16S (bf16 storage), unetk_norm_desc.storage, unetk_head_desc.storage; 6: norm dropout / guide_alpha / guide_per_sample, unetk_norm_se_bwd_add, fc sigmoid; 7: unetk_conv3x3_dgrad_nbr, unetk_norm_relu_bwd_pre, unetk_conv1d_*, unetk_maxpool1d_*, unetk_spatial_mean_*, unetk_conv3x3_*_ws, unetk_pack_many; 8: unetk_prof_* (kernel trace), unetk_nan_watch; 9: unetk_deconv{2x2,3d}_bwd_parts; 10: unetk_conv3d_desc.cin_live8 / cout_live8
 
 extern "C" const char* unetk_error_string(int code) {
   switch (code) {

@@ -621,11 +621,17 @@ def conv3x3_wgrad(x, dy, bf16=False, dilation=1, out=None, ws_pool=None):
     return dw
 
 
-def conv3d_desc(x_shape, cout, kd, stride, x_stride=None, y_stride=None):
+def conv3d_desc(x_shape, cout, kd, stride, x_stride=None, y_stride=None, live8=None):
+    """live8 = (cin mask, cout mask) of a channel-padded filter (NetworksV2/padded.py live8_masks): bit i = channels
+    [8 i, 8 i + 8) hold a real channel; the kernels skip the dead groups of their contraction axis (include/unetk.h)."""
     n, dd, h, w, cin = x_shape
     sd, sh, sw = stride
     assert sh == sw, "H and W strides must match"
-    return Conv3dDesc(n, dd, h, w, cin, cout, kd, sd, sh, x_stride or cin, y_stride or cout)
+    d = Conv3dDesc(n, dd, h, w, cin, cout, kd, sd, sh, x_stride or cin, y_stride or cout)
+    if live8 is not None:
+        for field, m in ((d.cin_live8, live8[0]), (d.cout_live8, live8[1])):
+            field[0], field[1] = m & 0xFFFFFFFF, (m >> 32) & 0xFFFFFFFF
+    return d
 
 
 def conv3d_out_shape(d):
@@ -1591,7 +1597,8 @@ class Conv3dNormRelu(_Op):
         kd, cin, cout = w.shape[0], w.shape[3], w.shape[4]
         mfma = conv_uses_mfma(cin, cout)
         need_dx = ctx.needs_input_grad[0]
-        d = conv3d_desc(x.shape, cout, kd, stride, x_stride=_pix_stride_nd(x))
+        live8 = getattr(w, "unetk_live8", None)      # set on channel-padded filters by PaddedParamStore
+        d = conv3d_desc(x.shape, cout, kd, stride, x_stride=_pix_stride_nd(x), live8=live8)
         if mfma:
             wp_f, wp_d = conv3d_pack(w, want_dgrad=need_dx)
         else:
@@ -1613,7 +1620,7 @@ class Conv3dNormRelu(_Op):
         norm_apply_relu(nd, y, aff, z)
         if spec.training:
             ctx.save_for_backward(x, y, aff)
-            ctx.wp_d, ctx.need_dx, ctx.d, ctx.nd = wp_d, need_dx, d, nd
+            ctx.wp_d, ctx.need_dx, ctx.d, ctx.nd, ctx.live8 = wp_d, need_dx, d, nd, live8
             ctx.has = (gamma is not None, beta is not None)
             ctx.sinks = (grad_sink(w, ctx), grad_sink(gamma, ctx), grad_sink(beta, ctx) if not plain else None)
             ctx.dbg = (w.detach(), gamma, beta, stride, z.detach()) if DEBUG_CAPTURE is not None else None
@@ -1633,7 +1640,7 @@ class Conv3dNormRelu(_Op):
             dw = conv3d_wgrad(x, dy, ctx.d, out=sw)
         elif SIDE_WGRAD3D_FIRST:
             dw = _wgrad3d_on_side(x, dy, ctx.d, sw)      # queued behind dy only: runs BESIDE this layer's input gradient
-        dense = conv3d_desc(x.shape, ctx.d.Cout, ctx.d.kd, (ctx.d.sd, ctx.d.shw, ctx.d.shw))   # dx is dense
+        dense = conv3d_desc(x.shape, ctx.d.Cout, ctx.d.kd, (ctx.d.sd, ctx.d.shw, ctx.d.shw), live8=ctx.live8)   # dx is dense
         dx = conv3d_dgrad(dy, ctx.wp_d, dense) if ctx.need_dx else None
         if on_side and not SIDE_WGRAD3D_FIRST:
             dw = _wgrad3d_on_side(x, dy, ctx.d, sw)      # queued behind the input gradient: runs beside the NEXT unit's norm backward

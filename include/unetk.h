@@ -186,6 +186,12 @@ typedef struct unetk_conv3d_desc {
   int32_t sd;   /* depth stride 1 or 2 (kd == 3 only) */
   int32_t shw;  /* H and W stride, 1 or 2 */
   int32_t x_stride, y_stride;
+  /* Channel-padded nets (UNet3D's 30/60/120/240 real channels inside 32/64/128/256; ABI 10): bit i of the 64-bit mask
+   * {lo, hi} = channels [8 i, 8 i + 8) of x (cin_live8) / of y (cout_live8) hold a real channel.  A promise by the caller that
+   * the filter is ZERO in every other input row / output column: the forward then skips the dead groups of its contraction over
+   * Cin, the input gradient those of its contraction over Cout (small-plane kernel; results equal to contracting the zeros).
+   * 0 = no information, every channel is contracted. */
+  uint32_t cin_live8[2], cout_live8[2];
 } unetk_conv3d_desc;
 
 int unetk_conv3d_pack(const float* w, int kd, int Cin, int Cout, float* wp_fwd, float* wp_dgrad,

@@ -72,6 +72,71 @@ def test_conv3d_forward_backward(ops, case):
     assert rel_err(dw.cpu().numpy(), wt.grad.numpy()) < 5e-6
 
 
+def _mask8(segs):
+    m = 0
+    for lo, hi in segs:
+        for g in range(lo // 8, (hi + 7) // 8):
+            m |= 1 << g
+    return m
+
+
+LIVE_CASES = [
+    # N, D, H, W, Cin, live Cin ranges, Cout, live Cout ranges, kd, stride -- UNet3D's channel-padded layers (NetworksV2/padded.py)
+    (1, 8, 12, 12, 256, [(0, 240)], 256, [(0, 240)], 3, (1, 1, 1)),                 # 240 in 256: chunk 15 is skipped
+    (1, 6, 24, 24, 128, [(0, 120)], 128, [(0, 120)], 3, (1, 1, 1)),                 # 120 in 128: chunk 7 runs half its MFMAs
+    (1, 8, 12, 12, 512, [(0, 240), (256, 496)], 256, [(0, 240)], 3, (1, 1, 1)),     # concat(skip, up) of two padded halves
+    (1, 4, 24, 24, 256, [(0, 120), (128, 248)], 128, [(0, 120)], 3, (1, 1, 1)),
+    (2, 4, 24, 24, 128, [(0, 120)], 256, [(0, 240)], 3, (1, 2, 2)),                 # grouped-tap forward, four-class input gradient
+    (1, 8, 12, 12, 256, [(0, 240)], 320, [(0, 320)], 3, (2, 2, 2)),                 # the bridge
+    (3, 16, 12, 12, 256, [(0, 240)], 256, [(0, 240)], 3, (1, 1, 1)),                # whole tiles + stream-K remainder
+]
+
+
+@pytest.mark.parametrize("case", LIVE_CASES)
+def test_conv3d_live_channel_masks(ops, case):
+    """unetk_conv3d_desc.cin_live8 / cout_live8: skipping the padded groups of the contraction axis gives the result of
+    contracting their zeros -- against the oracle on the padded tensors and against the same call without the masks."""
+    n, dd, h, w, cin, cin_live, cout, cout_live, kd, stride = case
+    rng = np.random.default_rng(cin * 7 + cout + h)
+    ci = np.zeros(cin, bool)
+    co = np.zeros(cout, bool)
+    for lo, hi in cin_live:
+        ci[lo:hi] = True
+    for lo, hi in cout_live:
+        co[lo:hi] = True
+    x_np = rng.standard_normal((n, dd, h, w, cin)) * ci
+    w_np = rng.standard_normal((kd, 3, 3, cin, cout)) / math.sqrt(9 * kd * cin) * ci[:, None] * co[None, :]
+    x = torch.tensor(x_np, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w_np, dtype=torch.float64, requires_grad=True)
+    y_ref = tf_ops.conv_nd_same(x, wt, stride=stride)
+    dy = rng.standard_normal(tuple(y_ref.shape)) * co
+    y_ref.backward(torch.tensor(dy))
+    live8 = (_mask8(cin_live), _mask8(cout_live))
+    d_live = ops.conv3d_desc(x.shape, cout, kd, stride, live8=live8)
+    d_all = ops.conv3d_desc(x.shape, cout, kd, stride)
+    assert tuple(d_live.cin_live8) == (live8[0] & 0xFFFFFFFF, live8[0] >> 32)
+    wp_f, wp_d = ops.conv3d_pack(dev(w_np))
+    xd, dyd = dev(x_np), dev(dy)
+    y, stats, rows = ops.conv3d_fwd(xd, wp_f, d_live, want_stats=True)
+    y0, stats0, rows0 = ops.conv3d_fwd(xd, wp_f, d_all, want_stats=True)
+    ref = y_ref.detach().numpy()
+    assert rel_err(y.cpu().numpy(), ref) < 3e-6
+    assert rel_err(y.cpu().numpy(), y0.cpu().numpy()) < 1e-6
+    assert rows == rows0
+    np.testing.assert_allclose(stats.cpu().numpy().reshape(2, -1, cout).sum(1), stats0.cpu().numpy().reshape(2, -1, cout).sum(1),
+                               rtol=2e-5, atol=2e-3)
+    dx = ops.conv3d_dgrad(dyd, wp_d, d_live)
+    dx0 = ops.conv3d_dgrad(dyd, wp_d, d_all)
+    assert rel_err(dx.cpu().numpy(), x.grad.numpy()) < 5e-6
+    assert rel_err(dx.cpu().numpy(), dx0.cpu().numpy()) < 1e-6
+    assert float(dx[..., ~torch.as_tensor(ci)].abs().max()) == 0.0 if not ci.all() else True
+    # bit-reproducible with the masks as without
+    assert torch.equal(ops.conv3d_fwd(xd, wp_f, d_live, want_stats=False)[0], y)
+    assert torch.equal(ops.conv3d_dgrad(dyd, wp_d, d_live), dx)
+    dw = ops.conv3d_wgrad(xd, dyd, d_live)                          # the filter gradient contracts pixels: masks unused
+    assert rel_err(dw.cpu().numpy(), wt.grad.numpy()) < 5e-6
+
+
 DECONV_CASES = [
     # N, D, H, W, Cin, Cout, kd
     (1, 3, 4, 8, 128, 64, 1),      # conv_d1/up: (1,2,2)

@@ -30,7 +30,7 @@ def test_header_symbols_all_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(_abi.EXPORTED_SYMBOLS)
-    assert lib.unetk_abi_version() == _abi.ABI_VERSION == 9
+    assert lib.unetk_abi_version() == _abi.ABI_VERSION == 10
 
 
 def test_abi_argument_validation_without_gpu():
@@ -118,6 +118,29 @@ def test_param_specs_match_oracle_and_counts():
     sd = store.state_dict()
     store2.load_state(sd)
     assert torch.equal(store2[store.specs[0][0]], store[store.specs[0][0]])
+
+
+def test_padded_store_hands_out_live_channel_masks():
+    """PaddedParamStore marks, per 8-channel group, where a padded UNet3D filter holds real channels (the conv kernels skip
+    the rest of their contraction axis): 240 in 256, 120 in 128, and the two padded halves of a concat input."""
+    from boxsegliver_amd.NetworksV2 import UNet3D as u3
+    from boxsegliver_amd.NetworksV2.padded import PaddedParamStore
+    specs, pads = u3.param_specs(1, 3, 30, 4, 320, "instance_norm", "UNet3D")
+    store = PaddedParamStore(specs, pads, torch.device("cpu"))
+    m = store["UNet3D/conv_e3/conv2/weights"].unetk_live8            # 240 -> 240 in 256 x 256
+    assert m == ((1 << 30) - 1, (1 << 30) - 1)
+    m = store["UNet3D/conv_d3/conv1/weights"].unetk_live8            # concat(240, 240) in 512
+    assert m[0] == ((1 << 30) - 1) | (((1 << 30) - 1) << 32)
+    m = store["UNet3D/conv_d2/conv1/weights"].unetk_live8            # concat(120, 120) in 256 -> 120 in 128
+    assert m == (((1 << 15) - 1) | (((1 << 15) - 1) << 16), (1 << 15) - 1)
+    m = store["UNet3D/conv_e0/conv2/weights"].unetk_live8            # 30 in 32: every group holds a real channel
+    assert m == (0xF, 0xF)
+    assert not hasattr(store["UNet3D/conv_d3/up/weights"], "unetk_live8")
+    # every physical entry outside the mask's groups is zero after initialisation (the promise behind the skip)
+    store.initialize("xavier", seed=0)
+    w = store["UNet3D/conv_d3/conv1/weights"]
+    dead = [c for c in range(512) if not (w.unetk_live8[0] >> (c // 8)) & 1]
+    assert dead == list(range(240, 256)) + list(range(496, 512)) and float(w.detach()[:, :, :, dead].abs().max()) == 0.0
 
 
 def test_solver_lr_policies_match_oracle():
