@@ -502,10 +502,17 @@ constexpr int S2TH = 4;             // stride-2 tile: 4 x 16 (or 4 x 12) output 
 
 bool wg_strided_ok(int Cin, int Cout) { return Cin % 32 == 0 && Cout % 64 == 0; }
 
+int wg_s2w6() {        // UNETK_WG_S2W6=0: measurement switch for the 6-wide stride-2 tile (read once)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("UNETK_WG_S2W6"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
 WgPlan wg_plan_strided(int N, int H, int W, int Cin, int Cout, int kd = 1) {   // H, W = output plane
   WgPlan pl{};
-  const int tw = (W % TW != 0 && W % STW == 0) ? STW : TW;
-  pl.mode = tw == STW ? 4 : 3;
+  // 6-wide output planes (UNet3D's (2,2,2) bridge, round 5): 4 x 6 tiles -- a 4 x 16 tile is 37 % full there (25 TFLOP/s)
+  const int tw = (W % TW != 0 && W % STW == 0) ? STW : ((W == 6 && wg_s2w6()) ? 6 : TW);
+  pl.mode = tw == STW ? 4 : (tw == 6 ? 6 : 3);
   pl.tiles_h = (H + S2TH - 1) / S2TH;
   pl.tiles_w = (W + tw - 1) / tw;
   pl.total_tiles = N * pl.tiles_h * pl.tiles_w;
@@ -622,6 +629,7 @@ int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_
     p.tiles_per_split = pl.tiles_per_split; p.n_ci_tiles = pl.n_ci_tiles; p.n_co_tiles = pl.n_co_tiles;
     const int grid = pl.S * KD * pl.n_ci_tiles * pl.n_co_tiles;
     const int rc = pl.mode == 4 ? launch_wgrad<32, 64, false, S2TH, STW, false, 2>(p, grid, st)
+                 : pl.mode == 6 ? launch_wgrad<32, 64, false, S2TH, 6, false, 2>(p, grid, st)
                                 : launch_wgrad<32, 64, false, S2TH, TW, false, 2>(p, grid, st);
     if (rc != UNETK_OK) return rc;
     if (pl.S == 1) return UNETK_OK;
