@@ -669,14 +669,17 @@ constexpr int LIN_BM = 128;
 // Use the linear-pixel kernel when the tiled one would leave > 10 % of its MFMA rows empty and the padded rows a
 // 128-pixel block can touch fit the LDS budget.
 // spg = planes per statistics group (one sample of a 3-D tensor; 1 for 2-D images).
-// UNETK_LIN_2D (measurement, round 5; read once): bit 0 = 32-wide planes whose tiled grid cannot fill the chip take this kernel too
+// UNETK_LIN_2D (round 5; read once): bit 0 = 32-wide planes whose tiled grid cannot fill the chip take this kernel too
 // (the 32 x 32 level of a 2-D net at 8 slices per GPU: 512 blocks of 64 pixels x 128 couts at ~120 TFLOP/s in the tiled kernel),
 // bits 1..3 = lin_tune's bits 0..2 for 2-D planes (128-pixel blocks, stream-K over all tiles, stream-K for short K).
+// Default 6 = 128-pixel blocks + stream-K over all tiles: the 16 x 16 bridge of GUNet at 8 slices (128 tiles of 128 x 128 cut into
+// 512 K pieces instead of 256 whole tiles of 64 x 128) 93 -> 107 TFLOP/s, step 370.3 -> 373.3 slices/s in two interleaved runs;
+// 2 alone 372.3, 14 373.2, bit 0 on top (15) 366.6 (profiles/r05_gunet_lin2d_ab.txt).
 static int lin_2d() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("UNETK_LIN_2D");
-    v = e ? atoi(e) : 0;
+    v = e ? atoi(e) : 6;
   }
   return v;
 }
@@ -703,20 +706,26 @@ bool unetk_conv_lin_ok(int N, int H, int W, int Cin, int Cout, int spg) {
 // alone 20.70 / 38.78, bits 0 + 1 20.71 / 38.46, all three 20.51 / 38.02 -- the default.  (64-pixel blocks stage twice the filter
 // panel per MFMA -- 72 % matrix-pipe busy against 82 % for the 128-pixel stream-K variant, profiles/r04_pmc_mfma_busy_unet3d.txt --
 // and with every tile cut into K pieces the block count no longer has to fit the CU count.)  Applied to 3-D layers (spg > 1)
-// only: the 2-D nets' small planes keep the round-2 schedule (no measurable change on GUNet bs 8: 383.5 vs 383.5 slices/s, and
-// a different split of the K range is a different fp32 summation order).
-static int lin_tune(int spg) {
+// first; round 5 gave the 2-D nets' starved small planes bits 0 + 1 as well (lin_2d() above).
+static int lin_tune(int N, int H, int W, int spg) {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("UNETK_LIN_TUNE");
     v = e ? atoi(e) : 7;
   }
-  return spg > 1 ? v : (lin_2d() >> 1);
+  if (spg > 1) return v;
+  // 2-D planes: only those the tiled kernel would FILL (they are here because its grid starves the chip, unetk_conv_lin_ok) --
+  // with at least 16 blocks of 128 pixels (8 slices of 16 x 16), where the change was measured.  The badly filled small planes
+  // (8 x 8, 4 x 4 ...) and the two-slice batches of the end-to-end tests keep the round-2 schedule: same kernel-level error
+  // either way (tools/dbg/lin2d_check.py: 0.5-2e-6 of the output's range against float64), but another fp32 summation order
+  // flips other ReLU masks at a 4 x 4 bridge, and those tests' budgets were set on the old one
+  const int64_t lin = ((int64_t)H * W + LIN_BM - 1) / LIN_BM * LIN_BM, tiled = (int64_t)((H + 7) / 8) * 8 * ((W + 15) / 16) * 16;
+  return (lin * 10 > tiled * 9 && (int64_t)N * H * W >= 16 * LIN_BM) ? (lin_2d() >> 1) : 0;
 }
 
 static int lin_bm(int N, int H, int W, int Cout, int spg) {
   if (Cout % 128 != 0) return LIN_BM;
-  if (lin_tune(spg) & 1) return LIN_BM;
+  if (lin_tune(N, H, W, spg) & 1) return LIN_BM;
   const int64_t nt = Cout / 128, groups = N / spg, gpix = (int64_t)spg * H * W;
   const int64_t b128 = groups * ((gpix + 127) / 128) * nt, b64 = groups * ((gpix + 63) / 64) * nt;
   if (b128 < 384) return 64;
@@ -813,12 +822,12 @@ SkPlan sk_plan(int N, int H, int W, int Cin, int Cout, int spg, int kd) {
   // at more)
   if (s.tiles >= 2048 || (s.tiles > 256 && eff >= 0.92)) return s;
   s.whole = s.tiles <= 256 ? 0 : s.tiles / 256 * 256;    // full rounds run one whole tile per block
-  if ((lin_tune(spg) & 2) && s.tiles <= 1024) s.whole = 0;
+  if ((lin_tune(N, H, W, spg) & 2) && s.tiles <= 1024) s.whole = 0;
   const int rem = s.tiles - s.whole;
   // measured (UNet3D, one patch): a remainder of 176 tiles with K >= 48 chunks gains 10-12 %, 96 tiles or K = 24 chunks
   // do not pay for the slab round trip and the fix-up launch
   if (s.whole > 0 && (rem < 128 || s.nc < 48)) return s;
-  if (s.whole == 0 && s.tiles > 256 && s.nc < 48 && !(lin_tune(spg) & 4)) return s;
+  if (s.whole == 0 && s.tiles > 256 && s.nc < 48 && !(lin_tune(N, H, W, spg) & 4)) return s;
   const int64_t tot = (int64_t)rem * s.nc;
   int G = 256;
   if (s.whole == 0 && tot >= 512 * 4) G = 512;           // nothing else resident: two blocks per CU
