@@ -99,6 +99,15 @@ R5 = """
 * `r05_probe_loader_waves.txt` (+ `.patch`) -- four loader waves for the same kernel: the kernel is 9-17 % FASTER, the step 2 % SLOWER
   (every other matrix kernel of the step runs 4 % slower behind it: clock).  Not kept.
 * `r05_probe_norm_mirror.txt` -- norm-pass traversal order probe (no gain).
+* `r05_unet3d_kskip_ab.txt` -- UNet3D's channel padding (30 / 60 / 120 / 240 in 32 / 64 / 128 / 256) no longer contracted: one bit per
+  8-channel group of Cin / Cout rides on every padded filter (`unetk_conv3d_desc.cin_live8 / cout_live8`, ABI 10); the linear-pixel
+  kernel leaves dead 16-channel chunks out of K and runs half the MFMAs of half-live ones: 20.51 -> 20.15 ms (- 1.7 %) in a same-call A/B.
+* `r05_gunet_lin2d_ab.txt` -- the 2-D nets' starved 16 x 16 planes at 8 slices per GPU: 128-pixel blocks + stream-K over all tiles
+  (`UNETK_LIN_2D`, default 6 now): bridge layers 93 -> 107 TFLOP/s, GUNet bs 8 370.3 -> 373.3 slices/s.
+* `r05_probe_wgrad_rounds.txt` -- one round of larger blocks instead of two for the stacked-plane filter gradient (a dispatch model says
+  - 5 %): no gain beside the main stream's kernels.  Not kept.
+* The bridge's filter gradient (6 x 6 output planes) on 4 x 6 stride-2 tiles: 0.309 -> 0.151 ms (`r05_bench_unet3d_96_bs1_by_layer.json`
+  `conv3d_wgrad [k3s22 ...]`; same-call step 20.19 -> 20.11 ms).
 """
 
 print("""# Round {rn} profiles (one MI355X, gfx950, ROCm 7.2)
