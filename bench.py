@@ -25,6 +25,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+from boxsegliver_amd.utils import hostcpu  # noqa: E402  (no torch inside)
+
+# before torch is imported: the intra-op pool follows the CPUs this process may USE (cgroup quota), not the host's count -- the
+# oracle legs (cpu_baseline, dice_vs_oracle) ran 128 threads on a 16-core quota before round 5 (boxsegliver_amd/utils/hostcpu.py)
+_USER_SET_OMP = "OMP_NUM_THREADS" in os.environ
+hostcpu.size_thread_pools()
+
 
 def launch(n_gpus, argv):
     """`python bench.py --gpus N` from a plain shell (no torchrun in front, WORLD_SIZE unset): this parent -- which has
@@ -38,7 +45,8 @@ def launch(n_gpus, argv):
     s.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_gpus)))
+    if not _USER_SET_OMP:                                   # the ranks share this node's CPU quota
+        env["OMP_NUM_THREADS"] = env["MKL_NUM_THREADS"] = str(max(1, hostcpu.usable_cpus() // n_gpus))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
@@ -121,12 +129,14 @@ def _cpu_oracle_steps(size, n_classes, bs, warm, timed):
     return statistics.median(times)
 
 
-def cpu_baseline(size, full=False):
+def cpu_baseline(size, full=True):
     """SURVEY.md 8d "CPU baseline beside it": the reference's own TF-1.13 CPU path cannot run (TensorFlow is not
     installable), so the labelled substitute is the oracle on this host's cores, fwd+bwd+TF-Adam: the
     configs[1]-shaped workload at bs 2 (3 classes; median of 2 timed steps after one warm-up) = `value`, and BASELINE.json
-    configs[0] (Liver only = 2 classes, bs 2; one timed step after one warm-up) -- ~25 s of CPU work in all, so the default
-    run is not mostly oracle.  --cpu-baseline-full adds the configs[1] shape at bs 8 (SURVEY.md 8d "bs 2 and bs 8", ~40 s more)."""
+    configs[0] (Liver only = 2 classes, bs 2; one timed step after one warm-up), and the configs[1] shape at bs 8 (SURVEY.md 8d
+    "bs 2 and bs 8") -- ~15 s of CPU work in all since the thread pool follows the CPUs the process may use (round 5: 16 threads
+    on a 16-core grant run the bs-2 step in 0.93 s; the 128 throttled threads before took 5.2 s), so the default run is not
+    mostly oracle."""
     threads = torch.get_num_threads()
     bs = 2
     t_start = time.perf_counter()
@@ -135,7 +145,8 @@ def cpu_baseline(size, full=False):
     out = {"value": round(bs / dt1, 4), "unit": "slices/s", "cores": threads, "kind": "port",
            "sample": "oracle (PyTorch-CPU restatement, not TF): UNet {0}x{0}x3 3-class bs {1} (configs[1] shape at bs 2), "
                      "fwd+bwd+Adam, median of 2 timed steps after 1 warm-up, {2:.2f} s/step, {3} torch threads, "
-                     "host os.cpu_count()={4}".format(size, bs, dt1, threads, os.cpu_count()),
+                     "host os.cpu_count()={4}, CPUs granted to this process {5}".format(size, bs, dt1, threads, os.cpu_count(),
+                                                                                          hostcpu.usable_cpus()),
            "cfg0": {"value": round(bs / dt0, 4), "unit": "slices/s",
                     "sample": "same, BASELINE.json configs[0]: Liver only (2 classes) bs 2, 1 timed step after 1 warm-up, "
                               "{:.2f} s/step".format(dt0)}}
@@ -291,7 +302,7 @@ def main():
                     help="UNet3D: patch depth (default = --size, i.e. a cube); the reference's own 3-D script trains "
                          "--depth 10 --size 256 --batch 4 (threed_script/201_unet_v1.sh:26)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the oracle at bs 8 (~40 s more of CPU work)")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="kept for old command lines: the bs 8 leg is part of the default since round 5")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP-event timing")
     ap.add_argument("--single-stream", action="store_true",
                     help="every step on ONE stream (filter gradients otherwise run beside input gradients on a second stream): "
@@ -677,7 +688,7 @@ def main():
             except (OSError, KeyError, ValueError, IndexError):
                 pass
         if not a.no_cpu_baseline and world == 1 and a.model == "UNet":
-            out["cpu_baseline"] = cpu_baseline(a.size, a.cpu_baseline_full)
+            out["cpu_baseline"] = cpu_baseline(a.size)
             if a.dtype == "fp32":
                 out["dice_vs_oracle"] = dice_vs_oracle()
         print(json.dumps(out, ensure_ascii=False), flush=True)

@@ -29,6 +29,8 @@ from pathlib import Path
 import numpy as np
 import torch
 
+from ..utils import hostcpu
+
 from .. import ops
 from ..utils import distribution_utils
 
@@ -269,7 +271,7 @@ class SliceStore(object):
                     raise ValueError("{}: {}x{} {}-bit, expected {}x{} {}-bit".format(path, ph, pw, pd, h, w, depth_bits))
                 dst[j].numpy()[:] = raw
 
-        workers = int(threads or min(32, (os.cpu_count() or 8)))
+        workers = int(threads or min(32, hostcpu.usable_cpus()))      # the cgroup's quota, not the host's count
         failure = None                     # a rank that cannot decode its share must not leave the others in the exchange below
         try:
             with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
