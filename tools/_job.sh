@@ -1,11 +1,7 @@
 # scratch job file for `gpurun -- 'bash tools/_job.sh'` (overwritten per experiment; the round's experiments are recorded in profiles/)
 set -e
 mkdir -p gpurun_out/job
-timeout -k 10 1100 python -m pytest tests -q -m gpu --durations=15 > gpurun_out/job/pytest.log 2>&1 || { tail -30 gpurun_out/job/pytest.log; exit 1; }
-tail -22 gpurun_out/job/pytest.log
-python -c "import __graft_entry__ as g; g.smoke()"
-SECONDS=0
-python bench.py > gpurun_out/job/bench_default.json
-echo "default bench.py took $SECONDS s"
-python -c "
-import json; d=json.loads(open('gpurun_out/job/bench_default.json').read().strip().splitlines()[-1]); print(d['value'], d['cpu_baseline'], d.get('dice_vs_oracle'))"
+ROUNDS=2 bash tools/ab_run.sh omp_gunetbf16 "--dtype bf16 --model GUNet --batch 8 --steps 20 --warmup 5 --no-kernel-events" base:OMP_NUM_THREADS=128,MKL_NUM_THREADS=128 base
+ROUNDS=2 bash tools/ab_run.sh omp_u3d "--model UNet3D --size 96 --batch 1 --steps 8 --warmup 2 --no-kernel-events" base:OMP_NUM_THREADS=128,MKL_NUM_THREADS=128 base
+ROUNDS=2 bash tools/ab_run.sh omp_bf16 "--dtype bf16 --size 512 --batch 8 --steps 20 --warmup 5 --no-kernel-events" base:OMP_NUM_THREADS=128,MKL_NUM_THREADS=128 base
+ROUNDS=1 bash tools/ab_run.sh omp_infer "--mode infer --model GUNet --batch 8 --steps 24 --warmup 8" base:OMP_NUM_THREADS=128,MKL_NUM_THREADS=128 base
