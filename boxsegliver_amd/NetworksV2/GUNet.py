@@ -489,10 +489,14 @@ class GUNet(base.BaseNet):
                         # ga < 0 -- per-channel slopes (1, 0) / (0, 1) of the guide activation -- and ba follows BEHIND it: the
                         # gb block [bias, slope+, slope-, post-shift] of unetk_norm_desc.guide_leaky == 3.  ga, ba and the
                         # guide's own variables get their gradients through these host-side products.
-                        if spec.se is not None:
-                            raise NotImplementedError("GUNet after_affine with --fix AND --use_se is not built")
                         ga, ba = p[scope + "/ChannelWiseAffine/gamma"], p[scope + "/ChannelWiseAffine/beta"]
-                        den = ga.expand(n, c) if den is None else den * ga
+                        if spec.se is not None:
+                            # --use_se as well: the gains are the gate's output, formed inside the op -- ga joins them there
+                            # (as in the branch above), the guide block is the same
+                            inner = spec.se
+                            spec.se = (lambda pooled, feat, _g=inner, _ga=ga: _g(pooled, feat) * _ga)
+                        else:
+                            den = ga.expand(n, c) if den is None else den * ga
                         gw, gb = gw * ga, gb * ga
                         pos = (ga.detach() >= 0).to(torch.float32)
                         gb = torch.stack((gb, pos.expand_as(gb), (1.0 - pos).expand_as(gb), ba.expand_as(gb)), dim=-2).contiguous()

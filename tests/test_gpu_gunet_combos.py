@@ -58,6 +58,26 @@ def test_gunet_after_affine_with_use_se_matches_oracle(normalizer):
     assert g is not None and float(g.abs().sum()) > 0
 
 
+@pytest.mark.parametrize("normalizer", ["instance_norm", "batch_norm"])
+def test_gunet_after_affine_with_fix_and_use_se_matches_oracle(normalizer):
+    """The triple --fix + --use_se under after_affine: relu((t * sigmoid(gate) + relu(norm(conv1x1(guide)))) * gamma' + beta') with
+    gamma' of both signs -- gamma' multiplies the gate's output inside the op, the guide branch takes the per-channel slopes and
+    the post-shift (unetk_norm_desc.guide_leaky == 3) as without the gate."""
+    yml = dict(YML, after_affine=True, context_fc_channels=[32, 16])
+    args = make_args(normalizer=normalizer, fix=True, use_context=True, use_se=True, side_dropout=0.0, im_height=64, im_width=64)
+    model, inputs, net, params, tensors = _setup_variant(args, yml, dict(after_affine=True, fix=True, use_se=True), ctx_len=10, size=64)
+    for name in list(params):
+        if name.endswith("ChannelWiseAffine/gamma"):
+            params[name] = params[name].clone()
+            params[name][1::2] *= -1.0                     # every other channel: a negative affine scale
+    model.params.load_state(params)
+    _whole_net_check(model, inputs, net, params, tensors, args, yml, {"context": tensors[3]}, grad_tol=5e-2)
+    for nm_ in ("GUNet/Encode/down_conv2/mod_conv1/ChannelWiseAffine/gamma", "GUNet/Encode/down_conv2/mod_conv1/ChannelWiseAffine/beta",
+                "GUNet/spatial/conv2/weights", "GUNet/Encode/down_conv2/mod_conv1/fully_connected/weights"):
+        g = model.params[nm_].grad
+        assert g is not None and float(g.abs().sum()) > 0, nm_
+
+
 def test_gunet_conv_context_subnet_with_use_se_matches_oracle():
     """ct_conv + --use_se: the conv context subnet's last layer keeps the plain gain count (GUNet.py:95-97), every modulated unit
     takes the next context_fc_channels[-1] columns of it as its gate's context feature (GUNet.py:193-194)."""
