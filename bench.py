@@ -538,6 +538,8 @@ def main():
         # two DP timings against the compute-only one in between cancels the drift of a clock-governed step over the run (the bf16
         # step moves by 1-2 % within one process; single comparisons read 0.977-0.993 on different boxes)
         try:
+            if world > 1:                                # rehearsal only: a diagnostic must not add collectives to a real N-rank run
+                raise RuntimeError("skipped at world > 1")
             solver.strategy = strategy
             one_step()                                   # re-creates the buckets
             torch.cuda.synchronize()
@@ -552,7 +554,8 @@ def main():
             dist.barrier()
             dp_diag["dp_again_ms_per_step"] = round((time.perf_counter() - tc) / a.steps * 1e3, 3)
         except Exception as e:                           # diagnostics only: never lose the line over them
-            dp_diag["dp_again_error"] = repr(e)[:200]
+            if world == 1:
+                dp_diag["dp_again_error"] = repr(e)[:200]
         ops.profile_on(None)
         ops.side_streams_pause(one_stream)
 
@@ -673,15 +676,18 @@ def main():
             # tools/pmc_summary.py; newest round wins) and ONLY when that file names this exact kernel -- else null.
             try:
                 import glob
-                suffix = {"fp32": "", "bf16": "_bf16", "bf16c": "_bf16c"}[a.dtype]
-                files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic" + suffix + ".json")))
-                pmc = json.load(open(files[-1]))["kernels"] if files else {}
+                # one PMC pass pair per measured configuration (tools/refresh_profiles.sh prof): (model, dtype, size, batch) -> file suffix
+                pmc_cfgs = {("UNet", "fp32", 256, 32, 0): "", ("UNet", "bf16", 512, 8, 0): "_bf16",
+                            ("UNet3D", "fp32", 96, 1, 0): "_unet3d", ("GUNet", "fp32", 256, 8, 0): "_gunet"}
+                suffix = pmc_cfgs.get((a.model, a.dtype, a.size, a.batch, a.depth))
+                shape_ok = suffix is not None
+                files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic" + (suffix or "") + ".json")))
+                pmc = json.load(open(files[-1]))["kernels"] if files and shape_ok else {}
                 # the PMC table is keyed like rocprofv3's kernel names minus "void ", the anonymous namespace and the arguments
                 want = top["name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
                 hit = pmc.get(want)
                 key = (hit["launches"], hit["launches"] * hit["hbm_bytes_per_launch_corrected"]) if hit else None
-                shape_ok = (a.size, a.batch) == ((256, 32) if a.dtype == "fp32" else (512, 8))     # the shapes the PMC passes ran
-                if key and key[0] and shape_ok and a.model == "UNet":
+                if key and key[0] and shape_ok:
                     out["roofline"]["traffic"] = round(key[1] / key[0])
                     out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(files[-1]) + \
                         " (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE)"

@@ -29,6 +29,8 @@
 
 namespace {
 
+__device__ const float kZeroF4[4] = {};      // what an out-of-image halo pixel reads (see load_halo)
+
 constexpr int CK = 16;   // input channels per K-chunk
 // tap steps at which the next chunk's halo is requested from HBM / written to LDS (registers in between)
 #ifndef HALO_LD_T
@@ -72,6 +74,7 @@ __global__ __launch_bounds__(WM* WN * 64, (TM * TN == 8 ? 2 : 1)) void conv3x3_i
   constexpr int HR = (HALO_PIX * 4 + NT - 1) / NT;   // float4 halo loads per thread
   constexpr int WR = (CK / 4 * BN + NT - 1) / NT;    // float4 weight loads per thread
   constexpr int WF4 = CK / 4 * BN;                   // float4s in one weight panel
+  constexpr bool W_ALL = WF4 == WR * NT;             // every thread owns exactly WR of them: no per-thread condition around the requests
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* halo = smem;               // [2][HALO_F]
@@ -133,9 +136,12 @@ __global__ __launch_bounds__(WM* WN * 64, (TM * TN == 8 ? 2 : 1)) void conv3x3_i
   auto load_halo = [&](int cc) {
     const int dt = p.kd > 1 ? cc / nchunks : 0, c = cc - dt * nchunks;
     const int64_t soff = (p.kd > 1 ? (int64_t)(p.dshift0 + dt) * p.dplane : 0) + c * CK;
+    // an out-of-image halo pixel reads a page of zeros: the request itself is UNCONDITIONAL.  (Rounds 1-4 branched around it,
+    // `ok ? ldg4(..) : 0`: exec-masked blocks, and the compiler closed each with an s_waitcnt vmcnt(0) -- at the halo tap the wave
+    // waited out the filter panel it had requested two instructions earlier, in front of the tap's MFMAs; same finding as in
+    // conv_igemm_lin.hip, where it cost 7-8 %.  tests/test_asm_lint.py checks the placement.)
 #pragma unroll
-    for (int r = 0; r < HR; ++r)
-      hreg[r] = hok[r] ? ldg4(p.x + hoff[r] + soff) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < HR; ++r) hreg[r] = ldg4(hok[r] ? p.x + hoff[r] + soff : kZeroF4);
   };
   auto store_halo = [&](int buf) {
 #pragma unroll
@@ -147,12 +153,12 @@ __global__ __launch_bounds__(WM* WN * 64, (TM * TN == 8 ? 2 : 1)) void conv3x3_i
     const float* base = p.wp + ((int64_t)(dt * 9 + t) * cin4 + c * (CK / 4)) * p.Cout * 4;
 #pragma unroll
     for (int r = 0; r < WR; ++r)
-      if (tid + r * NT < WF4) wreg[r] = ldg4(base + woff[r]);
+      if (W_ALL || tid + r * NT < WF4) wreg[r] = ldg4(base + woff[r]);
   };
   auto store_w = [&](int buf) {
 #pragma unroll
     for (int r = 0; r < WR; ++r)
-      if (tid + r * NT < WF4) *reinterpret_cast<float4*>(&wbuf[buf * WB_F + (tid + r * NT) * 4]) = wreg[r];
+      if (W_ALL || tid + r * NT < WF4) *reinterpret_cast<float4*>(&wbuf[buf * WB_F + (tid + r * NT) * 4]) = wreg[r];
   };
 
   // ---- fragment addresses
@@ -187,6 +193,7 @@ __global__ __launch_bounds__(WM* WN * 64, (TM * TN == 8 ? 2 : 1)) void conv3x3_i
       const bool has_next = (t < 8) || more_chunks;
       if (has_next) load_w(t < 8 ? c : c + 1, t < 8 ? t + 1 : 0);
       if (t == HALO_LD_T && more_chunks) load_halo(c + 1);
+      __builtin_amdgcn_sched_barrier(0);       // the requests stay in front of the tap's MFMAs (the scheduler sinks them to their LDS write otherwise)
 
       const float* wb = wbuf + (step & 1) * WB_F;
       const int toff = ((t / 3) * DIL * HWD + (t % 3) * DIL) * PS;

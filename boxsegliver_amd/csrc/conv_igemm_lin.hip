@@ -19,9 +19,24 @@
 
 namespace {
 
+__device__ const float kZeroF4[4] = {};      // what a pad pixel of the halo reads
+
 constexpr int CK = 16;
 constexpr int PS = 20;
 constexpr int LIN_MAXPIX = 416;   // staged padded pixels per block (host guarantees the bound)
+// LIN_HALO_LD (round 5): the tap at which the NEXT chunk's halo is requested from global memory; it is written to LDS at tap 5.
+// Rounds 2-4 requested it at tap 5 too, so every chunk's tap 5 ended in a full s_waitcnt on a load issued one tap earlier --
+// and under stream-K these loads (and the filter panels: blocks start at unrelated K offsets, so the panels they stream do not
+// meet in the XCD's L2; rocprofv3 FETCH_SIZE reads 820 MB per launch on UNet3D's 256-channel 12 x 12 layers against 35 MB of
+// operands) come from the Infinity Cache / HBM.  Requested at tap 2 (as the tiled kernel has done since round 2): the 12 x 12
+// and 24 x 24 layers run 7-8 % faster, UNet3D 96^3 at one patch 20.04 -> 19.51 ms; taps 0 / 1 / 3 the same within noise; the
+// filter panel requested two steps ahead instead of one gives the same gain alone and nothing on top
+// (profiles/r05_probe_lin_prefetch.txt, .patch).
+#ifndef UNETK_LIN_HALO_LD
+#define UNETK_LIN_HALO_LD 2
+#endif
+constexpr int LIN_HALO_LD = UNETK_LIN_HALO_LD;
+static_assert(LIN_HALO_LD >= 0 && LIN_HALO_LD <= 5, "the halo is stored at tap 5");
 
 // GEN = a SUBSET of the taps with an output scatter: the input gradient of a stride-2 conv, one output-parity class per
 // launch.  dx[hi, wi] only receives taps with kh = (hi + pbh) mod 2 (+2), so class (ph, pw) is a stride-1 contraction of
@@ -73,6 +88,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
   constexpr int HR = (LIN_MAXPIX * 4 + NT - 1) / NT;
   constexpr int WR = (CK / 4 * BN + NT - 1) / NT;
   constexpr int WF4 = CK / 4 * BN;
+  constexpr bool W_ALL = WF4 == WR * NT;      // every thread owns exactly WR float4 of a filter panel: no per-thread condition
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* halo = smem;               // [2][HALO_F]
@@ -166,7 +182,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
 #pragma unroll
     for (int r = 0; r < HR; ++r) {
       const bool ok = hok[r] && ((!GRP && KD == 1) || (hdep[r] + shift >= 0 && hdep[r] + shift < p.spg));
-      hreg[r] = ok ? ldg4(p.x + hoff[r] + soff) : make_float4(0.f, 0.f, 0.f, 0.f);
+      hreg[r] = ldg4(ok ? p.x + hoff[r] + soff : kZeroF4);      // unconditional request; a pad pixel reads a page of zeros (see load_w)
     }
   };
   auto store_halo = [&](int buf) {
@@ -176,17 +192,27 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
   };
   auto load_w = [&](int cc, int t) {      // GRP: t = the tap's position in its group's list
     const int dt = (GRP || KD > 1) ? cc / nchunks : 0, cl = cc - dt * nchunks;
+#ifdef UNETK_LIN_PROBE_W0      // timing probe (wrong results): every block reads chunk 0 of the filter -- L2 hits whatever the K offsets
+    const int c = 0 * cl;
+#else
     const int c = p.nlive ? p.klive[cl] : cl;
+#endif
     const int panel = GRP ? p.g_panel[dt][t] : ((FUSED && p.dpar) ? (dpar ? 9 + t : dt * 18 + t) : dt * 9 + t);
     const float* base = p.wp + ((int64_t)panel * cin4 + c * (CK / 4)) * p.Cout * 4;
+    // Where every thread owns WR float4 of the panel (W_ALL: all but the 32-cout variant): NO per-thread condition around these
+    // loads.  With one (`if (tid + r * NT < WF4)`, rounds 2-4) the loads sat in an exec-masked block and the compiler put the
+    // s_waitcnt vmcnt(0) for them at the END OF THAT BLOCK -- in front of the tap's 32 MFMAs instead of in front of the LDS
+    // write behind them: every tap of every chunk waited out the full latency of its filter panel (7-8 % of the 12 x 12 /
+    // 24 x 24 layers of UNet3D, whose panels stream from beyond L2 under stream-K; found through rocprofv3's FETCH_SIZE and
+    // a same-panel timing probe, profiles/r05_probe_lin_prefetch.txt; tests/test_asm_lint.py now checks the placement).
 #pragma unroll
     for (int r = 0; r < WR; ++r)
-      if (tid + r * NT < WF4) wreg[r] = ldg4(base + woff[r]);
+      if (W_ALL || tid + r * NT < WF4) wreg[r] = ldg4(base + woff[r]);
   };
   auto store_w = [&](int buf) {
 #pragma unroll
     for (int r = 0; r < WR; ++r)
-      if (tid + r * NT < WF4) *reinterpret_cast<float4*>(&wbuf[buf * WB_F + (tid + r * NT) * 4]) = wreg[r];
+      if (W_ALL || tid + r * NT < WF4) *reinterpret_cast<float4*>(&wbuf[buf * WB_F + (tid + r * NT) * 4]) = wreg[r];
   };
 
   // A fragment base of this lane's pixel (clamped into the block's range; out-of-range rows are masked in the epilogue)
@@ -234,7 +260,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
           const int nq = ti + 1 < NTAPS[qq] ? qq : (qq + 1) & 3, nti = ti + 1 < NTAPS[qq] ? ti + 1 : 0;
           const bool has_next = !last || more_chunks;
           if (has_next) load_w(last ? c + 1 : c, p.tap_panel[nq][nti]);
-          if (k == 5 && more_chunks) load_halo(c + 1);
+          if (k == LIN_HALO_LD && more_chunks) load_halo(c + 1);
           const float* wb = wbuf + (step & 1) * WB_F;
           const int toff = ((p.tap_off[qq][ti] >> 2) * WP + (p.tap_off[qq][ti] & 3)) * PS;
 #pragma unroll
@@ -394,7 +420,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
         const bool last = ti == nt - 1;
         const bool has_next = !last || more_chunks;
         if (has_next) load_w(last ? c + 1 : c, last ? 0 : ti + 1);
-        if (last && more_chunks) load_halo(c + 1);
+        if (ti == 0 && more_chunks) load_halo(c + 1);          // at the group's first tap, written at its last
         const float* wb = wbuf + (step & 1) * WB_F;
         const int toff = ((p.g_off[g][ti] >> 2) * WP + (p.g_off[g][ti] & 3)) * PS;
 #pragma unroll
@@ -440,7 +466,8 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
     for (int t = 0; t < 9; ++t, ++step) {
       const bool has_next = (t < 8) || more_chunks;
       if (has_next) load_w(t < 8 ? c : c + 1, t < 8 ? t + 1 : 0);
-      if (t == 5 && more_chunks) load_halo(c + 1);
+      if (t == LIN_HALO_LD && more_chunks) load_halo(c + 1);
+      __builtin_amdgcn_sched_barrier(0);       // the requests stay HERE, in front of the tap's MFMAs (the scheduler sinks them to their LDS write otherwise)
 
       const float* wb = wbuf + (step & 1) * WB_F;
       const int toff = ((t / 3) * WP + (t % 3)) * PS;

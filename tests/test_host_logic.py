@@ -143,6 +143,23 @@ def test_padded_store_hands_out_live_channel_masks():
     assert dead == list(range(240, 256)) + list(range(496, 512)) and float(w.detach()[:, :, :, dead].abs().max()) == 0.0
 
 
+def test_thread_pools_follow_the_cpus_the_process_may_use(tmp_path):
+    """boxsegliver_amd/utils/hostcpu.py: the pool size is the minimum of the host's count, the affinity mask and the cgroup quota,
+    the ranks of a node share it, and a value the user exported wins."""
+    from boxsegliver_amd.utils import hostcpu
+    n = hostcpu.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    env = {}
+    assert hostcpu.size_thread_pools(env) == n and env == {"OMP_NUM_THREADS": str(n), "MKL_NUM_THREADS": str(n)}
+    env = {"LOCAL_WORLD_SIZE": "4"}
+    assert hostcpu.size_thread_pools(env) == max(1, n // 4) and env["OMP_NUM_THREADS"] == str(max(1, n // 4))
+    env = {"OMP_NUM_THREADS": "3"}
+    hostcpu.size_thread_pools(env)
+    assert env["OMP_NUM_THREADS"] == "3"
+    # the test session itself runs sized (tests/conftest.py)
+    assert torch.get_num_threads() <= n
+
+
 def test_solver_lr_policies_match_oracle():
     p = _parser()
     for extra, kw in [

@@ -95,6 +95,21 @@ python tools/pmc_mfma.py "$(find "$OUT/pmc_mfma_u3d" -name '*counter_collection.
 F=$(find "$OUT/pmc_fetch_bf16" -name '*counter_collection.csv' | head -1)
 W=$(find "$OUT/pmc_write_bf16" -name '*counter_collection.csv' | head -1)
 python tools/pmc_summary.py "$F" "$W" "$OUT/pmc_traffic_bf16.json" | tee "$OUT/pmc_summary_bf16.txt"
+# HBM traffic of configs[4] (UNet3D 96^3, one patch) and configs[3] (GUNet bs 8): fills roofline.traffic of those lines
+cd /tmp
+for cfg in "unet3d --model UNet3D --size 96 --batch 1" "gunet --model GUNet --batch 8"; do
+  set -- $cfg; tag=$1; shift
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_${c}_$tag" -o pmc -- \
+      python3 "$ROOT/bench.py" "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --single-stream > "$OUT/pmc_${c}_$tag.log" 2>&1
+  done
+  F=$(find "$OUT/pmc_FETCH_SIZE_$tag" -name '*counter_collection.csv' | head -1)
+  W=$(find "$OUT/pmc_WRITE_SIZE_$tag" -name '*counter_collection.csv' | head -1)
+  python "$ROOT/tools/pmc_summary.py" "$F" "$W" "$OUT/pmc_traffic_$tag.json" > "$OUT/pmc_summary_$tag.txt"
+  rm -rf "$OUT/pmc_FETCH_SIZE_$tag" "$OUT/pmc_WRITE_SIZE_$tag"
+  echo "pmc traffic $tag done"
+done
+cd "$ROOT"
 cp "$(find "$OUT/prof_fp32" -name '*kernel_stats.csv' | head -1)" "$OUT/bench_kernel_stats.csv"
 cp "$(find "$OUT/prof_bf16" -name '*kernel_stats.csv' | head -1)" "$OUT/bench_bf16_kernel_stats.csv"
 cp "$(find "$OUT/prof_u3d" -name '*kernel_stats.csv' | head -1)" "$OUT/bench_unet3d_kernel_stats.csv"
