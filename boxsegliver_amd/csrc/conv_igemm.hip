@@ -29,7 +29,7 @@
 
 namespace {
 
-__device__ const float kZeroF4[4] = {};      // what an out-of-image halo pixel reads (see load_halo)
+__device__ float kZeroF4[4] = {};        // NOT const: a const array lives in the constant address space and selecting between it and a global pointer makes the load a FLAT load (lgkmcnt: every LDS read then waits for it)      // what an out-of-image halo pixel reads (see load_halo)
 
 constexpr int CK = 16;   // input channels per K-chunk
 // tap steps at which the next chunk's halo is requested from HBM / written to LDS (registers in between)
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(WM* WN * 64, (TM * TN == 8 ? 2 : 1)) void conv3x3_i
   int64_t woff[WR];
 #pragma unroll
   for (int r = 0; r < WR; ++r) {
-    const int idx = tid + r * NT;
+    const int idx = min(tid + r * NT, WF4 - 1);      // threads beyond a small panel (WF4 < NT) request its last float4 again: no branch
     const int q = idx / BN, n = idx - q * BN;
     woff[r] = ((int64_t)q * p.Cout + n0 + n) * 4;
   }
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(WM* WN * 64, (TM * TN == 8 ? 2 : 1)) void conv3x3_i
     const float* base = p.wp + ((int64_t)(dt * 9 + t) * cin4 + c * (CK / 4)) * p.Cout * 4;
 #pragma unroll
     for (int r = 0; r < WR; ++r)
-      if (W_ALL || tid + r * NT < WF4) wreg[r] = ldg4(base + woff[r]);
+      wreg[r] = ldg4(base + woff[r]);                 // unconditional (see woff)
   };
   auto store_w = [&](int buf) {
 #pragma unroll

@@ -19,7 +19,7 @@
 
 namespace {
 
-__device__ const float kZeroF4[4] = {};      // what a pad pixel of the halo reads
+__device__ float kZeroF4[4] = {};        // NOT const: a const array lives in the constant address space and selecting between it and a global pointer makes the load a FLAT load (lgkmcnt: every LDS read then waits for it)      // what a pad pixel of the halo reads
 
 constexpr int CK = 16;
 constexpr int PS = 20;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
   int64_t woff[WR];
 #pragma unroll
   for (int r = 0; r < WR; ++r) {
-    const int idx = tid + r * NT;
+    const int idx = min(tid + r * NT, WF4 - 1);      // threads beyond a small panel (WF4 < NT) request its last float4 again: no branch
     const int q = idx / BN, n = idx - q * BN;
     woff[r] = ((int64_t)q * p.Cout + n0 + n) * 4;
   }
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
     // a same-panel timing probe, profiles/r05_probe_lin_prefetch.txt; tests/test_asm_lint.py now checks the placement).
 #pragma unroll
     for (int r = 0; r < WR; ++r)
-      if (W_ALL || tid + r * NT < WF4) wreg[r] = ldg4(base + woff[r]);
+      wreg[r] = ldg4(base + woff[r]);                 // unconditional (see woff)
   };
   auto store_w = [&](int buf) {
 #pragma unroll
@@ -261,6 +261,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
           const bool has_next = !last || more_chunks;
           if (has_next) load_w(last ? c + 1 : c, p.tap_panel[nq][nti]);
           if (k == LIN_HALO_LD && more_chunks) load_halo(c + 1);
+          __builtin_amdgcn_sched_barrier(0);
           const float* wb = wbuf + (step & 1) * WB_F;
           const int toff = ((p.tap_off[qq][ti] >> 2) * WP + (p.tap_off[qq][ti] & 3)) * PS;
 #pragma unroll
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
       if (has_next) load_w(c2, p.tap_panel[q][ti2]);
       const bool more_chunks = c + 1 < nchunks;
       if (ti == 0 && more_chunks) load_halo(c + 1);
+      __builtin_amdgcn_sched_barrier(0);
       const float* hb = halo + (c & 1) * HALO_F;
       const float* wb = wbuf + (s & 1) * WB_F;
       const int toff = ((p.tap_off[q][ti] >> 2) * WP + (p.tap_off[q][ti] & 3)) * PS;
@@ -421,6 +423,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2))
         const bool has_next = !last || more_chunks;
         if (has_next) load_w(last ? c + 1 : c, last ? 0 : ti + 1);
         if (ti == 0 && more_chunks) load_halo(c + 1);          // at the group's first tap, written at its last
+        __builtin_amdgcn_sched_barrier(0);
         const float* wb = wbuf + (step & 1) * WB_F;
         const int toff = ((p.g_off[g][ti] >> 2) * WP + (p.g_off[g][ti] & 3)) * PS;
 #pragma unroll

@@ -15,6 +15,8 @@
 
 namespace {
 
+__device__ float kZeroF4[4] = {};        // NOT const: a const array lives in the constant address space and selecting between it and a global pointer makes the load a FLAT load (lgkmcnt: every LDS read then waits for it)      // what a row beyond M reads (pw_gemm_kernel load_a)
+
 constexpr int CK = 16, PS = 20;
 
 struct PwParams {
@@ -202,7 +204,9 @@ __global__ __launch_bounds__(WM* WN * 64, (TM * TN == 8 ? 2 : 1)) void pw_gemm_k
       koff = ((int64_t)(ab >> 1) * 2 * p.W + (ab & 1)) * p.Cout + co0;
     }
 #pragma unroll
-    for (int r = 0; r < AR; ++r) areg[r] = aok[r] ? ldg4(p.a + aoff[r] + koff) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // rows beyond M read a page of zeros: the request is unconditional (a branch around it = an exec-masked block the compiler
+    // closes with s_waitcnt vmcnt(0): the wave waited for these loads in front of the step's MFMAs; conv_igemm_lin.hip, round 5)
+    for (int r = 0; r < AR; ++r) areg[r] = ldg4(aok[r] ? p.a + aoff[r] + koff : kZeroF4);
   };
   auto store_a = [&](int buf) {
 #pragma unroll
@@ -246,6 +250,7 @@ __global__ __launch_bounds__(WM* WN * 64, (TM * TN == 8 ? 2 : 1)) void pw_gemm_k
       load_a(s + 1);
       load_w(s + 1);
     }
+    __builtin_amdgcn_sched_barrier(0);       // the requests stay in front of the step's MFMAs
     const float* ab_ = abuf + (s & 1) * A_F;
     const float* wb = wbuf + (s & 1) * WB_F;
 #pragma unroll
