@@ -52,3 +52,34 @@ def test_no_scratch_spills(rows):
     bad = [(r["kernel"], r["private_segment"], r["scratch_insts"]) for r in rows
            if (r["private_segment"] or r["scratch_insts"]) and not any(k in r["kernel"] for k in KNOWN_SCRATCH)]
     assert not bad, bad
+
+
+def test_no_flat_loads(rows):
+    """A load is `flat_` when the compiler cannot prove its address space -- round 5: a pointer select between a global tensor and a
+    `__device__ const` zero page (constant address space).  Flat loads count on lgkmcnt as well, so every LDS read behind one waits
+    for it: pw_gemm's A rows as flat loads made the headline step 27 % slower."""
+    # pack_many_kernel reads its source / destination pointers from a table in device memory (unetk_pack_item): pointers loaded from
+    # memory carry no address space, and neither an address_space(1) round trip nor __builtin_amdgcn_is_shared / is_private
+    # assumptions made the compiler treat them as global (tried in round 5).  An HBM-bound 0.13 ms per step with no LDS traffic to
+    # entangle with: left as it is.
+    known = ("pack_many_kernel(",)
+    bad = [(r["kernel"], r["flat_loads"]) for r in rows if r["flat_loads"] and not r["kernel"].startswith(known)]
+    assert not bad, bad
+
+
+# matrix kernels whose K loop prefetches through registers (global load -> VGPR -> LDS write behind the step's MFMAs)
+PREFETCH_LOOPS = ("conv3x3_igemm_kernel<", "pw_gemm_kernel<")
+# the linear-pixel kernel's plain / stream-K / accumulate / half-chunk variants (its tap-subset and grouped-tap variants keep one early
+# wait in their run-time tap loops: DESIGN.md 8)
+LIN_PLAIN = "conv3x3_igemm_lin_kernel<"
+
+
+def test_prefetch_waits_sit_behind_the_mfmas(rows):
+    """profiles/r05_probe_lin_prefetch.txt: no s_waitcnt vmcnt right behind the request it waits for, in front of the MFMAs that
+    were meant to hide it."""
+    checked = [r for r in rows if any(r["kernel"].startswith(("void " + k, k)) for k in PREFETCH_LOOPS)]
+    lin = [r for r in rows if LIN_PLAIN in r["kernel"] and ", false, false, " in r["kernel"].split(">")[0][len(LIN_PLAIN):]
+           and r["kernel"].split("<")[1].split(",")[4].strip() == "false" and r["kernel"].split("<")[1].split(",")[8].strip() == "false"]
+    assert len(checked) >= 20 and len(lin) >= 8, (len(checked), len(lin))
+    bad = [(r["kernel"], r["early_vm_waits"]) for r in checked + lin if r["early_vm_waits"]]
+    assert not bad, bad

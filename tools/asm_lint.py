@@ -64,6 +64,31 @@ def _compile(src, tmp):
     return open(out).read()
 
 
+def _early_vm_waits(body):
+    """Barrier-to-barrier stretches (in layout order) with >= 8 MFMAs in which an `s_waitcnt vmcnt(..)` follows a global load of
+    the SAME stretch before half of its MFMAs and within a quarter of them: the wave waits for a prefetch it has only just
+    requested, in front of the matrix work that was meant to hide it.  Round 5 found this in every fp32 conv kernel: requests
+    inside exec-masked blocks (`if (tid < ..) x = load`, `ok ? load : 0`), which the compiler closes with s_waitcnt vmcnt(0)."""
+    lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
+    cuts = [-1] + [i for i, l in enumerate(lines) if l.startswith("s_barrier")] + [len(lines)]
+    hits = 0
+    for k in range(len(cuts) - 1):
+        seg = lines[cuts[k] + 1:cuts[k + 1]]
+        nm = sum(1 for l in seg if l.startswith("v_mfma"))
+        if nm < 8:
+            continue
+        mf, loaded_at = 0, None
+        for l in seg:
+            if l.startswith("v_mfma"):
+                mf += 1
+            elif l.startswith(("global_load", "buffer_load")) and " lds" not in l:
+                loaded_at = mf
+            elif "vmcnt" in l and loaded_at is not None and mf < nm // 2 and mf - loaded_at < max(4, nm // 4):
+                hits += 1
+                break
+    return hits
+
+
 def lint(jobs=4):
     """[{file, kernel, n_mfma, early_acc_reads, opcodes, scratch_insts, private_segment, expect, findings}] over csrc."""
     rows = []
@@ -87,6 +112,8 @@ def lint(jobs=4):
             early = [x.start() for x in re.finditer(r"v_accvgpr_read", body) if mf and x.start() < mf[-1]]
             ops = sorted(set(re.findall(r"v_mfma_\w+", body)))
             scratch = len(re.findall(r"^\s*scratch_\w+", body, re.M))
+            flat = len(re.findall(r"^\s*flat_load", body, re.M))
+            early_waits = _early_vm_waits(body)
             want = expected_opcode(name)
             findings = []
             if early:
@@ -95,9 +122,11 @@ def lint(jobs=4):
                 findings.append("expected {} but the body has {}".format(want, ops or "no MFMA"))
             if private[sym] > 0 or scratch:
                 findings.append("scratch: private_segment {} B, {} scratch_ instruction(s)".format(private[sym], scratch))
+            if flat:
+                findings.append("{} flat_load(s): a load whose address space the compiler could not prove global".format(flat))
             rows.append(dict(file=os.path.basename(src), kernel=name, n_mfma=len(mf), early_acc_reads=len(early),
                              opcodes=ops, scratch_insts=scratch, private_segment=private[sym], expect=want,
-                             findings=findings))
+                             flat_loads=flat, early_vm_waits=early_waits, findings=findings))
     return rows
 
 
