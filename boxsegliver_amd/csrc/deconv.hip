@@ -363,13 +363,13 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_gemm_bf16_kernel(PwParams p) {
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
       if constexpr (BS) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(ab16 + aoff[r] + koff);
-        aq[r] = aok[r] ? v : u32x4{0u, 0u, 0u, 0u};
-      } else if (aok[r]) {
-        areg[r][0] = ldg4(p.a + aoff[r] + koff);
-        areg[r][1] = ldg4(p.a + aoff[r] + koff + 4);
+        // the request only; rows past M are zeroed where the value is USED (store_a): a select on the loaded value here made the
+        // wave wait for the load it had just issued, in front of the step's MFMAs (round 5)
+        aq[r] = *reinterpret_cast<const u32x4*>(ab16 + aoff[r] + koff);
       } else {
-        areg[r][0] = areg[r][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* src = aok[r] ? p.a + aoff[r] + koff : kZeroF4;      // rows past M read zeros: no branch around the request
+        areg[r][0] = ldg4(src);
+        areg[r][1] = ldg4(aok[r] ? src + 4 : kZeroF4);
       }
     }
   };
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_gemm_bf16_kernel(PwParams p) {
       const int idx = tid + r * NT;
       u32x4 v;
       if constexpr (BS) {
-        v = aq[r];
+        v = aok[r] ? aq[r] : u32x4{0u, 0u, 0u, 0u};
       } else {
         v.x = pk_bf16(areg[r][0].x, areg[r][0].y);
         v.y = pk_bf16(areg[r][0].z, areg[r][0].w);
@@ -424,6 +424,7 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_gemm_bf16_kernel(PwParams p) {
       load_a(s + 1);
       load_w(s + 1);
     }
+    __builtin_amdgcn_sched_barrier(0);       // the requests stay in front of the step's MFMAs
     const uint4* ab_ = abuf + (s & 1) * A_Q;
     const uint4* wb = wbuf + (s & 1) * WB_Q;
 #pragma unroll
