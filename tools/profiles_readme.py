@@ -106,6 +106,16 @@ R5 = """
   (`UNETK_LIN_2D`, default 6 now): bridge layers 93 -> 107 TFLOP/s, GUNet bs 8 370.3 -> 373.3 slices/s.
 * `r05_probe_wgrad_rounds.txt` -- one round of larger blocks instead of two for the stacked-plane filter gradient (a dispatch model says
   - 5 %): no gain beside the main stream's kernels.  Not kept.
+* `r05_probe_lin_prefetch.txt` (+ `.patch`) -- **the register-prefetch loops waited for their own requests**: rocprofv3's FETCH_SIZE on
+  UNet3D (`r05_pmc_traffic_unet3d.json`: 820 MB per launch beyond L2 on layers with 35 MB of operands) -> a same-panel timing probe (the
+  kernel waits for those loads) -> the ISA (`s_waitcnt vmcnt(0)` at the end of every exec-masked request block, in front of the tap's
+  MFMAs) -> unconditional requests (zero page by pointer select, NOT a const array: that made them flat loads) pinned by
+  `__builtin_amdgcn_sched_barrier`: headline 430.5 -> 434.7 slices/s, UNet3D 96^3 49.9 -> 51.85 patches/s, GUNet bs 8 373.6 -> 380.2,
+  inference bs 32 1385 -> 1407 (same-call A/Bs against the library before); `tools/asm_lint.py` counts such waits and flat loads.
+* `r05_pmc_traffic_unet3d.json`, `r05_pmc_traffic_gunet.json` -- FETCH_SIZE / WRITE_SIZE passes of configs[4] and configs[3]: their
+  bench lines carry `roofline.traffic` too.
+* The CPU thread pools follow the cgroup's quota (`boxsegliver_amd/utils/hostcpu.py`: the box shows 256 CPUs and grants 16):
+  `cpu_baseline` 0.38 -> 2.0 slices/s on 16 threads, the GPU test suite 525-600 s -> 150 s.
 * The bridge's filter gradient (6 x 6 output planes) on 4 x 6 stride-2 tiles: 0.309 -> 0.151 ms (`r05_bench_unet3d_96_bs1_by_layer.json`
   `conv3d_wgrad [k3s22 ...]`; same-call step 20.19 -> 20.11 ms).
 """
