@@ -68,7 +68,7 @@ def test_no_flat_loads(rows):
 
 
 # matrix kernels whose K loop prefetches through registers (global load -> VGPR -> LDS write behind the step's MFMAs)
-PREFETCH_LOOPS = ("conv3x3_igemm_kernel<", "pw_gemm_kernel<")
+PREFETCH_LOOPS = ("conv3x3_igemm_kernel<",)       # (pw_gemm keeps its branchy A-row loads: measured faster on the configuration in use, csrc/deconv.hip)
 # the linear-pixel kernel's plain / stream-K / accumulate / half-chunk variants (its tap-subset and grouped-tap variants keep one early
 # wait in their run-time tap loops: DESIGN.md 8)
 LIN_PLAIN = "conv3x3_igemm_lin_kernel<"
