@@ -89,6 +89,13 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output
   python3 "$ROOT/bench.py" --model UNet3D --size 96 --batch 1 --steps 2 --warmup 1 --detail --no-cpu-baseline --no-kernel-events > "$OUT/pmc_mfma_u3d.log" 2>&1
 echo "pmc mfma done"
 cd "$ROOT"
+# LDS bank conflicts per kernel (own pass): SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, fp32 headline
+cd /tmp
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_ldsc" -o lds -- \
+  python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_ldsc.log" 2>&1
+cd "$ROOT"
+python tools/pmc_lds.py "$(find "$OUT/pmc_ldsc" -name '*counter_collection.csv' | head -1)" "$OUT/pmc_lds.txt" > /dev/null
+rm -rf "$OUT/pmc_ldsc"
 python tools/pmc_mfma.py "$(find "$OUT/pmc_mfma" -name '*counter_collection.csv' | head -1)" "$OUT/pmc_mfma_busy.txt"
 python tools/pmc_mfma.py "$(find "$OUT/pmc_mfma_bf16" -name '*counter_collection.csv' | head -1)" "$OUT/pmc_mfma_busy_bf16.txt"
 python tools/pmc_mfma.py "$(find "$OUT/pmc_mfma_u3d" -name '*counter_collection.csv' | head -1)" "$OUT/pmc_mfma_busy_unet3d.txt"
