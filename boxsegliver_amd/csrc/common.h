@@ -51,6 +51,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 __device__ __forceinline__ int mfma32_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// floor(n / d) for 0 <= n < 2^22 and d >= 1 from a host-computed reciprocal: a float estimate (within 1 of the quotient) and one
+// correction -- 6 VALU instructions where the integer division by a run-time divisor expands to ~25.  (Round 5: the stacked-plane
+// filter gradient spent 5.1 VALU instructions per MFMA, the plain one 2.0: four such divisions per staged piece.)
+__device__ __forceinline__ int unetk_fdiv(int n, int d, float rcp) {
+  int q = (int)((float)n * rcp);
+  const int r = n - q * d;
+  q += (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+  return q;
+}
 __device__ __forceinline__ void stg4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 // ---- bf16 storage (UNETK_BF16S): activations / activation gradients live in HBM as bf16 (uint16_t bit patterns),
@@ -252,6 +261,9 @@ struct WgParams {
   int kd, dshift0, dsd, din, spg;
   int64_t dplane;
   int dbg;             // conv_wgrad_bf16s.hip probe build (-DUNETK_V3_PROBE): UNETK_V3_FLAGS
+  // reciprocals for the stacked-plane variant's per-lane index arithmetic (set by unetk_wgrad_run): 1 / (H + 1), 1 / xa.group,
+  // 1 / ya.group, 1 / spg -- unetk_fdiv below
+  float rcp_h1, rcp_xg, rcp_yg, rcp_spg;
 };
 // conv_wgrad.hip: dw[9][Cin][Cout] = filter gradient of one 2-D tap plane; ws layout as unetk_conv3x3_wgrad
 size_t unetk_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int kd = 1);

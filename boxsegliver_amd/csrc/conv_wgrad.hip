@@ -136,18 +136,22 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgParams p) {
         const int ph = (S != 1 && is_x) ? p.Hin : p.H, pw = (S != 1 && is_x) ? p.Win : p.W;
         bool ok;
         if (STK) {   // virtual row -> (plane, row); row == H is the shared zero row
-          const int v = gh < 0 ? 0 : gh;
-          const int n_img = v / (p.H + 1);
+          // (divisions by reciprocal, common.h unetk_fdiv: v < 2^20 by the plan's guard; dummy pieces carry rel_h = 1 << 20)
+          const int v = (gh < 0 || gh >= (1 << 20)) ? 0 : gh;
+          const int n_img = unetk_fdiv(v, p.H + 1, p.rcp_h1);
           const int r = v - n_img * (p.H + 1);
           ok = gh >= 0 && gh < (1 << 20) && n_img < p.N && r < p.H && gw >= 0 && gw < p.W;
           gh = r;
-          if (ok) {
-            ximg = p.xa.off(n_img) + x_dt;
-            yimg = p.ya.off(n_img);
-            if (KD > 1 && is_x) {
-              const int din_i = (n_img % p.spg) * p.dsd + p.dshift0 + dt;
-              ok = din_i >= 0 && din_i < p.din;
+          if (is_x) {
+            const int g = unetk_fdiv(n_img, p.xa.group, p.rcp_xg);
+            ximg = (int64_t)g * p.xa.group_stride + (int64_t)(n_img - g * p.xa.group) * p.xa.img_stride + x_dt;
+            if (KD > 1) {
+              const int din_i = (n_img - unetk_fdiv(n_img, p.spg, p.rcp_spg) * p.spg) * p.dsd + p.dshift0 + dt;
+              ok = ok && din_i >= 0 && din_i < p.din;
             }
+          } else {
+            const int g = unetk_fdiv(n_img, p.ya.group, p.rcp_yg);
+            yimg = (int64_t)g * p.ya.group_stride + (int64_t)(n_img - g * p.ya.group) * p.ya.img_stride;
           }
         } else {
           ok = gh >= 0 && gh < ph && gw >= 0 && gw < pw && (!is_x || xplane_ok);
@@ -617,6 +621,10 @@ size_t unetk_wgrad_strided_ws_bytes(int N, int Ho, int Wo, int Cin, int Cout, in
 }
 
 int unetk_wgrad_run(WgParams p, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
+  p.rcp_h1 = 1.0f / (float)(p.H + 1);
+  p.rcp_xg = 1.0f / (float)(p.xa.group > 0 ? p.xa.group : 1);
+  p.rcp_yg = 1.0f / (float)(p.ya.group > 0 ? p.ya.group : 1);
+  p.rcp_spg = 1.0f / (float)(p.spg > 0 ? p.spg : 1);
   if (p.stride == 2) {   // fp32 only: H, W = output plane
     if (!wg_strided_ok(p.Cin, p.Cout) || p.bf16) return UNETK_E_UNSUPPORTED;
     if (p.xs % 4 != 0 || p.ys % 4 != 0 || p.pbh < 0 || p.pbh > 1 || p.pbw < 0 || p.pbw > 1) return UNETK_E_BADARG;
