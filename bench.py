@@ -304,6 +304,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="kept for old command lines: the bs 8 leg is part of the default since round 5")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP-event timing")
+    ap.add_argument("--settle-seconds", type=float, default=45.0,
+                    help="N = 1: upper bound of the untimed settle phase in front of the warm-up (blocks of ten steps until two in a "
+                         "row show no one-step hiccup of the box); 0 = none")
     ap.add_argument("--single-stream", action="store_true",
                     help="every step on ONE stream (filter gradients otherwise run beside input gradients on a second stream): "
                          "what the traced steps do anyway; for rocprofv3 runs whose per-kernel averages are compared with the line's")
@@ -450,6 +453,27 @@ def main():
     n_ev_steps = len(range(0, a.steps, ev_stride))
     ops.PROFILE_SHAPES = bool(a.detail)
     launches_per_step = 4096
+    # Settle phase (world of one; in front of the W warm-up steps, untimed like them): on a box of this pool the second to fourth
+    # GPU process after its start see 0.4-1 s gaps on the GPU's own timeline every second or two, whatever the library
+    # (profiles/r05_step_hiccups.txt: detect 437 / 274 / 266, then 437 for every later process).  Blocks of ten steps with an event
+    # per step until two blocks in a row show no step above three times the block's median, or `--settle-seconds` (default 45) have
+    # passed.  The timed region below is unchanged: exactly K steps between barrier + synchronize.
+    settle = {"steps": 0, "hiccups": 0, "seconds": 0.0}
+    if world == 1 and a.settle_seconds > 0 and a.mode == "train":
+        t_settle, clean = time.perf_counter(), 0
+        while clean < 2 and time.perf_counter() - t_settle < a.settle_seconds:
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+            evs[0].record()
+            for i in range(10):
+                one_step()
+                evs[i + 1].record()
+            torch.cuda.synchronize()
+            ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(10)]
+            bad = sum(1 for v in ms if v > 3.0 * statistics.median(ms))
+            settle["steps"] += 10
+            settle["hiccups"] += bad
+            clean = 0 if bad else clean + 1
+        settle["seconds"] = round(time.perf_counter() - t_settle, 2)
     for j in range(a.warmup):
         if j == a.warmup - 1 and prof_list is not None:
             ops.profile_begin(0)
@@ -582,6 +606,7 @@ def main():
             # a hiccup of the box (one step far above the median: seen as 0.5 s GPU-side gaps on some boxes of the pool, whatever
             # the library) shows here and in `value`, which is wall time over all K steps by contract
             "ms_per_step_max_hipevents": round(max(step_ms), 3), "ms_sum_steps_hipevents": round(sum(step_ms), 3),
+            "settle": settle,
             "n_ranks_seen": n_ranks_seen,
             "rank_ms_per_step_min": round(min(rank_ms), 3), "rank_ms_per_step_max": round(max(rank_ms), 3),
             "dist_backend": (backend if world > 1 else None), "higher_is_better": True,
