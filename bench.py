@@ -305,7 +305,7 @@ def main():
     ap.add_argument("--cpu-baseline-full", action="store_true", help="kept for old command lines: the bs 8 leg is part of the default since round 5")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP-event timing")
     ap.add_argument("--settle-seconds", type=float, default=45.0,
-                    help="N = 1: upper bound of the untimed settle phase in front of the warm-up (blocks of ten steps until two in a "
+                    help="upper bound of the untimed settle phase in front of the warm-up (blocks of ten steps until two in a "
                          "row show no one-step hiccup of the box); 0 = none")
     ap.add_argument("--single-stream", action="store_true",
                     help="every step on ONE stream (filter gradients otherwise run beside input gradients on a second stream): "
@@ -453,15 +453,15 @@ def main():
     n_ev_steps = len(range(0, a.steps, ev_stride))
     ops.PROFILE_SHAPES = bool(a.detail)
     launches_per_step = 4096
-    # Settle phase (world of one; in front of the W warm-up steps, untimed like them): on a box of this pool the second to fourth
+    # Settle phase (in front of the W warm-up steps, untimed like them; N ranks agree block by block): on a box of this pool the second to fourth
     # GPU process after its start see 0.4-1 s gaps on the GPU's own timeline every second or two, whatever the library
     # (profiles/r05_step_hiccups.txt: detect 437 / 274 / 266, then 437 for every later process).  Blocks of ten steps with an event
-    # per step until two blocks in a row show no step above three times the block's median, or `--settle-seconds` (default 45) have
+    # per step until two blocks in a row show no step above three times the block's median (and 100 ms above it), or `--settle-seconds` (default 45) have
     # passed.  The timed region below is unchanged: exactly K steps between barrier + synchronize.
     settle = {"steps": 0, "hiccups": 0, "seconds": 0.0}
-    if world == 1 and a.settle_seconds > 0 and a.mode == "train":
-        t_settle, clean = time.perf_counter(), 0
-        while clean < 2 and time.perf_counter() - t_settle < a.settle_seconds:
+    if a.settle_seconds > 0 and a.mode == "train":
+        t_settle, clean, timed_out = time.perf_counter(), 0, False
+        while clean < 2 and not timed_out:
             evs = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
             evs[0].record()
             for i in range(10):
@@ -469,7 +469,14 @@ def main():
                 evs[i + 1].record()
             torch.cuda.synchronize()
             ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(10)]
-            bad = sum(1 for v in ms if v > 3.0 * statistics.median(ms))
+            med = statistics.median(ms)
+            bad = sum(1 for v in ms if v > 3.0 * med and v - med > 100.0)      # the gaps are 400 ms and more; launch jitter of tiny steps is not
+            timed_out = time.perf_counter() - t_settle >= a.settle_seconds
+            if world > 1:       # every rank takes the same blocks (the steps carry the gradient all-reduce): agree on what was seen
+                flags = torch.tensor([float(bad), 1.0 if timed_out else 0.0], dtype=torch.float32,
+                                     device="cuda" if backend == "nccl" else "cpu")
+                dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+                bad, timed_out = int(flags[0].item()), bool(flags[1].item() > 0)
             settle["steps"] += 10
             settle["hiccups"] += bad
             clean = 0 if bad else clean + 1
