@@ -160,6 +160,19 @@ def test_thread_pools_follow_the_cpus_the_process_may_use(tmp_path):
     assert torch.get_num_threads() <= n
 
 
+def test_reciprocal_division_of_the_stacked_plane_filter_gradient_is_exact():
+    """csrc/common.h unetk_fdiv (round 5): floor(n / d) from a float32 reciprocal -- estimate, one multiply-subtract, one correction --
+    restated in numpy and compared with integer division over the whole range the kernel uses (n < 2^20 virtual rows / planes by
+    the plan's guard; divisors H + 1, planes per sample, planes per address group, and the 2^30 of a dense address map)."""
+    n = np.arange(0, 1 << 20, dtype=np.int64)
+    for d in (1, 2, 3, 7, 13, 25, 33, 49, 65, 96, 97, 192, 1000, 4097, 1 << 19, (1 << 20) - 1, 1 << 30):
+        rcp = np.float32(1.0) / np.float32(d)
+        q = (n.astype(np.float32) * rcp).astype(np.int64)                  # (int)((float)n * rcp): truncation
+        r = n - q * d
+        q = q + (r >= d).astype(np.int64) - (r < 0).astype(np.int64)
+        assert np.array_equal(q, n // d), d
+
+
 def test_solver_lr_policies_match_oracle():
     p = _parser()
     for extra, kw in [
