@@ -112,6 +112,14 @@ R5 = """
   MFMAs) -> unconditional requests (zero page by pointer select, NOT a const array: that made them flat loads) pinned by
   `__builtin_amdgcn_sched_barrier`: headline 430.5 -> 434.7 slices/s, UNet3D 96^3 49.9 -> 51.85 patches/s, GUNet bs 8 373.6 -> 380.2,
   inference bs 32 1385 -> 1407 (same-call A/Bs against the library before); `tools/asm_lint.py` counts such waits and flat loads.
+* `r05_asm_lint.txt` -- `tools/asm_lint.py` over the final sources: per MFMA kernel, flat loads and prefetch waits in front of the MFMAs
+  (zero for the tiled, plain linear-pixel and wgrad kernels; the remaining ones are listed in DESIGN.md 4).
+* `r05_pmc_lds*.txt` (`tools/pmc_lds.py`) -- LDS bank-conflict share per kernel: the tiled conv 34.7 % -> 6.1 % after padding its halo rows
+  to 384 floats (`r05_pmc_lds_before_rowpad.txt`); no change of the step.
+* `r05_probe_wgrad_valu.txt` -- instructions per MFMA (SQ_INSTS_*): the stacked-plane filter gradient ran 5.1 VALU per MFMA (four run-time
+  integer divisions per staged piece) -> divisions by reciprocal: 98.8 -> 102.4 / 106.6 -> 111.5 TFLOP/s.
+* `r05_step_hiccups.txt`, `r05_bench_n1_noevents_hiccup.json` -- one-step GPU gaps (0.4-1 s) in the 2nd-4th process on a fresh box, and
+  `bench.py`'s settle phase.
 * `r05_pmc_traffic_unet3d.json`, `r05_pmc_traffic_gunet.json` -- FETCH_SIZE / WRITE_SIZE passes of configs[4] and configs[3]: their
   bench lines carry `roofline.traffic` too.
 * The CPU thread pools follow the cgroup's quota (`boxsegliver_amd/utils/hostcpu.py`: the box shows 256 CPUs and grants 16):
